@@ -1,0 +1,205 @@
+"""Pins oracle/gcond_oracle.py against fixtures produced by running the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from oracle import gcond_oracle as O
+
+torch.set_num_threads(4)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.asarray(a))
+    return t.to(dtype) if dtype is not None else t
+
+
+def test_g1_normalisation(golden_dir):
+    g = load(golden_dir, "g1_norm")
+    n = int(g["n"])
+    a = sp.coo_matrix((np.ones(len(g["a_row"])), (g["a_row"], g["a_col"])), shape=(n, n)).tocsr()
+    rp, col, val = O.normalize_adj_sparse(a)
+    dense = O.csr_to_torch(rp, col, val, n).to_dense().numpy()
+    np.testing.assert_array_equal(dense, g["sparse_norm_dense"])   # f64 scipy -> fp32: bit exact
+    dn = O.dense_gcn_norm(T(g["adj_d"]))
+    np.testing.assert_allclose(dn.numpy(), g["dense_norm"], rtol=1e-6, atol=1e-7)
+
+
+def test_g2_labels_syn(golden_dir):
+    g = load(golden_dir, "g2_labels")
+    names = sorted({k.split("__")[0] for k in g.files})
+    assert len(names) == 8
+    for name in names:
+        ls, ncd, _ = O.generate_labels_syn(g[name + "__labels_train"], float(g[name + "__rate"]))
+        np.testing.assert_array_equal(ls, g[name + "__labels_syn"])
+        np.testing.assert_array_equal(np.array(list(ncd.keys())), g[name + "__dict_keys"])
+        np.testing.assert_array_equal(np.array(list(ncd.values())), g[name + "__dict_vals"])
+    assert len(g["cora_0.5__labels_syn"]) == 70 and len(g["cora_0.25__labels_syn"]) == 35
+    assert len(g["cora_0.1__labels_syn"]) == 14 and len(g["citeseer_0.005__labels_syn"]) == 6
+
+
+def test_g3_init_draw_order(golden_dir):
+    g = load(golden_dir, "g3_init")
+    torch.manual_seed(123)
+    w, b = O.init_linear(6, 4)
+    w2, b2 = O.init_linear(4, 3)
+    for got, key in ((w, "mylinear_w"), (b, "mylinear_b"), (w2, "gconv_w"), (b2, "gconv_b")):
+        np.testing.assert_array_equal(got.numpy(), g[key])
+    torch.manual_seed(77)
+    O.init_sgc(6, 5, 3, 2)            # constructor draw
+    p = O.init_sgc(6, 5, 3, 2)        # initialize() draw
+    for i, t in enumerate(p):
+        np.testing.assert_array_equal(t.numpy(), g[f"sgc2_p{i}"])
+    torch.manual_seed(99)
+    pge = O.init_pge_reference_order(6, 128)
+    names = [str(g[f"pge_name{i}"]) for i in range(10)]
+    assert names[:6] == ["layers.0.weight", "layers.0.bias", "layers.1.weight", "layers.1.bias",
+                         "layers.2.weight", "layers.2.bias"]
+    for i, t in enumerate(pge["lin"] + pge["bn"]):
+        np.testing.assert_array_equal(t.numpy(), g[f"pge_p{i}"])
+
+
+def test_g4_model_forward(golden_dir):
+    g = load(golden_dir, "g4_models")
+    x = T(g["x"])
+    blocks = [O.block_to_torch((g[f"blk{k}_rowptr"], g[f"blk{k}_col"], g[f"blk{k}_val"], tuple(g[f"blk{k}_shape"])))
+              for k in range(2)]
+    n_id = T(g["n_id"])
+    adj = T(g["adj_dense"])
+    for kind in ("SGC", "GCN"):
+        for t in (1, 2):
+            tag = f"{kind}_T{t}"
+            params = [T(g[f"{tag}_p{i}"]) for i in range(2 * (t if kind == "SGC" else 2))]
+            np.testing.assert_allclose(O.model_forward(kind, x, adj, params, 2).numpy(), g[f"{tag}_dense"],
+                                       rtol=2e-5, atol=2e-6)
+            np.testing.assert_allclose(O.model_forward(kind, x[n_id], blocks, params, 2).numpy(), g[f"{tag}_blocks"],
+                                       rtol=2e-5, atol=2e-6)
+
+
+def test_g5_match_loss(golden_dir):
+    g = load(golden_dir, "g5_match")
+    gr = [T(g[f"gr{i}"]) for i in range(4)]
+    gs = [T(g[f"gs{i}"]).requires_grad_(True) for i in range(4)]
+    for metric in ("ours", "mse", "cos"):
+        np.testing.assert_allclose(float(O.match_loss(gs, gr, metric)), float(g[f"loss_{metric}"]), rtol=1e-6)
+    O.match_loss(gs, gr, "ours").backward()
+    np.testing.assert_allclose(gs[0].grad.numpy(), g["d_ours_dgs0"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(gs[2].grad.numpy(), g["d_ours_dgs2"], rtol=1e-5, atol=1e-7)
+    with pytest.raises(SystemExit):
+        O.match_loss(gs, gr, "nope")
+
+
+@pytest.mark.parametrize("tag", ["small", "h256"])
+def test_g6_pge(golden_dir, tag):
+    g = load(golden_dir, "g6_pge")
+    x = T(g[f"{tag}_x"]).requires_grad_(True)
+    ps = [T(g[f"{tag}_p{i}"]).requires_grad_(True) for i in range(10)]
+    pge = {"lin": ps[:6], "bn": ps[6:]}
+    adj = O.pge_forward(x, pge)
+    np.testing.assert_allclose(adj.detach().numpy(), g[f"{tag}_adj"], rtol=1e-5, atol=1e-6)
+    assert torch.equal(adj, adj.T) and float(adj.diagonal().abs().max()) == 0.0
+    (adj * T(g[f"{tag}_w"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g[f"{tag}_dx"], rtol=2e-3, atol=2e-6)
+    for i, p in enumerate(ps):
+        ref = g[f"{tag}_dp{i}"]
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=2e-3, atol=1e-5 * max(1.0, np.abs(ref).max()))
+    with torch.no_grad():
+        np.testing.assert_allclose(O.pge_forward(x.detach(), pge).numpy(), g[f"{tag}_inference"], rtol=1e-5, atol=1e-6)
+
+
+def rebuild_batches(g, tag):
+    n, nclass, d, hidden, t, calls0 = [int(v) for v in g[f"{tag}_meta"]]
+    a = sp.coo_matrix((np.ones(len(g[f"{tag}_a_row"])), (g[f"{tag}_a_row"], g[f"{tag}_a_col"])), shape=(n, n)).tocsr()
+    csr = O.normalize_adj_sparse(a)
+    idx_train, y = g[f"{tag}_idx_train"], g[f"{tag}_y"]
+    labels_train = y[idx_train]
+    sizes = [int(s) for s in g[f"{tag}_sizes"]]
+    batches = []
+    for c in range(nclass):
+        rng = np.random.default_rng(100000 + calls0 + c)
+        batch = rng.permutation(idx_train[labels_train == c])[:256]
+        batches.append(O.sample_blocks(*csr, batch, sizes, rng))
+    return batches, (n, nclass, d, hidden, t)
+
+
+@pytest.mark.parametrize("tag,kind,metric", [("t1", "SGC", "ours"), ("t2", "SGC", "ours"), ("t1mse", "SGC", "mse"),
+                                             ("gcn", "GCN", "ours")])
+def test_g7_train_class(golden_dir, tag, kind, metric):
+    g = load(golden_dir, "g7_train_class")
+    batches, (n, nclass, d, hidden, t) = rebuild_batches(g, tag)
+    nth = 4 if kind == "GCN" else 2 * t
+    theta = [T(g[f"{tag}_theta{i}"]).requires_grad_(True) for i in range(nth)]
+    ps = [T(g[f"{tag}_pge{i}"]).requires_grad_(True) for i in range(10)]
+    pge = {"lin": ps[:6], "bn": ps[6:]}
+    feat_syn = T(g[f"{tag}_feat_syn"]).requires_grad_(True)
+    labels_syn = T(g[f"{tag}_labels_syn"])
+    _, ncd, _ = O.generate_labels_syn(g[f"{tag}_y"][g[f"{tag}_idx_train"]], float(g[f"{tag}_rate"]))
+    adj_syn = O.pge_forward(feat_syn, pge)
+    np.testing.assert_allclose(adj_syn.detach().numpy(), g[f"{tag}_adj_syn"], rtol=1e-5, atol=1e-6)
+    adj_norm = O.dense_gcn_norm(adj_syn)
+    adj_norm.retain_grad()
+    loss = O.train_class(kind, theta, batches, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), feat_syn, adj_norm, labels_syn,
+                         ncd, nclass, 2, metric)
+    loss.backward()
+    # north_star gate: gradient-match loss within 1e-4 relative
+    np.testing.assert_allclose(float(loss), float(g[f"{tag}_loss"]), rtol=1e-4)
+
+    def close(a, ref, rtol=2e-3):
+        np.testing.assert_allclose(a, ref, rtol=rtol, atol=1e-4 * np.abs(ref).max())
+
+    close(adj_norm.grad.numpy(), g[f"{tag}_dadj_norm"])
+    close(feat_syn.grad.numpy(), g[f"{tag}_dfeat"])
+    for i, p in enumerate(ps):
+        ref = g[f"{tag}_dpge{i}"]
+        if np.abs(ref).max() > 1e-6:     # Linear biases feeding BatchNorm have ~0 gradient (noise)
+            close(p.grad.numpy(), ref)
+
+
+@pytest.mark.parametrize("tag", ["cora_like", "arxiv_like"])
+def test_g8_full_reduce_and_evaluate(golden_dir, tag):
+    """Replays a whole reference run (GCond.__init__ + reduce + intermediate evals + Evaluator.evaluate)."""
+    g = load(golden_dir, "g8_reduce")
+    n, nclass, d, hidden, t, inner, epochs, outer = [int(v) for v in g[f"{tag}_meta"]]
+    a = sp.coo_matrix((np.ones(len(g[f"{tag}_a_row"])), (g[f"{tag}_a_row"], g[f"{tag}_a_col"])), shape=(n, n)).tocsr()
+    csr = O.normalize_adj_sparse(a)
+    idx_train, y = g[f"{tag}_idx_train"], g[f"{tag}_y"]
+    labels_train = y[idx_train]
+
+    def batch_fn(c, call):
+        rng = np.random.default_rng(100000 + call)
+        batch = rng.permutation(idx_train[labels_train == c])[:256]
+        return O.sample_blocks(*csr, batch, [4, 3], rng)
+
+    out = O.reduce_and_evaluate(a, g[f"{tag}_x"], y, idx_train, g[f"{tag}_idx_val"], g[f"{tag}_idx_test"], nclass,
+                                reduction_rate=0.5, hidden=hidden, ntrans=t, pge_hid=256 if tag == "arxiv_like" else 128,
+                                epochs=epochs, outer_loop=outer, inner_loop=inner, checkpoints=[5, 11], lr_feat=0.01,
+                                lr_adj=0.01, lr_model=0.01, sizes=[4, 3], threshold=0.05, seed=1, run_inter_eval=2,
+                                eval_epochs=20, run_eval=3, batch_fn=batch_fn)
+    np.testing.assert_array_equal(out["saved"][2].numpy(), g[f"{tag}_saved_label"])
+    np.testing.assert_allclose(np.array(out["loss_avg"]), g[f"{tag}_loss_avg"], rtol=1e-4)
+    np.testing.assert_allclose(out["feat_syn"].numpy(), g[f"{tag}_feat_syn"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(out["adj_syn"].numpy(), g[f"{tag}_adj_syn"], rtol=1e-3, atol=2e-4)
+    for p, i in zip(out["state"].pge_param_list(), range(10)):
+        if i in (1, 3):
+            # layers.{0,1}.bias feed a batch-stat BatchNorm: their true gradient is exactly 0, so Adam
+            # random-walks them on rounding noise in the reference too; they cannot influence adj_syn.
+            continue
+        # Adam turns rounding-level gradient noise on near-dead units into O(lr) steps: allow 1e-3 abs
+        # (each parameter moved by up to epochs*outer*lr = 0.24 over the run).
+        np.testing.assert_allclose(p.detach().numpy(), g[f"{tag}_pge{i}"], rtol=1e-3, atol=1e-3)
+    # eval-GCN accuracy gate: +-0.3 pp  (here the trajectories agree, so the accuracies coincide)
+    assert abs(out["eval_mean"] - float(g[f"{tag}_eval_mean"])) <= 0.003
+    log = str(g[f"{tag}_log"])
+    vals = [float(l.split()[1]) for l in log.splitlines() if l.startswith("Val:") or l.startswith("\nVal:")]
+    vals = [float(l.split("Val:")[1].split()[0]) for l in log.split("\n") if "Val:" in l]
+    got = [100 * m[0] for m in out["inter"]]
+    np.testing.assert_allclose(got, vals, atol=0.3)
+    assert list(g[f"{tag}_files"]) == ["adj_cora_0.5_1.pt", "feat_cora_0.5_1.pt", "label_cora_0.5_1.pt"] or \
+        list(g[f"{tag}_files"]) == ["adj_ogbn-arxiv_0.5_1.pt", "feat_ogbn-arxiv_0.5_1.pt", "label_ogbn-arxiv_0.5_1.pt"]
