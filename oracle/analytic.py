@@ -1,0 +1,290 @@
+"""Autograd-free restatement of the GCond outer-iteration math.  TEST INFRASTRUCTURE ONLY.
+
+The HIP engine (graphslim_amd/csrc) has no autograd: it evaluates the second-order gradient of the
+matching loss in closed form.  This module states those closed forms step by step with plain dense
+tensor algebra so that (1) they can be checked against the autograd oracle (tests/test_analytic.py,
+fp64) and (2) every HIP kernel has a line here it can be compared with on the GPU.  It follows the same
+reference lines as oracle/gcond_oracle.py (gcond_base.py:156-241, condensation/utils.py:12-106,
+parametrized_adj.py:40-71, utils.py:429-439).  Never imported by the product path.
+
+Notation (SGC, K=2 propagations, T in {1,2} transforms):
+  Q = A^ A^,  rs = Q 1,  class rows [lo_c, hi_c) are contiguous in labels_syn (gcond_base.py:93-111).
+"""
+from __future__ import annotations
+
+import torch
+
+EPS_DIS = 1e-6
+EPS_BN = 1e-5
+
+# ------------------------------------------------------------------------------------------------
+# distance and its derivative wrt the synthetic gradient
+# ------------------------------------------------------------------------------------------------
+
+
+def dist_cols(r, s):
+    """'ours' on one 2-D parameter [in, out]: columns are output units (condensation/utils.py:86-104).
+    Returns (dis, D = d dis / d s).  ||s|| = 0 columns get a zero sub-gradient like torch.norm."""
+    rs = (r * s).sum(0)
+    nr, ns = r.norm(dim=0), s.norm(dim=0)
+    q = nr * ns + EPS_DIS
+    dis = (1 - rs / q).sum()
+    inv_ns = torch.where(ns > 0, 1 / ns, torch.zeros_like(ns))
+    D = -r / q + s * (rs * nr * inv_ns / (q * q))
+    return dis, D
+
+
+def match_and_D(metric, gw_real, gw_syn):
+    """Returns (loss, [D_k]) for the parameter list; D_k has the shape of parameter k."""
+    if metric == "ours":
+        loss, Ds = 0.0, []
+        for r, s in zip(gw_real, gw_syn):
+            if r.dim() == 1:
+                Ds.append(torch.zeros_like(s))
+            else:
+                l, D = dist_cols(r, s)
+                loss = loss + l
+                Ds.append(D)
+        return loss, Ds
+    if metric == "mse":
+        return sum(((s - r) ** 2).sum() for r, s in zip(gw_real, gw_syn)), [2 * (s - r) for r, s in zip(gw_real, gw_syn)]
+    if metric == "cos":
+        rv = torch.cat([g.reshape(-1) for g in gw_real])
+        sv = torch.cat([g.reshape(-1) for g in gw_syn])
+        dot, nr, ns = (rv * sv).sum(), rv.norm(), sv.norm()
+        q = nr * ns + EPS_DIS
+        inv_ns = 1 / ns if ns > 0 else torch.zeros(())
+        Ds = [-r / q + s * (dot * nr * inv_ns / (q * q)) for r, s in zip(gw_real, gw_syn)]
+        return 1 - dot / q, Ds
+    raise SystemExit("DC error: unknown distance function")
+
+
+# ------------------------------------------------------------------------------------------------
+# real side: per-class gradient of the sampled-batch NLL wrt theta (propagate-first form)
+# ------------------------------------------------------------------------------------------------
+
+
+def real_class_grad(theta, X, batch, cls):
+    """batch = (B, n_id, [blk0 (n1 x n2), blk1 (B x n1)]) with dense block matrices (tests only).
+    T=1: S = A1 A0 X_g;  T=2: S = A1 A0 relu(X_g W1 + b1).  Returns gw list like model.parameters()."""
+    B, n_id, (A0, A1) = batch
+    Xg = X[n_id]
+    one = torch.ones(Xg.shape[0], dtype=X.dtype)
+    rs = A1 @ (A0 @ one)
+    if len(theta) == 2:
+        W, b = theta
+        S = A1 @ (A0 @ Xg)
+        Z = S @ W + rs[:, None] * b
+        G = torch.softmax(Z, 1)
+        G[:, cls] -= 1
+        G /= B
+        return [S.T @ G, rs @ G]
+    W1, b1, W2, b2 = theta
+    Hp = Xg @ W1 + b1
+    H1 = Hp.clamp_min(0)
+    S = A1 @ (A0 @ H1)
+    Z = S @ W2 + rs[:, None] * b2
+    G = torch.softmax(Z, 1)
+    G[:, cls] -= 1
+    G /= B
+    Tm = G @ W2.T                 # [B, h]
+    Y1 = A1.T @ Tm                # [n1, h]
+    dHp = (A0.T @ Y1) * (Hp > 0)  # [n2, h]   (the engine forms this edge-wise, without A0^T)
+    return [Xg.T @ dHp, dHp.sum(0), S.T @ G, rs @ G]
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic side: loss, dL/dX~ (direct path), dL/dA^
+# ------------------------------------------------------------------------------------------------
+
+
+def syn_match(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="ours"):
+    """class_ranges[c] = (lo, hi) rows of class c (empty classes allowed: lo == hi -> skipped, the
+    reference would produce NaN there; GraphSlim never creates one because of max(...,1)).
+    Returns (loss, dX, dA) with dX the gradient through the GNN input only (PGE path added later)."""
+    n = Xs.shape[0]
+    C = len(class_ranges)
+    Q = A @ A
+    rs = Q.sum(1)
+    loss = torch.zeros((), dtype=Xs.dtype)
+    dQ = torch.zeros_like(Q)
+    dX = torch.zeros_like(Xs)
+    if len(theta) == 2:
+        W, b = theta
+        S = Q @ Xs
+        Z = S @ W + rs[:, None] * b
+        P = torch.softmax(Z, 1)
+        V = torch.zeros_like(P)
+        dS = torch.zeros_like(S)
+        drs = torch.zeros_like(rs)
+        for c, (lo, hi) in enumerate(class_ranges):
+            nc = hi - lo
+            if nc == 0:
+                continue
+            G = P[lo:hi].clone()
+            G[:, c] -= 1
+            G /= nc
+            gw = [S[lo:hi].T @ G, rs[lo:hi] @ G]
+            l, (D, Db) = match_and_D(metric, gw_real[c], gw)
+            loss = loss + coeffs[c] * l
+            D, Db = coeffs[c] * D, coeffs[c] * Db
+            U = S[lo:hi] @ D + rs[lo:hi, None] * Db
+            Pc = P[lo:hi]
+            V[lo:hi] = (Pc * U - Pc * (Pc * U).sum(1, keepdim=True)) / nc
+            dS[lo:hi] = G @ D.T
+            drs[lo:hi] = G @ Db
+        dS = dS + V @ W.T
+        drs = drs + V @ b
+        dX = Q.T @ dS
+        dQ = dS @ Xs.T + drs[:, None]
+    else:
+        W1, b1, W2, b2 = theta
+        Hp = Xs @ W1 + b1
+        M = (Hp > 0).to(Xs.dtype)
+        H1 = Hp * M
+        S = Q @ H1
+        Z = S @ W2 + rs[:, None] * b2
+        P = torch.softmax(Z, 1)
+        V = torch.zeros_like(P)
+        dS = torch.zeros_like(S)
+        drs = torch.zeros_like(rs)
+        for c, (lo, hi) in enumerate(class_ranges):
+            nc = hi - lo
+            if nc == 0:
+                continue
+            G = P[lo:hi].clone()
+            G[:, c] -= 1
+            G /= nc
+            dH2 = Q[lo:hi].T @ G                  # [n, C]
+            dHp = (dH2 @ W2.T) * M                # [n, h]
+            gw = [Xs.T @ dHp, dHp.sum(0), S[lo:hi].T @ G, rs[lo:hi] @ G]
+            l, (D1, Db1, D2, Db2) = match_and_D(metric, gw_real[c], gw)
+            loss = loss + coeffs[c] * l
+            D1, Db1, D2, Db2 = (coeffs[c] * t for t in (D1, Db1, D2, Db2))
+            A1m = (Xs @ D1 + Db1) * M             # d/d(dHp), masked
+            dX = dX + dHp @ D1.T
+            Bc = A1m @ W2                         # d/d(dH2)  [n, C]
+            dQ[lo:hi] += G @ Bc.T
+            U = Q[lo:hi] @ Bc + S[lo:hi] @ D2 + rs[lo:hi, None] * Db2
+            Pc = P[lo:hi]
+            V[lo:hi] = (Pc * U - Pc * (Pc * U).sum(1, keepdim=True)) / nc
+            dS[lo:hi] = G @ D2.T
+            drs[lo:hi] = G @ Db2
+        dS = dS + V @ W2.T
+        drs = drs + V @ b2
+        dH1 = Q.T @ dS
+        dQ = dQ + dS @ H1.T + drs[:, None]
+        dX = dX + (dH1 * M) @ W1.T
+    dA = dQ @ A.T + A.T @ dQ
+    return loss, dX, dA
+
+
+# ------------------------------------------------------------------------------------------------
+# dense GCN normalisation, forward and backward  (utils.py:429-439)
+# ------------------------------------------------------------------------------------------------
+
+
+def gcn_norm_fwd(adj):
+    M = adj + torch.eye(adj.shape[0], dtype=adj.dtype)
+    deg = M.sum(1)
+    r = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
+    return r[:, None] * M * r[None, :], (M, deg, r)
+
+
+def gcn_norm_bwd(dA, ctx):
+    M, deg, r = ctx
+    T = dA * M
+    dr = (T * r[None, :]).sum(1) + (T * r[:, None]).sum(0)
+    ddeg = torch.where(deg > 0, -0.5 * dr * r / deg, torch.zeros_like(deg))   # d deg^-1/2 = -1/2 deg^-3/2
+    return r[:, None] * dA * r[None, :] + ddeg[:, None]
+
+
+# ------------------------------------------------------------------------------------------------
+# PGE forward / backward with the layer-1 decomposition (parametrized_adj.py:40-71)
+# ------------------------------------------------------------------------------------------------
+
+
+def pge_fwd(X, lin, bn):
+    """lin = [W0[Ph,2d], b0, W1[Ph,Ph], b1, w2[1,Ph], b2]; bn = [g1, be1, g2, be2].
+    E1[r,c] = U[c] + V[r] + b0 with U = X W0[:, :d]^T, V = X W0[:, d:]^T; because the pairs form the
+    full n x n grid, BN-1 batch statistics are mean(U)+mean(V)+b0 and var(U)+var(V) exactly."""
+    n, d = X.shape
+    W0, b0, W1, b1, w2, b2 = lin
+    g1, be1, g2, be2 = bn
+    U, V = X @ W0[:, :d].T, X @ W0[:, d:].T
+    mu1 = U.mean(0) + V.mean(0) + b0
+    var1 = U.var(0, unbiased=False) + V.var(0, unbiased=False)
+    is1 = (var1 + EPS_BN).rsqrt()
+    E1 = (V[:, None, :] + U[None, :, :] + b0).reshape(n * n, -1)        # [r*n+c]
+    xh1 = (E1 - mu1) * is1
+    A1 = (g1 * xh1 + be1).clamp_min(0)
+    E2 = A1 @ W1.T + b1
+    mu2, var2 = E2.mean(0), E2.var(0, unbiased=False)
+    is2 = (var2 + EPS_BN).rsqrt()
+    xh2 = (E2 - mu2) * is2
+    A2 = (g2 * xh2 + be2).clamp_min(0)
+    R = (A2 @ w2.T + b2).reshape(n, n)
+    sg = torch.sigmoid((R + R.T) / 2)
+    adj = sg - torch.diag(torch.diag(sg))
+    return adj, dict(U=U, V=V, is1=is1, xh1=xh1, A1=A1, is2=is2, xh2=xh2, A2=A2, sg=sg)
+
+
+def pge_bwd(dAdj, X, lin, bn, c):
+    """Returns (dX, [dW0, db0, dW1, db1, dw2, db2], [dg1, dbe1, dg2, dbe2])."""
+    n, d = X.shape
+    W0, b0, W1, b1, w2, b2 = lin
+    g1, be1, g2, be2 = bn
+    sg = c["sg"]
+    dRs = dAdj * sg * (1 - sg)
+    dRs = dRs - torch.diag(torch.diag(dRs))
+    de3 = ((dRs + dRs.T) / 2).reshape(-1)
+    dw2 = (de3[:, None] * c["A2"]).sum(0, keepdim=True)
+    db2 = de3.sum().reshape(1)
+    dY2 = de3[:, None] * w2 * (c["A2"] > 0)
+    dg2, dbe2 = (dY2 * c["xh2"]).sum(0), dY2.sum(0)
+    N = n * n
+    dE2 = g2 * c["is2"] * (dY2 - dbe2 / N - c["xh2"] * dg2 / N)
+    dW1 = dE2.T @ c["A1"]
+    db1 = dE2.sum(0)
+    dY1 = (dE2 @ W1) * (c["A1"] > 0)
+    # BN-1 backward from the two marginal sums of dY1 only (what the fused kernel accumulates)
+    dY1g = dY1.reshape(n, n, -1)
+    rowsum_c = dY1g.sum(0)          # [c, k]  = sum over r
+    colsum_r = dY1g.sum(1)          # [r, k]  = sum over c
+    U, V, is1 = c["U"], c["V"], c["is1"]
+    mu1 = U.mean(0) + V.mean(0) + b0
+    dbe1 = rowsum_c.sum(0)
+    dg1 = ((U * rowsum_c).sum(0) + (V * colsum_r).sum(0) + (b0 - mu1) * dbe1) * is1
+    k = g1 * is1
+    sum_xh_over_r = (n * U + V.sum(0) + n * (b0 - mu1)) * is1       # [c, k]
+    sum_xh_over_c = (n * V + U.sum(0) + n * (b0 - mu1)) * is1       # [r, k]
+    dU = k * (rowsum_c - n * dbe1 / N - sum_xh_over_r * dg1 / N)
+    dV = k * (colsum_r - n * dbe1 / N - sum_xh_over_c * dg1 / N)
+    db0 = dU.sum(0)
+    dW0 = torch.cat([dU.T @ X, dV.T @ X], dim=1)
+    dX = dU @ W0[:, :d] + dV @ W0[:, d:]
+    return dX, [dW0, db0, dW1, db1, dw2, db2], [dg1, dbe1, dg2, dbe2]
+
+
+# ------------------------------------------------------------------------------------------------
+# inner model step on (X~, A^) : gradient of the full-graph NLL wrt theta  (gcond.py:67-72)
+# ------------------------------------------------------------------------------------------------
+
+
+def sgc_dense_grad(theta, Xs, A, labels):
+    n = Xs.shape[0]
+    Q = A @ A
+    rs = Q.sum(1)
+    Y = torch.nn.functional.one_hot(labels, theta[-1].shape[0]).to(Xs.dtype)
+    if len(theta) == 2:
+        W, b = theta
+        S = Q @ Xs
+        G = (torch.softmax(S @ W + rs[:, None] * b, 1) - Y) / n
+        return [S.T @ G, rs @ G]
+    W1, b1, W2, b2 = theta
+    Hp = Xs @ W1 + b1
+    H1 = Hp.clamp_min(0)
+    S = Q @ H1
+    G = (torch.softmax(S @ W2 + rs[:, None] * b2, 1) - Y) / n
+    dHp = ((Q.T @ G) @ W2.T) * (Hp > 0)
+    return [Xs.T @ dHp, dHp.sum(0), S.T @ G, rs @ G]

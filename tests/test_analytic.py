@@ -1,0 +1,116 @@
+"""Checks the closed-form second-order math (oracle/analytic.py — the spec the HIP kernels follow)
+against the autograd oracle in fp64.  CPU only."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.nn.functional as F
+
+from oracle import analytic as A
+from oracle import gcond_oracle as O
+
+DT = torch.float64
+
+
+def tiny_problem(T, seed=0, n=70, nclass=4, d=6, hidden=9, rate=0.4):
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    y = rng.integers(0, nclass, n)
+    src, dst = rng.integers(0, n, 4 * n), rng.integers(0, n, 4 * n)
+    a = sp.coo_matrix((np.ones(4 * n), (src, dst)), shape=(n, n)).tocsr()
+    a = ((a + a.T) > 0).astype(np.int64).tolil()
+    a.setdiag(0)
+    a = a.tocsr()
+    x = torch.randn(n, d, dtype=DT)
+    idx_train = np.sort(rng.permutation(n)[: n // 2])
+    labels_train = y[idx_train]
+    labels_syn, ncd, ranges = O.generate_labels_syn(labels_train, rate)
+    csr = O.normalize_adj_sparse(a)
+    batches = []
+    for c in range(nclass):
+        seeds = rng.permutation(idx_train[labels_train == c])[:8]
+        batches.append(O.sample_blocks(*csr, seeds, [3, 2], rng))
+    theta = [p.to(DT) for p in O.init_sgc(d, hidden, nclass, T)]
+    ns = len(labels_syn)
+    xs = torch.randn(ns, d, dtype=DT)
+    pge = O.init_pge(d, 8, dtype=DT)
+    pge["bn"] = [torch.rand(8, dtype=DT) + 0.5, torch.randn(8, dtype=DT) * 0.2, torch.rand(8, dtype=DT) + 0.5,
+                 torch.randn(8, dtype=DT) * 0.2]
+    return dict(x=x, y=torch.from_numpy(y), batches=batches, theta=theta, xs=xs, pge=pge, nclass=nclass,
+                labels_syn=torch.from_numpy(labels_syn), ncd=ncd, ranges=ranges)
+
+
+def dense_batch(b):
+    bs, n_id, adjs = b
+    return bs, torch.from_numpy(n_id), [O.block_to_torch(a, DT).to_dense() for a in adjs]
+
+
+@pytest.mark.parametrize("T", [1, 2])
+def test_real_class_grad(T):
+    p = tiny_problem(T)
+    for c in range(p["nclass"]):
+        theta = [t.clone().requires_grad_(True) for t in p["theta"]]
+        ref, _ = O.class_real_grads("SGC", theta, p["x"], p["y"], p["batches"][c])
+        got = A.real_class_grad(p["theta"], p["x"], dense_batch(p["batches"][c]), c)
+        for r, g in zip(ref, got):
+            np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("T", [1, 2])
+@pytest.mark.parametrize("metric", ["ours", "mse", "cos"])
+def test_syn_match_second_order(T, metric):
+    p = tiny_problem(T, seed=3)
+    theta = [t.clone().requires_grad_(True) for t in p["theta"]]
+    xs = p["xs"].clone().requires_grad_(True)
+    adj = O.pge_forward(xs.detach(), p["pge"])
+    an = O.dense_gcn_norm(adj).clone().requires_grad_(True)
+    loss = O.train_class("SGC", theta, p["batches"], p["x"], p["y"], xs, an, p["labels_syn"], p["ncd"], p["nclass"],
+                         2, metric)
+    gx, ga = torch.autograd.grad(loss, [xs, an])
+    gw_real = [A.real_class_grad(p["theta"], p["x"], dense_batch(p["batches"][c]), c) for c in range(p["nclass"])]
+    ns = len(p["labels_syn"])
+    ranges = [tuple(p["ranges"][c]) for c in range(p["nclass"])]
+    coeffs = [p["ncd"][c] / ns for c in range(p["nclass"])]
+    l, dX, dA = A.syn_match(p["theta"], p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric)
+    np.testing.assert_allclose(float(l), float(loss), rtol=1e-10)
+    np.testing.assert_allclose(dX.numpy(), gx.numpy(), rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(dA.numpy(), ga.numpy(), rtol=1e-7, atol=1e-11)
+
+
+def test_gcn_norm_backward():
+    torch.manual_seed(0)
+    adj = torch.rand(9, 9, dtype=DT)
+    adj = ((adj + adj.T) / 2).fill_diagonal_(0).requires_grad_(True)
+    w = torch.randn(9, 9, dtype=DT)
+    (O.dense_gcn_norm(adj) * w).sum().backward()
+    an, ctx = A.gcn_norm_fwd(adj.detach())
+    np.testing.assert_allclose(an.numpy(), O.dense_gcn_norm(adj.detach()).numpy(), rtol=1e-12)
+    np.testing.assert_allclose(A.gcn_norm_bwd(w, ctx).numpy(), adj.grad.numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_pge_forward_backward():
+    p = tiny_problem(1, seed=5)
+    xs = p["xs"].clone().requires_grad_(True)
+    lin = [t.clone().requires_grad_(True) for t in p["pge"]["lin"]]
+    bn = [t.clone().requires_grad_(True) for t in p["pge"]["bn"]]
+    adj = O.pge_forward(xs, {"lin": lin, "bn": bn})
+    w = torch.randn_like(adj)
+    (adj * w).sum().backward()
+    a2, ctx = A.pge_fwd(p["xs"], p["pge"]["lin"], p["pge"]["bn"])
+    np.testing.assert_allclose(a2.numpy(), adj.detach().numpy(), rtol=1e-10, atol=1e-13)
+    dX, dlin, dbn = A.pge_bwd(w, p["xs"], p["pge"]["lin"], p["pge"]["bn"], ctx)
+    np.testing.assert_allclose(dX.numpy(), xs.grad.numpy(), rtol=1e-7, atol=1e-12)
+    for got, ref in zip(dlin + dbn, lin + bn):
+        np.testing.assert_allclose(got.numpy(), ref.grad.numpy(), rtol=1e-7, atol=1e-11)
+
+
+@pytest.mark.parametrize("T", [1, 2])
+def test_inner_model_grad(T):
+    p = tiny_problem(T, seed=7)
+    theta = [t.clone().requires_grad_(True) for t in p["theta"]]
+    an = O.dense_gcn_norm(O.pge_forward(p["xs"], p["pge"]))
+    loss = F.nll_loss(O.sgc_forward(p["xs"], an, theta), p["labels_syn"])
+    ref = torch.autograd.grad(loss, theta)
+    got = A.sgc_dense_grad(p["theta"], p["xs"], an, p["labels_syn"])
+    for r, g in zip(ref, got):
+        np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-13)
