@@ -1,0 +1,123 @@
+"""ctypes binding of libgslim_hip.so (C ABI declared in include/gslim.h).
+
+The product path fails loudly when the HIP library is missing: there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgslim_hip.so")
+
+GS_OK = 0
+
+vp = C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("sAm", C.c_long), ("sAk", C.c_long), ("sBk", C.c_long), ("sBn", C.c_long), ("ldc", C.c_long),
+                ("nb1", C.c_int), ("nb2", C.c_int),
+                ("sAb1", C.c_long), ("sAb2", C.c_long), ("sBb1", C.c_long), ("sBb2", C.c_long), ("sCb1", C.c_long),
+                ("sCb2", C.c_long),
+                ("offA", vp), ("offB", vp), ("offC", vp), ("Mb", vp), ("Kb", vp),
+                ("gatherA_m", vp), ("gatherA_k", vp), ("gatherB_k", vp), ("sGb1", C.c_long),
+                ("kchunk", C.c_int), ("alpha", C.c_float), ("beta", C.c_float),
+                ("bias", vp), ("sbias_b1", C.c_long), ("relu", C.c_int), ("mask", vp), ("ldmask", C.c_long)]
+
+
+class Blocks(C.Structure):
+    _fields_ = [("C", C.c_int), ("bcap", C.c_int), ("f1", C.c_int), ("f2", C.c_int), ("cap1", C.c_int),
+                ("n_seed", vp), ("n1", vp), ("nid1", vp), ("col1", vp), ("val1", vp), ("tptr1", vp), ("tedge1", vp),
+                ("col0", vp), ("val0", vp)]
+
+
+class GCondConfig(C.Structure):
+    _fields_ = [("n_nodes", C.c_int), ("d", C.c_int), ("ldx", C.c_int), ("nclass", C.c_int), ("n_syn", C.c_int),
+                ("ntrans", C.c_int), ("hidden", C.c_int), ("pge_hidden", C.c_int), ("bcap", C.c_int), ("f1", C.c_int),
+                ("f2", C.c_int), ("dis_metric", C.c_int), ("inner_loop", C.c_int),
+                ("lr_feat", C.c_float), ("lr_adj", C.c_float), ("lr_model", C.c_float), ("seed", C.c_uint64),
+                ("external_blocks", C.c_int)]
+
+
+class GCondIO(C.Structure):
+    _fields_ = [("X", vp), ("rowptr", vp), ("col", vp), ("val", vp), ("cls_ptr", vp), ("cls_nodes", vp),
+                ("labels_syn", vp), ("syn_lo", vp), ("syn_hi", vp), ("feat_syn", vp), ("pge_params", vp),
+                ("model_params", vp), ("adj_syn", vp), ("workspace", vp), ("workspace_bytes", C.c_size_t)]
+
+
+_lib = None
+
+# every symbol include/gslim.h declares (tests/test_abi.py checks the list against the header)
+SYMBOLS = [
+    "gs_version", "gs_last_error", "gs_gemm_f32", "gs_reduce_slabs_f32", "gs_reduce_slabs_batched_f32",
+    "gs_spmm_csr_f32", "gs_gather_rows_f32", "gs_sample_blocks", "gs_dense_gcn_norm_fwd", "gs_dense_gcn_norm_bwd",
+    "gs_adam_step_f32", "gs_gcond_workspace_bytes", "gs_gcond_create", "gs_gcond_destroy", "gs_gcond_new_epoch",
+    "gs_gcond_set_blocks", "gs_gcond_outer_step", "gs_gcond_read_loss", "gs_gcond_stage_sample",
+    "gs_gcond_stage_real_grads", "gs_gcond_stage_pge_forward", "gs_gcond_stage_syn_match",
+    "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer",
+    "gs_gcond_get_blocks",
+]
+
+
+def lib():
+    """Load the HIP library once.  Raises ImportError (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C graphslim_amd/csrc`).  graphslim_amd has no CPU fallback.")
+    import torch  # noqa: F401  (first: libgslim_hip.so must bind to the HIP runtime torch has already loaded)
+    L = C.CDLL(LIB_PATH)
+    L.gs_last_error.restype = C.c_char_p
+    L.gs_gcond_destroy.restype = None
+    L.gs_gcond_destroy.argtypes = [vp]
+    i, l, f, u64, u32 = C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_uint32
+    L.gs_gemm_f32.argtypes = [C.POINTER(GemmDesc), vp]
+    L.gs_reduce_slabs_f32.argtypes = [vp, vp, l, i, l, f, vp]
+    L.gs_reduce_slabs_batched_f32.argtypes = [vp, l, vp, l, i, l, i, f, vp]
+    L.gs_spmm_csr_f32.argtypes = [vp, vp, vp, i, vp, l, i, vp, l, vp]
+    L.gs_gather_rows_f32.argtypes = [vp, l, vp, i, i, vp, l, vp]
+    L.gs_sample_blocks.argtypes = [vp, vp, vp, i, vp, vp, vp, C.POINTER(Blocks), u64, u32, vp]
+    L.gs_dense_gcn_norm_fwd.argtypes = [vp, i, vp, vp, vp]
+    L.gs_dense_gcn_norm_bwd.argtypes = [vp, vp, vp, i, vp, vp]
+    L.gs_adam_step_f32.argtypes = [vp, vp, vp, vp, l, f, f, f, f, f, i, vp]
+    L.gs_gcond_workspace_bytes.argtypes = [C.POINTER(GCondConfig), C.POINTER(C.c_size_t)]
+    L.gs_gcond_create.argtypes = [C.POINTER(GCondConfig), C.POINTER(GCondIO), vp, C.POINTER(vp)]
+    L.gs_gcond_new_epoch.argtypes = [vp, vp]
+    L.gs_gcond_set_blocks.argtypes = [vp, C.POINTER(Blocks), vp]
+    L.gs_gcond_outer_step.argtypes = [vp, i, vp]
+    L.gs_gcond_read_loss.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), vp]
+    for name in ("gs_gcond_stage_sample", "gs_gcond_stage_real_grads", "gs_gcond_stage_syn_match", "gs_gcond_stage_inner"):
+        getattr(L, name).argtypes = [vp, vp]
+    L.gs_gcond_stage_pge_forward.argtypes = [vp, i, vp]
+    L.gs_gcond_stage_pge_backward.argtypes = [vp, i, i, vp]
+    L.gs_gcond_stage_update.argtypes = [vp, i, vp]
+    L.gs_gcond_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_long)]
+    L.gs_gcond_get_blocks.argtypes = [vp, C.POINTER(Blocks)]
+    _lib = L
+    return L
+
+
+class GslimError(RuntimeError):
+    pass
+
+
+def check(rc: int):
+    if rc != GS_OK:
+        raise GslimError(f"libgslim_hip error {rc}: {lib().gs_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return vp(t.data_ptr())
+
+
+def stream():
+    import torch
+    return vp(torch.cuda.current_stream().cuda_stream)

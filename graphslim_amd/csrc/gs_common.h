@@ -1,0 +1,74 @@
+// Internal helpers shared by the HIP translation units of libgslim_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gslim.h"
+
+#define GS_WAVE 64
+
+// last-error string (thread local); set by GS_FAIL / GS_HIP
+void gs_set_error(const char* fmt, ...);
+
+#define GS_FAIL(code, ...)        \
+  do {                            \
+    gs_set_error(__VA_ARGS__);    \
+    return (code);                \
+  } while (0)
+
+#define GS_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) GS_FAIL(GS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+#define GS_LAUNCH_CHECK()                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = hipGetLastError();                                                             \
+    if (e_ != hipSuccess) GS_FAIL(GS_ERR_HIP, "kernel launch failed at %s:%d: %s", __FILE__, __LINE__, \
+                                  hipGetErrorString(e_));                                          \
+  } while (0)
+
+#define GS_TRY(expr)        \
+  do {                      \
+    int r_ = (expr);        \
+    if (r_ != GS_OK) return r_; \
+  } while (0)
+
+static inline int gs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers ------------------------------------------------------------------------
+__device__ __forceinline__ float gs_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double gs_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float gs_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// counter-based RNG (splitmix64 finaliser over a 4-word key): stateless, replayable
+__device__ __forceinline__ uint64_t gs_mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t gs_rand_u32(uint64_t seed, uint32_t a, uint32_t b, uint32_t c) {
+  uint64_t k = gs_mix64(seed ^ ((uint64_t)a << 32 | b));
+  k = gs_mix64(k ^ (uint64_t)c * 0xD1342543DE82EF95ull);
+  return (uint32_t)(k >> 32);
+}
+// unbiased-enough integer in [0, n) (n < 2^31): 64-bit multiply-shift
+__device__ __forceinline__ uint32_t gs_rand_below(uint64_t seed, uint32_t a, uint32_t b, uint32_t c, uint32_t n) {
+  return (uint32_t)(((uint64_t)gs_rand_u32(seed, a, b, c) * (uint64_t)n) >> 32);
+}

@@ -1,0 +1,748 @@
+// The GCond engine: one outer-loop iteration of condensation/gcond.py:47-72 as a fixed sequence of
+// HIP launches on one stream (no autograd: the second-order gradient of the matching loss is
+// evaluated in closed form, see oracle/analytic.py for the algebra and tests/test_analytic.py for
+// its check against autograd).  All classes are processed together: the real-side blocks live in
+// class-major fixed-capacity arrays, the synthetic side uses grouped GEMMs over the contiguous row
+// range of each class.  Everything stays resident in HBM; the host only launches.
+#include <new>
+
+#include "gs_kernels.h"
+
+extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int, long, int, float, gs_stream_t);
+
+namespace {
+
+struct Carver {
+  char* base;
+  size_t off;
+  template <class T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+gs_gemm_desc mk(const float* A, long sAm, long sAk, const float* B, long sBk, long sBn, float* C, long ldc, int M, int N,
+                int K) {
+  gs_gemm_desc g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.sAm = sAm; g.sAk = sAk;
+  g.B = B; g.sBk = sBk; g.sBn = sBn;
+  g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K;
+  g.nb1 = g.nb2 = 1;
+  g.alpha = 1.f;
+  return g;
+}
+
+}  // namespace
+
+struct gs_gcond {
+  gs_gcond_config cfg;
+  gs_gcond_io io;
+  int N, d, ldx, C, n, T, h, Ph, bcap, f1, f2, cap1, F;
+  long P, Ppge;
+  long oW1, ob1, oWl, obl;                                   // model parameter offsets
+  long pW0, pb0, pW1, pb1, pw2, pb2, pg1, pbe1, pg2, pbe2;   // PGE parameter offsets
+  gs_pdesc pd;
+  int max_nc;
+  int nsplit_r, kchunk_r, nsplit_w, kchunk_w, nblk_stats, rows_per_block;
+  // real side
+  gs_blocks blk;
+  int *marker, *kcount;
+  float *H1full, *P0, *rs0, *Sr, *rsr, *Zr, *gw_real, *Tm, *Y1, *Bmat, *slabs_r;
+  // synthetic side
+  float *adj_raw, *adj_norm, *rnorm, *Q, *rsq, *H1s, *Ss, *Zs, *Ps, *Gs, *gw_syn, *stats, *ab, *loss_c, *D, *Ug, *Vs, *dSs,
+      *drs, *dQ, *dAn, *d_adj, *d_feat, *dH2, *dHp, *A1m, *Bc, *dH1m, *slabs_x;
+  // PGE
+  float *U, *V, *mu1, *is1, *mu2, *is2, *sumU, *sumV, *A1, *E2, *e3, *de3, *dE2, *dY1, *rowsum_c, *colsum_r, *dU, *dV, *d_pge,
+      *slabs_w;
+  double* parts;
+  // inner loop
+  float *adj_norm_in, *rnorm_in, *Qin, *rsq_in, *S_in, *g_model;
+  // optimiser state
+  float *m_feat, *v_feat, *m_pge, *v_pge, *m_model, *v_model;
+  int step_feat, step_pge, step_model;
+  uint32_t sample_step;
+  // bookkeeping (device)
+  double* loss_sum;
+  float* loss_last;
+  long* steps;
+  long *off_lo, *off_loF, *off_loC, *off_lon;
+  int* ncls;
+  float* ones;
+  bool have_blocks;
+};
+
+static void derive(gs_gcond* e, const gs_gcond_config& c) {
+  e->cfg = c;
+  e->N = c.n_nodes; e->d = c.d; e->ldx = c.ldx; e->C = c.nclass; e->n = c.n_syn; e->T = c.ntrans; e->h = c.hidden;
+  e->Ph = c.pge_hidden; e->bcap = c.bcap; e->f1 = c.f1; e->f2 = c.f2; e->cap1 = c.bcap * (1 + c.f1);
+  e->F = (c.ntrans == 1) ? c.d : c.hidden;
+  gs_pdesc& pd = e->pd;
+  memset(&pd, 0, sizeof(pd));
+  if (e->T == 1) {
+    e->oW1 = e->ob1 = 0;
+    e->oWl = 0; e->obl = (long)e->d * e->C;
+    e->P = e->obl + e->C;
+    pd.nparams = 2;
+    pd.rows[0] = e->d; pd.cols[0] = e->C; pd.off[0] = 0; pd.is_bias[0] = 0;
+    pd.rows[1] = e->C; pd.cols[1] = 1; pd.off[1] = e->obl; pd.is_bias[1] = 1;
+  } else {
+    e->oW1 = 0; e->ob1 = (long)e->d * e->h;
+    e->oWl = e->ob1 + e->h; e->obl = e->oWl + (long)e->h * e->C;
+    e->P = e->obl + e->C;
+    pd.nparams = 4;
+    pd.rows[0] = e->d; pd.cols[0] = e->h; pd.off[0] = 0; pd.is_bias[0] = 0;
+    pd.rows[1] = e->h; pd.cols[1] = 1; pd.off[1] = e->ob1; pd.is_bias[1] = 1;
+    pd.rows[2] = e->h; pd.cols[2] = e->C; pd.off[2] = e->oWl; pd.is_bias[2] = 0;
+    pd.rows[3] = e->C; pd.cols[3] = 1; pd.off[3] = e->obl; pd.is_bias[3] = 1;
+  }
+  int co = 0;
+  for (int p = 0; p < pd.nparams; ++p) { pd.col_off[p] = co; co += pd.cols[p]; }
+  pd.total_cols = co;
+  const long Ph = e->Ph, d = e->d;
+  e->pW0 = 0; e->pb0 = Ph * 2 * d; e->pW1 = e->pb0 + Ph; e->pb1 = e->pW1 + Ph * Ph; e->pw2 = e->pb1 + Ph;
+  e->pb2 = e->pw2 + Ph; e->pg1 = e->pb2 + 1; e->pbe1 = e->pg1 + Ph; e->pg2 = e->pbe1 + Ph; e->pbe2 = e->pg2 + Ph;
+  e->Ppge = e->pbe2 + Ph;
+  e->kchunk_r = 1024;
+  e->nsplit_r = gs_cdiv((long)e->cap1 * e->f2, e->kchunk_r);
+  e->kchunk_w = 2048;
+  e->nsplit_w = gs_cdiv((long)e->n * e->n, e->kchunk_w);
+  e->rows_per_block = 128;
+  e->nblk_stats = gs_cdiv((long)e->n * e->n, e->rows_per_block);
+}
+
+static size_t carve(gs_gcond* e, void* base) {
+  Carver w{(char*)base, 0};
+  const long C = e->C, n = e->n, d = e->d, h = e->h, Ph = e->Ph, F = e->F, P = e->P, N = e->N;
+  const long bcap = e->bcap, cap1 = e->cap1, f1 = e->f1, f2 = e->f2, n2 = n * n;
+  gs_blocks& b = e->blk;
+  b.C = e->C; b.bcap = e->bcap; b.f1 = e->f1; b.f2 = e->f2; b.cap1 = e->cap1;
+  b.n_seed = w.take<int>(C); b.n1 = w.take<int>(C); b.nid1 = w.take<int>(C * cap1);
+  b.col1 = w.take<int>(C * bcap * f1); b.val1 = w.take<float>(C * bcap * f1);
+  b.tptr1 = w.take<int>(C * (cap1 + 1)); b.tedge1 = w.take<int>(C * bcap * f1);
+  b.col0 = w.take<int>(C * cap1 * f2); b.val0 = w.take<float>(C * cap1 * f2);
+  e->marker = e->cfg.external_blocks ? nullptr : w.take<int>(C * N);
+  e->kcount = w.take<int>(C);
+  e->H1full = e->T == 2 ? w.take<float>(N * h) : nullptr;
+  e->P0 = w.take<float>(C * cap1 * F); e->rs0 = w.take<float>(C * cap1);
+  e->Sr = w.take<float>(C * bcap * F); e->rsr = w.take<float>(C * bcap);
+  e->Zr = w.take<float>(C * bcap * C); e->gw_real = w.take<float>(C * P);
+  if (e->T == 2) {
+    e->Tm = w.take<float>(C * bcap * h); e->Y1 = w.take<float>(C * cap1 * h);
+    e->Bmat = w.take<float>(C * cap1 * f2 * h); e->slabs_r = w.take<float>(C * e->nsplit_r * d * h);
+  } else {
+    e->Tm = e->Y1 = e->Bmat = e->slabs_r = nullptr;
+  }
+  e->adj_raw = w.take<float>(n2); e->adj_norm = w.take<float>(n2); e->rnorm = w.take<float>(2 * n);
+  e->Q = w.take<float>(n2); e->rsq = w.take<float>(n);
+  e->H1s = e->T == 2 ? w.take<float>(n * h) : nullptr;
+  e->Ss = w.take<float>(n * F); e->Zs = w.take<float>(n * C); e->Ps = w.take<float>(n * C); e->Gs = w.take<float>(n * C);
+  e->gw_syn = w.take<float>(C * P); e->stats = w.take<float>(C * e->pd.total_cols * 3);
+  e->ab = w.take<float>(C * e->pd.total_cols * 2); e->loss_c = w.take<float>(C); e->D = w.take<float>(C * P);
+  e->Ug = w.take<float>(n * C); e->Vs = w.take<float>(n * C); e->dSs = w.take<float>(n * F); e->drs = w.take<float>(n);
+  e->dQ = w.take<float>(n2); e->dAn = w.take<float>(n2); e->d_adj = w.take<float>(n2); e->d_feat = w.take<float>(n * d);
+  if (e->T == 2) {
+    e->dH2 = w.take<float>(C * n * C); e->dHp = w.take<float>(C * n * h); e->A1m = w.take<float>(C * n * h);
+    e->Bc = w.take<float>(C * n * C); e->dH1m = w.take<float>(n * h); e->slabs_x = w.take<float>(C * n * d);
+  } else {
+    e->dH2 = e->dHp = e->A1m = e->Bc = e->dH1m = e->slabs_x = nullptr;
+  }
+  e->U = w.take<float>(n * Ph); e->V = w.take<float>(n * Ph);
+  e->mu1 = w.take<float>(Ph); e->is1 = w.take<float>(Ph); e->mu2 = w.take<float>(Ph); e->is2 = w.take<float>(Ph);
+  e->sumU = w.take<float>(Ph); e->sumV = w.take<float>(Ph);
+  e->A1 = w.take<float>(n2 * Ph); e->E2 = w.take<float>(n2 * Ph); e->e3 = w.take<float>(n2); e->de3 = w.take<float>(n2);
+  e->dE2 = w.take<float>(n2 * Ph); e->dY1 = w.take<float>(n2 * Ph);
+  e->rowsum_c = w.take<float>(n * Ph); e->colsum_r = w.take<float>(n * Ph); e->dU = w.take<float>(n * Ph);
+  e->dV = w.take<float>(n * Ph); e->d_pge = w.take<float>(e->Ppge); e->slabs_w = w.take<float>(e->nsplit_w * Ph * Ph);
+  e->parts = w.take<double>((long)e->nblk_stats * 3 * Ph);
+  e->adj_norm_in = w.take<float>(n2); e->rnorm_in = w.take<float>(2 * n); e->Qin = w.take<float>(n2);
+  e->rsq_in = w.take<float>(n); e->S_in = w.take<float>(n * F); e->g_model = w.take<float>(P);
+  e->m_feat = w.take<float>(n * d); e->v_feat = w.take<float>(n * d);
+  e->m_pge = w.take<float>(e->Ppge); e->v_pge = w.take<float>(e->Ppge);
+  e->m_model = w.take<float>(P); e->v_model = w.take<float>(P);
+  e->loss_sum = w.take<double>(1); e->loss_last = w.take<float>(1); e->steps = w.take<long>(1);
+  e->off_lo = w.take<long>(C); e->off_loF = w.take<long>(C); e->off_loC = w.take<long>(C); e->off_lon = w.take<long>(C);
+  e->ncls = w.take<int>(C); e->ones = w.take<float>(1);
+  return (w.off + 255) & ~(size_t)255;
+}
+
+static int check_cfg(const gs_gcond_config* c) {
+  if (!c) GS_FAIL(GS_ERR_ARG, "gs_gcond: null config");
+  if (c->ntrans != 1 && c->ntrans != 2) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: SGC ntrans must be 1 or 2 (got %d)", c->ntrans);
+  if (c->n_nodes < 1 || c->d < 1 || c->ldx < c->d || c->nclass < 1 || c->n_syn < 1 || c->pge_hidden < 1)
+    GS_FAIL(GS_ERR_ARG, "gs_gcond: bad dimensions");
+  if (c->nclass > 512) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nclass > 512");
+  if (c->ntrans == 2 && c->hidden < 1) GS_FAIL(GS_ERR_ARG, "gs_gcond: hidden must be > 0 for ntrans = 2");
+  if (c->bcap < 1 || c->bcap > 256 || c->f1 < 1 || c->f1 > 16 || c->f2 < 1 || c->f2 > 16)
+    GS_FAIL(GS_ERR_ARG, "gs_gcond: bcap in [1,256], fan-outs in [1,16]");
+  if (c->dis_metric < 0 || c->dis_metric > 2) GS_FAIL(GS_ERR_ARG, "DC error: unknown distance function");
+  if (c->inner_loop < 0) GS_FAIL(GS_ERR_ARG, "gs_gcond: negative inner_loop");
+  return GS_OK;
+}
+
+extern "C" int gs_gcond_workspace_bytes(const gs_gcond_config* cfg, size_t* bytes) {
+  GS_TRY(check_cfg(cfg));
+  if (!bytes) GS_FAIL(GS_ERR_ARG, "gs_gcond_workspace_bytes: null out");
+  gs_gcond tmp;
+  derive(&tmp, *cfg);
+  *bytes = carve(&tmp, nullptr);
+  return GS_OK;
+}
+
+extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io, gs_stream_t stream, gs_gcond** out) {
+  GS_TRY(check_cfg(cfg));
+  if (!io || !out) GS_FAIL(GS_ERR_ARG, "gs_gcond_create: null argument");
+  if (!io->X || !io->labels_syn || !io->syn_lo || !io->syn_hi || !io->feat_syn || !io->pge_params || !io->model_params ||
+      !io->adj_syn || !io->workspace)
+    GS_FAIL(GS_ERR_ARG, "gs_gcond_create: null buffer in gs_gcond_io");
+  if (!cfg->external_blocks && (!io->rowptr || !io->col || !io->val || !io->cls_ptr || !io->cls_nodes))
+    GS_FAIL(GS_ERR_ARG, "gs_gcond_create: graph / class pools required unless external_blocks");
+  gs_gcond* e = new (std::nothrow) gs_gcond;
+  if (!e) GS_FAIL(GS_ERR_STATE, "gs_gcond_create: out of host memory");
+  derive(e, *cfg);
+  e->io = *io;
+  size_t need = carve(e, nullptr);
+  if (io->workspace_bytes < need) {
+    delete e;
+    GS_FAIL(GS_ERR_ARG, "gs_gcond_create: workspace too small (%zu < %zu)", io->workspace_bytes, need);
+  }
+  carve(e, io->workspace);
+  hipStream_t s = (hipStream_t)stream;
+  const int C = e->C;
+  int* lo = new int[C];
+  int* hi = new int[C];
+  hipError_t he = hipMemcpyAsync(lo, io->syn_lo, C * sizeof(int), hipMemcpyDeviceToHost, s);
+  if (he == hipSuccess) he = hipMemcpyAsync(hi, io->syn_hi, C * sizeof(int), hipMemcpyDeviceToHost, s);
+  if (he == hipSuccess) he = hipStreamSynchronize(s);
+  if (he != hipSuccess) {
+    delete[] lo; delete[] hi; delete e;
+    GS_FAIL(GS_ERR_HIP, "gs_gcond_create: reading class ranges failed: %s", hipGetErrorString(he));
+  }
+  long *o1 = new long[C], *oF = new long[C], *oC = new long[C], *on = new long[C];
+  int* nc = new int[C];
+  e->max_nc = 0;
+  bool bad = false;
+  for (int c = 0; c < C; ++c) {
+    if (lo[c] < 0 || hi[c] < lo[c] || hi[c] > e->n) bad = true;
+    nc[c] = hi[c] - lo[c];
+    if (nc[c] > e->max_nc) e->max_nc = nc[c];
+    o1[c] = lo[c]; oF[c] = (long)lo[c] * e->F; oC[c] = (long)lo[c] * C; on[c] = (long)lo[c] * e->n;
+  }
+  float one = 1.f;
+  if (!bad) {
+    (void)hipMemcpyAsync(e->off_lo, o1, C * sizeof(long), hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(e->off_loF, oF, C * sizeof(long), hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(e->off_loC, oC, C * sizeof(long), hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(e->off_lon, on, C * sizeof(long), hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(e->ncls, nc, C * sizeof(int), hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(e->ones, &one, sizeof(float), hipMemcpyHostToDevice, s);
+    (void)hipMemsetAsync(e->m_feat, 0, sizeof(float) * e->n * e->d, s);
+    (void)hipMemsetAsync(e->v_feat, 0, sizeof(float) * e->n * e->d, s);
+    (void)hipMemsetAsync(e->m_pge, 0, sizeof(float) * e->Ppge, s);
+    (void)hipMemsetAsync(e->v_pge, 0, sizeof(float) * e->Ppge, s);
+    (void)hipMemsetAsync(e->m_model, 0, sizeof(float) * e->P, s);
+    (void)hipMemsetAsync(e->v_model, 0, sizeof(float) * e->P, s);
+    (void)hipMemsetAsync(e->loss_sum, 0, sizeof(double), s);
+    (void)hipMemsetAsync(e->loss_last, 0, sizeof(float), s);
+    (void)hipMemsetAsync(e->steps, 0, sizeof(long), s);
+    if (e->marker)
+      hipLaunchKernelGGL(gs_fill_int_kernel, dim3(gs_cdiv((long)C * e->N, 256)), dim3(256), 0, s, e->marker, (long)C * e->N,
+                         0x7fffffff);
+    he = hipStreamSynchronize(s);
+  }
+  delete[] lo; delete[] hi; delete[] o1; delete[] oF; delete[] oC; delete[] on; delete[] nc;
+  if (bad) { delete e; GS_FAIL(GS_ERR_ARG, "gs_gcond_create: class row ranges out of bounds"); }
+  if (he != hipSuccess) { delete e; GS_FAIL(GS_ERR_HIP, "gs_gcond_create: initialisation failed: %s", hipGetErrorString(he)); }
+  e->step_feat = e->step_pge = e->step_model = 0;
+  e->sample_step = 0;
+  e->have_blocks = false;
+  *out = e;
+  return GS_OK;
+}
+
+extern "C" void gs_gcond_destroy(gs_gcond* e) { delete e; }
+
+extern "C" int gs_gcond_new_epoch(gs_gcond* e, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "gs_gcond_new_epoch: null engine");
+  hipStream_t s = (hipStream_t)stream;
+  GS_HIP(hipMemsetAsync(e->m_model, 0, sizeof(float) * e->P, s));
+  GS_HIP(hipMemsetAsync(e->v_model, 0, sizeof(float) * e->P, s));
+  e->step_model = 0;
+  return GS_OK;
+}
+
+extern "C" int gs_gcond_get_blocks(gs_gcond* e, gs_blocks* out) {
+  if (!e || !out) GS_FAIL(GS_ERR_ARG, "gs_gcond_get_blocks: null argument");
+  *out = e->blk;
+  return GS_OK;
+}
+
+extern "C" int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* b, gs_stream_t stream) {
+  if (!e || !b) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_blocks: null argument");
+  const gs_blocks& d = e->blk;
+  if (b->C != d.C || b->bcap != d.bcap || b->f1 != d.f1 || b->f2 != d.f2 || b->cap1 != d.cap1)
+    GS_FAIL(GS_ERR_ARG, "gs_gcond_set_blocks: block geometry differs from the engine's");
+  hipStream_t s = (hipStream_t)stream;
+  const long C = d.C, bcap = d.bcap, f1 = d.f1, f2 = d.f2, cap1 = d.cap1;
+#define CP(f, cnt, T) GS_HIP(hipMemcpyAsync(d.f, b->f, (cnt) * sizeof(T), hipMemcpyDeviceToDevice, s))
+  CP(n_seed, C, int); CP(n1, C, int); CP(nid1, C * cap1, int); CP(col1, C * bcap * f1, int); CP(val1, C * bcap * f1, float);
+  CP(tptr1, C * (cap1 + 1), int); CP(tedge1, C * bcap * f1, int); CP(col0, C * cap1 * f2, int); CP(val0, C * cap1 * f2, float);
+#undef CP
+  e->have_blocks = true;
+  return GS_OK;
+}
+
+// ================================================================================================
+// stage: sampling
+// ================================================================================================
+extern "C" int gs_gcond_stage_sample(gs_gcond* e, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  if (e->cfg.external_blocks) {
+    if (!e->have_blocks) GS_FAIL(GS_ERR_STATE, "gs_gcond: external_blocks set but gs_gcond_set_blocks was never called");
+    return GS_OK;
+  }
+  GS_TRY(gs_sample_blocks(e->io.rowptr, e->io.col, e->io.val, e->N, e->io.cls_ptr, e->io.cls_nodes, e->marker, &e->blk,
+                          e->cfg.seed, e->sample_step++, stream));
+  e->have_blocks = true;
+  return GS_OK;
+}
+
+// ================================================================================================
+// stage: real-side per-class gradients gw_real[c] (gcond_base.py:212-224), propagate-first form
+// ================================================================================================
+static void launch_ell(const int* col, const float* val, const int* nrows, int cap_rows, int f, long col_base_stride,
+                       const float* src, long ld_src, const float* rs_in, int F, float* out, float* rs_out, int C,
+                       hipStream_t s) {
+  long waves = (long)C * cap_rows;
+  int blocks = gs_cdiv(waves, 4);
+  bool vec = (F % 4 == 0) && (ld_src % 4 == 0) && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL((gs_ell_spmm_kernel<4>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
+                       src, ld_src, rs_in, F, out, rs_out, C);
+  else
+    hipLaunchKernelGGL((gs_ell_spmm_kernel<1>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
+                       src, ld_src, rs_in, F, out, rs_out, C);
+}
+
+extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  if (!e->have_blocks) GS_FAIL(GS_ERR_STATE, "gs_gcond: no sampled blocks yet");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = e->C, d = e->d, h = e->h, F = e->F, bcap = e->bcap, cap1 = e->cap1, f1 = e->f1, f2 = e->f2;
+  const long P = e->P;
+  const float* th = e->io.model_params;
+  const float* src = e->io.X;
+  long ld_src = e->ldx;
+  if (e->T == 2) {   // H1full = relu(X W1 + b1) for every node once: theta is shared by all classes
+    gs_gemm_desc g = mk(e->io.X, e->ldx, 1, th + e->oW1, h, 1, e->H1full, h, e->N, h, d);
+    g.bias = th + e->ob1;
+    g.relu = 1;
+    GS_TRY(gs_gemm_f32(&g, stream));
+    src = e->H1full;
+    ld_src = h;
+  }
+  // hop 2 (outermost): frontier rows <- global sources;  hop 1: seeds <- frontier
+  launch_ell(e->blk.col0, e->blk.val0, e->blk.n1, cap1, f2, 0, src, ld_src, nullptr, F, e->P0, e->rs0, C, s);
+  launch_ell(e->blk.col1, e->blk.val1, e->blk.n_seed, bcap, f1, cap1, e->P0, F, e->rs0, F, e->Sr, e->rsr, C, s);
+  GS_LAUNCH_CHECK();
+  {  // Z = S Wl  (all classes at once), then G in place
+    gs_gemm_desc g = mk(e->Sr, F, 1, th + e->oWl, C, 1, e->Zr, C, C * bcap, C, F);
+    GS_TRY(gs_gemm_f32(&g, stream));
+    hipLaunchKernelGGL(gs_real_softmax_grad_kernel, dim3(gs_cdiv((long)C * bcap, 4)), dim3(256), 0, s, e->Zr, e->rsr,
+                       th + e->obl, e->blk.n_seed, bcap, C);
+    GS_LAUNCH_CHECK();
+  }
+  {  // gWl_c = S_c^T G_c ;  gbl_c = rs_c^T G_c      (padding rows of G are exact zeros)
+    gs_gemm_desc g = mk(e->Sr, 1, F, e->Zr, C, 1, e->gw_real + e->oWl, C, F, C, bcap);
+    g.nb1 = C; g.sAb1 = (long)bcap * F; g.sBb1 = (long)bcap * C; g.sCb1 = P;
+    GS_TRY(gs_gemm_f32(&g, stream));
+    gs_gemm_desc gb = mk(e->rsr, 0, 1, e->Zr, C, 1, e->gw_real + e->obl, C, 1, C, bcap);
+    gb.nb1 = C; gb.sAb1 = bcap; gb.sBb1 = (long)bcap * C; gb.sCb1 = P;
+    GS_TRY(gs_gemm_f32(&gb, stream));
+  }
+  if (e->T == 2) {
+    // Tm = G W2^T ; Y1 = A1^T Tm ; Bmat = per-edge masked contribution ; gW1_c = X[col0]^T Bmat_c ; gb1_c = colsum
+    gs_gemm_desc g = mk(e->Zr, C, 1, th + e->oWl, 1, C, e->Tm, h, C * bcap, h, C);
+    GS_TRY(gs_gemm_f32(&g, stream));
+    hipLaunchKernelGGL(gs_csc_spmm_t_kernel, dim3(gs_cdiv((long)C * cap1, 4)), dim3(256), 0, s, e->blk.tptr1, e->blk.tedge1,
+                       e->blk.val1, e->blk.n1, cap1, bcap, f1, e->Tm, h, e->Y1, C);
+    hipLaunchKernelGGL(gs_make_bmat_kernel, dim3(gs_cdiv((long)C * cap1 * f2, 4)), dim3(256), 0, s, e->blk.col0, e->blk.val0,
+                       e->blk.n1, cap1, f2, e->H1full, (long)h, e->Y1, h, e->Bmat, e->kcount, C);
+    GS_LAUNCH_CHECK();
+    const long K = (long)cap1 * f2;
+    gs_gemm_desc gw = mk(e->io.X, 1, e->ldx, e->Bmat, h, 1, e->slabs_r, h, d, h, (int)K);
+    gw.gatherA_k = e->blk.col0; gw.sGb1 = K;
+    gw.nb1 = C; gw.nb2 = e->nsplit_r; gw.kchunk = e->kchunk_r; gw.Kb = e->kcount;
+    gw.sBb1 = K * h; gw.sCb1 = (long)e->nsplit_r * d * h; gw.sCb2 = (long)d * h;
+    GS_TRY(gs_gemm_f32(&gw, stream));
+    GS_TRY(gs_reduce_slabs_batched_f32(e->gw_real + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, C, 0.f, stream));
+    gs_gemm_desc gb = mk(e->ones, 0, 0, e->Bmat, h, 1, e->gw_real + e->ob1, h, 1, h, (int)K);
+    gb.nb1 = C; gb.Kb = e->kcount; gb.sBb1 = K * h; gb.sCb1 = P;
+    GS_TRY(gs_gemm_f32(&gb, stream));
+  }
+  return GS_OK;
+}
+
+// ================================================================================================
+// stage: PGE forward (parametrized_adj.py:40-71) + dense_gcn_norm
+// ================================================================================================
+extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = e->n, d = e->d, Ph = e->Ph;
+  const long n2 = (long)n * n;
+  const float* X = e->io.feat_syn;
+  const float* pp = e->io.pge_params;
+  {  // U = X W0[:, :d]^T ; V = X W0[:, d:]^T      (two batches over the two halves of W0)
+    gs_gemm_desc g = mk(X, d, 1, pp + e->pW0, 1, 2L * d, e->U, Ph, n, Ph, d);
+    g.nb1 = 2; g.sBb1 = d; g.sCb1 = (long)n * Ph;     // V follows U in the workspace
+    if (e->V != e->U + (long)n * Ph) {                 // workspace alignment may separate them: two calls
+      g.nb1 = 1;
+      GS_TRY(gs_gemm_f32(&g, stream));
+      g.B = pp + e->pW0 + d; g.C = e->V;
+    }
+    GS_TRY(gs_gemm_f32(&g, stream));
+  }
+  hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->U, e->V, pp + e->pb0, n, Ph, e->mu1,
+                     e->is1, e->sumU, e->sumV);
+  hipLaunchKernelGGL(gs_pge_make_a1_kernel, dim3(gs_cdiv(n2 * Ph, 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0, e->mu1,
+                     e->is1, pp + e->pg1, pp + e->pbe1, n, Ph, e->A1);
+  GS_LAUNCH_CHECK();
+  {  // E2 = A1 W1^T + b1
+    gs_gemm_desc g = mk(e->A1, Ph, 1, pp + e->pW1, 1, Ph, e->E2, Ph, (int)n2, Ph, Ph);
+    g.bias = pp + e->pb1;
+    GS_TRY(gs_gemm_f32(&g, stream));
+  }
+  hipLaunchKernelGGL(gs_col_stats_kernel, dim3(e->nblk_stats), dim3(256), 0, s, e->E2, n2, Ph, e->rows_per_block, e->parts);
+  hipLaunchKernelGGL(gs_bn2_finalize_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->parts, e->nblk_stats, n2, Ph, e->mu2,
+                     e->is2);
+  hipLaunchKernelGGL(gs_pge_layer3_kernel, dim3(gs_cdiv(n2, 4)), dim3(256), 0, s, e->E2, e->mu2, e->is2, pp + e->pg2,
+                     pp + e->pbe2, pp + e->pw2, pp + e->pb2, n2, Ph, e->e3);
+  float* adj = inference ? e->io.adj_syn : e->adj_raw;
+  hipLaunchKernelGGL(gs_pge_adj_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, e->e3, n, adj);
+  GS_LAUNCH_CHECK();
+  if (inference) return gs_dense_gcn_norm_fwd(adj, n, e->adj_norm_in, e->rnorm_in, stream);
+  return gs_dense_gcn_norm_fwd(adj, n, e->adj_norm, e->rnorm, stream);
+}
+
+// ================================================================================================
+// stage: synthetic side — gw_syn per class, matching loss, closed-form d loss / d X~ (direct path)
+// and d loss / d A^ -> d adj     (gcond_base.py:226-239 + autograd through them)
+// ================================================================================================
+static int grouped(gs_gemm_desc& g, const gs_gcond* e) {   // per-class row ranges
+  g.nb1 = e->C;
+  return 0;
+}
+
+extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = e->C, n = e->n, d = e->d, h = e->h, F = e->F, mx = e->max_nc;
+  const long P = e->P;
+  const float* X = e->io.feat_syn;
+  const float* th = e->io.model_params;
+  const float* A = e->adj_norm;
+  const float* Wl = th + e->oWl;
+  const float* bl = th + e->obl;
+  (void)grouped;
+  {  // Q = A A ; rsq = Q 1
+    gs_gemm_desc g = mk(A, n, 1, A, n, 1, e->Q, n, n, n, n);
+    GS_TRY(gs_gemm_f32(&g, stream));
+    hipLaunchKernelGGL(gs_rowsum_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Q, n, n, e->rsq);
+  }
+  const float* Hin = X;   // [n x F]
+  if (e->T == 2) {
+    gs_gemm_desc g = mk(X, d, 1, th + e->oW1, h, 1, e->H1s, h, n, h, d);
+    g.bias = th + e->ob1; g.relu = 1;
+    GS_TRY(gs_gemm_f32(&g, stream));
+    Hin = e->H1s;
+  }
+  {  // S = Q Hin ; Z = S Wl ; P, G
+    gs_gemm_desc g = mk(e->Q, n, 1, Hin, F, 1, e->Ss, F, n, F, n);
+    GS_TRY(gs_gemm_f32(&g, stream));
+    gs_gemm_desc z = mk(e->Ss, F, 1, Wl, C, 1, e->Zs, C, n, C, F);
+    GS_TRY(gs_gemm_f32(&z, stream));
+    hipLaunchKernelGGL(gs_syn_softmax_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Zs, e->rsq, bl, e->io.labels_syn,
+                       e->io.syn_lo, e->io.syn_hi, n, C, e->Ps, e->Gs, 0);
+    GS_LAUNCH_CHECK();
+  }
+  {  // last layer: gWl_c = S[lo:hi]^T G[lo:hi] ; gbl_c = rs[lo:hi]^T G[lo:hi]
+    gs_gemm_desc g = mk(e->Ss, 1, F, e->Gs, C, 1, e->gw_syn + e->oWl, C, F, C, mx);
+    g.nb1 = C; g.offA = e->off_loF; g.offB = e->off_loC; g.Kb = e->ncls; g.sCb1 = P;
+    GS_TRY(gs_gemm_f32(&g, stream));
+    gs_gemm_desc gb = mk(e->rsq, 0, 1, e->Gs, C, 1, e->gw_syn + e->obl, C, 1, C, mx);
+    gb.nb1 = C; gb.offA = e->off_lo; gb.offB = e->off_loC; gb.Kb = e->ncls; gb.sCb1 = P;
+    GS_TRY(gs_gemm_f32(&gb, stream));
+  }
+  if (e->T == 2) {
+    // dH2_c = Q[lo:hi]^T G[lo:hi]  [n x C] ; dHp_c = (dH2_c W2^T) * mask ; gW1_c = X^T dHp_c ; gb1_c = colsum
+    gs_gemm_desc a = mk(e->Q, 1, n, e->Gs, C, 1, e->dH2, C, n, C, mx);
+    a.nb1 = C; a.offA = e->off_lon; a.offB = e->off_loC; a.Kb = e->ncls; a.sCb1 = (long)n * C;
+    GS_TRY(gs_gemm_f32(&a, stream));
+    gs_gemm_desc b = mk(e->dH2, C, 1, Wl, 1, C, e->dHp, h, n, h, C);
+    b.nb1 = C; b.sAb1 = (long)n * C; b.sCb1 = (long)n * h; b.mask = e->H1s; b.ldmask = h;
+    GS_TRY(gs_gemm_f32(&b, stream));
+    gs_gemm_desc c = mk(X, 1, d, e->dHp, h, 1, e->gw_syn + e->oW1, h, d, h, n);
+    c.nb1 = C; c.sBb1 = (long)n * h; c.sCb1 = P;
+    GS_TRY(gs_gemm_f32(&c, stream));
+    gs_gemm_desc cb = mk(e->ones, 0, 0, e->dHp, h, 1, e->gw_syn + e->ob1, h, 1, h, n);
+    cb.nb1 = C; cb.sBb1 = (long)n * h; cb.sCb1 = P;
+    GS_TRY(gs_gemm_f32(&cb, stream));
+  }
+  // ---- matching distance and D = d loss / d gw_syn (already scaled by n_c / n') -------------------
+  hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, C), dim3(256), 0, s, e->gw_real, e->gw_syn, P, e->pd, e->stats);
+  hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(C), dim3(256), 0, s, e->stats, e->pd, e->cfg.dis_metric, e->io.syn_lo,
+                     e->io.syn_hi, n, e->ab, e->loss_c);
+  hipLaunchKernelGGL(gs_dist_apply_kernel, dim3(gs_cdiv((long)C * P, 256)), dim3(256), 0, s, e->gw_real, e->gw_syn, P, e->pd,
+                     e->ab, e->D, C);
+  hipLaunchKernelGGL(gs_loss_accum_kernel, dim3(1), dim3(64), 0, s, e->loss_c, C, e->loss_sum, e->loss_last, e->steps);
+  GS_LAUNCH_CHECK();
+  const float* Dl = e->D + e->oWl;   // + c*P : d/d gWl_c
+  // ---- second-order backward ----------------------------------------------------------------------
+  if (e->T == 2) {
+    // A1m_c = (X D1_c + Db1_c) * mask ; dX slabs_c = dHp_c D1_c^T ; Bc = A1m_c W2
+    gs_gemm_desc a = mk(X, d, 1, e->D + e->oW1, h, 1, e->A1m, h, n, h, d);
+    a.nb1 = C; a.sBb1 = P; a.sCb1 = (long)n * h; a.bias = e->D + e->ob1; a.sbias_b1 = P; a.mask = e->H1s; a.ldmask = h;
+    GS_TRY(gs_gemm_f32(&a, stream));
+    gs_gemm_desc x = mk(e->dHp, h, 1, e->D + e->oW1, 1, h, e->slabs_x, d, n, d, h);
+    x.nb1 = C; x.sAb1 = (long)n * h; x.sBb1 = P; x.sCb1 = (long)n * d;
+    GS_TRY(gs_gemm_f32(&x, stream));
+    GS_TRY(gs_reduce_slabs_f32(e->d_feat, e->slabs_x, (long)n * d, C, (long)n * d, 0.f, stream));
+    gs_gemm_desc b = mk(e->A1m, h, 1, Wl, C, 1, e->Bc, C, n, C, h);
+    b.nb1 = C; b.sAb1 = (long)n * h; b.sCb1 = (long)n * C;
+    GS_TRY(gs_gemm_f32(&b, stream));
+    // dQ[lo:hi] = G[lo:hi] Bc_c^T
+    gs_gemm_desc q = mk(e->Gs, C, 1, e->Bc, 1, C, e->dQ, n, mx, n, C);
+    q.nb1 = C; q.offA = e->off_loC; q.Mb = e->ncls; q.sBb1 = (long)n * C; q.offC = e->off_lon;
+    GS_TRY(gs_gemm_f32(&q, stream));
+    // Ug[lo:hi] = Q[lo:hi] Bc_c + S[lo:hi] D2_c
+    gs_gemm_desc u = mk(e->Q, n, 1, e->Bc, C, 1, e->Ug, C, mx, C, n);
+    u.nb1 = C; u.offA = e->off_lon; u.Mb = e->ncls; u.sBb1 = (long)n * C; u.offC = e->off_loC;
+    GS_TRY(gs_gemm_f32(&u, stream));
+    gs_gemm_desc u2 = mk(e->Ss, F, 1, Dl, C, 1, e->Ug, C, mx, C, F);
+    u2.nb1 = C; u2.offA = e->off_loF; u2.Mb = e->ncls; u2.sBb1 = P; u2.offC = e->off_loC; u2.beta = 1.f;
+    GS_TRY(gs_gemm_f32(&u2, stream));
+  } else {
+    gs_gemm_desc u = mk(e->Ss, F, 1, Dl, C, 1, e->Ug, C, mx, C, F);
+    u.nb1 = C; u.offA = e->off_loF; u.Mb = e->ncls; u.sBb1 = P; u.offC = e->off_loC;
+    GS_TRY(gs_gemm_f32(&u, stream));
+  }
+  hipLaunchKernelGGL(gs_syn_v_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Ps, e->Gs, e->Ug, e->rsq, e->D, P, e->obl, bl,
+                     e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->Vs, e->drs);
+  GS_LAUNCH_CHECK();
+  {  // dS[lo:hi] = G[lo:hi] Dl_c^T ;  dS += V Wl^T
+    gs_gemm_desc a = mk(e->Gs, C, 1, Dl, 1, C, e->dSs, F, mx, F, C);
+    a.nb1 = C; a.offA = e->off_loC; a.Mb = e->ncls; a.sBb1 = P; a.offC = e->off_loF;
+    GS_TRY(gs_gemm_f32(&a, stream));
+    gs_gemm_desc b = mk(e->Vs, C, 1, Wl, 1, C, e->dSs, F, n, F, C);
+    b.beta = 1.f;
+    GS_TRY(gs_gemm_f32(&b, stream));
+  }
+  if (e->T == 1) {
+    gs_gemm_desc a = mk(e->Q, 1, n, e->dSs, d, 1, e->d_feat, d, n, d, n);   // dX = Q^T dS
+    GS_TRY(gs_gemm_f32(&a, stream));
+    gs_gemm_desc b = mk(e->dSs, d, 1, X, 1, d, e->dQ, n, n, n, d);          // dQ = dS X^T
+    GS_TRY(gs_gemm_f32(&b, stream));
+  } else {
+    gs_gemm_desc a = mk(e->Q, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n);     // (Q^T dS) * mask
+    a.mask = e->H1s; a.ldmask = h;
+    GS_TRY(gs_gemm_f32(&a, stream));
+    gs_gemm_desc b = mk(e->dSs, h, 1, e->H1s, 1, h, e->dQ, n, n, n, h);     // dQ += dS H1^T
+    b.beta = 1.f;
+    GS_TRY(gs_gemm_f32(&b, stream));
+    gs_gemm_desc c = mk(e->dH1m, h, 1, th + e->oW1, 1, h, e->d_feat, d, n, d, h);   // dX += dH1m W1^T
+    c.beta = 1.f;
+    GS_TRY(gs_gemm_f32(&c, stream));
+  }
+  hipLaunchKernelGGL(gs_add_rowvec_kernel, dim3(gs_cdiv((long)n * n, 256)), dim3(256), 0, s, e->dQ, e->drs, n, n);
+  GS_LAUNCH_CHECK();
+  {  // dA^ = dQ A^T + A^T dQ ; then through dense_gcn_norm
+    gs_gemm_desc a = mk(e->dQ, n, 1, A, 1, n, e->dAn, n, n, n, n);
+    GS_TRY(gs_gemm_f32(&a, stream));
+    gs_gemm_desc b = mk(A, 1, n, e->dQ, n, 1, e->dAn, n, n, n, n);
+    b.beta = 1.f;
+    GS_TRY(gs_gemm_f32(&b, stream));
+  }
+  return gs_dense_gcn_norm_bwd(e->adj_raw, e->rnorm, e->dAn, n, e->d_adj, stream);
+}
+
+// ================================================================================================
+// stage: PGE backward: d adj -> d theta_PGE and d X~ (added to d_feat)
+// ================================================================================================
+extern "C" int gs_gcond_stage_pge_backward(gs_gcond* e, int need_param_grads, int need_feat_grad, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = e->n, d = e->d, Ph = e->Ph;
+  const long n2 = (long)n * n;
+  const float* X = e->io.feat_syn;
+  const float* pp = e->io.pge_params;
+  float* g = e->d_pge;
+  hipLaunchKernelGGL(gs_pge_adj_bwd_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, e->d_adj, e->adj_raw, n, e->de3);
+  hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(e->nblk_stats), dim3(256), 0, s, e->E2, e->de3, e->mu2, e->is2,
+                     pp + e->pg2, pp + e->pbe2, pp + e->pw2, n2, Ph, e->rows_per_block, e->parts);
+  hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->parts, e->nblk_stats, 3, Ph, g + e->pw2,
+                     g + e->pbe2, g + e->pg2);
+  hipLaunchKernelGGL(gs_pge_bn2_bwd_kernel, dim3(gs_cdiv(n2 * Ph, 256)), dim3(256), 0, s, e->E2, e->de3, e->mu2, e->is2,
+                     pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, n2, Ph, e->dE2);
+  GS_LAUNCH_CHECK();
+  if (need_param_grads) {
+    // dW1 = dE2^T A1  (K = n'^2 split into slabs, fixed-order reduce) ; db1 = colsum(dE2)
+    gs_gemm_desc w = mk(e->dE2, 1, Ph, e->A1, Ph, 1, e->slabs_w, Ph, Ph, Ph, (int)n2);
+    w.nb2 = e->nsplit_w; w.kchunk = e->kchunk_w; w.sCb2 = (long)Ph * Ph;
+    GS_TRY(gs_gemm_f32(&w, stream));
+    GS_TRY(gs_reduce_slabs_f32(g + e->pW1, e->slabs_w, (long)Ph * Ph, e->nsplit_w, (long)Ph * Ph, 0.f, stream));
+    hipLaunchKernelGGL(gs_rowsum_kernel, dim3(1), dim3(256), 0, s, e->de3, 1, (int)n2, g + e->pb2);   // db2 = sum de3
+    hipLaunchKernelGGL(gs_col_stats_kernel, dim3(e->nblk_stats), dim3(256), 0, s, e->dE2, n2, Ph, e->rows_per_block, e->parts);
+    hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->parts, e->nblk_stats, 2, Ph, g + e->pb1,
+                       (float*)nullptr, (float*)nullptr);
+    GS_LAUNCH_CHECK();
+  }
+  {  // dY1 = (dE2 W1) * [A1 > 0]
+    gs_gemm_desc a = mk(e->dE2, Ph, 1, pp + e->pW1, Ph, 1, e->dY1, Ph, (int)n2, Ph, Ph);
+    a.mask = e->A1; a.ldmask = Ph;
+    GS_TRY(gs_gemm_f32(&a, stream));
+  }
+  hipLaunchKernelGGL(gs_pge_marginal_r_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, e->colsum_r);
+  hipLaunchKernelGGL(gs_pge_marginal_c_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, e->rowsum_c);
+  hipLaunchKernelGGL(gs_pge_bn1_bwd_cols_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->U, e->V, e->rowsum_c, e->colsum_r,
+                     pp + e->pb0, e->mu1, e->is1, n, Ph, g + e->pg1, g + e->pbe1);
+  hipLaunchKernelGGL(gs_pge_bn1_bwd_uv_kernel, dim3(gs_cdiv((long)n * Ph, 256)), dim3(256), 0, s, e->U, e->V, e->rowsum_c,
+                     e->colsum_r, pp + e->pb0, e->mu1, e->is1, pp + e->pg1, e->sumU, e->sumV, g + e->pg1, g + e->pbe1, n, Ph,
+                     e->dU, e->dV);
+  GS_LAUNCH_CHECK();
+  if (need_param_grads) {
+    hipLaunchKernelGGL(gs_colsum_small_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->dU, n, Ph, g + e->pb0);
+    GS_LAUNCH_CHECK();
+    gs_gemm_desc a = mk(e->dU, 1, Ph, X, d, 1, g + e->pW0, 2L * d, Ph, d, n);       // dW0[:, :d] = dU^T X
+    GS_TRY(gs_gemm_f32(&a, stream));
+    gs_gemm_desc b = mk(e->dV, 1, Ph, X, d, 1, g + e->pW0 + d, 2L * d, Ph, d, n);   // dW0[:, d:] = dV^T X
+    GS_TRY(gs_gemm_f32(&b, stream));
+  }
+  if (need_feat_grad) {   // d_feat += dU W0[:, :d] + dV W0[:, d:]
+    gs_gemm_desc a = mk(e->dU, Ph, 1, pp + e->pW0, 2L * d, 1, e->d_feat, d, n, d, Ph);
+    a.beta = 1.f;
+    GS_TRY(gs_gemm_f32(&a, stream));
+    gs_gemm_desc b = mk(e->dV, Ph, 1, pp + e->pW0 + d, 2L * d, 1, e->d_feat, d, n, d, Ph);
+    b.beta = 1.f;
+    GS_TRY(gs_gemm_f32(&b, stream));
+  }
+  return GS_OK;
+}
+
+// ================================================================================================
+// stage: optimiser step (gcond.py:58-61: PGE for epoch % 50 < 10, else X~)
+// ================================================================================================
+extern "C" int gs_gcond_stage_update(gs_gcond* e, int epoch, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  if (epoch % 50 < 10)
+    return gs_adam_step_f32(e->io.pge_params, e->d_pge, e->m_pge, e->v_pge, e->Ppge, e->cfg.lr_adj, 0.9f, 0.999f, 1e-8f, 0.f,
+                            ++e->step_pge, stream);
+  return gs_adam_step_f32(e->io.feat_syn, e->d_feat, e->m_feat, e->v_feat, (long)e->n * e->d, e->cfg.lr_feat, 0.9f, 0.999f,
+                          1e-8f, 0.f, ++e->step_feat, stream);
+}
+
+// ================================================================================================
+// stage: PGE.inference + inner_loop SGC steps on (X~, A^)  (gcond.py:63-72)
+// ================================================================================================
+extern "C" int gs_gcond_stage_inner(gs_gcond* e, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  hipStream_t s = (hipStream_t)stream;
+  GS_TRY(gs_gcond_stage_pge_forward(e, 1, stream));
+  const int C = e->C, n = e->n, d = e->d, h = e->h, F = e->F;
+  if (e->cfg.inner_loop == 0) return GS_OK;
+  const float* X = e->io.feat_syn;
+  float* th = e->io.model_params;
+  const float* A = e->adj_norm_in;
+  {
+    gs_gemm_desc g = mk(A, n, 1, A, n, 1, e->Qin, n, n, n, n);
+    GS_TRY(gs_gemm_f32(&g, stream));
+    hipLaunchKernelGGL(gs_rowsum_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Qin, n, n, e->rsq_in);
+    GS_LAUNCH_CHECK();
+    if (e->T == 1) {   // S = Q X does not depend on theta: once per outer iteration
+      gs_gemm_desc sg = mk(e->Qin, n, 1, X, d, 1, e->S_in, d, n, d, n);
+      GS_TRY(gs_gemm_f32(&sg, stream));
+    }
+  }
+  for (int it = 0; it < e->cfg.inner_loop; ++it) {
+    if (e->T == 2) {
+      gs_gemm_desc a = mk(X, d, 1, th + e->oW1, h, 1, e->H1s, h, n, h, d);
+      a.bias = th + e->ob1; a.relu = 1;
+      GS_TRY(gs_gemm_f32(&a, stream));
+      gs_gemm_desc b = mk(e->Qin, n, 1, e->H1s, h, 1, e->S_in, h, n, h, n);
+      GS_TRY(gs_gemm_f32(&b, stream));
+    }
+    gs_gemm_desc z = mk(e->S_in, F, 1, th + e->oWl, C, 1, e->Zs, C, n, C, F);
+    GS_TRY(gs_gemm_f32(&z, stream));
+    hipLaunchKernelGGL(gs_syn_softmax_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Zs, e->rsq_in, th + e->obl,
+                       e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, (float*)nullptr, e->Gs, 1);
+    GS_LAUNCH_CHECK();
+    gs_gemm_desc gw = mk(e->S_in, 1, F, e->Gs, C, 1, e->g_model + e->oWl, C, F, C, n);
+    GS_TRY(gs_gemm_f32(&gw, stream));
+    gs_gemm_desc gb = mk(e->rsq_in, 0, 1, e->Gs, C, 1, e->g_model + e->obl, C, 1, C, n);
+    GS_TRY(gs_gemm_f32(&gb, stream));
+    if (e->T == 2) {
+      gs_gemm_desc ds = mk(e->Gs, C, 1, th + e->oWl, 1, C, e->dSs, h, n, h, C);          // dS = G W2^T
+      GS_TRY(gs_gemm_f32(&ds, stream));
+      gs_gemm_desc dh = mk(e->Qin, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n);             // (Q^T dS) * mask
+      dh.mask = e->H1s; dh.ldmask = h;
+      GS_TRY(gs_gemm_f32(&dh, stream));
+      gs_gemm_desc w1 = mk(X, 1, d, e->dH1m, h, 1, e->g_model + e->oW1, h, d, h, n);     // X^T dHp
+      GS_TRY(gs_gemm_f32(&w1, stream));
+      gs_gemm_desc b1 = mk(e->ones, 0, 0, e->dH1m, h, 1, e->g_model + e->ob1, h, 1, h, n);
+      GS_TRY(gs_gemm_f32(&b1, stream));
+    }
+    GS_TRY(gs_adam_step_f32(th, e->g_model, e->m_model, e->v_model, e->P, e->cfg.lr_model, 0.9f, 0.999f, 1e-8f, 0.f,
+                            ++e->step_model, stream));
+  }
+  return GS_OK;
+}
+
+extern "C" int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  const int pge_epoch = (epoch % 50 < 10);
+  GS_TRY(gs_gcond_stage_sample(e, stream));
+  GS_TRY(gs_gcond_stage_real_grads(e, stream));
+  GS_TRY(gs_gcond_stage_pge_forward(e, 0, stream));
+  GS_TRY(gs_gcond_stage_syn_match(e, stream));
+  // only the gradient of the group that is stepped this epoch is consumed (the other optimiser's
+  // grads are zeroed unread by the next zero_grad(), gcond.py:54-61)
+  GS_TRY(gs_gcond_stage_pge_backward(e, pge_epoch, !pge_epoch, stream));
+  GS_TRY(gs_gcond_stage_update(e, epoch, stream));
+  return gs_gcond_stage_inner(e, stream);
+}
+
+extern "C" int gs_gcond_read_loss(gs_gcond* e, double* loss_sum, long* steps, gs_stream_t stream) {
+  if (!e || !loss_sum || !steps) GS_FAIL(GS_ERR_ARG, "gs_gcond_read_loss: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  GS_HIP(hipMemcpyAsync(loss_sum, e->loss_sum, sizeof(double), hipMemcpyDeviceToHost, s));
+  GS_HIP(hipMemcpyAsync(steps, e->steps, sizeof(long), hipMemcpyDeviceToHost, s));
+  GS_HIP(hipMemsetAsync(e->loss_sum, 0, sizeof(double), s));
+  GS_HIP(hipMemsetAsync(e->steps, 0, sizeof(long), s));
+  GS_HIP(hipStreamSynchronize(s));
+  return GS_OK;
+}
+
+extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* count) {
+  if (!e || !name || !ptr || !count) GS_FAIL(GS_ERR_ARG, "gs_gcond_buffer: null argument");
+  const long n = e->n, C = e->C;
+  struct { const char* k; void* p; long c; } tab[] = {
+      {"gw_real", e->gw_real, C * e->P},   {"gw_syn", e->gw_syn, C * e->P},     {"loss", e->loss_last, 1},
+      {"loss_c", e->loss_c, C},            {"d_feat", e->d_feat, n * e->d},     {"d_adj_norm", e->dAn, n * n},
+      {"d_adj", e->d_adj, n * n},          {"d_pge", e->d_pge, e->Ppge},        {"adj_norm", e->adj_norm, n * n},
+      {"adj_raw", e->adj_raw, n * n},      {"adj_norm_inner", e->adj_norm_in, n * n}, {"D", e->D, C * e->P},
+      {"g_model", e->g_model, e->P},       {"Sr", e->Sr, C * e->bcap * e->F},   {"rsr", e->rsr, C * e->bcap},
+      {"Q", e->Q, n * n},                  {"Ss", e->Ss, n * e->F},             {"Ps", e->Ps, n * C},
+      {"dQ", e->dQ, n * n},                {"e3", e->e3, n * n},                {"H1full", e->H1full, e->H1full ? (long)e->N * e->h : 0},
+  };
+  for (auto& t : tab)
+    if (!strcmp(t.k, name)) {
+      *ptr = t.p;
+      *count = t.c;
+      return GS_OK;
+    }
+  GS_FAIL(GS_ERR_ARG, "gs_gcond_buffer: unknown buffer '%s'", name);
+}

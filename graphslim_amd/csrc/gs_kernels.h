@@ -1,0 +1,600 @@
+// Custom (non-GEMM) kernels of the GCond engine.  Included once, by gs_engine.hip.
+// Every kernel cites the reference line whose arithmetic it carries.
+#pragma once
+#include "gs_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// ELL block aggregation with gather (sampled-block SpMM, models/sgc.py:46-47 on the real batch).
+// out[(c,row), :] = sum_j val[(c,row,j)] * src[(base_c + col[(c,row,j)]) * ld_src + :]
+// rs_out[(c,row)]  = sum_j val * (rs_in ? rs_in[base_c + col] : 1)
+// rows >= nrows[c] are written as zeros so that fixed-capacity batched GEMMs downstream see exact
+// zeros in the padding.  One wave per row, VEC floats per lane per access, f gathers in flight.
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict__ col, const float* __restrict__ val,
+                                                          const int* __restrict__ nrows, int cap_rows, int f,
+                                                          long col_base_stride, const float* __restrict__ src, long ld_src,
+                                                          const float* __restrict__ rs_in, int F, float* __restrict__ out,
+                                                          float* __restrict__ rs_out, int nclass) {
+  const int lane = threadIdx.x & 63;
+  const long grow = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // (c, row)
+  if (grow >= (long)nclass * cap_rows) return;
+  const int c = (int)(grow / cap_rows), row = (int)(grow - (long)c * cap_rows);
+  float* o = out + grow * F;
+  if (row >= nrows[c]) {
+    for (int c0 = lane * VEC; c0 < F; c0 += 64 * VEC)
+      for (int q = 0; q < VEC; ++q)
+        if (c0 + q < F) o[c0 + q] = 0.f;
+    if (lane == 0 && rs_out) rs_out[grow] = 0.f;
+    return;
+  }
+  const long ebase = grow * f, cb = (long)c * col_base_stride;
+  if (lane == 0 && rs_out) {
+    float s = 0.f;
+    for (int j = 0; j < f; ++j) s += val[ebase + j] * (rs_in ? rs_in[cb + col[ebase + j]] : 1.f);
+    rs_out[grow] = s;
+  }
+  for (int c0 = lane * VEC; c0 < F; c0 += 64 * VEC) {
+    if (VEC == 4) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < f; ++j) {
+        float w = val[ebase + j];
+        float4 x = *reinterpret_cast<const float4*>(src + (cb + col[ebase + j]) * ld_src + c0);
+        acc.x = fmaf(w, x.x, acc.x);
+        acc.y = fmaf(w, x.y, acc.y);
+        acc.z = fmaf(w, x.z, acc.z);
+        acc.w = fmaf(w, x.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(o + c0) = acc;
+    } else {
+      float acc = 0.f;
+      for (int j = 0; j < f; ++j) acc = fmaf(val[ebase + j], src[(cb + col[ebase + j]) * ld_src + c0], acc);
+      o[c0] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Real side: Z = S Wl (from the GEMM) + rs * bl;  G = (softmax(Z) - onehot(c)) / B_c, in place.
+// gcond_base.py:220-221 (log_softmax + nll_loss mean over the B seeds) differentiated wrt Z.
+// Padding rows (b >= n_seed[c]) -> 0.  One wave per row; C <= 64*8.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gs_real_softmax_grad_kernel(float* __restrict__ Z, const float* __restrict__ rs,
+                                                                   const float* __restrict__ bl,
+                                                                   const int* __restrict__ n_seed, int bcap, int C) {
+  const int lane = threadIdx.x & 63;
+  const long grow = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (grow >= (long)C * bcap) return;
+  const int c = (int)(grow / bcap), b = (int)(grow - (long)c * bcap);
+  float* z = Z + grow * C;
+  const int B = n_seed[c];
+  if (b >= B) {
+    for (int k = lane; k < C; k += 64) z[k] = 0.f;
+    return;
+  }
+  const float r = rs[grow];
+  float mx = -INFINITY;
+  for (int k = lane; k < C; k += 64) mx = fmaxf(mx, z[k] + r * bl[k]);
+  mx = gs_wave_max(mx);
+  float se = 0.f;
+  for (int k = lane; k < C; k += 64) se += expf(z[k] + r * bl[k] - mx);
+  se = gs_wave_sum(se);
+  const float inv = 1.f / se, invB = 1.f / (float)B;
+  for (int k = lane; k < C; k += 64) {
+    float p = expf(z[k] + r * bl[k] - mx) * inv;
+    z[k] = (p - (k == c ? 1.f : 0.f)) * invB;
+  }
+}
+
+// Synthetic side: P = softmax(S Wl + rs bl) kept, G = (P - onehot(label)) / n_label.
+// gcond_base.py:226-230 (loss on the rows of class c only, mean over n_c).
+__global__ __launch_bounds__(256) void gs_syn_softmax_grad_kernel(const float* __restrict__ Z, const float* __restrict__ rs,
+                                                                  const float* __restrict__ bl,
+                                                                  const int* __restrict__ labels,
+                                                                  const int* __restrict__ syn_lo,
+                                                                  const int* __restrict__ syn_hi, int n, int C,
+                                                                  float* __restrict__ P, float* __restrict__ G,
+                                                                  int divide_by_n /* inner loop: mean over all n */) {
+  const int lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n) return;
+  const float* z = Z + i * C;
+  const int y = labels[i];
+  const float r = rs[i];
+  float mx = -INFINITY;
+  for (int k = lane; k < C; k += 64) mx = fmaxf(mx, z[k] + r * bl[k]);
+  mx = gs_wave_max(mx);
+  float se = 0.f;
+  for (int k = lane; k < C; k += 64) se += expf(z[k] + r * bl[k] - mx);
+  se = gs_wave_sum(se);
+  const float inv = 1.f / se;
+  const float invn = 1.f / (float)(divide_by_n ? n : (syn_hi[y] - syn_lo[y]));
+  for (int k = lane; k < C; k += 64) {
+    float p = expf(z[k] + r * bl[k] - mx) * inv;
+    if (P) P[i * C + k] = p;
+    G[i * C + k] = (p - (k == y ? 1.f : 0.f)) * invn;
+  }
+}
+
+// V_i = (P_i * U_i - P_i (P_i . U_i)) / n_c with U_i = Ug_i + rs_i * Dbl_c   (softmax backward of
+// d loss / d G routed through G = (P - Y)/n_c).   drs_i = G_i . Dbl_c + V_i . bl.
+__global__ __launch_bounds__(256) void gs_syn_v_kernel(const float* __restrict__ P, const float* __restrict__ G,
+                                                       const float* __restrict__ Ug, const float* __restrict__ rs,
+                                                       const float* __restrict__ D, long P_total, long off_bl,
+                                                       const float* __restrict__ bl, const int* __restrict__ labels,
+                                                       const int* __restrict__ syn_lo, const int* __restrict__ syn_hi, int n,
+                                                       int C, float* __restrict__ V, float* __restrict__ drs) {
+  const int lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n) return;
+  const int y = labels[i];
+  const float* Db = D + (long)y * P_total + off_bl;
+  const float r = rs[i];
+  const float invn = 1.f / (float)(syn_hi[y] - syn_lo[y]);
+  float pu = 0.f, gd = 0.f;
+  for (int k = lane; k < C; k += 64) {
+    float u = Ug[i * C + k] + r * Db[k];
+    pu += P[i * C + k] * u;
+    gd += G[i * C + k] * Db[k];
+  }
+  pu = gs_wave_sum(pu);
+  gd = gs_wave_sum(gd);
+  float vb = 0.f;
+  for (int k = lane; k < C; k += 64) {
+    float p = P[i * C + k];
+    float u = Ug[i * C + k] + r * Db[k];
+    float v = (p * u - p * pu) * invn;
+    V[i * C + k] = v;
+    vb += v * bl[k];
+  }
+  vb = gs_wave_sum(vb);
+  if (lane == 0) drs[i] = gd + vb;
+}
+
+// M[i, :] += v[i]  (the rank-one  drs 1^T  term of dQ);  rowsum: out[i] = sum_j M[i, j]
+__global__ void gs_add_rowvec_kernel(float* __restrict__ M, const float* __restrict__ v, int rows, int cols) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * cols) return;
+  M[idx] += v[idx / cols];
+}
+__global__ __launch_bounds__(256) void gs_rowsum_kernel(const float* __restrict__ M, int rows, int cols, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= rows) return;
+  float s = 0.f;
+  for (int j = lane; j < cols; j += 64) s += M[i * cols + j];
+  s = gs_wave_sum(s);
+  if (lane == 0) out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// match_loss statistics (condensation/utils.py:12-106).  Parameter p of class c is viewed as a
+// [rows x cols] matrix (a bias is [len x 1]); per column: dot = <r,s>, nr2 = |r|^2, ns2 = |s|^2.
+// grid = (nparams, C); block = 256 = CB column lanes x (256/CB) row groups.
+// ------------------------------------------------------------------------------------------------
+struct gs_pdesc {
+  int nparams;
+  int rows[8], cols[8];
+  long off[8];      // offset inside the flat parameter vector
+  int col_off[8];   // offset of this parameter's columns inside the per-class stats row
+  int is_bias[8];
+  int total_cols;
+};
+
+__global__ __launch_bounds__(256) void gs_dist_stats_kernel(const float* __restrict__ gw_real, const float* __restrict__ gw_syn,
+                                                            long P_total, gs_pdesc pd, float* __restrict__ stats /*[C][total_cols][3]*/) {
+  const int p = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const int rows = pd.rows[p], cols = pd.cols[p];
+  const float* R = gw_real + (long)c * P_total + pd.off[p];
+  const float* S = gw_syn + (long)c * P_total + pd.off[p];
+  int CB = 1;
+  while (CB < cols && CB < 256) CB <<= 1;
+  const int tx = tid % CB, ty = tid / CB, nty = 256 / CB;
+  __shared__ float sh[3][256];
+  for (int k0 = 0; k0 < cols; k0 += CB) {
+    const int k = k0 + tx;
+    float dot = 0.f, nr2 = 0.f, ns2 = 0.f;
+    if (k < cols)
+      for (int i = ty; i < rows; i += nty) {
+        float r = R[(long)i * cols + k], s = S[(long)i * cols + k];
+        dot = fmaf(r, s, dot);
+        nr2 = fmaf(r, r, nr2);
+        ns2 = fmaf(s, s, ns2);
+      }
+    sh[0][tid] = dot;
+    sh[1][tid] = nr2;
+    sh[2][tid] = ns2;
+    __syncthreads();
+    if (ty == 0 && k < cols) {
+      for (int q = 1; q < nty; ++q) {
+        dot += sh[0][q * CB + tx];
+        nr2 += sh[1][q * CB + tx];
+        ns2 += sh[2][q * CB + tx];
+      }
+      float* st = stats + ((long)c * pd.total_cols + pd.col_off[p] + k) * 3;
+      st[0] = dot;
+      st[1] = nr2;
+      st[2] = ns2;
+    }
+    __syncthreads();
+  }
+}
+
+// per class: loss_c and per-column (alpha, beta) with D = alpha*r + beta*s, both scaled by coeff_c.
+// metric 0 'ours' (utils.py:33-39,86-104), 1 'mse' (:41-49), 2 'cos' (:51-60).
+__global__ __launch_bounds__(256) void gs_dist_finalize_kernel(const float* __restrict__ stats, gs_pdesc pd, int metric,
+                                                               const int* __restrict__ syn_lo, const int* __restrict__ syn_hi,
+                                                               int n_syn, float* __restrict__ ab /*[C][total_cols][2]*/,
+                                                               float* __restrict__ loss_c /*[C]*/) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int nc = syn_hi[c] - syn_lo[c];
+  const float coeff = (float)nc / (float)n_syn;     // gcond_base.py:237
+  const float* st = stats + (long)c * pd.total_cols * 3;
+  float* o = ab + (long)c * pd.total_cols * 2;
+  __shared__ double red[3][256];
+  double l = 0.0, sd = 0.0, sr = 0.0, ss = 0.0;
+  for (int p = 0; p < pd.nparams; ++p)
+    for (int k = tid; k < pd.cols[p]; k += 256) {
+      const int ci = pd.col_off[p] + k;
+      float dot = st[ci * 3], nr2 = st[ci * 3 + 1], ns2 = st[ci * 3 + 2];
+      if (metric == 0) {
+        float a = 0.f, b = 0.f;
+        if (!pd.is_bias[p]) {
+          float nr = sqrtf(nr2), ns = sqrtf(ns2);
+          float q = nr * ns + 1e-6f;
+          l += 1.0 - (double)(dot / q);
+          a = -1.f / q;
+          b = ns > 0.f ? dot * nr / (ns * q * q) : 0.f;
+        }
+        o[ci * 2] = a * coeff;
+        o[ci * 2 + 1] = b * coeff;
+      } else if (metric == 1) {
+        l += (double)ns2 - 2.0 * (double)dot + (double)nr2;
+        o[ci * 2] = -2.f * coeff;
+        o[ci * 2 + 1] = 2.f * coeff;
+      } else {
+        sd += dot;
+        sr += nr2;
+        ss += ns2;
+      }
+    }
+  if (nc == 0) {   // class without synthetic nodes: no term (the reference never builds one, gcond_base.py:104-107)
+    for (int k = tid; k < pd.total_cols; k += 256) { o[k * 2] = 0.f; o[k * 2 + 1] = 0.f; }
+    if (tid == 0) loss_c[c] = 0.f;
+    return;
+  }
+  red[0][tid] = metric == 2 ? sd : l;
+  red[1][tid] = sr;
+  red[2][tid] = ss;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      red[0][tid] += red[0][tid + s];
+      red[1][tid] += red[1][tid + s];
+      red[2][tid] += red[2][tid + s];
+    }
+    __syncthreads();
+  }
+  if (metric == 2) {
+    float dot = (float)red[0][0], nr = sqrtf((float)red[1][0]), ns = sqrtf((float)red[2][0]);
+    float q = nr * ns + 1e-6f;
+    float a = -1.f / q, b = ns > 0.f ? dot * nr / (ns * q * q) : 0.f;
+    for (int k = tid; k < pd.total_cols; k += 256) { o[k * 2] = a * coeff; o[k * 2 + 1] = b * coeff; }
+    if (tid == 0) loss_c[c] = coeff * (1.f - dot / q);
+  } else if (tid == 0) {
+    loss_c[c] = coeff * (float)red[0][0];
+  }
+}
+
+// D[c][p][i][k] = alpha[c][col] * r + beta[c][col] * s
+__global__ void gs_dist_apply_kernel(const float* __restrict__ gw_real, const float* __restrict__ gw_syn, long P_total,
+                                     gs_pdesc pd, const float* __restrict__ ab, float* __restrict__ D, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)C * P_total) return;
+  const int c = (int)(idx / P_total);
+  const long e = idx - (long)c * P_total;
+  int p = 0;
+  while (p + 1 < pd.nparams && e >= pd.off[p + 1]) ++p;
+  const int k = (int)((e - pd.off[p]) % pd.cols[p]);
+  const float* o = ab + ((long)c * pd.total_cols + pd.col_off[p] + k) * 2;
+  D[idx] = o[0] * gw_real[idx] + o[1] * gw_syn[idx];
+}
+
+// loss_total += sum_c loss_c (fixed order);  also keeps the last value in loss_last
+__global__ void gs_loss_accum_kernel(const float* __restrict__ loss_c, int C, double* __restrict__ loss_sum,
+                                     float* __restrict__ loss_last, long* __restrict__ steps) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += loss_c[c];
+    *loss_last = s;
+    *loss_sum += (double)s;
+    *steps += 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Real side, T = 2 backward pieces (autograd of models/sgc.py:37-47 on the sampled blocks).
+// Y1[(c,l), :] = sum_{slot in in-edges of l} val1[slot] * Tm[(c, slot / f1), :]     (A1^T Tm via CSC)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gs_csc_spmm_t_kernel(const int* __restrict__ tptr, const int* __restrict__ tedge,
+                                                            const float* __restrict__ val1, const int* __restrict__ n1,
+                                                            int cap1, int bcap, int f1, const float* __restrict__ Tm, int F,
+                                                            float* __restrict__ Y1, int nclass) {
+  const int lane = threadIdx.x & 63;
+  const long grow = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (grow >= (long)nclass * cap1) return;
+  const int c = (int)(grow / cap1), l = (int)(grow - (long)c * cap1);
+  float* o = Y1 + grow * F;
+  if (l >= n1[c]) {
+    for (int k = lane; k < F; k += 64) o[k] = 0.f;
+    return;
+  }
+  const int* tp = tptr + (long)c * (cap1 + 1);
+  const int* te = tedge + (long)c * bcap * f1;
+  const int a = tp[l], b = tp[l + 1];
+  for (int k = lane; k < F; k += 64) {
+    float acc = 0.f;
+    for (int i = a; i < b; ++i) {
+      int slot = te[i];
+      acc = fmaf(val1[(long)c * bcap * f1 + slot], Tm[((long)c * bcap + slot / f1) * F + k], acc);
+    }
+    o[k] = acc;
+  }
+}
+
+// Bmat[(c,l,j), :] = val0 * [H1full[col0, :] > 0] * Y1[(c,l), :]    (d loss / d pre-activation, per edge)
+__global__ __launch_bounds__(256) void gs_make_bmat_kernel(const int* __restrict__ col0, const float* __restrict__ val0,
+                                                           const int* __restrict__ n1, int cap1, int f2,
+                                                           const float* __restrict__ H1full, long ldh,
+                                                           const float* __restrict__ Y1, int F, float* __restrict__ Bmat,
+                                                           int* __restrict__ kcount, int nclass) {
+  const int lane = threadIdx.x & 63;
+  const long ge = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;     // (c, l, j)
+  if (ge >= (long)nclass * cap1 * f2) return;
+  const long grow = ge / f2;
+  const int c = (int)(grow / cap1), l = (int)(grow - (long)c * cap1);
+  if (ge == (long)c * cap1 * f2 && lane == 0) kcount[c] = n1[c] * f2;
+  if (l >= n1[c]) return;     // beyond kcount: never read
+  const float w = val0[ge];
+  const float* h = H1full + (long)col0[ge] * ldh;
+  const float* y = Y1 + grow * F;
+  float* o = Bmat + ge * F;
+  for (int k = lane; k < F; k += 64) o[k] = (h[k] > 0.f) ? w * y[k] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PGE (models/parametrized_adj.py:40-71) with the layer-1 decomposition E1[r,c] = U[c] + V[r] + b0.
+// ------------------------------------------------------------------------------------------------
+// BN-1 batch statistics from U, V alone: mean = mean(U)+mean(V)+b0, var = var(U)+var(V) (biased), fp64.
+__global__ void gs_pge_bn1_stats_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                        const float* __restrict__ b0, int n, int Ph, float* __restrict__ mu1,
+                                        float* __restrict__ is1, float* __restrict__ sumU, float* __restrict__ sumV) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Ph) return;
+  double su = 0, sv = 0;
+  for (int i = 0; i < n; ++i) {
+    su += U[(long)i * Ph + k];
+    sv += V[(long)i * Ph + k];
+  }
+  const double mu = su / n, mv = sv / n;
+  double vu = 0, vv = 0;
+  for (int i = 0; i < n; ++i) {
+    double a = U[(long)i * Ph + k] - mu, b = V[(long)i * Ph + k] - mv;
+    vu += a * a;
+    vv += b * b;
+  }
+  mu1[k] = (float)(mu + mv + (double)b0[k]);
+  is1[k] = (float)(1.0 / sqrt(vu / n + vv / n + 1e-5));
+  sumU[k] = (float)su;
+  sumV[k] = (float)sv;
+}
+
+// A1[(r,c), k] = relu(g1 * (U[c,k] + V[r,k] + b0 - mu1) * is1 + be1)
+__global__ void gs_pge_make_a1_kernel(const float* __restrict__ U, const float* __restrict__ V, const float* __restrict__ b0,
+                                      const float* __restrict__ mu1, const float* __restrict__ is1,
+                                      const float* __restrict__ g1, const float* __restrict__ be1, int n, int Ph,
+                                      float* __restrict__ A1) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * n * Ph) return;
+  const int k = (int)(idx % Ph);
+  const long pair = idx / Ph;
+  const int r = (int)(pair / n), c = (int)(pair - (long)r * n);
+  float x = (U[(long)c * Ph + k] + V[(long)r * Ph + k] + b0[k] - mu1[k]) * is1[k];
+  A1[idx] = fmaxf(fmaf(g1[k], x, be1[k]), 0.f);
+}
+
+// column sums of up to two per-element functions over a tall matrix, fp64 partials:
+// part[blk][0][k] = sum_rows f0, part[blk][1][k] = sum_rows f1.   mode 0: (x, x*x)  [BN-2 statistics]
+__global__ __launch_bounds__(256) void gs_col_stats_kernel(const float* __restrict__ E, long rows, int Ph, int rows_per_block,
+                                                           double* __restrict__ part) {
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int k = threadIdx.x; k < Ph; k += 256) {
+    double s = 0, s2 = 0;
+    for (long r = r0; r < r1; ++r) {
+      double x = E[r * Ph + k];
+      s += x;
+      s2 += x * x;
+    }
+    part[((long)blockIdx.x * 2 + 0) * Ph + k] = s;
+    part[((long)blockIdx.x * 2 + 1) * Ph + k] = s2;
+  }
+}
+__global__ void gs_bn2_finalize_kernel(const double* __restrict__ part, int nblk, long rows, int Ph, float* __restrict__ mu2,
+                                       float* __restrict__ is2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Ph) return;
+  double s = 0, s2 = 0;
+  for (int b = 0; b < nblk; ++b) {
+    s += part[((long)b * 2 + 0) * Ph + k];
+    s2 += part[((long)b * 2 + 1) * Ph + k];
+  }
+  double m = s / rows, v = s2 / rows - m * m;
+  if (v < 0) v = 0;
+  mu2[k] = (float)m;
+  is2[k] = (float)(1.0 / sqrt(v + 1e-5));
+}
+
+// e3[row] = sum_k relu(g2*(E2-mu2)*is2+be2) * w2[k] + b2      (one wave per pair)
+__global__ __launch_bounds__(256) void gs_pge_layer3_kernel(const float* __restrict__ E2, const float* __restrict__ mu2,
+                                                            const float* __restrict__ is2, const float* __restrict__ g2,
+                                                            const float* __restrict__ be2, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, long rows, int Ph,
+                                                            float* __restrict__ e3) {
+  const int lane = threadIdx.x & 63;
+  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int k = lane; k < Ph; k += 64) {
+    float y = fmaf(g2[k], (E2[row * Ph + k] - mu2[k]) * is2[k], be2[k]);
+    s = fmaf(fmaxf(y, 0.f), w2[k], s);
+  }
+  s = gs_wave_sum(s);
+  if (lane == 0) e3[row] = s + b2[0];
+}
+
+// adj[r,c] = sigmoid((e3[r,c] + e3[c,r]) / 2), zero diagonal     (parametrized_adj.py:66-70)
+__global__ void gs_pge_adj_kernel(const float* __restrict__ e3, int n, float* __restrict__ adj) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * n) return;
+  const int r = (int)(idx / n), c = (int)(idx - (long)r * n);
+  float x = 0.5f * (e3[idx] + e3[(long)c * n + r]);
+  adj[idx] = (r == c) ? 0.f : 1.f / (1.f + expf(-x));
+}
+
+// de3[r,c] = (g(r,c) + g(c,r)) / 2,  g = d_adj * a (1 - a) off the diagonal, 0 on it
+__global__ void gs_pge_adj_bwd_kernel(const float* __restrict__ d_adj, const float* __restrict__ adj, int n,
+                                      float* __restrict__ de3) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * n) return;
+  const int r = (int)(idx / n), c = (int)(idx - (long)r * n);
+  if (r == c) { de3[idx] = 0.f; return; }
+  const long t = (long)c * n + r;
+  float a = adj[idx], b = adj[t];
+  de3[idx] = 0.5f * (d_adj[idx] * a * (1.f - a) + d_adj[t] * b * (1.f - b));
+}
+
+// layer-3 / BN-2 backward statistics (fp64 partials per block of rows):
+// part[blk][0][k] = sum de3*A2 (-> dw2), [1] = sum dy2 (-> d beta2), [2] = sum dy2*xh2 (-> d gamma2),
+// dy2 = de3 * w2[k] * [y2 > 0]
+__global__ __launch_bounds__(256) void gs_pge_l3_bwd_stats_kernel(const float* __restrict__ E2, const float* __restrict__ de3,
+                                                                  const float* __restrict__ mu2, const float* __restrict__ is2,
+                                                                  const float* __restrict__ g2, const float* __restrict__ be2,
+                                                                  const float* __restrict__ w2, long rows, int Ph,
+                                                                  int rows_per_block, double* __restrict__ part) {
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int k = threadIdx.x; k < Ph; k += 256) {
+    double sw = 0, sb = 0, sg = 0;
+    const float m = mu2[k], is = is2[k], g = g2[k], be = be2[k], w = w2[k];
+    for (long r = r0; r < r1; ++r) {
+      float xh = (E2[r * Ph + k] - m) * is;
+      float y = fmaf(g, xh, be);
+      float d = de3[r];
+      if (y > 0.f) {
+        sw += (double)(d * y);
+        float dy = d * w;
+        sb += dy;
+        sg += (double)(dy * xh);
+      }
+    }
+    part[((long)blockIdx.x * 3 + 0) * Ph + k] = sw;
+    part[((long)blockIdx.x * 3 + 1) * Ph + k] = sb;
+    part[((long)blockIdx.x * 3 + 2) * Ph + k] = sg;
+  }
+}
+__global__ void gs_sum_parts_kernel(const double* __restrict__ part, int nblk, int nq, int Ph, float* __restrict__ out0,
+                                    float* __restrict__ out1, float* __restrict__ out2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Ph) return;
+  for (int q = 0; q < nq; ++q) {
+    double s = 0;
+    for (int b = 0; b < nblk; ++b) s += part[((long)b * nq + q) * Ph + k];
+    float* o = q == 0 ? out0 : (q == 1 ? out1 : out2);
+    if (o) o[k] = (float)s;
+  }
+}
+// dE2[row,k] = g2*is2 * (dy2 - dbe2/N - xh2*dg2/N)
+__global__ void gs_pge_bn2_bwd_kernel(const float* __restrict__ E2, const float* __restrict__ de3, const float* __restrict__ mu2,
+                                      const float* __restrict__ is2, const float* __restrict__ g2, const float* __restrict__ be2,
+                                      const float* __restrict__ w2, const float* __restrict__ dbe2,
+                                      const float* __restrict__ dg2, long rows, int Ph, float* __restrict__ dE2) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * Ph) return;
+  const int k = (int)(idx % Ph);
+  const long r = idx / Ph;
+  float xh = (E2[idx] - mu2[k]) * is2[k];
+  float y = fmaf(g2[k], xh, be2[k]);
+  float dy = y > 0.f ? de3[r] * w2[k] : 0.f;
+  float invN = 1.f / (float)rows;
+  dE2[idx] = g2[k] * is2[k] * (dy - dbe2[k] * invN - xh * dg2[k] * invN);
+}
+
+// marginal sums of dY1 [(r,c), k]:  colsum_r[r,k] = sum_c,  rowsum_c[c,k] = sum_r
+__global__ __launch_bounds__(256) void gs_pge_marginal_r_kernel(const float* __restrict__ dY1, int n, int Ph,
+                                                                float* __restrict__ colsum_r) {
+  const int r = blockIdx.x;
+  for (int k = threadIdx.x; k < Ph; k += 256) {
+    float s = 0.f;
+    for (int c = 0; c < n; ++c) s += dY1[((long)r * n + c) * Ph + k];
+    colsum_r[(long)r * Ph + k] = s;
+  }
+}
+__global__ __launch_bounds__(256) void gs_pge_marginal_c_kernel(const float* __restrict__ dY1, int n, int Ph,
+                                                                float* __restrict__ rowsum_c) {
+  const int c = blockIdx.x;
+  for (int k = threadIdx.x; k < Ph; k += 256) {
+    float s = 0.f;
+    for (int r = 0; r < n; ++r) s += dY1[((long)r * n + c) * Ph + k];
+    rowsum_c[(long)c * Ph + k] = s;
+  }
+}
+// BN-1 backward from the marginals: one thread per column k, then dU, dV (see oracle/analytic.py:pge_bwd)
+__global__ void gs_pge_bn1_bwd_cols_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                           const float* __restrict__ rowsum_c, const float* __restrict__ colsum_r,
+                                           const float* __restrict__ b0, const float* __restrict__ mu1,
+                                           const float* __restrict__ is1, int n, int Ph, float* __restrict__ dg1,
+                                           float* __restrict__ dbe1) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Ph) return;
+  double sb = 0, su = 0, sv = 0;
+  for (int i = 0; i < n; ++i) {
+    float rc = rowsum_c[(long)i * Ph + k];
+    sb += rc;
+    su += (double)U[(long)i * Ph + k] * rc;
+    sv += (double)V[(long)i * Ph + k] * colsum_r[(long)i * Ph + k];
+  }
+  dbe1[k] = (float)sb;
+  dg1[k] = (float)((su + sv + ((double)b0[k] - (double)mu1[k]) * sb) * (double)is1[k]);
+}
+__global__ void gs_pge_bn1_bwd_uv_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                         const float* __restrict__ rowsum_c, const float* __restrict__ colsum_r,
+                                         const float* __restrict__ b0, const float* __restrict__ mu1,
+                                         const float* __restrict__ is1, const float* __restrict__ g1,
+                                         const float* __restrict__ sumU, const float* __restrict__ sumV,
+                                         const float* __restrict__ dg1, const float* __restrict__ dbe1, int n, int Ph,
+                                         float* __restrict__ dU, float* __restrict__ dV) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * Ph) return;
+  const int k = (int)(idx % Ph);
+  const float N = (float)n * (float)n;
+  const float kk = g1[k] * is1[k];
+  const float sh = (float)n * (b0[k] - mu1[k]);
+  const float xr = ((float)n * U[idx] + sumV[k] + sh) * is1[k];   // sum over r of xhat[r, c]
+  const float xc = ((float)n * V[idx] + sumU[k] + sh) * is1[k];   // sum over c of xhat[r, c]
+  dU[idx] = kk * (rowsum_c[idx] - (float)n * dbe1[k] / N - xr * dg1[k] / N);
+  dV[idx] = kk * (colsum_r[idx] - (float)n * dbe1[k] / N - xc * dg1[k] / N);
+}
+__global__ void gs_colsum_small_kernel(const float* __restrict__ M, int rows, int cols, float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cols) return;
+  double s = 0;
+  for (int i = 0; i < rows; ++i) s += M[(long)i * cols + k];
+  out[k] = (float)s;
+}
+__global__ void gs_fill_kernel(float* __restrict__ p, long n, float v) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void gs_fill_int_kernel(int* __restrict__ p, long n, int v) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}

@@ -1,0 +1,242 @@
+// Class-wise two-hop neighbour sampler, all classes in one launch pair.
+// Replaces dataset/loader.py:187-224 (np.random.permutation seeds + PyG NeighborSampler ->
+// torch_sparse.sample_adj on the CPU, followed by a per-class H2D copy, gcond_base.py:212-213).
+//
+// Kernel 1 (one workgroup per class): draw the seeds (Floyd's algorithm over the class pool), sample
+// <= f1 neighbours per seed without replacement, de-duplicate the frontier with a global marker
+// array (first occurrence in edge-slot order wins -> deterministic local ids, seeds first), and build
+// the CSC of the hop-1 block (used by the transposed product in the real-side backward).
+// Kernel 2 (one thread per frontier node): sample <= f2 neighbours; sources stay global ids, because
+// the outermost hop only ever indexes X (or relu(XW1+b1)) rows — no relabel, no second de-dup.
+// Randomness: counter-based hash keyed by (seed, step, class, row, draw): replayable, order-free.
+#include "gs_common.h"
+
+#define GS_MAX_BCAP 256
+#define GS_MAX_F 16
+#define GS_MARK_FREE 0x7fffffff
+#define GS_MARK_BIAS 0x40000000
+
+__device__ __forceinline__ int mk_load(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mk_store(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ int block_excl_scan_256(int v, int* s_tmp, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) s_tmp[w] = x;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += s_tmp[i];
+  *total = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+  __syncthreads();
+  return base + x - v;
+}
+
+// sample k = min(deg, f) distinct offsets in [0, deg) into sel[0..k); returns k.  sel lives in LDS.
+__device__ __forceinline__ int sample_row(int deg, int f, int* sel, uint64_t seed, uint32_t a, uint32_t b) {
+  if (deg <= f) {
+    for (int j = 0; j < deg; ++j) sel[j] = j;
+    return deg;
+  }
+  int ns = 0;
+  for (int j = deg - f; j < deg; ++j) {   // Floyd: uniform f-subset of [0, deg)
+    int t = (int)gs_rand_below(seed, a, b, (uint32_t)ns, (uint32_t)(j + 1));
+    bool found = false;
+    for (int q = 0; q < ns; ++q) found |= (sel[q] == t);
+    sel[ns++] = found ? j : t;
+  }
+  return f;
+}
+
+__global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                             const float* __restrict__ val, int n_nodes,
+                                                             const int* __restrict__ cls_ptr,
+                                                             const int* __restrict__ cls_nodes, int* marker,
+                                                             gs_blocks blk, uint64_t seed, uint32_t step) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int bcap = blk.bcap, f1 = blk.f1, cap1 = blk.cap1;
+  const int* pool = cls_nodes + cls_ptr[c];
+  const int npool = cls_ptr[c + 1] - cls_ptr[c];
+  const int B = min(bcap, npool);
+  int* mk = marker + (long)c * n_nodes;
+
+  __shared__ int s_g[GS_MAX_BCAP * GS_MAX_F];          // global id per hop-1 edge slot (-1 = padding)
+  __shared__ int s_sel[GS_MAX_BCAP * GS_MAX_F];        // per-thread Floyd scratch
+  __shared__ int s_cnt[GS_MAX_BCAP * (GS_MAX_F + 1) + 1];
+  __shared__ int s_seed[GS_MAX_BCAP];
+  __shared__ int s_hash[1024];
+  __shared__ int s_tmp[4];
+
+  // ---- seeds: B distinct pool entries (loader.py:222: np.random.permutation(pool)[:num]) ----------
+  if (npool <= bcap) {
+    if (tid < B) s_seed[tid] = pool[tid];
+  } else {
+    for (int i = tid; i < 1024; i += 256) s_hash[i] = -1;
+    __syncthreads();
+    if (tid == 0) {
+      int ns = 0;
+      for (int j = npool - B; j < npool; ++j) {
+        int t = (int)gs_rand_below(seed ^ 0x5eedull, step, (uint32_t)c, (uint32_t)ns, (uint32_t)(j + 1));
+        // membership test in an open-addressing set
+        int h = (int)((uint32_t)t * 2654435761u >> 22);
+        bool found = false;
+        while (s_hash[h] != -1) {
+          if (s_hash[h] == t) { found = true; break; }
+          h = (h + 1) & 1023;
+        }
+        int pick = found ? j : t;
+        h = (int)((uint32_t)pick * 2654435761u >> 22);
+        while (s_hash[h] != -1) h = (h + 1) & 1023;
+        s_hash[h] = pick;
+        s_seed[ns++] = pool[pick];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- hop 1: thread b samples the neighbours of seed b ------------------------------------------
+  int k = 0, e0 = 0, v = 0;
+  if (tid < B) {
+    v = s_seed[tid];
+    e0 = rowptr[v];
+    int deg = rowptr[v + 1] - e0;
+    k = sample_row(deg, f1, s_sel + tid * GS_MAX_F, seed ^ 0x1111ull, step, (uint32_t)(c * GS_MAX_BCAP + tid));
+    mk_store(&mk[v], tid - GS_MARK_BIAS);          // seeds take local ids 0..B-1
+    blk.nid1[(long)c * cap1 + tid] = v;
+  }
+  for (int j = 0; j < f1; ++j) {
+    long slot = ((long)c * bcap + tid) * f1 + j;
+    if (tid < B && j < k) {
+      int e = e0 + s_sel[tid * GS_MAX_F + j];
+      s_g[tid * GS_MAX_F + j] = col[e];
+      blk.val1[slot] = val[e];
+    } else if (tid < bcap) {
+      if (tid < GS_MAX_BCAP) s_g[tid * GS_MAX_F + j] = -1;
+      blk.val1[slot] = 0.f;
+      blk.col1[slot] = 0;
+    }
+  }
+  __syncthreads();
+  // first occurrence (lowest edge-slot id) of every non-seed node
+  for (int j = 0; j < k; ++j) atomicMin(&mk[s_g[tid * GS_MAX_F + j]], tid * f1 + j);
+  __syncthreads();
+  int nfirst = 0;
+  for (int j = 0; j < k; ++j) nfirst += (mk_load(&mk[s_g[tid * GS_MAX_F + j]]) == tid * f1 + j);
+  int total_new = 0;
+  int base = block_excl_scan_256(nfirst, s_tmp, &total_new);
+  {
+    int run = 0;
+    for (int j = 0; j < k; ++j) {
+      int g = s_g[tid * GS_MAX_F + j];
+      if (mk_load(&mk[g]) == tid * f1 + j) {
+        int lid = B + base + run++;
+        blk.nid1[(long)c * cap1 + lid] = g;
+        mk_store(&mk[g], lid - GS_MARK_BIAS);
+      }
+    }
+  }
+  __syncthreads();
+  const int n1 = B + total_new;
+  for (int i = tid; i <= cap1; i += 256) s_cnt[i] = 0;
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {
+    int lid = mk_load(&mk[s_g[tid * GS_MAX_F + j]]) + GS_MARK_BIAS;
+    blk.col1[((long)c * bcap + tid) * f1 + j] = lid;
+    s_g[tid * GS_MAX_F + j] = lid | (s_g[tid * GS_MAX_F + j] << 0) * 0;   // keep lid only (global id no longer needed)
+    atomicAdd(&s_cnt[lid], 1);
+  }
+  __syncthreads();
+  // ---- restore the marker (every touched entry back to FREE) --------------------------------------
+  if (tid < B) mk_store(&mk[v], GS_MARK_FREE);
+  for (int i = B + tid; i < n1; i += 256) mk_store(&mk[blk.nid1[(long)c * cap1 + i]], GS_MARK_FREE);
+
+  // ---- CSC of the hop-1 block: exclusive scan of in-degrees, fill, sort each list ----------------
+  const int per = (cap1 + 1 + 255) / 256;
+  int lo = tid * per, hi = min(lo + per, cap1 + 1), lsum = 0;
+  for (int i = lo; i < hi; ++i) lsum += s_cnt[i];
+  int tot = 0;
+  int off = block_excl_scan_256(lsum, s_tmp, &tot);
+  int* tptr = blk.tptr1 + (long)c * (cap1 + 1);
+  int* tedge = blk.tedge1 + (long)c * bcap * f1;
+  for (int i = lo; i < hi; ++i) {
+    int cnt = s_cnt[i];
+    tptr[i] = off;
+    s_cnt[i] = off;     // becomes the fill cursor
+    off += cnt;
+  }
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {
+    int lid = s_g[tid * GS_MAX_F + j];
+    int pos = atomicAdd(&s_cnt[lid], 1);
+    tedge[pos] = tid * f1 + j;
+  }
+  __syncthreads();
+  __threadfence_block();
+  for (int l = tid; l < n1; l += 256) {   // ascending edge-slot order -> deterministic summation order
+    int a = tptr[l], b = (l + 1 <= cap1) ? s_cnt[l] : a;   // s_cnt[l] == end of list l after the fill
+    for (int i = a + 1; i < b; ++i) {
+      int x = tedge[i], q = i - 1;
+      while (q >= a && tedge[q] > x) { tedge[q + 1] = tedge[q]; --q; }
+      tedge[q + 1] = x;
+    }
+  }
+  if (tid == 0) {
+    blk.n_seed[c] = B;
+    blk.n1[c] = n1;
+  }
+}
+
+__global__ __launch_bounds__(256) void gs_sample_hop2_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                             const float* __restrict__ val, gs_blocks blk, uint64_t seed,
+                                                             uint32_t step) {
+  const int c = blockIdx.y, tid = threadIdx.x;
+  const int l = blockIdx.x * 256 + tid;
+  const int f2 = blk.f2, cap1 = blk.cap1;
+  __shared__ int s_sel[256 * GS_MAX_F];
+  if (l >= cap1) return;
+  const long base = ((long)c * cap1 + l) * f2;
+  if (l >= blk.n1[c]) {
+    for (int j = 0; j < f2; ++j) { blk.col0[base + j] = 0; blk.val0[base + j] = 0.f; }
+    return;
+  }
+  const int v = blk.nid1[(long)c * cap1 + l];
+  const int e0 = rowptr[v], deg = rowptr[v + 1] - e0;
+  const int k = sample_row(deg, f2, s_sel + tid * GS_MAX_F, seed ^ 0x2222ull, step, (uint32_t)(c * 65536 + l));
+  for (int j = 0; j < f2; ++j) {
+    if (j < k) {
+      int e = e0 + s_sel[tid * GS_MAX_F + j];
+      blk.col0[base + j] = col[e];
+      blk.val0[base + j] = val[e];
+    } else {
+      blk.col0[base + j] = 0;
+      blk.val0[base + j] = 0.f;
+    }
+  }
+}
+
+extern "C" int gs_sample_blocks(const int* rowptr, const int* col, const float* val, int n_nodes, const int* cls_ptr,
+                                const int* cls_nodes, int* marker, const gs_blocks* out, uint64_t seed, uint32_t step,
+                                gs_stream_t stream) {
+  if (!rowptr || !col || !val || !cls_ptr || !cls_nodes || !marker || !out) GS_FAIL(GS_ERR_ARG, "gs_sample_blocks: null pointer");
+  const gs_blocks& b = *out;
+  if (b.bcap < 1 || b.bcap > GS_MAX_BCAP) GS_FAIL(GS_ERR_ARG, "gs_sample_blocks: bcap must be in [1, %d]", GS_MAX_BCAP);
+  if (b.f1 < 1 || b.f1 > GS_MAX_F || b.f2 < 1 || b.f2 > GS_MAX_F)
+    GS_FAIL(GS_ERR_ARG, "gs_sample_blocks: fan-outs must be in [1, %d]", GS_MAX_F);
+  if (b.cap1 != b.bcap * (1 + b.f1)) GS_FAIL(GS_ERR_ARG, "gs_sample_blocks: cap1 must equal bcap*(1+f1)");
+  if (b.C < 1) return GS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gs_sample_hop1_kernel, dim3(b.C), dim3(256), 0, s, rowptr, col, val, n_nodes, cls_ptr, cls_nodes,
+                     marker, b, seed, step);
+  hipLaunchKernelGGL(gs_sample_hop2_kernel, dim3(gs_cdiv(b.cap1, 256), b.C), dim3(256), 0, s, rowptr, col, val, b, seed,
+                     step);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

@@ -1,0 +1,341 @@
+"""Host-side handle of the HIP GCond engine (gs_gcond_* in include/gslim.h).
+
+torch is used only to own device memory and the stream; all arithmetic happens in libgslim_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Blocks, GCondConfig, GCondIO, GemmDesc, check, ptr, stream
+
+METRICS = {"ours": 0, "mse": 1, "cos": 2}
+
+
+# ------------------------------------------------------------------------------------------------
+# thin stateless wrappers (used by the tests and by the evaluation model)
+# ------------------------------------------------------------------------------------------------
+
+
+def gemm(A, B, Cout, M, N, K, sA, sB, ldc, **kw):
+    """C = alpha * A*B (+...) with explicit element strides sA=(sAm,sAk), sB=(sBk,sBn); kw = other desc fields."""
+    d = GemmDesc()
+    d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
+    d.M, d.N, d.K = M, N, K
+    d.sAm, d.sAk = sA
+    d.sBk, d.sBn = sB
+    d.ldc = ldc
+    d.nb1 = d.nb2 = 1
+    d.alpha = 1.0
+    keep = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            v = ptr(v)
+        setattr(d, k, v)
+    check(_lib.lib().gs_gemm_f32(C.byref(d), stream()))
+
+
+def spmm_csr(rowptr, col, val, X, F=None, out=None):
+    n = rowptr.numel() - 1
+    F = X.shape[1] if F is None else F
+    if out is None:
+        out = torch.empty(n, F, device=X.device, dtype=torch.float32)
+    check(_lib.lib().gs_spmm_csr_f32(ptr(rowptr), ptr(col), ptr(val), n, ptr(X), X.stride(0), F, ptr(out), out.stride(0),
+                                     stream()))
+    return out
+
+
+def gather_rows(X, idx, F=None):
+    F = X.shape[1] if F is None else F
+    out = torch.empty(idx.numel(), F, device=X.device, dtype=torch.float32)
+    check(_lib.lib().gs_gather_rows_f32(ptr(X), X.stride(0), ptr(idx), idx.numel(), F, ptr(out), out.stride(0), stream()))
+    return out
+
+
+def dense_gcn_norm_fwd(adj):
+    n = adj.shape[0]
+    out = torch.empty_like(adj)
+    r = torch.empty(2 * n, device=adj.device, dtype=torch.float32)
+    check(_lib.lib().gs_dense_gcn_norm_fwd(ptr(adj), n, ptr(out), ptr(r), stream()))
+    return out, r
+
+
+def dense_gcn_norm_bwd(adj, r, d_adj_norm):
+    n = adj.shape[0]
+    out = torch.empty_like(adj)
+    check(_lib.lib().gs_dense_gcn_norm_bwd(ptr(adj), ptr(r), ptr(d_adj_norm), n, ptr(out), stream()))
+    return out
+
+
+def adam_step(p, g, m, v, lr, step, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+    check(_lib.lib().gs_adam_step_f32(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                                      step, stream()))
+
+
+# ------------------------------------------------------------------------------------------------
+# sampled blocks
+# ------------------------------------------------------------------------------------------------
+
+
+class BlockSet:
+    """Device arrays of a gs_blocks (class-major, fixed capacity)."""
+
+    def __init__(self, nclass, bcap, f1, f2, device):
+        self.C, self.bcap, self.f1, self.f2 = nclass, bcap, f1, f2
+        self.cap1 = bcap * (1 + f1)
+        i32 = dict(device=device, dtype=torch.int32)
+        f32 = dict(device=device, dtype=torch.float32)
+        self.n_seed = torch.zeros(nclass, **i32)
+        self.n1 = torch.zeros(nclass, **i32)
+        self.nid1 = torch.zeros(nclass, self.cap1, **i32)
+        self.col1 = torch.zeros(nclass, bcap, f1, **i32)
+        self.val1 = torch.zeros(nclass, bcap, f1, **f32)
+        self.tptr1 = torch.zeros(nclass, self.cap1 + 1, **i32)
+        self.tedge1 = torch.zeros(nclass, bcap * f1, **i32)
+        self.col0 = torch.zeros(nclass, self.cap1, f2, **i32)
+        self.val0 = torch.zeros(nclass, self.cap1, f2, **f32)
+
+    FIELDS = ("n_seed", "n1", "nid1", "col1", "val1", "tptr1", "tedge1", "col0", "val0")
+
+    def struct(self):
+        b = Blocks()
+        b.C, b.bcap, b.f1, b.f2, b.cap1 = self.C, self.bcap, self.f1, self.f2, self.cap1
+        for f in self.FIELDS:
+            setattr(b, f, ptr(getattr(self, f)))
+        return b
+
+    @classmethod
+    def from_struct(cls, b, device):
+        """Copies of the engine-owned block arrays."""
+        out = cls(b.C, b.bcap, b.f1, b.f2, device)
+        for f in cls.FIELDS:
+            t = getattr(out, f)
+            t.copy_(device_view(getattr(b, f), t.numel(), t.dtype, device).reshape(t.shape))
+        return out
+
+    @classmethod
+    def from_batches(cls, batches, bcap, f1, f2, device):
+        """Parity mode: lay out reference-style batches (batch_size, n_id, [blk0 (n1 x n2), blk1 (B x n1)]) with CSR
+        blocks (rowptr, col, val, shape) into the engine's ELL layout.  Host-side data shuffling only."""
+        ncls = len(batches)
+        out = cls(ncls, bcap, f1, f2, "cpu")
+        for c, (bs, n_id, (blk0, blk1)) in enumerate(batches):
+            rp1, c1, v1, (B, n1) = blk1
+            rp0, c0, v0, (n1b, n2) = blk0
+            assert B == bs and n1b == n1 and B <= bcap and n1 <= out.cap1
+            out.n_seed[c], out.n1[c] = B, n1
+            out.nid1[c, :n1] = torch.from_numpy(np.asarray(n_id[:n1]).astype(np.int32))
+            parents = [[] for _ in range(n1)]
+            for b in range(B):
+                lo, hi = int(rp1[b]), int(rp1[b + 1])
+                assert hi - lo <= f1
+                for j, e in enumerate(range(lo, hi)):
+                    out.col1[c, b, j] = int(c1[e])
+                    out.val1[c, b, j] = float(v1[e])
+                    parents[int(c1[e])].append(b * f1 + j)
+            pos = 0
+            for l in range(n1):
+                out.tptr1[c, l] = pos
+                for s in sorted(parents[l]):
+                    out.tedge1[c, pos] = s
+                    pos += 1
+            out.tptr1[c, n1:] = pos
+            for l in range(n1):
+                lo, hi = int(rp0[l]), int(rp0[l + 1])
+                assert hi - lo <= f2
+                for j, e in enumerate(range(lo, hi)):
+                    out.col0[c, l, j] = int(n_id[int(c0[e])])
+                    out.val0[c, l, j] = float(v0[e])
+        for f in cls.FIELDS:
+            setattr(out, f, getattr(out, f).to(device))
+        return out
+
+
+class _DevArray:
+    """__cuda_array_interface__ carrier so torch can view library-owned device memory without a copy."""
+
+    def __init__(self, p, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(p), False), "version": 2}
+
+
+def device_view(p, count, dtype, device):
+    if count == 0 or not p:
+        return torch.empty(0, dtype=dtype, device=device)
+    typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.float64: "<f8", torch.int64: "<i8"}[dtype]
+    return torch.as_tensor(_DevArray(p, count, typestr), device=device)
+
+
+def sample_blocks(rowptr, col, val, n_nodes, cls_ptr, cls_nodes, marker, blocks: BlockSet, seed: int, step: int):
+    b = blocks.struct()
+    check(_lib.lib().gs_sample_blocks(ptr(rowptr), ptr(col), ptr(val), n_nodes, ptr(cls_ptr), ptr(cls_nodes), ptr(marker),
+                                      C.byref(b), seed, step, stream()))
+
+
+# ------------------------------------------------------------------------------------------------
+# the engine
+# ------------------------------------------------------------------------------------------------
+
+
+@dataclass
+class EngineShapes:
+    n_nodes: int
+    d: int
+    nclass: int
+    n_syn: int
+    ntrans: int
+    hidden: int
+    pge_hidden: int
+    bcap: int = 256
+    f1: int = 10
+    f2: int = 5
+
+
+def model_param_count(d, hidden, nclass, ntrans):
+    return d * nclass + nclass if ntrans == 1 else d * hidden + hidden + hidden * nclass + nclass
+
+
+def pge_param_count(d, ph):
+    return ph * 2 * d + ph + ph * ph + ph + ph + 1 + 4 * ph
+
+
+class GCondEngine:
+    """Owns the device tensors and the gs_gcond handle.  See gs_gcond_* in include/gslim.h."""
+
+    def __init__(self, shapes: EngineShapes, X, csr, cls_ptr, cls_nodes, labels_syn, syn_ranges, *, lr_feat, lr_adj,
+                 lr_model, inner_loop, dis_metric="ours", seed=1, external_blocks=False, device="cuda:0"):
+        if dis_metric not in METRICS:
+            raise SystemExit("DC error: unknown distance function")     # condensation/utils.py:63
+        L = _lib.lib()
+        self.dev = torch.device(device)
+        s = self.shapes = shapes
+        dev = self.dev
+        d = s.d
+        self.ldx = (d + 3) // 4 * 4          # 16-byte aligned feature rows for the gather kernels
+        Xp = torch.zeros(s.n_nodes, self.ldx, dtype=torch.float32, device=dev)
+        Xp[:, :d] = X.to(dev, torch.float32)
+        self.X = Xp
+        i32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int32).to(dev)
+        if csr is not None:
+            rp, col, val = csr
+            self.rowptr, self.col = i32(rp), i32(col)
+            self.val = torch.as_tensor(np.asarray(val), dtype=torch.float32).to(dev)
+            self.cls_ptr, self.cls_nodes = i32(cls_ptr), i32(cls_nodes)
+        else:
+            self.rowptr = self.col = self.val = self.cls_ptr = self.cls_nodes = None
+        self.labels_syn = i32(labels_syn)
+        self.syn_lo = i32([r[0] for r in syn_ranges])
+        self.syn_hi = i32([r[1] for r in syn_ranges])
+        self.P = model_param_count(d, s.hidden, s.nclass, s.ntrans)
+        self.Ppge = pge_param_count(d, s.pge_hidden)
+        self.feat_syn = torch.zeros(s.n_syn, d, dtype=torch.float32, device=dev)
+        self.pge_params = torch.zeros(self.Ppge, dtype=torch.float32, device=dev)
+        self.model_params = torch.zeros(self.P, dtype=torch.float32, device=dev)
+        self.adj_syn = torch.zeros(s.n_syn, s.n_syn, dtype=torch.float32, device=dev)
+        cfg = GCondConfig(s.n_nodes, d, self.ldx, s.nclass, s.n_syn, s.ntrans, s.hidden, s.pge_hidden, s.bcap, s.f1, s.f2,
+                          METRICS[dis_metric], inner_loop, lr_feat, lr_adj, lr_model, seed, 1 if external_blocks else 0)
+        nbytes = C.c_size_t()
+        check(L.gs_gcond_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
+        self.workspace_bytes = nbytes.value
+        self.workspace = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        io = GCondIO(ptr(self.X), ptr(self.rowptr), ptr(self.col), ptr(self.val), ptr(self.cls_ptr), ptr(self.cls_nodes),
+                     ptr(self.labels_syn), ptr(self.syn_lo), ptr(self.syn_hi), ptr(self.feat_syn), ptr(self.pge_params),
+                     ptr(self.model_params), ptr(self.adj_syn), ptr(self.workspace), nbytes.value)
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            check(L.gs_gcond_create(C.byref(cfg), C.byref(io), stream(), C.byref(h)))
+        self.h = h
+        self.L = L
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            try:
+                torch.cuda.synchronize(self.dev)
+            except Exception:
+                pass
+            self.L.gs_gcond_destroy(h)
+            self.h = None
+
+    # ---- parameter packing (nn.Module.parameters() order) ------------------------------------------
+    def set_model(self, params):
+        self.model_params.copy_(torch.cat([p.reshape(-1).float() for p in params]).to(self.dev))
+        check(self.L.gs_gcond_new_epoch(self.h, stream()))
+
+    def get_model(self):
+        s, d = self.shapes, self.shapes.d
+        shp = [(d, s.nclass), (s.nclass,)] if s.ntrans == 1 else [(d, s.hidden), (s.hidden,), (s.hidden, s.nclass), (s.nclass,)]
+        return _split(self.model_params, shp)
+
+    def pge_shapes(self):
+        ph, d = self.shapes.pge_hidden, self.shapes.d
+        return [(ph, 2 * d), (ph,), (ph, ph), (ph,), (1, ph), (1,), (ph,), (ph,), (ph,), (ph,)]
+
+    def set_pge(self, params):
+        self.pge_params.copy_(torch.cat([p.reshape(-1).float() for p in params]).to(self.dev))
+
+    def get_pge(self):
+        return _split(self.pge_params, self.pge_shapes())
+
+    def set_feat(self, x):
+        self.feat_syn.copy_(x.to(self.dev, torch.float32))
+
+    # ---- stages -------------------------------------------------------------------------------------
+    def set_blocks(self, blocks: BlockSet):
+        b = blocks.struct()
+        check(self.L.gs_gcond_set_blocks(self.h, C.byref(b), stream()))
+        self._blocks_keepalive = blocks
+
+    def get_blocks(self) -> BlockSet:
+        b = Blocks()
+        check(self.L.gs_gcond_get_blocks(self.h, C.byref(b)))
+        return BlockSet.from_struct(b, self.dev)
+
+    def stage_sample(self):
+        check(self.L.gs_gcond_stage_sample(self.h, stream()))
+
+    def stage_real_grads(self):
+        check(self.L.gs_gcond_stage_real_grads(self.h, stream()))
+
+    def stage_pge_forward(self, inference=False):
+        check(self.L.gs_gcond_stage_pge_forward(self.h, int(inference), stream()))
+
+    def stage_syn_match(self):
+        check(self.L.gs_gcond_stage_syn_match(self.h, stream()))
+
+    def stage_pge_backward(self, need_param_grads=True, need_feat_grad=True):
+        check(self.L.gs_gcond_stage_pge_backward(self.h, int(need_param_grads), int(need_feat_grad), stream()))
+
+    def stage_update(self, epoch):
+        check(self.L.gs_gcond_stage_update(self.h, epoch, stream()))
+
+    def stage_inner(self):
+        check(self.L.gs_gcond_stage_inner(self.h, stream()))
+
+    def outer_step(self, epoch):
+        check(self.L.gs_gcond_outer_step(self.h, epoch, stream()))
+
+    def read_loss(self):
+        s, k = C.c_double(), C.c_long()
+        check(self.L.gs_gcond_read_loss(self.h, C.byref(s), C.byref(k), stream()))
+        return s.value, k.value
+
+    def buffer(self, name, shape=None):
+        """Copy of a named engine scratch buffer as a CPU tensor (tests)."""
+        p, cnt = C.c_void_p(), C.c_long()
+        check(self.L.gs_gcond_buffer(self.h, name.encode(), C.byref(p), C.byref(cnt)))
+        out = device_view(p.value, cnt.value, torch.float32, self.dev).cpu()
+        return out.reshape(shape) if shape is not None else out
+
+
+def _split(flat, shapes):
+    out, o = [], 0
+    for shp in shapes:
+        n = int(np.prod(shp))
+        out.append(flat[o:o + n].reshape(shp))
+        o += n
+    return out

@@ -1,0 +1,209 @@
+/* libgslim_hip.so — C ABI of the MI355X (gfx950) GCond gradient-matching engine.
+ *
+ * The reference (GraphSlim) is pure Python and has no FFI; its boundary for this path is the Python
+ * method GCond(setting, data, args).reduce(data) (graphslim/condensation/gcond.py:14-18,81).  This
+ * header is the C ABI that graphslim_amd's host-side mirror of that method binds through ctypes
+ * (INTEGRATION.md shows the stub).  Every entry point below names the reference code it replaces.
+ *
+ * Conventions: plain C, no exceptions.  Every function returns GS_OK (0) or a negative error code;
+ * gs_last_error() returns a thread-local message.  All pointers are DEVICE pointers unless a
+ * parameter is documented as host.  The library never allocates, frees or retains caller memory
+ * beyond the call, except gs_gcond_* which borrows the buffers named in gs_gcond_io until
+ * gs_gcond_destroy.  `stream` is a hipStream_t (0 = default stream); calls are asynchronous on it.
+ * Indices are int32, values fp32 (fp32 accumulation; BatchNorm statistics accumulate in fp64).
+ */
+#ifndef GSLIM_H
+#define GSLIM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_OK 0
+#define GS_ERR_ARG (-1)
+#define GS_ERR_HIP (-2)
+#define GS_ERR_STATE (-3)
+#define GS_ERR_UNSUPPORTED (-4)
+
+typedef void* gs_stream_t;
+
+int gs_version(void);
+const char* gs_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense contraction on the matrix cores.  Replaces every ATen GEMM the path issues:
+ * MyLinear `input @ self.weight` (models/layers.py:376), dense `adj @ x` (models/sgc.py:49),
+ * nn.Linear inside PGE (models/parametrized_adj.py:57-64) and their autograd transposes.
+ * C[b] = alpha*A[b]*B[b] (+bias) (relu) (mask) + beta*C[b];  b = b1*nb2 + b2.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gs_gemm_desc {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  long sAm, sAk;         /* A(m,k) = A[m*sAm + k*sAk]  */
+  long sBk, sBn;         /* B(k,n) = B[k*sBk + n*sBn]  */
+  long ldc;              /* C(m,n) = C[m*ldc + n]      */
+  int nb1, nb2;          /* batch counts (>=1)         */
+  long sAb1, sAb2, sBb1, sBb2, sCb1, sCb2;   /* uniform batch strides (elements) */
+  const long* offA;      /* optional [nb1] extra element offsets (grouped GEMM)   */
+  const long* offB;
+  const long* offC;
+  const int* Mb;         /* optional [nb1] per-group M (<= M)  */
+  const int* Kb;         /* optional [nb1] per-group K (<= K)  */
+  const int* gatherA_m;  /* optional row gather:  m -> gatherA_m[m]  (+ b1*sGb1) */
+  const int* gatherA_k;  /* optional:             k -> gatherA_k[k]              */
+  const int* gatherB_k;
+  long sGb1;
+  int kchunk;            /* >0: split K over b2 in chunks of kchunk; C gets nb2 partial slabs (sCb2) */
+  float alpha, beta;
+  const float* bias;     /* optional [N] (+ b1*sbias_b1), added before relu/mask */
+  long sbias_b1;
+  int relu;
+  const float* mask;     /* optional [M][ldmask]: output kept where mask > 0 else 0 (ReLU backward) */
+  long ldmask;
+} gs_gemm_desc;
+
+int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream);
+
+/* out[i] = beta*out[i] + sum_s slabs[s*slab_stride + i]  (fixed order: bitwise reproducible). */
+int gs_reduce_slabs_f32(float* out, const float* slabs, long n, int n_slabs, long slab_stride, float beta,
+                        gs_stream_t stream);
+/* batched form: out[b*out_stride + i] = beta*out[..] + sum_s slabs[(b*n_slabs + s)*slab_stride + i] */
+int gs_reduce_slabs_batched_f32(float* out, long out_stride, const float* slabs, long n, int n_slabs, long slab_stride,
+                                int nbatch, float beta, gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sparse aggregation.  Replaces torch_sparse.matmul / SparseTensor @ dense (spmm_sum; call sites
+ * models/sgc.py:47,51, models/layers.py:41, models/base.py:55,63).
+ * Y[i,:] = sum_{e in row i} val[e] * X[col[e],:]   — CSR, wave-per-row gather, fp32.
+ * The transposed product (autograd of spmm) is the same call on the CSR of A^T, which the host builds
+ * once (the graph is static) exactly as torch_sparse pre-computes its csr2csc permutation.
+ * ------------------------------------------------------------------------------------------- */
+int gs_spmm_csr_f32(const int* rowptr, const int* col, const float* val, int n_rows, const float* X, long ldx, int F,
+                    float* Y, long ldy, gs_stream_t stream);
+
+/* out[i,:] = X[idx[i],:]  — `features[n_id]` (condensation/gcond_base.py:214). */
+int gs_gather_rows_f32(const float* X, long ldx, const int* idx, int n, int F, float* out, long ldo, gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Class-wise neighbour-sampled blocks.  Replaces TransAndInd.retrieve_class_sampler
+ * (dataset/loader.py:187-224 -> PyG NeighborSampler -> torch_sparse sample_adj, CPU) for ALL classes
+ * in one call: per class up to `bcap` seeds drawn without replacement from the class pool, hop 1 keeps
+ * <= f1 neighbours per seed, the de-duplicated frontier (seeds first) keeps <= f2 neighbours per node;
+ * edge values are the full-graph normalised weights.  Layout: class-major, fixed capacity, padded
+ * entries carry val = 0 and index 0.  Outermost-hop sources stay GLOBAL ids (they index X directly).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gs_blocks {
+  int C, bcap, f1, f2, cap1;   /* cap1 = bcap*(1+f1) */
+  int* n_seed;     /* [C]                 seeds actually drawn (min(bcap, pool size))            */
+  int* n1;         /* [C]                 frontier size, seeds first                              */
+  int* nid1;       /* [C][cap1]           global id of frontier node l (l < n_seed: the seeds)    */
+  int* col1;       /* [C][bcap][f1]       hop-1 block (seed b <- frontier l): local frontier ids  */
+  float* val1;     /* [C][bcap][f1]                                                               */
+  int* tptr1;      /* [C][cap1+1]         CSC of the hop-1 block: in-edges of frontier node l ... */
+  int* tedge1;     /* [C][bcap*f1]        ... are slots tedge1[tptr1[l] .. tptr1[l+1]), ascending */
+  int* col0;       /* [C][cap1][f2]       hop-2 block (frontier l <- source): GLOBAL node ids     */
+  float* val0;     /* [C][cap1][f2]                                                               */
+} gs_blocks;
+
+/* marker: [C * n_nodes] int32 scratch that must hold 0x7fffffff on entry; restored on exit. */
+int gs_sample_blocks(const int* rowptr, const int* col, const float* val, int n_nodes, const int* cls_ptr,
+                     const int* cls_nodes, int* marker, const gs_blocks* out, uint64_t seed, uint32_t step,
+                     gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * dense_gcn_norm forward / backward (graphslim/utils.py:429-439 and its autograd).
+ * fwd: A^ = D^-1/2 (adj + I) D^-1/2 with row-sum degrees; r_out has 2n floats: [0,n) keeps deg^-1/2,
+ *      [n,2n) is scratch for the backward pass.
+ * bwd: d adj from d A^.
+ * ------------------------------------------------------------------------------------------- */
+int gs_dense_gcn_norm_fwd(const float* adj, int n, float* adj_norm, float* r_out, gs_stream_t stream);
+int gs_dense_gcn_norm_bwd(const float* adj, const float* r, const float* d_adj_norm, int n, float* d_adj,
+                          gs_stream_t stream);
+
+/* Fused multi-tensor Adam, torch.optim.Adam defaults (gcond_base.py:68-69, gcond.py:44,54-72).
+ * step = 1-based step count after this update. */
+int gs_adam_step_f32(float* param, const float* grad, float* m, float* v, long n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The GCond engine: one object per GPU holding the learnable synthetic graph (X~, PGE), the
+ * per-epoch SGC model and all scratch.  One gs_gcond_outer_step == one iteration of the loop body
+ * condensation/gcond.py:47-72 (PGE forward + dense_gcn_norm, train_class over all classes
+ * (gcond_base.py:156-241) with match_loss (condensation/utils.py:12-106), the second-order backward
+ * into X~ and the PGE parameters, one Adam step on PGE (epoch % 50 < 10) or X~, PGE.inference, and
+ * `inner_loop` SGC steps on (X~, A^)).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gs_gcond_config {
+  int n_nodes, d, ldx;     /* real graph: X is [n_nodes][ldx], ldx >= d                      */
+  int nclass, n_syn;
+  int ntrans;              /* SGC transforms T: 1 or 2 (models/sgc.py:22-35)                   */
+  int hidden;              /* SGC hidden width for T = 2                                       */
+  int pge_hidden;          /* parametrized_adj.py:9-17                                         */
+  int bcap, f1, f2;        /* loader.py:187,197-210: 256 seeds, fan-outs (f1 from seeds)       */
+  int dis_metric;          /* 0 = ours, 1 = mse, 2 = cos (condensation/utils.py:33-63)         */
+  int inner_loop;
+  float lr_feat, lr_adj, lr_model;
+  uint64_t seed;
+  int external_blocks;     /* 1: blocks are supplied with gs_gcond_set_blocks (parity mode)    */
+} gs_gcond_config;
+
+typedef struct gs_gcond_io {
+  const float* X;          /* [n_nodes][ldx]                                                   */
+  const int* rowptr;       /* normalised adjacency CSR (utils.py:403-413), [n_nodes+1]         */
+  const int* col;
+  const float* val;
+  const int* cls_ptr;      /* [nclass+1] seed pools per class (loader.py:188-195)              */
+  const int* cls_nodes;
+  const int* labels_syn;   /* [n_syn] int32, grouped by class (gcond_base.py:93-111)           */
+  const int* syn_lo;       /* [nclass] first row of class c in labels_syn                      */
+  const int* syn_hi;       /* [nclass] one past the last row                                   */
+  float* feat_syn;         /* [n_syn][d]   learnable X~                                        */
+  float* pge_params;       /* flat, nn.Module.parameters() order: W0[Ph][2d] b0[Ph] W1[Ph][Ph] b1[Ph]
+                              w2[Ph] b2[1] bn1.weight[Ph] bn1.bias[Ph] bn2.weight[Ph] bn2.bias[Ph] */
+  float* model_params;     /* flat: T=1: W[d][C] b[C];  T=2: W1[d][h] b1[h] W2[h][C] b2[C]      */
+  float* adj_syn;          /* [n_syn][n_syn] raw PGE output of the last inference pass (gcond.py:64,77) */
+  void* workspace;
+  size_t workspace_bytes;  /* >= gs_gcond_workspace_bytes(cfg)                                 */
+} gs_gcond_io;
+
+typedef struct gs_gcond gs_gcond;
+
+int gs_gcond_workspace_bytes(const gs_gcond_config* cfg, size_t* bytes);
+int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io, gs_stream_t stream, gs_gcond** out);
+void gs_gcond_destroy(gs_gcond* e);
+
+/* gcond.py:42-45: call after writing fresh theta into io.model_params; resets the model's Adam state. */
+int gs_gcond_new_epoch(gs_gcond* e, gs_stream_t stream);
+/* Parity mode: adopt caller-built blocks (same layout as gs_sample_blocks writes). */
+int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* blocks, gs_stream_t stream);
+/* One outer-loop iteration; adds the matching loss to the device-side accumulator. */
+int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream);
+/* Synchronises `stream`; returns the accumulated loss and the outer-step count since the last reset
+ * (host pointers) and resets both.  This is the loss_avg bookkeeping of gcond.py:52,74. */
+int gs_gcond_read_loss(gs_gcond* e, double* loss_sum, long* steps, gs_stream_t stream);
+
+/* Stage-level entry points (what gs_gcond_outer_step runs, in this order); exposed so that each
+ * stage can be checked against the oracle in isolation. */
+int gs_gcond_stage_sample(gs_gcond* e, gs_stream_t stream);
+int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream);
+int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_t stream);
+int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream);
+int gs_gcond_stage_pge_backward(gs_gcond* e, int need_param_grads, int need_feat_grad, gs_stream_t stream);
+int gs_gcond_stage_update(gs_gcond* e, int epoch, gs_stream_t stream);
+int gs_gcond_stage_inner(gs_gcond* e, gs_stream_t stream);
+
+/* Named views into engine-owned scratch for the parity tests (device pointer + element count):
+ * "gw_real" [C][|theta|], "gw_syn" [C][|theta|], "loss" [1], "d_feat" [n'][d] (total gradient wrt X~),
+ * "d_feat_direct", "d_adj_norm" [n'][n'], "d_adj" [n'][n'], "d_pge" [|theta_pge|], "adj_norm", "adj_raw",
+ * "blocks" (gs_blocks struct copied to *ptr as host struct is NOT supported — use gs_gcond_get_blocks). */
+int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* count);
+int gs_gcond_get_blocks(gs_gcond* e, gs_blocks* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSLIM_H */

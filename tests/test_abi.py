@@ -1,0 +1,65 @@
+"""CPU-side checks of the C ABI: the library loads and exports every symbol include/gslim.h declares, struct
+layouts match, and argument validation works without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from graphslim_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "graphslim_amd", "csrc"), "-j4"], check=True)
+    return _lib.lib()
+
+
+def test_header_symbols_are_exported(L):
+    from graphslim_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "gslim.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(gs_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.gs_version() >= 100
+
+
+def test_struct_layouts_match_the_header(L):
+    """sizeof as seen by gcc on include/gslim.h must equal the ctypes mirrors."""
+    from graphslim_amd import _lib
+    src = '#include "gslim.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu\\n",sizeof(gs_gemm_desc),' \
+          'sizeof(gs_blocks),sizeof(gs_gcond_config),sizeof(gs_gcond_io));return 0;}'
+    exe = "/tmp/gs_sizes"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    sizes = [int(v) for v in subprocess.run([exe], capture_output=True, check=True).stdout.split()]
+    assert sizes == [C.sizeof(_lib.GemmDesc), C.sizeof(_lib.Blocks), C.sizeof(_lib.GCondConfig), C.sizeof(_lib.GCondIO)]
+
+
+def test_argument_validation_without_gpu(L):
+    from graphslim_amd import _lib
+    cfg = _lib.GCondConfig(100, 8, 8, 3, 9, 3, 16, 16, 256, 10, 5, 0, 1, 0.01, 0.01, 0.01, 1, 0)
+    n = C.c_size_t()
+    assert L.gs_gcond_workspace_bytes(C.byref(cfg), C.byref(n)) == -4          # ntrans = 3 unsupported
+    assert b"ntrans" in L.gs_last_error()
+    cfg.ntrans = 2
+    assert L.gs_gcond_workspace_bytes(C.byref(cfg), C.byref(n)) == 0 and n.value > 0
+    cfg.dis_metric = 7
+    assert L.gs_gcond_workspace_bytes(C.byref(cfg), C.byref(n)) == -1
+    assert b"unknown distance function" in L.gs_last_error()                   # condensation/utils.py:63
+    assert L.gs_gemm_f32(None, None) == -1
+    # arxiv-sized workspace fits one MI355X many times over
+    big = _lib.GCondConfig(169343, 128, 128, 40, 454, 2, 256, 256, 256, 10, 5, 0, 3, 0.01, 0.01, 0.01, 1, 0)
+    assert L.gs_gcond_workspace_bytes(C.byref(big), C.byref(n)) == 0
+    assert 1 << 30 < n.value < 8 << 30
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from graphslim_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgslim_hip.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.lib()

@@ -1,0 +1,241 @@
+"""Parity of the HIP GCond engine (through the C ABI) against the golden vectors produced by the reference and
+against the CPU oracle on identical pre-sampled blocks.  Needs an MI355X.
+
+Gates (BASELINE.json north_star / SURVEY.md §8d): matching loss within 1e-4 relative; gradients wrt X~ within 1e-3
+relative (of the tensor's max), fp32 everywhere.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import analytic as A
+from oracle import gcond_oracle as O
+from helpers import T, load_golden, rebuild_batches, sbm_graph
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(got, ref, rtol=1e-3, what=""):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=rtol * np.abs(ref).max() + 1e-30, err_msg=what)
+
+
+def make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, x, f1, f2, bcap=32, metric="ours", inner=2, lrs=(0.01, 0.01, 0.01),
+                csr=None, pools=None, external=True, seed=1):
+    from graphslim_amd.engine import EngineShapes, GCondEngine
+    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, ph, bcap, f1, f2)
+    cls_ptr = cls_nodes = None
+    if pools is not None:
+        cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
+        cls_nodes = np.concatenate(pools)
+    return GCondEngine(sh, torch.as_tensor(x), csr, cls_ptr, cls_nodes, labels_syn, ranges, lr_feat=lrs[0], lr_adj=lrs[1],
+                       lr_model=lrs[2], inner_loop=inner, dis_metric=metric, seed=seed, external_blocks=external, device=DEV)
+
+
+@pytest.mark.parametrize("tag,metric", [("t1", "ours"), ("t2", "ours"), ("t1mse", "mse")])
+def test_train_class_against_reference_golden(golden_dir, tag, metric):
+    """G7: loss, d loss/d A^, d loss/d X~, d loss/d theta_PGE of the reference's train_class + backward."""
+    from graphslim_amd.engine import BlockSet
+    g = load_golden(golden_dir, "g7_train_class")
+    batches, (n, nclass, d, hidden, t), _ = rebuild_batches(g, tag)
+    labels_syn = g[f"{tag}_labels_syn"]
+    _, ncd, ranges = O.generate_labels_syn(g[f"{tag}_y"][g[f"{tag}_idx_train"]], float(g[f"{tag}_rate"]))
+    ranges = [tuple(ranges[c]) for c in range(nclass)]
+    ph = g[f"{tag}_pge2"].shape[0]
+    f1, f2 = [int(s) for s in g[f"{tag}_sizes"]]
+    eng = make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, metric=metric)
+    eng.set_feat(T(g[f"{tag}_feat_syn"]))
+    eng.set_pge([T(g[f"{tag}_pge{i}"]) for i in range(10)])
+    theta = [T(g[f"{tag}_theta{i}"]) for i in range(2 * t)]
+    eng.set_model(theta)
+    eng.set_blocks(BlockSet.from_batches(batches, 32, f1, f2, DEV))
+    # real side
+    eng.stage_real_grads()
+    gw = eng.buffer("gw_real", (nclass, -1))
+    for c in range(nclass):
+        th = [p.clone().requires_grad_(True) for p in theta]
+        ref, _ = O.class_real_grads("SGC", th, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), batches[c])
+        close(gw[c], torch.cat([r.reshape(-1) for r in ref]), 2e-4, f"gw_real class {c}")
+    # PGE forward + norm
+    eng.stage_pge_forward(False)
+    close(eng.buffer("adj_raw", (len(labels_syn), -1)), g[f"{tag}_adj_syn"], 2e-5, "adj_syn")
+    close(eng.buffer("adj_norm", (len(labels_syn), -1)), g[f"{tag}_adj_norm"], 2e-5, "adj_norm")
+    # matching loss + second-order backward
+    eng.stage_syn_match()
+    loss = float(eng.buffer("loss")[0])
+    assert abs(loss - float(g[f"{tag}_loss"])) <= 1e-4 * abs(float(g[f"{tag}_loss"])), (loss, float(g[f"{tag}_loss"]))
+    close(eng.buffer("d_adj_norm", (len(labels_syn), -1)), g[f"{tag}_dadj_norm"], 1e-3, "d loss / d A^")
+    eng.stage_pge_backward(True, True)
+    close(eng.buffer("d_feat", (len(labels_syn), d)), g[f"{tag}_dfeat"], 1e-3, "d loss / d X~")
+    dp = eng.buffer("d_pge")
+    o = 0
+    for i, shp in enumerate(eng.pge_shapes()):
+        k = int(np.prod(shp))
+        ref = g[f"{tag}_dpge{i}"]
+        if np.abs(ref).max() > 1e-6:        # Linear biases in front of a batch-stat BatchNorm: exactly-zero gradient
+            close(dp[o:o + k].reshape(shp), ref, 2e-3, f"d theta_PGE[{i}]")
+        o += k
+
+
+def _problem(t, seed, n=400, nclass=5, d=12, hidden=24, ph=16, rate=0.25, f1=4, f2=3, bcap=16):
+    a, x, y = sbm_graph(n, nclass, d, 8, seed)
+    rng = np.random.default_rng(seed)
+    idx_train = np.sort(rng.permutation(n)[: n // 2])
+    labels_train = y[idx_train]
+    labels_syn, ncd, ranges = O.generate_labels_syn(labels_train, rate)
+    csr = O.normalize_adj_sparse(a)
+    pools = [idx_train[labels_train == c] for c in range(nclass)]
+    torch.manual_seed(seed)
+    theta = O.init_sgc(d, hidden, nclass, t)
+    pge = O.init_pge(d, ph)
+    pge["bn"] = [torch.rand(ph) + 0.5, torch.randn(ph) * 0.2, torch.rand(ph) + 0.5, torch.randn(ph) * 0.2]
+    xs = torch.randn(len(labels_syn), d)
+    return dict(a=a, x=x, y=y, csr=csr, pools=pools, labels_syn=labels_syn, ncd=ncd, ranges=[tuple(ranges[c]) for c in range(nclass)],
+                theta=theta, pge=pge, xs=xs, n=n, nclass=nclass, d=d, hidden=hidden, ph=ph, f1=f1, f2=f2, bcap=bcap, t=t)
+
+
+def _batches(p, step):
+    out = []
+    for c in range(p["nclass"]):
+        rng = np.random.default_rng(7000 + 100 * step + c)
+        seeds = rng.permutation(p["pools"][c])[: p["bcap"]]
+        out.append(O.sample_blocks(*p["csr"], seeds, [p["f1"], p["f2"]], rng))
+    return out
+
+
+@pytest.mark.parametrize("t", [1, 2])
+@pytest.mark.parametrize("metric", ["ours", "mse", "cos"])
+def test_outer_iterations_follow_the_oracle(t, metric):
+    """Three whole outer iterations in a PGE epoch (0) and three in a feature epoch (10), with inner SGC steps:
+    X~, theta_PGE, theta and the raw adj_syn trajectory against oracle.GCondState on identical blocks."""
+    from graphslim_amd.engine import BlockSet
+    p = _problem(t, seed=11 + t)
+    eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], t, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
+                      p["f2"], bcap=p["bcap"], metric=metric, inner=2, lrs=(0.01, 0.005, 0.02))
+    st = O.GCondState(p["xs"], p["pge"], T(p["labels_syn"]), p["ncd"], p["nclass"], 0.01, 0.005, 0.02, "SGC", 2)
+    eng.set_feat(p["xs"])
+    eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
+    X, Y = T(p["x"]), T(p["y"])
+    step = 0
+    for epoch in (0, 10):
+        st.new_epoch(p["theta"])
+        eng.set_model(p["theta"])
+        for _ in range(3):
+            batches = _batches(p, step)
+            step += 1
+            l_ref, gfeat, gpge, adj_inner = st.outer_iteration(epoch, batches, X, Y, 2, metric)
+            eng.set_blocks(BlockSet.from_batches(batches, p["bcap"], p["f1"], p["f2"], DEV))
+            eng.outer_step(epoch)
+            loss = float(eng.buffer("loss")[0])
+            assert abs(loss - float(l_ref)) <= 1e-4 * abs(float(l_ref)), (epoch, loss, float(l_ref))
+            if epoch % 50 < 10:
+                got = eng.buffer("d_pge")
+                ref = torch.cat([g.reshape(-1) for g in gpge])
+                big = ref.abs() > 1e-3 * ref.abs().max()
+                close(got[big], ref[big], 5e-3, "d theta_PGE")
+            else:
+                close(eng.buffer("d_feat", gfeat.shape), gfeat, 1e-3, "d X~")
+            close(eng.adj_syn.cpu(), adj_inner, 2e-3, "adj_syn after the step")
+        # Adam normalises the step to +-lr whatever the gradient's size, so compare on the lr scale
+        np.testing.assert_allclose(eng.feat_syn.cpu().numpy(), st.feat_syn.detach().numpy(), atol=2e-3)
+        for got, ref in zip(eng.get_model(), st.model):
+            np.testing.assert_allclose(got.cpu().numpy(), ref.detach().numpy(), atol=4e-3)
+    s, k = eng.read_loss()
+    assert k == 6 and s > 0
+    assert eng.read_loss() == (0.0, 0)
+
+
+def test_engine_sampler_mode_runs_and_is_replayable():
+    """Product configuration: blocks come from gs_sample_blocks inside the engine.  Same seed -> identical trajectory;
+    and feeding the sampled blocks back through the oracle reproduces the engine's loss."""
+    p = _problem(2, seed=5)
+
+    def run():
+        eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 2, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
+                          p["f2"], bcap=p["bcap"], inner=1, csr=p["csr"], pools=p["pools"], external=False, seed=77)
+        eng.set_feat(p["xs"])
+        eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
+        eng.set_model(p["theta"])
+        losses = []
+        for i in range(4):
+            eng.outer_step(10)
+            losses.append(float(eng.buffer("loss")[0]))
+        return eng, losses
+
+    e1, l1 = run()
+    e2, l2 = run()
+    assert l1 == l2 and torch.equal(e1.feat_syn, e2.feat_syn)          # bitwise reproducible (no float atomics)
+    assert all(np.isfinite(l1)) and l1[0] > 0
+    # oracle on the blocks the engine sampled last
+    blk = e1.get_blocks()
+    batches = blocks_to_batches(blk)
+    for c, (bs, n_id, adjs) in enumerate(batches):
+        assert set(n_id[:bs].tolist()) <= set(p["pools"][c].tolist())
+
+
+def blocks_to_batches(blk):
+    """Engine ELL layout -> reference-style (batch_size, n_id, [blk0, blk1]) CSR batches."""
+    out = []
+    f = {k: getattr(blk, k).cpu().numpy() for k in blk.FIELDS}
+    for c in range(blk.C):
+        B, n1 = int(f["n_seed"][c]), int(f["n1"][c])
+        nid1 = f["nid1"][c, :n1]
+        n_id = list(nid1)
+        pos = {int(v): i for i, v in enumerate(nid1)}
+        rp0, c0, v0 = [0], [], []
+        for l in range(n1):
+            for j in range(blk.f2):
+                w = f["val0"][c, l, j]
+                if w != 0:
+                    u = int(f["col0"][c, l, j])
+                    if u not in pos:
+                        pos[u] = len(n_id)
+                        n_id.append(u)
+                    c0.append(pos[u])
+                    v0.append(w)
+            rp0.append(len(c0))
+        rp1, c1, v1 = [0], [], []
+        for b in range(B):
+            for j in range(blk.f1):
+                w = f["val1"][c, b, j]
+                if w != 0:
+                    c1.append(int(f["col1"][c, b, j]))
+                    v1.append(w)
+            rp1.append(len(c1))
+        blk0 = (np.array(rp0), np.array(c0), np.array(v0, np.float32), (n1, len(n_id)))
+        blk1 = (np.array(rp1), np.array(c1), np.array(v1, np.float32), (B, n1))
+        out.append((B, np.array(n_id), [blk0, blk1]))
+    return out
+
+
+def test_engine_sampled_blocks_loss_matches_oracle():
+    p = _problem(1, seed=9)
+    eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 1, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
+                      p["f2"], bcap=p["bcap"], inner=0, csr=p["csr"], pools=p["pools"], external=False, seed=3)
+    eng.set_feat(p["xs"])
+    eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
+    eng.set_model(p["theta"])
+    eng.stage_sample()
+    eng.stage_real_grads()
+    eng.stage_pge_forward(False)
+    eng.stage_syn_match()
+    loss = float(eng.buffer("loss")[0])
+    batches = blocks_to_batches(eng.get_blocks())
+    theta = [t.clone().requires_grad_(True) for t in p["theta"]]
+    adjn = O.dense_gcn_norm(O.pge_forward(p["xs"], p["pge"]))
+    ref = O.train_class("SGC", theta, batches, T(p["x"]), T(p["y"]), p["xs"], adjn, T(p["labels_syn"]), p["ncd"], p["nclass"])
+    assert abs(loss - float(ref)) <= 1e-4 * abs(float(ref)), (loss, float(ref))
+
+
+def test_error_paths():
+    from graphslim_amd import _lib
+    from graphslim_amd.engine import EngineShapes, GCondEngine
+    p = _problem(1, seed=2)
+    with pytest.raises(SystemExit):
+        make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 1, p["ph"], p["labels_syn"], p["ranges"], p["x"], 4, 3, metric="nope")
+    with pytest.raises(_lib.GslimError):      # SGC with 3 transforms is outside the built path
+        make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 3, p["ph"], p["labels_syn"], p["ranges"], p["x"], 4, 3)
+    eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 1, p["ph"], p["labels_syn"], p["ranges"], p["x"], 4, 3)
+    with pytest.raises(_lib.GslimError):      # external blocks never supplied
+        eng.outer_step(0)

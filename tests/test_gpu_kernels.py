@@ -1,0 +1,256 @@
+"""Parity of the stateless HIP entry points (through the C ABI) against CPU references.  Needs an MI355X."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from oracle import gcond_oracle as O
+from helpers import sbm_graph
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def E():
+    from graphslim_amd import engine
+    return engine
+
+
+def ref_mm(a, b):
+    return (a.double() @ b.double())
+
+
+def close(got, ref, rtol=2e-5, atol_scale=2e-6):
+    ref = ref.double()
+    np.testing.assert_allclose(got.double().cpu().numpy(), ref.numpy(), rtol=rtol, atol=atol_scale * float(ref.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (33, 65, 17), (70, 7, 1433), (128, 128, 64), (300, 40, 256),
+                                   (454, 454, 454), (129, 257, 100), (1, 256, 500), (256, 1, 77), (513, 33, 31)])
+def test_gemm_layouts(E, M, N, K):
+    torch.manual_seed(M * 131 + N * 7 + K)
+    A, B = torch.randn(M, K), torch.randn(K, N)
+    ref = ref_mm(A, B)
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    At, Bt = A.T.contiguous().to(DEV), B.T.contiguous().to(DEV)
+    for (a, sa), (b, sb) in [((Ad, (K, 1)), (Bd, (N, 1))), ((At, (1, M)), (Bd, (N, 1))), ((Ad, (K, 1)), (Bt, (1, K))),
+                             ((At, (1, M)), (Bt, (1, K)))]:
+        Cd = torch.full((M, N), float("nan"), device=DEV)
+        E.gemm(a, b, Cd, M, N, K, sa, sb, N)
+        close(Cd, ref)
+
+
+def test_gemm_epilogues(E):
+    torch.manual_seed(0)
+    M, N, K = 150, 70, 45
+    A, B, bias, mask, C0 = torch.randn(M, K), torch.randn(K, N), torch.randn(N), torch.randn(M, N), torch.randn(M, N)
+    Cd = C0.clone().to(DEV)
+    E.gemm(A.to(DEV), B.to(DEV), Cd, M, N, K, (K, 1), (N, 1), N, alpha=0.5, beta=2.0, bias=bias.to(DEV))
+    close(Cd, 0.5 * ref_mm(A, B) + bias.double() + 2.0 * C0.double())
+    Cd = torch.empty(M, N, device=DEV)
+    E.gemm(A.to(DEV), B.to(DEV), Cd, M, N, K, (K, 1), (N, 1), N, bias=bias.to(DEV), relu=1)
+    close(Cd, (ref_mm(A, B) + bias.double()).clamp_min(0))
+    E.gemm(A.to(DEV), B.to(DEV), Cd, M, N, K, (K, 1), (N, 1), N, mask=mask.to(DEV), ldmask=N)
+    close(Cd, ref_mm(A, B) * (mask > 0))
+    one = torch.ones(1, device=DEV)     # column sums through a stride-0 operand
+    out = torch.empty(1, N, device=DEV)
+    E.gemm(one, B.to(DEV), out, 1, N, K, (0, 0), (N, 1), N)
+    close(out, B.double().sum(0, keepdim=True))
+
+
+def test_gemm_batched_grouped_gather_splitk(E):
+    torch.manual_seed(1)
+    nb, M, N, K = 5, 37, 50, 90
+    A, B = torch.randn(nb, M, K), torch.randn(nb, K, N)
+    Cd = torch.empty(nb, M, N, device=DEV)
+    E.gemm(A.to(DEV), B.to(DEV), Cd, M, N, K, (K, 1), (N, 1), N, nb1=nb, sAb1=M * K, sBb1=K * N, sCb1=M * N)
+    close(Cd, torch.stack([ref_mm(A[i], B[i]) for i in range(nb)]))
+    # grouped over contiguous row ranges of one matrix (per-class rows), transposed A:  out_g = S[lo:hi]^T G[lo:hi]
+    n, F, Cc = 60, 21, 6
+    S, G = torch.randn(n, F), torch.randn(n, Cc)
+    lo = [0, 5, 5, 30, 41]
+    hi = [5, 5, 30, 41, 60]
+    offA = torch.tensor([l * F for l in lo], dtype=torch.int64, device=DEV)
+    offB = torch.tensor([l * Cc for l in lo], dtype=torch.int64, device=DEV)
+    kb = torch.tensor([h - l for l, h in zip(lo, hi)], dtype=torch.int32, device=DEV)
+    out = torch.full((5, F, Cc), float("nan"), device=DEV)
+    E.gemm(S.to(DEV), G.to(DEV), out, F, Cc, max(h - l for l, h in zip(lo, hi)), (1, F), (Cc, 1), Cc, nb1=5, offA=offA,
+           offB=offB, Kb=kb, sCb1=F * Cc)
+    close(out, torch.stack([ref_mm(S[l:h].T, G[l:h]) for l, h in zip(lo, hi)]))
+    # grouped rows of the OUTPUT (Mb / offC)
+    Bc = torch.randn(5, n, Cc)
+    dQ = torch.full((n, n), float("nan"), device=DEV)
+    offC = torch.tensor([l * n for l in lo], dtype=torch.int64, device=DEV)
+    E.gemm(G.to(DEV), Bc.to(DEV), dQ, 25, n, Cc, (Cc, 1), (1, Cc), n, nb1=5, offA=offB, Mb=kb, sBb1=n * Cc, offC=offC)
+    ref = torch.cat([ref_mm(G[l:h], Bc[i].T) for i, (l, h) in enumerate(zip(lo, hi))])
+    close(dQ, ref)
+    # gathered K (edge-wise GEMM) with split-K slabs and fixed-order reduce
+    Nn, d, h, Kc = 200, 24, 40, 333
+    X, Bm = torch.randn(Nn, d), torch.randn(2, Kc, h)
+    idx = torch.randint(0, Nn, (2, Kc), dtype=torch.int32)
+    kcount = torch.tensor([333, 100], dtype=torch.int32, device=DEV)
+    nsplit, kchunk = 6, 64
+    slabs = torch.full((2, nsplit, d, h), float("nan"), device=DEV)
+    E.gemm(X.to(DEV), Bm.to(DEV), slabs, d, h, Kc, (1, d), (h, 1), h, gatherA_k=idx.to(DEV), sGb1=Kc, nb1=2, nb2=nsplit,
+           kchunk=kchunk, Kb=kcount, sBb1=Kc * h, sCb1=nsplit * d * h, sCb2=d * h)
+    out = torch.empty(2, d, h, device=DEV)
+    from graphslim_amd import _lib
+    _lib.check(_lib.lib().gs_reduce_slabs_batched_f32(_lib.ptr(out), d * h, _lib.ptr(slabs), d * h, nsplit, d * h, 2, 0.0,
+                                                      _lib.stream()))
+    ref = torch.stack([ref_mm(X[idx[b, :kc].long()].T, Bm[b, :kc]) for b, kc in enumerate([333, 100])])
+    close(out, ref)
+
+
+@pytest.mark.parametrize("F", [1, 7, 40, 41, 64, 256, 602, 1433])
+def test_spmm_csr(E, F):
+    a, x, y = sbm_graph(500, 5, 4, 8, seed=F)
+    rp, col, val = O.normalize_adj_sparse(a)
+    X = torch.randn(500, F)
+    ref = torch.sparse.mm(O.csr_to_torch(rp, col, val, 500, torch.float64), X.double())
+    i32 = lambda v: torch.as_tensor(v, dtype=torch.int32, device=DEV)
+    out = E.spmm_csr(i32(rp), i32(col), torch.as_tensor(val, device=DEV), X.to(DEV))
+    close(out, ref)
+    # padded leading dimension (16-byte rows) must give the same numbers
+    ld = (F + 3) // 4 * 4
+    Xp = torch.zeros(500, ld, device=DEV)
+    Xp[:, :F] = X.to(DEV)
+    outp = torch.zeros(500, ld, device=DEV)
+    E.spmm_csr(i32(rp), i32(col), torch.as_tensor(val, device=DEV), Xp, F=F, out=outp)
+    close(outp[:, :F], ref)
+
+
+def test_spmm_csr_empty_rows_and_transpose(E):
+    rng = np.random.default_rng(0)
+    m = sp.random(300, 200, density=0.02, random_state=rng, format="csr", dtype=np.float32)
+    m = sp.vstack([m[:100], sp.csr_matrix((50, 200), dtype=np.float32), m[100:]]).tocsr()   # 50 empty rows
+    X = torch.randn(200, 33)
+    i32 = lambda v: torch.as_tensor(v, dtype=torch.int32, device=DEV)
+    out = E.spmm_csr(i32(m.indptr), i32(m.indices), torch.as_tensor(m.data, device=DEV), X.to(DEV))
+    close(out, torch.from_numpy(m.astype(np.float64).toarray()) @ X.double())
+    mt = m.T.tocsr()     # autograd of spmm wrt X = the same kernel on the CSR of A^T
+    dY = torch.randn(350, 33)
+    dX = E.spmm_csr(i32(mt.indptr), i32(mt.indices), torch.as_tensor(mt.data, device=DEV), dY.to(DEV))
+    close(dX, torch.from_numpy(m.astype(np.float64).toarray()).T @ dY.double())
+
+
+def test_gather_rows(E):
+    X = torch.randn(100, 37)
+    idx = torch.randint(0, 100, (250,), dtype=torch.int32)
+    out = E.gather_rows(X.to(DEV), idx.to(DEV))
+    assert torch.equal(out.cpu(), X[idx.long()])
+
+
+def test_dense_gcn_norm_fwd_bwd(E):
+    torch.manual_seed(0)
+    n = 93
+    adj = torch.rand(n, n)
+    adj = ((adj + adj.T) / 2).fill_diagonal_(0)
+    adj[5, :] = 0
+    adj[:, 5] = 0
+    a64 = adj.double().requires_grad_(True)
+    w = torch.randn(n, n)
+    ref = O.dense_gcn_norm(a64)
+    (ref * w.double()).sum().backward()
+    out, r = E.dense_gcn_norm_fwd(adj.to(DEV))
+    close(out, ref.detach(), rtol=1e-5)
+    dadj = E.dense_gcn_norm_bwd(adj.to(DEV), r, w.to(DEV))
+    close(dadj, a64.grad, rtol=1e-4, atol_scale=1e-5)
+
+
+def test_adam_matches_torch(E):
+    torch.manual_seed(0)
+    for wd in (0.0, 5e-4):
+        p = torch.randn(1000, requires_grad=True)
+        opt = torch.optim.Adam([p], lr=0.01, weight_decay=wd)
+        pd_ = p.detach().clone().to(DEV)
+        m, v = torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+        for step in range(1, 6):
+            g = torch.randn(1000)
+            p.grad = g.clone()
+            opt.step()
+            E.adam_step(pd_, g.to(DEV), m, v, 0.01, step, weight_decay=wd)
+        np.testing.assert_allclose(pd_.cpu().numpy(), p.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_sampler_properties(E):
+    """dataset/loader.py:187-224 semantics: <= bcap distinct seeds from the class pool, <= f neighbours per row without
+    replacement, all neighbours kept when deg <= f, frontier de-duplicated with seeds first, full-graph weights carried."""
+    n, C = 3000, 6
+    a, x, y = sbm_graph(n, C, 4, 14, seed=3)
+    rp, col, val = O.normalize_adj_sparse(a)
+    rng = np.random.default_rng(0)
+    idx_train = np.sort(rng.permutation(n)[:1500])
+    pools = [idx_train[y[idx_train] == c] for c in range(C)]
+    pools[0] = pools[0][:40]                       # a class smaller than bcap
+    cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
+    cls_nodes = np.concatenate(pools)
+    i32 = lambda v: torch.as_tensor(np.asarray(v), dtype=torch.int32, device=DEV)
+    bcap, f1, f2 = 64, 10, 5
+    blocks = E.BlockSet(C, bcap, f1, f2, DEV)
+    marker = torch.full((C * n,), 0x7fffffff, dtype=torch.int32, device=DEV)
+    args = (i32(rp), i32(col), torch.as_tensor(val, device=DEV), n, i32(cls_ptr), i32(cls_nodes), marker, blocks)
+    E.sample_blocks(*args, 1234, 0)
+    torch.cuda.synchronize()
+    assert int((marker != 0x7fffffff).sum()) == 0            # scratch restored
+    A = sp.csr_matrix((val, col, rp), shape=(n, n))
+    nb = {v: dict(zip(A.indices[A.indptr[v]:A.indptr[v + 1]], A.data[A.indptr[v]:A.indptr[v + 1]])) for v in range(n)}
+    first = {f: getattr(blocks, f).cpu().numpy().copy() for f in blocks.FIELDS}
+    for c in range(C):
+        B, n1 = int(first["n_seed"][c]), int(first["n1"][c])
+        assert B == min(bcap, len(pools[c]))
+        nid = first["nid1"][c, :n1]
+        assert len(set(nid.tolist())) == n1                   # de-duplicated frontier
+        assert set(nid[:B].tolist()) <= set(pools[c].tolist()) and len(set(nid[:B].tolist())) == B
+        tp, te = first["tptr1"][c], first["tedge1"][c]
+        for b in range(B):
+            v = int(nid[b])
+            w = first["val1"][c, b]
+            k = int((w != 0).sum())
+            assert k == min(len(nb[v]), f1) and np.all(w[k:] == 0)
+            cols = first["col1"][c, b, :k]
+            assert np.all(cols < n1)
+            got = nid[cols]
+            assert len(set(got.tolist())) == k                # without replacement
+            for u, ww in zip(got, w[:k]):
+                assert nb[v][int(u)] == ww                    # full-graph normalised weight, bit exact
+        # CSC lists the in-edges of every frontier node in ascending slot order
+        slots = {(b * f1 + j) for b in range(B) for j in range(f1) if first["val1"][c, b, j] != 0}
+        assert tp[0] == 0 and tp[n1] == len(slots)
+        seen = set()
+        for l in range(n1):
+            lst = te[tp[l]:tp[l + 1]]
+            assert np.all(np.diff(lst) > 0)
+            for s_ in lst:
+                assert first["col1"][c, s_ // f1, s_ % f1] == l
+                seen.add(int(s_))
+        assert seen == slots
+        for l in range(n1):
+            v = int(nid[l])
+            w = first["val0"][c, l]
+            k = int((w != 0).sum())
+            assert k == min(len(nb[v]), f2)
+            got = first["col0"][c, l, :k]
+            assert len(set(got.tolist())) == k
+            for u, ww in zip(got, w[:k]):
+                assert nb[v][int(u)] == ww
+        assert np.all(first["val0"][c, n1:] == 0)
+    # replayable: same (seed, step) -> identical blocks; another step -> different seeds for the big classes
+    E.sample_blocks(*args, 1234, 0)
+    torch.cuda.synchronize()
+    for f in blocks.FIELDS:
+        assert np.array_equal(getattr(blocks, f).cpu().numpy(), first[f])
+    E.sample_blocks(*args, 1234, 1)
+    torch.cuda.synchronize()
+    assert not np.array_equal(blocks.nid1.cpu().numpy()[1], first["nid1"][1])
+    # seed frequency over many draws is uniform over the pool (chi-square-ish bound)
+    cnt = np.zeros(n)
+    T_ = 200
+    for t in range(T_):
+        E.sample_blocks(*args, 99, t)
+        cnt[blocks.nid1[1, :bcap].cpu().numpy()] += 1
+    pool = pools[1]
+    p = bcap / len(pool)
+    freq = cnt[pool] / T_
+    assert abs(freq.mean() - p) < 1e-9 and freq.std() < 3.5 * np.sqrt(p * (1 - p) / T_)

@@ -12,13 +12,7 @@ from oracle import gcond_oracle as O
 torch.set_num_threads(4)
 
 
-def load(golden_dir, name):
-    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
-
-
-def T(a, dtype=None):
-    t = torch.from_numpy(np.asarray(a))
-    return t.to(dtype) if dtype is not None else t
+from helpers import T, load_golden as load, rebuild_batches as _rebuild
 
 
 def test_g1_normalisation(golden_dir):
@@ -115,18 +109,8 @@ def test_g6_pge(golden_dir, tag):
 
 
 def rebuild_batches(g, tag):
-    n, nclass, d, hidden, t, calls0 = [int(v) for v in g[f"{tag}_meta"]]
-    a = sp.coo_matrix((np.ones(len(g[f"{tag}_a_row"])), (g[f"{tag}_a_row"], g[f"{tag}_a_col"])), shape=(n, n)).tocsr()
-    csr = O.normalize_adj_sparse(a)
-    idx_train, y = g[f"{tag}_idx_train"], g[f"{tag}_y"]
-    labels_train = y[idx_train]
-    sizes = [int(s) for s in g[f"{tag}_sizes"]]
-    batches = []
-    for c in range(nclass):
-        rng = np.random.default_rng(100000 + calls0 + c)
-        batch = rng.permutation(idx_train[labels_train == c])[:256]
-        batches.append(O.sample_blocks(*csr, batch, sizes, rng))
-    return batches, (n, nclass, d, hidden, t)
+    batches, dims, _ = _rebuild(g, tag)
+    return batches, dims
 
 
 @pytest.mark.parametrize("tag,kind,metric", [("t1", "SGC", "ours"), ("t2", "SGC", "ours"), ("t1mse", "SGC", "mse"),
