@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py — GCond outer-loop iterations/sec on the ogbn-arxiv-shaped synthetic graph (r = 0.5 %).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one outer-loop iteration of condensation/gcond.py:47-72 on the HIP engine: GPU neighbour sampling for all
+40 classes, real-side class gradients, PGE forward + normalisation, gradient matching with its closed-form second-order
+backward, PGE backward, one Adam step (PGE or X~), PGE inference and `inner_loop` = 3 SGC steps.  The K timed steps sweep
+one 50-epoch PGE/feature cycle (20 % of them are PGE-update iterations, like the full 600-epoch job), and theta is
+re-initialised whenever the epoch changes (gcond.py:42-45).  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, live HIP-event timing) and
+`cpu_baseline` (the CPU oracle — a port of the reference path — on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (dataset shape, rate, ntrans, hidden, pge_hidden, outer_loop, inner_loop, lr_feat, lr_adj, fan-outs)
+    "ogbn-arxiv": ("ogbn-arxiv", 0.005, 2, 256, 256, 20, 3, 0.01, 0.01, (10, 5)),
+    "cora": ("cora", 0.5, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
+}
+
+
+def build_problem(name, seed=1, scale=1.0):
+    from graphslim_amd.dataset.loader import TransAndInd, splits
+    from graphslim_amd.dataset.synthetic import make_raw
+    from graphslim_amd.host import generate_labels_syn, normalize_adj_sparse
+    shape, rate, T, hidden, ph, outer, inner, lrf, lra, fan = WORKLOADS[name]
+    raw = splits(make_raw(shape, seed=seed, scale=scale))
+    data = TransAndInd(raw, shape)
+    labels_train = data.labels_train.numpy()
+    labels_syn, ncd, ranges = generate_labels_syn(labels_train, rate)
+    csr = normalize_adj_sparse(data.adj_full)
+    pools = data.class_pools("trans")
+    return dict(data=data, labels_syn=labels_syn, ncd=ncd, ranges=[tuple(ranges[c]) for c in range(data.nclass)], csr=csr,
+                pools=pools, T=T, hidden=hidden, ph=ph, outer=outer, inner=inner, lrf=lrf, lra=lra, fan=fan, rate=rate, name=name)
+
+
+def make_engine(p, device, bcap=256):
+    from graphslim_amd.engine import EngineShapes, GCondEngine
+    d = p["data"].feat_full.shape[1]
+    sh = EngineShapes(p["data"].num_nodes, d, p["data"].nclass, len(p["labels_syn"]), p["T"], p["hidden"], p["ph"], bcap,
+                      p["fan"][0], p["fan"][1])
+    cls_ptr = np.concatenate([[0], np.cumsum([len(q) for q in p["pools"]])])
+    eng = GCondEngine(sh, p["data"].feat_full, p["csr"], cls_ptr, np.concatenate(p["pools"]), p["labels_syn"], p["ranges"],
+                      lr_feat=p["lrf"], lr_adj=p["lra"], lr_model=0.01, inner_loop=p["inner"], seed=1, device=device)
+    return eng
+
+
+def init_state(p, eng, seed=1):
+    """X~ = features of randomly picked train nodes per class (sparsification/random.py:9-17); PGE as nn.Linear/BN default."""
+    from graphslim_amd.host import init_pge_params, random_init_indices
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    sel = random_init_indices(p["data"].idx_train.numpy(), p["data"].labels_train.numpy(), p["ncd"])
+    eng.set_feat(p["data"].feat_full[sel])
+    eng.set_pge(init_pge_params(p["data"].feat_full.shape[1], p["ph"]))
+
+
+def new_model(p, eng):
+    from graphslim_amd.host import init_sgc_params
+    d = p["data"].feat_full.shape[1]
+    eng.set_model(init_sgc_params(d, p["hidden"], p["data"].nclass, p["T"]))
+
+
+def run_steps(p, eng, k, cycle_len):
+    """k outer iterations sweeping epochs 0..49 uniformly; fresh theta when the epoch changes."""
+    last = -1
+    for i in range(k):
+        epoch = (i * 50) // cycle_len
+        if epoch != last:
+            new_model(p, eng)
+            last = epoch
+        eng.outer_step(epoch)
+
+
+def roofline_probe(eng, reps=20):
+    """Dominant kernel: the PGE layer-2 contraction E2[n'^2, Ph] = A1[n'^2, Ph] W1^T on the fp32 matrix cores
+    (gs_gemm_f32_kernel<128,128,64,64>); algorithmic FLOPs = 2 n'^2 Ph^2.  Timed with events on the launch stream."""
+    from graphslim_amd.engine import gemm
+    n, ph = eng.shapes.n_syn, eng.shapes.pge_hidden
+    rows = n * n
+    a = torch.randn(rows, ph, device=eng.dev)
+    w = torch.randn(ph, ph, device=eng.dev)
+    out = torch.empty(rows, ph, device=eng.dev)
+    for _ in range(3):
+        gemm(a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        gemm(a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph)
+    ev1.record()
+    ev1.synchronize()
+    sec = ev0.elapsed_time(ev1) / 1e3 / reps
+    flops = 2.0 * rows * ph * ph
+    peak = 157.3      # TFLOP/s, fp32 matrix (MI355X_MICROARCH.md chip table)
+    ach = flops / sec / 1e12
+    return {"bound": "mfma", "kernel": "gs_gemm_f32_kernel<128,128,64,64> (PGE layer 2, fp32 MFMA 32x32x2)",
+            "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "avg_launch_us": round(sec * 1e6, 2), "flops_per_launch": flops}
+
+
+def blocks_to_batches(blk):
+    f = {k: getattr(blk, k).cpu().numpy() for k in blk.FIELDS}
+    out = []
+    for c in range(blk.C):
+        B, n1 = int(f["n_seed"][c]), int(f["n1"][c])
+        nid1 = f["nid1"][c, :n1]
+        v0, c0g = f["val0"][c, :n1].reshape(-1), f["col0"][c, :n1].reshape(-1)
+        keep = v0 != 0
+        rows0 = np.repeat(np.arange(n1), blk.f2)[keep]
+        uniq, inv = np.unique(np.concatenate([nid1, c0g[keep]]), return_inverse=True)
+        # targets first, then the new sources in first-seen order
+        pos = -np.ones(int(uniq.max()) + 1, dtype=np.int64)
+        pos[nid1] = np.arange(n1)
+        rest = c0g[keep][pos[c0g[keep]] < 0]
+        _, first = np.unique(rest, return_index=True)
+        new = rest[np.sort(first)]
+        pos[new] = n1 + np.arange(len(new))
+        n_id = np.concatenate([nid1, new])
+        rp0 = np.concatenate([[0], np.cumsum(np.bincount(rows0, minlength=n1))])
+        blk0 = (rp0, pos[c0g[keep]], v0[keep].astype(np.float32), (n1, len(n_id)))
+        v1, c1 = f["val1"][c, :B].reshape(-1), f["col1"][c, :B].reshape(-1)
+        k1 = v1 != 0
+        rows1 = np.repeat(np.arange(B), blk.f1)[k1]
+        rp1 = np.concatenate([[0], np.cumsum(np.bincount(rows1, minlength=B))])
+        blk1 = (rp1, c1[k1].astype(np.int64), v1[k1].astype(np.float32), (B, n1))
+        out.append((B, n_id, [blk0, blk1]))
+    return out
+
+
+def cpu_baseline(p, eng):
+    """The oracle (a CPU port of the reference path, pinned against reference golden vectors) on a bounded sample:
+    1 warm-up + 1 timed outer iteration of the same workload, on the blocks the engine sampled, all host cores."""
+    from oracle import gcond_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    eng.stage_sample()
+    batches = blocks_to_batches(eng.get_blocks())
+    d = p["data"].feat_full.shape[1]
+    xs = eng.feat_syn.cpu()
+    pge = [t.cpu().clone() for t in eng.get_pge()]
+    st = O.GCondState(xs, {"lin": pge[:6], "bn": pge[6:]}, torch.from_numpy(p["labels_syn"]), p["ncd"], p["data"].nclass,
+                      p["lrf"], p["lra"], 0.01, "SGC", 2)
+    torch.manual_seed(0)
+    st.new_epoch(O.init_sgc(d, p["hidden"], p["data"].nclass, p["T"]))
+    X, Y = p["data"].feat_full, p["data"].labels_full
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        st.outer_iteration(10, batches, X, Y, p["inner"])
+        times.append(time.perf_counter() - t0)
+    return {"value": round(1.0 / times[-1], 4), "unit": "outer-iters/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 warm-up + 1 timed outer iteration of the same workload on identical engine-sampled blocks "
+                      f"(timed iteration {times[-1]:.2f} s; sampling excluded on the CPU side)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="ogbn-arxiv", choices=sorted(WORKLOADS))
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink N for smoke runs (invalidates the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    p = build_problem(args.workload, seed=1, scale=args.scale)
+    from graphslim_amd import parallel
+    eng = parallel.make_engine(p, dev, rank, world) if world > 1 else make_engine(p, dev)
+    init_state(p, eng)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(p, eng, args.warmup, max(args.warmup, 1))
+    eng.read_loss()
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(p, eng, args.steps, args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_sum, k = eng.read_loss()
+    if rank == 0:
+        units = args.steps * (world if getattr(eng, "replicas_only", False) else 1)
+        out = {
+            "metric": "GCond outer-loop iters/sec", "value": round(units / dt, 3), "unit": "outer-iters/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-shaped synthetic graph, GCond r={p['rate']}, SGC T={p['T']} h={p['hidden']}, "
+                                   f"PGE h={p['ph']}, n'={len(p['labels_syn'])}, seeds/class 256, fan-out {list(p['fan'])}, "
+                                   f"inner_loop {p['inner']}, GPU sampler", "N": int(p['data'].num_nodes),
+                       "nnz": int(p['csr'][0][-1]), "scale": args.scale, "mean_match_loss": loss_sum / max(k, 1) / p['data'].nclass,
+                       "parallelism": getattr(eng, "parallelism", "single")},
+        }
+        out["roofline"] = roofline_probe(eng)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(p, eng)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""Dataset-shaped synthetic graphs (no network on the GPU box).
+
+Each generator returns a raw PyG-like record (x, y, edge_index, train/val/test masks) with the node/edge/feature/class
+counts and split sizes of the named dataset; `TransAndInd` (loader.py) then applies the same preprocessing the reference
+applies (dataset/loader.py:110-121: StandardScaler fitted on train rows for arxiv/reddit/flickr, L1 row normalisation for
+the Planetoid sets).  Graph model: degree-corrected stochastic block model, power-law degree propensities, homophily
+0.8, symmetrised, no self loops.  Features: Planetoid-shaped = sparse non-negative bag-of-words with class-dependent
+word distribution; arxiv/reddit-shaped = class mean + N(0,1).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+# name: (N, directed nnz, d, C, n_train, n_val, n_test, feature kind, words per row)
+SHAPES = {
+    "cora": (2708, 10556, 1433, 7, 140, 500, 1000, "bow", 18),
+    "citeseer": (3327, 9104, 3703, 6, 120, 500, 1000, "bow", 32),
+    "pubmed": (19717, 88648, 500, 3, 60, 500, 1000, "bow", 50),
+    "ogbn-arxiv": (169343, 2315598, 128, 40, 90941, 29799, 48603, "dense", 0),
+    "reddit": (232965, 23213838, 602, 41, 153932, 23699, 55334, "dense", 0),
+    "flickr": (89250, 899756, 500, 7, 44625, 22312, 22313, "dense", 0),
+}
+
+
+def _class_sizes(n, c, rng, balanced):
+    if balanced:
+        base = np.full(c, n // c)
+        base[: n - base.sum()] += 1
+        return base
+    w = (np.arange(1, c + 1, dtype=np.float64)) ** -0.9          # long-tailed like arxiv / reddit
+    w = rng.permutation(w / w.sum())
+    s = np.maximum((w * n).astype(np.int64), 8)
+    s[np.argmax(s)] += n - s.sum()
+    return s
+
+
+def make_raw(name: str, seed: int = 1, scale: float = 1.0):
+    """`scale` < 1 shrinks N (and the splits) proportionally for CPU-sized tests; d, C and the degree stay."""
+    if name not in SHAPES:
+        raise ValueError(f"unknown dataset shape '{name}' (have {sorted(SHAPES)})")
+    n, nnz, d, c, n_tr, n_va, n_te, kind, words = SHAPES[name]
+    if scale != 1.0:
+        n_tr, n_va, n_te = (max(int(v * scale), 4 * c) for v in (n_tr, n_va, n_te))
+        n = max(int(n * scale), n_tr + n_va + n_te)
+        nnz = int(nnz * scale)
+    rng = np.random.default_rng(seed)
+    planetoid = kind == "bow"
+    sizes = _class_sizes(n, c, rng, balanced=planetoid)
+    y = rng.permutation(np.repeat(np.arange(c), sizes))
+    # degree-corrected SBM: endpoint propensity ~ power law; 80 % of edges stay inside the class
+    m = nnz // 2
+    theta = rng.pareto(2.5, n) + 1.0
+    order = np.argsort(y, kind="stable")
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    p_all = theta / theta.sum()
+    src = rng.choice(n, size=m, p=p_all)
+    dst = rng.choice(n, size=m, p=p_all)
+    same = rng.random(m) < 0.8
+    # redraw the intra-class partners class by class (vectorised per class)
+    ys = y[src]
+    for k in range(c):
+        sel = np.nonzero(same & (ys == k))[0]
+        if len(sel):
+            members = order[starts[k]:starts[k + 1]]
+            pk = theta[members] / theta[members].sum()
+            dst[sel] = rng.choice(members, size=len(sel), p=pk)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    ei = np.vstack([np.concatenate([src, dst]), np.concatenate([dst, src])])
+    ei = np.unique(ei, axis=1)
+    if planetoid:
+        x = np.zeros((n, d), dtype=np.float32)
+        topic = rng.dirichlet(np.full(d, 0.05), size=c)
+        for k in range(c):
+            rows = np.nonzero(y == k)[0]
+            mix = 0.7 * topic[k] + 0.3 / d
+            wid = rng.choice(d, size=(len(rows), words), p=mix / mix.sum())
+            x[np.repeat(rows, words), wid.reshape(-1)] = 1.0
+        empty = x.sum(1) == 0
+        x[empty, rng.integers(0, d, empty.sum())] = 1.0
+    else:
+        mu = rng.normal(scale=0.6, size=(c, d)).astype(np.float32)
+        x = mu[y] + rng.normal(size=(n, d)).astype(np.float32)
+    # splits: Planetoid = 20 train nodes per class; others = random split of the stated sizes
+    perm = rng.permutation(n)
+    if planetoid:
+        tr = np.concatenate([np.nonzero(y == k)[0][rng.permutation((y == k).sum())[: n_tr // c]] for k in range(c)])
+        rest = np.setdiff1d(perm, tr, assume_unique=False)
+        rest = rng.permutation(rest)
+        va, te = rest[:n_va], rest[n_va:n_va + n_te]
+    else:
+        tr, va, te = perm[:n_tr], perm[n_tr:n_tr + n_va], perm[n_tr + n_va:n_tr + n_va + n_te]
+    masks = []
+    for idx in (tr, va, te):
+        mk = np.zeros(n, dtype=bool)
+        mk[idx] = True
+        masks.append(torch.from_numpy(mk))
+    return SimpleNamespace(x=torch.from_numpy(x), y=torch.from_numpy(y.astype(np.int64)),
+                           edge_index=torch.from_numpy(ei.astype(np.int64)), num_nodes=n, train_mask=masks[0],
+                           val_mask=masks[1], test_mask=masks[2], name=name, synthetic=True)

@@ -1,0 +1,122 @@
+"""Host-side (CPU) preparation the reference also performs on the host, before the device loop starts:
+synthetic-label allocation, the one-off scipy normalisation of the real adjacency, parameter initialisation
+draws and the random feature initialisation.  Product code (never imports oracle/)."""
+from __future__ import annotations
+
+import math
+from collections import Counter
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+
+def generate_labels_syn(labels_train, reduction_rate):
+    """graphslim/condensation/gcond_base.py:79-115.  Classes are laid out by ascending train count (stable for ties,
+    Counter first-appearance order); every class gets max(int(count*rate), 1) rows, the largest gets the remainder
+    max(int(n*rate) - sum, 1).  Returns (labels_syn int64, {class: count} in layout order, {class: [lo, hi]})."""
+    lab = np.asarray(labels_train).tolist()
+    by_count = sorted(Counter(lab).items(), key=lambda kv: kv[1])
+    total = int(len(lab) * reduction_rate)
+    counts, ranges, out, used = {}, {}, [], 0
+    for pos, (cls, cnt) in enumerate(by_count):
+        k = max(total - used, 1) if pos == len(by_count) - 1 else max(int(cnt * reduction_rate), 1)
+        if pos != len(by_count) - 1:
+            used += k
+        counts[cls] = k
+        ranges[cls] = [len(out), len(out) + k]
+        out.extend([cls] * k)
+    return np.asarray(out, dtype=np.int64), counts, ranges
+
+
+def normalize_adj_sparse(adj):
+    """graphslim/utils.py:403-413,451-458: D^-1/2 (A + I) D^-1/2 in scipy float64, cast to fp32, transposed CSR
+    (the reference builds SparseTensor(...).t()).  Returns (rowptr, col, val)."""
+    a = sp.csr_matrix(adj, dtype=np.float64) + sp.eye(adj.shape[0], dtype=np.float64)
+    deg = np.asarray(a.sum(1)).ravel()
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, -0.5)
+    dinv[np.isinf(dinv)] = 0.0
+    dm = sp.diags(dinv)
+    m = sp.csr_matrix(dm.dot(a).dot(dm)).astype(np.float32).T.tocsr()
+    m.sum_duplicates()
+    m.sort_indices()
+    return m.indptr.astype(np.int64), m.indices.astype(np.int64), m.data.astype(np.float32)
+
+
+def csr_transpose(rowptr, col, val, n_rows, n_cols):
+    """CSR of A^T (host, one-off): what torch_sparse keeps as its csr2csc permutation for the backward spmm."""
+    m = sp.csr_matrix((val, col, rowptr), shape=(n_rows, n_cols)).T.tocsr()
+    m.sort_indices()
+    return m.indptr.astype(np.int64), m.indices.astype(np.int64), m.data.astype(np.float32)
+
+
+def random_init_indices(idx_train, labels_train, num_class_dict):
+    """graphslim/sparsification/random.py:9-17: per class, in layout order, np.random.permutation(ids)[:count]."""
+    idx_train, labels_train = np.asarray(idx_train), np.asarray(labels_train)
+    return np.hstack([np.random.permutation(idx_train[labels_train == c])[:k] for c, k in num_class_dict.items()])
+
+
+def _uniform_linear(n_in, n_out):
+    """MyLinear / GraphConvolution.reset_parameters (models/layers.py:29-33,369-373): W[in,out] then b, U(+-1/sqrt(in))."""
+    s = 1.0 / math.sqrt(n_in)
+    return torch.empty(n_in, n_out).uniform_(-s, s), torch.zeros(n_out).uniform_(-s, s)
+
+
+def layer_dims(nfeat, nhid, nclass, depth):
+    return [(nfeat, nclass)] if depth == 1 else [(nfeat, nhid)] + [(nhid, nhid)] * (depth - 2) + [(nhid, nclass)]
+
+
+def init_sgc_params(nfeat, nhid, nclass, ntrans):
+    """models/sgc.py:16-35 + models/base.py:44-49: one torch-CPU draw per layer, weight first."""
+    out = []
+    for a, b in layer_dims(nfeat, nhid, nclass, ntrans):
+        out += list(_uniform_linear(a, b))
+    return out
+
+
+def init_gcn_params(nfeat, nhid, nclass, nlayers=2):
+    """models/gcn.py:8-23."""
+    return init_sgc_params(nfeat, nhid, nclass, nlayers)
+
+
+def _nn_linear(fan_in, fan_out):
+    gain = math.sqrt(2.0 / (1 + math.sqrt(5) ** 2))          # kaiming_uniform_(a=sqrt(5)), as torch evaluates it
+    bound = math.sqrt(3.0) * (gain / math.sqrt(fan_in))
+    w = torch.empty(fan_out, fan_in).uniform_(-bound, bound)
+    b = torch.empty(fan_out).uniform_(-1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+    return w, b
+
+
+def pge_hidden(dataset, reduction_rate):
+    """models/parametrized_adj.py:9-17."""
+    if dataset in ("ogbn-arxiv", "arxiv", "flickr"):
+        return 256
+    if dataset == "reddit":
+        return 128 if reduction_rate == 0.01 else 256
+    return 128
+
+
+def init_pge_params(nfeat, nhid, nlayers=3):
+    """models/parametrized_adj.py:20-37,79-86: nn.Linear draws happen twice (constructor, then reset_parameters());
+    the second set remains.  Order = nn.Module.parameters(): layers.{0,1,2}.{weight,bias}, bns.{0,1}.{weight,bias}."""
+    dims = [(2 * nfeat, nhid)] + [(nhid, nhid)] * (nlayers - 2) + [(nhid, 1)]
+    for fi, fo in dims:
+        _nn_linear(fi, fo)
+    lin = []
+    for fi, fo in dims:
+        lin += list(_nn_linear(fi, fo))
+    bn = []
+    for _ in range(nlayers - 1):
+        bn += [torch.ones(nhid), torch.zeros(nhid)]
+    return lin + bn
+
+
+def seed_everything(seed):
+    """graphslim/utils.py:86-91."""
+    import os
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
