@@ -139,29 +139,54 @@ def blocks_to_batches(blk):
     return out
 
 
-def cpu_baseline(p, eng):
+def cpu_baseline(p, eng, timeout_s=300):
     """The oracle (a CPU port of the reference path, pinned against reference golden vectors) on a bounded sample:
-    1 warm-up + 1 timed outer iteration of the same workload, on the blocks the engine sampled, all host cores."""
-    from oracle import gcond_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    1 warm-up + 1 timed outer iteration of the same workload on the blocks the engine sampled.  Runs in a child
+    process (no GPU) with a hard time limit so that the default bench finishes within minutes."""
+    import subprocess
+    import tempfile
     eng.stage_sample()
     batches = blocks_to_batches(eng.get_blocks())
+    f = tempfile.NamedTemporaryFile(suffix=".pt", delete=False)
+    f.close()
+    torch.save({"batches": batches, "xs": eng.feat_syn.cpu(), "pge": [t.cpu().clone() for t in eng.get_pge()],
+                "workload": p["name"]}, f.name)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", f.name], env=env,
+                           capture_output=True, text=True, timeout=timeout_s)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if not line:
+            return {"value": None, "unit": "outer-iters/s", "cores": None, "kind": "port", "sample": "failed: " + r.stderr[-300:]}
+        return json.loads(line[-1])
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "outer-iters/s", "cores": None, "kind": "port",
+                "sample": f"did not finish 2 outer iterations within {timeout_s} s"}
+    finally:
+        os.unlink(f.name)
+
+
+def cpu_baseline_child(path):
+    from oracle import gcond_oracle as O
+    blob = torch.load(path, weights_only=False)
+    ncores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(ncores)
+    p = build_problem(blob["workload"], seed=1)
     d = p["data"].feat_full.shape[1]
-    xs = eng.feat_syn.cpu()
-    pge = [t.cpu().clone() for t in eng.get_pge()]
-    st = O.GCondState(xs, {"lin": pge[:6], "bn": pge[6:]}, torch.from_numpy(p["labels_syn"]), p["ncd"], p["data"].nclass,
-                      p["lrf"], p["lra"], 0.01, "SGC", 2)
+    pge = blob["pge"]
+    st = O.GCondState(blob["xs"], {"lin": pge[:6], "bn": pge[6:]}, torch.from_numpy(p["labels_syn"]), p["ncd"],
+                      p["data"].nclass, p["lrf"], p["lra"], 0.01, "SGC", 2)
     torch.manual_seed(0)
     st.new_epoch(O.init_sgc(d, p["hidden"], p["data"].nclass, p["T"]))
     X, Y = p["data"].feat_full, p["data"].labels_full
     times = []
     for _ in range(2):
         t0 = time.perf_counter()
-        st.outer_iteration(10, batches, X, Y, p["inner"])
+        st.outer_iteration(10, blob["batches"], X, Y, p["inner"])
         times.append(time.perf_counter() - t0)
-    return {"value": round(1.0 / times[-1], 4), "unit": "outer-iters/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 warm-up + 1 timed outer iteration of the same workload on identical engine-sampled blocks "
-                      f"(timed iteration {times[-1]:.2f} s; sampling excluded on the CPU side)"}
+    print(json.dumps({"value": round(1.0 / times[-1], 4), "unit": "outer-iters/s", "cores": ncores, "kind": "port",
+                      "sample": "1 warm-up + 1 timed outer iteration of the same workload on identical engine-sampled "
+                                f"blocks (timed iteration {times[-1]:.2f} s; neighbour sampling excluded on the CPU side)"}))
 
 
 def main():
@@ -172,7 +197,10 @@ def main():
     ap.add_argument("--workload", default="ogbn-arxiv", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink N for smoke runs (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args.cpu_baseline_child)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -52,7 +52,7 @@ struct gs_gcond {
   // real side
   gs_blocks blk;
   int *marker, *kcount;
-  float *H1full, *P0, *rs0, *Sr, *rsr, *Zr, *gw_real, *Tm, *Y1, *Bmat, *slabs_r;
+  float *H1full, *P0, *rs0, *Sr, *rsr, *Zr, *gw_real, *Tm, *Y1, *Bmat, *slabs_r, *colpart;
   // synthetic side
   float *adj_raw, *adj_norm, *rnorm, *Q, *rsq, *H1s, *Ss, *Zs, *Ps, *Gs, *gw_syn, *stats, *ab, *loss_c, *D, *Ug, *Vs, *dSs,
       *drs, *dQ, *dAn, *d_adj, *d_feat, *dH2, *dHp, *A1m, *Bc, *dH1m, *slabs_x;
@@ -111,7 +111,7 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   e->nsplit_r = gs_cdiv((long)e->cap1 * e->f2, e->kchunk_r);
   e->kchunk_w = 2048;
   e->nsplit_w = gs_cdiv((long)e->n * e->n, e->kchunk_w);
-  e->rows_per_block = 128;
+  e->rows_per_block = 512;
   e->nblk_stats = gs_cdiv((long)e->n * e->n, e->rows_per_block);
 }
 
@@ -127,6 +127,10 @@ static size_t carve(gs_gcond* e, void* base) {
   b.col0 = w.take<int>(C * cap1 * f2); b.val0 = w.take<float>(C * cap1 * f2);
   e->marker = e->cfg.external_blocks ? nullptr : w.take<int>(C * N);
   e->kcount = w.take<int>(C);
+  {
+    long nch = gs_cdiv(cap1 * f2, 256) > gs_cdiv(n, 256) ? gs_cdiv(cap1 * f2, 256) : gs_cdiv(n, 256);
+    e->colpart = w.take<float>(C * nch * (h > 0 ? h : 1));
+  }
   e->H1full = e->T == 2 ? w.take<float>(N * h) : nullptr;
   e->P0 = w.take<float>(C * cap1 * F); e->rs0 = w.take<float>(C * cap1);
   e->Sr = w.take<float>(C * bcap * F); e->rsr = w.take<float>(C * bcap);
@@ -296,6 +300,16 @@ extern "C" int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* b, gs_stream_t 
   return GS_OK;
 }
 
+// column sums of nbatch [rows x cols] matrices: chunked partials + fixed-order reduce (no atomics)
+static int colsum_batched(gs_gcond* e, const float* M, long batch_stride, int rows, const int* rows_b, int cols, int nbatch,
+                          float* out, long out_stride, gs_stream_t stream) {
+  const int chunk = 256, nchunk = gs_cdiv(rows, chunk);
+  hipLaunchKernelGGL(gs_colsum_chunks_kernel, dim3(nchunk, nbatch), dim3(256), 0, (hipStream_t)stream, M, batch_stride, rows,
+                     rows_b, cols, chunk, e->colpart);
+  GS_LAUNCH_CHECK();
+  return gs_reduce_slabs_batched_f32(out, out_stride, e->colpart, cols, nchunk, cols, nbatch, 0.f, stream);
+}
+
 // ================================================================================================
 // stage: sampling
 // ================================================================================================
@@ -380,9 +394,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     gw.sBb1 = K * h; gw.sCb1 = (long)e->nsplit_r * d * h; gw.sCb2 = (long)d * h;
     GS_TRY(gs_gemm_f32(&gw, stream));
     GS_TRY(gs_reduce_slabs_batched_f32(e->gw_real + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, C, 0.f, stream));
-    gs_gemm_desc gb = mk(e->ones, 0, 0, e->Bmat, h, 1, e->gw_real + e->ob1, h, 1, h, (int)K);
-    gb.nb1 = C; gb.Kb = e->kcount; gb.sBb1 = K * h; gb.sCb1 = P;
-    GS_TRY(gs_gemm_f32(&gb, stream));
+    GS_TRY(colsum_batched(e, e->Bmat, K * h, (int)K, e->kcount, h, C, e->gw_real + e->ob1, P, stream));
   }
   return GS_OK;
 }
@@ -407,7 +419,7 @@ extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_
     }
     GS_TRY(gs_gemm_f32(&g, stream));
   }
-  hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->U, e->V, pp + e->pb0, n, Ph, e->mu1,
+  hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 32)), dim3(256), 0, s, e->U, e->V, pp + e->pb0, n, Ph, e->mu1,
                      e->is1, e->sumU, e->sumV);
   hipLaunchKernelGGL(gs_pge_make_a1_kernel, dim3(gs_cdiv(n2 * Ph, 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0, e->mu1,
                      e->is1, pp + e->pg1, pp + e->pbe1, n, Ph, e->A1);
@@ -418,7 +430,7 @@ extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_
     GS_TRY(gs_gemm_f32(&g, stream));
   }
   hipLaunchKernelGGL(gs_col_stats_kernel, dim3(e->nblk_stats), dim3(256), 0, s, e->E2, n2, Ph, e->rows_per_block, e->parts);
-  hipLaunchKernelGGL(gs_bn2_finalize_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->parts, e->nblk_stats, n2, Ph, e->mu2,
+  hipLaunchKernelGGL(gs_bn2_finalize_kernel, dim3(gs_cdiv(Ph, 32)), dim3(256), 0, s, e->parts, e->nblk_stats, n2, Ph, e->mu2,
                      e->is2);
   hipLaunchKernelGGL(gs_pge_layer3_kernel, dim3(gs_cdiv(n2, 4)), dim3(256), 0, s, e->E2, e->mu2, e->is2, pp + e->pg2,
                      pp + e->pbe2, pp + e->pw2, pp + e->pb2, n2, Ph, e->e3);
@@ -489,9 +501,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     gs_gemm_desc c = mk(X, 1, d, e->dHp, h, 1, e->gw_syn + e->oW1, h, d, h, n);
     c.nb1 = C; c.sBb1 = (long)n * h; c.sCb1 = P;
     GS_TRY(gs_gemm_f32(&c, stream));
-    gs_gemm_desc cb = mk(e->ones, 0, 0, e->dHp, h, 1, e->gw_syn + e->ob1, h, 1, h, n);
-    cb.nb1 = C; cb.sBb1 = (long)n * h; cb.sCb1 = P;
-    GS_TRY(gs_gemm_f32(&cb, stream));
+    GS_TRY(colsum_batched(e, e->dHp, (long)n * h, n, nullptr, h, C, e->gw_syn + e->ob1, P, stream));
   }
   // ---- matching distance and D = d loss / d gw_syn (already scaled by n_c / n') -------------------
   hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, C), dim3(256), 0, s, e->gw_real, e->gw_syn, P, e->pd, e->stats);
@@ -584,7 +594,7 @@ extern "C" int gs_gcond_stage_pge_backward(gs_gcond* e, int need_param_grads, in
   hipLaunchKernelGGL(gs_pge_adj_bwd_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, e->d_adj, e->adj_raw, n, e->de3);
   hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(e->nblk_stats), dim3(256), 0, s, e->E2, e->de3, e->mu2, e->is2,
                      pp + e->pg2, pp + e->pbe2, pp + e->pw2, n2, Ph, e->rows_per_block, e->parts);
-  hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->parts, e->nblk_stats, 3, Ph, g + e->pw2,
+  hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 32), 3), dim3(256), 0, s, e->parts, e->nblk_stats, 3, Ph, g + e->pw2,
                      g + e->pbe2, g + e->pg2);
   hipLaunchKernelGGL(gs_pge_bn2_bwd_kernel, dim3(gs_cdiv(n2 * Ph, 256)), dim3(256), 0, s, e->E2, e->de3, e->mu2, e->is2,
                      pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, n2, Ph, e->dE2);
@@ -595,9 +605,9 @@ extern "C" int gs_gcond_stage_pge_backward(gs_gcond* e, int need_param_grads, in
     w.nb2 = e->nsplit_w; w.kchunk = e->kchunk_w; w.sCb2 = (long)Ph * Ph;
     GS_TRY(gs_gemm_f32(&w, stream));
     GS_TRY(gs_reduce_slabs_f32(g + e->pW1, e->slabs_w, (long)Ph * Ph, e->nsplit_w, (long)Ph * Ph, 0.f, stream));
-    hipLaunchKernelGGL(gs_rowsum_kernel, dim3(1), dim3(256), 0, s, e->de3, 1, (int)n2, g + e->pb2);   // db2 = sum de3
+    hipLaunchKernelGGL(gs_sum_kernel, dim3(1), dim3(1024), 0, s, e->de3, n2, g + e->pb2);   // db2 = sum de3
     hipLaunchKernelGGL(gs_col_stats_kernel, dim3(e->nblk_stats), dim3(256), 0, s, e->dE2, n2, Ph, e->rows_per_block, e->parts);
-    hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->parts, e->nblk_stats, 2, Ph, g + e->pb1,
+    hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 32), 1), dim3(256), 0, s, e->parts, e->nblk_stats, 2, Ph, g + e->pb1,
                        (float*)nullptr, (float*)nullptr);
     GS_LAUNCH_CHECK();
   }
@@ -608,7 +618,7 @@ extern "C" int gs_gcond_stage_pge_backward(gs_gcond* e, int need_param_grads, in
   }
   hipLaunchKernelGGL(gs_pge_marginal_r_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, e->colsum_r);
   hipLaunchKernelGGL(gs_pge_marginal_c_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, e->rowsum_c);
-  hipLaunchKernelGGL(gs_pge_bn1_bwd_cols_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->U, e->V, e->rowsum_c, e->colsum_r,
+  hipLaunchKernelGGL(gs_pge_bn1_bwd_cols_kernel, dim3(gs_cdiv(Ph, 32)), dim3(256), 0, s, e->U, e->V, e->rowsum_c, e->colsum_r,
                      pp + e->pb0, e->mu1, e->is1, n, Ph, g + e->pg1, g + e->pbe1);
   hipLaunchKernelGGL(gs_pge_bn1_bwd_uv_kernel, dim3(gs_cdiv((long)n * Ph, 256)), dim3(256), 0, s, e->U, e->V, e->rowsum_c,
                      e->colsum_r, pp + e->pb0, e->mu1, e->is1, pp + e->pg1, e->sumU, e->sumV, g + e->pg1, g + e->pbe1, n, Ph,
@@ -692,8 +702,7 @@ extern "C" int gs_gcond_stage_inner(gs_gcond* e, gs_stream_t stream) {
       GS_TRY(gs_gemm_f32(&dh, stream));
       gs_gemm_desc w1 = mk(X, 1, d, e->dH1m, h, 1, e->g_model + e->oW1, h, d, h, n);     // X^T dHp
       GS_TRY(gs_gemm_f32(&w1, stream));
-      gs_gemm_desc b1 = mk(e->ones, 0, 0, e->dH1m, h, 1, e->g_model + e->ob1, h, 1, h, n);
-      GS_TRY(gs_gemm_f32(&b1, stream));
+      GS_TRY(colsum_batched(e, e->dH1m, 0, n, nullptr, h, 1, e->g_model + e->ob1, 0, stream));
     }
     GS_TRY(gs_adam_step_f32(th, e->g_model, e->m_model, e->v_model, e->P, e->cfg.lr_model, 0.9f, 0.999f, 1e-8f, 0.f,
                             ++e->step_model, stream));

@@ -20,16 +20,117 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define GS_BK 16
-#define GS_PAD 4
+#define GS_KS 20   // row stride (floats) of a k-contiguous LDS image: 16-B aligned rows, conflict-free ds_read_b128
+#define GS_PAD 4   // pad of an m-contiguous LDS image [k][BM + 4]
 
-template <int BM, int BN, int WM, int WN>
+// operand access modes (chosen on the host from the strides)
+#define GS_MODE_K 0   // k contiguous in memory  -> global float4 along k, LDS [m][20], fragment = one ds_read_b128
+#define GS_MODE_M 1   // m contiguous in memory  -> global float4 along m, LDS [k][BM+4], fragment = 4 ds_read_b32
+#define GS_MODE_G 2   // anything else (scalar, clamped, branch-free)
+
+// Within a K tile of 16 the MFMA steps consume k in the order k = 8q + 4*(lane>>5) + t  (q = 0,1; t = 0..3): both
+// operands use the same permutation, so a k-contiguous operand gets its 4 values for t = 0..3 with one 16-byte read.
+
+template <int BMN, int MODE>
+struct TileLds {
+  static constexpr int SIZE = (MODE == GS_MODE_K) ? BMN * GS_KS : GS_BK * (BMN + GS_PAD);
+};
+
+// Loads one operand tile (BMN rows of the operand's "outer" dimension x 16 k) into registers.
+//   outer index o in [0, BMN) (+ o0), k in [k0, k0+16);  element(o, k) = base[row(o)*s_o + kidx(k)*s_k]
+// interior == true (block-uniform): every element in range and 16-byte vector loads are legal -> no selects.
+template <int BMN, int MODE>
+struct TileLoader {
+  static constexpr int UNITS = (MODE == GS_MODE_G) ? BMN * GS_BK : BMN * GS_BK / 4;   // float4 units or scalars
+  static constexpr int PER = (UNITS + 255) / 256;
+  float4 r4[(MODE == GS_MODE_G) ? 1 : PER];
+  float r1[(MODE == GS_MODE_G) ? PER : 1];
+
+  __device__ __forceinline__ void load(const float* __restrict__ base, long s_o, long s_k, const int* __restrict__ g_o,
+                                       const int* __restrict__ g_k, int o0, int n_o, int k0, int k_hi, bool interior, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * 256;
+      if (UNITS % 256 != 0 && u >= UNITS) break;
+      if (MODE == GS_MODE_K) {
+        const int o = u >> 2, kq = (u & 3) * 4;
+        const int go = min(o0 + o, n_o - 1);
+        const long ro = (g_o ? (long)g_o[go] : (long)go) * s_o;
+        if (interior) {
+          r4[i] = *reinterpret_cast<const float4*>(base + ro + (k0 + kq));
+        } else {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = k0 + kq + j;
+            const float x = base[ro + min(k, k_hi - 1)];
+            v[j] = (o0 + o < n_o && k < k_hi) ? x : 0.f;
+          }
+          r4[i] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else if (MODE == GS_MODE_M) {
+        constexpr int Q = BMN / 4;
+        const int k = u / Q, o4 = (u % Q) * 4;
+        const int gk = min(k0 + k, k_hi - 1);
+        const long rk = (g_k ? (long)g_k[gk] : (long)gk) * s_k;
+        if (interior) {
+          r4[i] = *reinterpret_cast<const float4*>(base + rk + (o0 + o4));
+        } else {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int o = o0 + o4 + j;
+            const float x = base[rk + min(o, n_o - 1)];
+            v[j] = (o < n_o && k0 + k < k_hi) ? x : 0.f;
+          }
+          r4[i] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+        const int o = u % BMN, k = u / BMN;
+        const int go = min(o0 + o, n_o - 1), gk = min(k0 + k, k_hi - 1);
+        const long a = (g_o ? (long)g_o[go] : (long)go) * s_o + (g_k ? (long)g_k[gk] : (long)gk) * s_k;
+        const float x = base[a];
+        r1[i] = (o0 + o < n_o && k0 + k < k_hi) ? x : 0.f;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * 256;
+      if (UNITS % 256 != 0 && u >= UNITS) break;
+      if (MODE == GS_MODE_K) {
+        *reinterpret_cast<float4*>(lds + (u >> 2) * GS_KS + (u & 3) * 4) = r4[i];
+      } else if (MODE == GS_MODE_M) {
+        constexpr int Q = BMN / 4;
+        *reinterpret_cast<float4*>(lds + (u / Q) * (BMN + GS_PAD) + (u % Q) * 4) = r4[i];
+      } else {
+        lds[(u / BMN) * (BMN + GS_PAD) + (u % BMN)] = r1[i];
+      }
+    }
+  }
+};
+
+// fragment of the 4 MFMA steps t = 0..3 of half-tile q for operand row `r`
+template <int BMN, int MODE>
+__device__ __forceinline__ void read_frag(const float* __restrict__ lds, int r, int q, int kh, float (&f)[4]) {
+  if (MODE == GS_MODE_K) {
+    const float4 v = *reinterpret_cast<const float4*>(lds + r * GS_KS + q * 8 + kh * 4);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f[t] = lds[(q * 8 + kh * 4 + t) * (BMN + GS_PAD) + r];
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-  constexpr int LA = BM * GS_BK / 256, LB = BN * GS_BK / 256;  // elements per thread per tile
-  __shared__ float As[GS_BK][BM + GS_PAD];
-  __shared__ float Bs[GS_BK][BN + GS_PAD];
+  __shared__ __attribute__((aligned(16))) float As[TileLds<BM, AMODE>::SIZE];
+  __shared__ __attribute__((aligned(16))) float Bs[TileLds<BN, BMODE>::SIZE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, b1 = b / p.nb2, b2 = b - b1 * p.nb2;
@@ -51,51 +152,21 @@ __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
   const int* gAk = p.gatherA_k ? p.gatherA_k + (long)b1 * p.sGb1 : nullptr;
   const int* gBk = p.gatherB_k ? p.gatherB_k + (long)b1 * p.sGb1 : nullptr;
 
-  // thread -> tile element mapping: contiguous lanes along the memory-contiguous dimension
-  const bool a_kfast = (p.sAk == 1 && !gAk);   // A rows contiguous in k
-  const bool b_kfast = (p.sBk == 1 && !gBk);   // B columns contiguous in k  (B given as [N][K])
-  float ra[LA], rb[LB];
+  // 16-byte vector loads are legal for this block?  (block-uniform)
+  bool vecA = (((uintptr_t)A & 15) == 0) && ((k_lo & 3) == 0);
+  if (AMODE == GS_MODE_K) vecA = vecA && ((p.sAm & 3) == 0);
+  if (AMODE == GS_MODE_M) vecA = vecA && ((p.sAk & 3) == 0);
+  bool vecB = (((uintptr_t)B & 15) == 0) && ((k_lo & 3) == 0);
+  if (BMODE == GS_MODE_K) vecB = vecB && ((p.sBn & 3) == 0);
+  if (BMODE == GS_MODE_M) vecB = vecB && ((p.sBk & 3) == 0);
+  const bool fullM = (m0 + BM <= M), fullN = (n0 + BN <= p.N);
 
+  TileLoader<BM, AMODE> la;
+  TileLoader<BN, BMODE> lb;
   auto load_tiles = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-      int e = tid + i * 256, m, k;
-      if (a_kfast) { k = e % GS_BK; m = e / GS_BK; } else { m = e % BM; k = e / BM; }
-      int gm = m0 + m, gk = k0 + k;
-      float v = 0.f;
-      if (gm < M && gk < k_hi) {
-        long im = gAm ? (long)gAm[gm] : (long)gm;
-        long ik = gAk ? (long)gAk[gk] : (long)gk;
-        v = A[im * p.sAm + ik * p.sAk];
-      }
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < LB; ++i) {
-      int e = tid + i * 256, n, k;
-      if (b_kfast) { k = e % GS_BK; n = e / GS_BK; } else { n = e % BN; k = e / BN; }
-      int gn = n0 + n, gk = k0 + k;
-      float v = 0.f;
-      if (gn < p.N && gk < k_hi) {
-        long ik = gBk ? (long)gBk[gk] : (long)gk;
-        v = B[ik * p.sBk + (long)gn * p.sBn];
-      }
-      rb[i] = v;
-    }
-  };
-  auto store_tiles = [&]() {
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-      int e = tid + i * 256, m, k;
-      if (a_kfast) { k = e % GS_BK; m = e / GS_BK; } else { m = e % BM; k = e / BM; }
-      As[k][m] = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < LB; ++i) {
-      int e = tid + i * 256, n, k;
-      if (b_kfast) { k = e % GS_BK; n = e / GS_BK; } else { n = e % BN; k = e / BN; }
-      Bs[k][n] = rb[i];
-    }
+    const bool fullK = (k0 + GS_BK <= k_hi);
+    la.load(A, p.sAm, p.sAk, gAm, gAk, m0, M, k0, k_hi, vecA && fullM && fullK, tid);
+    lb.load(B, p.sBn, p.sBk, nullptr, gBk, n0, p.N, k0, k_hi, vecB && fullN && fullK, tid);
   };
 
   f32x16 acc[TM][TN];
@@ -112,44 +183,61 @@ __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
   if (k_lo < k_hi) {
     load_tiles(k_lo);
     for (int k0 = k_lo; k0 < k_hi; k0 += GS_BK) {
-      store_tiles();
+      la.store(As, tid);
+      lb.store(Bs, tid);
       __syncthreads();
       if (k0 + GS_BK < k_hi) load_tiles(k0 + GS_BK);   // in flight under the MFMAs below
 #pragma unroll
-      for (int s = 0; s < GS_BK / 2; ++s) {
-        float a[TM], bb[TN];
+      for (int q = 0; q < 2; ++q) {
+        float a[TM][4], bb[TN][4];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = As[2 * s + kh][wm0 + i * 32 + li];
+        for (int i = 0; i < TM; ++i) read_frag<BM, AMODE>(As, wm0 + i * 32 + li, q, kh, a[i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bb[j] = Bs[2 * s + kh][wn0 + j * 32 + li];
+        for (int j = 0; j < TN; ++j) read_frag<BN, BMODE>(Bs, wn0 + j * 32 + li, q, kh, bb[j]);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], bb[j][t], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
     }
   }
 
-  // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // Optional inputs (bias / mask / old C) are fetched 16 at a time behind block-uniform branches with clamped
+  // addresses, so no load sits behind a per-element branch.
+  const bool has_bias = p.bias != nullptr, has_mask = p.mask != nullptr, has_beta = p.beta != 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn0 + j * 32 + li;
+      const int colc = min(col, p.N - 1);
+      const int rbase = m0 + wm0 + i * 32 + 4 * kh;
+      float bv = 0.f;
+      if (has_bias) bv = p.bias[(long)b1 * p.sbias_b1 + colc];
+      float mk[16], cv[16];
+      if (has_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mk[r] = p.mask[(long)min(rbase + (r & 3) + 8 * (r >> 2), M - 1) * p.ldmask + colc];
+      }
+      if (has_beta) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cv[r] = C[(long)min(rbase + (r & 3) + 8 * (r >> 2), M - 1) * p.ldc + colc];
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        int col = n0 + wn0 + j * 32 + li;
-        if (row < M && col < p.N) {
-          float v = p.alpha * acc[i][j][r];
-          if (p.bias) v += p.bias[(long)b1 * p.sbias_b1 + col];
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (p.mask) v = (p.mask[(long)row * p.ldmask + col] > 0.f) ? v : 0.f;
-          long ci = (long)row * p.ldc + col;
-          if (p.beta != 0.f) v += p.beta * C[ci];
-          C[ci] = v;
-        }
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        float v = p.alpha * acc[i][j][r] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (has_mask) v = (mk[r] > 0.f) ? v : 0.f;
+        if (has_beta) v += p.beta * cv[r];
+        if (row < M && col < p.N) C[(long)row * p.ldc + col] = v;
       }
+    }
 }
 
 __global__ void gs_reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, long n, int ns,
@@ -193,12 +281,23 @@ extern "C" int gs_reduce_slabs_batched_f32(float* out, long out_stride, const fl
   return GS_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_gemm(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int AM, int BMD>
+static int launch_gemm2(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
   dim3 grid(gs_cdiv(p.N, BN), gs_cdiv(p.M, BM), nbatch);
-  hipLaunchKernelGGL((gs_gemm_f32_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gs_gemm_f32_kernel<BM, BN, WM, WN, AM, BMD>), grid, dim3(256), 0, s, p);
   GS_LAUNCH_CHECK();
   return GS_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
+  int am = (p.sAk == 1 && !p.gatherA_k) ? GS_MODE_K : ((p.sAm == 1 && !p.gatherA_m) ? GS_MODE_M : GS_MODE_G);
+  int bm = (p.sBk == 1 && !p.gatherB_k) ? GS_MODE_K : ((p.sBn == 1) ? GS_MODE_M : GS_MODE_G);
+  if (am == GS_MODE_G || bm == GS_MODE_G) return launch_gemm2<BM, BN, WM, WN, GS_MODE_G, GS_MODE_G>(p, nbatch, s);
+  if (am == GS_MODE_K && bm == GS_MODE_K) return launch_gemm2<BM, BN, WM, WN, GS_MODE_K, GS_MODE_K>(p, nbatch, s);
+  if (am == GS_MODE_K && bm == GS_MODE_M) return launch_gemm2<BM, BN, WM, WN, GS_MODE_K, GS_MODE_M>(p, nbatch, s);
+  if (am == GS_MODE_M && bm == GS_MODE_K) return launch_gemm2<BM, BN, WM, WN, GS_MODE_M, GS_MODE_K>(p, nbatch, s);
+  return launch_gemm2<BM, BN, WM, WN, GS_MODE_M, GS_MODE_M>(p, nbatch, s);
 }
 
 extern "C" int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream) {

@@ -366,27 +366,45 @@ __global__ __launch_bounds__(256) void gs_make_bmat_kernel(const int* __restrict
 // PGE (models/parametrized_adj.py:40-71) with the layer-1 decomposition E1[r,c] = U[c] + V[r] + b0.
 // ------------------------------------------------------------------------------------------------
 // BN-1 batch statistics from U, V alone: mean = mean(U)+mean(V)+b0, var = var(U)+var(V) (biased), fp64.
-__global__ void gs_pge_bn1_stats_kernel(const float* __restrict__ U, const float* __restrict__ V,
-                                        const float* __restrict__ b0, int n, int Ph, float* __restrict__ mu1,
-                                        float* __restrict__ is1, float* __restrict__ sumU, float* __restrict__ sumV) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= Ph) return;
+// block = 32 columns x 8 row groups; two passes (mean, then centred squares) with an LDS reduction each.
+__global__ __launch_bounds__(256) void gs_pge_bn1_stats_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                               const float* __restrict__ b0, int n, int Ph,
+                                                               float* __restrict__ mu1, float* __restrict__ is1,
+                                                               float* __restrict__ sumU, float* __restrict__ sumV) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + tx;
+  __shared__ double sh[2][8][32];
   double su = 0, sv = 0;
-  for (int i = 0; i < n; ++i) {
-    su += U[(long)i * Ph + k];
-    sv += V[(long)i * Ph + k];
-  }
+  if (k < Ph)
+    for (int i = ty; i < n; i += 8) {
+      su += U[(long)i * Ph + k];
+      sv += V[(long)i * Ph + k];
+    }
+  sh[0][ty][tx] = su;
+  sh[1][ty][tx] = sv;
+  __syncthreads();
+  su = sv = 0;
+  for (int q = 0; q < 8; ++q) { su += sh[0][q][tx]; sv += sh[1][q][tx]; }
+  __syncthreads();
   const double mu = su / n, mv = sv / n;
   double vu = 0, vv = 0;
-  for (int i = 0; i < n; ++i) {
-    double a = U[(long)i * Ph + k] - mu, b = V[(long)i * Ph + k] - mv;
-    vu += a * a;
-    vv += b * b;
+  if (k < Ph)
+    for (int i = ty; i < n; i += 8) {
+      double a = U[(long)i * Ph + k] - mu, b = V[(long)i * Ph + k] - mv;
+      vu += a * a;
+      vv += b * b;
+    }
+  sh[0][ty][tx] = vu;
+  sh[1][ty][tx] = vv;
+  __syncthreads();
+  if (ty == 0 && k < Ph) {
+    vu = vv = 0;
+    for (int q = 0; q < 8; ++q) { vu += sh[0][q][tx]; vv += sh[1][q][tx]; }
+    mu1[k] = (float)(mu + mv + (double)b0[k]);
+    is1[k] = (float)(1.0 / sqrt(vu / n + vv / n + 1e-5));
+    sumU[k] = (float)su;
+    sumV[k] = (float)sv;
   }
-  mu1[k] = (float)(mu + mv + (double)b0[k]);
-  is1[k] = (float)(1.0 / sqrt(vu / n + vv / n + 1e-5));
-  sumU[k] = (float)su;
-  sumV[k] = (float)sv;
 }
 
 // A1[(r,c), k] = relu(g1 * (U[c,k] + V[r,k] + b0 - mu1) * is1 + be1)
@@ -419,19 +437,29 @@ __global__ __launch_bounds__(256) void gs_col_stats_kernel(const float* __restri
     part[((long)blockIdx.x * 2 + 1) * Ph + k] = s2;
   }
 }
-__global__ void gs_bn2_finalize_kernel(const double* __restrict__ part, int nblk, long rows, int Ph, float* __restrict__ mu2,
-                                       float* __restrict__ is2) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= Ph) return;
+// block = 32 columns x 8 groups of partial blocks
+__global__ __launch_bounds__(256) void gs_bn2_finalize_kernel(const double* __restrict__ part, int nblk, long rows, int Ph,
+                                                              float* __restrict__ mu2, float* __restrict__ is2) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + tx;
+  __shared__ double sh[2][8][32];
   double s = 0, s2 = 0;
-  for (int b = 0; b < nblk; ++b) {
-    s += part[((long)b * 2 + 0) * Ph + k];
-    s2 += part[((long)b * 2 + 1) * Ph + k];
+  if (k < Ph)
+    for (int b = ty; b < nblk; b += 8) {
+      s += part[((long)b * 2 + 0) * Ph + k];
+      s2 += part[((long)b * 2 + 1) * Ph + k];
+    }
+  sh[0][ty][tx] = s;
+  sh[1][ty][tx] = s2;
+  __syncthreads();
+  if (ty == 0 && k < Ph) {
+    s = s2 = 0;
+    for (int q = 0; q < 8; ++q) { s += sh[0][q][tx]; s2 += sh[1][q][tx]; }
+    double m = s / rows, v = s2 / rows - m * m;
+    if (v < 0) v = 0;
+    mu2[k] = (float)m;
+    is2[k] = (float)(1.0 / sqrt(v + 1e-5));
   }
-  double m = s / rows, v = s2 / rows - m * m;
-  if (v < 0) v = 0;
-  mu2[k] = (float)m;
-  is2[k] = (float)(1.0 / sqrt(v + 1e-5));
 }
 
 // e3[row] = sum_k relu(g2*(E2-mu2)*is2+be2) * w2[k] + b2      (one wave per pair)
@@ -501,15 +529,23 @@ __global__ __launch_bounds__(256) void gs_pge_l3_bwd_stats_kernel(const float* _
     part[((long)blockIdx.x * 3 + 2) * Ph + k] = sg;
   }
 }
-__global__ void gs_sum_parts_kernel(const double* __restrict__ part, int nblk, int nq, int Ph, float* __restrict__ out0,
-                                    float* __restrict__ out1, float* __restrict__ out2) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= Ph) return;
-  for (int q = 0; q < nq; ++q) {
-    double s = 0;
-    for (int b = 0; b < nblk; ++b) s += part[((long)b * nq + q) * Ph + k];
-    float* o = q == 0 ? out0 : (q == 1 ? out1 : out2);
-    if (o) o[k] = (float)s;
+// grid = (ceil(Ph/32), nq); block = 32 columns x 8 groups of partial blocks
+__global__ __launch_bounds__(256) void gs_sum_parts_kernel(const double* __restrict__ part, int nblk, int nq, int Ph,
+                                                           float* __restrict__ out0, float* __restrict__ out1,
+                                                           float* __restrict__ out2) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + tx, q = blockIdx.y;
+  __shared__ double sh[8][32];
+  double s = 0;
+  if (k < Ph)
+    for (int b = ty; b < nblk; b += 8) s += part[((long)b * nq + q) * Ph + k];
+  sh[ty][tx] = s;
+  __syncthreads();
+  float* o = q == 0 ? out0 : (q == 1 ? out1 : out2);
+  if (ty == 0 && k < Ph && o) {
+    s = 0;
+    for (int g = 0; g < 8; ++g) s += sh[g][tx];
+    o[k] = (float)s;
   }
 }
 // dE2[row,k] = g2*is2 * (dy2 - dbe2/N - xh2*dg2/N)
@@ -547,23 +583,34 @@ __global__ __launch_bounds__(256) void gs_pge_marginal_c_kernel(const float* __r
     rowsum_c[(long)c * Ph + k] = s;
   }
 }
-// BN-1 backward from the marginals: one thread per column k, then dU, dV (see oracle/analytic.py:pge_bwd)
-__global__ void gs_pge_bn1_bwd_cols_kernel(const float* __restrict__ U, const float* __restrict__ V,
-                                           const float* __restrict__ rowsum_c, const float* __restrict__ colsum_r,
-                                           const float* __restrict__ b0, const float* __restrict__ mu1,
-                                           const float* __restrict__ is1, int n, int Ph, float* __restrict__ dg1,
-                                           float* __restrict__ dbe1) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= Ph) return;
+// BN-1 backward from the marginals (see oracle/analytic.py:pge_bwd); block = 32 columns x 8 row groups
+__global__ __launch_bounds__(256) void gs_pge_bn1_bwd_cols_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                                  const float* __restrict__ rowsum_c,
+                                                                  const float* __restrict__ colsum_r,
+                                                                  const float* __restrict__ b0, const float* __restrict__ mu1,
+                                                                  const float* __restrict__ is1, int n, int Ph,
+                                                                  float* __restrict__ dg1, float* __restrict__ dbe1) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + tx;
+  __shared__ double sh[3][8][32];
   double sb = 0, su = 0, sv = 0;
-  for (int i = 0; i < n; ++i) {
-    float rc = rowsum_c[(long)i * Ph + k];
-    sb += rc;
-    su += (double)U[(long)i * Ph + k] * rc;
-    sv += (double)V[(long)i * Ph + k] * colsum_r[(long)i * Ph + k];
+  if (k < Ph)
+    for (int i = ty; i < n; i += 8) {
+      float rc = rowsum_c[(long)i * Ph + k];
+      sb += rc;
+      su += (double)U[(long)i * Ph + k] * rc;
+      sv += (double)V[(long)i * Ph + k] * colsum_r[(long)i * Ph + k];
+    }
+  sh[0][ty][tx] = sb;
+  sh[1][ty][tx] = su;
+  sh[2][ty][tx] = sv;
+  __syncthreads();
+  if (ty == 0 && k < Ph) {
+    sb = su = sv = 0;
+    for (int q = 0; q < 8; ++q) { sb += sh[0][q][tx]; su += sh[1][q][tx]; sv += sh[2][q][tx]; }
+    dbe1[k] = (float)sb;
+    dg1[k] = (float)((su + sv + ((double)b0[k] - (double)mu1[k]) * sb) * (double)is1[k]);
   }
-  dbe1[k] = (float)sb;
-  dg1[k] = (float)((su + sv + ((double)b0[k] - (double)mu1[k]) * sb) * (double)is1[k]);
 }
 __global__ void gs_pge_bn1_bwd_uv_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                          const float* __restrict__ rowsum_c, const float* __restrict__ colsum_r,
@@ -597,4 +644,37 @@ __global__ void gs_fill_kernel(float* __restrict__ p, long n, float v) {
 __global__ void gs_fill_int_kernel(int* __restrict__ p, long n, int v) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
+}
+
+// out[0] = sum_i x[i]   (one block of 1024 threads, fp64 accumulation)
+__global__ __launch_bounds__(1024) void gs_sum_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  double s = 0;
+  for (long i = threadIdx.x; i < n; i += 1024) s += x[i];
+  s = gs_wave_sum_d(s);
+  __shared__ double sh[16];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    out[0] = (float)t;
+  }
+}
+
+// batched column sums of [rows_b x cols] matrices: partial[b][chunk][k] = sum over the chunk's rows; the partials are
+// then summed in fixed order by gs_reduce_slabs_batched_f32.  grid = (nchunk, nbatch), rows of batch b limited by
+// rows_b[b] (device) when given.
+__global__ __launch_bounds__(256) void gs_colsum_chunks_kernel(const float* __restrict__ M, long batch_stride, int rows,
+                                                               const int* __restrict__ rows_b, int cols, int chunk,
+                                                               float* __restrict__ partial) {
+  const int b = blockIdx.y;
+  const int nr = rows_b ? min(rows, rows_b[b]) : rows;
+  const int r0 = blockIdx.x * chunk, r1 = min(nr, r0 + chunk);
+  const float* m = M + (long)b * batch_stride;
+  float* o = partial + ((long)b * gridDim.x + blockIdx.x) * cols;
+  for (int k = threadIdx.x; k < cols; k += 256) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += m[(long)r * cols + k];
+    o[k] = s;
+  }
 }
