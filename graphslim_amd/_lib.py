@@ -57,7 +57,7 @@ SYMBOLS = [
     "gs_gcond_set_blocks", "gs_gcond_outer_step", "gs_gcond_read_loss", "gs_gcond_stage_sample",
     "gs_gcond_stage_real_grads", "gs_gcond_stage_pge_forward", "gs_gcond_stage_syn_match",
     "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer",
-    "gs_gcond_get_blocks",
+    "gs_gcond_get_blocks", "gs_bias_act_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
 ]
 
 
@@ -85,6 +85,10 @@ def lib():
     L.gs_dense_gcn_norm_fwd.argtypes = [vp, i, vp, vp, vp]
     L.gs_dense_gcn_norm_bwd.argtypes = [vp, vp, vp, i, vp, vp]
     L.gs_adam_step_f32.argtypes = [vp, vp, vp, vp, l, f, f, f, f, f, i, vp]
+    L.gs_bias_act_f32.argtypes = [vp, l, vp, l, i, i, vp]
+    L.gs_softmax_nll_grad_f32.argtypes = [vp, l, vp, l, i, vp, vp, vp]
+    L.gs_colsum_f32.argtypes = [vp, l, l, i, vp, vp]
+    L.gs_count_correct.argtypes = [vp, l, i, vp, vp, l, vp, vp]
     L.gs_gcond_workspace_bytes.argtypes = [C.POINTER(GCondConfig), C.POINTER(C.c_size_t)]
     L.gs_gcond_create.argtypes = [C.POINTER(GCondConfig), C.POINTER(GCondIO), vp, C.POINTER(vp)]
     L.gs_gcond_new_epoch.argtypes = [vp, vp]

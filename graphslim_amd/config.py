@@ -1,0 +1,162 @@
+"""Command line / configuration of the reference (graphslim/config.py) for the GCond path: same flags, same precedence
+(click defaults < configs/<method>/<dataset>.json < setting_config < explicit command-line values), same derived fields
+(setting, metric, run_inter_eval, eval_interval, checkpoints, eval_epochs, device, logger)."""
+import json
+import logging
+import os
+from pprint import pformat
+
+import click
+
+from .utils import accuracy, seed_everything  # noqa: F401
+
+
+class Obj(object):
+    def __init__(self, dict_):
+        self.__dict__.update(dict_)
+
+    def __repr__(self):
+        return pformat(self.__dict__, compact=True)
+
+
+def dict2obj(d):
+    return json.loads(json.dumps(d), object_hook=Obj)
+
+
+def update_from_dict(obj, updates):
+    for key, value in updates.items():
+        if key in ["init"] and obj.init is not None:      # command line keeps priority for the init method
+            continue
+        setattr(obj, key, value)
+
+
+def setting_config(args):
+    """config.py:209-236."""
+    representative_r = {"cora": 0.5, "citeseer": 0.5, "flickr": 0.01, "reddit": 0.001, "ogbn-arxiv": 0.01, "yelp": 0.001,
+                        "amazon": 0.002, "pubmed": 0.1}
+    if args.reduction_rate == -1:
+        args.reduction_rate = representative_r[args.dataset]
+    if args.dataset in ["cora", "citeseer", "pubmed", "ogbn-arxiv"]:
+        args.setting = "trans"
+    if args.dataset in ["flickr", "reddit", "amazon", "yelp"]:
+        args.setting = "ind"
+    if args.dataset in ["yelp", "amazon"]:
+        raise NotImplementedError("graphslim_amd: multi-label datasets (f1 metric) are outside the built path")
+    args.metric = accuracy
+    args.run_inter_eval = 3
+    args.eval_interval = args.epochs // 10
+    args.checkpoints = list(range(-1, args.epochs + 1, args.eval_interval))     # epochs < 10 -> ValueError, as upstream
+    args.eval_epochs = 300
+    return args
+
+
+def method_config(args):
+    """config.py:240-257."""
+    try:
+        path = os.path.join(os.path.dirname(__file__), "configs", args.method, args.dataset) + ".json"
+        conf = json.load(open(path))
+        update_from_dict(args, conf)
+        args._method_config_keys = set(conf.keys())
+    except Exception:
+        print("No config file found or error in json format, please use method_config(args)")
+    return args
+
+
+def _table(args):
+    rows = sorted((k, getattr(v, "__name__", v) if callable(v) else v) for k, v in args.__dict__.items()
+                  if not k.startswith("_") and k != "logger")
+    w = max(len(k) for k, _ in rows)
+    return "\n".join(f"| {k.ljust(w)} | {v}" for k, v in rows)
+
+
+_MODELS = ["GCN", "GAT", "SGC", "APPNP", "Cheby", "GraphSage", "SGFormer"]
+_INITS = ["variation_neighborhoods", "variation_edges", "variation_cliques", "heavy_edge", "algebraic_JC", "affinity_GS",
+          "kron", "vng", "clustering", "averaging", "cent_d", "cent_p", "kcenter", "herding", "random"]
+
+
+@click.command()
+@click.option("--dataset", "-D", default="cora", show_default=True)
+@click.option("--method", "-M", default="kcenter", show_default=True)
+@click.option("--gpu_id", "-G", default=0, help="gpu id start from 0, -1 means cpu", show_default=True)
+@click.option("--setting", type=click.Choice(["trans", "ind"]), show_default=True)
+@click.option("--split", default="fixed", show_default=True)
+@click.option("--run_reduction", default=3, show_default=True)
+@click.option("--run_eval", default=10, show_default=True)
+@click.option("--run_inter_eval", default=5, show_default=True)
+@click.option("--eval_interval", default=100, show_default=True)
+@click.option("--hidden", "-H", default=256, show_default=True)
+@click.option("--condense_model", default="SGC", type=click.Choice(_MODELS[:6]), show_default=True)
+@click.option("--epochs", "-E", default=1000, show_default=True)
+@click.option("--agg", is_flag=True, show_default=True)
+@click.option("--multi_label", is_flag=True, show_default=True)
+@click.option("--dis_metric", default="ours", show_default=True)
+@click.option("--lr_adj", default=1e-4, show_default=True)
+@click.option("--lr_feat", default=1e-4, show_default=True)
+@click.option("--optim", default="Adam", show_default=True)
+@click.option("--threshold", default=0.0, show_default=True)
+@click.option("--dropout", default=0.0, show_default=True)
+@click.option("--ntrans", default=1, show_default=True)
+@click.option("--with_bn", is_flag=True, show_default=True)
+@click.option("--save_path", "--sp", default="../checkpoints", show_default=True)
+@click.option("--load_path", "--lp", default="./data", show_default=True)
+@click.option("--eval_whole", "-W", is_flag=True, show_default=True)
+@click.option("--with_structure", default=1, show_default=True)
+@click.option("--lr", default=0.01, show_default=True)
+@click.option("--weight_decay", "--wd", default=0.0, show_default=True)
+@click.option("--pre_norm", default=True, show_default=True)
+@click.option("--outer_loop", default=10, show_default=True)
+@click.option("--inner_loop", default=1, show_default=True)
+@click.option("--reduction_rate", "-R", default=-1.0, show_default=True)
+@click.option("--seed", "-S", default=1, show_default=True)
+@click.option("--nlayers", default=2, show_default=True)
+@click.option("--verbose", "-V", is_flag=True, show_default=True)
+@click.option("--soft_label", default=0, show_default=True)
+@click.option("--wandb", is_flag=True, show_default=True)
+@click.option("--wandb_project", default="graphslim", show_default=True)
+@click.option("--wandb_run_name", default=None)
+@click.option("--wandb_required", is_flag=True, show_default=True)
+@click.option("--init", default="random", type=click.Choice(_INITS), show_default=True)
+@click.option("--eval_epochs", "--ee", default=300, show_default=True)
+@click.option("--eval_model", "--em", default="GCN", type=click.Choice(_MODELS), show_default=True)
+@click.option("--eval_wd", "--ewd", default=0.0, show_default=True)
+@click.option("--eval_loss", "--eloss", default="CE", type=click.Choice(["CE", "KLD", "MSE"]), show_default=True)
+@click.option("--activation", default="relu", show_default=True)
+@click.option("--alpha", default=0.1, show_default=True)
+@click.option("--ptb_r", "-P", default=0.25, show_default=True)
+@click.option("--attack", "-A", default=None, type=click.Choice(["random_adj", "metattack", "random_feat"]))
+@click.pass_context
+def cli(ctx, **kwargs):
+    """config.py:363-399."""
+    args = dict2obj(kwargs)
+    if args.gpu_id >= 0:
+        # the reference narrows CUDA_VISIBLE_DEVICES and then addresses cuda:<gpu_id>; keep its device string
+        args.device = f"cuda:{args.gpu_id}"
+        try:
+            import torch
+            torch.cuda.set_device(args.gpu_id)
+        except Exception:
+            pass
+    else:
+        args.device = "cpu"
+    path = args.save_path
+    args = method_config(args)
+    args = setting_config(args)
+    for key, value in ctx.params.items():
+        if ctx.get_parameter_source(key) == click.core.ParameterSource.COMMANDLINE:
+            setattr(args, key, value)
+    os.makedirs(f"{path}/logs/{args.method}", exist_ok=True)
+    logging.basicConfig(filename=f"{path}/logs/{args.method}/{args.dataset}_{args.reduction_rate}.log", level=logging.INFO,
+                        format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
+    args.logger = logging.getLogger(__name__)
+    table = _table(args)
+    args.logger.info("Resolved configuration:\n%s", table)
+    click.echo(table)
+    return args
+
+
+def get_args():
+    return cli(standalone_mode=False)
+
+
+if __name__ == "__main__":
+    cli()

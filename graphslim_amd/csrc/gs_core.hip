@@ -253,3 +253,119 @@ extern "C" int gs_adam_step_f32(float* param, const float* grad, float* m, float
   GS_LAUNCH_CHECK();
   return GS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Pieces of the evaluation GCN (models/base.py:51-78,80-187, layers.py:36-51): bias + ReLU in place,
+// log-softmax / NLL gradient, column sums, argmax accuracy count.
+// ------------------------------------------------------------------------------------------------
+__global__ void gs_bias_act_kernel(float* __restrict__ X, long ld, const float* __restrict__ bias, long n, int F, int relu) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * F) return;
+  const long i = idx / F;
+  const int k = (int)(idx - i * F);
+  float v = X[i * ld + k] + (bias ? bias[k] : 0.f);
+  X[i * ld + k] = relu ? fmaxf(v, 0.f) : v;
+}
+
+extern "C" int gs_bias_act_f32(float* X, long ld, const float* bias, long n, int F, int relu, gs_stream_t stream) {
+  if (n <= 0 || F <= 0) return GS_OK;
+  if (!X || ld < F) GS_FAIL(GS_ERR_ARG, "gs_bias_act_f32: bad argument");
+  hipLaunchKernelGGL(gs_bias_act_kernel, dim3(gs_cdiv(n * F, 256)), dim3(256), 0, (hipStream_t)stream, X, ld, bias, n, F, relu);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// G[i,:] = (softmax(Z[i,:]) - onehot(labels[i])) / n ; loss_rows[i] = -log_softmax(Z[i])[label]   (F.nll_loss mean)
+__global__ __launch_bounds__(256) void gs_softmax_nll_grad_kernel(const float* __restrict__ Z, long ldz,
+                                                                  const int* __restrict__ labels, long n, int C,
+                                                                  float* __restrict__ G, float* __restrict__ loss_rows) {
+  const int lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n) return;
+  const float* z = Z + i * ldz;
+  const int y = labels[i];
+  float mx = -INFINITY;
+  for (int k = lane; k < C; k += 64) mx = fmaxf(mx, z[k]);
+  mx = gs_wave_max(mx);
+  float se = 0.f;
+  for (int k = lane; k < C; k += 64) se += expf(z[k] - mx);
+  se = gs_wave_sum(se);
+  const float inv = 1.f / se, invn = 1.f / (float)n;
+  for (int k = lane; k < C; k += 64) {
+    float p = expf(z[k] - mx) * inv;
+    if (G) G[i * C + k] = (p - (k == y ? 1.f : 0.f)) * invn;
+  }
+  if (lane == 0 && loss_rows) loss_rows[i] = -(z[y] - mx - logf(se));
+}
+
+extern "C" int gs_softmax_nll_grad_f32(const float* Z, long ldz, const int* labels, long n, int C, float* G,
+                                       float* loss_rows, gs_stream_t stream) {
+  if (n <= 0 || C <= 0) return GS_OK;
+  if (!Z || !labels || ldz < C) GS_FAIL(GS_ERR_ARG, "gs_softmax_nll_grad_f32: bad argument");
+  hipLaunchKernelGGL(gs_softmax_nll_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, Z, ldz, labels, n, C, G,
+                     loss_rows);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// out[k] = sum_i M[i*ld + k]  (fp64 accumulation; block = 32 columns x 8 row groups)
+__global__ __launch_bounds__(256) void gs_colsum_kernel(const float* __restrict__ M, long ld, long rows, int cols,
+                                                        float* __restrict__ out) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + tx;
+  __shared__ double sh[8][32];
+  double s = 0;
+  if (k < cols)
+    for (long i = ty; i < rows; i += 8) s += M[i * ld + k];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && k < cols) {
+    s = 0;
+    for (int q = 0; q < 8; ++q) s += sh[q][tx];
+    out[k] = (float)s;
+  }
+}
+
+extern "C" int gs_colsum_f32(const float* M, long ld, long rows, int cols, float* out, gs_stream_t stream) {
+  if (cols <= 0) return GS_OK;
+  if (!M || !out || ld < cols) GS_FAIL(GS_ERR_ARG, "gs_colsum_f32: bad argument");
+  hipLaunchKernelGGL(gs_colsum_kernel, dim3(gs_cdiv(cols, 32)), dim3(256), 0, (hipStream_t)stream, M, ld, rows, cols, out);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// count[0] += #{ i : argmax_k Z[idx[i], k] == labels[i] }   (graphslim/utils.py:516-538; first maximum wins like torch.max)
+__global__ __launch_bounds__(256) void gs_count_correct_kernel(const float* __restrict__ Z, long ldz, int C,
+                                                               const int* __restrict__ idx, const int* __restrict__ labels,
+                                                               long n, int* __restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int ok = 0;
+  if (i < n) {
+    const float* z = Z + (long)(idx ? idx[i] : i) * ldz;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int k = lane; k < C; k += 64) {
+      float v = z[k];
+      if (v > best) { best = v; arg = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ob = __shfl_xor(best, o, 64);
+      int oa = __shfl_xor(arg, o, 64);
+      if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    ok = (lane == 0 && arg == labels[i]) ? 1 : 0;
+  }
+  if (ok) atomicAdd(count, 1);     // integer atomics: order-independent
+}
+
+extern "C" int gs_count_correct(const float* Z, long ldz, int C, const int* idx, const int* labels, long n, int* count,
+                                gs_stream_t stream) {
+  if (n <= 0) return GS_OK;
+  if (!Z || !labels || !count || C <= 0) GS_FAIL(GS_ERR_ARG, "gs_count_correct: bad argument");
+  hipLaunchKernelGGL(gs_count_correct_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, Z, ldz, C, idx, labels, n,
+                     count);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

@@ -1,0 +1,225 @@
+"""Evaluation GCN of the reference (graphslim/models/gcn.py + models/base.py + models/layers.py:17-51), with every
+tensor operation executed by libgslim_hip.so (gs_gemm_f32 on the matrix cores, gs_spmm_csr_f32 for the full-graph
+aggregation, gs_adam_step_f32, ...).  This module is host-side orchestration: same constructor and method names,
+argument meaning and return values as the reference's `GCN`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from .. import _lib, host
+from .._lib import check, ptr, stream
+from ..engine import adam_step, dense_gcn_norm_fwd, gemm, spmm_csr
+
+
+def _dev_csr(adj, device):
+    """normalize_adj_tensor(adj, sparse=True) (utils.py:403-413) -> device CSR of the normalised matrix."""
+    rp, col, val = host.normalize_adj_sparse(adj)
+    i32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int32).to(device)
+    return i32(rp), i32(col), torch.as_tensor(val, dtype=torch.float32).to(device)
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class GCN:
+    """2-layer GCN: per layer adj @ (x @ W) + b, ReLU between, log_softmax (models/base.py:51-78)."""
+
+    def __init__(self, nfeat, nhid, nclass, args, mode="train"):
+        if getattr(args, "nlayers", 2) != 2:
+            raise NotImplementedError("graphslim_amd.GCN: only nlayers = 2 (the GCond evaluation configuration)")
+        if getattr(args, "with_bn", False):
+            raise NotImplementedError("graphslim_amd.GCN: with_bn is outside the built path")
+        if not str(args.device).startswith("cuda"):
+            raise RuntimeError("graphslim_amd has no CPU path: run with a GPU (-G 0)")
+        self.args = args
+        self.device = torch.device(args.device)
+        self.nfeat, self.nhid, self.nclass = nfeat, nhid, nclass
+        self.lr = args.lr
+        self.weight_decay = args.weight_decay
+        self.dropout = args.dropout
+        if mode == "eval":                      # models/base.py:28-30
+            self.dropout = 0
+            self.weight_decay = 5e-4
+        if self.dropout != 0:
+            raise NotImplementedError("graphslim_amd.GCN: dropout > 0 is outside the built path")
+        self.metric = args.metric
+        self.sizes = [nfeat * nhid, nhid, nhid * nclass, nclass]
+        self.P = torch.zeros(sum(self.sizes), dtype=torch.float32, device=self.device)
+        self.ldc = _pad4(nclass)
+        self.initialize()
+
+    # -- parameters -----------------------------------------------------------------------------------
+    def initialize(self):
+        """models/base.py:44-49 -> GraphConvolution.reset_parameters (layers.py:29-33): torch-CPU draws, W then b."""
+        ps = host.init_gcn_params(self.nfeat, self.nhid, self.nclass, 2)
+        self.P.copy_(torch.cat([p.reshape(-1) for p in ps]).to(self.device))
+
+    def _views(self, flat):
+        o, out = 0, []
+        for n, shp in zip(self.sizes, [(self.nfeat, self.nhid), (self.nhid,), (self.nhid, self.nclass), (self.nclass,)]):
+            out.append(flat[o:o + n].view(shp))
+            o += n
+        return out
+
+    def parameters(self):
+        return self._views(self.P)
+
+    def state_dict(self):
+        return {"flat": self.P.clone()}
+
+    def load_state_dict(self, sd):
+        self.P.copy_(sd["flat"])
+
+    def eval(self):
+        return self
+
+    def train(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    # -- forward passes -------------------------------------------------------------------------------
+    def _forward_sparse(self, X, csr):
+        """Full graph: Z = A (relu(A (X W1) + b1) W2) + b2.  X [N, ld] (row stride may be padded)."""
+        W1, b1, W2, b2 = self.parameters()
+        N, d, h, Cn, ldc = X.shape[0], self.nfeat, self.nhid, self.nclass, self.ldc
+        dev = self.device
+        T1 = torch.empty(N, h, device=dev)
+        gemm(X, W1, T1, N, h, d, (X.stride(0), 1), (h, 1), h)
+        H = spmm_csr(*csr, T1)
+        check(_lib.lib().gs_bias_act_f32(ptr(H), h, ptr(b1), N, h, 1, stream()))
+        T2 = torch.zeros(N, ldc, device=dev)
+        gemm(H, W2, T2, N, Cn, h, (h, 1), (Cn, 1), ldc)
+        Z = torch.zeros(N, ldc, device=dev)
+        spmm_csr(*csr, T2, F=ldc, out=Z)
+        check(_lib.lib().gs_bias_act_f32(ptr(Z), ldc, ptr(b2), N, Cn, 0, stream()))
+        return Z      # logits, row stride ldc
+
+    def _train_step_dense(self, X, A, labels_i32, opt):
+        """One optimisation step on the condensed graph (models/base.py:156-161) with dense A^ [n, n]."""
+        W1, b1, W2, b2 = self.parameters()
+        n, d, h, Cn = X.shape[0], self.nfeat, self.nhid, self.nclass
+        dev = self.device
+        L = _lib.lib()
+        T1 = torch.empty(n, h, device=dev)
+        gemm(X, W1, T1, n, h, d, (d, 1), (h, 1), h)
+        H = torch.empty(n, h, device=dev)
+        gemm(A, T1, H, n, h, n, (n, 1), (h, 1), h, bias=b1, relu=1)
+        T2 = torch.empty(n, Cn, device=dev)
+        gemm(H, W2, T2, n, Cn, h, (h, 1), (Cn, 1), Cn)
+        Z = torch.empty(n, Cn, device=dev)
+        gemm(A, T2, Z, n, Cn, n, (n, 1), (Cn, 1), Cn, bias=b2)
+        G = torch.empty(n, Cn, device=dev)
+        lossr = torch.empty(n, device=dev)
+        check(L.gs_softmax_nll_grad_f32(ptr(Z), Cn, ptr(labels_i32), n, Cn, ptr(G), ptr(lossr), stream()))
+        g = torch.empty_like(self.P)
+        gW1, gb1, gW2, gb2 = self._views(g)
+        check(L.gs_colsum_f32(ptr(G), Cn, n, Cn, ptr(gb2), stream()))
+        dT2 = torch.empty(n, Cn, device=dev)
+        gemm(A, G, dT2, n, Cn, n, (1, n), (Cn, 1), Cn)                     # A^T G
+        gemm(H, dT2, gW2, h, Cn, n, (1, h), (Cn, 1), Cn)                   # H^T dT2
+        dH = torch.empty(n, h, device=dev)
+        gemm(dT2, W2, dH, n, h, Cn, (Cn, 1), (1, Cn), h, mask=H, ldmask=h)  # (dT2 W2^T) * [H > 0]
+        check(L.gs_colsum_f32(ptr(dH), h, n, h, ptr(gb1), stream()))
+        dT1 = torch.empty(n, h, device=dev)
+        gemm(A, dH, dT1, n, h, n, (1, n), (h, 1), h)                       # A^T dH
+        gemm(X, dT1, gW1, d, h, n, (1, d), (h, 1), h)                      # X^T dT1
+        opt["step"] += 1
+        adam_step(self.P, g, opt["m"], opt["v"], opt["lr"], opt["step"], weight_decay=self.weight_decay)
+        return lossr
+
+    def _new_opt(self, lr):
+        return {"m": torch.zeros_like(self.P), "v": torch.zeros_like(self.P), "step": 0, "lr": lr}
+
+    def _accuracy(self, Z, idx_i32, labels_i32):
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        n = labels_i32.numel()
+        check(_lib.lib().gs_count_correct(ptr(Z), Z.stride(0), self.nclass, ptr(idx_i32), ptr(labels_i32), n, ptr(cnt), stream()))
+        return int(cnt.item()) / n
+
+    # -- reference API ----------------------------------------------------------------------------------
+    def _graph_for(self, data, which):
+        """Device copies (cached on the data object) of a split's features and normalised CSR."""
+        cache = data.__dict__.setdefault("_gs_dev", {})
+        key = (which, str(self.device))
+        if key not in cache:
+            feat = {"full": data.feat_full, "val": data.feat_val, "test": data.feat_test, "train": data.feat_train}[which]
+            adj = {"full": data.adj_full, "val": data.adj_val, "test": data.adj_test, "train": data.adj_train}[which]
+            X = torch.zeros(feat.shape[0], _pad4(feat.shape[1]), device=self.device)
+            X[:, :feat.shape[1]] = feat.to(self.device, torch.float32)
+            cache[key] = (X, _dev_csr(adj, self.device))
+        return cache[key]
+
+    def fit_with_val(self, data, train_iters=600, verbose=False, normadj=True, setting="trans", reduced=False,
+                     final_output=False, best_val=None, **kwargs):
+        """models/base.py:80-187 for the reduced-graph case: train on (adj_syn, feat_syn, labels_syn), validate on the
+        full graph (trans) / validation graph (ind) every epoch, keep the best-validation weights."""
+        if not reduced:
+            raise NotImplementedError("graphslim_amd.GCN.fit_with_val: only reduced=True (GCond evaluation) is built")
+        dev = self.device
+        self.initialize()
+        adj = torch.as_tensor(data.adj_syn).to(dev, torch.float32).contiguous()
+        feat = torch.as_tensor(data.feat_syn).to(dev, torch.float32).contiguous()
+        labels = torch.as_tensor(data.labels_syn).to(dev).to(torch.int32)
+        if normadj or True:          # base.py:112 normalises the (dense) synthetic adjacency unconditionally
+            adj, _ = dense_gcn_norm_fwd(adj)
+        labels_val = data.labels_val.to(dev).to(torch.int32)
+        if setting == "ind":
+            Xv, csr = self._graph_for(data, "val")
+            idx_val = None
+        else:
+            Xv, csr = self._graph_for(data, "full")
+            idx_val = data.idx_val.to(dev).to(torch.int32)
+        best_acc = 0 if best_val is None else best_val
+        weights = None
+        opt = self._new_opt(self.lr)
+        for i in range(train_iters):
+            if i == train_iters // 2 and self.lr > 0.001:           # base.py:153-154
+                opt = self._new_opt(self.lr * 0.1)
+            lossr = self._train_step_dense(feat, adj, labels, opt)
+            if verbose and i % 100 == 0:
+                print("Epoch {}, training loss: {}".format(i, float(lossr.mean())))
+            acc_val = self._accuracy(self._forward_sparse(Xv, csr), idx_val, labels_val)
+            if acc_val > best_acc:
+                best_acc = acc_val
+                weights = self.state_dict()
+        if final_output:
+            return
+        if weights is not None:
+            self.load_state_dict(weights)
+        return float(best_acc)
+
+    @torch.no_grad()
+    def test(self, data, setting="trans", verbose=False):
+        """models/base.py:190-215."""
+        dev = self.device
+        labels_test = torch.as_tensor(data.labels_test).to(dev).to(torch.int32)
+        if setting == "ind":
+            X, csr = self._graph_for(data, "test")
+            idx = None
+        else:
+            X, csr = self._graph_for(data, "full")
+            idx = data.idx_test.to(dev).to(torch.int32)
+        Z = self._forward_sparse(X, csr)
+        acc = self._accuracy(Z, idx, labels_test)
+        if verbose:
+            print("Test set results:", "accuracy= {:.4f}".format(acc))
+        return acc
+
+    @torch.no_grad()
+    def predict(self, features=None, adj=None, normadj=True, output_layer_features=False):
+        """models/base.py:218-225: log-probabilities [N, C] for a (features, scipy adjacency) pair."""
+        dev = self.device
+        X = torch.zeros(features.shape[0], _pad4(features.shape[1]), device=dev)
+        X[:, :features.shape[1]] = torch.as_tensor(features).to(dev, torch.float32)
+        if not sp.issparse(adj):
+            raise NotImplementedError("graphslim_amd.GCN.predict expects a scipy sparse adjacency")
+        Z = self._forward_sparse(X, _dev_csr(adj, dev))[:, :self.nclass]
+        return torch.log_softmax(Z, dim=1)       # presentation only; accuracy paths use the logits directly

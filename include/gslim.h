@@ -130,6 +130,22 @@ int gs_adam_step_f32(float* param, const float* grad, float* m, float* v, long n
                      float eps, float weight_decay, int step, gs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Pieces of the evaluation GCN (models/gcn.py, models/layers.py:36-51 GraphConvolution, models/base.py:80-225
+ * fit_with_val / test / predict, graphslim/utils.py:516-538 accuracy).  The trainer itself is host-side
+ * orchestration (graphslim_amd/models/gcn.py) over gs_gemm_f32, gs_spmm_csr_f32, gs_adam_step_f32 and these.
+ * ------------------------------------------------------------------------------------------- */
+/* X[i,k] = act(X[i,k] + bias[k]) in place (bias may be NULL). */
+int gs_bias_act_f32(float* X, long ld, const float* bias, long n, int F, int relu, gs_stream_t stream);
+/* G = (softmax(Z) - onehot(labels)) / n (may be NULL);  loss_rows[i] = -log_softmax(Z[i])[labels[i]] (may be NULL). */
+int gs_softmax_nll_grad_f32(const float* Z, long ldz, const int* labels, long n, int C, float* G, float* loss_rows,
+                            gs_stream_t stream);
+/* out[k] = sum_i M[i*ld + k] (fp64 accumulation). */
+int gs_colsum_f32(const float* M, long ld, long rows, int cols, float* out, gs_stream_t stream);
+/* count[0] += #{i < n : argmax_k Z[idx[i]][k] == labels[i]}  (idx may be NULL = identity). */
+int gs_count_correct(const float* Z, long ldz, int C, const int* idx, const int* labels, long n, int* count,
+                     gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The GCond engine: one object per GPU holding the learnable synthetic graph (X~, PGE), the
  * per-epoch SGC model and all scratch.  One gs_gcond_outer_step == one iteration of the loop body
  * condensation/gcond.py:47-72 (PGE forward + dense_gcn_norm, train_class over all classes
