@@ -74,6 +74,10 @@ struct gs_gcond {
   int* ncls;
   float* ones;
   bool have_blocks;
+  // shard of this rank: classes [c_lo, c_hi) (real side + per-class synthetic terms), PGE pair rows [r_lo, r_hi)
+  int c_lo, c_hi, r_lo, r_hi;
+  double* sums;     // [3][Ph] fp64 column sums exchanged between ranks
+  float *ar_syn, *ar_marg;
 };
 
 static void derive(gs_gcond* e, const gs_gcond_config& c) {
@@ -146,9 +150,12 @@ static size_t carve(gs_gcond* e, void* base) {
   e->H1s = e->T == 2 ? w.take<float>(n * h) : nullptr;
   e->Ss = w.take<float>(n * F); e->Zs = w.take<float>(n * C); e->Ps = w.take<float>(n * C); e->Gs = w.take<float>(n * C);
   e->gw_syn = w.take<float>(C * P); e->stats = w.take<float>(C * e->pd.total_cols * 3);
-  e->ab = w.take<float>(C * e->pd.total_cols * 2); e->loss_c = w.take<float>(C); e->D = w.take<float>(C * P);
+  e->ab = w.take<float>(C * e->pd.total_cols * 2); e->D = w.take<float>(C * P);
   e->Ug = w.take<float>(n * C); e->Vs = w.take<float>(n * C); e->dSs = w.take<float>(n * F); e->drs = w.take<float>(n);
-  e->dQ = w.take<float>(n2); e->dAn = w.take<float>(n2); e->d_adj = w.take<float>(n2); e->d_feat = w.take<float>(n * d);
+  e->dQ = w.take<float>(n2); e->dAn = w.take<float>(n2);
+  // one contiguous block [d_feat | d_adj | loss_c]: a single all-reduce when classes are sharded over ranks
+  e->ar_syn = w.take<float>(n * d + n2 + C);
+  e->d_feat = e->ar_syn; e->d_adj = e->ar_syn ? e->ar_syn + n * d : nullptr; e->loss_c = e->ar_syn ? e->ar_syn + n * d + n2 : nullptr;
   if (e->T == 2) {
     e->dH2 = w.take<float>(C * n * C); e->dHp = w.take<float>(C * n * h); e->A1m = w.take<float>(C * n * h);
     e->Bc = w.take<float>(C * n * C); e->dH1m = w.take<float>(n * h); e->slabs_x = w.take<float>(C * n * d);
@@ -160,9 +167,11 @@ static size_t carve(gs_gcond* e, void* base) {
   e->sumU = w.take<float>(Ph); e->sumV = w.take<float>(Ph);
   e->A1 = w.take<float>(n2 * Ph); e->E2 = w.take<float>(n2 * Ph); e->e3 = w.take<float>(n2); e->de3 = w.take<float>(n2);
   e->dE2 = w.take<float>(n2 * Ph); e->dY1 = w.take<float>(n2 * Ph);
-  e->rowsum_c = w.take<float>(n * Ph); e->colsum_r = w.take<float>(n * Ph); e->dU = w.take<float>(n * Ph);
+  e->ar_marg = w.take<float>(2 * n * Ph);     // [rowsum_c | colsum_r] contiguous (one all-reduce)
+  e->rowsum_c = e->ar_marg; e->colsum_r = e->ar_marg ? e->ar_marg + n * Ph : nullptr; e->dU = w.take<float>(n * Ph);
   e->dV = w.take<float>(n * Ph); e->d_pge = w.take<float>(e->Ppge); e->slabs_w = w.take<float>(e->nsplit_w * Ph * Ph);
   e->parts = w.take<double>((long)e->nblk_stats * 3 * Ph);
+  e->sums = w.take<double>(3 * Ph);
   e->adj_norm_in = w.take<float>(n2); e->rnorm_in = w.take<float>(2 * n); e->Qin = w.take<float>(n2);
   e->rsq_in = w.take<float>(n); e->S_in = w.take<float>(n * F); e->g_model = w.take<float>(P);
   e->m_feat = w.take<float>(n * d); e->v_feat = w.take<float>(n * d);
@@ -264,6 +273,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->step_feat = e->step_pge = e->step_model = 0;
   e->sample_step = 0;
   e->have_blocks = false;
+  e->c_lo = 0; e->c_hi = e->C; e->r_lo = 0; e->r_hi = e->n;
   *out = e;
   return GS_OK;
 }
@@ -311,6 +321,36 @@ static int colsum_batched(gs_gcond* e, const float* M, long batch_stride, int ro
 }
 
 // ================================================================================================
+// sharding over ranks (one process per GPU).  Classes [c_lo, c_hi) are this rank's share of the real side and of
+// the per-class synthetic terms; pair rows [r_lo, r_hi) its share of the PGE grid.  Every quantity that crosses
+// ranks is a SUM of per-rank partials laid out in a contiguous buffer (see gs_gcond_buffer "ar_*"), so the only
+// collective is all-reduce(sum).  With the default full ranges the stages are the single-GPU path.
+// ================================================================================================
+extern "C" int gs_gcond_set_shard(gs_gcond* e, int c_lo, int c_hi, int r_lo, int r_hi) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  if (c_lo < 0 || c_hi < c_lo || c_hi > e->C || r_lo < 0 || r_hi < r_lo || r_hi > e->n)
+    GS_FAIL(GS_ERR_ARG, "gs_gcond_set_shard: ranges out of bounds");
+  e->c_lo = c_lo; e->c_hi = c_hi; e->r_lo = r_lo; e->r_hi = r_hi;
+  return GS_OK;
+}
+
+static inline bool sharded_c(const gs_gcond* e) { return e->c_lo != 0 || e->c_hi != e->C; }
+static inline bool sharded_r(const gs_gcond* e) { return e->r_lo != 0 || e->r_hi != e->n; }
+
+// gs_blocks view of the classes [c_lo, c_hi)
+static gs_blocks blocks_view(const gs_gcond* e) {
+  gs_blocks b = e->blk;
+  const long c0 = e->c_lo, bcap = b.bcap, f1 = b.f1, f2 = b.f2, cap1 = b.cap1;
+  b.C = e->c_hi - e->c_lo;
+  b.n_seed += c0; b.n1 += c0; b.nid1 += c0 * cap1; b.col1 += c0 * bcap * f1; b.val1 += c0 * bcap * f1;
+  b.tptr1 += c0 * (cap1 + 1); b.tedge1 += c0 * bcap * f1; b.col0 += c0 * cap1 * f2; b.val0 += c0 * cap1 * f2;
+  return b;
+}
+
+int gs_sample_blocks_ex(const int*, const int*, const float*, int, const int*, const int*, int*, const gs_blocks*, uint64_t,
+                        uint32_t, int, gs_stream_t);
+
+// ================================================================================================
 // stage: sampling
 // ================================================================================================
 extern "C" int gs_gcond_stage_sample(gs_gcond* e, gs_stream_t stream) {
@@ -319,8 +359,12 @@ extern "C" int gs_gcond_stage_sample(gs_gcond* e, gs_stream_t stream) {
     if (!e->have_blocks) GS_FAIL(GS_ERR_STATE, "gs_gcond: external_blocks set but gs_gcond_set_blocks was never called");
     return GS_OK;
   }
-  GS_TRY(gs_sample_blocks(e->io.rowptr, e->io.col, e->io.val, e->N, e->io.cls_ptr, e->io.cls_nodes, e->marker, &e->blk,
-                          e->cfg.seed, e->sample_step++, stream));
+  if (e->c_hi > e->c_lo) {
+    gs_blocks b = blocks_view(e);
+    GS_TRY(gs_sample_blocks_ex(e->io.rowptr, e->io.col, e->io.val, e->N, e->io.cls_ptr + e->c_lo, e->io.cls_nodes,
+                               e->marker + (long)e->c_lo * e->N, &b, e->cfg.seed, e->sample_step, e->c_lo, stream));
+  }
+  e->sample_step++;
   e->have_blocks = true;
   return GS_OK;
 }
@@ -346,8 +390,14 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   if (!e->have_blocks) GS_FAIL(GS_ERR_STATE, "gs_gcond: no sampled blocks yet");
   hipStream_t s = (hipStream_t)stream;
-  const int C = e->C, d = e->d, h = e->h, F = e->F, bcap = e->bcap, cap1 = e->cap1, f1 = e->f1, f2 = e->f2;
-  const long P = e->P;
+  const int Cl = e->c_hi - e->c_lo, C = e->C, d = e->d, h = e->h, F = e->F, bcap = e->bcap, cap1 = e->cap1, f1 = e->f1, f2 = e->f2;
+  if (Cl == 0) return GS_OK;
+  const long P = e->P, c0 = e->c_lo;
+  const gs_blocks b = blocks_view(e);
+  // class-major scratch of this rank's classes
+  float* P0 = e->P0 + c0 * cap1 * F; float* rs0 = e->rs0 + c0 * cap1;
+  float* Sr = e->Sr + c0 * bcap * F; float* rsr = e->rsr + c0 * bcap;
+  float* Zr = e->Zr + c0 * bcap * C; float* gw = e->gw_real + c0 * P;
   const float* th = e->io.model_params;
   const float* src = e->io.X;
   long ld_src = e->ldx;
@@ -360,80 +410,94 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     ld_src = h;
   }
   // hop 2 (outermost): frontier rows <- global sources;  hop 1: seeds <- frontier
-  launch_ell(e->blk.col0, e->blk.val0, e->blk.n1, cap1, f2, 0, src, ld_src, nullptr, F, e->P0, e->rs0, C, s);
-  launch_ell(e->blk.col1, e->blk.val1, e->blk.n_seed, bcap, f1, cap1, e->P0, F, e->rs0, F, e->Sr, e->rsr, C, s);
+  launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, src, ld_src, nullptr, F, P0, rs0, Cl, s);
+  launch_ell(b.col1, b.val1, b.n_seed, bcap, f1, cap1, P0, F, rs0, F, Sr, rsr, Cl, s);
   GS_LAUNCH_CHECK();
   {  // Z = S Wl  (all classes at once), then G in place
-    gs_gemm_desc g = mk(e->Sr, F, 1, th + e->oWl, C, 1, e->Zr, C, C * bcap, C, F);
+    gs_gemm_desc g = mk(Sr, F, 1, th + e->oWl, C, 1, Zr, C, Cl * bcap, C, F);
     GS_TRY(gs_gemm_f32(&g, stream));
-    hipLaunchKernelGGL(gs_real_softmax_grad_kernel, dim3(gs_cdiv((long)C * bcap, 4)), dim3(256), 0, s, e->Zr, e->rsr,
-                       th + e->obl, e->blk.n_seed, bcap, C);
+    hipLaunchKernelGGL(gs_real_softmax_grad_kernel, dim3(gs_cdiv((long)Cl * bcap, 4)), dim3(256), 0, s, Zr, rsr, th + e->obl,
+                       b.n_seed, bcap, C, (int)c0, Cl);
     GS_LAUNCH_CHECK();
   }
   {  // gWl_c = S_c^T G_c ;  gbl_c = rs_c^T G_c      (padding rows of G are exact zeros)
-    gs_gemm_desc g = mk(e->Sr, 1, F, e->Zr, C, 1, e->gw_real + e->oWl, C, F, C, bcap);
-    g.nb1 = C; g.sAb1 = (long)bcap * F; g.sBb1 = (long)bcap * C; g.sCb1 = P;
+    gs_gemm_desc g = mk(Sr, 1, F, Zr, C, 1, gw + e->oWl, C, F, C, bcap);
+    g.nb1 = Cl; g.sAb1 = (long)bcap * F; g.sBb1 = (long)bcap * C; g.sCb1 = P;
     GS_TRY(gs_gemm_f32(&g, stream));
-    gs_gemm_desc gb = mk(e->rsr, 0, 1, e->Zr, C, 1, e->gw_real + e->obl, C, 1, C, bcap);
-    gb.nb1 = C; gb.sAb1 = bcap; gb.sBb1 = (long)bcap * C; gb.sCb1 = P;
+    gs_gemm_desc gb = mk(rsr, 0, 1, Zr, C, 1, gw + e->obl, C, 1, C, bcap);
+    gb.nb1 = Cl; gb.sAb1 = bcap; gb.sBb1 = (long)bcap * C; gb.sCb1 = P;
     GS_TRY(gs_gemm_f32(&gb, stream));
   }
   if (e->T == 2) {
     // Tm = G W2^T ; Y1 = A1^T Tm ; Bmat = per-edge masked contribution ; gW1_c = X[col0]^T Bmat_c ; gb1_c = colsum
-    gs_gemm_desc g = mk(e->Zr, C, 1, th + e->oWl, 1, C, e->Tm, h, C * bcap, h, C);
-    GS_TRY(gs_gemm_f32(&g, stream));
-    hipLaunchKernelGGL(gs_csc_spmm_t_kernel, dim3(gs_cdiv((long)C * cap1, 4)), dim3(256), 0, s, e->blk.tptr1, e->blk.tedge1,
-                       e->blk.val1, e->blk.n1, cap1, bcap, f1, e->Tm, h, e->Y1, C);
-    hipLaunchKernelGGL(gs_make_bmat_kernel, dim3(gs_cdiv((long)C * cap1 * f2, 4)), dim3(256), 0, s, e->blk.col0, e->blk.val0,
-                       e->blk.n1, cap1, f2, e->H1full, (long)h, e->Y1, h, e->Bmat, e->kcount, C);
-    GS_LAUNCH_CHECK();
     const long K = (long)cap1 * f2;
-    gs_gemm_desc gw = mk(e->io.X, 1, e->ldx, e->Bmat, h, 1, e->slabs_r, h, d, h, (int)K);
-    gw.gatherA_k = e->blk.col0; gw.sGb1 = K;
-    gw.nb1 = C; gw.nb2 = e->nsplit_r; gw.kchunk = e->kchunk_r; gw.Kb = e->kcount;
-    gw.sBb1 = K * h; gw.sCb1 = (long)e->nsplit_r * d * h; gw.sCb2 = (long)d * h;
-    GS_TRY(gs_gemm_f32(&gw, stream));
-    GS_TRY(gs_reduce_slabs_batched_f32(e->gw_real + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, C, 0.f, stream));
-    GS_TRY(colsum_batched(e, e->Bmat, K * h, (int)K, e->kcount, h, C, e->gw_real + e->ob1, P, stream));
+    float* Tm = e->Tm + c0 * bcap * h; float* Y1 = e->Y1 + c0 * cap1 * h; float* Bmat = e->Bmat + c0 * K * h;
+    int* kcount = e->kcount + c0;
+    gs_gemm_desc g = mk(Zr, C, 1, th + e->oWl, 1, C, Tm, h, Cl * bcap, h, C);
+    GS_TRY(gs_gemm_f32(&g, stream));
+    hipLaunchKernelGGL(gs_csc_spmm_t_kernel, dim3(gs_cdiv((long)Cl * cap1, 4)), dim3(256), 0, s, b.tptr1, b.tedge1, b.val1, b.n1,
+                       cap1, bcap, f1, Tm, h, Y1, Cl);
+    hipLaunchKernelGGL(gs_make_bmat_kernel, dim3(gs_cdiv((long)Cl * cap1 * f2, 4)), dim3(256), 0, s, b.col0, b.val0, b.n1, cap1,
+                       f2, e->H1full, (long)h, Y1, h, Bmat, kcount, Cl);
+    GS_LAUNCH_CHECK();
+    gs_gemm_desc gwd = mk(e->io.X, 1, e->ldx, Bmat, h, 1, e->slabs_r, h, d, h, (int)K);
+    gwd.gatherA_k = b.col0; gwd.sGb1 = K;
+    gwd.nb1 = Cl; gwd.nb2 = e->nsplit_r; gwd.kchunk = e->kchunk_r; gwd.Kb = kcount;
+    gwd.sBb1 = K * h; gwd.sCb1 = (long)e->nsplit_r * d * h; gwd.sCb2 = (long)d * h;
+    GS_TRY(gs_gemm_f32(&gwd, stream));
+    GS_TRY(gs_reduce_slabs_batched_f32(gw + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, Cl, 0.f, stream));
+    GS_TRY(colsum_batched(e, Bmat, K * h, (int)K, kcount, h, Cl, gw + e->ob1, P, stream));
   }
   return GS_OK;
 }
 
 // ================================================================================================
-// stage: PGE forward (parametrized_adj.py:40-71) + dense_gcn_norm
+// stage: PGE forward (parametrized_adj.py:40-71) + dense_gcn_norm, in three parts so that ranks can exchange
+// (1 -> 2) the BN-2 column sums "ar_bn2" and (2 -> 3) the pre-sigmoid pair scores "e3".
 // ================================================================================================
-extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_t stream) {
+extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int part, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   hipStream_t s = (hipStream_t)stream;
-  const int n = e->n, d = e->d, Ph = e->Ph;
-  const long n2 = (long)n * n;
+  const int n = e->n, d = e->d, Ph = e->Ph, nr = e->r_hi - e->r_lo;
+  const long n2 = (long)n * n, rows = (long)nr * n;
   const float* X = e->io.feat_syn;
   const float* pp = e->io.pge_params;
-  {  // U = X W0[:, :d]^T ; V = X W0[:, d:]^T      (two batches over the two halves of W0)
-    gs_gemm_desc g = mk(X, d, 1, pp + e->pW0, 1, 2L * d, e->U, Ph, n, Ph, d);
-    g.nb1 = 2; g.sBb1 = d; g.sCb1 = (long)n * Ph;     // V follows U in the workspace
-    if (e->V != e->U + (long)n * Ph) {                 // workspace alignment may separate them: two calls
-      g.nb1 = 1;
+  const int nblk = gs_cdiv(rows > 0 ? rows : 1, e->rows_per_block);
+  if (part == 1) {
+    {  // U = X W0[:, :d]^T ; V = X W0[:, d:]^T
+      gs_gemm_desc g = mk(X, d, 1, pp + e->pW0, 1, 2L * d, e->U, Ph, n, Ph, d);
       GS_TRY(gs_gemm_f32(&g, stream));
       g.B = pp + e->pW0 + d; g.C = e->V;
+      GS_TRY(gs_gemm_f32(&g, stream));
     }
-    GS_TRY(gs_gemm_f32(&g, stream));
+    hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 32)), dim3(256), 0, s, e->U, e->V, pp + e->pb0, n, Ph, e->mu1,
+                       e->is1, e->sumU, e->sumV);
+    GS_LAUNCH_CHECK();
+    if (rows > 0) {
+      hipLaunchKernelGGL(gs_pge_make_a1_kernel, dim3(gs_cdiv(rows * Ph, 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0, e->mu1,
+                         e->is1, pp + e->pg1, pp + e->pbe1, n, Ph, e->r_lo, nr, e->A1);
+      GS_LAUNCH_CHECK();
+      gs_gemm_desc g = mk(e->A1, Ph, 1, pp + e->pW1, 1, Ph, e->E2, Ph, (int)rows, Ph, Ph);     // E2 = A1 W1^T + b1
+      g.bias = pp + e->pb1;
+      GS_TRY(gs_gemm_f32(&g, stream));
+      hipLaunchKernelGGL(gs_col_stats_kernel, dim3(nblk), dim3(256), 0, s, e->E2, rows, Ph, e->rows_per_block, e->parts);
+      hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 32), 2), dim3(256), 0, s, e->parts, nblk, 2, Ph, e->sums);
+      GS_LAUNCH_CHECK();
+    } else {
+      GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 2 * Ph, s));
+    }
+    return GS_OK;
   }
-  hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 32)), dim3(256), 0, s, e->U, e->V, pp + e->pb0, n, Ph, e->mu1,
-                     e->is1, e->sumU, e->sumV);
-  hipLaunchKernelGGL(gs_pge_make_a1_kernel, dim3(gs_cdiv(n2 * Ph, 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0, e->mu1,
-                     e->is1, pp + e->pg1, pp + e->pbe1, n, Ph, e->A1);
-  GS_LAUNCH_CHECK();
-  {  // E2 = A1 W1^T + b1
-    gs_gemm_desc g = mk(e->A1, Ph, 1, pp + e->pW1, 1, Ph, e->E2, Ph, (int)n2, Ph, Ph);
-    g.bias = pp + e->pb1;
-    GS_TRY(gs_gemm_f32(&g, stream));
+  if (part == 2) {
+    hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, n2, Ph, e->mu2, e->is2);
+    if (sharded_r(e)) GS_HIP(hipMemsetAsync(e->e3, 0, sizeof(float) * n2, s));
+    if (rows > 0)
+      hipLaunchKernelGGL(gs_pge_layer3_kernel, dim3(gs_cdiv(rows, 4)), dim3(256), 0, s, e->E2, e->mu2, e->is2, pp + e->pg2,
+                         pp + e->pbe2, pp + e->pw2, pp + e->pb2, rows, Ph, e->e3 + (long)e->r_lo * n);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
   }
-  hipLaunchKernelGGL(gs_col_stats_kernel, dim3(e->nblk_stats), dim3(256), 0, s, e->E2, n2, Ph, e->rows_per_block, e->parts);
-  hipLaunchKernelGGL(gs_bn2_finalize_kernel, dim3(gs_cdiv(Ph, 32)), dim3(256), 0, s, e->parts, e->nblk_stats, n2, Ph, e->mu2,
-                     e->is2);
-  hipLaunchKernelGGL(gs_pge_layer3_kernel, dim3(gs_cdiv(n2, 4)), dim3(256), 0, s, e->E2, e->mu2, e->is2, pp + e->pg2,
-                     pp + e->pbe2, pp + e->pw2, pp + e->pb2, n2, Ph, e->e3);
+  if (part != 3) GS_FAIL(GS_ERR_ARG, "gs_gcond_stage_pge_forward_part: part must be 1, 2 or 3");
   float* adj = inference ? e->io.adj_syn : e->adj_raw;
   hipLaunchKernelGGL(gs_pge_adj_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, e->e3, n, adj);
   GS_LAUNCH_CHECK();
@@ -441,26 +505,33 @@ extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_
   return gs_dense_gcn_norm_fwd(adj, n, e->adj_norm, e->rnorm, stream);
 }
 
-// ================================================================================================
-// stage: synthetic side — gw_syn per class, matching loss, closed-form d loss / d X~ (direct path)
-// and d loss / d A^ -> d adj     (gcond_base.py:226-239 + autograd through them)
-// ================================================================================================
-static int grouped(gs_gemm_desc& g, const gs_gcond* e) {   // per-class row ranges
-  g.nb1 = e->C;
-  return 0;
+extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_t stream) {
+  if (e && (sharded_r(e))) GS_FAIL(GS_ERR_STATE, "gs_gcond_stage_pge_forward: sharded engines must run the _part entry points with all-reduces in between");
+  GS_TRY(gs_gcond_stage_pge_forward_part(e, inference, 1, stream));
+  GS_TRY(gs_gcond_stage_pge_forward_part(e, inference, 2, stream));
+  return gs_gcond_stage_pge_forward_part(e, inference, 3, stream);
 }
 
+// ================================================================================================
+// stage: synthetic side — gw_syn per class, matching loss, closed-form d loss / d X~ (direct path)
+// and d loss / d A^ -> d adj     (gcond_base.py:226-239 + autograd through them).
+// Writes this rank's PARTIAL [d_feat | d_adj | loss_c] ("ar_syn"); gs_gcond_stage_syn_finish books the loss.
+// ================================================================================================
 extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   hipStream_t s = (hipStream_t)stream;
-  const int C = e->C, n = e->n, d = e->d, h = e->h, F = e->F, mx = e->max_nc;
-  const long P = e->P;
+  const int C = e->C, Cl = e->c_hi - e->c_lo, n = e->n, d = e->d, h = e->h, F = e->F, mx = e->max_nc;
+  const long P = e->P, c0 = e->c_lo;
+  const bool part = sharded_c(e);
   const float* X = e->io.feat_syn;
   const float* th = e->io.model_params;
   const float* A = e->adj_norm;
   const float* Wl = th + e->oWl;
   const float* bl = th + e->obl;
-  (void)grouped;
+  // per-class views of this rank's classes
+  const long* off_lo = e->off_lo + c0; const long* off_loF = e->off_loF + c0; const long* off_loC = e->off_loC + c0;
+  const long* off_lon = e->off_lon + c0; const int* ncls = e->ncls + c0;
+  float* gws = e->gw_syn + c0 * P; const float* gwr = e->gw_real + c0 * P; float* Dv = e->D + c0 * P;
   {  // Q = A A ; rsq = Q 1
     gs_gemm_desc g = mk(A, n, 1, A, n, 1, e->Q, n, n, n, n);
     GS_TRY(gs_gemm_f32(&g, stream));
@@ -482,72 +553,83 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
                        e->io.syn_lo, e->io.syn_hi, n, C, e->Ps, e->Gs, 0);
     GS_LAUNCH_CHECK();
   }
-  {  // last layer: gWl_c = S[lo:hi]^T G[lo:hi] ; gbl_c = rs[lo:hi]^T G[lo:hi]
-    gs_gemm_desc g = mk(e->Ss, 1, F, e->Gs, C, 1, e->gw_syn + e->oWl, C, F, C, mx);
-    g.nb1 = C; g.offA = e->off_loF; g.offB = e->off_loC; g.Kb = e->ncls; g.sCb1 = P;
-    GS_TRY(gs_gemm_f32(&g, stream));
-    gs_gemm_desc gb = mk(e->rsq, 0, 1, e->Gs, C, 1, e->gw_syn + e->obl, C, 1, C, mx);
-    gb.nb1 = C; gb.offA = e->off_lo; gb.offB = e->off_loC; gb.Kb = e->ncls; gb.sCb1 = P;
-    GS_TRY(gs_gemm_f32(&gb, stream));
+  if (part) {   // rows / classes of other ranks contribute zero from this rank
+    GS_HIP(hipMemsetAsync(e->loss_c, 0, sizeof(float) * C, s));
+    GS_HIP(hipMemsetAsync(e->dSs, 0, sizeof(float) * (long)n * F, s));
+    GS_HIP(hipMemsetAsync(e->dQ, 0, sizeof(float) * (long)n * n, s));
+    if (e->T == 2) GS_HIP(hipMemsetAsync(e->d_feat, 0, sizeof(float) * (long)n * d, s));
   }
-  if (e->T == 2) {
-    // dH2_c = Q[lo:hi]^T G[lo:hi]  [n x C] ; dHp_c = (dH2_c W2^T) * mask ; gW1_c = X^T dHp_c ; gb1_c = colsum
-    gs_gemm_desc a = mk(e->Q, 1, n, e->Gs, C, 1, e->dH2, C, n, C, mx);
-    a.nb1 = C; a.offA = e->off_lon; a.offB = e->off_loC; a.Kb = e->ncls; a.sCb1 = (long)n * C;
-    GS_TRY(gs_gemm_f32(&a, stream));
-    gs_gemm_desc b = mk(e->dH2, C, 1, Wl, 1, C, e->dHp, h, n, h, C);
-    b.nb1 = C; b.sAb1 = (long)n * C; b.sCb1 = (long)n * h; b.mask = e->H1s; b.ldmask = h;
-    GS_TRY(gs_gemm_f32(&b, stream));
-    gs_gemm_desc c = mk(X, 1, d, e->dHp, h, 1, e->gw_syn + e->oW1, h, d, h, n);
-    c.nb1 = C; c.sBb1 = (long)n * h; c.sCb1 = P;
-    GS_TRY(gs_gemm_f32(&c, stream));
-    GS_TRY(colsum_batched(e, e->dHp, (long)n * h, n, nullptr, h, C, e->gw_syn + e->ob1, P, stream));
-  }
-  // ---- matching distance and D = d loss / d gw_syn (already scaled by n_c / n') -------------------
-  hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, C), dim3(256), 0, s, e->gw_real, e->gw_syn, P, e->pd, e->stats);
-  hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(C), dim3(256), 0, s, e->stats, e->pd, e->cfg.dis_metric, e->io.syn_lo,
-                     e->io.syn_hi, n, e->ab, e->loss_c);
-  hipLaunchKernelGGL(gs_dist_apply_kernel, dim3(gs_cdiv((long)C * P, 256)), dim3(256), 0, s, e->gw_real, e->gw_syn, P, e->pd,
-                     e->ab, e->D, C);
-  hipLaunchKernelGGL(gs_loss_accum_kernel, dim3(1), dim3(64), 0, s, e->loss_c, C, e->loss_sum, e->loss_last, e->steps);
-  GS_LAUNCH_CHECK();
-  const float* Dl = e->D + e->oWl;   // + c*P : d/d gWl_c
-  // ---- second-order backward ----------------------------------------------------------------------
-  if (e->T == 2) {
-    // A1m_c = (X D1_c + Db1_c) * mask ; dX slabs_c = dHp_c D1_c^T ; Bc = A1m_c W2
-    gs_gemm_desc a = mk(X, d, 1, e->D + e->oW1, h, 1, e->A1m, h, n, h, d);
-    a.nb1 = C; a.sBb1 = P; a.sCb1 = (long)n * h; a.bias = e->D + e->ob1; a.sbias_b1 = P; a.mask = e->H1s; a.ldmask = h;
-    GS_TRY(gs_gemm_f32(&a, stream));
-    gs_gemm_desc x = mk(e->dHp, h, 1, e->D + e->oW1, 1, h, e->slabs_x, d, n, d, h);
-    x.nb1 = C; x.sAb1 = (long)n * h; x.sBb1 = P; x.sCb1 = (long)n * d;
-    GS_TRY(gs_gemm_f32(&x, stream));
-    GS_TRY(gs_reduce_slabs_f32(e->d_feat, e->slabs_x, (long)n * d, C, (long)n * d, 0.f, stream));
-    gs_gemm_desc b = mk(e->A1m, h, 1, Wl, C, 1, e->Bc, C, n, C, h);
-    b.nb1 = C; b.sAb1 = (long)n * h; b.sCb1 = (long)n * C;
-    GS_TRY(gs_gemm_f32(&b, stream));
-    // dQ[lo:hi] = G[lo:hi] Bc_c^T
-    gs_gemm_desc q = mk(e->Gs, C, 1, e->Bc, 1, C, e->dQ, n, mx, n, C);
-    q.nb1 = C; q.offA = e->off_loC; q.Mb = e->ncls; q.sBb1 = (long)n * C; q.offC = e->off_lon;
-    GS_TRY(gs_gemm_f32(&q, stream));
-    // Ug[lo:hi] = Q[lo:hi] Bc_c + S[lo:hi] D2_c
-    gs_gemm_desc u = mk(e->Q, n, 1, e->Bc, C, 1, e->Ug, C, mx, C, n);
-    u.nb1 = C; u.offA = e->off_lon; u.Mb = e->ncls; u.sBb1 = (long)n * C; u.offC = e->off_loC;
-    GS_TRY(gs_gemm_f32(&u, stream));
-    gs_gemm_desc u2 = mk(e->Ss, F, 1, Dl, C, 1, e->Ug, C, mx, C, F);
-    u2.nb1 = C; u2.offA = e->off_loF; u2.Mb = e->ncls; u2.sBb1 = P; u2.offC = e->off_loC; u2.beta = 1.f;
-    GS_TRY(gs_gemm_f32(&u2, stream));
-  } else {
-    gs_gemm_desc u = mk(e->Ss, F, 1, Dl, C, 1, e->Ug, C, mx, C, F);
-    u.nb1 = C; u.offA = e->off_loF; u.Mb = e->ncls; u.sBb1 = P; u.offC = e->off_loC;
-    GS_TRY(gs_gemm_f32(&u, stream));
+  const float* Dl = Dv + e->oWl;   // + c*P : d/d gWl_c
+  if (Cl > 0) {
+    {  // last layer: gWl_c = S[lo:hi]^T G[lo:hi] ; gbl_c = rs[lo:hi]^T G[lo:hi]
+      gs_gemm_desc g = mk(e->Ss, 1, F, e->Gs, C, 1, gws + e->oWl, C, F, C, mx);
+      g.nb1 = Cl; g.offA = off_loF; g.offB = off_loC; g.Kb = ncls; g.sCb1 = P;
+      GS_TRY(gs_gemm_f32(&g, stream));
+      gs_gemm_desc gb = mk(e->rsq, 0, 1, e->Gs, C, 1, gws + e->obl, C, 1, C, mx);
+      gb.nb1 = Cl; gb.offA = off_lo; gb.offB = off_loC; gb.Kb = ncls; gb.sCb1 = P;
+      GS_TRY(gs_gemm_f32(&gb, stream));
+    }
+    float* dH2 = e->T == 2 ? e->dH2 + c0 * n * C : nullptr; float* dHp = e->T == 2 ? e->dHp + c0 * n * h : nullptr;
+    float* A1m = e->T == 2 ? e->A1m + c0 * n * h : nullptr; float* Bc = e->T == 2 ? e->Bc + c0 * n * C : nullptr;
+    if (e->T == 2) {
+      // dH2_c = Q[lo:hi]^T G[lo:hi]  [n x C] ; dHp_c = (dH2_c W2^T) * mask ; gW1_c = X^T dHp_c ; gb1_c = colsum
+      gs_gemm_desc a = mk(e->Q, 1, n, e->Gs, C, 1, dH2, C, n, C, mx);
+      a.nb1 = Cl; a.offA = off_lon; a.offB = off_loC; a.Kb = ncls; a.sCb1 = (long)n * C;
+      GS_TRY(gs_gemm_f32(&a, stream));
+      gs_gemm_desc b = mk(dH2, C, 1, Wl, 1, C, dHp, h, n, h, C);
+      b.nb1 = Cl; b.sAb1 = (long)n * C; b.sCb1 = (long)n * h; b.mask = e->H1s; b.ldmask = h;
+      GS_TRY(gs_gemm_f32(&b, stream));
+      gs_gemm_desc c = mk(X, 1, d, dHp, h, 1, gws + e->oW1, h, d, h, n);
+      c.nb1 = Cl; c.sBb1 = (long)n * h; c.sCb1 = P;
+      GS_TRY(gs_gemm_f32(&c, stream));
+      GS_TRY(colsum_batched(e, dHp, (long)n * h, n, nullptr, h, Cl, gws + e->ob1, P, stream));
+    }
+    // ---- matching distance and D = d loss / d gw_syn (already scaled by n_c / n') -------------------
+    float* stats = e->stats + c0 * e->pd.total_cols * 3; float* ab = e->ab + c0 * e->pd.total_cols * 2;
+    hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, Cl), dim3(256), 0, s, gwr, gws, P, e->pd, stats);
+    hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(Cl), dim3(256), 0, s, stats, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
+                       e->io.syn_hi + c0, n, ab, e->loss_c + c0);
+    hipLaunchKernelGGL(gs_dist_apply_kernel, dim3(gs_cdiv((long)Cl * P, 256)), dim3(256), 0, s, gwr, gws, P, e->pd, ab, Dv, Cl);
+    GS_LAUNCH_CHECK();
+    // ---- second-order backward, per-class part ------------------------------------------------------
+    if (e->T == 2) {
+      // A1m_c = (X D1_c + Db1_c) * mask ; dX slabs_c = dHp_c D1_c^T ; Bc = A1m_c W2
+      gs_gemm_desc a = mk(X, d, 1, Dv + e->oW1, h, 1, A1m, h, n, h, d);
+      a.nb1 = Cl; a.sBb1 = P; a.sCb1 = (long)n * h; a.bias = Dv + e->ob1; a.sbias_b1 = P; a.mask = e->H1s; a.ldmask = h;
+      GS_TRY(gs_gemm_f32(&a, stream));
+      gs_gemm_desc x = mk(dHp, h, 1, Dv + e->oW1, 1, h, e->slabs_x, d, n, d, h);
+      x.nb1 = Cl; x.sAb1 = (long)n * h; x.sBb1 = P; x.sCb1 = (long)n * d;
+      GS_TRY(gs_gemm_f32(&x, stream));
+      GS_TRY(gs_reduce_slabs_f32(e->d_feat, e->slabs_x, (long)n * d, Cl, (long)n * d, 0.f, stream));
+      gs_gemm_desc b = mk(A1m, h, 1, Wl, C, 1, Bc, C, n, C, h);
+      b.nb1 = Cl; b.sAb1 = (long)n * h; b.sCb1 = (long)n * C;
+      GS_TRY(gs_gemm_f32(&b, stream));
+      // dQ[lo:hi] = G[lo:hi] Bc_c^T
+      gs_gemm_desc q = mk(e->Gs, C, 1, Bc, 1, C, e->dQ, n, mx, n, C);
+      q.nb1 = Cl; q.offA = off_loC; q.Mb = ncls; q.sBb1 = (long)n * C; q.offC = off_lon;
+      GS_TRY(gs_gemm_f32(&q, stream));
+      // Ug[lo:hi] = Q[lo:hi] Bc_c + S[lo:hi] D2_c
+      gs_gemm_desc u = mk(e->Q, n, 1, Bc, C, 1, e->Ug, C, mx, C, n);
+      u.nb1 = Cl; u.offA = off_lon; u.Mb = ncls; u.sBb1 = (long)n * C; u.offC = off_loC;
+      GS_TRY(gs_gemm_f32(&u, stream));
+      gs_gemm_desc u2 = mk(e->Ss, F, 1, Dl, C, 1, e->Ug, C, mx, C, F);
+      u2.nb1 = Cl; u2.offA = off_loF; u2.Mb = ncls; u2.sBb1 = P; u2.offC = off_loC; u2.beta = 1.f;
+      GS_TRY(gs_gemm_f32(&u2, stream));
+    } else {
+      gs_gemm_desc u = mk(e->Ss, F, 1, Dl, C, 1, e->Ug, C, mx, C, F);
+      u.nb1 = Cl; u.offA = off_loF; u.Mb = ncls; u.sBb1 = P; u.offC = off_loC;
+      GS_TRY(gs_gemm_f32(&u, stream));
+    }
   }
   hipLaunchKernelGGL(gs_syn_v_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Ps, e->Gs, e->Ug, e->rsq, e->D, P, e->obl, bl,
-                     e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->Vs, e->drs);
+                     e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->c_lo, e->c_hi, e->Vs, e->drs);
   GS_LAUNCH_CHECK();
   {  // dS[lo:hi] = G[lo:hi] Dl_c^T ;  dS += V Wl^T
-    gs_gemm_desc a = mk(e->Gs, C, 1, Dl, 1, C, e->dSs, F, mx, F, C);
-    a.nb1 = C; a.offA = e->off_loC; a.Mb = e->ncls; a.sBb1 = P; a.offC = e->off_loF;
-    GS_TRY(gs_gemm_f32(&a, stream));
+    if (Cl > 0) {
+      gs_gemm_desc a = mk(e->Gs, C, 1, Dl, 1, C, e->dSs, F, mx, F, C);
+      a.nb1 = Cl; a.offA = off_loC; a.Mb = ncls; a.sBb1 = P; a.offC = off_loF;
+      GS_TRY(gs_gemm_f32(&a, stream));
+    }
     gs_gemm_desc b = mk(e->Vs, C, 1, Wl, 1, C, e->dSs, F, n, F, C);
     b.beta = 1.f;
     GS_TRY(gs_gemm_f32(&b, stream));
@@ -570,7 +652,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   }
   hipLaunchKernelGGL(gs_add_rowvec_kernel, dim3(gs_cdiv((long)n * n, 256)), dim3(256), 0, s, e->dQ, e->drs, n, n);
   GS_LAUNCH_CHECK();
-  {  // dA^ = dQ A^T + A^T dQ ; then through dense_gcn_norm
+  {  // dA^ = dQ A^T + A^T dQ ; then through dense_gcn_norm (both linear in dQ: partial sums stay partial sums)
     gs_gemm_desc a = mk(e->dQ, n, 1, A, 1, n, e->dAn, n, n, n, n);
     GS_TRY(gs_gemm_f32(&a, stream));
     gs_gemm_desc b = mk(A, 1, n, e->dQ, n, 1, e->dAn, n, n, n, n);
@@ -580,44 +662,79 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   return gs_dense_gcn_norm_bwd(e->adj_raw, e->rnorm, e->dAn, n, e->d_adj, stream);
 }
 
+extern "C" int gs_gcond_stage_syn_finish(gs_gcond* e, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  hipLaunchKernelGGL(gs_loss_accum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->loss_c, e->C, e->loss_sum, e->loss_last,
+                     e->steps);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 // ================================================================================================
-// stage: PGE backward: d adj -> d theta_PGE and d X~ (added to d_feat)
+// stage: PGE backward: d adj -> d theta_PGE and d X~ (added to d_feat), in three parts; ranks exchange
+// (1 -> 2) the BN-2 backward column sums "ar_l3" and (2 -> 3) the marginals "ar_marg" (+ "ar_w1" in PGE epochs).
 // ================================================================================================
-extern "C" int gs_gcond_stage_pge_backward(gs_gcond* e, int need_param_grads, int need_feat_grad, gs_stream_t stream) {
+extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grads, int need_feat_grad, int part,
+                                                gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   hipStream_t s = (hipStream_t)stream;
-  const int n = e->n, d = e->d, Ph = e->Ph;
-  const long n2 = (long)n * n;
+  const int n = e->n, d = e->d, Ph = e->Ph, nr = e->r_hi - e->r_lo;
+  const long n2 = (long)n * n, rows = (long)nr * n;
   const float* X = e->io.feat_syn;
   const float* pp = e->io.pge_params;
   float* g = e->d_pge;
-  hipLaunchKernelGGL(gs_pge_adj_bwd_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, e->d_adj, e->adj_raw, n, e->de3);
-  hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(e->nblk_stats), dim3(256), 0, s, e->E2, e->de3, e->mu2, e->is2,
-                     pp + e->pg2, pp + e->pbe2, pp + e->pw2, n2, Ph, e->rows_per_block, e->parts);
-  hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 32), 3), dim3(256), 0, s, e->parts, e->nblk_stats, 3, Ph, g + e->pw2,
-                     g + e->pbe2, g + e->pg2);
-  hipLaunchKernelGGL(gs_pge_bn2_bwd_kernel, dim3(gs_cdiv(n2 * Ph, 256)), dim3(256), 0, s, e->E2, e->de3, e->mu2, e->is2,
-                     pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, n2, Ph, e->dE2);
-  GS_LAUNCH_CHECK();
-  if (need_param_grads) {
-    // dW1 = dE2^T A1  (K = n'^2 split into slabs, fixed-order reduce) ; db1 = colsum(dE2)
-    gs_gemm_desc w = mk(e->dE2, 1, Ph, e->A1, Ph, 1, e->slabs_w, Ph, Ph, Ph, (int)n2);
-    w.nb2 = e->nsplit_w; w.kchunk = e->kchunk_w; w.sCb2 = (long)Ph * Ph;
-    GS_TRY(gs_gemm_f32(&w, stream));
-    GS_TRY(gs_reduce_slabs_f32(g + e->pW1, e->slabs_w, (long)Ph * Ph, e->nsplit_w, (long)Ph * Ph, 0.f, stream));
-    hipLaunchKernelGGL(gs_sum_kernel, dim3(1), dim3(1024), 0, s, e->de3, n2, g + e->pb2);   // db2 = sum de3
-    hipLaunchKernelGGL(gs_col_stats_kernel, dim3(e->nblk_stats), dim3(256), 0, s, e->dE2, n2, Ph, e->rows_per_block, e->parts);
-    hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 32), 1), dim3(256), 0, s, e->parts, e->nblk_stats, 2, Ph, g + e->pb1,
-                       (float*)nullptr, (float*)nullptr);
+  const float* de3l = e->de3 + (long)e->r_lo * n;
+  const int nblk = gs_cdiv(rows > 0 ? rows : 1, e->rows_per_block);
+  if (part == 1) {
+    hipLaunchKernelGGL(gs_pge_adj_bwd_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, e->d_adj, e->adj_raw, n, e->de3);
+    if (rows > 0) {
+      hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(nblk), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2, pp + e->pg2,
+                         pp + e->pbe2, pp + e->pw2, rows, Ph, e->rows_per_block, e->parts);
+      hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 32), 3), dim3(256), 0, s, e->parts, nblk, 3, Ph, e->sums);
+    } else {
+      GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 3 * Ph, s));
+    }
     GS_LAUNCH_CHECK();
+    return GS_OK;
   }
-  {  // dY1 = (dE2 W1) * [A1 > 0]
-    gs_gemm_desc a = mk(e->dE2, Ph, 1, pp + e->pW1, Ph, 1, e->dY1, Ph, (int)n2, Ph, Ph);
-    a.mask = e->A1; a.ldmask = Ph;
-    GS_TRY(gs_gemm_f32(&a, stream));
+  if (part == 2) {
+    hipLaunchKernelGGL(gs_sums_to_float_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, 3, Ph, g + e->pw2, g + e->pbe2,
+                       g + e->pg2);
+    if (sharded_r(e)) GS_HIP(hipMemsetAsync(e->ar_marg, 0, sizeof(float) * 2 * (long)n * Ph, s));
+    if (need_param_grads) {
+      hipLaunchKernelGGL(gs_sum_kernel, dim3(1), dim3(1024), 0, s, e->de3, n2, g + e->pb2);   // db2 = sum de3 (replicated)
+      if (rows == 0) GS_HIP(hipMemsetAsync(g + e->pW1, 0, sizeof(float) * ((long)Ph * Ph + Ph), s));
+    }
+    GS_LAUNCH_CHECK();
+    if (rows > 0) {
+      hipLaunchKernelGGL(gs_pge_bn2_bwd_kernel, dim3(gs_cdiv(rows * Ph, 256)), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2,
+                         pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, rows, n2, Ph, e->dE2);
+      GS_LAUNCH_CHECK();
+      if (need_param_grads) {
+        // dW1 = dE2^T A1  (K = local pair rows split into slabs, fixed-order reduce) ; db1 = colsum(dE2)   [partials]
+        const int nsplit = gs_cdiv(rows, e->kchunk_w);
+        gs_gemm_desc w = mk(e->dE2, 1, Ph, e->A1, Ph, 1, e->slabs_w, Ph, Ph, Ph, (int)rows);
+        w.nb2 = nsplit; w.kchunk = e->kchunk_w; w.sCb2 = (long)Ph * Ph;
+        GS_TRY(gs_gemm_f32(&w, stream));
+        GS_TRY(gs_reduce_slabs_f32(g + e->pW1, e->slabs_w, (long)Ph * Ph, nsplit, (long)Ph * Ph, 0.f, stream));
+        hipLaunchKernelGGL(gs_col_stats_kernel, dim3(nblk), dim3(256), 0, s, e->dE2, rows, Ph, e->rows_per_block, e->parts);
+        hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 32), 1), dim3(256), 0, s, e->parts, nblk, 2, Ph, e->sums);
+        hipLaunchKernelGGL(gs_sums_to_float_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, 1, Ph, g + e->pb1,
+                           (float*)nullptr, (float*)nullptr);
+        GS_LAUNCH_CHECK();
+      }
+      {  // dY1 = (dE2 W1) * [A1 > 0]
+        gs_gemm_desc a = mk(e->dE2, Ph, 1, pp + e->pW1, Ph, 1, e->dY1, Ph, (int)rows, Ph, Ph);
+        a.mask = e->A1; a.ldmask = Ph;
+        GS_TRY(gs_gemm_f32(&a, stream));
+      }
+      hipLaunchKernelGGL(gs_pge_marginal_r_kernel, dim3(nr), dim3(256), 0, s, e->dY1, n, Ph, e->r_lo, e->colsum_r);
+      hipLaunchKernelGGL(gs_pge_marginal_c_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, nr, e->rowsum_c);
+      GS_LAUNCH_CHECK();
+    }
+    return GS_OK;
   }
-  hipLaunchKernelGGL(gs_pge_marginal_r_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, e->colsum_r);
-  hipLaunchKernelGGL(gs_pge_marginal_c_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, e->rowsum_c);
+  if (part != 3) GS_FAIL(GS_ERR_ARG, "gs_gcond_stage_pge_backward_part: part must be 1, 2 or 3");
   hipLaunchKernelGGL(gs_pge_bn1_bwd_cols_kernel, dim3(gs_cdiv(Ph, 32)), dim3(256), 0, s, e->U, e->V, e->rowsum_c, e->colsum_r,
                      pp + e->pb0, e->mu1, e->is1, n, Ph, g + e->pg1, g + e->pbe1);
   hipLaunchKernelGGL(gs_pge_bn1_bwd_uv_kernel, dim3(gs_cdiv((long)n * Ph, 256)), dim3(256), 0, s, e->U, e->V, e->rowsum_c,
@@ -643,6 +760,12 @@ extern "C" int gs_gcond_stage_pge_backward(gs_gcond* e, int need_param_grads, in
   return GS_OK;
 }
 
+extern "C" int gs_gcond_stage_pge_backward(gs_gcond* e, int need_param_grads, int need_feat_grad, gs_stream_t stream) {
+  if (e && sharded_r(e)) GS_FAIL(GS_ERR_STATE, "gs_gcond_stage_pge_backward: sharded engines must run the _part entry points");
+  for (int part = 1; part <= 3; ++part) GS_TRY(gs_gcond_stage_pge_backward_part(e, need_param_grads, need_feat_grad, part, stream));
+  return GS_OK;
+}
+
 // ================================================================================================
 // stage: optimiser step (gcond.py:58-61: PGE for epoch % 50 < 10, else X~)
 // ================================================================================================
@@ -656,12 +779,11 @@ extern "C" int gs_gcond_stage_update(gs_gcond* e, int epoch, gs_stream_t stream)
 }
 
 // ================================================================================================
-// stage: PGE.inference + inner_loop SGC steps on (X~, A^)  (gcond.py:63-72)
+// stage: inner_loop SGC steps on (X~, A^) after PGE.inference  (gcond.py:63-72).  Replicated on every rank.
 // ================================================================================================
-extern "C" int gs_gcond_stage_inner(gs_gcond* e, gs_stream_t stream) {
+extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   hipStream_t s = (hipStream_t)stream;
-  GS_TRY(gs_gcond_stage_pge_forward(e, 1, stream));
   const int C = e->C, n = e->n, d = e->d, h = e->h, F = e->F;
   if (e->cfg.inner_loop == 0) return GS_OK;
   const float* X = e->io.feat_syn;
@@ -710,13 +832,21 @@ extern "C" int gs_gcond_stage_inner(gs_gcond* e, gs_stream_t stream) {
   return GS_OK;
 }
 
+extern "C" int gs_gcond_stage_inner(gs_gcond* e, gs_stream_t stream) {
+  GS_TRY(gs_gcond_stage_pge_forward(e, 1, stream));
+  return gs_gcond_stage_inner_steps(e, stream);
+}
+
 extern "C" int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  if (sharded_c(e) || sharded_r(e))
+    GS_FAIL(GS_ERR_STATE, "gs_gcond_outer_step: a sharded engine is driven stage by stage with all-reduces in between (graphslim_amd/parallel.py)");
   const int pge_epoch = (epoch % 50 < 10);
   GS_TRY(gs_gcond_stage_sample(e, stream));
   GS_TRY(gs_gcond_stage_real_grads(e, stream));
   GS_TRY(gs_gcond_stage_pge_forward(e, 0, stream));
   GS_TRY(gs_gcond_stage_syn_match(e, stream));
+  GS_TRY(gs_gcond_stage_syn_finish(e, stream));
   // only the gradient of the group that is stepped this epoch is consumed (the other optimiser's
   // grads are zeroed unread by the next zero_grad(), gcond.py:54-61)
   GS_TRY(gs_gcond_stage_pge_backward(e, pge_epoch, !pge_epoch, stream));
@@ -737,7 +867,7 @@ extern "C" int gs_gcond_read_loss(gs_gcond* e, double* loss_sum, long* steps, gs
 
 extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* count) {
   if (!e || !name || !ptr || !count) GS_FAIL(GS_ERR_ARG, "gs_gcond_buffer: null argument");
-  const long n = e->n, C = e->C;
+  const long n = e->n, C = e->C, Ph = e->Ph;
   struct { const char* k; void* p; long c; } tab[] = {
       {"gw_real", e->gw_real, C * e->P},   {"gw_syn", e->gw_syn, C * e->P},     {"loss", e->loss_last, 1},
       {"loss_c", e->loss_c, C},            {"d_feat", e->d_feat, n * e->d},     {"d_adj_norm", e->dAn, n * n},
@@ -746,6 +876,10 @@ extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* 
       {"g_model", e->g_model, e->P},       {"Sr", e->Sr, C * e->bcap * e->F},   {"rsr", e->rsr, C * e->bcap},
       {"Q", e->Q, n * n},                  {"Ss", e->Ss, n * e->F},             {"Ps", e->Ps, n * C},
       {"dQ", e->dQ, n * n},                {"e3", e->e3, n * n},                {"H1full", e->H1full, e->H1full ? (long)e->N * e->h : 0},
+      // all-reduce(sum) buffers of the sharded engine.  ar_bn2 / ar_l3 are fp64 (count in doubles), the rest fp32.
+      {"ar_bn2", e->sums, 2 * Ph},         {"ar_l3", e->sums, 3 * Ph},          {"ar_syn", e->ar_syn, n * e->d + n * n + C},
+      {"ar_marg", e->ar_marg, 2 * n * Ph}, {"ar_w1", e->d_pge + e->pW1, Ph * Ph + Ph},
+      {"ar_gw_real", e->gw_real, C * e->P},
   };
   for (auto& t : tab)
     if (!strcmp(t.k, name)) {

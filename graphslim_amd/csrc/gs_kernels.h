@@ -61,10 +61,11 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gs_real_softmax_grad_kernel(float* __restrict__ Z, const float* __restrict__ rs,
                                                                    const float* __restrict__ bl,
-                                                                   const int* __restrict__ n_seed, int bcap, int C) {
+                                                                   const int* __restrict__ n_seed, int bcap, int C,
+                                                                   int class0, int nclass_local) {
   const int lane = threadIdx.x & 63;
   const long grow = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (grow >= (long)C * bcap) return;
+  if (grow >= (long)nclass_local * bcap) return;
   const int c = (int)(grow / bcap), b = (int)(grow - (long)c * bcap);
   float* z = Z + grow * C;
   const int B = n_seed[c];
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void gs_real_softmax_grad_kernel(float* __rest
   const float inv = 1.f / se, invB = 1.f / (float)B;
   for (int k = lane; k < C; k += 64) {
     float p = expf(z[k] + r * bl[k] - mx) * inv;
-    z[k] = (p - (k == c ? 1.f : 0.f)) * invB;
+    z[k] = (p - (k == class0 + c ? 1.f : 0.f)) * invB;
   }
 }
 
@@ -123,11 +124,17 @@ __global__ __launch_bounds__(256) void gs_syn_v_kernel(const float* __restrict__
                                                        const float* __restrict__ D, long P_total, long off_bl,
                                                        const float* __restrict__ bl, const int* __restrict__ labels,
                                                        const int* __restrict__ syn_lo, const int* __restrict__ syn_hi, int n,
-                                                       int C, float* __restrict__ V, float* __restrict__ drs) {
+                                                       int C, int c_lo, int c_hi, float* __restrict__ V,
+                                                       float* __restrict__ drs) {
   const int lane = threadIdx.x & 63;
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (i >= n) return;
   const int y = labels[i];
+  if (y < c_lo || y >= c_hi) {     // rows of classes owned by another rank: no contribution from this rank
+    for (int k = lane; k < C; k += 64) V[i * C + k] = 0.f;
+    if (lane == 0) drs[i] = 0.f;
+    return;
+  }
   const float* Db = D + (long)y * P_total + off_bl;
   const float r = rs[i];
   const float invn = 1.f / (float)(syn_hi[y] - syn_lo[y]);
@@ -411,12 +418,12 @@ __global__ __launch_bounds__(256) void gs_pge_bn1_stats_kernel(const float* __re
 __global__ void gs_pge_make_a1_kernel(const float* __restrict__ U, const float* __restrict__ V, const float* __restrict__ b0,
                                       const float* __restrict__ mu1, const float* __restrict__ is1,
                                       const float* __restrict__ g1, const float* __restrict__ be1, int n, int Ph,
-                                      float* __restrict__ A1) {
+                                      int r_lo, int nr, float* __restrict__ A1) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)n * n * Ph) return;
+  if (idx >= (long)nr * n * Ph) return;
   const int k = (int)(idx % Ph);
   const long pair = idx / Ph;
-  const int r = (int)(pair / n), c = (int)(pair - (long)r * n);
+  const int rl = (int)(pair / n), c = (int)(pair - (long)rl * n), r = r_lo + rl;
   float x = (U[(long)c * Ph + k] + V[(long)r * Ph + k] + b0[k] - mu1[k]) * is1[k];
   A1[idx] = fmaxf(fmaf(g1[k], x, be1[k]), 0.f);
 }
@@ -437,29 +444,15 @@ __global__ __launch_bounds__(256) void gs_col_stats_kernel(const float* __restri
     part[((long)blockIdx.x * 2 + 1) * Ph + k] = s2;
   }
 }
-// block = 32 columns x 8 groups of partial blocks
-__global__ __launch_bounds__(256) void gs_bn2_finalize_kernel(const double* __restrict__ part, int nblk, long rows, int Ph,
-                                                              float* __restrict__ mu2, float* __restrict__ is2) {
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + tx;
-  __shared__ double sh[2][8][32];
-  double s = 0, s2 = 0;
-  if (k < Ph)
-    for (int b = ty; b < nblk; b += 8) {
-      s += part[((long)b * 2 + 0) * Ph + k];
-      s2 += part[((long)b * 2 + 1) * Ph + k];
-    }
-  sh[0][ty][tx] = s;
-  sh[1][ty][tx] = s2;
-  __syncthreads();
-  if (ty == 0 && k < Ph) {
-    s = s2 = 0;
-    for (int q = 0; q < 8; ++q) { s += sh[0][q][tx]; s2 += sh[1][q][tx]; }
-    double m = s / rows, v = s2 / rows - m * m;
-    if (v < 0) v = 0;
-    mu2[k] = (float)m;
-    is2[k] = (float)(1.0 / sqrt(v + 1e-5));
-  }
+// mean / inverse std of BN-2 from the (all-reduced) column sums:  sums = [sum x | sum x^2], fp64
+__global__ void gs_bn2_from_sums_kernel(const double* __restrict__ sums, long rows, int Ph, float* __restrict__ mu2,
+                                        float* __restrict__ is2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Ph) return;
+  double m = sums[k] / rows, v = sums[Ph + k] / rows - m * m;
+  if (v < 0) v = 0;
+  mu2[k] = (float)m;
+  is2[k] = (float)(1.0 / sqrt(v + 1e-5));
 }
 
 // e3[row] = sum_k relu(g2*(E2-mu2)*is2+be2) * w2[k] + b2      (one wave per pair)
@@ -529,10 +522,9 @@ __global__ __launch_bounds__(256) void gs_pge_l3_bwd_stats_kernel(const float* _
     part[((long)blockIdx.x * 3 + 2) * Ph + k] = sg;
   }
 }
-// grid = (ceil(Ph/32), nq); block = 32 columns x 8 groups of partial blocks
+// sums[q][k] = sum over partial blocks (fp64).  grid = (ceil(Ph/32), nq); block = 32 columns x 8 groups
 __global__ __launch_bounds__(256) void gs_sum_parts_kernel(const double* __restrict__ part, int nblk, int nq, int Ph,
-                                                           float* __restrict__ out0, float* __restrict__ out1,
-                                                           float* __restrict__ out2) {
+                                                           double* __restrict__ sums) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int k = blockIdx.x * 32 + tx, q = blockIdx.y;
   __shared__ double sh[8][32];
@@ -541,18 +533,27 @@ __global__ __launch_bounds__(256) void gs_sum_parts_kernel(const double* __restr
     for (int b = ty; b < nblk; b += 8) s += part[((long)b * nq + q) * Ph + k];
   sh[ty][tx] = s;
   __syncthreads();
-  float* o = q == 0 ? out0 : (q == 1 ? out1 : out2);
-  if (ty == 0 && k < Ph && o) {
+  if (ty == 0 && k < Ph) {
     s = 0;
     for (int g = 0; g < 8; ++g) s += sh[g][tx];
-    o[k] = (float)s;
+    sums[(long)q * Ph + k] = s;
   }
+}
+// out_q[k] = (float) sums[q][k]
+__global__ void gs_sums_to_float_kernel(const double* __restrict__ sums, int nq, int Ph, float* __restrict__ out0,
+                                        float* __restrict__ out1, float* __restrict__ out2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Ph) return;
+  if (out0) out0[k] = (float)sums[k];
+  if (nq > 1 && out1) out1[k] = (float)sums[Ph + k];
+  if (nq > 2 && out2) out2[k] = (float)sums[2 * Ph + k];
 }
 // dE2[row,k] = g2*is2 * (dy2 - dbe2/N - xh2*dg2/N)
 __global__ void gs_pge_bn2_bwd_kernel(const float* __restrict__ E2, const float* __restrict__ de3, const float* __restrict__ mu2,
                                       const float* __restrict__ is2, const float* __restrict__ g2, const float* __restrict__ be2,
                                       const float* __restrict__ w2, const float* __restrict__ dbe2,
-                                      const float* __restrict__ dg2, long rows, int Ph, float* __restrict__ dE2) {
+                                      const float* __restrict__ dg2, long rows, long total_rows, int Ph,
+                                      float* __restrict__ dE2) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * Ph) return;
   const int k = (int)(idx % Ph);
@@ -560,26 +561,27 @@ __global__ void gs_pge_bn2_bwd_kernel(const float* __restrict__ E2, const float*
   float xh = (E2[idx] - mu2[k]) * is2[k];
   float y = fmaf(g2[k], xh, be2[k]);
   float dy = y > 0.f ? de3[r] * w2[k] : 0.f;
-  float invN = 1.f / (float)rows;
+  float invN = 1.f / (float)total_rows;
   dE2[idx] = g2[k] * is2[k] * (dy - dbe2[k] * invN - xh * dg2[k] * invN);
 }
 
 // marginal sums of dY1 [(r,c), k]:  colsum_r[r,k] = sum_c,  rowsum_c[c,k] = sum_r
-__global__ __launch_bounds__(256) void gs_pge_marginal_r_kernel(const float* __restrict__ dY1, int n, int Ph,
+// (dY1 holds the nr local pair rows r_lo .. r_lo+nr-1; colsum_r is written for those rows, rowsum_c is the partial sum)
+__global__ __launch_bounds__(256) void gs_pge_marginal_r_kernel(const float* __restrict__ dY1, int n, int Ph, int r_lo,
                                                                 float* __restrict__ colsum_r) {
-  const int r = blockIdx.x;
+  const int rl = blockIdx.x;
   for (int k = threadIdx.x; k < Ph; k += 256) {
     float s = 0.f;
-    for (int c = 0; c < n; ++c) s += dY1[((long)r * n + c) * Ph + k];
-    colsum_r[(long)r * Ph + k] = s;
+    for (int c = 0; c < n; ++c) s += dY1[((long)rl * n + c) * Ph + k];
+    colsum_r[(long)(r_lo + rl) * Ph + k] = s;
   }
 }
-__global__ __launch_bounds__(256) void gs_pge_marginal_c_kernel(const float* __restrict__ dY1, int n, int Ph,
+__global__ __launch_bounds__(256) void gs_pge_marginal_c_kernel(const float* __restrict__ dY1, int n, int Ph, int nr,
                                                                 float* __restrict__ rowsum_c) {
   const int c = blockIdx.x;
   for (int k = threadIdx.x; k < Ph; k += 256) {
     float s = 0.f;
-    for (int r = 0; r < n; ++r) s += dY1[((long)r * n + c) * Ph + k];
+    for (int r = 0; r < nr; ++r) s += dY1[((long)r * n + c) * Ph + k];
     rowsum_c[(long)c * Ph + k] = s;
   }
 }

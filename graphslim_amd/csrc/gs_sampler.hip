@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
                                                              const float* __restrict__ val, int n_nodes,
                                                              const int* __restrict__ cls_ptr,
                                                              const int* __restrict__ cls_nodes, int* marker,
-                                                             gs_blocks blk, uint64_t seed, uint32_t step) {
+                                                             gs_blocks blk, uint64_t seed, uint32_t step, int class_key0) {
   const int c = blockIdx.x, tid = threadIdx.x;
+  const int ckey = class_key0 + c;   // RNG key = global class id (a class shard draws what the full run draws)
   const int bcap = blk.bcap, f1 = blk.f1, cap1 = blk.cap1;
   const int* pool = cls_nodes + cls_ptr[c];
   const int npool = cls_ptr[c + 1] - cls_ptr[c];
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
     if (tid == 0) {
       int ns = 0;
       for (int j = npool - B; j < npool; ++j) {
-        int t = (int)gs_rand_below(seed ^ 0x5eedull, step, (uint32_t)c, (uint32_t)ns, (uint32_t)(j + 1));
+        int t = (int)gs_rand_below(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)ns, (uint32_t)(j + 1));
         // membership test in an open-addressing set
         int h = (int)((uint32_t)t * 2654435761u >> 22);
         bool found = false;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
     v = s_seed[tid];
     e0 = rowptr[v];
     int deg = rowptr[v + 1] - e0;
-    k = sample_row(deg, f1, s_sel + tid * GS_MAX_F, seed ^ 0x1111ull, step, (uint32_t)(c * GS_MAX_BCAP + tid));
+    k = sample_row(deg, f1, s_sel + tid * GS_MAX_F, seed ^ 0x1111ull, step, (uint32_t)(ckey * GS_MAX_BCAP + tid));
     mk_store(&mk[v], tid - GS_MARK_BIAS);          // seeds take local ids 0..B-1
     blk.nid1[(long)c * cap1 + tid] = v;
   }
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
   for (int j = 0; j < k; ++j) {
     int lid = mk_load(&mk[s_g[tid * GS_MAX_F + j]]) + GS_MARK_BIAS;
     blk.col1[((long)c * bcap + tid) * f1 + j] = lid;
-    s_g[tid * GS_MAX_F + j] = lid | (s_g[tid * GS_MAX_F + j] << 0) * 0;   // keep lid only (global id no longer needed)
+    s_g[tid * GS_MAX_F + j] = lid;   // the global id is no longer needed
     atomicAdd(&s_cnt[lid], 1);
   }
   __syncthreads();
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
 
 __global__ __launch_bounds__(256) void gs_sample_hop2_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                              const float* __restrict__ val, gs_blocks blk, uint64_t seed,
-                                                             uint32_t step) {
+                                                             uint32_t step, int class_key0) {
   const int c = blockIdx.y, tid = threadIdx.x;
   const int l = blockIdx.x * 256 + tid;
   const int f2 = blk.f2, cap1 = blk.cap1;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void gs_sample_hop2_kernel(const int* __restri
   }
   const int v = blk.nid1[(long)c * cap1 + l];
   const int e0 = rowptr[v], deg = rowptr[v + 1] - e0;
-  const int k = sample_row(deg, f2, s_sel + tid * GS_MAX_F, seed ^ 0x2222ull, step, (uint32_t)(c * 65536 + l));
+  const int k = sample_row(deg, f2, s_sel + tid * GS_MAX_F, seed ^ 0x2222ull, step, (uint32_t)((class_key0 + c) * 65536 + l));
   for (int j = 0; j < f2; ++j) {
     if (j < k) {
       int e = e0 + s_sel[tid * GS_MAX_F + j];
@@ -222,9 +223,9 @@ __global__ __launch_bounds__(256) void gs_sample_hop2_kernel(const int* __restri
   }
 }
 
-extern "C" int gs_sample_blocks(const int* rowptr, const int* col, const float* val, int n_nodes, const int* cls_ptr,
-                                const int* cls_nodes, int* marker, const gs_blocks* out, uint64_t seed, uint32_t step,
-                                gs_stream_t stream) {
+int gs_sample_blocks_ex(const int* rowptr, const int* col, const float* val, int n_nodes, const int* cls_ptr,
+                        const int* cls_nodes, int* marker, const gs_blocks* out, uint64_t seed, uint32_t step, int class_key0,
+                        gs_stream_t stream) {
   if (!rowptr || !col || !val || !cls_ptr || !cls_nodes || !marker || !out) GS_FAIL(GS_ERR_ARG, "gs_sample_blocks: null pointer");
   const gs_blocks& b = *out;
   if (b.bcap < 1 || b.bcap > GS_MAX_BCAP) GS_FAIL(GS_ERR_ARG, "gs_sample_blocks: bcap must be in [1, %d]", GS_MAX_BCAP);
@@ -234,9 +235,15 @@ extern "C" int gs_sample_blocks(const int* rowptr, const int* col, const float* 
   if (b.C < 1) return GS_OK;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gs_sample_hop1_kernel, dim3(b.C), dim3(256), 0, s, rowptr, col, val, n_nodes, cls_ptr, cls_nodes,
-                     marker, b, seed, step);
+                     marker, b, seed, step, class_key0);
   hipLaunchKernelGGL(gs_sample_hop2_kernel, dim3(gs_cdiv(b.cap1, 256), b.C), dim3(256), 0, s, rowptr, col, val, b, seed,
-                     step);
+                     step, class_key0);
   GS_LAUNCH_CHECK();
   return GS_OK;
+}
+
+extern "C" int gs_sample_blocks(const int* rowptr, const int* col, const float* val, int n_nodes, const int* cls_ptr,
+                                const int* cls_nodes, int* marker, const gs_blocks* out, uint64_t seed, uint32_t step,
+                                gs_stream_t stream) {
+  return gs_sample_blocks_ex(rowptr, col, val, n_nodes, cls_ptr, cls_nodes, marker, out, seed, step, 0, stream);
 }

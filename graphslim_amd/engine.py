@@ -319,6 +319,28 @@ class GCondEngine:
     def outer_step(self, epoch):
         check(self.L.gs_gcond_outer_step(self.h, epoch, stream()))
 
+    # ---- sharded (multi-GPU) driving: see graphslim_amd/parallel.py ------------------------------------
+    def set_shard(self, c_lo, c_hi, r_lo, r_hi):
+        check(self.L.gs_gcond_set_shard(self.h, c_lo, c_hi, r_lo, r_hi))
+
+    def pge_forward_part(self, inference, part):
+        check(self.L.gs_gcond_stage_pge_forward_part(self.h, int(inference), part, stream()))
+
+    def pge_backward_part(self, need_param_grads, need_feat_grad, part):
+        check(self.L.gs_gcond_stage_pge_backward_part(self.h, int(need_param_grads), int(need_feat_grad), part, stream()))
+
+    def syn_finish(self):
+        check(self.L.gs_gcond_stage_syn_finish(self.h, stream()))
+
+    def inner_steps(self):
+        check(self.L.gs_gcond_stage_inner_steps(self.h, stream()))
+
+    def view(self, name, dtype=torch.float32):
+        """Zero-copy torch view of a named engine buffer (the all-reduce buffers are exchanged in place)."""
+        p, cnt = C.c_void_p(), C.c_long()
+        check(self.L.gs_gcond_buffer(self.h, name.encode(), C.byref(p), C.byref(cnt)))
+        return device_view(p.value, cnt.value, dtype, self.dev)
+
     def read_loss(self):
         s, k = C.c_double(), C.c_long()
         check(self.L.gs_gcond_read_loss(self.h, C.byref(s), C.byref(k), stream()))

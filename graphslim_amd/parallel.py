@@ -1,5 +1,108 @@
-"""Multi-GPU (one process per GPU, RCCL) — filled in below once the single-GPU profile is known."""
+"""Multi-GPU GCond: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+
+What shards: inside one outer iteration theta, X~ and A^ are fixed, so the C class terms of
+train_class (gcond_base.py:210-239) are independent summands — classes are partitioned over ranks (sampler, real-side
+gradients, per-class synthetic terms) — and the PGE works on the n' x n' pair grid row by row — pair rows are
+partitioned over ranks.  What is exchanged: sums of per-rank partials only, five to eight all-reduce(sum) of <= 1.1 MB
+per outer iteration (BN-2 column sums, pair scores, [dX~ | d adj | loss_c], BN-2 backward sums, BN-1 marginals, and
+dW1/db1 in PGE epochs).  After each exchange every rank holds identical values, applies the identical fused Adam step
+and runs the (tiny) inner SGC steps replicated, so the replicas never drift.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def split_even(n, world):
+    """[lo, hi) of `n` items for each of `world` ranks, sizes differing by at most one."""
+    base, rem = divmod(n, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def split_classes(costs, world):
+    """Contiguous class ranges with balanced total cost (cost ~ seeds drawn per class = min(256, pool size))."""
+    costs = np.asarray(costs, dtype=np.float64)
+    total, out, lo, acc = costs.sum(), [], 0, 0.0
+    for r in range(world):
+        target = total * (r + 1) / world
+        hi = lo
+        while hi < len(costs) and (acc + costs[hi] <= target + 1e-9 or hi == lo) and len(costs) - hi > world - r - 1:
+            acc += costs[hi]
+            hi += 1
+        if r == world - 1:
+            hi = len(costs)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+class Collective:
+    """all-reduce(sum) in place on engine buffers.  `dist` = torch.distributed (nccl on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, dist=None, group=None):
+        self.dist, self.group = dist, group
+
+    def allreduce(self, t):
+        if self.dist is not None and self.dist.get_world_size(self.group) > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+class ShardedGCond:
+    """Drives one rank's engine through a sharded outer iteration (same order as gs_gcond_outer_step)."""
+
+    parallelism = "class-parallel + PGE pair-row sharding, all-reduce(sum)"
+
+    def __init__(self, engine, rank, world, pool_sizes, collective: Collective):
+        self.eng, self.rank, self.world, self.col = engine, rank, world, collective
+        s = engine.shapes
+        self.class_ranges = split_classes([min(s.bcap, int(p)) for p in pool_sizes], world)
+        self.row_ranges = split_even(s.n_syn, world)
+        (c_lo, c_hi), (r_lo, r_hi) = self.class_ranges[rank], self.row_ranges[rank]
+        engine.set_shard(c_lo, c_hi, r_lo, r_hi)
+        f64 = torch.float64
+        self.v = {k: engine.view(k, f64 if k in ("ar_bn2", "ar_l3") else torch.float32)
+                  for k in ("ar_bn2", "ar_l3", "e3", "ar_syn", "ar_marg", "ar_w1")}
+        # passthroughs so a ShardedGCond can stand in for a GCondEngine in bench.py / GCond.reduce
+        for name in ("set_feat", "set_pge", "set_model", "get_model", "get_pge", "read_loss", "buffer", "shapes", "dev", "feat_syn",
+                     "adj_syn", "pge_params", "model_params", "stage_sample", "get_blocks"):
+            setattr(self, name, getattr(engine, name))
+
+    def phases(self, epoch):
+        """The sharded outer iteration as (stage call, name of the buffer to all-reduce afterwards or None)."""
+        e = self.eng
+        pge_epoch = epoch % 50 < 10
+        np_, nf = pge_epoch, not pge_epoch
+
+        def fwd(inference):
+            return [(lambda: e.pge_forward_part(inference, 1), "ar_bn2"), (lambda: e.pge_forward_part(inference, 2), "e3"),
+                    (lambda: e.pge_forward_part(inference, 3), None)]
+
+        ph = [(e.stage_sample, None), (e.stage_real_grads, None)] + fwd(False)
+        ph += [(e.stage_syn_match, "ar_syn"), (e.syn_finish, None),
+               (lambda: e.pge_backward_part(np_, nf, 1), "ar_l3"),
+               (lambda: e.pge_backward_part(np_, nf, 2), "ar_marg")]
+        if pge_epoch:
+            ph += [(lambda: None, "ar_w1")]
+        ph += [(lambda: e.pge_backward_part(np_, nf, 3), None), (lambda: e.stage_update(epoch), None)]
+        ph += fwd(True) + [(e.inner_steps, None)]
+        return ph
+
+    def outer_step(self, epoch):
+        for fn, buf in self.phases(epoch):
+            fn()
+            if buf is not None:
+                self.col.allreduce(self.v[buf])
 
 
 def make_engine(p, dev, rank, world):
-    raise NotImplementedError("multi-GPU engine not built yet")
+    """bench.py entry: this rank's sharded engine over torch.distributed (process group already initialised)."""
+    import torch.distributed as dist
+    import bench
+    eng = bench.make_engine(p, dev)
+    return ShardedGCond(eng, rank, world, [len(q) for q in p["pools"]], Collective(dist))

@@ -212,6 +212,21 @@ int gs_gcond_stage_pge_backward(gs_gcond* e, int need_param_grads, int need_feat
 int gs_gcond_stage_update(gs_gcond* e, int epoch, gs_stream_t stream);
 int gs_gcond_stage_inner(gs_gcond* e, gs_stream_t stream);
 
+/* ---- multi-GPU (one process per GPU): shard the independent units across ranks --------------------------------
+ * Classes [c_lo, c_hi) are this rank's share of the sampler, of the real-side gradients and of the per-class
+ * synthetic terms of train_class (gcond_base.py:210-239: the class terms are independent summands); pair rows
+ * [r_lo, r_hi) its share of the PGE n' x n' grid.  Everything that crosses ranks is a SUM of per-rank partials in a
+ * contiguous buffer, so the only collective is all-reduce(sum) (RCCL) on these gs_gcond_buffer views, between parts:
+ *   pge_forward_part 1 -> "ar_bn2" (fp64, 2*Ph) -> part 2 -> "e3" (n'^2) -> part 3
+ *   syn_match -> "ar_syn" ([d_feat | d_adj | loss_c]) -> syn_finish
+ *   pge_backward_part 1 -> "ar_l3" (fp64, 3*Ph) -> part 2 -> "ar_marg" (2*n'*Ph) [+ "ar_w1" (Ph^2+Ph) when the PGE
+ *   is stepped] -> part 3.     The reference has no distributed code; this is new. */
+int gs_gcond_set_shard(gs_gcond* e, int c_lo, int c_hi, int r_lo, int r_hi);
+int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int part, gs_stream_t stream);
+int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grads, int need_feat_grad, int part, gs_stream_t stream);
+int gs_gcond_stage_syn_finish(gs_gcond* e, gs_stream_t stream);       /* books the (all-reduced) loss_c into the accumulator */
+int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream);      /* the SGC steps of gs_gcond_stage_inner, without PGE.inference */
+
 /* Named views into engine-owned scratch for the parity tests (device pointer + element count):
  * "gw_real" [C][|theta|], "gw_syn" [C][|theta|], "loss" [1], "d_feat" [n'][d] (total gradient wrt X~),
  * "d_feat_direct", "d_adj_norm" [n'][n'], "d_adj" [n'][n'], "d_pge" [|theta_pge|], "adj_norm", "adj_raw",

@@ -239,3 +239,62 @@ def test_error_paths():
     eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 1, p["ph"], p["labels_syn"], p["ranges"], p["x"], 4, 3)
     with pytest.raises(_lib.GslimError):      # external blocks never supplied
         eng.outer_step(0)
+
+
+class _LockStep:
+    """world sharded engines on ONE GPU driven phase by phase; the all-reduce is emulated by summing the buffers."""
+
+    def __init__(self, shs):
+        self.shs = shs
+
+    def outer_step(self, epoch):
+        phases = [sh.phases(epoch) for sh in self.shs]
+        for i in range(len(phases[0])):
+            for ph in phases:
+                ph[i][0]()
+            buf = phases[0][i][1]
+            if buf is not None:
+                views = [sh.v[buf] for sh in self.shs]
+                total = torch.stack(views).sum(0)
+                for v in views:
+                    v.copy_(total)
+
+
+@pytest.mark.parametrize("t,world", [(1, 2), (2, 2), (2, 3), (2, 8)])
+def test_sharded_engines_reproduce_the_single_gpu_run(t, world):
+    """class-parallel + PGE pair-row sharding with all-reduce(sum) == the unsharded iteration
+    (same sampled blocks because the sampler keys its RNG by the global class id)."""
+    from graphslim_amd.parallel import Collective, ShardedGCond
+    p = _problem(t, seed=21, nclass=5)
+
+    def build():
+        eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], t, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
+                          p["f2"], bcap=p["bcap"], inner=2, lrs=(0.01, 0.005, 0.02), csr=p["csr"], pools=p["pools"],
+                          external=False, seed=5)
+        eng.set_feat(p["xs"])
+        eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
+        return eng
+
+    ref = build()
+    engs = [build() for _ in range(world)]
+    shs = [ShardedGCond(e, r, world, [len(q) for q in p["pools"]], Collective(None)) for r, e in enumerate(engs)]
+    lock = _LockStep(shs)
+    for epoch in (0, 10):
+        ref.set_model(p["theta"])
+        for e in engs:
+            e.set_model(p["theta"])
+        for _ in range(2):
+            ref.outer_step(epoch)
+            lock.outer_step(epoch)
+            l0 = float(ref.buffer("loss")[0])
+            for e in engs:
+                assert abs(float(e.buffer("loss")[0]) - l0) <= 2e-5 * abs(l0)
+    for e in engs:
+        np.testing.assert_allclose(e.feat_syn.cpu().numpy(), ref.feat_syn.cpu().numpy(), atol=2e-4)
+        np.testing.assert_allclose(e.adj_syn.cpu().numpy(), ref.adj_syn.cpu().numpy(), atol=2e-4)
+        np.testing.assert_allclose(e.pge_params.cpu().numpy(), ref.pge_params.cpu().numpy(), atol=5e-4)
+        np.testing.assert_allclose(e.model_params.cpu().numpy(), ref.model_params.cpu().numpy(), atol=5e-4)
+    # replicas hold identical state after the exchanges (no drift between ranks)
+    for e in engs[1:]:
+        assert torch.equal(e.feat_syn, engs[0].feat_syn) and torch.equal(e.pge_params, engs[0].pge_params)
+        assert torch.equal(e.model_params, engs[0].model_params)
