@@ -63,6 +63,7 @@ def test_train_class_against_reference_golden(golden_dir, tag, metric):
     close(eng.buffer("adj_norm", (len(labels_syn), -1)), g[f"{tag}_adj_norm"], 2e-5, "adj_norm")
     # matching loss + second-order backward
     eng.stage_syn_match()
+    eng.syn_finish()
     loss = float(eng.buffer("loss")[0])
     assert abs(loss - float(g[f"{tag}_loss"])) <= 1e-4 * abs(float(g[f"{tag}_loss"])), (loss, float(g[f"{tag}_loss"]))
     close(eng.buffer("d_adj_norm", (len(labels_syn), -1)), g[f"{tag}_dadj_norm"], 1e-3, "d loss / d A^")
@@ -220,6 +221,7 @@ def test_engine_sampled_blocks_loss_matches_oracle():
     eng.stage_real_grads()
     eng.stage_pge_forward(False)
     eng.stage_syn_match()
+    eng.syn_finish()
     loss = float(eng.buffer("loss")[0])
     batches = blocks_to_batches(eng.get_blocks())
     theta = [t.clone().requires_grad_(True) for t in p["theta"]]
@@ -292,9 +294,43 @@ def test_sharded_engines_reproduce_the_single_gpu_run(t, world):
     for e in engs:
         np.testing.assert_allclose(e.feat_syn.cpu().numpy(), ref.feat_syn.cpu().numpy(), atol=2e-4)
         np.testing.assert_allclose(e.adj_syn.cpu().numpy(), ref.adj_syn.cpu().numpy(), atol=2e-4)
-        np.testing.assert_allclose(e.pge_params.cpu().numpy(), ref.pge_params.cpu().numpy(), atol=5e-4)
+        # layers.{0,1}.bias sit in front of a batch-stat BatchNorm: exactly-zero true gradient, Adam random-walks them
+        # on rounding noise (in the reference too) and they cannot influence adj_syn -> excluded
+        ph, d = p["ph"], p["d"]
+        keep = np.ones(ref.pge_params.numel(), dtype=bool)
+        keep[ph * 2 * d: ph * 2 * d + ph] = False
+        keep[ph * 2 * d + ph + ph * ph: ph * 2 * d + ph + ph * ph + ph] = False
+        np.testing.assert_allclose(e.pge_params.cpu().numpy()[keep], ref.pge_params.cpu().numpy()[keep], atol=5e-4)
         np.testing.assert_allclose(e.model_params.cpu().numpy(), ref.model_params.cpu().numpy(), atol=5e-4)
     # replicas hold identical state after the exchanges (no drift between ranks)
     for e in engs[1:]:
         assert torch.equal(e.feat_syn, engs[0].feat_syn) and torch.equal(e.pge_params, engs[0].pge_params)
         assert torch.equal(e.model_params, engs[0].model_params)
+
+
+def test_rccl_allreduce_on_engine_views_world1():
+    """The collectives of graphslim_amd/parallel.py run on zero-copy views of library-owned buffers (fp32 and fp64):
+    check that RCCL accepts them (single-rank group on this box; multi-rank equivalence is covered by the lock-step test)."""
+    import os
+    import torch.distributed as dist
+    from graphslim_amd.parallel import Collective, ShardedGCond
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        p = _problem(2, seed=3)
+        eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 2, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
+                          p["f2"], bcap=p["bcap"], inner=1, csr=p["csr"], pools=p["pools"], external=False, seed=5)
+        eng.set_feat(p["xs"])
+        eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
+        eng.set_model(p["theta"])
+        sh = ShardedGCond(eng, 0, 1, [len(q) for q in p["pools"]], Collective(dist))
+        sh.outer_step(0)
+        for name, v in sh.v.items():
+            before = v.clone()
+            dist.all_reduce(v)                      # world 1: identity, but exercises RCCL on the view
+            torch.cuda.synchronize()
+            assert torch.equal(v, before), name
+        assert np.isfinite(float(eng.buffer("loss")[0]))
+    finally:
+        dist.destroy_process_group()
