@@ -105,8 +105,13 @@ def roofline_probe(eng, reps=20):
     flops = 2.0 * rows * ph * ph
     peak = 157.3      # TFLOP/s, fp32 matrix (MI355X_MICROARCH.md chip table)
     ach = flops / sec / 1e12
-    return {"bound": "mfma", "kernel": "gs_gemm_f32_kernel<128,128,64,64> (PGE layer 2, fp32 MFMA 32x32x2)",
-            "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+    # HBM traffic of this kernel at this shape from rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of
+    # tools/probe_kernels.py, profiles/r01/pmc_*): 209 843 KiB fetched + 206 116 KiB written per launch = the
+    # algorithmic A-read + C-write (the 64-B row-segment loads of this kernel count 1:1 — the A operand is exactly
+    # 206 116 KiB — so no gfx950 x2 correction applies to this access pattern).  PMC cannot be sampled inside bench.py.
+    traffic = (209843 + 206116) * 1024 if (n, ph) == (454, 256) else None
+    return {"bound": "mfma", "kernel": "gs_gemm_f32_kernel<128,128,64,64,K,K> (PGE layer 2, fp32 MFMA 32x32x2)",
+            "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
             "avg_launch_us": round(sec * 1e6, 2), "flops_per_launch": flops}
 
 
@@ -248,7 +253,7 @@ def main():
                        "parallelism": getattr(eng, "parallelism", "single")},
         }
         out["roofline"] = roofline_probe(eng)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(p, eng)
         print(json.dumps(out))
     if world > 1:
