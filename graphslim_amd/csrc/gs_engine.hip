@@ -77,6 +77,7 @@ struct gs_gcond {
   // shard of this rank: classes [c_lo, c_hi) (real side + per-class synthetic terms), PGE pair rows [r_lo, r_hi)
   int c_lo, c_hi, r_lo, r_hi;
   double* sums;     // [3][Ph] fp64 column sums exchanged between ranks
+  float* statp;     // [ceil(n'^2 / 32)][2][Ph] per-tile column sums written by the E2 GEMM epilogue
   float *ar_syn, *ar_marg;
 };
 
@@ -172,6 +173,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->dV = w.take<float>(n * Ph); e->d_pge = w.take<float>(e->Ppge); e->slabs_w = w.take<float>(e->nsplit_w * Ph * Ph);
   e->parts = w.take<double>((long)e->nblk_stats * 3 * Ph);
   e->sums = w.take<double>(3 * Ph);
+  e->statp = w.take<float>((long)gs_cdiv(n2, 32) * 2 * Ph);
   e->adj_norm_in = w.take<float>(n2); e->rnorm_in = w.take<float>(2 * n); e->Qin = w.take<float>(n2);
   e->rsq_in = w.take<float>(n); e->S_in = w.take<float>(n * F); e->g_model = w.take<float>(P);
   e->m_feat = w.take<float>(n * d); e->v_feat = w.take<float>(n * d);
@@ -259,6 +261,8 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
     (void)hipMemsetAsync(e->v_pge, 0, sizeof(float) * e->Ppge, s);
     (void)hipMemsetAsync(e->m_model, 0, sizeof(float) * e->P, s);
     (void)hipMemsetAsync(e->v_model, 0, sizeof(float) * e->P, s);
+    (void)hipMemsetAsync(e->gw_real, 0, sizeof(float) * C * e->P, s);
+    (void)hipMemsetAsync(e->gw_syn, 0, sizeof(float) * C * e->P, s);
     (void)hipMemsetAsync(e->loss_sum, 0, sizeof(double), s);
     (void)hipMemsetAsync(e->loss_last, 0, sizeof(float), s);
     (void)hipMemsetAsync(e->steps, 0, sizeof(long), s);
@@ -446,7 +450,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     gwd.sBb1 = K * h; gwd.sCb1 = (long)e->nsplit_r * d * h; gwd.sCb2 = (long)d * h;
     GS_TRY(gs_gemm_f32(&gwd, stream));
     GS_TRY(gs_reduce_slabs_batched_f32(gw + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, Cl, 0.f, stream));
-    GS_TRY(colsum_batched(e, Bmat, K * h, (int)K, kcount, h, Cl, gw + e->ob1, P, stream));
+    if (e->cfg.dis_metric != 0)   // 'ours' gives every bias a zero distance and a zero D (condensation/utils.py:98-101)
+      GS_TRY(colsum_batched(e, Bmat, K * h, (int)K, kcount, h, Cl, gw + e->ob1, P, stream));
   }
   return GS_OK;
 }
@@ -479,9 +484,10 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       GS_LAUNCH_CHECK();
       gs_gemm_desc g = mk(e->A1, Ph, 1, pp + e->pW1, 1, Ph, e->E2, Ph, (int)rows, Ph, Ph);     // E2 = A1 W1^T + b1
       g.bias = pp + e->pb1;
+      g.colstat = e->statp;            // BN-2 batch statistics come out of the epilogue: no second pass over E2
       GS_TRY(gs_gemm_f32(&g, stream));
-      hipLaunchKernelGGL(gs_col_stats_kernel, dim3(nblk), dim3(256), 0, s, e->E2, rows, Ph, e->rows_per_block, e->parts);
-      hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 32), 2), dim3(256), 0, s, e->parts, nblk, 2, Ph, e->sums);
+      hipLaunchKernelGGL(gs_sum_parts_f32_kernel, dim3(gs_cdiv(Ph, 32), 2), dim3(256), 0, s, e->statp, gs_gemm_tiles_m(&g), 2, Ph,
+                         e->sums);
       GS_LAUNCH_CHECK();
     } else {
       GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 2 * Ph, s));
@@ -582,7 +588,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       gs_gemm_desc c = mk(X, 1, d, dHp, h, 1, gws + e->oW1, h, d, h, n);
       c.nb1 = Cl; c.sBb1 = (long)n * h; c.sCb1 = P;
       GS_TRY(gs_gemm_f32(&c, stream));
-      GS_TRY(colsum_batched(e, dHp, (long)n * h, n, nullptr, h, Cl, gws + e->ob1, P, stream));
+      if (e->cfg.dis_metric != 0) GS_TRY(colsum_batched(e, dHp, (long)n * h, n, nullptr, h, Cl, gws + e->ob1, P, stream));
     }
     // ---- matching distance and D = d loss / d gw_syn (already scaled by n_c / n') -------------------
     float* stats = e->stats + c0 * e->pd.total_cols * 3; float* ab = e->ab + c0 * e->pd.total_cols * 2;

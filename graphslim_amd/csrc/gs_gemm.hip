@@ -210,6 +210,10 @@ __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
   // Optional inputs (bias / mask / old C) are fetched 16 at a time behind block-uniform branches with clamped
   // addresses, so no load sits behind a per-element branch.
   const bool has_bias = p.bias != nullptr, has_mask = p.mask != nullptr, has_beta = p.beta != 0.f;
+  const bool has_stat = p.colstat != nullptr;
+  float cs1[TN], cs2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -235,9 +239,37 @@ __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
         if (p.relu) v = fmaxf(v, 0.f);
         if (has_mask) v = (mk[r] > 0.f) ? v : 0.f;
         if (has_beta) v += p.beta * cv[r];
-        if (row < M && col < p.N) C[(long)row * p.ldc + col] = v;
+        if (row < M && col < p.N) {
+          C[(long)row * p.ldc + col] = v;
+          cs1[j] += v;
+          cs2[j] = fmaf(v, v, cs2[j]);
+        }
       }
     }
+  if (has_stat) {
+    // per-block column sums of the written tile: colstat[(blockIdx.y*2 + q)*N + col], q = 0: sum, 1: sum of squares
+    // (BatchNorm statistics without a second pass over C).  Reduce: lane halves -> waves along M (through LDS) -> global.
+    constexpr int WAVES_M = BM / WM;
+    __syncthreads();                       // the operand tiles are dead: reuse As as scratch
+    float* red = As;                       // [2][WAVES_M][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float a = cs1[j] + __shfl_xor(cs1[j], 32, 64), b = cs2[j] + __shfl_xor(cs2[j], 32, 64);
+      if (kh == 0) {
+        const int c = wn0 + j * 32 + li;
+        red[(0 * WAVES_M + wave / WAVES_N) * BN + c] = a;
+        red[(1 * WAVES_M + wave / WAVES_N) * BN + c] = b;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += 256) {
+      const int q = c / BN, cc = c % BN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) t += red[(q * WAVES_M + w) * BN + cc];
+      if (n0 + cc < p.N) p.colstat[((long)blockIdx.y * 2 + q) * p.N + n0 + cc] = t;
+    }
+  }
 }
 
 __global__ void gs_reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, long n, int ns,
@@ -300,20 +332,37 @@ static int launch_gemm(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
   return launch_gemm2<BM, BN, WM, WN, GS_MODE_M, GS_MODE_M>(p, nbatch, s);
 }
 
+static int pick_tile(const gs_gemm_desc& p, int nbatch) {   // 0: 128x32, 1: 32x128, 2: 64x64, 3: 128x128
+  if (p.N <= 32) return 0;
+  if (p.M <= 32) return 1;
+  long tiles128 = (long)gs_cdiv(p.M, 128) * gs_cdiv(p.N, 128) * nbatch;
+  if (p.M <= 64 || p.N <= 64 || tiles128 < 192) return 2;
+  return 3;
+}
+
+extern "C" int gs_gemm_tiles_m(const gs_gemm_desc* d) {
+  if (!d) return 0;
+  const int nb = (d->nb1 < 1 ? 1 : d->nb1) * (d->nb2 < 1 ? 1 : d->nb2);
+  static const int bm[4] = {128, 32, 64, 128};
+  return gs_cdiv(d->M, bm[pick_tile(*d, nb)]);
+}
+
 extern "C" int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream) {
   if (!d || !d->A || !d->B || !d->C) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: null operand");
   gs_gemm_desc p = *d;
   if (p.M <= 0 || p.N <= 0) return GS_OK;
   if (p.K < 0) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: negative K");
+  if (p.colstat && (p.nb1 > 1 || p.nb2 > 1)) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: colstat is for unbatched calls");
   if (p.nb1 < 1) p.nb1 = 1;
   if (p.nb2 < 1) p.nb2 = 1;
   const int nbatch = p.nb1 * p.nb2;
   if ((long)nbatch > 65535) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: too many batches (%d)", nbatch);
   hipStream_t s = (hipStream_t)stream;
   // tile choice: fill the 256 CUs; narrow outputs get the tall/flat tiles
-  if (p.N <= 32) return launch_gemm<128, 32, 32, 32>(p, nbatch, s);
-  if (p.M <= 32) return launch_gemm<32, 128, 32, 32>(p, nbatch, s);
-  long tiles128 = (long)gs_cdiv(p.M, 128) * gs_cdiv(p.N, 128) * nbatch;
-  if (p.M <= 64 || p.N <= 64 || tiles128 < 192) return launch_gemm<64, 64, 32, 32>(p, nbatch, s);
-  return launch_gemm<128, 128, 64, 64>(p, nbatch, s);
+  switch (pick_tile(p, nbatch)) {
+    case 0: return launch_gemm<128, 32, 32, 32>(p, nbatch, s);
+    case 1: return launch_gemm<32, 128, 32, 32>(p, nbatch, s);
+    case 2: return launch_gemm<64, 64, 32, 32>(p, nbatch, s);
+    default: return launch_gemm<128, 128, 64, 64>(p, nbatch, s);
+  }
 }

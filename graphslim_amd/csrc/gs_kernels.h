@@ -539,6 +539,23 @@ __global__ __launch_bounds__(256) void gs_sum_parts_kernel(const double* __restr
     sums[(long)q * Ph + k] = s;
   }
 }
+// same from fp32 partials laid out [blk][nq][Ph] (the GEMM epilogue's colstat)
+__global__ __launch_bounds__(256) void gs_sum_parts_f32_kernel(const float* __restrict__ part, int nblk, int nq, int Ph,
+                                                               double* __restrict__ sums) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + tx, q = blockIdx.y;
+  __shared__ double sh[8][32];
+  double s = 0;
+  if (k < Ph)
+    for (int b = ty; b < nblk; b += 8) s += (double)part[((long)b * nq + q) * Ph + k];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && k < Ph) {
+    s = 0;
+    for (int g = 0; g < 8; ++g) s += sh[g][tx];
+    sums[(long)q * Ph + k] = s;
+  }
+}
 // out_q[k] = (float) sums[q][k]
 __global__ void gs_sums_to_float_kernel(const double* __restrict__ sums, int nq, int Ph, float* __restrict__ out0,
                                         float* __restrict__ out1, float* __restrict__ out2) {

@@ -64,7 +64,12 @@ typedef struct gs_gemm_desc {
   int relu;
   const float* mask;     /* optional [M][ldmask]: output kept where mask > 0 else 0 (ReLU backward) */
   long ldmask;
+  float* colstat;        /* optional [tiles_m][2][N]: per-M-tile column sums / sums of squares of the written C
+                            (BatchNorm batch statistics fused into the epilogue); tiles_m = gs_gemm_tiles_m(desc) */
 } gs_gemm_desc;
+
+/* number of M tiles gs_gemm_f32 will use for this descriptor (first dimension of colstat) */
+int gs_gemm_tiles_m(const gs_gemm_desc* d);
 
 int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream);
 

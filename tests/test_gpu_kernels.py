@@ -60,6 +60,25 @@ def test_gemm_epilogues(E):
     close(out, B.double().sum(0, keepdim=True))
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (300, 70, 33), (129, 40, 64), (50, 200, 16)])
+def test_gemm_fused_column_statistics(E, M, N, K):
+    """colstat: per-M-tile column sums / sums of squares of the written C (BatchNorm statistics in the epilogue)."""
+    import ctypes as C
+    from graphslim_amd import _lib
+    torch.manual_seed(M + N)
+    A, B, bias = torch.randn(M, K), torch.randn(N, K), torch.randn(N)
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K, d.nb1, d.nb2 = M, N, K, 1, 1
+    tiles = _lib.lib().gs_gemm_tiles_m(C.byref(d))
+    stat = torch.full((tiles, 2, N), float("nan"), device=DEV)
+    Cd = torch.empty(M, N, device=DEV)
+    E.gemm(A.to(DEV), B.to(DEV), Cd, M, N, K, (K, 1), (1, K), N, bias=bias.to(DEV), colstat=stat)
+    ref = ref_mm(A, B.T) + bias.double()
+    close(Cd, ref)
+    close(stat[:, 0].double().sum(0), ref.sum(0), rtol=1e-4, atol_scale=1e-5)
+    close(stat[:, 1].double().sum(0), (ref * ref).sum(0), rtol=1e-4, atol_scale=1e-5)
+
+
 def test_gemm_batched_grouped_gather_splitk(E):
     torch.manual_seed(1)
     nb, M, N, K = 5, 37, 50, 90
