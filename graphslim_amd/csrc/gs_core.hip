@@ -55,29 +55,55 @@ __global__ __launch_bounds__(256) void gs_spmm_csr_kernel(const int* __restrict_
   const long wave_g = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int sub = lane / LPR, l = lane % LPR;
   const long row = wave_g * RPW + sub;
-  if (row >= n_rows) return;
-  const int e0 = rowptr[row], e1 = rowptr[row + 1];
-  for (int c0 = l * VEC; c0 < F; c0 += LPR * VEC) {
+  const bool live = row < n_rows;
+  const int e0 = live ? rowptr[row] : 0, e1 = live ? rowptr[row + 1] : 0;
+  // the widest row of the wave decides the trip count, so the shuffles below are executed by all 64 lanes
+  int span = e1 - e0;
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) span = max(span, __shfl_xor(span, o, 64));
+  const int mine = e1 - e0;
+  for (int ch = 0; ch * LPR * VEC < F; ++ch) {        // same trip count in every lane: the shuffles need all 64 lanes
+    const int c0 = (ch * LPR + l) * VEC;
+    const bool colok = c0 < F;
     V acc;
     zero(acc);
-    int e = e0;
-    for (; e + 4 <= e1; e += 4) {
-      int j0 = col[e], j1 = col[e + 1], j2 = col[e + 2], j3 = col[e + 3];
-      float w0 = val[e], w1 = val[e + 1], w2 = val[e + 2], w3 = val[e + 3];
-      V x0 = *reinterpret_cast<const V*>(X + (long)j0 * ldx + c0);
-      V x1 = *reinterpret_cast<const V*>(X + (long)j1 * ldx + c0);
-      V x2 = *reinterpret_cast<const V*>(X + (long)j2 * ldx + c0);
-      V x3 = *reinterpret_cast<const V*>(X + (long)j3 * ldx + c0);
-      fma_acc(acc, w0, x0);
-      fma_acc(acc, w1, x1);
-      fma_acc(acc, w2, x2);
-      fma_acc(acc, w3, x3);
+    for (int base = 0; base < span; base += LPR) {
+      // one coalesced load of up to LPR (col, val) pairs per row group; edges are then broadcast by shuffle, so the
+      // gathers of a chunk do not wait on a second dependent index load
+      const int my = e0 + base + l;
+      const int cj = (my < e1) ? col[my] : 0;
+      const float wj = (my < e1) ? val[my] : 0.f;
+      const int cnt = min(LPR, span - base);
+      int j = 0;
+      for (; j + 4 <= cnt; j += 4) {
+        const int s0 = sub * LPR + j;
+        const int j0 = __shfl(cj, s0, 64), j1 = __shfl(cj, s0 + 1, 64), j2 = __shfl(cj, s0 + 2, 64), j3 = __shfl(cj, s0 + 3, 64);
+        const float w0 = __shfl(wj, s0, 64), w1 = __shfl(wj, s0 + 1, 64), w2 = __shfl(wj, s0 + 2, 64), w3 = __shfl(wj, s0 + 3, 64);
+        if (colok) {
+          V x0 = *reinterpret_cast<const V*>(X + (long)j0 * ldx + c0);
+          V x1 = *reinterpret_cast<const V*>(X + (long)j1 * ldx + c0);
+          V x2 = *reinterpret_cast<const V*>(X + (long)j2 * ldx + c0);
+          V x3 = *reinterpret_cast<const V*>(X + (long)j3 * ldx + c0);
+          V z;
+          zero(z);   // slots past this row's own edges read row 0 with weight 0: drop the value so 0*inf cannot appear
+          fma_acc(acc, w0, base + j + 0 < mine ? x0 : z);
+          fma_acc(acc, w1, base + j + 1 < mine ? x1 : z);
+          fma_acc(acc, w2, base + j + 2 < mine ? x2 : z);
+          fma_acc(acc, w3, base + j + 3 < mine ? x3 : z);
+        }
+      }
+      for (; j < cnt; ++j) {
+        const int jj = __shfl(cj, sub * LPR + j, 64);
+        const float ww = __shfl(wj, sub * LPR + j, 64);
+        if (colok) {
+          V x = *reinterpret_cast<const V*>(X + (long)jj * ldx + c0);
+          V z;
+          zero(z);
+          fma_acc(acc, ww, base + j < mine ? x : z);
+        }
+      }
     }
-    for (; e < e1; ++e) {
-      V x = *reinterpret_cast<const V*>(X + (long)col[e] * ldx + c0);
-      fma_acc(acc, val[e], x);
-    }
-    *reinterpret_cast<V*>(Y + row * ldy + c0) = acc;
+    if (live && colok) *reinterpret_cast<V*>(Y + row * ldy + c0) = acc;
   }
 }
 

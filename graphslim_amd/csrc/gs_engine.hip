@@ -116,7 +116,7 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   e->nsplit_r = gs_cdiv((long)e->cap1 * e->f2, e->kchunk_r);
   e->kchunk_w = 2048;
   e->nsplit_w = gs_cdiv((long)e->n * e->n, e->kchunk_w);
-  e->rows_per_block = 512;
+  e->rows_per_block = 64;
   e->nblk_stats = gs_cdiv((long)e->n * e->n, e->rows_per_block);
 }
 
@@ -191,6 +191,8 @@ static int check_cfg(const gs_gcond_config* c) {
   if (c->n_nodes < 1 || c->d < 1 || c->ldx < c->d || c->nclass < 1 || c->n_syn < 1 || c->pge_hidden < 1)
     GS_FAIL(GS_ERR_ARG, "gs_gcond: bad dimensions");
   if (c->nclass > 512) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nclass > 512");
+  if (c->pge_hidden % 4 != 0 || c->pge_hidden > 1024 || c->pge_hidden < 4)
+    GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: pge_hidden must be a multiple of 4 in [4, 1024] (the reference uses 128 / 256)");
   if (c->ntrans == 2 && c->hidden < 1) GS_FAIL(GS_ERR_ARG, "gs_gcond: hidden must be > 0 for ntrans = 2");
   if (c->bcap < 1 || c->bcap > 256 || c->f1 < 1 || c->f1 > 16 || c->f2 < 1 || c->f2 > 16)
     GS_FAIL(GS_ERR_ARG, "gs_gcond: bcap in [1,256], fan-outs in [1,16]");
@@ -479,8 +481,8 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
                        e->is1, e->sumU, e->sumV);
     GS_LAUNCH_CHECK();
     if (rows > 0) {
-      hipLaunchKernelGGL(gs_pge_make_a1_kernel, dim3(gs_cdiv(rows * Ph, 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0, e->mu1,
-                         e->is1, pp + e->pg1, pp + e->pbe1, n, Ph, e->r_lo, nr, e->A1);
+      hipLaunchKernelGGL(gs_pge_make_a1_v4_kernel, dim3(gs_cdiv(rows * (Ph / 4), 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0,
+                         e->mu1, e->is1, pp + e->pg1, pp + e->pbe1, n, Ph, e->r_lo, nr, e->A1);
       GS_LAUNCH_CHECK();
       gs_gemm_desc g = mk(e->A1, Ph, 1, pp + e->pW1, 1, Ph, e->E2, Ph, (int)rows, Ph, Ph);     // E2 = A1 W1^T + b1
       g.bias = pp + e->pb1;
@@ -713,8 +715,8 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
     }
     GS_LAUNCH_CHECK();
     if (rows > 0) {
-      hipLaunchKernelGGL(gs_pge_bn2_bwd_kernel, dim3(gs_cdiv(rows * Ph, 256)), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2,
-                         pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, rows, n2, Ph, e->dE2);
+      hipLaunchKernelGGL(gs_pge_bn2_bwd_v4_kernel, dim3(gs_cdiv(rows * (Ph / 4), 256)), dim3(256), 0, s, e->E2, de3l, e->mu2,
+                         e->is2, pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, rows, n2, Ph, e->dE2);
       GS_LAUNCH_CHECK();
       if (need_param_grads) {
         // dW1 = dE2^T A1  (K = local pair rows split into slabs, fixed-order reduce) ; db1 = colsum(dE2)   [partials]

@@ -428,6 +428,30 @@ __global__ void gs_pge_make_a1_kernel(const float* __restrict__ U, const float* 
   A1[idx] = fmaxf(fmaf(g1[k], x, be1[k]), 0.f);
 }
 
+// float4 variant (Ph % 4 == 0): one thread per 4 consecutive k
+__global__ void gs_pge_make_a1_v4_kernel(const float* __restrict__ U, const float* __restrict__ V, const float* __restrict__ b0,
+                                         const float* __restrict__ mu1, const float* __restrict__ is1,
+                                         const float* __restrict__ g1, const float* __restrict__ be1, int n, int Ph, int r_lo,
+                                         int nr, float* __restrict__ A1) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Q = Ph >> 2;
+  if (idx >= (long)nr * n * Q) return;
+  const int k = (int)(idx % Q) * 4;
+  const long pair = idx / Q;
+  const int rl = (int)(pair / n), c = (int)(pair - (long)rl * n), r = r_lo + rl;
+  const float4 u = *reinterpret_cast<const float4*>(U + (long)c * Ph + k);
+  const float4 v = *reinterpret_cast<const float4*>(V + (long)r * Ph + k);
+  const float4 b = *reinterpret_cast<const float4*>(b0 + k), m = *reinterpret_cast<const float4*>(mu1 + k);
+  const float4 is = *reinterpret_cast<const float4*>(is1 + k), g = *reinterpret_cast<const float4*>(g1 + k);
+  const float4 be = *reinterpret_cast<const float4*>(be1 + k);
+  float4 o;
+  o.x = fmaxf(fmaf(g.x, (u.x + v.x + b.x - m.x) * is.x, be.x), 0.f);
+  o.y = fmaxf(fmaf(g.y, (u.y + v.y + b.y - m.y) * is.y, be.y), 0.f);
+  o.z = fmaxf(fmaf(g.z, (u.z + v.z + b.z - m.z) * is.z, be.z), 0.f);
+  o.w = fmaxf(fmaf(g.w, (u.w + v.w + b.w - m.w) * is.w, be.w), 0.f);
+  *reinterpret_cast<float4*>(A1 + pair * Ph + k) = o;
+}
+
 // column sums of up to two per-element functions over a tall matrix, fp64 partials:
 // part[blk][0][k] = sum_rows f0, part[blk][1][k] = sum_rows f1.   mode 0: (x, x*x)  [BN-2 statistics]
 __global__ __launch_bounds__(256) void gs_col_stats_kernel(const float* __restrict__ E, long rows, int Ph, int rows_per_block,
@@ -582,24 +606,75 @@ __global__ void gs_pge_bn2_bwd_kernel(const float* __restrict__ E2, const float*
   dE2[idx] = g2[k] * is2[k] * (dy - dbe2[k] * invN - xh * dg2[k] * invN);
 }
 
+__global__ void gs_pge_bn2_bwd_v4_kernel(const float* __restrict__ E2, const float* __restrict__ de3,
+                                         const float* __restrict__ mu2, const float* __restrict__ is2,
+                                         const float* __restrict__ g2, const float* __restrict__ be2,
+                                         const float* __restrict__ w2, const float* __restrict__ dbe2,
+                                         const float* __restrict__ dg2, long rows, long total_rows, int Ph,
+                                         float* __restrict__ dE2) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Q = Ph >> 2;
+  if (idx >= rows * Q) return;
+  const int k = (int)(idx % Q) * 4;
+  const long r = idx / Q;
+  const float4 e = *reinterpret_cast<const float4*>(E2 + r * Ph + k);
+  const float d = de3[r], invN = 1.f / (float)total_rows;
+  float ev[4] = {e.x, e.y, e.z, e.w}, o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float xh = (ev[j] - mu2[k + j]) * is2[k + j];
+    float y = fmaf(g2[k + j], xh, be2[k + j]);
+    float dy = y > 0.f ? d * w2[k + j] : 0.f;
+    o[j] = g2[k + j] * is2[k + j] * (dy - dbe2[k + j] * invN - xh * dg2[k + j] * invN);
+  }
+  *reinterpret_cast<float4*>(dE2 + r * Ph + k) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // marginal sums of dY1 [(r,c), k]:  colsum_r[r,k] = sum_c,  rowsum_c[c,k] = sum_r
 // (dY1 holds the nr local pair rows r_lo .. r_lo+nr-1; colsum_r is written for those rows, rowsum_c is the partial sum)
+// block = QL float4 lanes (QL = Ph/4 <= 64) x G row groups; each group strides over the summed index; LDS reduce.
 __global__ __launch_bounds__(256) void gs_pge_marginal_r_kernel(const float* __restrict__ dY1, int n, int Ph, int r_lo,
                                                                 float* __restrict__ colsum_r) {
   const int rl = blockIdx.x;
-  for (int k = threadIdx.x; k < Ph; k += 256) {
-    float s = 0.f;
-    for (int c = 0; c < n; ++c) s += dY1[((long)rl * n + c) * Ph + k];
-    colsum_r[(long)(r_lo + rl) * Ph + k] = s;
+  const int Q = Ph >> 2, G = 256 / Q;              // Ph in {16..256}, multiple of 4 (checked by the caller)
+  const int q = threadIdx.x % Q, g = threadIdx.x / Q;
+  __shared__ float4 sh[256];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g < G)
+    for (int c = g; c < n; c += G) {
+      const float4 v = *reinterpret_cast<const float4*>(dY1 + ((long)rl * n + c) * Ph + q * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0) {
+    for (int t = 1; t < G; ++t) {
+      const float4 v = sh[t * Q + q];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(colsum_r + (long)(r_lo + rl) * Ph + q * 4) = s;
   }
 }
 __global__ __launch_bounds__(256) void gs_pge_marginal_c_kernel(const float* __restrict__ dY1, int n, int Ph, int nr,
                                                                 float* __restrict__ rowsum_c) {
   const int c = blockIdx.x;
-  for (int k = threadIdx.x; k < Ph; k += 256) {
-    float s = 0.f;
-    for (int r = 0; r < nr; ++r) s += dY1[((long)r * n + c) * Ph + k];
-    rowsum_c[(long)c * Ph + k] = s;
+  const int Q = Ph >> 2, G = 256 / Q;
+  const int q = threadIdx.x % Q, g = threadIdx.x / Q;
+  __shared__ float4 sh[256];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g < G)
+    for (int r = g; r < nr; r += G) {
+      const float4 v = *reinterpret_cast<const float4*>(dY1 + ((long)r * n + c) * Ph + q * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0) {
+    for (int t = 1; t < G; ++t) {
+      const float4 v = sh[t * Q + q];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(rowsum_c + (long)c * Ph + q * 4) = s;
   }
 }
 // BN-1 backward from the marginals (see oracle/analytic.py:pge_bwd); block = 32 columns x 8 row groups

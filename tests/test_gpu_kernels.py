@@ -273,3 +273,24 @@ def test_sampler_properties(E):
     p = bcap / len(pool)
     freq = cnt[pool] / T_
     assert abs(freq.mean() - p) < 1e-9 and freq.std() < 3.5 * np.sqrt(p * (1 - p) / T_)
+
+
+def test_spmm_csr_ragged_rows_and_nonfinite_row0(E):
+    """Rows of very different length inside one wave (sub-wave row groups), F not a multiple of the lane tile, and a
+    non-finite X[0] that no row references: padding slots must not leak 0*inf."""
+    rng = np.random.default_rng(1)
+    n, ncol = 257, 300
+    deg = rng.integers(0, 70, n)
+    deg[::7] = 0
+    indptr = np.concatenate([[0], np.cumsum(deg)])
+    indices = np.concatenate([rng.choice(np.arange(1, ncol), size=d, replace=False) for d in deg]).astype(np.int32)
+    data = rng.normal(size=indptr[-1]).astype(np.float32)
+    m = sp.csr_matrix((data, indices, indptr), shape=(n, ncol))
+    i32 = lambda v: torch.as_tensor(v, dtype=torch.int32, device=DEV)
+    for F in (5, 36, 40, 132, 260):
+        X = torch.randn(ncol, F)
+        X[0] = float("inf")
+        out = E.spmm_csr(i32(indptr), i32(indices), torch.as_tensor(data, device=DEV), X.to(DEV))
+        Xf = X.clone()
+        Xf[0] = 0
+        close(out, torch.from_numpy(m.astype(np.float64).toarray()) @ Xf.double())
