@@ -77,6 +77,7 @@ struct gs_gcond {
   // shard of this rank: classes [c_lo, c_hi) (real side + per-class synthetic terms), PGE pair rows [r_lo, r_hi)
   int c_lo, c_hi, r_lo, r_hi;
   double* sums;     // [3][Ph] fp64 column sums exchanged between ranks
+  double* sums2;    // [32][3][Ph] first-stage slices of the partial-block reduction
   float* statp;     // [ceil(n'^2 / 32)][2][Ph] per-tile column sums written by the E2 GEMM epilogue
   float *ar_syn, *ar_marg;
 };
@@ -173,6 +174,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->dV = w.take<float>(n * Ph); e->d_pge = w.take<float>(e->Ppge); e->slabs_w = w.take<float>(e->nsplit_w * Ph * Ph);
   e->parts = w.take<double>((long)e->nblk_stats * 3 * Ph);
   e->sums = w.take<double>(3 * Ph);
+  e->sums2 = w.take<double>(32 * 3 * Ph);
   e->statp = w.take<float>((long)gs_cdiv(n2, 32) * 2 * Ph);
   e->adj_norm_in = w.take<float>(n2); e->rnorm_in = w.take<float>(2 * n); e->Qin = w.take<float>(n2);
   e->rsq_in = w.take<float>(n); e->S_in = w.take<float>(n * F); e->g_model = w.take<float>(P);
@@ -314,6 +316,21 @@ extern "C" int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* b, gs_stream_t 
 #undef CP
   e->have_blocks = true;
   return GS_OK;
+}
+
+// sums[q][k] = sum over nblk partial blocks (fp64, fixed order): two stages so that the first one fills the chip
+template <class T>
+static void reduce_parts(gs_gcond* e, const T* part, int nblk, int nq, int nq_out, hipStream_t s) {
+  const int Ph = e->Ph;
+  const int S = nblk > 64 ? 32 : 1;
+  dim3 g1(gs_cdiv(Ph, 32), nq_out, S), g2(gs_cdiv(Ph, 32), nq_out, 1);
+  double* out1 = S > 1 ? e->sums2 : e->sums;
+  if (sizeof(T) == 8)
+    hipLaunchKernelGGL(gs_sum_parts_kernel, g1, dim3(256), 0, s, (const double*)part, nblk, nq, Ph, out1);
+  else
+    hipLaunchKernelGGL(gs_sum_parts_f32_kernel, g1, dim3(256), 0, s, (const float*)part, nblk, nq, Ph, out1);
+  // stage 1 writes [slice][nq_out... laid out with stride nq]: it used nq as the row stride of its OUTPUT too
+  if (S > 1) hipLaunchKernelGGL(gs_sum_parts_kernel, g2, dim3(256), 0, s, (const double*)e->sums2, S, nq, Ph, e->sums);
 }
 
 // column sums of nbatch [rows x cols] matrices: chunked partials + fixed-order reduce (no atomics)
@@ -488,8 +505,7 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       g.bias = pp + e->pb1;
       g.colstat = e->statp;            // BN-2 batch statistics come out of the epilogue: no second pass over E2
       GS_TRY(gs_gemm_f32(&g, stream));
-      hipLaunchKernelGGL(gs_sum_parts_f32_kernel, dim3(gs_cdiv(Ph, 32), 2), dim3(256), 0, s, e->statp, gs_gemm_tiles_m(&g), 2, Ph,
-                         e->sums);
+      reduce_parts(e, e->statp, gs_gemm_tiles_m(&g), 2, 2, s);
       GS_LAUNCH_CHECK();
     } else {
       GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 2 * Ph, s));
@@ -698,7 +714,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
     if (rows > 0) {
       hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(nblk), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2, pp + e->pg2,
                          pp + e->pbe2, pp + e->pw2, rows, Ph, e->rows_per_block, e->parts);
-      hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 32), 3), dim3(256), 0, s, e->parts, nblk, 3, Ph, e->sums);
+      reduce_parts(e, e->parts, nblk, 3, 3, s);
     } else {
       GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 3 * Ph, s));
     }
@@ -715,7 +731,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
     }
     GS_LAUNCH_CHECK();
     if (rows > 0) {
-      hipLaunchKernelGGL(gs_pge_bn2_bwd_v4_kernel, dim3(gs_cdiv(rows * (Ph / 4), 256)), dim3(256), 0, s, e->E2, de3l, e->mu2,
+      hipLaunchKernelGGL(gs_pge_bn2_bwd_v4_kernel, dim3(gs_cdiv(gs_cdiv(rows, 8) * (long)(Ph / 4), 256)), dim3(256), 0, s, e->E2, de3l, e->mu2,
                          e->is2, pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, rows, n2, Ph, e->dE2);
       GS_LAUNCH_CHECK();
       if (need_param_grads) {
@@ -726,7 +742,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
         GS_TRY(gs_gemm_f32(&w, stream));
         GS_TRY(gs_reduce_slabs_f32(g + e->pW1, e->slabs_w, (long)Ph * Ph, nsplit, (long)Ph * Ph, 0.f, stream));
         hipLaunchKernelGGL(gs_col_stats_kernel, dim3(nblk), dim3(256), 0, s, e->dE2, rows, Ph, e->rows_per_block, e->parts);
-        hipLaunchKernelGGL(gs_sum_parts_kernel, dim3(gs_cdiv(Ph, 32), 1), dim3(256), 0, s, e->parts, nblk, 2, Ph, e->sums);
+        reduce_parts(e, e->parts, nblk, 2, 1, s);
         hipLaunchKernelGGL(gs_sums_to_float_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, 1, Ph, g + e->pb1,
                            (float*)nullptr, (float*)nullptr);
         GS_LAUNCH_CHECK();

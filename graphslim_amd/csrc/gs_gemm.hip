@@ -19,29 +19,30 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define GS_BK 16
-#define GS_KS 20   // row stride (floats) of a k-contiguous LDS image: 16-B aligned rows, conflict-free ds_read_b128
-#define GS_PAD 4   // pad of an m-contiguous LDS image [k][BM + 4]
+#define GS_PAD 4   // pad of an m-contiguous LDS image [k][BM + 4]; a k-contiguous image uses rows of BK + 4 floats
+                   // (16-B aligned rows; 20 or 36 dwords per row keep the 16 lanes of a ds_read_b128 group on 16 distinct
+                   // 4-bank slots -> conflict-free)
 
 // operand access modes (chosen on the host from the strides)
 #define GS_MODE_K 0   // k contiguous in memory  -> global float4 along k, LDS [m][20], fragment = one ds_read_b128
 #define GS_MODE_M 1   // m contiguous in memory  -> global float4 along m, LDS [k][BM+4], fragment = 4 ds_read_b32
 #define GS_MODE_G 2   // anything else (scalar, clamped, branch-free)
 
-// Within a K tile of 16 the MFMA steps consume k in the order k = 8q + 4*(lane>>5) + t  (q = 0,1; t = 0..3): both
+// Within a K tile of BK (16 or 32) the MFMA steps consume k in the order k = 8q + 4*(lane>>5) + t  (q < BK/8; t = 0..3): both
 // operands use the same permutation, so a k-contiguous operand gets its 4 values for t = 0..3 with one 16-byte read.
 
-template <int BMN, int MODE>
+template <int BMN, int MODE, int BK>
 struct TileLds {
-  static constexpr int SIZE = (MODE == GS_MODE_K) ? BMN * GS_KS : GS_BK * (BMN + GS_PAD);
+  static constexpr int SIZE = (MODE == GS_MODE_K) ? BMN * (BK + 4) : BK * (BMN + GS_PAD);
 };
 
 // Loads one operand tile (BMN rows of the operand's "outer" dimension x 16 k) into registers.
 //   outer index o in [0, BMN) (+ o0), k in [k0, k0+16);  element(o, k) = base[row(o)*s_o + kidx(k)*s_k]
 // interior == true (block-uniform): every element in range and 16-byte vector loads are legal -> no selects.
-template <int BMN, int MODE>
+template <int BMN, int MODE, int BK>
 struct TileLoader {
-  static constexpr int UNITS = (MODE == GS_MODE_G) ? BMN * GS_BK : BMN * GS_BK / 4;   // float4 units or scalars
+  static constexpr int KS = BK + 4, KQ = BK / 4;
+  static constexpr int UNITS = (MODE == GS_MODE_G) ? BMN * BK : BMN * BK / 4;   // float4 units or scalars
   static constexpr int PER = (UNITS + 255) / 256;
   float4 r4[(MODE == GS_MODE_G) ? 1 : PER];
   float r1[(MODE == GS_MODE_G) ? PER : 1];
@@ -53,7 +54,7 @@ struct TileLoader {
       const int u = tid + i * 256;
       if (UNITS % 256 != 0 && u >= UNITS) break;
       if (MODE == GS_MODE_K) {
-        const int o = u >> 2, kq = (u & 3) * 4;
+        const int o = u / KQ, kq = (u % KQ) * 4;
         const int go = min(o0 + o, n_o - 1);
         const long ro = (g_o ? (long)g_o[go] : (long)go) * s_o;
         if (interior) {
@@ -101,7 +102,7 @@ struct TileLoader {
       const int u = tid + i * 256;
       if (UNITS % 256 != 0 && u >= UNITS) break;
       if (MODE == GS_MODE_K) {
-        *reinterpret_cast<float4*>(lds + (u >> 2) * GS_KS + (u & 3) * 4) = r4[i];
+        *reinterpret_cast<float4*>(lds + (u / KQ) * KS + (u % KQ) * 4) = r4[i];
       } else if (MODE == GS_MODE_M) {
         constexpr int Q = BMN / 4;
         *reinterpret_cast<float4*>(lds + (u / Q) * (BMN + GS_PAD) + (u % Q) * 4) = r4[i];
@@ -113,10 +114,10 @@ struct TileLoader {
 };
 
 // fragment of the 4 MFMA steps t = 0..3 of half-tile q for operand row `r`
-template <int BMN, int MODE>
+template <int BMN, int MODE, int BK>
 __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int r, int q, int kh, float (&f)[4]) {
   if (MODE == GS_MODE_K) {
-    const float4 v = *reinterpret_cast<const float4*>(lds + r * GS_KS + q * 8 + kh * 4);
+    const float4 v = *reinterpret_cast<const float4*>(lds + r * (BK + 4) + q * 8 + kh * 4);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
   } else {
 #pragma unroll
@@ -124,13 +125,14 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int r, 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE>
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int BK>
 __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
+  constexpr int GS_BK = BK;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-  __shared__ __attribute__((aligned(16))) float As[TileLds<BM, AMODE>::SIZE];
-  __shared__ __attribute__((aligned(16))) float Bs[TileLds<BN, BMODE>::SIZE];
+  __shared__ __attribute__((aligned(16))) float As[TileLds<BM, AMODE, BK>::SIZE];
+  __shared__ __attribute__((aligned(16))) float Bs[TileLds<BN, BMODE, BK>::SIZE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, b1 = b / p.nb2, b2 = b - b1 * p.nb2;
@@ -161,8 +163,8 @@ __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
   if (BMODE == GS_MODE_M) vecB = vecB && ((p.sBk & 3) == 0);
   const bool fullM = (m0 + BM <= M), fullN = (n0 + BN <= p.N);
 
-  TileLoader<BM, AMODE> la;
-  TileLoader<BN, BMODE> lb;
+  TileLoader<BM, AMODE, BK> la;
+  TileLoader<BN, BMODE, BK> lb;
   auto load_tiles = [&](int k0) {
     const bool fullK = (k0 + GS_BK <= k_hi);
     la.load(A, p.sAm, p.sAk, gAm, gAk, m0, M, k0, k_hi, vecA && fullM && fullK, tid);
@@ -188,12 +190,12 @@ __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
       __syncthreads();
       if (k0 + GS_BK < k_hi) load_tiles(k0 + GS_BK);   // in flight under the MFMAs below
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < BK / 8; ++q) {
         float a[TM][4], bb[TN][4];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) read_frag<BM, AMODE>(As, wm0 + i * 32 + li, q, kh, a[i]);
+        for (int i = 0; i < TM; ++i) read_frag<BM, AMODE, BK>(As, wm0 + i * 32 + li, q, kh, a[i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) read_frag<BN, BMODE>(Bs, wn0 + j * 32 + li, q, kh, bb[j]);
+        for (int j = 0; j < TN; ++j) read_frag<BN, BMODE, BK>(Bs, wn0 + j * 32 + li, q, kh, bb[j]);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -313,12 +315,28 @@ extern "C" int gs_reduce_slabs_batched_f32(float* out, long out_stride, const fl
   return GS_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int AM, int BMD>
-static int launch_gemm2(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
+static int g_bk_small = 32, g_bk_big = 16;   // K-tile depth of the small (latency-bound) and the 128x128 tiles
+
+extern "C" int gs_gemm_set_tuning(int bk_small, int bk_big) {
+  if ((bk_small != 16 && bk_small != 32) || (bk_big != 16 && bk_big != 32)) GS_FAIL(GS_ERR_ARG, "gs_gemm_set_tuning: BK must be 16 or 32");
+  g_bk_small = bk_small;
+  g_bk_big = bk_big;
+  return GS_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int AM, int BMD, int BK>
+static int launch_gemm3(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
   dim3 grid(gs_cdiv(p.N, BN), gs_cdiv(p.M, BM), nbatch);
-  hipLaunchKernelGGL((gs_gemm_f32_kernel<BM, BN, WM, WN, AM, BMD>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gs_gemm_f32_kernel<BM, BN, WM, WN, AM, BMD, BK>), grid, dim3(256), 0, s, p);
   GS_LAUNCH_CHECK();
   return GS_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int AM, int BMD>
+static int launch_gemm2(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
+  const int bk = (BM == 128 && BN == 128) ? g_bk_big : g_bk_small;
+  if (bk == 32) return launch_gemm3<BM, BN, WM, WN, AM, BMD, 32>(p, nbatch, s);
+  return launch_gemm3<BM, BN, WM, WN, AM, BMD, 16>(p, nbatch, s);
 }
 
 template <int BM, int BN, int WM, int WN>

@@ -548,36 +548,40 @@ __global__ __launch_bounds__(256) void gs_pge_l3_bwd_stats_kernel(const float* _
 }
 // sums[q][k] = sum over partial blocks (fp64).  grid = (ceil(Ph/32), nq); block = 32 columns x 8 groups
 __global__ __launch_bounds__(256) void gs_sum_parts_kernel(const double* __restrict__ part, int nblk, int nq, int Ph,
-                                                           double* __restrict__ sums) {
+    double* __restrict__ sums) {
+  // grid = (ceil(Ph/32), nq, slices): slice z sums its share of the partial blocks into sums[z][q][k]
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int k = blockIdx.x * 32 + tx, q = blockIdx.y;
+  const int per = (nblk + gridDim.z - 1) / gridDim.z, b0 = blockIdx.z * per, b1 = min(nblk, b0 + per);
   __shared__ double sh[8][32];
   double s = 0;
   if (k < Ph)
-    for (int b = ty; b < nblk; b += 8) s += part[((long)b * nq + q) * Ph + k];
+    for (int b = b0 + ty; b < b1; b += 8) s += part[((long)b * nq + q) * Ph + k];
   sh[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && k < Ph) {
     s = 0;
     for (int g = 0; g < 8; ++g) s += sh[g][tx];
-    sums[(long)q * Ph + k] = s;
+    sums[((long)blockIdx.z * nq + q) * Ph + k] = s;
   }
 }
 // same from fp32 partials laid out [blk][nq][Ph] (the GEMM epilogue's colstat)
 __global__ __launch_bounds__(256) void gs_sum_parts_f32_kernel(const float* __restrict__ part, int nblk, int nq, int Ph,
-                                                               double* __restrict__ sums) {
+    double* __restrict__ sums) {
+  // grid = (ceil(Ph/32), nq, slices): slice z sums its share of the partial blocks into sums[z][q][k]
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int k = blockIdx.x * 32 + tx, q = blockIdx.y;
+  const int per = (nblk + gridDim.z - 1) / gridDim.z, b0 = blockIdx.z * per, b1 = min(nblk, b0 + per);
   __shared__ double sh[8][32];
   double s = 0;
   if (k < Ph)
-    for (int b = ty; b < nblk; b += 8) s += (double)part[((long)b * nq + q) * Ph + k];
+    for (int b = b0 + ty; b < b1; b += 8) s += (double)part[((long)b * nq + q) * Ph + k];
   sh[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && k < Ph) {
     s = 0;
     for (int g = 0; g < 8; ++g) s += sh[g][tx];
-    sums[(long)q * Ph + k] = s;
+    sums[((long)blockIdx.z * nq + q) * Ph + k] = s;
   }
 }
 // out_q[k] = (float) sums[q][k]
@@ -612,22 +616,34 @@ __global__ void gs_pge_bn2_bwd_v4_kernel(const float* __restrict__ E2, const flo
                                          const float* __restrict__ w2, const float* __restrict__ dbe2,
                                          const float* __restrict__ dg2, long rows, long total_rows, int Ph,
                                          float* __restrict__ dE2) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // thread = (row group, 4 consecutive columns); the 7 per-column constants are loaded once (16-B loads) and reused
+  // over ROWS_PER_THREAD rows
+  constexpr int RPT = 8;
   const int Q = Ph >> 2;
-  if (idx >= rows * Q) return;
-  const int k = (int)(idx % Q) * 4;
-  const long r = idx / Q;
-  const float4 e = *reinterpret_cast<const float4*>(E2 + r * Ph + k);
-  const float d = de3[r], invN = 1.f / (float)total_rows;
-  float ev[4] = {e.x, e.y, e.z, e.w}, o[4];
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = (int)(gid % Q) * 4;
+  const long r0 = (gid / Q) * RPT;
+  if (r0 >= rows) return;
+  const float4 m = *reinterpret_cast<const float4*>(mu2 + k), is = *reinterpret_cast<const float4*>(is2 + k);
+  const float4 g = *reinterpret_cast<const float4*>(g2 + k), be = *reinterpret_cast<const float4*>(be2 + k);
+  const float4 w = *reinterpret_cast<const float4*>(w2 + k), db = *reinterpret_cast<const float4*>(dbe2 + k);
+  const float4 dg = *reinterpret_cast<const float4*>(dg2 + k);
+  const float invN = 1.f / (float)total_rows;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float xh = (ev[j] - mu2[k + j]) * is2[k + j];
-    float y = fmaf(g2[k + j], xh, be2[k + j]);
-    float dy = y > 0.f ? d * w2[k + j] : 0.f;
-    o[j] = g2[k + j] * is2[k + j] * (dy - dbe2[k + j] * invN - xh * dg2[k + j] * invN);
+  for (int t = 0; t < RPT; ++t) {
+    const long r = r0 + t;
+    if (r < rows) {
+      const float4 e = *reinterpret_cast<const float4*>(E2 + r * Ph + k);
+      const float d = de3[r];
+      float4 o;
+      float xh, y;
+      xh = (e.x - m.x) * is.x; y = fmaf(g.x, xh, be.x); o.x = g.x * is.x * ((y > 0.f ? d * w.x : 0.f) - db.x * invN - xh * dg.x * invN);
+      xh = (e.y - m.y) * is.y; y = fmaf(g.y, xh, be.y); o.y = g.y * is.y * ((y > 0.f ? d * w.y : 0.f) - db.y * invN - xh * dg.y * invN);
+      xh = (e.z - m.z) * is.z; y = fmaf(g.z, xh, be.z); o.z = g.z * is.z * ((y > 0.f ? d * w.z : 0.f) - db.z * invN - xh * dg.z * invN);
+      xh = (e.w - m.w) * is.w; y = fmaf(g.w, xh, be.w); o.w = g.w * is.w * ((y > 0.f ? d * w.w : 0.f) - db.w * invN - xh * dg.w * invN);
+      *reinterpret_cast<float4*>(dE2 + r * Ph + k) = o;
+    }
   }
-  *reinterpret_cast<float4*>(dE2 + r * Ph + k) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 // marginal sums of dY1 [(r,c), k]:  colsum_r[r,k] = sum_c,  rowsum_c[c,k] = sum_r

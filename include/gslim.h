@@ -68,6 +68,8 @@ typedef struct gs_gemm_desc {
                             (BatchNorm batch statistics fused into the epilogue); tiles_m = gs_gemm_tiles_m(desc) */
 } gs_gemm_desc;
 
+/* K-tile depth (16 or 32) of the small tiles and of the 128x128 tile; a measurement knob (defaults 32 / 16). */
+int gs_gemm_set_tuning(int bk_small, int bk_big);
 /* number of M tiles gs_gemm_f32 will use for this descriptor (first dimension of colstat) */
 int gs_gemm_tiles_m(const gs_gemm_desc* d);
 
