@@ -18,6 +18,9 @@
 #include "gs_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// 16-byte global load that only needs 4-byte alignment (gfx950 runs in unaligned-access mode; hipcc emits
+// global_load_dwordx4 for it): rows whose stride is not a multiple of 4 floats (n' = 454) stay on the vector path
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 #define GS_PAD 4   // pad of an m-contiguous LDS image [k][BM + 4]; a k-contiguous image uses rows of BK + 4 floats
                    // (16-B aligned rows; 20 or 36 dwords per row keep the 16 lanes of a ds_read_b128 group on 16 distinct
@@ -58,7 +61,7 @@ struct TileLoader {
         const int go = min(o0 + o, n_o - 1);
         const long ro = (g_o ? (long)g_o[go] : (long)go) * s_o;
         if (interior) {
-          r4[i] = *reinterpret_cast<const float4*>(base + ro + (k0 + kq));
+          { const f32x4u t = *reinterpret_cast<const f32x4u*>(base + ro + (k0 + kq)); r4[i] = make_float4(t.x, t.y, t.z, t.w); }
         } else {
           float v[4];
 #pragma unroll
@@ -75,7 +78,7 @@ struct TileLoader {
         const int gk = min(k0 + k, k_hi - 1);
         const long rk = (g_k ? (long)g_k[gk] : (long)gk) * s_k;
         if (interior) {
-          r4[i] = *reinterpret_cast<const float4*>(base + rk + (o0 + o4));
+          { const f32x4u t = *reinterpret_cast<const f32x4u*>(base + rk + (o0 + o4)); r4[i] = make_float4(t.x, t.y, t.z, t.w); }
         } else {
           float v[4];
 #pragma unroll
@@ -154,13 +157,7 @@ __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
   const int* gAk = p.gatherA_k ? p.gatherA_k + (long)b1 * p.sGb1 : nullptr;
   const int* gBk = p.gatherB_k ? p.gatherB_k + (long)b1 * p.sGb1 : nullptr;
 
-  // 16-byte vector loads are legal for this block?  (block-uniform)
-  bool vecA = (((uintptr_t)A & 15) == 0) && ((k_lo & 3) == 0);
-  if (AMODE == GS_MODE_K) vecA = vecA && ((p.sAm & 3) == 0);
-  if (AMODE == GS_MODE_M) vecA = vecA && ((p.sAk & 3) == 0);
-  bool vecB = (((uintptr_t)B & 15) == 0) && ((k_lo & 3) == 0);
-  if (BMODE == GS_MODE_K) vecB = vecB && ((p.sBn & 3) == 0);
-  if (BMODE == GS_MODE_M) vecB = vecB && ((p.sBk & 3) == 0);
+  const bool vecA = true, vecB = true;   // 4-byte alignment suffices for the global vector loads (f32x4u)
   const bool fullM = (m0 + BM <= M), fullN = (n0 + BN <= p.N);
 
   TileLoader<BM, AMODE, BK> la;
