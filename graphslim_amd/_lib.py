@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
                 ("gatherA_m", vp), ("gatherA_k", vp), ("gatherB_k", vp), ("sGb1", C.c_long),
                 ("kchunk", C.c_int), ("alpha", C.c_float), ("beta", C.c_float),
                 ("bias", vp), ("sbias_b1", C.c_long), ("relu", C.c_int), ("mask", vp), ("ldmask", C.c_long),
-                ("colstat", vp), ("dbg", C.c_int)]
+                ("colstat", vp)]
 
 
 class Blocks(C.Structure):
@@ -52,7 +52,7 @@ _lib = None
 
 # every symbol include/gslim.h declares (tests/test_abi.py checks the list against the header)
 SYMBOLS = [
-    "gs_version", "gs_last_error", "gs_gemm_f32", "gs_gemm_tiles_m", "gs_gemm_set_tuning", "gs_gemm_set_debug", "gs_reduce_slabs_f32", "gs_reduce_slabs_batched_f32",
+    "gs_version", "gs_last_error", "gs_gemm_f32", "gs_gemm_tiles_m", "gs_gemm_set_tuning", "gs_reduce_slabs_f32", "gs_reduce_slabs_batched_f32",
     "gs_spmm_csr_f32", "gs_gather_rows_f32", "gs_sample_blocks", "gs_dense_gcn_norm_fwd", "gs_dense_gcn_norm_bwd",
     "gs_adam_step_f32", "gs_gcond_workspace_bytes", "gs_gcond_create", "gs_gcond_destroy", "gs_gcond_new_epoch",
     "gs_gcond_set_blocks", "gs_gcond_outer_step", "gs_gcond_read_loss", "gs_gcond_stage_sample",
@@ -81,7 +81,6 @@ def lib():
     L.gs_gemm_f32.argtypes = [C.POINTER(GemmDesc), vp]
     L.gs_gemm_tiles_m.argtypes = [C.POINTER(GemmDesc)]
     L.gs_gemm_set_tuning.argtypes = [i, i]
-    L.gs_gemm_set_debug.argtypes = [i]
     L.gs_reduce_slabs_f32.argtypes = [vp, vp, l, i, l, f, vp]
     L.gs_reduce_slabs_batched_f32.argtypes = [vp, l, vp, l, i, l, i, f, vp]
     L.gs_spmm_csr_f32.argtypes = [vp, vp, vp, i, vp, l, i, vp, l, vp]

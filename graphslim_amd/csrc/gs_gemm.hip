@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
       la.store(As, tid);
       lb.store(Bs, tid);
       __syncthreads();
-      if (k0 + GS_BK < k_hi && !(p.dbg & 1)) load_tiles(k0 + GS_BK);   // in flight under the MFMAs below
+      if (k0 + GS_BK < k_hi) load_tiles(k0 + GS_BK);   // in flight under the MFMAs below
 #pragma unroll
       for (int q = 0; q < BK / 8; ++q) {
         float a[TM][4], bb[TN][4];
@@ -199,8 +199,7 @@ __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              if (!(p.dbg & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], bb[j][t], acc[i][j], 0, 0, 0);
-              else acc[i][j][0] += a[i][t] * bb[j][t];
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], bb[j][t], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
     }
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
         if (p.relu) v = fmaxf(v, 0.f);
         if (has_mask) v = (mk[r] > 0.f) ? v : 0.f;
         if (has_beta) v += p.beta * cv[r];
-        if (row < M && col < p.N && (!(p.dbg & 2) || v == 12345.678f)) {
+        if (row < M && col < p.N) {
           C[(long)row * p.ldc + col] = v;
           cs1[j] += v;
           cs2[j] = fmaf(v, v, cs2[j]);
@@ -313,9 +312,7 @@ extern "C" int gs_reduce_slabs_batched_f32(float* out, long out_stride, const fl
   return GS_OK;
 }
 
-static int g_bk_small = 32, g_bk_big = 16;
-static int g_dbg = 0;   // ablation bits for tools/ab_gemm.py: 1 = no global loads after the first tile, 2 = no C stores, 4 = no MFMA
-extern "C" int gs_gemm_set_debug(int bits) { g_dbg = bits; return GS_OK; }   // K-tile depth of the small (latency-bound) and the 128x128 tiles
+static int g_bk_small = 32, g_bk_big = 16;   // K-tile depth of the small (latency-bound) and the 128x128 tiles
 
 extern "C" int gs_gemm_set_tuning(int bk_small, int bk_big) {
   if ((bk_small != 16 && bk_small != 32) || (bk_big != 16 && bk_big != 32)) GS_FAIL(GS_ERR_ARG, "gs_gemm_set_tuning: BK must be 16 or 32");
@@ -368,7 +365,6 @@ extern "C" int gs_gemm_tiles_m(const gs_gemm_desc* d) {
 extern "C" int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream) {
   if (!d || !d->A || !d->B || !d->C) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: null operand");
   gs_gemm_desc p = *d;
-  p.dbg = g_dbg;
   if (p.M <= 0 || p.N <= 0) return GS_OK;
   if (p.K < 0) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: negative K");
   if (p.colstat && (p.nb1 > 1 || p.nb2 > 1)) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: colstat is for unbatched calls");

@@ -66,13 +66,10 @@ typedef struct gs_gemm_desc {
   long ldmask;
   float* colstat;        /* optional [tiles_m][2][N]: per-M-tile column sums / sums of squares of the written C
                             (BatchNorm batch statistics fused into the epilogue); tiles_m = gs_gemm_tiles_m(desc) */
-  int dbg;               /* ignored on input (set from gs_gemm_set_debug; measurement ablations only) */
 } gs_gemm_desc;
 
 /* K-tile depth (16 or 32) of the small tiles and of the 128x128 tile; a measurement knob (defaults 32 / 16). */
 int gs_gemm_set_tuning(int bk_small, int bk_big);
-/* ablation bits for kernel studies (0 = normal): 1 no global loads after the first tile, 2 no C stores, 4 no MFMA */
-int gs_gemm_set_debug(int bits);
 /* number of M tiles gs_gemm_f32 will use for this descriptor (first dimension of colstat) */
 int gs_gemm_tiles_m(const gs_gemm_desc* d);
 
