@@ -52,7 +52,7 @@ struct gs_gcond {
   // real side
   gs_blocks blk;
   int *marker, *kcount;
-  float *H1full, *P0, *rs0, *Sr, *rsr, *Zr, *gw_real, *Tm, *Y1, *Bmat, *slabs_r, *colpart;
+  float *H1full, *P0, *rs0, *Sr, *rsr, *Zr, *gw_real, *Tm, *Y1, *Bmat, *slabs_r, *colpart, *colpart_r;
   // synthetic side
   float *adj_raw, *adj_norm, *rnorm, *Q, *rsq, *H1s, *Ss, *Zs, *Ps, *Gs, *gw_syn, *stats, *ab, *loss_c, *D, *Ug, *Vs, *dSs,
       *drs, *dQ, *dAn, *d_adj, *d_feat, *dH2, *dHp, *A1m, *Bc, *dH1m, *slabs_x;
@@ -80,6 +80,11 @@ struct gs_gcond {
   double* sums2;    // [32][3][Ph] first-stage slices of the partial-block reduction
   float* statp;     // [ceil(n'^2 / 32)][2][Ph] per-tile column sums written by the E2 GEMM epilogue
   float *ar_syn, *ar_marg;
+  // the real-side branch (sampling + class gradients) is independent of the synthetic-side branch until the
+  // distance statistics: it runs on its own stream and joins through an event
+  hipStream_t aux;
+  hipEvent_t ev_fork, ev_join;
+  bool overlap, join_pending;
 };
 
 static void derive(gs_gcond* e, const gs_gcond_config& c) {
@@ -134,8 +139,11 @@ static size_t carve(gs_gcond* e, void* base) {
   e->marker = e->cfg.external_blocks ? nullptr : w.take<int>(C * N);
   e->kcount = w.take<int>(C);
   {
-    long nch = gs_cdiv(cap1 * f2, 256) > gs_cdiv(n, 256) ? gs_cdiv(cap1 * f2, 256) : gs_cdiv(n, 256);
-    e->colpart = w.take<float>(C * nch * (h > 0 ? h : 1));
+    // chunk counts of colsum_batched: <= 64 chunks of >= 8 rows, or rows/256 chunks
+    long nch_r = gs_cdiv(cap1 * f2, 256) > 72 ? gs_cdiv(cap1 * f2, 256) : 72;
+    long nch_s = gs_cdiv(n, 256) > 72 ? gs_cdiv(n, 256) : 72;
+    e->colpart = w.take<float>(C * nch_s * (h > 0 ? h : 1));
+    e->colpart_r = w.take<float>(C * nch_r * (h > 0 ? h : 1));      // the real-side branch may run on its own stream
   }
   e->H1full = e->T == 2 ? w.take<float>(N * h) : nullptr;
   e->P0 = w.take<float>(C * cap1 * F); e->rs0 = w.take<float>(C * cap1);
@@ -282,11 +290,27 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->sample_step = 0;
   e->have_blocks = false;
   e->c_lo = 0; e->c_hi = e->C; e->r_lo = 0; e->r_hi = e->n;
+  e->aux = nullptr; e->ev_fork = e->ev_join = nullptr; e->join_pending = false;
+  e->overlap = (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) == hipSuccess) &&
+               (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess) &&
+               (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess);
   *out = e;
   return GS_OK;
 }
 
-extern "C" void gs_gcond_destroy(gs_gcond* e) { delete e; }
+extern "C" void gs_gcond_destroy(gs_gcond* e) {
+  if (!e) return;
+  if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  delete e;
+}
+
+extern "C" int gs_gcond_set_overlap(gs_gcond* e, int on) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  e->overlap = on && e->aux && e->ev_fork && e->ev_join;
+  return GS_OK;
+}
 
 extern "C" int gs_gcond_new_epoch(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "gs_gcond_new_epoch: null engine");
@@ -335,12 +359,15 @@ static void reduce_parts(gs_gcond* e, const T* part, int nblk, int nq, int nq_ou
 
 // column sums of nbatch [rows x cols] matrices: chunked partials + fixed-order reduce (no atomics)
 static int colsum_batched(gs_gcond* e, const float* M, long batch_stride, int rows, const int* rows_b, int cols, int nbatch,
-                          float* out, long out_stride, gs_stream_t stream) {
-  const int chunk = 256, nchunk = gs_cdiv(rows, chunk);
+                          float* out, long out_stride, gs_stream_t stream, float* scratch = nullptr) {
+  int chunk = gs_cdiv(rows, 64);          // ~64 chunks per matrix: short serial loops, enough blocks
+  chunk = chunk < 8 ? 8 : (chunk > 256 ? 256 : chunk);
+  const int nchunk = gs_cdiv(rows, chunk);
+  float* part = scratch ? scratch : e->colpart;
   hipLaunchKernelGGL(gs_colsum_chunks_kernel, dim3(nchunk, nbatch), dim3(256), 0, (hipStream_t)stream, M, batch_stride, rows,
-                     rows_b, cols, chunk, e->colpart);
+                     rows_b, cols, chunk, part);
   GS_LAUNCH_CHECK();
-  return gs_reduce_slabs_batched_f32(out, out_stride, e->colpart, cols, nchunk, cols, nbatch, 0.f, stream);
+  return gs_reduce_slabs_batched_f32(out, out_stride, part, cols, nchunk, cols, nbatch, 0.f, stream);
 }
 
 // ================================================================================================
@@ -470,7 +497,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     GS_TRY(gs_gemm_f32(&gwd, stream));
     GS_TRY(gs_reduce_slabs_batched_f32(gw + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, Cl, 0.f, stream));
     if (e->cfg.dis_metric != 0)   // 'ours' gives every bias a zero distance and a zero D (condensation/utils.py:98-101)
-      GS_TRY(colsum_batched(e, Bmat, K * h, (int)K, kcount, h, Cl, gw + e->ob1, P, stream));
+      GS_TRY(colsum_batched(e, Bmat, K * h, (int)K, kcount, h, Cl, gw + e->ob1, P, stream, e->colpart_r));
   }
   return GS_OK;
 }
@@ -609,6 +636,10 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       if (e->cfg.dis_metric != 0) GS_TRY(colsum_batched(e, dHp, (long)n * h, n, nullptr, h, Cl, gws + e->ob1, P, stream));
     }
     // ---- matching distance and D = d loss / d gw_syn (already scaled by n_c / n') -------------------
+    if (e->join_pending) {      // gw_real comes from the real-side branch running on the aux stream
+      GS_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
+      e->join_pending = false;
+    }
     float* stats = e->stats + c0 * e->pd.total_cols * 3; float* ab = e->ab + c0 * e->pd.total_cols * 2;
     hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, Cl), dim3(256), 0, s, gwr, gws, P, e->pd, stats);
     hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(Cl), dim3(256), 0, s, stats, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
@@ -866,8 +897,18 @@ extern "C" int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream) {
   if (sharded_c(e) || sharded_r(e))
     GS_FAIL(GS_ERR_STATE, "gs_gcond_outer_step: a sharded engine is driven stage by stage with all-reduces in between (graphslim_amd/parallel.py)");
   const int pge_epoch = (epoch % 50 < 10);
-  GS_TRY(gs_gcond_stage_sample(e, stream));
-  GS_TRY(gs_gcond_stage_real_grads(e, stream));
+  if (e->overlap) {
+    hipStream_t s = (hipStream_t)stream;
+    GS_HIP(hipEventRecord(e->ev_fork, s));
+    GS_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+    GS_TRY(gs_gcond_stage_sample(e, (gs_stream_t)e->aux));
+    GS_TRY(gs_gcond_stage_real_grads(e, (gs_stream_t)e->aux));
+    GS_HIP(hipEventRecord(e->ev_join, e->aux));
+    e->join_pending = true;
+  } else {
+    GS_TRY(gs_gcond_stage_sample(e, stream));
+    GS_TRY(gs_gcond_stage_real_grads(e, stream));
+  }
   GS_TRY(gs_gcond_stage_pge_forward(e, 0, stream));
   GS_TRY(gs_gcond_stage_syn_match(e, stream));
   GS_TRY(gs_gcond_stage_syn_finish(e, stream));

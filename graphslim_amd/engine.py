@@ -319,6 +319,9 @@ class GCondEngine:
     def outer_step(self, epoch):
         check(self.L.gs_gcond_outer_step(self.h, epoch, stream()))
 
+    def set_overlap(self, on):
+        check(self.L.gs_gcond_set_overlap(self.h, int(on)))
+
     # ---- sharded (multi-GPU) driving: see graphslim_amd/parallel.py ------------------------------------
     def set_shard(self, c_lo, c_hi, r_lo, r_hi):
         check(self.L.gs_gcond_set_shard(self.h, c_lo, c_hi, r_lo, r_hi))

@@ -203,6 +203,9 @@ void gs_gcond_destroy(gs_gcond* e);
 int gs_gcond_new_epoch(gs_gcond* e, gs_stream_t stream);
 /* Parity mode: adopt caller-built blocks (same layout as gs_sample_blocks writes). */
 int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* blocks, gs_stream_t stream);
+/* gs_gcond_outer_step runs the real-side branch (sampling + class gradients) on an engine-owned second stream and joins
+ * it by event before the distance statistics (default on; results are identical either way). */
+int gs_gcond_set_overlap(gs_gcond* e, int on);
 /* One outer-loop iteration; adds the matching loss to the device-side accumulator. */
 int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream);
 /* Synchronises `stream`; returns the accumulated loss and the outer-step count since the last reset

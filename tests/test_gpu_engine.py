@@ -154,9 +154,10 @@ def test_engine_sampler_mode_runs_and_is_replayable():
     and feeding the sampled blocks back through the oracle reproduces the engine's loss."""
     p = _problem(2, seed=5)
 
-    def run():
+    def run(overlap=True):
         eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 2, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
                           p["f2"], bcap=p["bcap"], inner=1, csr=p["csr"], pools=p["pools"], external=False, seed=77)
+        eng.set_overlap(overlap)
         eng.set_feat(p["xs"])
         eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
         eng.set_model(p["theta"])
@@ -169,6 +170,8 @@ def test_engine_sampler_mode_runs_and_is_replayable():
     e1, l1 = run()
     e2, l2 = run()
     assert l1 == l2 and torch.equal(e1.feat_syn, e2.feat_syn)          # bitwise reproducible (no float atomics)
+    e3, l3 = run(overlap=False)                                        # one stream instead of the fork/join: same bits
+    assert l3 == l1 and torch.equal(e3.feat_syn, e1.feat_syn) and torch.equal(e3.model_params, e1.model_params)
     assert all(np.isfinite(l1)) and l1[0] > 0
     # oracle on the blocks the engine sampled last
     blk = e1.get_blocks()

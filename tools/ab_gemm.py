@@ -64,5 +64,13 @@ for rnd in range(3):
         _lib.check(L.gs_gemm_set_tuning(bs, bb))
         for ep in (0, 10):
             steps.setdefault((bs, bb, ep), []).append(timeit(lambda: eng.outer_step(ep), reps=10))
+_lib.check(L.gs_gemm_set_tuning(32, 16))
+ov = {}
+for rnd in range(3):
+    for on in (0, 1):
+        eng.set_overlap(on)
+        for ep in (0, 10):
+            ov.setdefault((on, ep), []).append(timeit(lambda: eng.outer_step(ep), reps=10))
+print("overlap off/on (us):", {f"ep{ep}/ov{on}": round(float(np.median(v)), 0) for (on, ep), v in ov.items()})
 for ep in (0, 10):
     print("outer step us, epoch", ep, {f"small{bs}/big{bb}": round(float(np.median(steps[(bs, bb, ep)])), 0) for bs, bb in ((16, 16), (32, 16), (16, 32), (32, 32))})
