@@ -240,6 +240,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_sum, k = eng.read_loss()
+    # informational second measurement: the engine's forward reuse (the training PGE forward of iteration i+1 is adopted
+    # from the bit-identical inference forward that closed iteration i).  NOT the headline: `value` recomputes both passes.
+    eng.set_forward_reuse(True)
+    run_steps(p, eng, args.warmup, max(args.warmup, 1))
+    barrier()
+    t1 = time.perf_counter()
+    run_steps(p, eng, args.steps, args.steps)
+    barrier()
+    dt_reuse = time.perf_counter() - t1
+    eng.set_forward_reuse(False)
+    eng.read_loss()
     if rank == 0:
         units = args.steps * (world if getattr(eng, "replicas_only", False) else 1)
         out = {
@@ -250,7 +261,8 @@ def main():
                                    f"PGE h={p['ph']}, n'={len(p['labels_syn'])}, seeds/class 256, fan-out {list(p['fan'])}, "
                                    f"inner_loop {p['inner']}, GPU sampler", "N": int(p['data'].num_nodes),
                        "nnz": int(p['csr'][0][-1]), "scale": args.scale, "mean_match_loss": loss_sum / max(k, 1) / p['data'].nclass,
-                       "parallelism": getattr(eng, "parallelism", "single")},
+                       "parallelism": getattr(eng, "parallelism", "single"),
+                       "iters_per_sec_with_forward_reuse": round(args.steps / dt_reuse, 3)},
         }
         out["roofline"] = roofline_probe(eng)
         if not args.no_cpu_baseline and world == 1:

@@ -46,6 +46,7 @@ class GCond(GCondBase):
                                         device=self.device)
         eng.set_feat(torch.as_tensor(feat_init))
         eng.set_pge(self.pge_init)
+        eng.set_forward_reuse(True)      # gcond.py:48 recomputes what gcond.py:64 just produced; same values, one pass
         self.feat_syn = eng.feat_syn
         outer_loop, inner_loop = self.get_loops(args)
         loss_avg, best_val = 0, 0

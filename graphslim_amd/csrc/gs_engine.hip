@@ -85,6 +85,9 @@ struct gs_gcond {
   hipStream_t aux;
   hipEvent_t ev_fork, ev_join;
   bool overlap, join_pending;
+  // PGE.inference at the end of iteration i and the training forward of iteration i+1 are the same function of the
+  // same (X~, theta_PGE): with reuse_fwd the second one is not recomputed (its activations are still in place)
+  bool reuse_fwd, fwd_cached;
 };
 
 static void derive(gs_gcond* e, const gs_gcond_config& c) {
@@ -291,6 +294,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->have_blocks = false;
   e->c_lo = 0; e->c_hi = e->C; e->r_lo = 0; e->r_hi = e->n;
   e->aux = nullptr; e->ev_fork = e->ev_join = nullptr; e->join_pending = false;
+  e->reuse_fwd = false; e->fwd_cached = false;
   e->overlap = (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess);
@@ -304,6 +308,19 @@ extern "C" void gs_gcond_destroy(gs_gcond* e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   delete e;
+}
+
+extern "C" int gs_gcond_set_forward_reuse(gs_gcond* e, int on) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  e->reuse_fwd = on != 0;
+  e->fwd_cached = false;
+  return GS_OK;
+}
+
+extern "C" int gs_gcond_invalidate_forward(gs_gcond* e) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  e->fwd_cached = false;
+  return GS_OK;
 }
 
 extern "C" int gs_gcond_set_overlap(gs_gcond* e, int on) {
@@ -515,6 +532,7 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
   const float* pp = e->io.pge_params;
   const int nblk = gs_cdiv(rows > 0 ? rows : 1, e->rows_per_block);
   if (part == 1) {
+    e->fwd_cached = false;
     {  // U = X W0[:, :d]^T ; V = X W0[:, d:]^T
       gs_gemm_desc g = mk(X, d, 1, pp + e->pW0, 1, 2L * d, e->U, Ph, n, Ph, d);
       GS_TRY(gs_gemm_f32(&g, stream));
@@ -552,9 +570,31 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
   float* adj = inference ? e->io.adj_syn : e->adj_raw;
   hipLaunchKernelGGL(gs_pge_adj_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, e->e3, n, adj);
   GS_LAUNCH_CHECK();
-  if (inference) return gs_dense_gcn_norm_fwd(adj, n, e->adj_norm_in, e->rnorm_in, stream);
+  if (inference) {
+    GS_TRY(gs_dense_gcn_norm_fwd(adj, n, e->adj_norm_in, e->rnorm_in, stream));
+    e->fwd_cached = true;     // U, V, A1, E2, BN statistics and e3 of the current (X~, theta_PGE) are in place
+    return GS_OK;
+  }
   return gs_dense_gcn_norm_fwd(adj, n, e->adj_norm, e->rnorm, stream);
 }
+
+// adopt the last inference forward as this iteration's training forward (three small device copies)
+static int adopt_cached_forward(gs_gcond* e, gs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const long n = e->n;
+  GS_HIP(hipMemcpyAsync(e->adj_raw, e->io.adj_syn, sizeof(float) * n * n, hipMemcpyDeviceToDevice, s));
+  GS_HIP(hipMemcpyAsync(e->adj_norm, e->adj_norm_in, sizeof(float) * n * n, hipMemcpyDeviceToDevice, s));
+  GS_HIP(hipMemcpyAsync(e->rnorm, e->rnorm_in, sizeof(float) * 2 * n, hipMemcpyDeviceToDevice, s));
+  return GS_OK;
+}
+
+extern "C" int gs_gcond_adopt_cached_forward(gs_gcond* e, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  if (!e->fwd_cached) GS_FAIL(GS_ERR_STATE, "gs_gcond_adopt_cached_forward: no inference forward of the current state is cached");
+  return adopt_cached_forward(e, stream);
+}
+
+extern "C" int gs_gcond_forward_cached(gs_gcond* e) { return e && e->reuse_fwd && e->fwd_cached ? 1 : 0; }
 
 extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_t stream) {
   if (e && (sharded_r(e))) GS_FAIL(GS_ERR_STATE, "gs_gcond_stage_pge_forward: sharded engines must run the _part entry points with all-reduces in between");
@@ -909,7 +949,10 @@ extern "C" int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream) {
     GS_TRY(gs_gcond_stage_sample(e, stream));
     GS_TRY(gs_gcond_stage_real_grads(e, stream));
   }
-  GS_TRY(gs_gcond_stage_pge_forward(e, 0, stream));
+  if (e->reuse_fwd && e->fwd_cached)
+    GS_TRY(adopt_cached_forward(e, stream));
+  else
+    GS_TRY(gs_gcond_stage_pge_forward(e, 0, stream));
   GS_TRY(gs_gcond_stage_syn_match(e, stream));
   GS_TRY(gs_gcond_stage_syn_finish(e, stream));
   // only the gradient of the group that is stepped this epoch is consumed (the other optimiser's

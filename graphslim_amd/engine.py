@@ -277,12 +277,23 @@ class GCondEngine:
 
     def set_pge(self, params):
         self.pge_params.copy_(torch.cat([p.reshape(-1).float() for p in params]).to(self.dev))
+        self.L.gs_gcond_invalidate_forward(self.h)
 
     def get_pge(self):
         return _split(self.pge_params, self.pge_shapes())
 
     def set_feat(self, x):
         self.feat_syn.copy_(x.to(self.dev, torch.float32))
+        self.L.gs_gcond_invalidate_forward(self.h)
+
+    def set_forward_reuse(self, on):
+        check(self.L.gs_gcond_set_forward_reuse(self.h, int(on)))
+
+    def forward_cached(self):
+        return bool(self.L.gs_gcond_forward_cached(self.h))
+
+    def adopt_cached_forward(self):
+        check(self.L.gs_gcond_adopt_cached_forward(self.h, stream()))
 
     # ---- stages -------------------------------------------------------------------------------------
     def set_blocks(self, blocks: BlockSet):

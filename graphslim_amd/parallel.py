@@ -69,7 +69,7 @@ class ShardedGCond:
         self.v = {k: engine.view(k, f64 if k in ("ar_bn2", "ar_l3") else torch.float32)
                   for k in ("ar_bn2", "ar_l3", "e3", "ar_syn", "ar_marg", "ar_w1")}
         # passthroughs so a ShardedGCond can stand in for a GCondEngine in bench.py / GCond.reduce
-        for name in ("set_feat", "set_pge", "set_model", "get_model", "get_pge", "read_loss", "buffer", "shapes", "dev", "feat_syn",
+        for name in ("set_feat", "set_pge", "set_model", "set_forward_reuse", "get_model", "get_pge", "read_loss", "buffer", "shapes", "dev", "feat_syn",
                      "adj_syn", "pge_params", "model_params", "stage_sample", "get_blocks"):
             setattr(self, name, getattr(engine, name))
 
@@ -83,7 +83,8 @@ class ShardedGCond:
             return [(lambda: e.pge_forward_part(inference, 1), "ar_bn2"), (lambda: e.pge_forward_part(inference, 2), "e3"),
                     (lambda: e.pge_forward_part(inference, 3), None)]
 
-        ph = [(e.stage_sample, None), (e.stage_real_grads, None)] + fwd(False)
+        ph = [(e.stage_sample, None), (e.stage_real_grads, None)]
+        ph += [(e.adopt_cached_forward, None)] if e.forward_cached() else fwd(False)
         ph += [(e.stage_syn_match, "ar_syn"), (e.syn_finish, None),
                (lambda: e.pge_backward_part(np_, nf, 1), "ar_l3"),
                (lambda: e.pge_backward_part(np_, nf, 2), "ar_marg")]

@@ -203,6 +203,14 @@ void gs_gcond_destroy(gs_gcond* e);
 int gs_gcond_new_epoch(gs_gcond* e, gs_stream_t stream);
 /* Parity mode: adopt caller-built blocks (same layout as gs_sample_blocks writes). */
 int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* blocks, gs_stream_t stream);
+/* PGE.inference at the end of iteration i (gcond.py:63-65) and `adj_syn = pge(self.feat_syn)` at the start of iteration i+1
+ * (gcond.py:48) evaluate the same function on the same (X~, theta_PGE).  With forward reuse on, gs_gcond_outer_step adopts the
+ * cached pass instead of recomputing it (bitwise the same values).  Off by default; call gs_gcond_invalidate_forward after
+ * writing X~ or theta_PGE from the host.  gs_gcond_forward_cached returns 1 when the next step would adopt. */
+int gs_gcond_set_forward_reuse(gs_gcond* e, int on);
+int gs_gcond_invalidate_forward(gs_gcond* e);
+int gs_gcond_forward_cached(gs_gcond* e);
+int gs_gcond_adopt_cached_forward(gs_gcond* e, gs_stream_t stream);
 /* gs_gcond_outer_step runs the real-side branch (sampling + class gradients) on an engine-owned second stream and joins
  * it by event before the distance statistics (default on; results are identical either way). */
 int gs_gcond_set_overlap(gs_gcond* e, int on);

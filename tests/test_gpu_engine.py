@@ -154,10 +154,11 @@ def test_engine_sampler_mode_runs_and_is_replayable():
     and feeding the sampled blocks back through the oracle reproduces the engine's loss."""
     p = _problem(2, seed=5)
 
-    def run(overlap=True):
+    def run(overlap=True, reuse=False):
         eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 2, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
                           p["f2"], bcap=p["bcap"], inner=1, csr=p["csr"], pools=p["pools"], external=False, seed=77)
         eng.set_overlap(overlap)
+        eng.set_forward_reuse(reuse)
         eng.set_feat(p["xs"])
         eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
         eng.set_model(p["theta"])
@@ -172,6 +173,11 @@ def test_engine_sampler_mode_runs_and_is_replayable():
     assert l1 == l2 and torch.equal(e1.feat_syn, e2.feat_syn)          # bitwise reproducible (no float atomics)
     e3, l3 = run(overlap=False)                                        # one stream instead of the fork/join: same bits
     assert l3 == l1 and torch.equal(e3.feat_syn, e1.feat_syn) and torch.equal(e3.model_params, e1.model_params)
+    e4, l4 = run(reuse=True)       # training forward of step i+1 adopted from the inference forward of step i: same bits
+    assert l4 == l1 and torch.equal(e4.feat_syn, e1.feat_syn) and torch.equal(e4.pge_params, e1.pge_params)
+    assert torch.equal(e4.adj_syn, e1.adj_syn) and e4.forward_cached()
+    e4.set_feat(p["xs"])
+    assert not e4.forward_cached()                                     # host wrote X~: the cached pass is stale
     assert all(np.isfinite(l1)) and l1[0] > 0
     # oracle on the blocks the engine sampled last
     blk = e1.get_blocks()

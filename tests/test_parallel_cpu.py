@@ -41,12 +41,15 @@ class FakeEngine:
         self.rank, self.calls, self.shapes, self.dev = rank, [], self.S(), "cpu"
         self.bufs = {k: torch.zeros(6, dtype=torch.float64 if k in ("ar_bn2", "ar_l3") else torch.float32)
                      for k in ("ar_bn2", "ar_l3", "e3", "ar_syn", "ar_marg", "ar_w1")}
-        for name in ("set_feat", "set_pge", "set_model", "get_model", "get_pge", "read_loss", "buffer", "feat_syn", "adj_syn",
+        for name in ("set_feat", "set_pge", "set_model", "set_forward_reuse", "get_model", "get_pge", "read_loss", "buffer", "feat_syn", "adj_syn",
                      "pge_params", "model_params", "get_blocks"):
             setattr(self, name, None)
 
     def view(self, name, dtype=torch.float32):
         return self.bufs[name]
+
+    def forward_cached(self):
+        return False
 
     def set_shard(self, *a):
         self.shard = a
@@ -97,7 +100,7 @@ def test_sharded_driver_over_gloo_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=60) for _ in range(2))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
