@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
                 ("gatherA_m", vp), ("gatherA_k", vp), ("gatherB_k", vp), ("sGb1", C.c_long),
                 ("kchunk", C.c_int), ("alpha", C.c_float), ("beta", C.c_float),
                 ("bias", vp), ("sbias_b1", C.c_long), ("relu", C.c_int), ("mask", vp), ("ldmask", C.c_long),
-                ("colstat", vp)]
+                ("colstat", vp), ("bgen_mask", vp), ("bgen_ldm", C.c_long), ("bgen_idx", vp), ("bgen_w", vp), ("bgen_div", C.c_int)]
 
 
 class Blocks(C.Structure):

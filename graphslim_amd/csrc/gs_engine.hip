@@ -88,6 +88,10 @@ struct gs_gcond {
   // PGE.inference at the end of iteration i and the training forward of iteration i+1 are the same function of the
   // same (X~, theta_PGE): with reuse_fwd the second one is not recomputed (its activations are still in place)
   bool reuse_fwd, fwd_cached;
+  // blocks are double-buffered: the set for iteration i+1 is sampled on the aux stream while iteration i finishes
+  gs_blocks blkbuf[2];
+  int blk_cur;
+  bool prefetched;
 };
 
 static void derive(gs_gcond* e, const gs_gcond_config& c) {
@@ -133,12 +137,15 @@ static size_t carve(gs_gcond* e, void* base) {
   Carver w{(char*)base, 0};
   const long C = e->C, n = e->n, d = e->d, h = e->h, Ph = e->Ph, F = e->F, P = e->P, N = e->N;
   const long bcap = e->bcap, cap1 = e->cap1, f1 = e->f1, f2 = e->f2, n2 = n * n;
-  gs_blocks& b = e->blk;
-  b.C = e->C; b.bcap = e->bcap; b.f1 = e->f1; b.f2 = e->f2; b.cap1 = e->cap1;
-  b.n_seed = w.take<int>(C); b.n1 = w.take<int>(C); b.nid1 = w.take<int>(C * cap1);
-  b.col1 = w.take<int>(C * bcap * f1); b.val1 = w.take<float>(C * bcap * f1);
-  b.tptr1 = w.take<int>(C * (cap1 + 1)); b.tedge1 = w.take<int>(C * bcap * f1);
-  b.col0 = w.take<int>(C * cap1 * f2); b.val0 = w.take<float>(C * cap1 * f2);
+  for (int q = 0; q < 2; ++q) {
+    gs_blocks& b = e->blkbuf[q];
+    b.C = e->C; b.bcap = e->bcap; b.f1 = e->f1; b.f2 = e->f2; b.cap1 = e->cap1;
+    b.n_seed = w.take<int>(C); b.n1 = w.take<int>(C); b.nid1 = w.take<int>(C * cap1);
+    b.col1 = w.take<int>(C * bcap * f1); b.val1 = w.take<float>(C * bcap * f1);
+    b.tptr1 = w.take<int>(C * (cap1 + 1)); b.tedge1 = w.take<int>(C * bcap * f1);
+    b.col0 = w.take<int>(C * cap1 * f2); b.val0 = w.take<float>(C * cap1 * f2);
+  }
+  e->blk = e->blkbuf[0];
   e->marker = e->cfg.external_blocks ? nullptr : w.take<int>(C * N);
   e->kcount = w.take<int>(C);
   {
@@ -295,6 +302,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->c_lo = 0; e->c_hi = e->C; e->r_lo = 0; e->r_hi = e->n;
   e->aux = nullptr; e->ev_fork = e->ev_join = nullptr; e->join_pending = false;
   e->reuse_fwd = false; e->fwd_cached = false;
+  e->blk_cur = 0; e->prefetched = false;
   e->overlap = (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess);
@@ -346,6 +354,7 @@ extern "C" int gs_gcond_get_blocks(gs_gcond* e, gs_blocks* out) {
 
 extern "C" int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* b, gs_stream_t stream) {
   if (!e || !b) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_blocks: null argument");
+  e->prefetched = false;
   const gs_blocks& d = e->blk;
   if (b->C != d.C || b->bcap != d.bcap || b->f1 != d.f1 || b->f2 != d.f2 || b->cap1 != d.cap1)
     GS_FAIL(GS_ERR_ARG, "gs_gcond_set_blocks: block geometry differs from the engine's");
@@ -420,18 +429,32 @@ int gs_sample_blocks_ex(const int*, const int*, const float*, int, const int*, c
 // ================================================================================================
 // stage: sampling
 // ================================================================================================
+static int sample_into(gs_gcond* e, int which, gs_stream_t stream) {
+  if (e->c_hi > e->c_lo) {
+    const gs_blocks keep = e->blk;
+    e->blk = e->blkbuf[which];
+    gs_blocks b = blocks_view(e);
+    e->blk = keep;
+    GS_TRY(gs_sample_blocks_ex(e->io.rowptr, e->io.col, e->io.val, e->N, e->io.cls_ptr + e->c_lo, e->io.cls_nodes,
+                               e->marker + (long)e->c_lo * e->N, &b, e->cfg.seed, e->sample_step, e->c_lo, stream));
+  }
+  e->sample_step++;
+  return GS_OK;
+}
+
 extern "C" int gs_gcond_stage_sample(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   if (e->cfg.external_blocks) {
     if (!e->have_blocks) GS_FAIL(GS_ERR_STATE, "gs_gcond: external_blocks set but gs_gcond_set_blocks was never called");
     return GS_OK;
   }
-  if (e->c_hi > e->c_lo) {
-    gs_blocks b = blocks_view(e);
-    GS_TRY(gs_sample_blocks_ex(e->io.rowptr, e->io.col, e->io.val, e->N, e->io.cls_ptr + e->c_lo, e->io.cls_nodes,
-                               e->marker + (long)e->c_lo * e->N, &b, e->cfg.seed, e->sample_step, e->c_lo, stream));
+  if (e->prefetched) {          // the set for this iteration was sampled ahead on the aux stream: adopt it
+    e->blk_cur ^= 1;
+    e->blk = e->blkbuf[e->blk_cur];
+    e->prefetched = false;
+  } else {
+    GS_TRY(sample_into(e, e->blk_cur, stream));
   }
-  e->sample_step++;
   e->have_blocks = true;
   return GS_OK;
 }
@@ -504,17 +527,24 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     GS_TRY(gs_gemm_f32(&g, stream));
     hipLaunchKernelGGL(gs_csc_spmm_t_kernel, dim3(gs_cdiv((long)Cl * cap1, 4)), dim3(256), 0, s, b.tptr1, b.tedge1, b.val1, b.n1,
                        cap1, bcap, f1, Tm, h, Y1, Cl);
-    hipLaunchKernelGGL(gs_make_bmat_kernel, dim3(gs_cdiv((long)Cl * cap1 * f2, 4)), dim3(256), 0, s, b.col0, b.val0, b.n1, cap1,
-                       f2, e->H1full, (long)h, Y1, h, Bmat, kcount, Cl);
+    const bool fused = (e->cfg.dis_metric == 0);   // 'ours' needs no bias gradient -> Bmat is generated inside the GEMM
+    if (fused)
+      hipLaunchKernelGGL(gs_kcount_kernel, dim3(gs_cdiv(Cl, 64)), dim3(64), 0, s, b.n1, f2, Cl, kcount);
+    else
+      hipLaunchKernelGGL(gs_make_bmat_kernel, dim3(gs_cdiv((long)Cl * cap1 * f2, 4)), dim3(256), 0, s, b.col0, b.val0, b.n1, cap1,
+                         f2, e->H1full, (long)h, Y1, h, Bmat, kcount, Cl);
     GS_LAUNCH_CHECK();
     gs_gemm_desc gwd = mk(e->io.X, 1, e->ldx, Bmat, h, 1, e->slabs_r, h, d, h, (int)K);
     gwd.gatherA_k = b.col0; gwd.sGb1 = K;
     gwd.nb1 = Cl; gwd.nb2 = e->nsplit_r; gwd.kchunk = e->kchunk_r; gwd.Kb = kcount;
     gwd.sBb1 = K * h; gwd.sCb1 = (long)e->nsplit_r * d * h; gwd.sCb2 = (long)d * h;
+    if (fused) {   // B(k, :) = val0[k] * [H1full[col0[k]] > 0] * Y1[k / f2]
+      gwd.B = Y1; gwd.sBb1 = (long)cap1 * h;
+      gwd.bgen_mask = e->H1full; gwd.bgen_ldm = h; gwd.bgen_idx = b.col0; gwd.bgen_w = b.val0; gwd.bgen_div = f2;
+    }
     GS_TRY(gs_gemm_f32(&gwd, stream));
     GS_TRY(gs_reduce_slabs_batched_f32(gw + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, Cl, 0.f, stream));
-    if (e->cfg.dis_metric != 0)   // 'ours' gives every bias a zero distance and a zero D (condensation/utils.py:98-101)
-      GS_TRY(colsum_batched(e, Bmat, K * h, (int)K, kcount, h, Cl, gw + e->ob1, P, stream, e->colpart_r));
+    if (!fused) GS_TRY(colsum_batched(e, Bmat, K * h, (int)K, kcount, h, Cl, gw + e->ob1, P, stream, e->colpart_r));
   }
   return GS_OK;
 }
@@ -945,6 +975,10 @@ extern "C" int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream) {
     GS_TRY(gs_gcond_stage_real_grads(e, (gs_stream_t)e->aux));
     GS_HIP(hipEventRecord(e->ev_join, e->aux));
     e->join_pending = true;
+    if (!e->cfg.external_blocks) {   // sample the NEXT iteration's blocks behind this one's gradients (same RNG sequence)
+      GS_TRY(sample_into(e, e->blk_cur ^ 1, (gs_stream_t)e->aux));
+      e->prefetched = true;
+    }
   } else {
     GS_TRY(gs_gcond_stage_sample(e, stream));
     GS_TRY(gs_gcond_stage_real_grads(e, stream));

@@ -15,6 +15,8 @@
 // per-lane MFMA operand read (lane = row, k = lane>>5) is a conflict-free ds_read_b32; the next
 // tile's global loads are issued before the current tile's MFMAs (register double buffer, one
 // barrier pair per K step).
+#include <type_traits>
+
 #include "gs_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -128,7 +130,52 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int r, 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int BK>
+// Generated B operand of the real-side edge GEMM (never materialised):
+//   B(k, n) = w[k] * [mask[idx[k]][n] > 0] * Y[k / div][n]          (n contiguous: the LDS image of GS_MODE_M)
+// = d loss / d pre-activation of sampled edge k (gcond_base.py:223 autograd through relu and the hop-2 block).
+template <int BN, int BK>
+struct BGenLoader {
+  static constexpr int Q = BN / 4, UNITS = BK * Q, PER = (UNITS + 255) / 256;
+  float4 r4[PER];
+  __device__ __forceinline__ void load(const float* __restrict__ Y, long ldy, const float* __restrict__ mask, long ldm,
+                                       const int* __restrict__ idx, const float* __restrict__ w, int div, int n0, int N, int k0,
+                                       int k_hi, bool interior, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * 256;
+      if (UNITS % 256 != 0 && u >= UNITS) break;
+      const int k = u / Q, o4 = (u % Q) * 4;
+      const int gk = min(k0 + k, k_hi - 1);
+      const long yr = (long)(gk / div) * ldy, mr = (long)idx[gk] * ldm;
+      const float wk = (k0 + k < k_hi) ? w[gk] : 0.f;
+      if (interior) {
+        const f32x4u y = *reinterpret_cast<const f32x4u*>(Y + yr + n0 + o4);
+        const f32x4u m = *reinterpret_cast<const f32x4u*>(mask + mr + n0 + o4);
+        r4[i] = make_float4(m.x > 0.f ? wk * y.x : 0.f, m.y > 0.f ? wk * y.y : 0.f, m.z > 0.f ? wk * y.z : 0.f,
+                            m.w > 0.f ? wk * y.w : 0.f);
+      } else {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int o = min(n0 + o4 + j, N - 1);
+          const float y = Y[yr + o], m = mask[mr + o];
+          v[j] = (n0 + o4 + j < N && m > 0.f) ? wk * y : 0.f;
+        }
+        r4[i] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * 256;
+      if (UNITS % 256 != 0 && u >= UNITS) break;
+      *reinterpret_cast<float4*>(lds + (u / Q) * (BN + GS_PAD) + (u % Q) * 4) = r4[i];
+    }
+  }
+};
+
+template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int BK, bool BGEN = false>
 __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
   constexpr int GS_BK = BK;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -161,11 +208,16 @@ __global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
   const bool fullM = (m0 + BM <= M), fullN = (n0 + BN <= p.N);
 
   TileLoader<BM, AMODE, BK> la;
-  TileLoader<BN, BMODE, BK> lb;
+  typename std::conditional<BGEN, BGenLoader<BN, BK>, TileLoader<BN, BMODE, BK>>::type lb;
+  const int* bg_idx = BGEN ? p.bgen_idx + (long)b1 * p.sGb1 : nullptr;
+  const float* bg_w = BGEN ? p.bgen_w + (long)b1 * p.sGb1 : nullptr;
   auto load_tiles = [&](int k0) {
     const bool fullK = (k0 + GS_BK <= k_hi);
     la.load(A, p.sAm, p.sAk, gAm, gAk, m0, M, k0, k_hi, vecA && fullM && fullK, tid);
-    lb.load(B, p.sBn, p.sBk, nullptr, gBk, n0, p.N, k0, k_hi, vecB && fullN && fullK, tid);
+    if constexpr (BGEN)
+      lb.load(B, p.sBk, p.bgen_mask, p.bgen_ldm, bg_idx, bg_w, p.bgen_div, n0, p.N, k0, k_hi, fullN && fullK, tid);
+    else
+      lb.load(B, p.sBn, p.sBk, nullptr, gBk, n0, p.N, k0, k_hi, vecB && fullN && fullK, tid);
   };
 
   f32x16 acc[TM][TN];
@@ -329,6 +381,14 @@ static int launch_gemm3(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
   return GS_OK;
 }
 
+template <int BM, int BN, int WM, int WN, int AM, int BK>
+static int launch_gemm_bgen(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
+  dim3 grid(gs_cdiv(p.N, BN), gs_cdiv(p.M, BM), nbatch);
+  hipLaunchKernelGGL((gs_gemm_f32_kernel<BM, BN, WM, WN, AM, GS_MODE_M, BK, true>), grid, dim3(256), 0, s, p);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int AM, int BMD>
 static int launch_gemm2(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
   const int bk = (BM == 128 && BN == 128) ? g_bk_big : g_bk_small;
@@ -338,6 +398,11 @@ static int launch_gemm2(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
+  if (p.bgen_mask) {   // generated B operand: A must be the m-contiguous gathered operand of the edge GEMM
+    const int bk = (BM == 128 && BN == 128) ? g_bk_big : g_bk_small;
+    if (bk == 32) return launch_gemm_bgen<BM, BN, WM, WN, GS_MODE_M, 32>(p, nbatch, s);
+    return launch_gemm_bgen<BM, BN, WM, WN, GS_MODE_M, 16>(p, nbatch, s);
+  }
   int am = (p.sAk == 1 && !p.gatherA_k) ? GS_MODE_K : ((p.sAm == 1 && !p.gatherA_m) ? GS_MODE_M : GS_MODE_G);
   int bm = (p.sBk == 1 && !p.gatherB_k) ? GS_MODE_K : ((p.sBn == 1) ? GS_MODE_M : GS_MODE_G);
   if (am == GS_MODE_G || bm == GS_MODE_G) return launch_gemm2<BM, BN, WM, WN, GS_MODE_G, GS_MODE_G>(p, nbatch, s);
@@ -368,6 +433,8 @@ extern "C" int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream) {
   if (p.M <= 0 || p.N <= 0) return GS_OK;
   if (p.K < 0) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: negative K");
   if (p.colstat && (p.nb1 > 1 || p.nb2 > 1)) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: colstat is for unbatched calls");
+  if (p.bgen_mask && (!p.bgen_idx || !p.bgen_w || p.bgen_div < 1 || p.sAm != 1 || p.gatherA_m || p.gatherB_k))
+    GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: bgen needs idx, w, div >= 1 and an m-contiguous A");
   if (p.nb1 < 1) p.nb1 = 1;
   if (p.nb2 < 1) p.nb2 = 1;
   const int nbatch = p.nb1 * p.nb2;

@@ -788,3 +788,9 @@ __global__ __launch_bounds__(256) void gs_colsum_chunks_kernel(const float* __re
     o[k] = s;
   }
 }
+
+// kcount[c] = n1[c] * f2  (rows of the per-class edge list that are live)
+__global__ void gs_kcount_kernel(const int* __restrict__ n1, int f2, int nclass, int* __restrict__ kcount) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nclass) kcount[c] = n1[c] * f2;
+}

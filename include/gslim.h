@@ -66,6 +66,13 @@ typedef struct gs_gemm_desc {
   long ldmask;
   float* colstat;        /* optional [tiles_m][2][N]: per-M-tile column sums / sums of squares of the written C
                             (BatchNorm batch statistics fused into the epilogue); tiles_m = gs_gemm_tiles_m(desc) */
+  /* optional generated B operand (the real-side edge GEMM): B(k,n) = bgen_w[k] * [bgen_mask[bgen_idx[k]][n] > 0] *
+     B[(k / bgen_div) * sBk + n]; bgen_idx / bgen_w advance by sGb1 per b1 like the gathers; needs sAm == 1, sBn == 1 */
+  const float* bgen_mask;
+  long bgen_ldm;
+  const int* bgen_idx;
+  const float* bgen_w;
+  int bgen_div;
 } gs_gemm_desc;
 
 /* K-tile depth (16 or 32) of the small tiles and of the 128x128 tile; a measurement knob (defaults 32 / 16). */
