@@ -55,7 +55,7 @@ SYMBOLS = [
     "gs_version", "gs_last_error", "gs_gemm_f32", "gs_gemm_tiles_m", "gs_gemm_set_tuning", "gs_reduce_slabs_f32", "gs_reduce_slabs_batched_f32",
     "gs_spmm_csr_f32", "gs_gather_rows_f32", "gs_sample_blocks", "gs_dense_gcn_norm_fwd", "gs_dense_gcn_norm_bwd",
     "gs_adam_step_f32", "gs_gcond_workspace_bytes", "gs_gcond_create", "gs_gcond_destroy", "gs_gcond_new_epoch",
-    "gs_gcond_set_blocks", "gs_gcond_outer_step", "gs_gcond_read_loss", "gs_gcond_stage_sample",
+    "gs_gcond_set_blocks", "gs_gcond_outer_step", "gs_gcond_outer_step_ex", "gs_gcond_set_identity_structure", "gs_gcond_read_loss", "gs_gcond_stage_sample",
     "gs_gcond_stage_real_grads", "gs_gcond_stage_pge_forward", "gs_gcond_stage_syn_match",
     "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer",
     "gs_gcond_get_blocks", "gs_gcond_set_shard", "gs_gcond_set_overlap", "gs_gcond_set_forward_reuse", "gs_gcond_invalidate_forward",
@@ -99,6 +99,8 @@ def lib():
     L.gs_gcond_new_epoch.argtypes = [vp, vp]
     L.gs_gcond_set_blocks.argtypes = [vp, C.POINTER(Blocks), vp]
     L.gs_gcond_outer_step.argtypes = [vp, i, vp]
+    L.gs_gcond_outer_step_ex.argtypes = [vp, i, i, i, i, vp]
+    L.gs_gcond_set_identity_structure.argtypes = [vp, i, vp]
     L.gs_gcond_read_loss.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), vp]
     for name in ("gs_gcond_stage_sample", "gs_gcond_stage_real_grads", "gs_gcond_stage_syn_match", "gs_gcond_stage_inner"):
         getattr(L, name).argtypes = [vp, vp]

@@ -11,11 +11,16 @@ from ..host import init_sgc_params, normalize_adj_sparse
 from .gcond_base import GCondBase
 
 
-class GCond(GCondBase):
-    """"Graph Condensation for Graph Neural Networks" (Jin et al.) — gradient matching with a learned structure."""
+class _GradMatch(GCondBase):
+    """Shared host loop of the gradient-matching family.  Sub-classes state their update rule."""
 
-    def __init__(self, setting, data, args, **kwargs):
-        super().__init__(setting, data, args, **kwargs)
+    identity_structure = False       # GCondX / DosCondX: adj_syn = I (gcondx.py:30)
+    inner_steps = True               # model steps on the condensed graph after each outer iteration
+    inference_each_step = True       # PGE.inference after every outer iteration (gcond.py:63-65)
+
+    def rule(self, it, ol):
+        """(step_pge, step_feat) for outer iteration `ol` of epoch `it`."""
+        raise NotImplementedError
 
     @verbose_time_memory
     def reduce(self, data, verbose=True):
@@ -46,20 +51,38 @@ class GCond(GCondBase):
                                         device=self.device)
         eng.set_feat(torch.as_tensor(feat_init))
         eng.set_pge(self.pge_init)
+        if self.identity_structure:
+            eng.set_identity_structure(True)
         eng.set_forward_reuse(True)      # gcond.py:48 recomputes what gcond.py:64 just produced; same values, one pass
         self.feat_syn = eng.feat_syn
         outer_loop, inner_loop = self.get_loops(args)
         loss_avg, best_val = 0, 0
         init_sgc_params(self.d, args.hidden, nclass, args.ntrans)           # model constructor draw (gcond.py:38)
         labels_t = torch.from_numpy(labels_syn).to(self.device)
+        run_inner = self.inner_steps and inner_loop > 0
+        run_inf = self.inference_each_step and not self.identity_structure
         for it in trange(args.epochs):
             eng.set_model(init_sgc_params(self.d, args.hidden, nclass, args.ntrans))   # gcond.py:42-45
             for ol in range(outer_loop):
-                eng.outer_step(it)
+                step_pge, step_feat = self.rule(it, ol)
+                eng.outer_step_ex(step_pge, step_feat, run_inf, run_inner)
             loss_sum, _ = eng.read_loss()            # one host sync per epoch instead of one .item() per iteration
             loss_avg = (loss_avg + loss_sum) / (nclass * outer_loop)        # gcond.py:52,74 (running value is not reset)
             if it in args.checkpoints:
-                self.adj_syn = eng.adj_syn.clone()
+                if self.identity_structure:
+                    self.adj_syn = torch.eye(self.nnodes_syn, device=self.device)       # gcondx.py:68-69
+                else:
+                    if not run_inf:
+                        eng.stage_pge_forward(True)                                     # doscond.py:53
+                    self.adj_syn = eng.adj_syn.clone()
                 data.adj_syn, data.feat_syn, data.labels_syn = self.adj_syn, eng.feat_syn.clone(), labels_t
                 best_val = self.intermediate_evaluation(best_val, loss_avg)
         return data
+
+
+class GCond(_GradMatch):
+    """"Graph Condensation for Graph Neural Networks" (Jin et al.) — gradient matching with a learned structure."""
+
+    def rule(self, it, ol):
+        pge = it % 50 < 10               # gcond.py:58-61: keyed on the EPOCH index
+        return pge, not pge

@@ -92,6 +92,7 @@ struct gs_gcond {
   gs_blocks blkbuf[2];
   int blk_cur;
   bool prefetched;
+  bool identity;    // structure-free variants (GCondX / DosCondX): adj_syn = I, no PGE
 };
 
 static void derive(gs_gcond* e, const gs_gcond_config& c) {
@@ -302,7 +303,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->c_lo = 0; e->c_hi = e->C; e->r_lo = 0; e->r_hi = e->n;
   e->aux = nullptr; e->ev_fork = e->ev_join = nullptr; e->join_pending = false;
   e->reuse_fwd = false; e->fwd_cached = false;
-  e->blk_cur = 0; e->prefetched = false;
+  e->blk_cur = 0; e->prefetched = false; e->identity = false;
   e->overlap = (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess);
@@ -784,6 +785,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     b.beta = 1.f;
     GS_TRY(gs_gemm_f32(&b, stream));
   }
+  if (e->identity) return GS_OK;     // adj_syn is the constant identity: nothing upstream of A^
   return gs_dense_gcn_norm_bwd(e->adj_raw, e->rnorm, e->dAn, n, e->d_adj, stream);
 }
 
@@ -962,11 +964,38 @@ extern "C" int gs_gcond_stage_inner(gs_gcond* e, gs_stream_t stream) {
   return gs_gcond_stage_inner_steps(e, stream);
 }
 
-extern "C" int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream) {
+__global__ void gs_eye_kernel(float* __restrict__ a, int n) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < (long)n * n) a[idx] = (idx / n == idx % n) ? 1.f : 0.f;
+}
+
+extern "C" int gs_gcond_set_identity_structure(gs_gcond* e, int on, gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  e->identity = on != 0;
+  e->fwd_cached = false;
+  if (e->identity) {   // gcondx.py:30 / doscondx.py:30: self.adj_syn = torch.eye(n) is used as is (not re-normalised)
+    hipStream_t s = (hipStream_t)stream;
+    const int n = e->n;
+    dim3 g(gs_cdiv((long)n * n, 256));
+    hipLaunchKernelGGL(gs_eye_kernel, g, dim3(256), 0, s, e->adj_norm, n);
+    hipLaunchKernelGGL(gs_eye_kernel, g, dim3(256), 0, s, e->adj_norm_in, n);
+    hipLaunchKernelGGL(gs_eye_kernel, g, dim3(256), 0, s, e->io.adj_syn, n);
+    GS_LAUNCH_CHECK();
+  }
+  return GS_OK;
+}
+
+// One outer iteration with the update rule chosen by the caller (the sibling methods share train_class and differ only here):
+//   GCond    (gcond.py:47-72)   : step_pge = epoch%50<10, step_feat = !step_pge, inference + inner steps
+//   DosCond  (doscond.py:40-50) : both optimisers stepped, no inference, no inner steps
+//   GCondX   (gcondx.py:44-66)  : identity structure, feat stepped unless ol%5<1, inner steps on A^ = I
+//   DosCondX (doscondx.py:42-49): identity structure, feat stepped, nothing else
+extern "C" int gs_gcond_outer_step_ex(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner,
+                                      gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   if (sharded_c(e) || sharded_r(e))
     GS_FAIL(GS_ERR_STATE, "gs_gcond_outer_step: a sharded engine is driven stage by stage with all-reduces in between (graphslim_amd/parallel.py)");
-  const int pge_epoch = (epoch % 50 < 10);
+  if (e->identity) { step_pge = 0; run_inference = 0; }
   if (e->overlap) {
     hipStream_t s = (hipStream_t)stream;
     GS_HIP(hipEventRecord(e->ev_fork, s));
@@ -983,17 +1012,34 @@ extern "C" int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream) {
     GS_TRY(gs_gcond_stage_sample(e, stream));
     GS_TRY(gs_gcond_stage_real_grads(e, stream));
   }
-  if (e->reuse_fwd && e->fwd_cached)
-    GS_TRY(adopt_cached_forward(e, stream));
-  else
-    GS_TRY(gs_gcond_stage_pge_forward(e, 0, stream));
+  if (!e->identity) {
+    if (e->reuse_fwd && e->fwd_cached)
+      GS_TRY(adopt_cached_forward(e, stream));
+    else
+      GS_TRY(gs_gcond_stage_pge_forward(e, 0, stream));
+  }
   GS_TRY(gs_gcond_stage_syn_match(e, stream));
   GS_TRY(gs_gcond_stage_syn_finish(e, stream));
-  // only the gradient of the group that is stepped this epoch is consumed (the other optimiser's
-  // grads are zeroed unread by the next zero_grad(), gcond.py:54-61)
-  GS_TRY(gs_gcond_stage_pge_backward(e, pge_epoch, !pge_epoch, stream));
-  GS_TRY(gs_gcond_stage_update(e, epoch, stream));
-  return gs_gcond_stage_inner(e, stream);
+  // only the gradient of a group that is stepped is consumed (zero_grad() discards the rest unread, gcond.py:54-61)
+  if (!e->identity && (step_pge || step_feat)) GS_TRY(gs_gcond_stage_pge_backward(e, step_pge, step_feat, stream));
+  if (step_pge)
+    GS_TRY(gs_adam_step_f32(e->io.pge_params, e->d_pge, e->m_pge, e->v_pge, e->Ppge, e->cfg.lr_adj, 0.9f, 0.999f, 1e-8f, 0.f,
+                            ++e->step_pge, stream));
+  if (step_feat)
+    GS_TRY(gs_adam_step_f32(e->io.feat_syn, e->d_feat, e->m_feat, e->v_feat, (long)e->n * e->d, e->cfg.lr_feat, 0.9f, 0.999f,
+                            1e-8f, 0.f, ++e->step_feat, stream));
+  if (step_pge || step_feat) e->fwd_cached = false;
+  if (run_inference) GS_TRY(gs_gcond_stage_pge_forward(e, 1, stream));
+  if (run_inner) {
+    if (!e->identity && !run_inference) GS_FAIL(GS_ERR_ARG, "gs_gcond_outer_step_ex: inner steps need the inference pass");
+    GS_TRY(gs_gcond_stage_inner_steps(e, stream));
+  }
+  return GS_OK;
+}
+
+extern "C" int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream) {
+  const int pge_epoch = (epoch % 50 < 10);     // gcond.py:58-61
+  return gs_gcond_outer_step_ex(e, pge_epoch, !pge_epoch, 1, 1, stream);
 }
 
 extern "C" int gs_gcond_read_loss(gs_gcond* e, double* loss_sum, long* steps, gs_stream_t stream) {

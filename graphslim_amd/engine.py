@@ -330,6 +330,12 @@ class GCondEngine:
     def outer_step(self, epoch):
         check(self.L.gs_gcond_outer_step(self.h, epoch, stream()))
 
+    def outer_step_ex(self, step_pge, step_feat, run_inference, run_inner):
+        check(self.L.gs_gcond_outer_step_ex(self.h, int(step_pge), int(step_feat), int(run_inference), int(run_inner), stream()))
+
+    def set_identity_structure(self, on=True):
+        check(self.L.gs_gcond_set_identity_structure(self.h, int(on), stream()))
+
     def set_overlap(self, on):
         check(self.L.gs_gcond_set_overlap(self.h, int(on)))
 

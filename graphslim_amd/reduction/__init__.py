@@ -6,7 +6,8 @@ def create_reducer(name, setting, data, args, **kwargs):
     if key == "random":
         from ..sparsification.random import Random
         return Random(setting, data, args, **kwargs)
-    if key == "gcond":
-        from ..condensation.gcond import GCond
-        return GCond(setting, data, args, **kwargs)
+    if key in ("gcond", "doscond", "gcondx", "doscondx"):
+        from .. import condensation as cd
+        cls = {"gcond": cd.GCond, "doscond": cd.DosCond, "gcondx": cd.GCondX, "doscondx": cd.DosCondX}[key]
+        return cls(setting, data, args, **kwargs)
     raise NotImplementedError(f"graphslim_amd builds the GCond path only; reducer '{name}' is out of scope (SURVEY.md §8)")

@@ -223,6 +223,12 @@ int gs_gcond_adopt_cached_forward(gs_gcond* e, gs_stream_t stream);
 int gs_gcond_set_overlap(gs_gcond* e, int on);
 /* One outer-loop iteration; adds the matching loss to the device-side accumulator. */
 int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream);
+/* The sibling gradient-matching methods reuse train_class unchanged and differ in the update rule and in whether a
+ * structure is learned (condensation/doscond.py:40-50, gcondx.py:30,44-66, doscondx.py:30,42-49):
+ * gs_gcond_outer_step(e, epoch) == gs_gcond_outer_step_ex(e, epoch%50<10, !(epoch%50<10), 1, 1). */
+int gs_gcond_outer_step_ex(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_stream_t stream);
+/* adj_syn = I (no PGE): GCondX / DosCondX. */
+int gs_gcond_set_identity_structure(gs_gcond* e, int on, gs_stream_t stream);
 /* Synchronises `stream`; returns the accumulated loss and the outer-step count since the last reset
  * (host pointers) and resets both.  This is the loss_avg bookkeeping of gcond.py:52,74. */
 int gs_gcond_read_loss(gs_gcond* e, double* loss_sum, long* steps, gs_stream_t stream);

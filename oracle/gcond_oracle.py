@@ -408,6 +408,39 @@ class GCondState:
         self.model = [p.clone().requires_grad_(True) for p in model_params]
         self.opt_model = Adam(self.model, self.lr_model)
 
+    def outer_iteration_ex(self, batches, features, labels, inner_loop, *, step_pge, step_feat, run_inference, run_inner,
+                           identity=False, dis_metric="ours"):
+        """The sibling loops: DosCond (doscond.py:40-50: both optimisers, no inner steps), GCondX (gcondx.py:30,44-66:
+        adj_syn = I, feature step unless ol % 5 < 1, inner steps on I), DosCondX (doscondx.py:30,42-49)."""
+        n = self.feat_syn.shape[0]
+        if identity:
+            adj_norm = torch.eye(n, dtype=self.feat_syn.dtype)
+        else:
+            adj_norm = dense_gcn_norm(pge_forward(self.feat_syn, self.pge))
+        loss = train_class(self.kind, self.model, batches, features, labels, self.feat_syn, adj_norm, self.labels_syn,
+                           self.num_class_dict, self.nclass, self.nlayers, dis_metric)
+        plist = self.pge_param_list()
+        wrt = [self.feat_syn] + ([] if identity else plist)
+        grads = torch.autograd.grad(loss, wrt, allow_unused=True)
+        if step_pge and not identity:
+            self.opt_pge.step([g if g is not None else torch.zeros_like(p) for g, p in zip(grads[1:], plist)])
+        if step_feat:
+            self.opt_feat.step([grads[0]])
+        adj_inner = None
+        with torch.no_grad():
+            if identity:
+                adj_inner, adj_inner_norm = torch.eye(n), torch.eye(n)
+            elif run_inference:
+                adj_inner = pge_forward(self.feat_syn.detach(), {"lin": [p.detach() for p in self.pge["lin"]],
+                                                                 "bn": [p.detach() for p in self.pge["bn"]]})
+                adj_inner_norm = dense_gcn_norm(adj_inner)
+        if run_inner:
+            for _ in range(inner_loop):
+                out = model_forward(self.kind, self.feat_syn.detach(), adj_inner_norm, self.model, self.nlayers)
+                gm = torch.autograd.grad(F.nll_loss(out, self.labels_syn), self.model)
+                self.opt_model.step(list(gm))
+        return loss.detach(), grads[0].detach(), adj_inner
+
     def outer_iteration(self, epoch, batches, features, labels, inner_loop, dis_metric="ours"):
         """gcond.py:47-72.  Returns (loss value, grads wrt feat_syn, grads wrt pge params)."""
         adj_syn = pge_forward(self.feat_syn, self.pge)

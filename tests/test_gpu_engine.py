@@ -345,3 +345,68 @@ def test_rccl_allreduce_on_engine_views_world1():
         assert np.isfinite(float(eng.buffer("loss")[0]))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant", ["doscond", "gcondx", "doscondx"])
+@pytest.mark.parametrize("t", [1, 2])
+def test_sibling_methods_follow_the_oracle(variant, t):
+    """DosCond / GCondX / DosCondX (doscond.py:40-50, gcondx.py:30,44-66, doscondx.py:30,42-49) reuse train_class and
+    differ in the update rule / structure: six outer iterations against oracle.GCondState.outer_iteration_ex."""
+    from graphslim_amd.engine import BlockSet
+    metric = "ours" if variant == "doscond" else "mse"
+    p = _problem(t, seed=31 + t)
+    eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], t, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
+                      p["f2"], bcap=p["bcap"], metric=metric, inner=2, lrs=(0.01, 0.005, 0.02))
+    st = O.GCondState(p["xs"], p["pge"], T(p["labels_syn"]), p["ncd"], p["nclass"], 0.01, 0.005, 0.02, "SGC", 2)
+    eng.set_feat(p["xs"])
+    eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
+    identity = variant != "doscond"
+    if identity:
+        eng.set_identity_structure(True)
+    st.new_epoch(p["theta"])
+    eng.set_model(p["theta"])
+    X, Y = T(p["x"]), T(p["y"])
+    for ol in range(6):
+        if variant == "doscond":
+            rule = dict(step_pge=True, step_feat=True, run_inference=False, run_inner=False)
+        elif variant == "gcondx":
+            rule = dict(step_pge=False, step_feat=not (ol % 5 < 1), run_inference=False, run_inner=True)
+        else:
+            rule = dict(step_pge=False, step_feat=True, run_inference=False, run_inner=False)
+        batches = _batches(p, ol)
+        l_ref, gfeat, _ = st.outer_iteration_ex(batches, X, Y, 2, identity=identity, dis_metric=metric, **rule)
+        eng.set_blocks(BlockSet.from_batches(batches, p["bcap"], p["f1"], p["f2"], DEV))
+        eng.outer_step_ex(rule["step_pge"], rule["step_feat"], rule["run_inference"], rule["run_inner"])
+        loss = float(eng.buffer("loss")[0])
+        assert abs(loss - float(l_ref)) <= 2e-4 * abs(float(l_ref)), (variant, ol, loss, float(l_ref))
+        if rule["step_feat"]:
+            close(eng.buffer("d_feat", gfeat.shape), gfeat, 2e-3, "d X~")
+    np.testing.assert_allclose(eng.feat_syn.cpu().numpy(), st.feat_syn.detach().numpy(), atol=3e-3)
+    for got, ref in zip(eng.get_model(), st.model):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.detach().numpy(), atol=4e-3)
+    if identity:
+        assert torch.equal(eng.adj_syn.cpu(), torch.eye(len(p["labels_syn"])))
+    else:
+        eng.stage_pge_forward(True)      # doscond.py:53: inference at the checkpoint
+        with torch.no_grad():
+            ref = O.pge_forward(st.feat_syn.detach(), {"lin": [q.detach() for q in st.pge["lin"]], "bn": [q.detach() for q in st.pge["bn"]]})
+        close(eng.adj_syn.cpu(), ref, 3e-3, "adj_syn")
+
+
+def test_sibling_methods_reduce_api(tmp_path):
+    import graphslim  # noqa: F401
+    from graphslim.config import cli
+    from graphslim.condensation import DosCond, DosCondX, GCondX
+    from graphslim.dataset import get_dataset
+    from graphslim.evaluation.eval_agent import Evaluator
+    for cls, method in ((DosCond, "doscond"), (GCondX, "gcondx"), (DosCondX, "doscondx")):
+        args = cli(["-D", "pubmed", "-M", method, "-R", "0.5", "-G", "0", "--epochs", "20", "--eval_epochs", "30", "--run_eval",
+                    "2", "--condense_model", "SGC", "--save_path", str(tmp_path)], standalone_mode=False)
+        args.run_inter_eval = 1
+        graph = get_dataset(args.dataset, args)
+        reduced = cls(setting=args.setting, data=graph, args=args).reduce(graph, verbose=False)
+        n = reduced.feat_syn.shape[0]
+        if method != "doscond":
+            assert torch.equal(reduced.adj_syn.cpu(), torch.eye(n))
+        mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
+        assert mean > 0.5, (method, mean)
