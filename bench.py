@@ -209,13 +209,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local)
-    dev = f"cuda:{local}"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    elif args.gpus > 1:
+        raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     p = build_problem(args.workload, seed=1, scale=args.scale)
     from graphslim_amd import parallel
     eng = parallel.make_engine(p, dev, rank, world) if world > 1 else make_engine(p, dev)
