@@ -60,7 +60,7 @@ SYMBOLS = [
     "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer",
     "gs_gcond_get_blocks", "gs_gcond_set_shard", "gs_gcond_set_overlap", "gs_gcond_set_forward_reuse", "gs_gcond_invalidate_forward",
     "gs_gcond_forward_cached", "gs_gcond_adopt_cached_forward", "gs_gcond_stage_pge_forward_part", "gs_gcond_stage_pge_backward_part",
-    "gs_gcond_stage_syn_finish", "gs_gcond_stage_inner_steps", "gs_bias_act_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
+    "gs_gcond_stage_syn_finish", "gs_gcond_stage_inner_steps", "gs_bias_act_f32", "gs_log_softmax_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
 ]
 
 
@@ -93,6 +93,7 @@ def lib():
     L.gs_bias_act_f32.argtypes = [vp, l, vp, l, i, i, vp]
     L.gs_softmax_nll_grad_f32.argtypes = [vp, l, vp, l, i, vp, vp, vp]
     L.gs_colsum_f32.argtypes = [vp, l, l, i, vp, vp]
+    L.gs_log_softmax_f32.argtypes = [vp, l, l, i, vp, l, vp]
     L.gs_count_correct.argtypes = [vp, l, i, vp, vp, l, vp, vp]
     L.gs_gcond_workspace_bytes.argtypes = [C.POINTER(GCondConfig), C.POINTER(C.c_size_t)]
     L.gs_gcond_create.argtypes = [C.POINTER(GCondConfig), C.POINTER(GCondIO), vp, C.POINTER(vp)]

@@ -395,3 +395,28 @@ extern "C" int gs_count_correct(const float* Z, long ldz, int C, const int* idx,
   GS_LAUNCH_CHECK();
   return GS_OK;
 }
+
+// out[i,:] = log_softmax(Z[i,:])   (F.log_softmax, models/base.py:78) — one wave per row
+__global__ __launch_bounds__(256) void gs_log_softmax_kernel(const float* __restrict__ Z, long ldz, long n, int C,
+                                                             float* __restrict__ out, long ldo) {
+  const int lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n) return;
+  const float* z = Z + i * ldz;
+  float mx = -INFINITY;
+  for (int k = lane; k < C; k += 64) mx = fmaxf(mx, z[k]);
+  mx = gs_wave_max(mx);
+  float se = 0.f;
+  for (int k = lane; k < C; k += 64) se += expf(z[k] - mx);
+  se = gs_wave_sum(se);
+  const float lse = mx + logf(se);
+  for (int k = lane; k < C; k += 64) out[i * ldo + k] = z[k] - lse;
+}
+
+extern "C" int gs_log_softmax_f32(const float* Z, long ldz, long n, int C, float* out, long ldo, gs_stream_t stream) {
+  if (n <= 0 || C <= 0) return GS_OK;
+  if (!Z || !out || ldz < C || ldo < C) GS_FAIL(GS_ERR_ARG, "gs_log_softmax_f32: bad argument");
+  hipLaunchKernelGGL(gs_log_softmax_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, Z, ldz, n, C, out, ldo);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

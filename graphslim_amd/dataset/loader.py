@@ -53,6 +53,29 @@ def splits(data):
     return data
 
 
+class SampledBlock:
+    """One bipartite hop of a sampled batch: CSR [n_dst x n_src] with the full-graph normalised weights as values
+    (the role torch_sparse.SparseTensor plays in PyG's `Adj.adj_t`)."""
+
+    def __init__(self, rowptr, col, val, shape):
+        self.rowptr, self.col, self.val, self.shape = rowptr, col, val, tuple(shape)
+
+    def to(self, device):
+        return SampledBlock(self.rowptr.to(device), self.col.to(device), self.val.to(device), self.shape)
+
+    def sparse_sizes(self):
+        return self.shape
+
+    def csr(self):
+        return self.rowptr, self.col, self.val
+
+    def to_dense(self):
+        out = torch.zeros(self.shape, device=self.val.device)
+        rows = torch.arange(self.shape[0], device=self.val.device).repeat_interleave(self.rowptr[1:] - self.rowptr[:-1])
+        out[rows, self.col] = self.val
+        return out
+
+
 class TransAndInd:
     """Attribute-for-attribute mirror of graphslim/dataset/loader.py:100-175."""
 
@@ -102,6 +125,59 @@ class TransAndInd:
         else:
             ids = np.arange(len(lt))
         return [ids[lt == c] for c in range(self.nclass)]
+
+    def retrieve_class_sampler(self, c, adj, args, num=256):
+        """dataset/loader.py:187-224 on the HIP sampler: (batch_size, n_id, adjs) for class `c`, `adjs` outermost hop
+        first, each `(adj_t, e_id, size)` with `adj_t` a `SampledBlock` (CSR rowptr / col / val on the device, targets
+        first) — what PyG's NeighborSampler.sample returns with return_e_id=False.  `adj` = (rowptr, col, val) of the
+        normalised adjacency (host.normalize_adj_sparse) or None to build it from adj_full / adj_train.
+        GCond.reduce does not go through this method (the engine samples all classes at once); it is here for callers of
+        the GraphData contract.  Index shuffling below is host-side plumbing on torch tensors; the sampling is HIP."""
+        from ..engine import BlockSet, sample_blocks
+        from ..host import normalize_adj_sparse
+        dev = torch.device(args.device)
+        if not str(dev).startswith("cuda"):
+            raise RuntimeError("graphslim_amd has no CPU path: run with a GPU (-G 0)")
+        st = self.__dict__.setdefault("_gs_sampler", {})
+        if "csr" not in st:
+            if adj is None:
+                adj = normalize_adj_sparse(self.adj_full if args.setting == "trans" else self.adj_train)
+            pools = self.class_pools(args.setting)
+            i32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int32).to(dev)
+            st["csr"] = (i32(adj[0]), i32(adj[1]), torch.as_tensor(np.asarray(adj[2]), dtype=torch.float32).to(dev))
+            st["n"] = len(adj[0]) - 1
+            st["ptr"] = i32(np.concatenate([[0], np.cumsum([len(p) for p in pools])]))
+            st["nodes"] = i32(np.concatenate(pools))
+            st["marker"] = torch.full((self.nclass * st["n"],), 0x7fffffff, dtype=torch.int32, device=dev)
+            st["step"] = 0
+        if args.nlayers != 2:
+            raise NotImplementedError("graphslim_amd: the sampler is built for two hops (nlayers = 2)")
+        f1, f2 = (15, 8) if args.dataset in ("reddit", "flickr") else (10, 5)
+        blk = BlockSet(self.nclass, min(num, 256), f1, f2, dev)
+        sample_blocks(*st["csr"], st["n"], st["ptr"], st["nodes"], st["marker"], blk, int(getattr(args, "seed", 1)), st["step"])
+        st["step"] += 1
+        B, n1 = int(blk.n_seed[c]), int(blk.n1[c])
+        nid1 = blk.nid1[c, :n1].long()
+        # hop-2 block: frontier (targets) <- sources; relabel the global sources targets-first like sample_adj
+        v0, c0 = blk.val0[c, :n1].reshape(-1), blk.col0[c, :n1].reshape(-1).long()
+        keep = v0 != 0
+        rows0 = torch.arange(n1, device=dev).repeat_interleave(f2)[keep]
+        src = c0[keep]
+        pos = torch.full((st["n"],), -1, dtype=torch.long, device=dev)
+        pos[nid1] = torch.arange(n1, device=dev)
+        new = torch.unique(src[pos[src] < 0])
+        pos[new] = n1 + torch.arange(new.numel(), device=dev)
+        n_id = torch.cat([nid1, new])
+        rp0 = torch.zeros(n1 + 1, dtype=torch.long, device=dev)
+        rp0[1:] = torch.cumsum(torch.bincount(rows0, minlength=n1), 0)
+        blk0 = SampledBlock(rp0, pos[src], v0[keep], (n1, n_id.numel()))
+        v1, c1 = blk.val1[c, :B].reshape(-1), blk.col1[c, :B].reshape(-1).long()
+        k1 = v1 != 0
+        rows1 = torch.arange(B, device=dev).repeat_interleave(f1)[k1]
+        rp1 = torch.zeros(B + 1, dtype=torch.long, device=dev)
+        rp1[1:] = torch.cumsum(torch.bincount(rows1, minlength=B), 0)
+        blk1 = SampledBlock(rp1, c1[k1], v1[k1], (B, n1))
+        return B, n_id, [(blk0, None, (n_id.numel(), n1)), (blk1, None, (n1, B))]
 
     def retrieve_class(self, c, num=256):
         """loader.py:177-185."""

@@ -221,5 +221,7 @@ class GCN:
         X[:, :features.shape[1]] = torch.as_tensor(features).to(dev, torch.float32)
         if not sp.issparse(adj):
             raise NotImplementedError("graphslim_amd.GCN.predict expects a scipy sparse adjacency")
-        Z = self._forward_sparse(X, _dev_csr(adj, dev))[:, :self.nclass]
-        return torch.log_softmax(Z, dim=1)       # presentation only; accuracy paths use the logits directly
+        Z = self._forward_sparse(X, _dev_csr(adj, dev))
+        out = torch.empty(Z.shape[0], self.nclass, device=dev)
+        check(_lib.lib().gs_log_softmax_f32(ptr(Z), Z.stride(0), Z.shape[0], self.nclass, ptr(out), self.nclass, stream()))
+        return out

@@ -153,6 +153,8 @@ int gs_bias_act_f32(float* X, long ld, const float* bias, long n, int F, int rel
 /* G = (softmax(Z) - onehot(labels)) / n (may be NULL);  loss_rows[i] = -log_softmax(Z[i])[labels[i]] (may be NULL). */
 int gs_softmax_nll_grad_f32(const float* Z, long ldz, const int* labels, long n, int C, float* G, float* loss_rows,
                             gs_stream_t stream);
+/* out = log_softmax(Z) row-wise (F.log_softmax, models/base.py:78). */
+int gs_log_softmax_f32(const float* Z, long ldz, long n, int C, float* out, long ldo, gs_stream_t stream);
 /* out[k] = sum_i M[i*ld + k] (fp64 accumulation). */
 int gs_colsum_f32(const float* M, long ld, long rows, int cols, float* out, gs_stream_t stream);
 /* count[0] += #{i < n : argmax_k Z[idx[i]][k] == labels[i]}  (idx may be NULL = identity). */

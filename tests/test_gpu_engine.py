@@ -410,3 +410,56 @@ def test_sibling_methods_reduce_api(tmp_path):
             assert torch.equal(reduced.adj_syn.cpu(), torch.eye(n))
         mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
         assert mean > 0.5, (method, mean)
+
+
+def test_edge_cases_tiny_classes_and_one_row_per_class():
+    """One synthetic row per class (max(int(cnt*r),1) everywhere, gcond_base.py:106), class pools smaller than the seed
+    budget (down to a single train node), nodes of degree < fan-out: loss / gradients still follow the oracle."""
+    from graphslim_amd.engine import BlockSet
+    p = _problem(2, seed=41, n=300, nclass=6, rate=0.001, bcap=16)
+    assert len(p["labels_syn"]) == 6
+    p["pools"][0] = p["pools"][0][:1]            # a class with ONE train node
+    p["pools"][1] = p["pools"][1][:3]
+    eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 2, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
+                      p["f2"], bcap=p["bcap"], inner=1)
+    st = O.GCondState(p["xs"], p["pge"], T(p["labels_syn"]), p["ncd"], p["nclass"], 0.01, 0.01, 0.01, "SGC", 2)
+    eng.set_feat(p["xs"])
+    eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
+    st.new_epoch(p["theta"])
+    eng.set_model(p["theta"])
+    batches = _batches(p, 0)
+    assert batches[0][0] == 1 and batches[1][0] == 3
+    l_ref, gfeat, gpge, adj_inner = st.outer_iteration(10, batches, T(p["x"]), T(p["y"]), 1)
+    eng.set_blocks(BlockSet.from_batches(batches, p["bcap"], p["f1"], p["f2"], DEV))
+    eng.outer_step(10)
+    loss = float(eng.buffer("loss")[0])
+    assert abs(loss - float(l_ref)) <= 1e-4 * abs(float(l_ref))
+    close(eng.buffer("d_feat", gfeat.shape), gfeat, 2e-3)
+    close(eng.adj_syn.cpu(), adj_inner, 2e-3)
+
+
+def test_retrieve_class_sampler_contract():
+    """GraphData.retrieve_class_sampler (loader.py:187-224) backed by gs_sample_blocks: reference-shaped output whose blocks
+    reproduce the class gradient through the oracle, i.e. the blocks are a valid targets-first two-hop sample."""
+    import types
+    from graphslim_amd.dataset.loader import TransAndInd, splits
+    from graphslim_amd.dataset.synthetic import make_raw
+    from graphslim_amd.host import normalize_adj_sparse
+    data = TransAndInd(splits(make_raw("cora", seed=2)), "cora")
+    args = types.SimpleNamespace(device=DEV, setting="trans", nlayers=2, dataset="cora", seed=3)
+    csr = normalize_adj_sparse(data.adj_full)
+    dense = O.csr_to_torch(*csr, data.num_nodes).to_dense()
+    for c in (0, 4):
+        bs, n_id, adjs = data.retrieve_class_sampler(c, csr, args)
+        assert bs == 20 and len(adjs) == 2                      # 20 train nodes per class; outermost hop first
+        (b0, e0, s0), (b1, e1, s1) = adjs
+        assert e0 is None and e1 is None and s1 == (b1.shape[1], bs) and s0 == (n_id.numel(), b0.shape[0])
+        n_id = n_id.cpu()
+        assert set(n_id[:bs].tolist()) <= set(data.class_pools("trans")[c].tolist())
+        assert len(set(n_id.tolist())) == n_id.numel()          # de-duplicated, targets first
+        d0, d1 = b0.to_dense().cpu(), b1.to_dense().cpu()
+        # every block entry carries the full-graph normalised weight of that edge
+        n1 = d1.shape[1]
+        assert torch.equal(d1[d1 != 0], dense[n_id[:bs]][:, n_id[:n1]][d1 != 0])
+        assert torch.equal(d0[d0 != 0], dense[n_id[:n1]][:, n_id][d0 != 0])
+        assert int((d1 != 0).sum(1).max()) <= 10 and int((d0 != 0).sum(1).max()) <= 5
