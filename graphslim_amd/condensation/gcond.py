@@ -25,8 +25,9 @@ class _GradMatch(GCondBase):
     @verbose_time_memory
     def reduce(self, data, verbose=True):
         args = self.args
-        if args.condense_model != "SGC":
-            raise NotImplementedError("graphslim_amd: condense_model must be SGC (GCN as condense model is a 'next' row, SURVEY §8f)")
+        if args.condense_model not in ("SGC", "GCN"):
+            raise NotImplementedError(f"graphslim_amd: condense_model must be SGC or GCN (got {args.condense_model})")
+        depth = 2 if args.condense_model == "GCN" else args.ntrans      # models/gcn.py:8-23 vs models/sgc.py:16-35
         if args.nlayers != 2:
             raise NotImplementedError("graphslim_amd: nlayers (propagations) must be 2")
         if getattr(args, "with_bn", False):
@@ -42,8 +43,8 @@ class _GradMatch(GCondBase):
         sizes = (15, 8) if args.dataset in ("reddit", "flickr") else (10, 5)     # loader.py:197-210
         nclass = data.nclass
         ranges = [tuple(self.syn_class_indices.get(c, (0, 0))) for c in range(nclass)]
-        shapes = EngineShapes(features.shape[0], self.d, nclass, self.nnodes_syn, args.ntrans, args.hidden, self.pge_hidden,
-                              256, sizes[0], sizes[1])
+        shapes = EngineShapes(features.shape[0], self.d, nclass, self.nnodes_syn, depth, args.hidden, self.pge_hidden,
+                              256, sizes[0], sizes[1], model=args.condense_model)
         cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
         eng = self.engine = GCondEngine(shapes, features, csr, cls_ptr, np.concatenate(pools), labels_syn, ranges,
                                         lr_feat=args.lr_feat, lr_adj=args.lr_adj, lr_model=args.lr,
@@ -57,12 +58,12 @@ class _GradMatch(GCondBase):
         self.feat_syn = eng.feat_syn
         outer_loop, inner_loop = self.get_loops(args)
         loss_avg, best_val = 0, 0
-        init_sgc_params(self.d, args.hidden, nclass, args.ntrans)           # model constructor draw (gcond.py:38)
+        init_sgc_params(self.d, args.hidden, nclass, depth)                 # model constructor draw (gcond.py:38)
         labels_t = torch.from_numpy(labels_syn).to(self.device)
         run_inner = self.inner_steps and inner_loop > 0
         run_inf = self.inference_each_step and not self.identity_structure
         for it in trange(args.epochs):
-            eng.set_model(init_sgc_params(self.d, args.hidden, nclass, args.ntrans))   # gcond.py:42-45
+            eng.set_model(init_sgc_params(self.d, args.hidden, nclass, depth))         # gcond.py:42-45
             for ol in range(outer_loop):
                 step_pge, step_feat = self.rule(it, ol)
                 eng.outer_step_ex(step_pge, step_feat, run_inf, run_inner)

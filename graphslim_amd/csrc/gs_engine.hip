@@ -92,6 +92,8 @@ struct gs_gcond {
   gs_blocks blkbuf[2];
   int blk_cur;
   bool prefetched;
+  bool gcn;         // condense model GCN (2 layers) instead of SGC
+  float *P0g, *T2r, *dT2r, *dH1r, *S1, *dS1, *Tmat, *Rmat;   // GCN-only scratch
   bool identity;    // structure-free variants (GCondX / DosCondX): adj_syn = I, no PGE
 };
 
@@ -99,7 +101,9 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   e->cfg = c;
   e->N = c.n_nodes; e->d = c.d; e->ldx = c.ldx; e->C = c.nclass; e->n = c.n_syn; e->T = c.ntrans; e->h = c.hidden;
   e->Ph = c.pge_hidden; e->bcap = c.bcap; e->f1 = c.f1; e->f2 = c.f2; e->cap1 = c.bcap * (1 + c.f1);
-  e->F = (c.ntrans == 1) ? c.d : c.hidden;
+  e->gcn = (c.condense_model == 1);
+  if (e->gcn) e->T = 2;                       // GCN: two GraphConvolution layers, same parameter layout as SGC T = 2
+  e->F = (e->T == 1) ? c.d : c.hidden;
   gs_pdesc& pd = e->pd;
   memset(&pd, 0, sizeof(pd));
   if (e->T == 1) {
@@ -202,19 +206,28 @@ static size_t carve(gs_gcond* e, void* base) {
   e->m_model = w.take<float>(P); e->v_model = w.take<float>(P);
   e->loss_sum = w.take<double>(1); e->loss_last = w.take<float>(1); e->steps = w.take<long>(1);
   e->off_lo = w.take<long>(C); e->off_loF = w.take<long>(C); e->off_loC = w.take<long>(C); e->off_lon = w.take<long>(C);
-  e->ncls = w.take<int>(C); e->ones = w.take<float>(1);
+  e->ncls = w.take<int>(C); e->ones = w.take<float>(n > C * bcap ? n : C * bcap);
+  if (e->gcn) {
+    e->P0g = w.take<float>(C * cap1 * d); e->T2r = w.take<float>(C * cap1 * C); e->dT2r = w.take<float>(C * cap1 * C);
+    e->dH1r = w.take<float>(C * cap1 * h); e->S1 = w.take<float>(n * d); e->dS1 = w.take<float>(n * d);
+    e->Tmat = w.take<float>(n * h); e->Rmat = w.take<float>(n * h);
+  } else {
+    e->P0g = e->T2r = e->dT2r = e->dH1r = e->S1 = e->dS1 = e->Tmat = e->Rmat = nullptr;
+  }
   return (w.off + 255) & ~(size_t)255;
 }
 
 static int check_cfg(const gs_gcond_config* c) {
   if (!c) GS_FAIL(GS_ERR_ARG, "gs_gcond: null config");
-  if (c->ntrans != 1 && c->ntrans != 2) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: SGC ntrans must be 1 or 2 (got %d)", c->ntrans);
+  if (c->condense_model != 0 && c->condense_model != 1) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: condense_model must be 0 (SGC) or 1 (GCN)");
+  if (c->condense_model == 0 && c->ntrans != 1 && c->ntrans != 2) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: SGC ntrans must be 1 or 2 (got %d)", c->ntrans);
+  if (c->condense_model == 1 && c->hidden < 1) GS_FAIL(GS_ERR_ARG, "gs_gcond: hidden must be > 0 for GCN");
   if (c->n_nodes < 1 || c->d < 1 || c->ldx < c->d || c->nclass < 1 || c->n_syn < 1 || c->pge_hidden < 1)
     GS_FAIL(GS_ERR_ARG, "gs_gcond: bad dimensions");
   if (c->nclass > 512) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nclass > 512");
   if (c->pge_hidden % 4 != 0 || c->pge_hidden > 1024 || c->pge_hidden < 4)
     GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: pge_hidden must be a multiple of 4 in [4, 1024] (the reference uses 128 / 256)");
-  if (c->ntrans == 2 && c->hidden < 1) GS_FAIL(GS_ERR_ARG, "gs_gcond: hidden must be > 0 for ntrans = 2");
+  if (c->condense_model == 0 && c->ntrans == 2 && c->hidden < 1) GS_FAIL(GS_ERR_ARG, "gs_gcond: hidden must be > 0 for ntrans = 2");
   if (c->bcap < 1 || c->bcap > 256 || c->f1 < 1 || c->f1 > 16 || c->f2 < 1 || c->f2 > 16)
     GS_FAIL(GS_ERR_ARG, "gs_gcond: bcap in [1,256], fan-outs in [1,16]");
   if (c->dis_metric < 0 || c->dis_metric > 2) GS_FAIL(GS_ERR_ARG, "DC error: unknown distance function");
@@ -277,7 +290,9 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
     (void)hipMemcpyAsync(e->off_loC, oC, C * sizeof(long), hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(e->off_lon, on, C * sizeof(long), hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(e->ncls, nc, C * sizeof(int), hipMemcpyHostToDevice, s);
-    (void)hipMemcpyAsync(e->ones, &one, sizeof(float), hipMemcpyHostToDevice, s);
+    hipLaunchKernelGGL(gs_fill_kernel, dim3(gs_cdiv(e->n > C * e->bcap ? e->n : C * e->bcap, 256)), dim3(256), 0, s, e->ones,
+                       (long)(e->n > C * e->bcap ? e->n : C * e->bcap), 1.f);
+    (void)one;
     (void)hipMemsetAsync(e->m_feat, 0, sizeof(float) * e->n * e->d, s);
     (void)hipMemsetAsync(e->v_feat, 0, sizeof(float) * e->n * e->d, s);
     (void)hipMemsetAsync(e->m_pge, 0, sizeof(float) * e->Ppge, s);
@@ -490,6 +505,37 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   float* Sr = e->Sr + c0 * bcap * F; float* rsr = e->rsr + c0 * bcap;
   float* Zr = e->Zr + c0 * bcap * C; float* gw = e->gw_real + c0 * P;
   const float* th = e->io.model_params;
+  if (e->gcn) {
+    // GCN (layers.py:36-51), propagate-first: P0 = A0 X_g ; H1 = relu(P0 W1 + b1) ; Z = A1 (H1 W2) + b2
+    float* P0g = e->P0g + c0 * cap1 * d; float* H1r = e->Y1 + c0 * cap1 * h; float* T2r = e->T2r + c0 * cap1 * C;
+    float* dT2 = e->dT2r + c0 * cap1 * C; float* dH1 = e->dH1r + c0 * cap1 * h;
+    launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, e->io.X, e->ldx, nullptr, d, P0g, nullptr, Cl, s);
+    GS_LAUNCH_CHECK();
+    gs_gemm_desc g1 = mk(P0g, d, 1, th + e->oW1, h, 1, H1r, h, Cl * cap1, h, d);
+    g1.bias = th + e->ob1; g1.relu = 1;
+    GS_TRY(gs_gemm_f32(&g1, stream));
+    gs_gemm_desc g2 = mk(H1r, h, 1, th + e->oWl, C, 1, T2r, C, Cl * cap1, C, h);
+    GS_TRY(gs_gemm_f32(&g2, stream));
+    launch_ell(b.col1, b.val1, b.n_seed, bcap, f1, cap1, T2r, C, nullptr, C, Zr, nullptr, Cl, s);
+    hipLaunchKernelGGL(gs_real_softmax_grad_kernel, dim3(gs_cdiv((long)Cl * bcap, 4)), dim3(256), 0, s, Zr, e->ones, th + e->obl,
+                       b.n_seed, bcap, C, (int)c0, Cl);                      // Z + 1 * b2 ; G in place
+    GS_LAUNCH_CHECK();
+    GS_TRY(colsum_batched(e, Zr, (long)bcap * C, bcap, nullptr, C, Cl, gw + e->obl, P, stream, e->colpart_r));   // gb2
+    hipLaunchKernelGGL(gs_csc_spmm_t_kernel, dim3(gs_cdiv((long)Cl * cap1, 4)), dim3(256), 0, s, b.tptr1, b.tedge1, b.val1, b.n1,
+                       cap1, bcap, f1, Zr, C, dT2, Cl);                      // dT2 = A1^T G   (rows >= n1 are zeros)
+    GS_LAUNCH_CHECK();
+    gs_gemm_desc w2 = mk(H1r, 1, h, dT2, C, 1, gw + e->oWl, C, h, C, cap1);   // gW2_c = H1_c^T dT2_c
+    w2.nb1 = Cl; w2.sAb1 = (long)cap1 * h; w2.sBb1 = (long)cap1 * C; w2.sCb1 = P;
+    GS_TRY(gs_gemm_f32(&w2, stream));
+    gs_gemm_desc dh = mk(dT2, C, 1, th + e->oWl, 1, C, dH1, h, Cl * cap1, h, C);   // dH1p = (dT2 W2^T) * [H1 > 0]
+    dh.mask = H1r; dh.ldmask = h;
+    GS_TRY(gs_gemm_f32(&dh, stream));
+    GS_TRY(colsum_batched(e, dH1, (long)cap1 * h, cap1, nullptr, h, Cl, gw + e->ob1, P, stream, e->colpart_r));   // gb1
+    gs_gemm_desc w1 = mk(P0g, 1, d, dH1, h, 1, gw + e->oW1, h, d, h, cap1);   // gW1_c = P0_c^T dH1p_c
+    w1.nb1 = Cl; w1.sAb1 = (long)cap1 * d; w1.sBb1 = (long)cap1 * h; w1.sCb1 = P;
+    GS_TRY(gs_gemm_f32(&w1, stream));
+    return GS_OK;
+  }
   const float* src = e->io.X;
   long ld_src = e->ldx;
   if (e->T == 2) {   // H1full = relu(X W1 + b1) for every node once: theta is shared by all classes
@@ -654,6 +700,88 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   const long* off_lo = e->off_lo + c0; const long* off_loF = e->off_loF + c0; const long* off_loC = e->off_loC + c0;
   const long* off_lon = e->off_lon + c0; const int* ncls = e->ncls + c0;
   float* gws = e->gw_syn + c0 * P; const float* gwr = e->gw_real + c0 * P; float* Dv = e->D + c0 * P;
+  if (e->gcn) {
+    // ---- GCN condense model: S1 = A X ; H1 = relu(S1 W1 + b1) ; S2 = A H1 ; Z = S2 W2 + b2 (oracle/analytic.py:syn_match_gcn)
+    const float* W1 = th + e->oW1;
+    float* S2 = e->Ss;                               // [n x h]
+    { gs_gemm_desc g = mk(A, n, 1, X, d, 1, e->S1, d, n, d, n); GS_TRY(gs_gemm_f32(&g, stream)); }
+    { gs_gemm_desc g = mk(e->S1, d, 1, W1, h, 1, e->H1s, h, n, h, d); g.bias = th + e->ob1; g.relu = 1; GS_TRY(gs_gemm_f32(&g, stream)); }
+    { gs_gemm_desc g = mk(A, n, 1, e->H1s, h, 1, S2, h, n, h, n); GS_TRY(gs_gemm_f32(&g, stream)); }
+    { gs_gemm_desc g = mk(S2, h, 1, Wl, C, 1, e->Zs, C, n, C, h); GS_TRY(gs_gemm_f32(&g, stream)); }
+    hipLaunchKernelGGL(gs_syn_softmax_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Zs, e->ones, bl, e->io.labels_syn,
+                       e->io.syn_lo, e->io.syn_hi, n, C, e->Ps, e->Gs, 0);
+    GS_LAUNCH_CHECK();
+    { gs_gemm_desc g = mk(e->Gs, C, 1, Wl, 1, C, e->Tmat, h, n, h, C); GS_TRY(gs_gemm_f32(&g, stream)); }   // T = G W2^T (rows partition by class)
+    if (part) {
+      GS_HIP(hipMemsetAsync(e->loss_c, 0, sizeof(float) * C, s));
+      GS_HIP(hipMemsetAsync(e->dSs, 0, sizeof(float) * (long)n * h, s));
+      GS_HIP(hipMemsetAsync(e->dAn, 0, sizeof(float) * (long)n * n, s));
+      GS_HIP(hipMemsetAsync(e->dS1, 0, sizeof(float) * (long)n * d, s));
+      GS_HIP(hipMemsetAsync(e->Rmat, 0, sizeof(float) * (long)n * h, s));
+    }
+    const float* Dl2 = Dv + e->oWl;
+    if (Cl > 0) {
+      float* dHp = e->dHp + c0 * n * h; float* A1m = e->A1m + c0 * n * h;
+      // dH1p_c = (A[lo:hi]^T T[lo:hi]) * mask ; gW1_c = S1^T dH1p_c ; gb1_c ; gW2_c = S2[lo:hi]^T G[lo:hi] ; gb2_c = colsum G[lo:hi]
+      gs_gemm_desc a = mk(A, 1, n, e->Tmat, h, 1, dHp, h, n, h, mx);
+      a.nb1 = Cl; a.offA = off_lon; a.offB = off_loF; a.Kb = ncls; a.sCb1 = (long)n * h; a.mask = e->H1s; a.ldmask = h;
+      GS_TRY(gs_gemm_f32(&a, stream));
+      gs_gemm_desc w1 = mk(e->S1, 1, d, dHp, h, 1, gws + e->oW1, h, d, h, n);
+      w1.nb1 = Cl; w1.sBb1 = (long)n * h; w1.sCb1 = P;
+      GS_TRY(gs_gemm_f32(&w1, stream));
+      if (e->cfg.dis_metric != 0) GS_TRY(colsum_batched(e, dHp, (long)n * h, n, nullptr, h, Cl, gws + e->ob1, P, stream));
+      gs_gemm_desc w2 = mk(S2, 1, h, e->Gs, C, 1, gws + e->oWl, C, h, C, mx);
+      w2.nb1 = Cl; w2.offA = off_loF; w2.offB = off_loC; w2.Kb = ncls; w2.sCb1 = P;
+      GS_TRY(gs_gemm_f32(&w2, stream));
+      gs_gemm_desc gb = mk(e->ones, 0, 0, e->Gs, C, 1, gws + e->obl, C, 1, C, mx);
+      gb.nb1 = Cl; gb.offB = off_loC; gb.Kb = ncls; gb.sCb1 = P;
+      GS_TRY(gs_gemm_f32(&gb, stream));
+      float* stats = e->stats + c0 * e->pd.total_cols * 3; float* ab = e->ab + c0 * e->pd.total_cols * 2;
+      if (e->join_pending) { GS_HIP(hipStreamWaitEvent(s, e->ev_join, 0)); e->join_pending = false; }
+      hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, Cl), dim3(256), 0, s, gwr, gws, P, e->pd, stats);
+      hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(Cl), dim3(256), 0, s, stats, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
+                         e->io.syn_hi + c0, n, ab, e->loss_c + c0);
+      hipLaunchKernelGGL(gs_dist_apply_kernel, dim3(gs_cdiv((long)Cl * P, 256)), dim3(256), 0, s, gwr, gws, P, e->pd, ab, Dv, Cl);
+      GS_LAUNCH_CHECK();
+      // A1m_c = (S1 D1_c + Db1_c) * mask ; dS1 slabs_c = dH1p_c D1_c^T ; dA[lo:hi] = T[lo:hi] A1m_c^T ; R[lo:hi] = A[lo:hi] A1m_c
+      gs_gemm_desc m1 = mk(e->S1, d, 1, Dv + e->oW1, h, 1, A1m, h, n, h, d);
+      m1.nb1 = Cl; m1.sBb1 = P; m1.sCb1 = (long)n * h; m1.bias = Dv + e->ob1; m1.sbias_b1 = P; m1.mask = e->H1s; m1.ldmask = h;
+      GS_TRY(gs_gemm_f32(&m1, stream));
+      gs_gemm_desc x = mk(dHp, h, 1, Dv + e->oW1, 1, h, e->slabs_x, d, n, d, h);
+      x.nb1 = Cl; x.sAb1 = (long)n * h; x.sBb1 = P; x.sCb1 = (long)n * d;
+      GS_TRY(gs_gemm_f32(&x, stream));
+      GS_TRY(gs_reduce_slabs_f32(e->dS1, e->slabs_x, (long)n * d, Cl, (long)n * d, 0.f, stream));
+      gs_gemm_desc da = mk(e->Tmat, h, 1, A1m, 1, h, e->dAn, n, mx, n, h);
+      da.nb1 = Cl; da.offA = off_loF; da.Mb = ncls; da.sBb1 = (long)n * h; da.offC = off_lon;
+      GS_TRY(gs_gemm_f32(&da, stream));
+      gs_gemm_desc r = mk(A, n, 1, A1m, h, 1, e->Rmat, h, mx, h, n);
+      r.nb1 = Cl; r.offA = off_lon; r.Mb = ncls; r.sBb1 = (long)n * h; r.offC = off_loF;
+      GS_TRY(gs_gemm_f32(&r, stream));
+      // Ug[lo:hi] = S2[lo:hi] D2_c  (+ R W2 below, + Db2 inside the V kernel)
+      gs_gemm_desc u = mk(S2, h, 1, Dl2, C, 1, e->Ug, C, mx, C, h);
+      u.nb1 = Cl; u.offA = off_loF; u.Mb = ncls; u.sBb1 = P; u.offC = off_loC;
+      GS_TRY(gs_gemm_f32(&u, stream));
+      // dS2[lo:hi] = G[lo:hi] D2_c^T
+      gs_gemm_desc ds = mk(e->Gs, C, 1, Dl2, 1, C, e->dSs, h, mx, h, C);
+      ds.nb1 = Cl; ds.offA = off_loC; ds.Mb = ncls; ds.sBb1 = P; ds.offC = off_loF;
+      GS_TRY(gs_gemm_f32(&ds, stream));
+    } else if (e->join_pending) {
+      GS_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
+      e->join_pending = false;
+    }
+    { gs_gemm_desc g = mk(e->Rmat, h, 1, Wl, C, 1, e->Ug, C, n, C, h); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }   // Ug += R W2
+    hipLaunchKernelGGL(gs_syn_v_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Ps, e->Gs, e->Ug, e->ones, e->D, P, e->obl, bl,
+                       e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->c_lo, e->c_hi, e->Vs, e->drs);
+    GS_LAUNCH_CHECK();
+    { gs_gemm_desc g = mk(e->Vs, C, 1, Wl, 1, C, e->dSs, h, n, h, C); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }    // dS2 += V W2^T
+    { gs_gemm_desc g = mk(e->dSs, h, 1, e->H1s, 1, h, e->dAn, n, n, n, h); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }  // dA += dS2 H1^T
+    { gs_gemm_desc g = mk(A, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n); g.mask = e->H1s; g.ldmask = h; GS_TRY(gs_gemm_f32(&g, stream)); }  // (A^T dS2)*mask
+    { gs_gemm_desc g = mk(e->dH1m, h, 1, W1, 1, h, e->dS1, d, n, d, h); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }   // dS1 += dH1p W1^T
+    { gs_gemm_desc g = mk(e->dS1, d, 1, X, 1, d, e->dAn, n, n, n, d); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }     // dA += dS1 X^T
+    { gs_gemm_desc g = mk(A, 1, n, e->dS1, d, 1, e->d_feat, d, n, d, n); GS_TRY(gs_gemm_f32(&g, stream)); }               // dX = A^T dS1
+    if (e->identity) return GS_OK;
+    return gs_dense_gcn_norm_bwd(e->adj_raw, e->rnorm, e->dAn, n, e->d_adj, stream);
+  }
   {  // Q = A A ; rsq = Q 1
     gs_gemm_desc g = mk(A, n, 1, A, n, 1, e->Q, n, n, n, n);
     GS_TRY(gs_gemm_f32(&g, stream));
@@ -916,6 +1044,26 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
   const float* X = e->io.feat_syn;
   float* th = e->io.model_params;
   const float* A = e->adj_norm_in;
+  if (e->gcn) {   // oracle/analytic.py:gcn_dense_grad
+    { gs_gemm_desc g = mk(A, n, 1, X, d, 1, e->S1, d, n, d, n); GS_TRY(gs_gemm_f32(&g, stream)); }      // S1 = A X: once per outer iteration
+    for (int it = 0; it < e->cfg.inner_loop; ++it) {
+      { gs_gemm_desc g = mk(e->S1, d, 1, th + e->oW1, h, 1, e->H1s, h, n, h, d); g.bias = th + e->ob1; g.relu = 1; GS_TRY(gs_gemm_f32(&g, stream)); }
+      { gs_gemm_desc g = mk(A, n, 1, e->H1s, h, 1, e->S_in, h, n, h, n); GS_TRY(gs_gemm_f32(&g, stream)); }
+      { gs_gemm_desc g = mk(e->S_in, h, 1, th + e->oWl, C, 1, e->Zs, C, n, C, h); GS_TRY(gs_gemm_f32(&g, stream)); }
+      hipLaunchKernelGGL(gs_syn_softmax_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Zs, e->ones, th + e->obl,
+                         e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, (float*)nullptr, e->Gs, 1);
+      GS_LAUNCH_CHECK();
+      { gs_gemm_desc g = mk(e->S_in, 1, h, e->Gs, C, 1, e->g_model + e->oWl, C, h, C, n); GS_TRY(gs_gemm_f32(&g, stream)); }
+      GS_TRY(colsum_batched(e, e->Gs, 0, n, nullptr, C, 1, e->g_model + e->obl, 0, stream));
+      { gs_gemm_desc g = mk(e->Gs, C, 1, th + e->oWl, 1, C, e->dSs, h, n, h, C); GS_TRY(gs_gemm_f32(&g, stream)); }
+      { gs_gemm_desc g = mk(A, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n); g.mask = e->H1s; g.ldmask = h; GS_TRY(gs_gemm_f32(&g, stream)); }
+      { gs_gemm_desc g = mk(e->S1, 1, d, e->dH1m, h, 1, e->g_model + e->oW1, h, d, h, n); GS_TRY(gs_gemm_f32(&g, stream)); }
+      GS_TRY(colsum_batched(e, e->dH1m, 0, n, nullptr, h, 1, e->g_model + e->ob1, 0, stream));
+      GS_TRY(gs_adam_step_f32(th, e->g_model, e->m_model, e->v_model, e->P, e->cfg.lr_model, 0.9f, 0.999f, 1e-8f, 0.f,
+                              ++e->step_model, stream));
+    }
+    return GS_OK;
+  }
   {
     gs_gemm_desc g = mk(A, n, 1, A, n, 1, e->Qin, n, n, n, n);
     GS_TRY(gs_gemm_f32(&g, stream));

@@ -193,6 +193,7 @@ class EngineShapes:
     bcap: int = 256
     f1: int = 10
     f2: int = 5
+    model: str = "SGC"     # condense model: SGC (ntrans transforms) or GCN (two layers)
 
 
 def model_param_count(d, hidden, nclass, ntrans):
@@ -230,14 +231,15 @@ class GCondEngine:
         self.labels_syn = i32(labels_syn)
         self.syn_lo = i32([r[0] for r in syn_ranges])
         self.syn_hi = i32([r[1] for r in syn_ranges])
-        self.P = model_param_count(d, s.hidden, s.nclass, s.ntrans)
+        self.P = model_param_count(d, s.hidden, s.nclass, 2 if s.model == "GCN" else s.ntrans)
         self.Ppge = pge_param_count(d, s.pge_hidden)
         self.feat_syn = torch.zeros(s.n_syn, d, dtype=torch.float32, device=dev)
         self.pge_params = torch.zeros(self.Ppge, dtype=torch.float32, device=dev)
         self.model_params = torch.zeros(self.P, dtype=torch.float32, device=dev)
         self.adj_syn = torch.zeros(s.n_syn, s.n_syn, dtype=torch.float32, device=dev)
         cfg = GCondConfig(s.n_nodes, d, self.ldx, s.nclass, s.n_syn, s.ntrans, s.hidden, s.pge_hidden, s.bcap, s.f1, s.f2,
-                          METRICS[dis_metric], inner_loop, lr_feat, lr_adj, lr_model, seed, 1 if external_blocks else 0)
+                          METRICS[dis_metric], inner_loop, lr_feat, lr_adj, lr_model, seed, 1 if external_blocks else 0,
+                          {"SGC": 0, "GCN": 1}[s.model])
         nbytes = C.c_size_t()
         check(L.gs_gcond_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
         self.workspace_bytes = nbytes.value
@@ -268,7 +270,7 @@ class GCondEngine:
 
     def get_model(self):
         s, d = self.shapes, self.shapes.d
-        shp = [(d, s.nclass), (s.nclass,)] if s.ntrans == 1 else [(d, s.hidden), (s.hidden,), (s.hidden, s.nclass), (s.nclass,)]
+        shp = [(d, s.nclass), (s.nclass,)] if (s.ntrans == 1 and s.model == "SGC") else [(d, s.hidden), (s.hidden,), (s.hidden, s.nclass), (s.nclass,)]
         return _split(self.model_params, shp)
 
     def pge_shapes(self):

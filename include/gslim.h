@@ -181,6 +181,7 @@ typedef struct gs_gcond_config {
   float lr_feat, lr_adj, lr_model;
   uint64_t seed;
   int external_blocks;     /* 1: blocks are supplied with gs_gcond_set_blocks (parity mode)    */
+  int condense_model;      /* 0 = SGC (models/sgc.py), 1 = 2-layer GCN (models/gcn.py): parameters laid out like SGC T = 2 */
 } gs_gcond_config;
 
 typedef struct gs_gcond_io {

@@ -288,3 +288,82 @@ def sgc_dense_grad(theta, Xs, A, labels):
     G = (torch.softmax(S @ W2 + rs[:, None] * b2, 1) - Y) / n
     dHp = ((Q.T @ G) @ W2.T) * (Hp > 0)
     return [Xs.T @ dHp, dHp.sum(0), S.T @ G, rs @ G]
+
+
+# ------------------------------------------------------------------------------------------------
+# GCN as the condense model (models/gcn.py, layers.py:36-51): per layer adj @ (x @ W) + b, ReLU between.
+# Two layers.  Propagate-first: A (X W) = (A X) W, so   S1 = A X,  H1 = relu(S1 W1 + b1),  S2 = A H1,  Z = S2 W2 + b2.
+# ------------------------------------------------------------------------------------------------
+
+
+def real_class_grad_gcn(theta, X, batch, cls):
+    """batch = (B, n_id, [A0 (n1 x n2), A1 (B x n1)]) dense blocks.  Layer i uses adjs[i] (models/base.py:53-54)."""
+    B, n_id, (A0, A1) = batch
+    W1, b1, W2, b2 = theta
+    P0 = A0 @ X[n_id]                       # [n1, d]   (the engine: ELL gather of X rows)
+    H1p = P0 @ W1 + b1
+    H1 = H1p.clamp_min(0)
+    Z = A1 @ (H1 @ W2) + b2
+    G = torch.softmax(Z, 1)
+    G[:, cls] -= 1
+    G /= B
+    dT2 = A1.T @ G                          # [n1, C]
+    dH1p = (dT2 @ W2.T) * (H1p > 0)
+    return [P0.T @ dH1p, dH1p.sum(0), H1.T @ dT2, G.sum(0)]
+
+
+def syn_match_gcn(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="ours"):
+    """Returns (loss, dX, dA) for the 2-layer GCN condense model on the dense normalised A."""
+    W1, b1, W2, b2 = theta
+    S1 = A @ Xs
+    H1p = S1 @ W1 + b1
+    M = (H1p > 0).to(Xs.dtype)
+    H1 = H1p * M
+    S2 = A @ H1
+    P = torch.softmax(S2 @ W2 + b2, 1)
+    loss = torch.zeros((), dtype=Xs.dtype)
+    dA = torch.zeros_like(A)
+    dS1 = torch.zeros_like(S1)
+    dS2 = torch.zeros_like(S2)
+    V = torch.zeros_like(P)
+    for c, (lo, hi) in enumerate(class_ranges):
+        nc = hi - lo
+        if nc == 0:
+            continue
+        G = P[lo:hi].clone()
+        G[:, c] -= 1
+        G /= nc
+        Tc = G @ W2.T                               # [n_c, h]
+        dH1p = (A[lo:hi].T @ Tc) * M                # [n, h]
+        gw = [S1.T @ dH1p, dH1p.sum(0), S2[lo:hi].T @ G, G.sum(0)]
+        l, (D1, Db1, D2, Db2) = match_and_D(metric, gw_real[c], gw)
+        loss = loss + coeffs[c] * l
+        D1, Db1, D2, Db2 = (coeffs[c] * t for t in (D1, Db1, D2, Db2))
+        A1m = (S1 @ D1 + Db1) * M                   # d / d(dH1_c)
+        dS1 = dS1 + dH1p @ D1.T
+        dA[lo:hi] += Tc @ A1m.T
+        Rc = A[lo:hi] @ A1m                         # d / d Tc
+        U = Rc @ W2 + S2[lo:hi] @ D2 + Db2
+        Pc = P[lo:hi]
+        V[lo:hi] = (Pc * U - Pc * (Pc * U).sum(1, keepdim=True)) / nc
+        dS2[lo:hi] = G @ D2.T
+    dS2 = dS2 + V @ W2.T
+    dA = dA + dS2 @ H1.T
+    dH1p_tot = (A.T @ dS2) * M
+    dS1 = dS1 + dH1p_tot @ W1.T
+    dA = dA + dS1 @ Xs.T
+    dX = A.T @ dS1
+    return loss, dX, dA
+
+
+def gcn_dense_grad(theta, Xs, A, labels):
+    n = Xs.shape[0]
+    W1, b1, W2, b2 = theta
+    Y = torch.nn.functional.one_hot(labels, W2.shape[1]).to(Xs.dtype)
+    S1 = A @ Xs
+    H1p = S1 @ W1 + b1
+    H1 = H1p.clamp_min(0)
+    S2 = A @ H1
+    G = (torch.softmax(S2 @ W2 + b2, 1) - Y) / n
+    dH1p = (A.T @ (G @ W2.T)) * (H1p > 0)
+    return [S1.T @ dH1p, dH1p.sum(0), S2.T @ G, G.sum(0)]

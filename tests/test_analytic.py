@@ -114,3 +114,38 @@ def test_inner_model_grad(T):
     got = A.sgc_dense_grad(p["theta"], p["xs"], an, p["labels_syn"])
     for r, g in zip(ref, got):
         np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-13)
+
+
+def test_gcn_condense_model_real_and_inner_grads():
+    p = tiny_problem(2, seed=9)
+    theta = [t.to(DT) for t in O.init_gcn(6, 9, p["nclass"], 2)]
+    for c in range(p["nclass"]):
+        th = [t.clone().requires_grad_(True) for t in theta]
+        ref, _ = O.class_real_grads("GCN", th, p["x"], p["y"], p["batches"][c])
+        got = A.real_class_grad_gcn(theta, p["x"], dense_batch(p["batches"][c]), c)
+        for r, g in zip(ref, got):
+            np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
+    th = [t.clone().requires_grad_(True) for t in theta]
+    an = O.dense_gcn_norm(O.pge_forward(p["xs"], p["pge"]))
+    loss = F.nll_loss(O.gcn_forward(p["xs"], an, th), p["labels_syn"])
+    for r, g in zip(torch.autograd.grad(loss, th), A.gcn_dense_grad(theta, p["xs"], an, p["labels_syn"])):
+        np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize("metric", ["ours", "mse", "cos"])
+def test_gcn_condense_model_second_order(metric):
+    p = tiny_problem(2, seed=13)
+    theta0 = [t.to(DT) for t in O.init_gcn(6, 9, p["nclass"], 2)]
+    theta = [t.clone().requires_grad_(True) for t in theta0]
+    xs = p["xs"].clone().requires_grad_(True)
+    an = O.dense_gcn_norm(O.pge_forward(xs.detach(), p["pge"])).clone().requires_grad_(True)
+    loss = O.train_class("GCN", theta, p["batches"], p["x"], p["y"], xs, an, p["labels_syn"], p["ncd"], p["nclass"], 2, metric)
+    gx, ga = torch.autograd.grad(loss, [xs, an])
+    gw_real = [A.real_class_grad_gcn(theta0, p["x"], dense_batch(p["batches"][c]), c) for c in range(p["nclass"])]
+    ns = len(p["labels_syn"])
+    ranges = [tuple(p["ranges"][c]) for c in range(p["nclass"])]
+    coeffs = [p["ncd"][c] / ns for c in range(p["nclass"])]
+    l, dX, dA = A.syn_match_gcn(theta0, p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric)
+    np.testing.assert_allclose(float(l), float(loss), rtol=1e-10)
+    np.testing.assert_allclose(dX.numpy(), gx.numpy(), rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(dA.numpy(), ga.numpy(), rtol=1e-7, atol=1e-11)

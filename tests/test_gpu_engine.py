@@ -22,9 +22,9 @@ def close(got, ref, rtol=1e-3, what=""):
 
 
 def make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, x, f1, f2, bcap=32, metric="ours", inner=2, lrs=(0.01, 0.01, 0.01),
-                csr=None, pools=None, external=True, seed=1):
+                csr=None, pools=None, external=True, seed=1, model="SGC"):
     from graphslim_amd.engine import EngineShapes, GCondEngine
-    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, ph, bcap, f1, f2)
+    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, ph, bcap, f1, f2, model=model)
     cls_ptr = cls_nodes = None
     if pools is not None:
         cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
@@ -33,7 +33,7 @@ def make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, x, f1, f2, bcap
                        lr_model=lrs[2], inner_loop=inner, dis_metric=metric, seed=seed, external_blocks=external, device=DEV)
 
 
-@pytest.mark.parametrize("tag,metric", [("t1", "ours"), ("t2", "ours"), ("t1mse", "mse")])
+@pytest.mark.parametrize("tag,metric", [("t1", "ours"), ("t2", "ours"), ("t1mse", "mse"), ("gcn", "ours")])
 def test_train_class_against_reference_golden(golden_dir, tag, metric):
     """G7: loss, d loss/d A^, d loss/d X~, d loss/d theta_PGE of the reference's train_class + backward."""
     from graphslim_amd.engine import BlockSet
@@ -44,7 +44,10 @@ def test_train_class_against_reference_golden(golden_dir, tag, metric):
     ranges = [tuple(ranges[c]) for c in range(nclass)]
     ph = g[f"{tag}_pge2"].shape[0]
     f1, f2 = [int(s) for s in g[f"{tag}_sizes"]]
-    eng = make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, metric=metric)
+    kind = "GCN" if tag == "gcn" else "SGC"
+    if kind == "GCN":
+        t = 2
+    eng = make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, metric=metric, model=kind)
     eng.set_feat(T(g[f"{tag}_feat_syn"]))
     eng.set_pge([T(g[f"{tag}_pge{i}"]) for i in range(10)])
     theta = [T(g[f"{tag}_theta{i}"]) for i in range(2 * t)]
@@ -55,8 +58,8 @@ def test_train_class_against_reference_golden(golden_dir, tag, metric):
     gw = eng.buffer("gw_real", (nclass, -1))
     for c in range(nclass):
         th = [p.clone().requires_grad_(True) for p in theta]
-        ref, _ = O.class_real_grads("SGC", th, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), batches[c])
-        if metric == "ours" and t == 2:   # biases get distance 0 and D = 0 under 'ours' (utils.py:98-101): the costly
+        ref, _ = O.class_real_grads(kind, th, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), batches[c])
+        if metric == "ours" and t == 2 and kind == "SGC":   # biases get distance 0 and D = 0 under 'ours' (utils.py:98-101): the costly
             ref[1] = torch.zeros_like(ref[1])   # first-layer bias gradient (a pass over all sampled edges) is not formed
         close(gw[c], torch.cat([r.reshape(-1) for r in ref]), 2e-4, f"gw_real class {c}")
     # PGE forward + norm
@@ -463,3 +466,53 @@ def test_retrieve_class_sampler_contract():
         assert torch.equal(d1[d1 != 0], dense[n_id[:bs]][:, n_id[:n1]][d1 != 0])
         assert torch.equal(d0[d0 != 0], dense[n_id[:n1]][:, n_id][d0 != 0])
         assert int((d1 != 0).sum(1).max()) <= 10 and int((d0 != 0).sum(1).max()) <= 5
+
+
+@pytest.mark.parametrize("metric", ["ours", "mse"])
+def test_gcn_condense_model_follows_the_oracle(metric):
+    """condense_model = GCN (models/gcn.py, layers.py:36-51): three outer iterations per optimiser against the oracle."""
+    from graphslim_amd.engine import BlockSet
+    p = _problem(2, seed=51)
+    torch.manual_seed(5)
+    theta = O.init_gcn(p["d"], p["hidden"], p["nclass"], 2)
+    eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 2, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
+                      p["f2"], bcap=p["bcap"], metric=metric, inner=2, lrs=(0.01, 0.005, 0.02), model="GCN")
+    st = O.GCondState(p["xs"], p["pge"], T(p["labels_syn"]), p["ncd"], p["nclass"], 0.01, 0.005, 0.02, "GCN", 2)
+    eng.set_feat(p["xs"])
+    eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
+    X, Y = T(p["x"]), T(p["y"])
+    step = 0
+    for epoch in (0, 10):
+        st.new_epoch(theta)
+        eng.set_model(theta)
+        for _ in range(3):
+            batches = _batches(p, step)
+            step += 1
+            l_ref, gfeat, gpge, adj_inner = st.outer_iteration(epoch, batches, X, Y, 2, metric)
+            eng.set_blocks(BlockSet.from_batches(batches, p["bcap"], p["f1"], p["f2"], DEV))
+            eng.outer_step(epoch)
+            loss = float(eng.buffer("loss")[0])
+            assert abs(loss - float(l_ref)) <= 1e-4 * abs(float(l_ref)), (epoch, loss, float(l_ref))
+            if epoch % 50 >= 10:
+                close(eng.buffer("d_feat", gfeat.shape), gfeat, 1e-3, "d X~")
+            close(eng.adj_syn.cpu(), adj_inner, 2e-3, "adj_syn after the step")
+        np.testing.assert_allclose(eng.feat_syn.cpu().numpy(), st.feat_syn.detach().numpy(), atol=2e-3)
+        for got, ref in zip(eng.get_model(), st.model):
+            np.testing.assert_allclose(got.cpu().numpy(), ref.detach().numpy(), atol=4e-3)
+
+
+def test_gcn_condense_model_reduce_api(tmp_path):
+    """The Planetoid configs of the sibling methods use condense_model = GCN (configs/doscond/cora.json)."""
+    import graphslim  # noqa: F401
+    from graphslim.config import cli
+    from graphslim.condensation import DosCond
+    from graphslim.dataset import get_dataset
+    from graphslim.evaluation.eval_agent import Evaluator
+    args = cli(["-D", "cora", "-M", "doscond", "-R", "0.5", "-G", "0", "--epochs", "20", "--eval_epochs", "30", "--run_eval", "2",
+                "--save_path", str(tmp_path)], standalone_mode=False)
+    assert args.condense_model == "GCN" and args.dis_metric == "mse" and args.outer_loop == 3
+    args.run_inter_eval = 1
+    graph = get_dataset(args.dataset, args)
+    reduced = DosCond(setting=args.setting, data=graph, args=args).reduce(graph, verbose=False)
+    mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
+    assert mean > 0.5
