@@ -28,6 +28,8 @@ WORKLOADS = {
     # name: (dataset shape, rate, ntrans, hidden, pge_hidden, outer_loop, inner_loop, lr_feat, lr_adj, fan-outs)
     "ogbn-arxiv": ("ogbn-arxiv", 0.005, 2, 256, 256, 20, 3, 0.01, 0.01, (10, 5)),
     "cora": ("cora", 0.5, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
+    # BASELINE.json configs[4]: inductive, train sub-graph, wide rows (d = 602) and fan-outs [15, 8]: the gather stress case
+    "reddit": ("reddit", 0.001, 1, 256, 256, 10, 1, 0.1, 0.1, (15, 8)),
 }
 
 
@@ -40,8 +42,14 @@ def build_problem(name, seed=1, scale=1.0):
     data = TransAndInd(raw, shape)
     labels_train = data.labels_train.numpy()
     labels_syn, ncd, ranges = generate_labels_syn(labels_train, rate)
-    csr = normalize_adj_sparse(data.adj_full)
-    pools = data.class_pools("trans")
+    setting = "ind" if shape in ("reddit", "flickr") else "trans"
+    if setting == "ind":      # gcond.py:25-27: the inductive setting condenses the TRAIN sub-graph
+        csr = normalize_adj_sparse(data.adj_train)
+        data.bench_feat, data.bench_labels, data.bench_n = data.feat_train, data.labels_train, data.feat_train.shape[0]
+    else:
+        csr = normalize_adj_sparse(data.adj_full)
+        data.bench_feat, data.bench_labels, data.bench_n = data.feat_full, data.labels_full, data.num_nodes
+    pools = data.class_pools(setting)
     return dict(data=data, labels_syn=labels_syn, ncd=ncd, ranges=[tuple(ranges[c]) for c in range(data.nclass)], csr=csr,
                 pools=pools, T=T, hidden=hidden, ph=ph, outer=outer, inner=inner, lrf=lrf, lra=lra, fan=fan, rate=rate, name=name)
 
@@ -49,10 +57,10 @@ def build_problem(name, seed=1, scale=1.0):
 def make_engine(p, device, bcap=256):
     from graphslim_amd.engine import EngineShapes, GCondEngine
     d = p["data"].feat_full.shape[1]
-    sh = EngineShapes(p["data"].num_nodes, d, p["data"].nclass, len(p["labels_syn"]), p["T"], p["hidden"], p["ph"], bcap,
+    sh = EngineShapes(p["data"].bench_n, d, p["data"].nclass, len(p["labels_syn"]), p["T"], p["hidden"], p["ph"], bcap,
                       p["fan"][0], p["fan"][1])
     cls_ptr = np.concatenate([[0], np.cumsum([len(q) for q in p["pools"]])])
-    eng = GCondEngine(sh, p["data"].feat_full, p["csr"], cls_ptr, np.concatenate(p["pools"]), p["labels_syn"], p["ranges"],
+    eng = GCondEngine(sh, p["data"].bench_feat, p["csr"], cls_ptr, np.concatenate(p["pools"]), p["labels_syn"], p["ranges"],
                       lr_feat=p["lrf"], lr_adj=p["lra"], lr_model=0.01, inner_loop=p["inner"], seed=1, device=device)
     return eng
 
@@ -62,8 +70,9 @@ def init_state(p, eng, seed=1):
     from graphslim_amd.host import init_pge_params, random_init_indices
     np.random.seed(seed)
     torch.manual_seed(seed)
-    sel = random_init_indices(p["data"].idx_train.numpy(), p["data"].labels_train.numpy(), p["ncd"])
-    eng.set_feat(p["data"].feat_full[sel])
+    ids = p["data"].idx_train.numpy() if p["data"].bench_n == p["data"].num_nodes else np.arange(p["data"].bench_n)
+    sel = random_init_indices(ids, p["data"].labels_train.numpy(), p["ncd"])
+    eng.set_feat(p["data"].bench_feat[sel])
     eng.set_pge(init_pge_params(p["data"].feat_full.shape[1], p["ph"]))
 
 
@@ -183,7 +192,7 @@ def cpu_baseline_child(path):
                       p["data"].nclass, p["lrf"], p["lra"], 0.01, "SGC", 2)
     torch.manual_seed(0)
     st.new_epoch(O.init_sgc(d, p["hidden"], p["data"].nclass, p["T"]))
-    X, Y = p["data"].feat_full, p["data"].labels_full
+    X, Y = p["data"].bench_feat, p["data"].bench_labels
     times = []
     for _ in range(2):
         t0 = time.perf_counter()
@@ -262,7 +271,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped synthetic graph, GCond r={p['rate']}, SGC T={p['T']} h={p['hidden']}, "
                                    f"PGE h={p['ph']}, n'={len(p['labels_syn'])}, seeds/class 256, fan-out {list(p['fan'])}, "
-                                   f"inner_loop {p['inner']}, GPU sampler", "N": int(p['data'].num_nodes),
+                                   f"inner_loop {p['inner']}, GPU sampler", "N": int(p['data'].bench_n),
                        "nnz": int(p['csr'][0][-1]), "scale": args.scale, "mean_match_loss": loss_sum / max(k, 1) / p['data'].nclass,
                        "parallelism": getattr(eng, "parallelism", "single"),
                        "iters_per_sec_with_forward_reuse": round(args.steps / dt_reuse, 3)},
