@@ -175,8 +175,13 @@ struct BGenLoader {
   }
 };
 
+// Occupancy bound: left alone the 128x128 tile compiles to 188 VGPR + 64 AGPR (2 waves/SIMD); asking for 3 brings it to 168
+// registers with a handful of scalar spills and measures 10-16 % faster on the PGE / H1 shapes (tools/ab_occ.py, r01);
+// 4 waves/SIMD spills ~100 registers and is slower again.
+constexpr int gs_min_waves(int bm, int bn) { return bm * bn >= 128 * 128 ? 3 : 1; }
+
 template <int BM, int BN, int WM, int WN, int AMODE, int BMODE, int BK, bool BGEN = false>
-__global__ __launch_bounds__(256) void gs_gemm_f32_kernel(gs_gemm_desc p) {
+__global__ __launch_bounds__(256, gs_min_waves(BM, BN)) void gs_gemm_f32_kernel(gs_gemm_desc p) {
   constexpr int GS_BK = BK;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
