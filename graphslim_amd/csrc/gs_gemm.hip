@@ -328,6 +328,142 @@ __global__ __launch_bounds__(256, gs_min_waves(BM, BN)) void gs_gemm_f32_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Latency-bound shapes (the synthetic-graph side: n' x {d, h, C, n'} with K <= a few thousand).  With 64x64 tiles such a
+// product fills 30-60 of the 256 CUs and every K step pays one global-load latency (~1.5 us): 17-35 us for 30-190 MFLOP.
+// This kernel gives each workgroup ONE 32x32 output tile, splits K four ways over its waves, and lets each wave fetch its
+// MFMA fragments straight from global memory (no LDS staging, no barriers in the K loop) 64 k at a time — 16 loads per
+// operand in flight per lane — so the whole product costs about one memory latency + K/8 MFMAs.  The four partial tiles
+// are summed through LDS in wave order (fixed order: reproducible).  Same k permutation as the tiled kernel
+// (k = 8q + 4*(lane>>5) + t), same epilogue.  Not for gathers along k, generated B or column statistics.
+template <bool VEC>
+__device__ __forceinline__ void small_frag(const float* __restrict__ rowp, long sk, int kb, int w_hi, bool whole, float (&f)[4]) {
+  if (whole) {            // wave-uniform: the q-step lies inside [.., w_hi)
+    if (VEC) {
+      const f32x4u t = *reinterpret_cast<const f32x4u*>(rowp + kb);
+      f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) f[t] = rowp[(long)(kb + t) * sk];
+    }
+  } else {                // the ragged last q-step of the K range: clamped addresses, zero fill
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float x = rowp[(long)min(kb + t, w_hi - 1) * sk];
+      f[t] = (kb + t < w_hi) ? x : 0.f;
+    }
+  }
+}
+
+template <bool AVEC, bool BVEC>
+__global__ __launch_bounds__(256) void gs_gemm_small_kernel(gs_gemm_desc p) {
+  constexpr int QS = 8;   // q-steps (8 k each) per round
+  __shared__ float red[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+  const int b = blockIdx.z, b1 = b / p.nb2, b2 = b - b1 * p.nb2;
+  int M = p.M, K = p.K;
+  if (p.Mb) M = p.Mb[b1];
+  if (p.Kb) K = p.Kb[b1];
+  int k_lo = 0, k_hi = K;
+  if (p.kchunk > 0) {
+    k_lo = b2 * p.kchunk;
+    k_hi = min(K, k_lo + p.kchunk);
+  }
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  if (m0 >= M) return;
+  const float* __restrict__ A = p.A + (long)b1 * p.sAb1 + (p.kchunk > 0 ? 0 : (long)b2 * p.sAb2) + (p.offA ? p.offA[b1] : 0);
+  const float* __restrict__ B = p.B + (long)b1 * p.sBb1 + (p.kchunk > 0 ? 0 : (long)b2 * p.sBb2) + (p.offB ? p.offB[b1] : 0);
+  float* __restrict__ C = p.C + (long)b1 * p.sCb1 + (long)b2 * p.sCb2 + (p.offC ? p.offC[b1] : 0);
+  const int am = min(m0 + li, M - 1), bn = min(n0 + li, p.N - 1);
+  const long arow = p.gatherA_m ? (long)p.gatherA_m[(long)b1 * p.sGb1 + am] : (long)am;
+  const float* __restrict__ ap = A + arow * p.sAm;
+  const float* __restrict__ bp = B + (long)bn * p.sBn;
+
+  // this wave's K range: a quarter of [k_lo, k_hi), in whole q-steps
+  const int per = ((k_hi - k_lo + 31) / 32) * 8;
+  const int w_lo = k_lo + wave * per, w_hi = min(k_hi, w_lo + per);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = w_lo; k0 < w_hi; k0 += 8 * QS) {
+    float a[QS][4], bb[QS][4];
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      const int ks = k0 + 8 * q;
+      if (ks < w_hi) {                       // wave-uniform
+        const bool whole = ks + 8 <= w_hi;
+        small_frag<AVEC>(ap, p.sAk, ks + 4 * kh, w_hi, whole, a[q]);
+        small_frag<BVEC>(bp, p.sBk, ks + 4 * kh, w_hi, whole, bb[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      if (k0 + 8 * q < w_hi) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][t], bb[q][t], acc, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  // wave w finishes accumulator registers r = 4w .. 4w+3: rows m0 + 8w + {0..3} + 4*(lane>>5), column n0 + (lane&31)
+  const int col = n0 + li, colc = min(col, p.N - 1);
+  float bv = 0.f;
+  if (p.bias) bv = p.bias[(long)b1 * p.sbias_b1 + colc];
+  const bool has_mask = p.mask != nullptr, has_beta = p.beta != 0.f;
+  float mk[4], cv[4];
+  const int rbase = m0 + 8 * wave + 4 * kh;
+  if (has_mask) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) mk[rr] = p.mask[(long)min(rbase + rr, M - 1) * p.ldmask + colc];
+  }
+  if (has_beta) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) cv[rr] = C[(long)min(rbase + rr, M - 1) * p.ldc + colc];
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = 4 * wave + rr;
+    const float sum = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+    float v = p.alpha * sum + bv;
+    if (p.relu) v = fmaxf(v, 0.f);
+    if (has_mask) v = (mk[rr] > 0.f) ? v : 0.f;
+    if (has_beta) v += p.beta * cv[rr];
+    const int row = rbase + rr;
+    if (row < M && col < p.N) C[(long)row * p.ldc + col] = v;
+  }
+}
+
+static long g_small_tiles = 1024;      // route to the small kernel when the 32x32 tile count is at most this ...
+static double g_small_gflop = 1.5;     // ... and the product is at most this many GFLOP
+
+extern "C" int gs_gemm_set_small(long max_tiles, double max_gflop) {
+  g_small_tiles = max_tiles;
+  g_small_gflop = max_gflop;
+  return GS_OK;
+}
+
+static bool small_route(const gs_gemm_desc& p, int nbatch) {
+  if (p.bgen_mask || p.colstat || p.gatherA_k || p.gatherB_k) return false;
+  const long t32 = (long)gs_cdiv(p.M, 32) * gs_cdiv(p.N, 32) * nbatch;
+  if (t32 > g_small_tiles) return false;
+  const double keff = p.kchunk > 0 ? (double)p.kchunk : (double)p.K;
+  return 2.0 * p.M * p.N * keff * nbatch <= g_small_gflop * 1e9;
+}
+
+static int launch_small(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
+  dim3 grid(gs_cdiv(p.N, 32), gs_cdiv(p.M, 32), nbatch);
+  const bool av = p.sAk == 1, bv = p.sBk == 1;
+  if (av && bv) hipLaunchKernelGGL((gs_gemm_small_kernel<true, true>), grid, dim3(256), 0, s, p);
+  else if (av) hipLaunchKernelGGL((gs_gemm_small_kernel<true, false>), grid, dim3(256), 0, s, p);
+  else if (bv) hipLaunchKernelGGL((gs_gemm_small_kernel<false, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gs_gemm_small_kernel<false, false>), grid, dim3(256), 0, s, p);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 __global__ void gs_reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slabs, long n, int ns,
                                        long slab_stride, float beta) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,6 +581,7 @@ extern "C" int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream) {
   const int nbatch = p.nb1 * p.nb2;
   if ((long)nbatch > 65535) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: too many batches (%d)", nbatch);
   hipStream_t s = (hipStream_t)stream;
+  if (small_route(p, nbatch)) return launch_small(p, nbatch, s);
   // tile choice: fill the 256 CUs; narrow outputs get the tall/flat tiles
   switch (pick_tile(p, nbatch)) {
     case 0: return launch_gemm<128, 32, 32, 32>(p, nbatch, s);

@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of the GEMM K-tile depth in ONE process (interleaved rounds, median): PGE layer-2 shape, a few small
-synthetic-side shapes, and the whole outer iteration."""
+"""A/B of the latency-bound GEMM routing (gs_gemm_set_small) in ONE process (interleaved rounds, median): synthetic-side
+shapes, correctness of the routed kernel against the tiled one, and the whole outer iteration."""
 import os
 import sys
-import time
 
 import numpy as np
 import torch
@@ -15,6 +14,11 @@ from graphslim_amd.engine import gemm  # noqa: E402
 
 dev = "cuda:0"
 L = _lib.lib()
+CFG = {"off": (0, 0.0), "on": (1024, 1.5)}
+if len(sys.argv) > 1:
+    for a in sys.argv[1:]:
+        t, g = a.split(":")
+        CFG[f"{t}/{g}"] = (int(t), float(g))
 
 
 def timeit(fn, reps=20):
@@ -29,30 +33,43 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-n, ph = 454, 256
-a = torch.randn(n * n, ph, device=dev)
-w = torch.randn(ph, ph, device=dev)
-out = torch.empty(n * n, ph, device=dev)
+n, d, h, C = 454, 128, 256, 40
 A = torch.randn(n, n, device=dev)
-Q = torch.empty(n, n, device=dev)
-X = torch.randn(n, 128, device=dev)
-W1 = torch.randn(128, 256, device=dev)
-H = torch.empty(n, 256, device=dev)
+X = torch.randn(n, d, device=dev)
+W1 = torch.randn(d, h, device=dev)
+W2 = torch.randn(h, C, device=dev)
+H = torch.randn(n, h, device=dev)
+G = torch.randn(n, C, device=dev)
+o_nn, o_nd, o_nh, o_nc, o_hc, o_dh = (torch.empty(*s, device=dev) for s in ((n, n), (n, d), (n, h), (n, C), (h, C), (d, h)))
 shapes = {
-    "pge_l2 206116x256x256 (K,K)": lambda: gemm(a, w, out, n * n, ph, ph, (ph, 1), (1, ph), ph),
-    "dY1    206116x256x256 (K,M)": lambda: gemm(a, w, out, n * n, ph, ph, (ph, 1), (ph, 1), ph),
-    "Q=AA   454x454x454": lambda: gemm(A, A, Q, n, n, n, (n, 1), (n, 1), n),
-    "XW1    454x256x128": lambda: gemm(X, W1, H, n, 256, 128, (128, 1), (256, 1), 256),
-    "QH     454x256x454": lambda: gemm(A, H, out, n, 256, n, (n, 1), (256, 1), 256),
+    "S1=A X      454x128x454 (K,M)": lambda: gemm(A, X, o_nd, n, d, n, (n, 1), (d, 1), d),
+    "H=S1 W1     454x256x128 (K,M)": lambda: gemm(X, W1, o_nh, n, h, d, (d, 1), (h, 1), h),
+    "S2=A H      454x256x454 (K,M)": lambda: gemm(A, H, o_nh, n, h, n, (n, 1), (h, 1), h),
+    "Z=S2 W2     454x40x256  (K,M)": lambda: gemm(H, W2, o_nc, n, C, h, (h, 1), (C, 1), C),
+    "T=G W2^T    454x256x40  (K,K)": lambda: gemm(G, W2, o_nh, n, h, C, (C, 1), (1, C), h),
+    "dA=dS H^T   454x454x256 (K,K)": lambda: gemm(H, H, o_nn, n, n, h, (h, 1), (1, h), n),
+    "dH=A^T dS   454x256x454 (M,M)": lambda: gemm(A, H, o_nh, n, h, n, (1, n), (h, 1), h),
+    "gW2=S^T G   256x40x454  (M,M)": lambda: gemm(H, G, o_hc, h, C, n, (1, h), (C, 1), C),
+    "gW1=S1^T dH 128x256x454 (M,M)": lambda: gemm(X, H, o_dh, d, h, n, (1, d), (h, 1), h),
 }
+# correctness of the routed kernel vs the tiled kernel and vs torch
+for k, fn in shapes.items():
+    outs = []
+    for name in ("off", "on"):
+        _lib.check(L.gs_gemm_set_small(*CFG[name]))
+        fn()
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (o_nn, o_nd, o_nh, o_nc, o_hc, o_dh)])
+    err = max(float((a - b).abs().max() / (a.abs().max() + 1e-30)) for a, b in zip(*outs))
+    print(f"{k}: max rel diff small vs tiled {err:.2e}")
 res = {}
 for rnd in range(3):
-    for bs, bb in ((16, 16), (32, 16), (16, 32), (32, 32)):
-        _lib.check(L.gs_gemm_set_tuning(bs, bb))
+    for name, cfg in CFG.items():
+        _lib.check(L.gs_gemm_set_small(*cfg))
         for k, fn in shapes.items():
-            res.setdefault((k, bs, bb), []).append(timeit(fn))
+            res.setdefault((k, name), []).append(timeit(fn))
 for k in shapes:
-    print(k, {f"small{bs}/big{bb}": round(float(np.median(res[(k, bs, bb)])), 1) for bs, bb in ((16, 16), (32, 16), (16, 32), (32, 32))})
+    print(k, {name: round(float(np.median(res[(k, name)])), 1) for name in CFG})
 
 p = bench.build_problem("ogbn-arxiv")
 eng = bench.make_engine(p, dev)
@@ -60,17 +77,10 @@ bench.init_state(p, eng)
 bench.new_model(p, eng)
 steps = {}
 for rnd in range(3):
-    for bs, bb in ((16, 16), (32, 16), (16, 32), (32, 32)):
-        _lib.check(L.gs_gemm_set_tuning(bs, bb))
+    for name, cfg in CFG.items():
+        _lib.check(L.gs_gemm_set_small(*cfg))
         for ep in (0, 10):
-            steps.setdefault((bs, bb, ep), []).append(timeit(lambda: eng.outer_step(ep), reps=10))
-_lib.check(L.gs_gemm_set_tuning(32, 16))
-ov = {}
-for rnd in range(3):
-    for on in (0, 1):
-        eng.set_overlap(on)
-        for ep in (0, 10):
-            ov.setdefault((on, ep), []).append(timeit(lambda: eng.outer_step(ep), reps=10))
-print("overlap off/on (us):", {f"ep{ep}/ov{on}": round(float(np.median(v)), 0) for (on, ep), v in ov.items()})
+            steps.setdefault((name, ep), []).append(timeit(lambda: eng.outer_step(ep), reps=10))
+_lib.check(L.gs_gemm_set_small(*CFG["on"]))
 for ep in (0, 10):
-    print("outer step us, epoch", ep, {f"small{bs}/big{bb}": round(float(np.median(steps[(bs, bb, ep)])), 0) for bs, bb in ((16, 16), (32, 16), (16, 32), (32, 32))})
+    print("outer step us, epoch", ep, {name: round(float(np.median(steps[(name, ep)])), 0) for name in CFG})

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Compute-only estimate of multi-GPU scaling on ONE GPU: for world in (1, 2, 4, 8) every virtual rank's sharded outer
+iteration (graphslim_amd/parallel.py phases, all-reduce replaced by a no-op) is timed in turn; max over ranks is the
+per-step time the slowest rank would need, without RCCL latency.  Partial sums are not exchanged, so the values are
+meaningless — only the timing is used (no data-dependent control flow in the engine)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from graphslim_amd.parallel import Collective, ShardedGCond  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "ogbn-arxiv"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+p = bench.build_problem(wl, seed=1)
+dev = "cuda:0"
+eng = bench.make_engine(p, dev)
+bench.init_state(p, eng)
+pools = [len(q) for q in p["pools"]]
+
+
+def timed(e):
+    bench.run_steps(p, e, 5, 5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bench.run_steps(p, e, steps, steps)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+base = timed(eng)
+print(f"fused single-GPU outer step: {base:.3f} ms")
+for world in (1, 2, 4, 8):
+    ts = []
+    for r in range(world):
+        sh = ShardedGCond(eng, r, world, pools, Collective(None))
+        bench.init_state(p, eng)
+        ts.append(timed(sh))
+    print(f"world {world}: per-rank ms {[round(t, 3) for t in ts]}  max {max(ts):.3f}  compute-only speed-up {base / max(ts):.2f}x", flush=True)
+eng.set_shard(0, p["data"].nclass, 0, len(p["labels_syn"]))
