@@ -56,7 +56,7 @@ SYMBOLS = [
     "gs_spmm_csr_f32", "gs_gather_rows_f32", "gs_sample_blocks", "gs_dense_gcn_norm_fwd", "gs_dense_gcn_norm_bwd",
     "gs_adam_step_f32", "gs_gcond_workspace_bytes", "gs_gcond_create", "gs_gcond_destroy", "gs_gcond_new_epoch",
     "gs_gcond_set_blocks", "gs_gcond_outer_step", "gs_gcond_outer_step_ex", "gs_gcond_set_identity_structure", "gs_gcond_read_loss", "gs_gcond_stage_sample",
-    "gs_gcond_stage_real_grads", "gs_gcond_stage_pge_forward", "gs_gcond_stage_syn_match",
+    "gs_gcond_stage_real_grads", "gs_gcond_stage_real_async", "gs_gcond_stage_pge_forward", "gs_gcond_stage_syn_match",
     "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer",
     "gs_gcond_get_blocks", "gs_gcond_set_shard", "gs_gcond_set_overlap", "gs_gcond_set_forward_reuse", "gs_gcond_invalidate_forward",
     "gs_gcond_forward_cached", "gs_gcond_adopt_cached_forward", "gs_gcond_stage_pge_forward_part", "gs_gcond_stage_pge_backward_part",
@@ -104,7 +104,7 @@ def lib():
     L.gs_gcond_outer_step_ex.argtypes = [vp, i, i, i, i, vp]
     L.gs_gcond_set_identity_structure.argtypes = [vp, i, vp]
     L.gs_gcond_read_loss.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), vp]
-    for name in ("gs_gcond_stage_sample", "gs_gcond_stage_real_grads", "gs_gcond_stage_syn_match", "gs_gcond_stage_inner"):
+    for name in ("gs_gcond_stage_sample", "gs_gcond_stage_real_grads", "gs_gcond_stage_real_async", "gs_gcond_stage_real_async", "gs_gcond_stage_syn_match", "gs_gcond_stage_inner"):
         getattr(L, name).argtypes = [vp, vp]
     L.gs_gcond_set_shard.argtypes = [vp, i, i, i, i]
     L.gs_gcond_set_overlap.argtypes = [vp, i]

@@ -1133,17 +1133,10 @@ extern "C" int gs_gcond_set_identity_structure(gs_gcond* e, int on, gs_stream_t 
   return GS_OK;
 }
 
-// One outer iteration with the update rule chosen by the caller (the sibling methods share train_class and differ only here):
-//   GCond    (gcond.py:47-72)   : step_pge = epoch%50<10, step_feat = !step_pge, inference + inner steps
-//   DosCond  (doscond.py:40-50) : both optimisers stepped, no inference, no inner steps
-//   GCondX   (gcondx.py:44-66)  : identity structure, feat stepped unless ol%5<1, inner steps on A^ = I
-//   DosCondX (doscondx.py:42-49): identity structure, feat stepped, nothing else
-extern "C" int gs_gcond_outer_step_ex(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner,
-                                      gs_stream_t stream) {
+// Sampling + real-side class gradients of this rank's classes, forked onto the engine's second stream when overlap is on
+// (the join is taken by the first stage that reads gw_real); also samples the NEXT iteration's blocks behind them.
+extern "C" int gs_gcond_stage_real_async(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
-  if (sharded_c(e) || sharded_r(e))
-    GS_FAIL(GS_ERR_STATE, "gs_gcond_outer_step: a sharded engine is driven stage by stage with all-reduces in between (graphslim_amd/parallel.py)");
-  if (e->identity) { step_pge = 0; run_inference = 0; }
   if (e->overlap) {
     hipStream_t s = (hipStream_t)stream;
     GS_HIP(hipEventRecord(e->ev_fork, s));
@@ -1160,6 +1153,21 @@ extern "C" int gs_gcond_outer_step_ex(gs_gcond* e, int step_pge, int step_feat, 
     GS_TRY(gs_gcond_stage_sample(e, stream));
     GS_TRY(gs_gcond_stage_real_grads(e, stream));
   }
+  return GS_OK;
+}
+
+// One outer iteration with the update rule chosen by the caller (the sibling methods share train_class and differ only here):
+//   GCond    (gcond.py:47-72)   : step_pge = epoch%50<10, step_feat = !step_pge, inference + inner steps
+//   DosCond  (doscond.py:40-50) : both optimisers stepped, no inference, no inner steps
+//   GCondX   (gcondx.py:44-66)  : identity structure, feat stepped unless ol%5<1, inner steps on A^ = I
+//   DosCondX (doscondx.py:42-49): identity structure, feat stepped, nothing else
+extern "C" int gs_gcond_outer_step_ex(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner,
+                                      gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  if (sharded_c(e) || sharded_r(e))
+    GS_FAIL(GS_ERR_STATE, "gs_gcond_outer_step: a sharded engine is driven stage by stage with all-reduces in between (graphslim_amd/parallel.py)");
+  if (e->identity) { step_pge = 0; run_inference = 0; }
+  GS_TRY(gs_gcond_stage_real_async(e, stream));
   if (!e->identity) {
     if (e->reuse_fwd && e->fwd_cached)
       GS_TRY(adopt_cached_forward(e, stream));

@@ -314,6 +314,9 @@ class GCondEngine:
     def stage_real_grads(self):
         check(self.L.gs_gcond_stage_real_grads(self.h, stream()))
 
+    def stage_real_async(self):
+        check(self.L.gs_gcond_stage_real_async(self.h, stream()))
+
     def stage_pge_forward(self, inference=False):
         check(self.L.gs_gcond_stage_pge_forward(self.h, int(inference), stream()))
 

@@ -83,7 +83,7 @@ class ShardedGCond:
             return [(lambda: e.pge_forward_part(inference, 1), "ar_bn2"), (lambda: e.pge_forward_part(inference, 2), "e3"),
                     (lambda: e.pge_forward_part(inference, 3), None)]
 
-        ph = [(e.stage_sample, None), (e.stage_real_grads, None)]
+        ph = [(e.stage_real_async, None)]      # second stream: overlaps the PGE forward and its two exchanges
         ph += [(e.adopt_cached_forward, None)] if e.forward_cached() else fwd(False)
         ph += [(e.stage_syn_match, "ar_syn"), (e.syn_finish, None),
                (lambda: e.pge_backward_part(np_, nf, 1), "ar_l3"),

@@ -244,6 +244,9 @@ int gs_gcond_read_loss(gs_gcond* e, double* loss_sum, long* steps, gs_stream_t s
  * stage can be checked against the oracle in isolation. */
 int gs_gcond_stage_sample(gs_gcond* e, gs_stream_t stream);
 int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream);
+/* stage_sample + stage_real_grads forked onto the engine's second stream (when overlap is on; otherwise run in line), plus
+ * the prefetch of the next iteration's blocks; the stage that first reads the real-side gradients joins it. */
+int gs_gcond_stage_real_async(gs_gcond* e, gs_stream_t stream);
 int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_t stream);
 int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream);
 int gs_gcond_stage_pge_backward(gs_gcond* e, int need_param_grads, int need_feat_grad, gs_stream_t stream);

@@ -59,6 +59,7 @@ class FakeEngine:
 
     def stage_sample(self): self.calls.append("sample")
     def stage_real_grads(self): self.calls.append("real")
+    def stage_real_async(self): self.calls.extend(["sample", "real"])
     def pge_forward_part(self, inf, part):
         self.calls.append(f"fwd{int(inf)}{part}")
         if part == 1: self._fill("ar_bn2")
