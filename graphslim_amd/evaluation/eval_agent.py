@@ -6,6 +6,7 @@ from tqdm import trange
 from ..dataset.utils import get_syn_data
 from ..host import seed_everything
 from ..models.gcn import GCN
+from ..parallel import RowShard, RunShard, active_dist
 
 _MODELS = {"GCN": GCN}
 
@@ -39,19 +40,28 @@ class Evaluator:
         args = self.args
         if reduced:
             data.feat_syn, data.adj_syn, data.labels_syn = get_syn_data(data, args, model_type=model_type, verbose=verbose)
+        # multi-GPU (one process per GPU under torch.distributed): the seeded runs are sharded over the ranks
+        # (args.eval_parallel = "runs", default) or every run row-shards its full-graph passes (= "rows")
+        dist = active_dist()
+        by_rows = dist is not None and getattr(args, "eval_parallel", "runs") == "rows"
+        if by_rows:
+            args.eval_row_shard = RowShard(dist)
+        shard = RunShard(None if by_rows else dist)
+        mine = shard.mine(args.run_eval)
         if verbose:
             print(f"Evaluating reduced data using {model_type}")
-            runs = trange(args.run_eval)
+            runs = trange(len(mine))
         else:
-            runs = range(args.run_eval)
-        res = []
-        for i in runs:
+            runs = range(len(mine))
+        res = {}
+        for k in runs:
+            i = mine[k]
             seed_everything(args.seed + i)
             _, acc = self.test(data, model_type=model_type, verbose=args.verbose, reduced=reduced, mode=mode)
-            res.append(acc)
+            res[i] = acc
             if verbose:
                 runs.set_postfix(test_acc=acc)
-        res = np.array(res)
+        res = shard.combine(args.run_eval, res, self.device if dist is not None and str(self.device).startswith("cuda") else "cpu")
         msg = f"Seed:{args.seed}, Test Mean Accuracy: {100 * res.mean():.2f} +/- {100 * res.std():.2f}"
         if hasattr(args, "logger"):
             args.logger.info(msg)

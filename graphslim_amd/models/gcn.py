@@ -16,15 +16,52 @@ from .._lib import check, ptr, stream
 from ..engine import adam_step, dense_gcn_norm_fwd, gemm, spmm_csr
 
 
-def _dev_csr(adj, device):
-    """normalize_adj_tensor(adj, sparse=True) (utils.py:403-413) -> device CSR of the normalised matrix."""
-    rp, col, val = host.normalize_adj_sparse(adj)
-    i32 = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int32).to(device)
-    return i32(rp), i32(col), torch.as_tensor(val, dtype=torch.float32).to(device)
+def _i32(a, device):
+    return torch.as_tensor(np.asarray(a), dtype=torch.int32).to(device)
 
 
 def _pad4(n):
     return (n + 3) // 4 * 4
+
+
+class DeviceGraph:
+    """One evaluation graph resident in HBM, prepared once per (split, device):
+
+      * the normalised adjacency A^ = D^-1/2 (A + I) D^-1/2 (normalize_adj_tensor(sparse=True), utils.py:403-413) as CSR,
+        restricted to this rank's row block [lo, hi) when the evaluation is row-sharded;
+      * S = A^ X for those rows.  X never changes while a model is evaluated, so layer 1 of the reference's GCN,
+        A^ (X W1) + b1, is computed as S W1 + b1: the width-h full-graph SpMM of every epoch becomes one width-d SpMM per
+        graph (same value up to fp32 re-association);
+      * for every target set (validation / test rows) the CSR of just those rows, so the last aggregation of an epoch
+        only produces the rows whose accuracy is read.
+    """
+
+    def __init__(self, feat, adj, device, lo=0, hi=None):
+        rp, col, val = host.normalize_adj_sparse(adj)
+        self.n = len(rp) - 1
+        self.lo, self.hi = lo, self.n if hi is None else hi
+        self.device = device
+        self._norm = sp.csr_matrix((val, col, rp), shape=(self.n, self.n))
+        d = feat.shape[1]
+        X = torch.zeros(self.n, _pad4(d), device=device)
+        X[:, :d] = feat.to(device, torch.float32)
+        loc = self._norm[self.lo:self.hi]
+        csr = (_i32(loc.indptr, device), _i32(loc.indices, device), torch.as_tensor(loc.data, dtype=torch.float32).to(device))
+        self.S = spmm_csr(*csr, X)                    # [hi - lo, pad4(d)]
+        self._targets = {None: (csr, self.hi - self.lo)}
+
+    def target(self, idx):
+        """CSR of the target rows `idx` (global ids; None = all rows) that fall into this rank's block, cached."""
+        key = None if idx is None else id(idx)
+        if key not in self._targets:
+            ids = np.asarray(idx.cpu() if isinstance(idx, torch.Tensor) else idx)
+            mine = ids[(ids >= self.lo) & (ids < self.hi)]
+            sub = self._norm[mine]
+            csr = (_i32(sub.indptr, self.device), _i32(sub.indices, self.device),
+                   torch.as_tensor(sub.data, dtype=torch.float32).to(self.device))
+            # the idx object is kept in the entry so that its id() cannot be recycled while the cache lives
+            self._targets[key] = (csr, len(mine), torch.as_tensor((ids >= self.lo) & (ids < self.hi)), idx)
+        return self._targets[key]
 
 
 class GCN:
@@ -52,6 +89,9 @@ class GCN:
         self.sizes = [nfeat * nhid, nhid, nhid * nclass, nclass]
         self.P = torch.zeros(sum(self.sizes), dtype=torch.float32, device=self.device)
         self.ldc = _pad4(nclass)
+        # row-block sharding of the full-graph passes (parallel.RowShard); a single-GPU run owns every row
+        from ..parallel import RowShard
+        self.shard = getattr(args, "eval_row_shard", None) or RowShard()
         self.initialize()
 
     # -- parameters -----------------------------------------------------------------------------------
@@ -86,21 +126,24 @@ class GCN:
         return self
 
     # -- forward passes -------------------------------------------------------------------------------
-    def _forward_sparse(self, X, csr):
-        """Full graph: Z = A (relu(A (X W1) + b1) W2) + b2.  X [N, ld] (row stride may be padded)."""
+    def _forward_graph(self, G, idx=None):
+        """Full graph: Z = A^ (relu(S W1 + b1) W2) + b2 on the target rows `idx` (None = every row); S = A^ X is cached
+        in `G`.  Returns logits [n_target, ldc] (row stride ldc >= nclass)."""
         W1, b1, W2, b2 = self.parameters()
-        N, d, h, Cn, ldc = X.shape[0], self.nfeat, self.nhid, self.nclass, self.ldc
+        d, h, Cn, ldc = self.nfeat, self.nhid, self.nclass, self.ldc
         dev = self.device
-        T1 = torch.empty(N, h, device=dev)
-        gemm(X, W1, T1, N, h, d, (X.stride(0), 1), (h, 1), h)
-        H = spmm_csr(*csr, T1)
-        check(_lib.lib().gs_bias_act_f32(ptr(H), h, ptr(b1), N, h, 1, stream()))
-        T2 = torch.zeros(N, ldc, device=dev)
-        gemm(H, W2, T2, N, Cn, h, (h, 1), (Cn, 1), ldc)
-        Z = torch.zeros(N, ldc, device=dev)
-        spmm_csr(*csr, T2, F=ldc, out=Z)
-        check(_lib.lib().gs_bias_act_f32(ptr(Z), ldc, ptr(b2), N, Cn, 0, stream()))
-        return Z      # logits, row stride ldc
+        nl = G.S.shape[0]
+        H = torch.empty(nl, h, device=dev)
+        gemm(G.S, W1, H, nl, h, d, (G.S.stride(0), 1), (h, 1), h, bias=b1, relu=1)
+        T2 = torch.zeros(nl, ldc, device=dev)
+        gemm(H, W2, T2, nl, Cn, h, (h, 1), (Cn, 1), ldc)
+        T2 = self.shard.all_gather_rows(T2, G.n, G.blocks)          # identity on one GPU
+        tgt = G.target(idx)
+        Z = torch.zeros(tgt[1], ldc, device=dev)
+        if tgt[1] > 0:
+            spmm_csr(*tgt[0], T2, F=ldc, out=Z)
+            check(_lib.lib().gs_bias_act_f32(ptr(Z), ldc, ptr(b2), tgt[1], Cn, 0, stream()))
+        return Z
 
     def _train_step_dense(self, X, A, labels_i32, opt):
         """One optimisation step on the condensed graph (models/base.py:156-161) with dense A^ [n, n]."""
@@ -138,24 +181,36 @@ class GCN:
     def _new_opt(self, lr):
         return {"m": torch.zeros_like(self.P), "v": torch.zeros_like(self.P), "step": 0, "lr": lr}
 
-    def _accuracy(self, Z, idx_i32, labels_i32):
+    def _accuracy(self, Z, labels_i32, n_total):
+        """Correct predictions among this rank's target rows (rows of Z), summed over ranks, over the global count."""
         cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
         n = labels_i32.numel()
-        check(_lib.lib().gs_count_correct(ptr(Z), Z.stride(0), self.nclass, ptr(idx_i32), ptr(labels_i32), n, ptr(cnt), stream()))
-        return int(cnt.item()) / n
+        if n > 0:
+            check(_lib.lib().gs_count_correct(ptr(Z), Z.stride(0), self.nclass, None, ptr(labels_i32), n, ptr(cnt), stream()))
+        return int(self.shard.all_reduce_sum(cnt).item()) / n_total
 
     # -- reference API ----------------------------------------------------------------------------------
     def _graph_for(self, data, which):
-        """Device copies (cached on the data object) of a split's features and normalised CSR."""
+        """DeviceGraph of a split (cached on the data object per device and row block)."""
         cache = data.__dict__.setdefault("_gs_dev", {})
-        key = (which, str(self.device))
+        feat, adj = getattr(data, f"feat_{which}"), getattr(data, f"adj_{which}")
+        lo, hi = self.shard.row_block(adj)
+        key = (which, str(self.device), lo, hi)
         if key not in cache:
-            feat = {"full": data.feat_full, "val": data.feat_val, "test": data.feat_test, "train": data.feat_train}[which]
-            adj = {"full": data.adj_full, "val": data.adj_val, "test": data.adj_test, "train": data.adj_train}[which]
-            X = torch.zeros(feat.shape[0], _pad4(feat.shape[1]), device=self.device)
-            X[:, :feat.shape[1]] = feat.to(self.device, torch.float32)
-            cache[key] = (X, _dev_csr(adj, self.device))
+            cache[key] = DeviceGraph(feat, adj, self.device, lo, hi)
+            cache[key].blocks = self.shard.blocks(adj) if self.shard.world > 1 else [(0, adj.shape[0])]
         return cache[key]
+
+    def _targets(self, G, idx, labels):
+        """(idx, int32 labels of the target rows this rank owns, global target count)."""
+        labels = torch.as_tensor(labels)
+        n_total = labels.numel()
+        if self.shard.world > 1:
+            if idx is None:
+                labels = labels[G.lo:G.hi]
+            else:
+                labels = labels[G.target(idx)[2]]
+        return idx, labels.to(self.device).to(torch.int32), n_total
 
     def fit_with_val(self, data, train_iters=600, verbose=False, normadj=True, setting="trans", reduced=False,
                      final_output=False, best_val=None, **kwargs):
@@ -168,15 +223,13 @@ class GCN:
         adj = torch.as_tensor(data.adj_syn).to(dev, torch.float32).contiguous()
         feat = torch.as_tensor(data.feat_syn).to(dev, torch.float32).contiguous()
         labels = torch.as_tensor(data.labels_syn).to(dev).to(torch.int32)
-        if normadj or True:          # base.py:112 normalises the (dense) synthetic adjacency unconditionally
-            adj, _ = dense_gcn_norm_fwd(adj)
-        labels_val = data.labels_val.to(dev).to(torch.int32)
+        adj, _ = dense_gcn_norm_fwd(adj)          # base.py:112 normalises the (dense) synthetic adjacency unconditionally
         if setting == "ind":
-            Xv, csr = self._graph_for(data, "val")
-            idx_val = None
+            G = self._graph_for(data, "val")
+            idx_val, labels_val, n_val = self._targets(G, None, data.labels_val)
         else:
-            Xv, csr = self._graph_for(data, "full")
-            idx_val = data.idx_val.to(dev).to(torch.int32)
+            G = self._graph_for(data, "full")
+            idx_val, labels_val, n_val = self._targets(G, data.idx_val, data.labels_val)
         best_acc = 0 if best_val is None else best_val
         weights = None
         opt = self._new_opt(self.lr)
@@ -186,7 +239,7 @@ class GCN:
             lossr = self._train_step_dense(feat, adj, labels, opt)
             if verbose and i % 100 == 0:
                 print("Epoch {}, training loss: {}".format(i, float(lossr.mean())))
-            acc_val = self._accuracy(self._forward_sparse(Xv, csr), idx_val, labels_val)
+            acc_val = self._accuracy(self._forward_graph(G, idx_val), labels_val, n_val)
             if acc_val > best_acc:
                 best_acc = acc_val
                 weights = self.state_dict()
@@ -199,29 +252,27 @@ class GCN:
     @torch.no_grad()
     def test(self, data, setting="trans", verbose=False):
         """models/base.py:190-215."""
-        dev = self.device
-        labels_test = torch.as_tensor(data.labels_test).to(dev).to(torch.int32)
         if setting == "ind":
-            X, csr = self._graph_for(data, "test")
-            idx = None
+            G = self._graph_for(data, "test")
+            idx, labels_test, n = self._targets(G, None, data.labels_test)
         else:
-            X, csr = self._graph_for(data, "full")
-            idx = data.idx_test.to(dev).to(torch.int32)
-        Z = self._forward_sparse(X, csr)
-        acc = self._accuracy(Z, idx, labels_test)
+            G = self._graph_for(data, "full")
+            idx, labels_test, n = self._targets(G, data.idx_test, data.labels_test)
+        acc = self._accuracy(self._forward_graph(G, idx), labels_test, n)
         if verbose:
             print("Test set results:", "accuracy= {:.4f}".format(acc))
         return acc
 
     @torch.no_grad()
     def predict(self, features=None, adj=None, normadj=True, output_layer_features=False):
-        """models/base.py:218-225: log-probabilities [N, C] for a (features, scipy adjacency) pair."""
-        dev = self.device
-        X = torch.zeros(features.shape[0], _pad4(features.shape[1]), device=dev)
-        X[:, :features.shape[1]] = torch.as_tensor(features).to(dev, torch.float32)
+        """models/base.py:218-225: log-probabilities [N, C] for a (features, scipy adjacency) pair (this rank's row block
+        when the evaluation is row-sharded)."""
         if not sp.issparse(adj):
             raise NotImplementedError("graphslim_amd.GCN.predict expects a scipy sparse adjacency")
-        Z = self._forward_sparse(X, _dev_csr(adj, dev))
-        out = torch.empty(Z.shape[0], self.nclass, device=dev)
+        lo, hi = self.shard.row_block(adj)
+        G = DeviceGraph(torch.as_tensor(features), adj, self.device, lo, hi)
+        G.blocks = self.shard.blocks(adj) if self.shard.world > 1 else [(0, adj.shape[0])]
+        Z = self._forward_graph(G)
+        out = torch.empty(Z.shape[0], self.nclass, device=self.device)
         check(_lib.lib().gs_log_softmax_f32(ptr(Z), Z.stride(0), Z.shape[0], self.nclass, ptr(out), self.nclass, stream()))
         return out

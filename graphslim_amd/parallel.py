@@ -101,6 +101,98 @@ class ShardedGCond:
                 self.col.allreduce(self.v[buf])
 
 
+class RowShard:
+    """Row-block sharding of a full-graph pass (SURVEY.md §8e "mode F": the evaluation GCN's per-epoch full-graph forward,
+    models/base.py:168-173).  Rank r owns the contiguous row block [lo, hi) of the normalised adjacency, balanced by
+    non-zeros.  Per forward there is ONE exchange: an all-gather of the [N, C] second-layer operand (the first layer is
+    local because S = A^ X is precomputed per row block); accuracies are an all-reduce(sum) of correct counts.  Rows are
+    computed by the same kernels in the same order as on one GPU, so a sharded forward is bit-identical to the unsharded
+    one.  `dist` = torch.distributed (nccl = RCCL on GPUs, gloo in the CPU tests); None = single process."""
+
+    def __init__(self, dist=None, group=None):
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if dist is not None else 1
+        self.rank = dist.get_rank(group) if dist is not None else 0
+        self._blocks = {}
+
+    @staticmethod
+    def split_rows(rowptr, world):
+        """Contiguous row blocks with balanced non-zero counts: [(lo, hi)] * world, covering every row exactly once."""
+        rowptr = np.asarray(rowptr, dtype=np.int64)
+        n, nnz = len(rowptr) - 1, int(rowptr[-1])
+        cuts = [0]
+        for r in range(1, world):
+            t = nnz * r / world
+            c = int(np.searchsorted(rowptr, t, side="left"))
+            if c > 0 and t - rowptr[c - 1] < rowptr[min(c, n)] - t:
+                c -= 1
+            cuts.append(min(max(c, cuts[-1]), n))
+        cuts.append(n)
+        return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+    def blocks(self, adj):
+        key = id(adj)
+        if key not in self._blocks:
+            a = adj.tocsr()
+            self._blocks[key] = (self.split_rows(a.indptr + np.arange(a.shape[0] + 1), self.world), adj)   # + self loops
+        return self._blocks[key][0]
+
+    def row_block(self, adj):
+        if self.world == 1:
+            return 0, adj.shape[0]
+        return self.blocks(adj)[self.rank]
+
+    def all_gather_rows(self, local, n, blocks):
+        """[hi - lo, ld] row blocks of every rank -> [n, ld] on every rank (blocks padded to the largest, one collective)."""
+        if self.world == 1:
+            return local
+        cap = max(hi - lo for lo, hi in blocks)
+        send = local.new_zeros(cap, local.shape[1])
+        send[: local.shape[0]] = local
+        recv = local.new_empty(self.world * cap, local.shape[1])
+        self.dist.all_gather_into_tensor(recv, send, group=self.group)
+        out = local.new_empty(n, local.shape[1])
+        for r, (lo, hi) in enumerate(blocks):
+            out[lo:hi] = recv[r * cap: r * cap + (hi - lo)]
+        return out
+
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+class RunShard:
+    """The `run_eval` seeded evaluation runs of Evaluator.evaluate (eval_agent.py:266-283) are independent: run i goes
+    to rank i % world; the per-run accuracies are combined with one all-reduce(sum) of a zero-filled vector, so every
+    rank returns the same mean / std as a single-GPU evaluation (same seeds, same per-run arithmetic)."""
+
+    def __init__(self, dist=None, group=None):
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group) if dist is not None else 1
+        self.rank = dist.get_rank(group) if dist is not None else 0
+
+    def mine(self, n_runs):
+        return [i for i in range(n_runs) if i % self.world == self.rank]
+
+    def combine(self, n_runs, results, device="cpu"):
+        """results: {run index: value} of this rank's runs -> float64 vector of all runs on every rank."""
+        v = torch.zeros(n_runs, dtype=torch.float64, device=device)
+        for i, r in results.items():
+            v[i] = r
+        if self.world > 1:
+            self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM, group=self.group)
+        return v.cpu().numpy()
+
+
+def active_dist():
+    """torch.distributed if a multi-rank process group is initialised, else None."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
 def make_engine(p, dev, rank, world):
     """bench.py entry: this rank's sharded engine over torch.distributed (process group already initialised)."""
     import torch.distributed as dist

@@ -489,7 +489,112 @@ def g8():
     save("g8_reduce", **out)
 
 
+# ---------------------------------------------------------------- G9 fit_with_val trace --------
+
+
+def g9():
+    """models/base.py:80-225: GCN(mode='eval').fit_with_val(reduced=True) + test, transductive and inductive, with the
+    per-epoch validation accuracies captured through the model's metric hook."""
+    out = {}
+    n, nclass, d, hidden, ns, iters = 120, 4, 10, 16, 12, 40
+    a, x, y = make_graph(n, nclass, d, 6, seed=91)
+    data = FakeData(a, x, y, nclass, [6, 8, 10, 12], 30, 40, seed=9)
+    rng = np.random.default_rng(5)
+    pick = rng.permutation(len(data.idx_train))[:ns]
+    feat_syn = data.feat_train[pick].clone() + 0.1 * torch.from_numpy(rng.normal(size=(ns, d)).astype(np.float32))
+    labels_syn = data.labels_train[pick].clone()
+    raw = rng.random((ns, ns)).astype(np.float32)
+    adj_syn = torch.from_numpy((raw + raw.T) / 2)
+    adj_syn[adj_syn < 0.35] = 0
+    adj_syn.fill_diagonal_(0)
+    data.feat_syn, data.adj_syn, data.labels_syn = feat_syn, adj_syn, labels_syn
+    coo = a.tocoo()
+    out.update(a_row=coo.row, a_col=coo.col, x=x, y=y, idx_train=np_(data.idx_train), idx_val=np_(data.idx_val),
+               idx_test=np_(data.idx_test), feat_syn=np_(feat_syn), adj_syn=np_(adj_syn), labels_syn=np_(labels_syn),
+               meta=np.array([n, nclass, d, hidden, ns, iters]))
+    for setting in ("trans", "ind"):
+        args = args_obj(hidden=hidden, setting=setting, lr=0.01, weight_decay=0.0, dropout=0.0)
+        RU.seed_everything(7)
+        model = GCN(d, hidden, nclass, args, mode="eval")
+        accs, inits = [], []
+        base_metric = model.metric
+
+        def metric(o, l):
+            v = base_metric(o, l)
+            accs.append(float(v))
+            return v
+
+        model.metric = metric
+        base_init = model.initialize
+
+        def init_spy():
+            base_init()
+            inits.append([np_(p).copy() for p in model.parameters()])
+
+        model.initialize = init_spy
+        best = model.fit_with_val(data, train_iters=iters, normadj=True, verbose=False, setting=setting, reduced=True)
+        acc_test = model.test(data, setting=setting, verbose=False)
+        out[f"{setting}_val_trace"] = np.array(accs[:iters])
+        out[f"{setting}_best"] = np.array(best)
+        out[f"{setting}_test"] = np.array(float(acc_test))
+        for i, w in enumerate(inits[-1]):
+            out[f"{setting}_init{i}"] = w
+        for i, w in enumerate(model.parameters()):
+            out[f"{setting}_final{i}"] = np_(w)
+    save("g9_fit_with_val", **out)
+
+
+# ---------------------------------------------------------------- G10 sparsify + file layout ---
+
+
+def g10():
+    """dataset/utils.py:8-66 (sparsify) and :136-258 (save_reduced / load_reduced incl. the missing-file fall-backs)."""
+    out = {}
+    rng = np.random.default_rng(3)
+    raw = rng.random((9, 9)).astype(np.float32)
+    adj = (raw + raw.T) / 2
+    np.fill_diagonal(adj, 0)
+    out["adj"] = adj
+    cases = [("GCN", "gcond", "cora", 0.05), ("GCN", "gcond", "ogbn-arxiv", 0.5), ("GCN", "doscond", "cora", 0.6),
+             ("GCN", "gcondx", "cora", 0.5), ("MLP", "gcond", "cora", 0.5), ("GAT", "gcond", "cora", 0.05),
+             ("GAT", "gcond", "flickr", 0.05), ("GAT", "msgc", "cora", 0.45), ("GAT", "kcenter", "cora", 0.05),
+             ("SGC", "gcond", "cora", 0.0)]
+    out["cases"] = np.array(["|".join(map(str, c)) for c in cases])
+    for i, (mt, method, ds, thr) in enumerate(cases):
+        args = args_obj(method=method, dataset=ds, threshold=thr)
+        out[f"sparsify{i}"] = np_(sparsify(mt, torch.from_numpy(adj.copy()), args, verbose=False))
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    try:
+        n, nclass, d = 60, 3, 5
+        a, x, y = make_graph(n, nclass, d, 4, seed=17)
+        data = FakeData(a, x, y, nclass, [5, 6, 7], 10, 20, seed=2)
+        args = args_obj(method="gcond", dataset="cora", reduction_rate=0.25, seed=3, save_path=tmp, logger=CapLogger())
+        feat = torch.from_numpy(rng.normal(size=(9, d)).astype(np.float32))
+        lab = torch.from_numpy(rng.integers(0, nclass, 9))
+        save_reduced(torch.from_numpy(adj), feat, lab, args)
+        files = []
+        for root, _, fs in os.walk(tmp):
+            files += [os.path.relpath(os.path.join(root, f), tmp) for f in fs]
+        out["files"] = np.array(sorted(files))
+        la, lf, ll = load_reduced(args, data)
+        out["loaded_adj"], out["loaded_feat"], out["loaded_label"] = np_(la), np_(lf), np_(ll)
+        out["loaded_dtypes"] = np.array([str(la.dtype), str(lf.dtype), str(ll.dtype)])
+        # missing files: every part falls back independently
+        args2 = args_obj(method="gcond", dataset="cora", reduction_rate=0.125, seed=3, save_path=tmp, logger=CapLogger())
+        ma, mf, ml = load_reduced(args2, data)
+        out["missing_adj_is_eye"] = np.array(bool(torch.equal(ma.cpu(), torch.eye(mf.shape[0]))))
+        out["missing_feat_shape"] = np.array(mf.shape)
+        out["missing_label"] = np_(ml)
+        args3 = args_obj(method="gcond", dataset="cora", reduction_rate=0.125, seed=3, save_path=tmp, logger=CapLogger(),
+                         setting="ind")
+        _, mf3, _ = load_reduced(args3, data)
+        out["missing_feat_shape_ind"] = np.array(mf3.shape)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    save("g10_files", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

@@ -1,4 +1,6 @@
 """Host-side product logic (graphslim_amd/host.py, dataset/) against the reference golden vectors.  CPU only."""
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -64,3 +66,37 @@ def test_dataset_shaped_generators_and_contract():
     assert data.nclass == 40 and data.feat_full.shape[1] == 128
     ls, ncd, _ = H.generate_labels_syn(data.labels_train.numpy(), 0.05)
     assert len(ls) >= 40
+
+
+def test_g10_sparsify_and_reduced_graph_files(golden_dir, tmp_path):
+    """dataset/utils.py:8-66,136-258 of the reference vs graphslim_amd.dataset.utils: thresholds per (model, method,
+    dataset), file names / dtypes of the saved condensed graph, and the independent fall-backs of load_reduced."""
+    import logging
+    from types import SimpleNamespace
+    from helpers import load_golden
+    from graphslim_amd.dataset import utils as DU
+    g = load_golden(golden_dir, "g10_files")
+    adj = g["adj"]
+    for i, case in enumerate(g["cases"]):
+        mt, method, ds, thr = str(case).split("|")
+        args = SimpleNamespace(method=method, dataset=ds, threshold=float(thr))
+        got = DU.sparsify(mt, torch.from_numpy(adj.copy()), args, verbose=False)
+        np.testing.assert_array_equal(got.numpy(), g[f"sparsify{i}"], err_msg=str(case))
+    base = dict(method="gcond", dataset="cora", seed=3, save_path=str(tmp_path), device="cpu", setting="trans", attack=None,
+                logger=logging.getLogger("t"))
+    args = SimpleNamespace(reduction_rate=0.25, **base)
+    DU.save_reduced(torch.from_numpy(adj), torch.from_numpy(g["loaded_feat"]), torch.from_numpy(g["loaded_label"]), args)
+    files = sorted(os.path.relpath(os.path.join(r, f), tmp_path) for r, _, fs in os.walk(tmp_path) for f in fs)
+    assert files == list(g["files"])
+    data = SimpleNamespace(feat_full=torch.zeros(60, 5), feat_train=torch.zeros(18, 5), labels_train=torch.from_numpy(g["missing_label"]))
+    la, lf, ll = DU.load_reduced(args, data)
+    assert [str(t.dtype) for t in (la, lf, ll)] == list(g["loaded_dtypes"])
+    np.testing.assert_array_equal(la.numpy(), g["loaded_adj"])
+    np.testing.assert_array_equal(lf.numpy(), g["loaded_feat"])
+    np.testing.assert_array_equal(ll.numpy(), g["loaded_label"])
+    ma, mf, ml = DU.load_reduced(SimpleNamespace(reduction_rate=0.125, **base), data)
+    assert bool(g["missing_adj_is_eye"]) and torch.equal(ma, torch.eye(mf.shape[0]))
+    assert list(mf.shape) == list(g["missing_feat_shape"])
+    np.testing.assert_array_equal(ml.numpy(), g["missing_label"])
+    _, mf3, _ = DU.load_reduced(SimpleNamespace(reduction_rate=0.125, **{**base, "setting": "ind"}), data)
+    assert list(mf3.shape) == list(g["missing_feat_shape_ind"])

@@ -187,3 +187,39 @@ def test_g8_full_reduce_and_evaluate(golden_dir, tag):
     np.testing.assert_allclose(got, vals, atol=0.3)
     assert list(g[f"{tag}_files"]) == ["adj_cora_0.5_1.pt", "feat_cora_0.5_1.pt", "label_cora_0.5_1.pt"] or \
         list(g[f"{tag}_files"]) == ["adj_ogbn-arxiv_0.5_1.pt", "feat_ogbn-arxiv_0.5_1.pt", "label_ogbn-arxiv_0.5_1.pt"]
+
+
+@pytest.mark.parametrize("setting", ["trans", "ind"])
+def test_g9_fit_with_val_trace(golden_dir, setting):
+    """models/base.py:80-225 replayed by the oracle from the reference's own initial weights: per-epoch validation
+    accuracy, best-validation restore, final weights and test accuracy."""
+    g = load(golden_dir, "g9_fit_with_val")
+    n, nclass, d, hidden, ns, iters = [int(v) for v in g["meta"]]
+    a = sp.coo_matrix((np.ones(len(g["a_row"])), (g["a_row"], g["a_col"])), shape=(n, n)).tocsr()
+    x, y = T(g["x"]), T(g["y"])
+    idx_val, idx_test = g["idx_val"], g["idx_test"]
+    if setting == "trans":
+        feat, adj = x, O.csr_to_torch(*O.normalize_adj_sparse(a), n)
+        iv, it = T(idx_val), T(idx_test)
+    else:
+        feat = x[idx_val]
+        adj = O.csr_to_torch(*O.normalize_adj_sparse(a[np.ix_(idx_val, idx_val)]), len(idx_val))
+        iv, it = torch.arange(len(idx_val)), torch.arange(len(idx_test))
+    init = [T(g[f"{setting}_init{i}"]) for i in range(4)]
+    trace = []
+    best, w = O.fit_with_val(init, T(g["adj_syn"]), T(g["feat_syn"]), T(g["labels_syn"]), feat, adj, iv, y[idx_val], iters,
+                             lr=0.01, weight_decay=5e-4, trace=trace)
+    ref = g[f"{setting}_val_trace"]
+    got = np.array([t[1] for t in trace])
+    # accuracies are k / n_val: allow one validation node to flip on an fp32 tie
+    assert np.abs(got - ref).max() <= 1.0 / len(idx_val) + 1e-12
+    assert abs(best - float(g[f"{setting}_best"])) <= 1.0 / len(idx_val) + 1e-12
+    if np.array_equal(got, ref):
+        for i in range(4):
+            np.testing.assert_allclose(w[i].numpy(), g[f"{setting}_final{i}"], rtol=1e-3, atol=1e-5)
+    if setting == "trans":
+        acc = O.eval_test(w, x, adj, it, y[idx_test])
+    else:
+        adj_t = O.csr_to_torch(*O.normalize_adj_sparse(a[np.ix_(idx_test, idx_test)]), len(idx_test))
+        acc = O.eval_test(w, x[idx_test], adj_t, it, y[idx_test])
+    assert abs(acc - float(g[f"{setting}_test"])) <= 1.0 / len(idx_test) + 1e-12

@@ -118,3 +118,180 @@ def test_sharded_driver_over_gloo_world2():
     assert bufs0["ar_bn2"][0] == 9.0 and bufs0["e3"][0] == 9.0
     # feature epoch: ar_w1 is filled locally but NOT reduced (3 + own contribution only)
     assert w0 == [4.0] * 6 and w1 == [5.0] * 6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Row-sharded / run-sharded evaluation (graphslim_amd/models/gcn.py, evaluation/eval_agent.py) under gloo, world 2.
+# The HIP entry points the evaluation GCN calls are replaced by torch-CPU test doubles (tests only), so the host logic
+# that matters for N > 1 — row blocks, the all-gather of the layer-2 operand, target rows per rank, count all-reduce,
+# run sharding — is the product code.
+# ---------------------------------------------------------------------------------------------------------------
+def test_row_blocks_cover_rows_and_balance_nonzeros():
+    from graphslim_amd.parallel import RowShard
+    rng = np.random.default_rng(1)
+    for n in (1, 5, 100, 1000):
+        deg = rng.integers(0, 30, n)
+        rowptr = np.concatenate([[0], np.cumsum(deg)])
+        for w in (1, 2, 3, 8):
+            b = RowShard.split_rows(rowptr, w)
+            assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+            if n >= 100:
+                loads = [rowptr[h] - rowptr[l] for l, h in b]
+                assert max(loads) <= rowptr[-1] / w + deg.max()
+
+
+def _install_cpu_doubles():
+    import ctypes
+    import graphslim_amd.models.gcn as G
+    import graphslim_amd.engine as E
+
+    def gemm(A, B, C, M, N, K, sa, sb, ldc, bias=None, relu=0, mask=None, ldmask=0, **kw):
+        a = torch.as_strided(A, (M, K), sa)
+        b = torch.as_strided(B, (K, N), sb)
+        out = a @ b
+        if bias is not None:
+            out = out + bias[:N]
+        if relu:
+            out = out.clamp_min(0)
+        if mask is not None:
+            out = out * (torch.as_strided(mask, (M, N), (ldmask, 1)) > 0)
+        torch.as_strided(C, (M, N), (ldc, 1)).copy_(out)
+        return C
+
+    def spmm_csr(rp, col, val, X, F=None, out=None):
+        n = rp.numel() - 1
+        F = X.shape[1] if F is None else F
+        a = torch.sparse_csr_tensor(rp.long(), col.long(), val, size=(n, X.shape[0]))
+        r = (a @ X[:, :F]) if n > 0 else torch.zeros(0, F)
+        if out is None:
+            return r
+        out[:, :F] = r
+        return out
+
+    def dense_gcn_norm_fwd(adj):
+        a = adj + torch.eye(adj.shape[0])
+        d = a.sum(1).pow(-0.5)
+        d[torch.isinf(d)] = 0
+        return d[:, None] * a * d[None, :], None
+
+    class Lib:
+        def gs_bias_act_f32(self, z, ld, b, n, c, relu, s):
+            z, b = z.t, b.t
+            z[:, :c] += b[:c]
+            if relu:
+                z.clamp_min_(0)
+            return 0
+
+        def gs_count_correct(self, z, ldz, c, idx, labels, n, cnt, s):
+            cnt.t += int((z.t[:, :c].argmax(1) == labels.t.long()).sum())
+            return 0
+
+        def gs_softmax_nll_grad_f32(self, z, ldz, labels, n, c, g, lossr, s):
+            lp = torch.log_softmax(z.t[:, :c], 1)
+            oh = torch.nn.functional.one_hot(labels.t.long(), c).float()
+            g.t.copy_((lp.exp() - oh) / n)
+            lossr.t.copy_(-(lp * oh).sum(1))
+            return 0
+
+        def gs_colsum_f32(self, m, ld, rows, cols, out, s):
+            out.t.copy_(m.t[:, :cols].sum(0))
+            return 0
+
+        def gs_log_softmax_f32(self, z, ldz, n, c, out, ldo, s):
+            out.t.copy_(torch.log_softmax(z.t[:, :c], 1))
+            return 0
+
+    def adam_step(p, g, m, v, lr, step, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
+        g = g + weight_decay * p
+        m.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+        v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+        p.addcdiv_(m / (1 - betas[0] ** step), (v / (1 - betas[1] ** step)).sqrt() + eps, value=-lr)
+
+    class P:
+        def __init__(self, t):
+            self.t = t
+
+    G.gemm, G.spmm_csr, G.dense_gcn_norm_fwd, G.adam_step = gemm, spmm_csr, dense_gcn_norm_fwd, adam_step
+    G.ptr, G.stream, G.check = (lambda t: None if t is None else P(t)), (lambda: None), (lambda rc: None)
+    G._lib = type("L", (), {"lib": staticmethod(lambda: Lib())})
+
+
+def _eval_worker(rank, world, port, q, mode):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from types import SimpleNamespace
+    from helpers import sbm_graph
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    _install_cpu_doubles()
+    import graphslim_amd.models.gcn as G
+    from graphslim_amd.parallel import RowShard, RunShard
+    from graphslim_amd.utils import accuracy
+    n, C, d = 150, 3, 6
+    a, x, y = sbm_graph(n, C, d, 6, seed=2)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(n)
+    it, iv, ie = np.sort(perm[:40]), np.sort(perm[40:90]), np.sort(perm[90:])
+    data = SimpleNamespace(feat_full=torch.from_numpy(x), adj_full=a, labels_full=torch.from_numpy(y), nclass=C,
+                           idx_val=torch.from_numpy(iv), idx_test=torch.from_numpy(ie), labels_val=torch.from_numpy(y[iv]),
+                           labels_test=torch.from_numpy(y[ie]), feat_syn=torch.from_numpy(x[it[:9]]),
+                           adj_syn=torch.eye(9), labels_syn=torch.from_numpy(y[it[:9]]))
+    args = SimpleNamespace(device="cuda:fake", nlayers=2, with_bn=False, lr=0.01, weight_decay=0.0, dropout=0.0, metric=accuracy)
+    if mode == "rows":
+        if world > 1:
+            args.eval_row_shard = RowShard(dist)
+        torch.manual_seed(5)
+        m = G.GCN.__new__(G.GCN)
+        # the constructor insists on a cuda device; keep every tensor on the CPU for the doubles
+        G.torch.device = lambda s: torch.zeros(0).device
+        m.__init__(d, 8, C, args, mode="eval")
+        best = m.fit_with_val(data, train_iters=12, setting="trans", reduced=True)
+        acc = m.test(data, setting="trans")
+        lp = m.predict(data.feat_full, a)
+        lo, hi = m.shard.row_block(a)
+        q.put((rank, best, acc, lo, hi, lp.numpy().tolist()))
+    else:
+        shard = RunShard(dist if world > 1 else None)
+        mine = shard.mine(5)
+        res = shard.combine(5, {i: 0.1 * i + 1 for i in mine})
+        q.put((rank, mine, res.tolist()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _spawn(target, world, *extra):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + extra) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_row_sharded_evaluation_equals_single_rank_gloo():
+    single = _spawn(_eval_worker, 1, "rows")[0]
+    r0, r1 = _spawn(_eval_worker, 2, "rows")
+    # same best-validation accuracy, same test accuracy on both ranks and as the unsharded run
+    assert r0[1] == r1[1] == single[1] and r0[2] == r1[2] == single[2]
+    # the two row blocks tile the graph and each rank's predict() is its block of the unsharded log-probabilities
+    assert r0[3] == 0 and r0[4] == r1[3] and r1[4] == 150
+    full = np.array(single[5])
+    np.testing.assert_allclose(np.array(r0[5]), full[r0[3]:r0[4]], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.array(r1[5]), full[r1[3]:r1[4]], rtol=0, atol=1e-6)
+
+
+def test_run_sharded_evaluation_gloo():
+    r0, r1 = _spawn(_eval_worker, 2, "runs")
+    assert r0[1] == [0, 2, 4] and r1[1] == [1, 3]
+    np.testing.assert_allclose(r0[2], [1.0, 1.1, 1.2, 1.3, 1.4])
+    assert r0[2] == r1[2]

@@ -26,17 +26,20 @@ def timed(e):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     bench.run_steps(p, e, steps, steps)
+    global host_ms
+    host_ms = (time.perf_counter() - t0) / steps * 1e3      # host time to ISSUE the steps (before the sync)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
 
 base = timed(eng)
-print(f"fused single-GPU outer step: {base:.3f} ms")
+print(f"fused single-GPU outer step: {base:.3f} ms (host issue {host_ms:.3f} ms)")
 for world in (1, 2, 4, 8):
-    ts = []
+    ts, hs = [], []
     for r in range(world):
         sh = ShardedGCond(eng, r, world, pools, Collective(None))
         bench.init_state(p, eng)
         ts.append(timed(sh))
-    print(f"world {world}: per-rank ms {[round(t, 3) for t in ts]}  max {max(ts):.3f}  compute-only speed-up {base / max(ts):.2f}x", flush=True)
+        hs.append(round(host_ms, 3))
+    print(f"world {world}: per-rank ms {[round(t, 3) for t in ts]}  max {max(ts):.3f}  compute-only speed-up {base / max(ts):.2f}x  host issue ms {hs}", flush=True)
 eng.set_shard(0, p["data"].nclass, 0, len(p["labels_syn"]))
