@@ -186,8 +186,9 @@ __global__ __launch_bounds__(256, gs_min_waves(BM, BN)) void gs_gemm_f32_kernel(
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-  __shared__ __attribute__((aligned(16))) float As[TileLds<BM, AMODE, BK>::SIZE];
-  __shared__ __attribute__((aligned(16))) float Bs[TileLds<BN, BMODE, BK>::SIZE];
+  constexpr int ASZ = TileLds<BM, AMODE, BK>::SIZE, BSZ = TileLds<BN, BMODE, BK>::SIZE;
+  __shared__ __attribute__((aligned(16))) float As[ASZ];
+  __shared__ __attribute__((aligned(16))) float Bs[BSZ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, b1 = b / p.nb2, b2 = b - b1 * p.nb2;
@@ -236,72 +237,123 @@ __global__ __launch_bounds__(256, gs_min_waves(BM, BN)) void gs_gemm_f32_kernel(
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   const int li = lane & 31, kh = lane >> 5;
 
+  auto mfma_tile = [&](const float* __restrict__ as, const float* __restrict__ bs) {
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      float a[TM][4], bb[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) read_frag<BM, AMODE, BK>(as, wm0 + i * 32 + li, q, kh, a[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) read_frag<BN, BMODE, BK>(bs, wn0 + j * 32 + li, q, kh, bb[j]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], bb[j][t], acc[i][j], 0, 0, 0);
+    }
+  };
   if (k_lo < k_hi) {
     load_tiles(k_lo);
+    // (two LDS images with one barrier per K step were tried: no gain, 293 vs 293 us — the barriers are not the limiter)
     for (int k0 = k_lo; k0 < k_hi; k0 += GS_BK) {
       la.store(As, tid);
       lb.store(Bs, tid);
       __syncthreads();
       if (k0 + GS_BK < k_hi) load_tiles(k0 + GS_BK);   // in flight under the MFMAs below
-#pragma unroll
-      for (int q = 0; q < BK / 8; ++q) {
-        float a[TM][4], bb[TN][4];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) read_frag<BM, AMODE, BK>(As, wm0 + i * 32 + li, q, kh, a[i]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) read_frag<BN, BMODE, BK>(Bs, wn0 + j * 32 + li, q, kh, bb[j]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], bb[j][t], acc[i][j], 0, 0, 0);
-      }
+      mfma_tile(As, Bs);
       __syncthreads();
     }
   }
 
   // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  // Optional inputs (bias / mask / old C) are fetched 16 at a time behind block-uniform branches with clamped
-  // addresses, so no load sits behind a per-element branch.
   const bool has_bias = p.bias != nullptr, has_mask = p.mask != nullptr, has_beta = p.beta != 0.f;
   const bool has_stat = p.colstat != nullptr;
   float cs1[TN], cs2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
+  // Fast path (block-uniform): the tile lies inside C and every element offset fits 32 bits, so each of the 16 values of a
+  // 32x32 tile costs one fma, one max, one 32-bit offset add and the store — the generic path below spends ~8 VALU
+  // instructions of 64-bit index arithmetic per element, which at K = 128..256 is a quarter of the kernel's issue slots.
+  const bool fit32 = (long)M * p.ldc < (1L << 29) && (!has_mask || (long)M * p.ldmask < (1L << 29));
+  if (fullM && fullN && fit32) {
+    const unsigned ldc = (unsigned)p.ldc, ldm = (unsigned)p.ldmask;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn0 + j * 32 + li;
-      const int colc = min(col, p.N - 1);
-      const int rbase = m0 + wm0 + i * 32 + 4 * kh;
-      float bv = 0.f;
-      if (has_bias) bv = p.bias[(long)b1 * p.sbias_b1 + colc];
-      float mk[16], cv[16];
-      if (has_mask) {
+      for (int j = 0; j < TN; ++j) {
+        const unsigned col = n0 + wn0 + j * 32 + li, row0 = m0 + wm0 + i * 32 + 4 * kh;
+        const float bv = has_bias ? p.bias[(long)b1 * p.sbias_b1 + col] : 0.f;
+        const unsigned off = row0 * ldc + col;
+        float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mk[r] = p.mask[(long)min(rbase + (r & 3) + 8 * (r >> 2), M - 1) * p.ldmask + colc];
-      }
-      if (has_beta) {
+        for (int r = 0; r < 16; ++r) v[r] = fmaf(p.alpha, acc[i][j][r], bv);
+        if (p.relu) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cv[r] = C[(long)min(rbase + (r & 3) + 8 * (r >> 2), M - 1) * p.ldc + colc];
-      }
+          for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (has_mask) {
+          const unsigned moff = row0 * ldm + col;
+          float mk[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        float v = p.alpha * acc[i][j][r] + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (has_mask) v = (mk[r] > 0.f) ? v : 0.f;
-        if (has_beta) v += p.beta * cv[r];
-        if (row < M && col < p.N) {
-          C[(long)row * p.ldc + col] = v;
-          cs1[j] += v;
-          cs2[j] = fmaf(v, v, cs2[j]);
+          for (int r = 0; r < 16; ++r) mk[r] = p.mask[moff + ((r & 3) + 8 * (r >> 2)) * ldm];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = (mk[r] > 0.f) ? v[r] : 0.f;
+        }
+        if (has_beta) {
+          float cv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cv[r] = C[off + ((r & 3) + 8 * (r >> 2)) * ldc];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = fmaf(p.beta, cv[r], v[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) C[off + ((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+        if (has_stat) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            cs1[j] += v[r];
+            cs2[j] = fmaf(v[r], v[r], cs2[j]);
+          }
         }
       }
-    }
+  } else {
+    // Edge tiles / huge outputs.  Optional inputs (bias / mask / old C) are fetched 16 at a time behind block-uniform
+    // branches with clamped addresses, so no load sits behind a per-element branch.
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 32 + li;
+        const int colc = min(col, p.N - 1);
+        const int rbase = m0 + wm0 + i * 32 + 4 * kh;
+        float bv = 0.f;
+        if (has_bias) bv = p.bias[(long)b1 * p.sbias_b1 + colc];
+        float mk[16], cv[16];
+        if (has_mask) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mk[r] = p.mask[(long)min(rbase + (r & 3) + 8 * (r >> 2), M - 1) * p.ldmask + colc];
+        }
+        if (has_beta) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cv[r] = C[(long)min(rbase + (r & 3) + 8 * (r >> 2), M - 1) * p.ldc + colc];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          float v = fmaf(p.alpha, acc[i][j][r], bv);
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (has_mask) v = (mk[r] > 0.f) ? v : 0.f;
+          if (has_beta) v = fmaf(p.beta, cv[r], v);
+          if (row < M && col < p.N) {
+            C[(long)row * p.ldc + col] = v;
+            cs1[j] += v;
+            cs2[j] = fmaf(v, v, cs2[j]);
+          }
+        }
+      }
+  }
   if (has_stat) {
     // per-block column sums of the written tile: colstat[(blockIdx.y*2 + q)*N + col], q = 0: sum, 1: sum of squares
     // (BatchNorm statistics without a second pass over C).  Reduce: lane halves -> waves along M (through LDS) -> global.
@@ -505,10 +557,12 @@ extern "C" int gs_reduce_slabs_batched_f32(float* out, long out_stride, const fl
   return GS_OK;
 }
 
-static int g_bk_small = 32, g_bk_big = 16;   // K-tile depth of the small (latency-bound) and the 128x128 tiles
+static int g_bk_small = 32, g_bk_big = 0;   // 0 = by operand mode
+   // K-tile depth of the small (latency-bound) and the 128x128 tiles
 
 extern "C" int gs_gemm_set_tuning(int bk_small, int bk_big) {
-  if ((bk_small != 16 && bk_small != 32) || (bk_big != 16 && bk_big != 32)) GS_FAIL(GS_ERR_ARG, "gs_gemm_set_tuning: BK must be 16 or 32");
+  if ((bk_small != 16 && bk_small != 32) || (bk_big != 0 && bk_big != 16 && bk_big != 32))
+    GS_FAIL(GS_ERR_ARG, "gs_gemm_set_tuning: BK must be 16 or 32 (bk_big = 0: chosen by operand mode)");
   g_bk_small = bk_small;
   g_bk_big = bk_big;
   return GS_OK;
@@ -532,7 +586,10 @@ static int launch_gemm_bgen(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int AM, int BMD>
 static int launch_gemm2(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
-  const int bk = (BM == 128 && BN == 128) ? g_bk_big : g_bk_small;
+  // the 128x128 tile: K step 32 when both operands are k-contiguous (two ds_read_b128 per fragment pair, half the
+  // barriers: 264 vs 277 us at the PGE layer-2 shape), 16 otherwise (m-contiguous images get slower with 32: 311 vs 293 us)
+  int bk = (BM == 128 && BN == 128) ? g_bk_big : g_bk_small;
+  if (BM == 128 && BN == 128 && g_bk_big == 0) bk = (AM == GS_MODE_K && BMD == GS_MODE_K) ? 32 : 16;
   if (bk == 32) return launch_gemm3<BM, BN, WM, WN, AM, BMD, 32>(p, nbatch, s);
   return launch_gemm3<BM, BN, WM, WN, AM, BMD, 16>(p, nbatch, s);
 }

@@ -75,7 +75,7 @@ typedef struct gs_gemm_desc {
   int bgen_div;
 } gs_gemm_desc;
 
-/* K-tile depth (16 or 32) of the small tiles and of the 128x128 tile; a measurement knob (defaults 32 / 16). */
+/* K-tile depth (16 or 32) of the small tiles and of the 128x128 tile (0 = by operand mode); a measurement knob (defaults 32 / 0). */
 int gs_gemm_set_tuning(int bk_small, int bk_big);
 /* Routing of latency-bound products to the one-tile-per-workgroup kernel (32x32 tile, K split over the 4 waves, fragments
    fetched straight from global memory): taken when the 32x32 tile count is <= max_tiles and the product is <= max_gflop
