@@ -115,10 +115,10 @@ def roofline_probe(eng, reps=20):
     peak = 157.3      # TFLOP/s, fp32 matrix (MI355X_MICROARCH.md chip table)
     ach = flops / sec / 1e12
     # HBM traffic of this kernel at this shape from rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of
-    # tools/probe_kernels.py, profiles/r01/pmc_*): 209 843 KiB fetched + 206 116 KiB written per launch = the
-    # algorithmic A-read + C-write (the 64-B row-segment loads of this kernel count 1:1 — the A operand is exactly
-    # 206 116 KiB — so no gfx950 x2 correction applies to this access pattern).  PMC cannot be sampled inside bench.py.
-    traffic = (209843 + 206116) * 1024 if (n, ph) == (454, 256) else None
+    # tools/probe_gemm.py, profiles/r01/pmc_v4_*): 208 560 KiB fetched + 206 140 KiB written per launch = the algorithmic
+    # A-read + C-write (the 64-B row-segment loads of this kernel count 1:1 — the A operand is exactly 206 116 KiB — so
+    # no gfx950 x2 correction applies to this access pattern).  PMC cannot be sampled inside bench.py.
+    traffic = (208560 + 206140) * 1024 if (n, ph) == (454, 256) else None
     return {"bound": "mfma", "kernel": "gs_gemm_f32_kernel<128,128,64,64,K,K> (PGE layer 2, fp32 MFMA 32x32x2)",
             "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
             "avg_launch_us": round(sec * 1e6, 2), "flops_per_launch": flops}
