@@ -261,7 +261,9 @@ __global__ __launch_bounds__(256, gs_min_waves(BM, BN)) void gs_gemm_f32_kernel(
       la.store(As, tid);
       lb.store(Bs, tid);
       __syncthreads();
+#ifndef GS_TRIAGE_NO_GLOAD                             // (tools/micro/gemm_triage.hip: phase-removal experiments)
       if (k0 + GS_BK < k_hi) load_tiles(k0 + GS_BK);   // in flight under the MFMAs below
+#endif
       mfma_tile(As, Bs);
       __syncthreads();
     }
@@ -277,6 +279,9 @@ __global__ __launch_bounds__(256, gs_min_waves(BM, BN)) void gs_gemm_f32_kernel(
   // 32x32 tile costs one fma, one max, one 32-bit offset add and the store — the generic path below spends ~8 VALU
   // instructions of 64-bit index arithmetic per element, which at K = 128..256 is a quarter of the kernel's issue slots.
   const bool fit32 = (long)M * p.ldc < (1L << 29) && (!has_mask || (long)M * p.ldmask < (1L << 29));
+#ifdef GS_TRIAGE_NO_STORE
+  if (acc[0][0][0] != 12345.678f) return;
+#endif
   if (fullM && fullN && fit32) {
     const unsigned ldc = (unsigned)p.ldc, ldm = (unsigned)p.ldmask;
 #pragma unroll
@@ -588,8 +593,9 @@ template <int BM, int BN, int WM, int WN, int AM, int BMD>
 static int launch_gemm2(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
   // the 128x128 tile: K step 32 when both operands are k-contiguous (two ds_read_b128 per fragment pair, half the
   // barriers: 264 vs 277 us at the PGE layer-2 shape), 16 otherwise (m-contiguous images get slower with 32: 311 vs 293 us)
-  int bk = (BM == 128 && BN == 128) ? g_bk_big : g_bk_small;
-  if (BM == 128 && BN == 128 && g_bk_big == 0) bk = (AM == GS_MODE_K && BMD == GS_MODE_K) ? 32 : 16;
+  constexpr bool BIG = BM == 128 && BN == 128;
+  int bk = BIG ? g_bk_big : g_bk_small;
+  if (BIG && g_bk_big == 0) bk = (AM == GS_MODE_K && BMD == GS_MODE_K) ? 32 : 16;
   if (bk == 32) return launch_gemm3<BM, BN, WM, WN, AM, BMD, 32>(p, nbatch, s);
   return launch_gemm3<BM, BN, WM, WN, AM, BMD, 16>(p, nbatch, s);
 }
@@ -644,6 +650,6 @@ extern "C" int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream) {
     case 0: return launch_gemm<128, 32, 32, 32>(p, nbatch, s);
     case 1: return launch_gemm<32, 128, 32, 32>(p, nbatch, s);
     case 2: return launch_gemm<64, 64, 32, 32>(p, nbatch, s);
-    default: return launch_gemm<128, 128, 64, 64>(p, nbatch, s);
+    default: return launch_gemm<128, 128, 64, 64>(p, nbatch, s);   // (128x64 / 64x128 at 4 waves/SIMD measured within +-5 %)
   }
 }
