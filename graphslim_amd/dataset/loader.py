@@ -19,11 +19,20 @@ def ei2csr(edge_index, n):
     return sp.csr_matrix((np.ones(ei.shape[1], dtype=np.int64), (ei[0], ei[1])), shape=(n, n))
 
 
+_STANDARD = ["flickr", "reddit", "cora", "citeseer", "pubmed", "ogbn-arxiv"]
+
+
 def get_dataset(name="cora", args=None, load_path=None):
-    """graphslim/dataset/loader.py:39-97.  There is no network on the target boxes, so every dataset name resolves to
-    the dataset-shaped synthetic generator (graphslim_amd/dataset/synthetic.py) unless `<load_path>/<name>.npz` holds
-    real arrays (x, y, edge_index, train_mask, val_mask, test_mask)."""
-    name = {"arxiv": "ogbn-arxiv"}.get(name, name)
+    """graphslim/dataset/loader.py:39-97.  Resolution order for a dataset name (spelling normalised like :41-50):
+      1. `<load_path>/<name>.npz` with arrays x, y, edge_index, train_mask, val_mask, test_mask;
+      2. the raw files upstream GraphSlim / PyTorch-Geometric keep under `load_path` (Planetoid `ind.<name>.*`, GraphSAINT
+         `adj_full.npz, feats.npy, class_map.json, role.json`) — graphslim_amd/dataset/readers.py;
+      3. the dataset-shaped synthetic generator (graphslim_amd/dataset/synthetic.py) — there is no network on the target
+         boxes, so nothing is ever downloaded."""
+    key = name.lower().replace("-", "").replace("_", "")
+    table = {n.replace("-", ""): n for n in _STANDARD}
+    table["arxiv"] = "ogbn-arxiv"
+    name = table.get(key, name)
     load_path = load_path or getattr(args, "load_path", None)
     raw = None
     if load_path and os.path.exists(os.path.join(load_path, f"{name}.npz")):
@@ -33,6 +42,9 @@ def get_dataset(name="cora", args=None, load_path=None):
                               edge_index=torch.from_numpy(z["edge_index"]).long(), num_nodes=int(z["x"].shape[0]),
                               train_mask=torch.from_numpy(z["train_mask"]), val_mask=torch.from_numpy(z["val_mask"]),
                               test_mask=torch.from_numpy(z["test_mask"]), name=name, synthetic=False)
+    if raw is None and load_path:
+        from .readers import find_and_read
+        raw = find_and_read(load_path, name)
     if raw is None:
         if name not in SHAPES:
             raise ValueError(f"dataset '{name}' is not available offline; known shapes: {sorted(SHAPES)}")

@@ -100,3 +100,101 @@ def test_g10_sparsify_and_reduced_graph_files(golden_dir, tmp_path):
     np.testing.assert_array_equal(ml.numpy(), g["missing_label"])
     _, mf3, _ = DU.load_reduced(SimpleNamespace(reduction_rate=0.125, **{**base, "setting": "ind"}), data)
     assert list(mf3.shape) == list(g["missing_feat_shape_ind"])
+
+
+def _write_planetoid(root, name, rng, n_all=60, n_train=12, n_test=20, d=7, C=3, isolated=()):
+    """Files in the Planetoid raw layout for a random graph; returns the arrays a reader must reproduce."""
+    import pickle
+    from collections import defaultdict
+    raw = os.path.join(root, name, "raw")
+    os.makedirs(raw)
+    n = n_all + n_test + len(isolated)
+    test_ids = np.setdiff1d(np.arange(n_all, n), np.asarray(isolated, dtype=np.int64))
+    test_index = rng.permutation(test_ids)
+    feats = (rng.random((n, d)) < 0.3).astype(np.float32)
+    labels = rng.integers(0, C, n)
+    feats[list(isolated)] = 0
+    labels[list(isolated)] = 0
+    onehot = np.eye(C, dtype=np.int32)[labels]
+    onehot[list(isolated)] = 0
+    g = defaultdict(list)
+    edges = set()
+    for _ in range(4 * n):
+        a, b = rng.integers(0, n, 2)
+        if a in isolated or b in isolated:
+            continue
+        edges.add((int(a), int(b)))
+    for a, b in edges:                      # adjacency lists with a few duplicates and self loops, like the real files
+        g[a].append(b)
+        g[b].append(a)
+    g[0].append(0)
+    g[1] += [g[1][0]] if g[1] else []
+    dump = {"x": sp.csr_matrix(feats[:n_train]), "y": onehot[:n_train], "allx": sp.csr_matrix(feats[:n_all]), "ally": onehot[:n_all],
+            "tx": sp.csr_matrix(feats[test_index]), "ty": onehot[test_index], "graph": g}
+    # (row i of tx / ty belongs to node test.index[i]; the reader moves it to that node's row)
+    for k, v in dump.items():
+        with open(os.path.join(raw, f"ind.{name}.{k}"), "wb") as f:
+            pickle.dump(v, f)
+    with open(os.path.join(raw, f"ind.{name}.test.index"), "w") as f:
+        f.write("\n".join(str(int(i)) for i in test_index) + "\n")
+    und = {(a, b) for a, b in edges if a != b} | {(b, a) for a, b in edges if a != b}
+    return feats, labels, und, np.arange(n_train), np.arange(n_train, n_train + 500), test_index, n
+
+
+def test_planetoid_raw_reader_roundtrip(tmp_path):
+    from graphslim_amd.dataset.readers import find_and_read
+    rng = np.random.default_rng(0)
+    feats, labels, und, tr, va, te, n = _write_planetoid(str(tmp_path), "cora", rng, n_all=560, n_train=12, n_test=20)
+    rec = find_and_read(str(tmp_path), "cora")
+    assert rec is not None and rec.num_nodes == n
+    # tx rows are stored in test.index order and re-placed by node id: features / labels of every node come back
+    np.testing.assert_array_equal(rec.x.numpy(), feats)
+    np.testing.assert_array_equal(rec.y.numpy(), labels)
+    got = set(map(tuple, rec.edge_index.numpy().T.tolist()))
+    assert got == und                                        # symmetrised, no self loops, no duplicates
+    assert rec.train_mask.nonzero().view(-1).tolist() == tr.tolist()
+    assert rec.val_mask.nonzero().view(-1).tolist() == va.tolist()
+    assert sorted(rec.test_mask.nonzero().view(-1).tolist()) == sorted(te.tolist())
+
+
+def test_planetoid_citeseer_isolated_test_nodes(tmp_path):
+    from graphslim_amd.dataset.readers import find_and_read
+    rng = np.random.default_rng(1)
+    feats, labels, und, tr, va, te, n = _write_planetoid(str(tmp_path), "citeseer", rng, n_all=560, n_train=12, n_test=20,
+                                                         isolated=(565, 571))
+    rec = find_and_read(str(tmp_path), "citeseer")
+    assert rec.num_nodes == n
+    np.testing.assert_array_equal(rec.x.numpy(), feats)      # the isolated nodes are zero rows with label 0
+    np.testing.assert_array_equal(rec.y.numpy(), labels)
+    assert not rec.test_mask[565] and not rec.test_mask[571]
+
+
+def test_graphsaint_raw_reader_and_get_dataset(tmp_path):
+    import json
+    from types import SimpleNamespace
+    from graphslim_amd.dataset import get_dataset
+    rng = np.random.default_rng(2)
+    n, d, C = 300, 6, 5
+    raw = os.path.join(str(tmp_path), "ogbn_arxiv", "raw")
+    os.makedirs(raw)
+    src, dst = rng.integers(0, n, 900), rng.integers(0, n, 900)
+    keep = src != dst
+    a = sp.coo_matrix((np.ones(keep.sum()), (src[keep], dst[keep])), shape=(n, n)).tocsr()
+    a.data[:] = 1
+    sp.save_npz(os.path.join(raw, "adj_full.npz"), a)                 # directed, like the citation graph
+    x = rng.normal(size=(n, d)).astype(np.float32)
+    np.save(os.path.join(raw, "feats.npy"), x)
+    y = rng.integers(0, C, n)
+    perm = rng.permutation(n)
+    json.dump({str(i): int(y[i]) for i in range(n)}, open(os.path.join(raw, "class_map.json"), "w"))
+    json.dump({"tr": perm[:150].tolist(), "va": perm[150:200].tolist(), "te": perm[200:].tolist()}, open(os.path.join(raw, "role.json"), "w"))
+    args = SimpleNamespace(load_path=str(tmp_path), seed=1)
+    data = get_dataset("ogbn_arxiv", args)
+    assert data.num_nodes == n and data.nclass == C and args.nclass == C
+    sym = ((a + a.T) > 0).astype(np.int64)
+    assert (data.adj_full != sym).nnz == 0                             # loader.py:426-429 symmetrisation
+    np.testing.assert_array_equal(np.sort(data.idx_train.numpy()), np.sort(perm[:150]))
+    np.testing.assert_array_equal(data.labels_full.numpy(), y)
+    # loader.py:113-119: features standardised with the TRAIN rows' statistics
+    mu, sd = x[np.sort(perm[:150])].astype(np.float64).mean(0), x[np.sort(perm[:150])].astype(np.float64).std(0)
+    np.testing.assert_allclose(data.feat_full.numpy(), (x - mu) / sd, rtol=1e-5, atol=1e-5)
