@@ -130,7 +130,7 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   e->pW0 = 0; e->pb0 = Ph * 2 * d; e->pW1 = e->pb0 + Ph; e->pb1 = e->pW1 + Ph * Ph; e->pw2 = e->pb1 + Ph;
   e->pb2 = e->pw2 + Ph; e->pg1 = e->pb2 + 1; e->pbe1 = e->pg1 + Ph; e->pg2 = e->pbe1 + Ph; e->pbe2 = e->pg2 + Ph;
   e->Ppge = e->pbe2 + Ph;
-  e->kchunk_r = 1024;
+  e->kchunk_r = 512;    // ~23 slabs per class at arxiv sizes: 1 840 workgroups for 768 resident slots (1 024 left a 25 %-full second round: 667 vs 528 us, tools/probe_bgen.py)
   e->nsplit_r = gs_cdiv((long)e->cap1 * e->f2, e->kchunk_r);
   e->kchunk_w = 2048;
   e->nsplit_w = gs_cdiv((long)e->n * e->n, e->kchunk_w);
