@@ -132,7 +132,15 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   e->Ppge = e->pbe2 + Ph;
   e->kchunk_r = 512;    // ~23 slabs per class at arxiv sizes: 1 840 workgroups for 768 resident slots (1 024 left a 25 %-full second round: 667 vs 528 us, tools/probe_bgen.py)
   e->nsplit_r = gs_cdiv((long)e->cap1 * e->f2, e->kchunk_r);
-  e->kchunk_w = 2048;
+  // dW1 = dE2^T A1 over K = n'^2 pair rows: Ph/128 x Ph/128 output tiles per slab; aim at one full round of the 768
+  // resident 128x128 workgroups (2 048 gave 404 workgroups at n' = 454: half the chip idle)
+  {
+    const long tiles = (long)gs_cdiv(e->Ph, 128) * gs_cdiv(e->Ph, 128);
+    const long slabs = 768 / (tiles > 0 ? tiles : 1) > 0 ? 768 / tiles : 1;
+    long kc = gs_cdiv((long)e->n * e->n, slabs);
+    kc = ((kc + 15) / 16) * 16;
+    e->kchunk_w = (int)(kc < 256 ? 256 : kc);
+  }
   e->nsplit_w = gs_cdiv((long)e->n * e->n, e->kchunk_w);
   e->rows_per_block = 64;
   e->nblk_stats = gs_cdiv((long)e->n * e->n, e->rows_per_block);
@@ -616,12 +624,19 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       g.B = pp + e->pW0 + d; g.C = e->V;
       GS_TRY(gs_gemm_f32(&g, stream));
     }
-    hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 32)), dim3(256), 0, s, e->U, e->V, pp + e->pb0, n, Ph, e->mu1,
+    hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 32)), dim3(1024), 0, s, e->U, e->V, pp + e->pb0, n, Ph, e->mu1,
                        e->is1, e->sumU, e->sumV);
     GS_LAUNCH_CHECK();
     if (rows > 0) {
-      hipLaunchKernelGGL(gs_pge_make_a1_v4_kernel, dim3(gs_cdiv(rows * (Ph / 4), 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0,
-                         e->mu1, e->is1, pp + e->pg1, pp + e->pbe1, n, Ph, e->r_lo, nr, e->A1);
+      if (Ph == 256)
+        hipLaunchKernelGGL((gs_pge_make_a1_v5_kernel<64>), dim3(gs_cdiv(n, 4 * 8), nr), dim3(256), 0, s, e->U, e->V, pp + e->pb0, e->mu1,
+                           e->is1, pp + e->pg1, pp + e->pbe1, n, e->r_lo, nr, e->A1);
+      else if (Ph == 128)
+        hipLaunchKernelGGL((gs_pge_make_a1_v5_kernel<32>), dim3(gs_cdiv(n, 8 * 8), nr), dim3(256), 0, s, e->U, e->V, pp + e->pb0, e->mu1,
+                           e->is1, pp + e->pg1, pp + e->pbe1, n, e->r_lo, nr, e->A1);
+      else
+        hipLaunchKernelGGL(gs_pge_make_a1_v4_kernel, dim3(gs_cdiv(rows * (Ph / 4), 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0,
+                           e->mu1, e->is1, pp + e->pg1, pp + e->pbe1, n, Ph, e->r_lo, nr, e->A1);
       GS_LAUNCH_CHECK();
       gs_gemm_desc g = mk(e->A1, Ph, 1, pp + e->pW1, 1, Ph, e->E2, Ph, (int)rows, Ph, Ph);     // E2 = A1 W1^T + b1
       g.bias = pp + e->pb1;
@@ -637,9 +652,18 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
   if (part == 2) {
     hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, n2, Ph, e->mu2, e->is2);
     if (sharded_r(e)) GS_HIP(hipMemsetAsync(e->e3, 0, sizeof(float) * n2, s));
-    if (rows > 0)
-      hipLaunchKernelGGL(gs_pge_layer3_kernel, dim3(gs_cdiv(rows, 4)), dim3(256), 0, s, e->E2, e->mu2, e->is2, pp + e->pg2,
-                         pp + e->pbe2, pp + e->pw2, pp + e->pb2, rows, Ph, e->e3 + (long)e->r_lo * n);
+    if (rows > 0) {
+      float* e3o = e->e3 + (long)e->r_lo * n;
+      if (Ph == 256)
+        hipLaunchKernelGGL((gs_pge_layer3_v4_kernel<64>), dim3(gs_cdiv(rows, 4 * 8)), dim3(256), 0, s, e->E2, e->mu2, e->is2, pp + e->pg2,
+                           pp + e->pbe2, pp + e->pw2, pp + e->pb2, rows, e3o);
+      else if (Ph == 128)
+        hipLaunchKernelGGL((gs_pge_layer3_v4_kernel<32>), dim3(gs_cdiv(rows, 4 * 16)), dim3(256), 0, s, e->E2, e->mu2, e->is2, pp + e->pg2,
+                           pp + e->pbe2, pp + e->pw2, pp + e->pb2, rows, e3o);
+      else
+        hipLaunchKernelGGL(gs_pge_layer3_kernel, dim3(gs_cdiv(rows, 4)), dim3(256), 0, s, e->E2, e->mu2, e->is2, pp + e->pg2,
+                           pp + e->pbe2, pp + e->pw2, pp + e->pb2, rows, Ph, e3o);
+    }
     GS_LAUNCH_CHECK();
     return GS_OK;
   }
@@ -943,8 +967,15 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
   if (part == 1) {
     hipLaunchKernelGGL(gs_pge_adj_bwd_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, e->d_adj, e->adj_raw, n, e->de3);
     if (rows > 0) {
-      hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(nblk), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2, pp + e->pg2,
-                         pp + e->pbe2, pp + e->pw2, rows, Ph, e->rows_per_block, e->parts);
+      if (Ph == 256)
+        hipLaunchKernelGGL((gs_pge_l3_bwd_stats_v4_kernel<64>), dim3(nblk), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2, pp + e->pg2,
+                           pp + e->pbe2, pp + e->pw2, rows, e->rows_per_block, e->parts);
+      else if (Ph == 128)
+        hipLaunchKernelGGL((gs_pge_l3_bwd_stats_v4_kernel<32>), dim3(nblk), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2, pp + e->pg2,
+                           pp + e->pbe2, pp + e->pw2, rows, e->rows_per_block, e->parts);
+      else
+        hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(nblk), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2, pp + e->pg2,
+                           pp + e->pbe2, pp + e->pw2, rows, Ph, e->rows_per_block, e->parts);
       reduce_parts(e, e->parts, nblk, 3, 3, s);
     } else {
       GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 3 * Ph, s));

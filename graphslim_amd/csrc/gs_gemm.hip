@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void gs_gemm_small_kernel(gs_gemm_desc p) {
   }
 }
 
-static long g_small_tiles = 1024;      // route to the small kernel when the 32x32 tile count is at most this ...
+static long g_small_tiles = 8192;      // route to the small kernel when the 32x32 tile count is at most this ...
 static double g_small_gflop = 1.5;     // ... and the product is at most this many GFLOP
 
 extern "C" int gs_gemm_set_small(long max_tiles, double max_gflop) {

@@ -373,40 +373,60 @@ __global__ __launch_bounds__(256) void gs_make_bmat_kernel(const int* __restrict
 // PGE (models/parametrized_adj.py:40-71) with the layer-1 decomposition E1[r,c] = U[c] + V[r] + b0.
 // ------------------------------------------------------------------------------------------------
 // BN-1 batch statistics from U, V alone: mean = mean(U)+mean(V)+b0, var = var(U)+var(V) (biased), fp64.
-// block = 32 columns x 8 row groups; two passes (mean, then centred squares) with an LDS reduction each.
-__global__ __launch_bounds__(256) void gs_pge_bn1_stats_kernel(const float* __restrict__ U, const float* __restrict__ V,
-                                                               const float* __restrict__ b0, int n, int Ph,
-                                                               float* __restrict__ mu1, float* __restrict__ is1,
-                                                               float* __restrict__ sumU, float* __restrict__ sumV) {
+// block = 32 columns x 32 row groups (1024 threads); two passes (mean, then centred squares) with an LDS reduction each.
+// The matrices are tiny (n' x Ph) and this sits on the critical path of both PGE passes: the row loop is 8-way unrolled with
+// clamped, unconditional loads so that a thread keeps 16 loads in flight instead of walking a dependent chain.
+#define GS_BN1_RG 32
+__global__ __launch_bounds__(1024) void gs_pge_bn1_stats_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                                const float* __restrict__ b0, int n, int Ph,
+                                                                float* __restrict__ mu1, float* __restrict__ is1,
+                                                                float* __restrict__ sumU, float* __restrict__ sumV) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + tx;
-  __shared__ double sh[2][8][32];
+  const int k = min(blockIdx.x * 32 + tx, Ph - 1);
+  __shared__ double sh[2][GS_BN1_RG][32];
   double su = 0, sv = 0;
-  if (k < Ph)
-    for (int i = ty; i < n; i += 8) {
-      su += U[(long)i * Ph + k];
-      sv += V[(long)i * Ph + k];
+  for (int i0 = ty; i0 < n; i0 += 8 * GS_BN1_RG) {
+    float u[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = min(i0 + j * GS_BN1_RG, n - 1);
+      u[j] = U[(long)i * Ph + k];
+      v[j] = V[(long)i * Ph + k];
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (i0 + j * GS_BN1_RG < n) { su += u[j]; sv += v[j]; }
+  }
   sh[0][ty][tx] = su;
   sh[1][ty][tx] = sv;
   __syncthreads();
   su = sv = 0;
-  for (int q = 0; q < 8; ++q) { su += sh[0][q][tx]; sv += sh[1][q][tx]; }
+  for (int q = 0; q < GS_BN1_RG; ++q) { su += sh[0][q][tx]; sv += sh[1][q][tx]; }
   __syncthreads();
   const double mu = su / n, mv = sv / n;
   double vu = 0, vv = 0;
-  if (k < Ph)
-    for (int i = ty; i < n; i += 8) {
-      double a = U[(long)i * Ph + k] - mu, b = V[(long)i * Ph + k] - mv;
-      vu += a * a;
-      vv += b * b;
+  for (int i0 = ty; i0 < n; i0 += 8 * GS_BN1_RG) {
+    float u[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = min(i0 + j * GS_BN1_RG, n - 1);
+      u[j] = U[(long)i * Ph + k];
+      v[j] = V[(long)i * Ph + k];
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (i0 + j * GS_BN1_RG < n) {
+        const double a = u[j] - mu, b = v[j] - mv;
+        vu += a * a;
+        vv += b * b;
+      }
+  }
   sh[0][ty][tx] = vu;
   sh[1][ty][tx] = vv;
   __syncthreads();
-  if (ty == 0 && k < Ph) {
+  if (ty == 0 && blockIdx.x * 32 + tx < Ph) {
     vu = vv = 0;
-    for (int q = 0; q < 8; ++q) { vu += sh[0][q][tx]; vv += sh[1][q][tx]; }
+    for (int q = 0; q < GS_BN1_RG; ++q) { vu += sh[0][q][tx]; vv += sh[1][q][tx]; }
     mu1[k] = (float)(mu + mv + (double)b0[k]);
     is1[k] = (float)(1.0 / sqrt(vu / n + vv / n + 1e-5));
     sumU[k] = (float)su;
@@ -452,6 +472,37 @@ __global__ void gs_pge_make_a1_v4_kernel(const float* __restrict__ U, const floa
   *reinterpret_cast<float4*>(A1 + pair * Ph + k) = o;
 }
 
+// Streaming form for Ph = 4 * Q, Q in {32, 64}: a thread keeps the BN-1 affine, b0 and V[r] of its 4 columns in registers and
+// sweeps 8 pair columns c of one pair row r, so one output float4 costs one L2 read (U[c]) instead of seven.
+template <int Q>
+__global__ __launch_bounds__(256) void gs_pge_make_a1_v5_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                                const float* __restrict__ b0, const float* __restrict__ mu1,
+                                                                const float* __restrict__ is1, const float* __restrict__ g1,
+                                                                const float* __restrict__ be1, int n, int r_lo, int nr,
+                                                                float* __restrict__ A1) {
+  constexpr int Ph = 4 * Q, CS = 256 / Q, SWEEP = 8;      // CS pair columns per pass, SWEEP passes per block
+  const int k = (threadIdx.x % Q) * 4, cs = threadIdx.x / Q;
+  const int rl = blockIdx.y, r = r_lo + rl;
+  const int c0 = blockIdx.x * (CS * SWEEP);
+  const float4 v = *reinterpret_cast<const float4*>(V + (long)r * Ph + k);
+  const float4 b = *reinterpret_cast<const float4*>(b0 + k), m = *reinterpret_cast<const float4*>(mu1 + k);
+  const float4 is = *reinterpret_cast<const float4*>(is1 + k), g = *reinterpret_cast<const float4*>(g1 + k);
+  const float4 be = *reinterpret_cast<const float4*>(be1 + k);
+  float4 u[SWEEP];
+#pragma unroll
+  for (int i = 0; i < SWEEP; ++i) u[i] = *reinterpret_cast<const float4*>(U + (long)min(c0 + i * CS + cs, n - 1) * Ph + k);
+#pragma unroll
+  for (int i = 0; i < SWEEP; ++i) {
+    const int c = c0 + i * CS + cs;
+    float4 o;
+    o.x = fmaxf(fmaf(g.x, (u[i].x + v.x + b.x - m.x) * is.x, be.x), 0.f);
+    o.y = fmaxf(fmaf(g.y, (u[i].y + v.y + b.y - m.y) * is.y, be.y), 0.f);
+    o.z = fmaxf(fmaf(g.z, (u[i].z + v.z + b.z - m.z) * is.z, be.z), 0.f);
+    o.w = fmaxf(fmaf(g.w, (u[i].w + v.w + b.w - m.w) * is.w, be.w), 0.f);
+    if (c < n) *reinterpret_cast<float4*>(A1 + ((long)rl * n + c) * Ph + k) = o;
+  }
+}
+
 // column sums of up to two per-element functions over a tall matrix, fp64 partials:
 // part[blk][0][k] = sum_rows f0, part[blk][1][k] = sum_rows f1.   mode 0: (x, x*x)  [BN-2 statistics]
 __global__ __launch_bounds__(256) void gs_col_stats_kernel(const float* __restrict__ E, long rows, int Ph, int rows_per_block,
@@ -495,6 +546,46 @@ __global__ __launch_bounds__(256) void gs_pge_layer3_kernel(const float* __restr
   }
   s = gs_wave_sum(s);
   if (lane == 0) e3[row] = s + b2[0];
+}
+
+// Same, streaming form for Ph = 4 * LPR (LPR = 64 or 32 lanes per row): each lane owns 4 consecutive columns, the BN-2 affine
+// and w2 of those columns stay in registers, and a wave sweeps 8 passes of 64 / LPR rows with all its 16-byte loads in
+// flight at once (the wave-per-row form re-read five per-column constants per element and ran at 2.4 TB/s).
+template <int LPR>
+__global__ __launch_bounds__(256) void gs_pge_layer3_v4_kernel(const float* __restrict__ E2, const float* __restrict__ mu2,
+                                                               const float* __restrict__ is2, const float* __restrict__ g2,
+                                                               const float* __restrict__ be2, const float* __restrict__ w2,
+                                                               const float* __restrict__ b2, long rows, float* __restrict__ e3) {
+  constexpr int RPW = 64 / LPR, PASSES = 8, Ph = 4 * LPR;
+  const int lane = threadIdx.x & 63, sub = lane / LPR, cl = lane % LPR;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long base = wave * (RPW * PASSES);
+  if (base >= rows) return;
+  const float4 g = *reinterpret_cast<const float4*>(g2 + 4 * cl), m = *reinterpret_cast<const float4*>(mu2 + 4 * cl);
+  const float4 is = *reinterpret_cast<const float4*>(is2 + 4 * cl), be = *reinterpret_cast<const float4*>(be2 + 4 * cl);
+  const float4 w = *reinterpret_cast<const float4*>(w2 + 4 * cl);
+  const float4 a = make_float4(g.x * is.x, g.y * is.y, g.z * is.z, g.w * is.w);
+  // y = g*(E - mu)*is + be, evaluated as in the wave-per-row kernel (same rounding of the BN affine)
+  float4 ev[PASSES];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const long row = min(base + ps * RPW + sub, rows - 1);
+    ev[ps] = *reinterpret_cast<const float4*>(E2 + row * Ph + 4 * cl);
+  }
+  const float bias = b2[0];
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const float4 e = ev[ps];
+    float s = fmaxf(fmaf(g.x, (e.x - m.x) * is.x, be.x), 0.f) * w.x;
+    s = fmaf(fmaxf(fmaf(g.y, (e.y - m.y) * is.y, be.y), 0.f), w.y, s);
+    s = fmaf(fmaxf(fmaf(g.z, (e.z - m.z) * is.z, be.z), 0.f), w.z, s);
+    s = fmaf(fmaxf(fmaf(g.w, (e.w - m.w) * is.w, be.w), 0.f), w.w, s);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const long row = base + ps * RPW + sub;
+    if (cl == 0 && row < rows) e3[row] = s + bias;
+  }
+  (void)a;
 }
 
 // adj[r,c] = sigmoid((e3[r,c] + e3[c,r]) / 2), zero diagonal     (parametrized_adj.py:66-70)
@@ -546,6 +637,66 @@ __global__ __launch_bounds__(256) void gs_pge_l3_bwd_stats_kernel(const float* _
     part[((long)blockIdx.x * 3 + 2) * Ph + k] = sg;
   }
 }
+// Same partials, streaming form for Ph = 4 * QG (QG = 64 or 32 column groups): a thread owns 4 columns and every RG-th row of
+// the block's rows (RG = 256 / QG), loads 8 rows of E2 as float4 before touching them, and selects instead of branching;
+// the RG row groups meet in LDS.  Same fp64 accumulation; rows are visited in a different order than the scalar kernel.
+template <int QG>
+__global__ __launch_bounds__(256) void gs_pge_l3_bwd_stats_v4_kernel(const float* __restrict__ E2, const float* __restrict__ de3,
+                                                                     const float* __restrict__ mu2, const float* __restrict__ is2,
+                                                                     const float* __restrict__ g2, const float* __restrict__ be2,
+                                                                     const float* __restrict__ w2, long rows, int rows_per_block,
+                                                                     double* __restrict__ part) {
+  constexpr int Ph = 4 * QG, RG = 256 / QG, UN = 8;
+  const int cg = threadIdx.x % QG, rg = threadIdx.x / QG, k = 4 * cg;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  const float4 m = *reinterpret_cast<const float4*>(mu2 + k), is = *reinterpret_cast<const float4*>(is2 + k);
+  const float4 g = *reinterpret_cast<const float4*>(g2 + k), be = *reinterpret_cast<const float4*>(be2 + k);
+  const float4 w = *reinterpret_cast<const float4*>(w2 + k);
+  const float mm[4] = {m.x, m.y, m.z, m.w}, ii[4] = {is.x, is.y, is.z, is.w}, gg[4] = {g.x, g.y, g.z, g.w};
+  const float bb[4] = {be.x, be.y, be.z, be.w}, ww[4] = {w.x, w.y, w.z, w.w};
+  double sw[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
+  for (long rb = r0 + rg; rb < r1; rb += (long)UN * RG) {
+    float4 e[UN];
+    float d[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long r = min(rb + (long)u * RG, r1 - 1);
+      e[u] = *reinterpret_cast<const float4*>(E2 + r * Ph + k);
+      d[u] = de3[r];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const bool in = rb + (long)u * RG < r1;
+      const float ev[4] = {e[u].x, e[u].y, e[u].z, e[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (ev[j] - mm[j]) * ii[j];
+        const float y = fmaf(gg[j], xh, bb[j]);
+        const bool on = in && y > 0.f;
+        const float dy = d[u] * ww[j];
+        sw[j] += on ? (double)(d[u] * y) : 0.0;
+        sb[j] += on ? (double)dy : 0.0;
+        sg[j] += on ? (double)(dy * xh) : 0.0;
+      }
+    }
+  }
+  __shared__ double sh[3][RG][Ph];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sh[0][rg][k + j] = sw[j];
+    sh[1][rg][k + j] = sb[j];
+    sh[2][rg][k + j] = sg[j];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 3 * Ph; t += 256) {
+    const int q = t / Ph, kk = t % Ph;
+    double a = 0;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) a += sh[q][r][kk];
+    part[((long)blockIdx.x * 3 + q) * Ph + kk] = a;
+  }
+}
+
 // sums[q][k] = sum over partial blocks (fp64).  grid = (ceil(Ph/32), nq); block = 32 columns x 8 groups
 __global__ __launch_bounds__(256) void gs_sum_parts_kernel(const double* __restrict__ part, int nblk, int nq, int Ph,
     double* __restrict__ sums) {

@@ -79,7 +79,7 @@ typedef struct gs_gemm_desc {
 int gs_gemm_set_tuning(int bk_small, int bk_big);
 /* Routing of latency-bound products to the one-tile-per-workgroup kernel (32x32 tile, K split over the 4 waves, fragments
    fetched straight from global memory): taken when the 32x32 tile count is <= max_tiles and the product is <= max_gflop
-   (defaults 1024 / 1.5); max_tiles = 0 switches it off.  A measurement knob. */
+   (defaults 8192 / 1.5); max_tiles = 0 switches it off.  A measurement knob. */
 int gs_gemm_set_small(long max_tiles, double max_gflop);
 /* number of M tiles gs_gemm_f32 will use for this descriptor (first dimension of colstat) */
 int gs_gemm_tiles_m(const gs_gemm_desc* d);

@@ -14,7 +14,7 @@ from graphslim_amd.engine import gemm  # noqa: E402
 
 dev = "cuda:0"
 L = _lib.lib()
-CFG = {"off": (0, 0.0), "on": (1024, 1.5)}
+CFG = {"off": (0, 0.0), "on": (8192, 1.5)}
 if len(sys.argv) > 1:
     for a in sys.argv[1:]:
         t, g = a.split(":")
