@@ -5,9 +5,10 @@
 
 A "step" is one outer-loop iteration of condensation/gcond.py:47-72 on the HIP engine: GPU neighbour sampling for all
 40 classes, real-side class gradients, PGE forward + normalisation, gradient matching with its closed-form second-order
-backward, PGE backward, one Adam step (PGE or X~), PGE inference and `inner_loop` = 3 SGC steps.  The K timed steps sweep
-one 50-epoch PGE/feature cycle (20 % of them are PGE-update iterations, like the full 600-epoch job), and theta is
-re-initialised whenever the epoch changes (gcond.py:42-45).  Inputs are resident in HBM before the timed region.
+backward, PGE backward, one Adam step (PGE or X~), PGE inference and `inner_loop` = 3 SGC steps.  The K timed steps keep
+the job's mix and cadence: 20 % of them are PGE-update iterations (like the full 600-epoch job) and theta is re-initialised
+every `outer_loop` = 20 iterations, i.e. whenever the epoch changes (gcond.py:42-45).  Inputs are resident in HBM before
+the timed region.
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, live HIP-event timing) and
 `cpu_baseline` (the CPU oracle — a port of the reference path — on a bounded sample of the same workload).
@@ -83,14 +84,13 @@ def new_model(p, eng):
 
 
 def run_steps(p, eng, k, cycle_len):
-    """k outer iterations sweeping epochs 0..49 uniformly; fresh theta when the epoch changes."""
-    last = -1
+    """k outer iterations with the job's own mix and cadence: the first 20 % are PGE-update iterations (epoch % 50 < 10,
+    gcond.py:58-61), the rest feature-update iterations, and theta is re-drawn and uploaded every `outer_loop` iterations —
+    an epoch of the real job is `outer_loop` consecutive iterations on one theta (gcond.py:42-47)."""
     for i in range(k):
-        epoch = (i * 50) // cycle_len
-        if epoch != last:
+        if i % p["outer"] == 0:
             new_model(p, eng)
-            last = epoch
-        eng.outer_step(epoch)
+        eng.outer_step(0 if i * 5 < cycle_len else 10)
 
 
 def roofline_probe(eng, reps=20):

@@ -1085,11 +1085,11 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
                          e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, (float*)nullptr, e->Gs, 1);
       GS_LAUNCH_CHECK();
       { gs_gemm_desc g = mk(e->S_in, 1, h, e->Gs, C, 1, e->g_model + e->oWl, C, h, C, n); GS_TRY(gs_gemm_f32(&g, stream)); }
-      GS_TRY(colsum_batched(e, e->Gs, 0, n, nullptr, C, 1, e->g_model + e->obl, 0, stream));
+      { gs_gemm_desc g = mk(e->ones, 0, 1, e->Gs, C, 1, e->g_model + e->obl, C, 1, C, n); GS_TRY(gs_gemm_f32(&g, stream)); }   // gb2 = 1^T G
       { gs_gemm_desc g = mk(e->Gs, C, 1, th + e->oWl, 1, C, e->dSs, h, n, h, C); GS_TRY(gs_gemm_f32(&g, stream)); }
       { gs_gemm_desc g = mk(A, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n); g.mask = e->H1s; g.ldmask = h; GS_TRY(gs_gemm_f32(&g, stream)); }
       { gs_gemm_desc g = mk(e->S1, 1, d, e->dH1m, h, 1, e->g_model + e->oW1, h, d, h, n); GS_TRY(gs_gemm_f32(&g, stream)); }
-      GS_TRY(colsum_batched(e, e->dH1m, 0, n, nullptr, h, 1, e->g_model + e->ob1, 0, stream));
+      { gs_gemm_desc g = mk(e->ones, 0, 1, e->dH1m, h, 1, e->g_model + e->ob1, h, 1, h, n); GS_TRY(gs_gemm_f32(&g, stream)); }   // gb1 = 1^T dH1p (one launch)
       GS_TRY(gs_adam_step_f32(th, e->g_model, e->m_model, e->v_model, e->P, e->cfg.lr_model, 0.9f, 0.999f, 1e-8f, 0.f,
                               ++e->step_model, stream));
     }
@@ -1130,7 +1130,8 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
       GS_TRY(gs_gemm_f32(&dh, stream));
       gs_gemm_desc w1 = mk(X, 1, d, e->dH1m, h, 1, e->g_model + e->oW1, h, d, h, n);     // X^T dHp
       GS_TRY(gs_gemm_f32(&w1, stream));
-      GS_TRY(colsum_batched(e, e->dH1m, 0, n, nullptr, h, 1, e->g_model + e->ob1, 0, stream));
+      gs_gemm_desc b1g = mk(e->ones, 0, 1, e->dH1m, h, 1, e->g_model + e->ob1, h, 1, h, n);   // gb1 = 1^T dHp (one launch)
+      GS_TRY(gs_gemm_f32(&b1g, stream));
     }
     GS_TRY(gs_adam_step_f32(th, e->g_model, e->m_model, e->v_model, e->P, e->cfg.lr_model, 0.9f, 0.999f, 1e-8f, 0.f,
                             ++e->step_model, stream));
