@@ -327,7 +327,11 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->aux = nullptr; e->ev_fork = e->ev_join = nullptr; e->join_pending = false;
   e->reuse_fwd = false; e->fwd_cached = false;
   e->blk_cur = 0; e->prefetched = false; e->identity = false;
-  e->overlap = (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) == hipSuccess) &&
+  // the real-side branch is the longer of the two concurrent branches (kernel trace, r01): its stream gets the higher
+  // priority so that its latency-bound kernels are not queued behind the PGE forward's big GEMM
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  e->overlap = (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, prio_hi) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess);
   *out = e;
@@ -580,8 +584,12 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     int* kcount = e->kcount + c0;
     gs_gemm_desc g = mk(Zr, C, 1, th + e->oWl, 1, C, Tm, h, Cl * bcap, h, C);
     GS_TRY(gs_gemm_f32(&g, stream));
-    hipLaunchKernelGGL(gs_csc_spmm_t_kernel, dim3(gs_cdiv((long)Cl * cap1, 4)), dim3(256), 0, s, b.tptr1, b.tedge1, b.val1, b.n1,
-                       cap1, bcap, f1, Tm, h, Y1, Cl);
+    if (h == 256)
+      hipLaunchKernelGGL(gs_csc_spmm_t_v4_kernel, dim3(gs_cdiv((long)Cl * cap1, 4)), dim3(256), 0, s, b.tptr1, b.tedge1, b.val1, b.n1,
+                         cap1, bcap, f1, Tm, Y1, Cl);
+    else
+      hipLaunchKernelGGL(gs_csc_spmm_t_kernel, dim3(gs_cdiv((long)Cl * cap1, 4)), dim3(256), 0, s, b.tptr1, b.tedge1, b.val1, b.n1,
+                         cap1, bcap, f1, Tm, h, Y1, Cl);
     const bool fused = (e->cfg.dis_metric == 0);   // 'ours' needs no bias gradient -> Bmat is generated inside the GEMM
     if (fused)
       hipLaunchKernelGGL(gs_kcount_kernel, dim3(gs_cdiv(Cl, 64)), dim3(64), 0, s, b.n1, f2, Cl, kcount);

@@ -349,6 +349,43 @@ __global__ __launch_bounds__(256) void gs_csc_spmm_t_kernel(const int* __restric
   }
 }
 
+// F = 256: one wave per frontier row, each lane owns 4 consecutive columns (one 16-byte load per in-edge, the edge list is
+// walked once instead of once per 64-column slice).
+__global__ __launch_bounds__(256) void gs_csc_spmm_t_v4_kernel(const int* __restrict__ tptr, const int* __restrict__ tedge,
+                                                               const float* __restrict__ val1, const int* __restrict__ n1,
+                                                               int cap1, int bcap, int f1, const float* __restrict__ Tm,
+                                                               float* __restrict__ Y1, int nclass) {
+  constexpr int F = 256;
+  const int lane = threadIdx.x & 63;
+  const long grow = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (grow >= (long)nclass * cap1) return;
+  const int c = (int)(grow / cap1), l = (int)(grow - (long)c * cap1);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (l < n1[c]) {
+    const int* tp = tptr + (long)c * (cap1 + 1);
+    const int* te = tedge + (long)c * bcap * f1;
+    const float* vv = val1 + (long)c * bcap * f1;
+    const float* tm = Tm + (long)c * bcap * F + 4 * lane;
+    const int a = tp[l], b = tp[l + 1];
+    int i = a;
+    for (; i + 1 < b; i += 2) {                 // two edges in flight
+      const int s0 = te[i], s1 = te[i + 1];
+      const float w0 = vv[s0], w1 = vv[s1];
+      const float4 t0 = *reinterpret_cast<const float4*>(tm + (long)(s0 / f1) * F);
+      const float4 t1 = *reinterpret_cast<const float4*>(tm + (long)(s1 / f1) * F);
+      acc.x = fmaf(w0, t0.x, acc.x); acc.y = fmaf(w0, t0.y, acc.y); acc.z = fmaf(w0, t0.z, acc.z); acc.w = fmaf(w0, t0.w, acc.w);
+      acc.x = fmaf(w1, t1.x, acc.x); acc.y = fmaf(w1, t1.y, acc.y); acc.z = fmaf(w1, t1.z, acc.z); acc.w = fmaf(w1, t1.w, acc.w);
+    }
+    if (i < b) {
+      const int s0 = te[i];
+      const float w0 = vv[s0];
+      const float4 t0 = *reinterpret_cast<const float4*>(tm + (long)(s0 / f1) * F);
+      acc.x = fmaf(w0, t0.x, acc.x); acc.y = fmaf(w0, t0.y, acc.y); acc.z = fmaf(w0, t0.z, acc.z); acc.w = fmaf(w0, t0.w, acc.w);
+    }
+  }
+  *reinterpret_cast<float4*>(Y1 + grow * F + 4 * lane) = acc;
+}
+
 // Bmat[(c,l,j), :] = val0 * [H1full[col0, :] > 0] * Y1[(c,l), :]    (d loss / d pre-activation, per edge)
 __global__ __launch_bounds__(256) void gs_make_bmat_kernel(const int* __restrict__ col0, const float* __restrict__ val0,
                                                            const int* __restrict__ n1, int cap1, int f2,
