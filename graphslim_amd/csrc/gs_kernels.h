@@ -34,12 +34,34 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
     for (int j = 0; j < f; ++j) s += val[ebase + j] * (rs_in ? rs_in[cb + col[ebase + j]] : 1.f);
     rs_out[grow] = s;
   }
+  // the row's (col, val) pairs are fetched once by lanes 0..f-1 and read back with v_readlane (wave-uniform j; works when
+  // only some lanes run the column loop, F < 256); the gathers go out four at a time before their FMAs (same j order as a
+  // plain loop: identical sums)
+  const int ecol = (lane < f) ? col[ebase + lane] : 0;
+  const int evalb = (lane < f) ? __float_as_int(val[ebase + lane]) : 0;
   for (int c0 = lane * VEC; c0 < F; c0 += 64 * VEC) {
     if (VEC == 4) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int j = 0; j < f; ++j) {
-        float w = val[ebase + j];
-        float4 x = *reinterpret_cast<const float4*>(src + (cb + col[ebase + j]) * ld_src + c0);
+      int j = 0;
+      for (; j + 4 <= f; j += 4) {
+        float w[4];
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          w[u] = __int_as_float(__builtin_amdgcn_readlane(evalb, j + u));
+          x[u] = *reinterpret_cast<const float4*>(src + (cb + __builtin_amdgcn_readlane(ecol, j + u)) * ld_src + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc.x = fmaf(w[u], x[u].x, acc.x);
+          acc.y = fmaf(w[u], x[u].y, acc.y);
+          acc.z = fmaf(w[u], x[u].z, acc.z);
+          acc.w = fmaf(w[u], x[u].w, acc.w);
+        }
+      }
+      for (; j < f; ++j) {
+        const float w = __int_as_float(__builtin_amdgcn_readlane(evalb, j));
+        const float4 x = *reinterpret_cast<const float4*>(src + (cb + __builtin_amdgcn_readlane(ecol, j)) * ld_src + c0);
         acc.x = fmaf(w, x.x, acc.x);
         acc.y = fmaf(w, x.y, acc.y);
         acc.z = fmaf(w, x.z, acc.z);
