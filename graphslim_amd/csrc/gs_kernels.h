@@ -904,32 +904,56 @@ __global__ __launch_bounds__(256) void gs_pge_marginal_c_kernel(const float* __r
   }
 }
 // BN-1 backward from the marginals (see oracle/analytic.py:pge_bwd); block = 32 columns x 8 row groups
-__global__ __launch_bounds__(256) void gs_pge_bn1_bwd_cols_kernel(const float* __restrict__ U, const float* __restrict__ V,
-                                                                  const float* __restrict__ rowsum_c,
-                                                                  const float* __restrict__ colsum_r,
-                                                                  const float* __restrict__ b0, const float* __restrict__ mu1,
-                                                                  const float* __restrict__ is1, int n, int Ph,
-                                                                  float* __restrict__ dg1, float* __restrict__ dbe1) {
+__global__ __launch_bounds__(1024) void gs_pge_bn1_bwd_cols_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                                   const float* __restrict__ rowsum_c,
+                                                                   const float* __restrict__ colsum_r,
+                                                                   const float* __restrict__ b0, const float* __restrict__ mu1,
+                                                                   const float* __restrict__ is1, int n, int Ph,
+                                                                   float* __restrict__ dg1, float* __restrict__ dbe1) {
+  // 32 columns x 32 row groups, 4 rows x 4 arrays of loads in flight per thread (tiny matrices, critical path)
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + tx;
-  __shared__ double sh[3][8][32];
+  const int k = min(blockIdx.x * 32 + tx, Ph - 1);
+  __shared__ double sh[3][GS_BN1_RG][32];
   double sb = 0, su = 0, sv = 0;
-  if (k < Ph)
-    for (int i = ty; i < n; i += 8) {
-      float rc = rowsum_c[(long)i * Ph + k];
-      sb += rc;
-      su += (double)U[(long)i * Ph + k] * rc;
-      sv += (double)V[(long)i * Ph + k] * colsum_r[(long)i * Ph + k];
+  for (int i0 = ty; i0 < n; i0 += 4 * GS_BN1_RG) {
+    float rc[4], u[4], v[4], cr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long o = (long)min(i0 + j * GS_BN1_RG, n - 1) * Ph + k;
+      rc[j] = rowsum_c[o]; u[j] = U[o]; v[j] = V[o]; cr[j] = colsum_r[o];
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j * GS_BN1_RG < n) {
+        sb += rc[j];
+        su += (double)u[j] * rc[j];
+        sv += (double)v[j] * cr[j];
+      }
+  }
   sh[0][ty][tx] = sb;
   sh[1][ty][tx] = su;
   sh[2][ty][tx] = sv;
   __syncthreads();
-  if (ty == 0 && k < Ph) {
+  if (ty == 0 && blockIdx.x * 32 + tx < Ph) {
     sb = su = sv = 0;
-    for (int q = 0; q < 8; ++q) { sb += sh[0][q][tx]; su += sh[1][q][tx]; sv += sh[2][q][tx]; }
+    for (int q = 0; q < GS_BN1_RG; ++q) { sb += sh[0][q][tx]; su += sh[1][q][tx]; sv += sh[2][q][tx]; }
     dbe1[k] = (float)sb;
     dg1[k] = (float)((su + sv + ((double)b0[k] - (double)mu1[k]) * sb) * (double)is1[k]);
+  }
+}
+// out[c][r] = in[r][c] for a small matrix (weights): lets a product that wants W^T as its n-contiguous operand run with both
+// operands k-contiguous
+__global__ void gs_transpose_small_kernel(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    t[j][threadIdx.x] = (r < rows && c < cols) ? in[(long)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (c < cols && r < rows) out[(long)c * rows + r] = t[threadIdx.x][j];
   }
 }
 __global__ void gs_pge_bn1_bwd_uv_kernel(const float* __restrict__ U, const float* __restrict__ V,
