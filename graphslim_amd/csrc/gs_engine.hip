@@ -58,7 +58,7 @@ struct gs_gcond {
       *drs, *dQ, *dAn, *d_adj, *d_feat, *dH2, *dHp, *A1m, *Bc, *dH1m, *slabs_x;
   // PGE
   float *U, *V, *mu1, *is1, *mu2, *is2, *sumU, *sumV, *A1, *E2, *e3, *de3, *dE2, *dY1, *rowsum_c, *colsum_r, *dU, *dV, *d_pge,
-      *slabs_w, *W1T;
+      *slabs_w, *W1T, *W1mT;
   double* parts;
   // inner loop
   float *adj_norm_in, *rnorm_in, *Qin, *rsq_in, *S_in, *g_model;
@@ -201,7 +201,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->A1 = w.take<float>(n2 * Ph); e->E2 = w.take<float>(n2 * Ph); e->e3 = w.take<float>(n2); e->de3 = w.take<float>(n2);
   e->dE2 = w.take<float>(n2 * Ph); e->dY1 = w.take<float>(n2 * Ph);
   e->ar_marg = w.take<float>(2 * n * Ph);     // [rowsum_c | colsum_r] contiguous (one all-reduce)
-  e->rowsum_c = e->ar_marg; e->colsum_r = e->ar_marg ? e->ar_marg + n * Ph : nullptr; e->dU = w.take<float>(n * Ph); e->W1T = w.take<float>(Ph * Ph);
+  e->rowsum_c = e->ar_marg; e->colsum_r = e->ar_marg ? e->ar_marg + n * Ph : nullptr; e->dU = w.take<float>(n * Ph); e->W1T = w.take<float>(Ph * Ph); e->W1mT = w.take<float>(d * h);
   e->dV = w.take<float>(n * Ph); e->d_pge = w.take<float>(e->Ppge); e->slabs_w = w.take<float>(e->nsplit_w * Ph * Ph);
   e->parts = w.take<double>((long)e->nblk_stats * 3 * Ph);
   e->sums = w.take<double>(3 * Ph);
@@ -551,7 +551,10 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   const float* src = e->io.X;
   long ld_src = e->ldx;
   if (e->T == 2) {   // H1full = relu(X W1 + b1) for every node once: theta is shared by all classes
-    gs_gemm_desc g = mk(e->io.X, e->ldx, 1, th + e->oW1, h, 1, e->H1full, h, e->N, h, d);
+    // (W1 transposed first so that both operands are k-contiguous — see the dY1 product)
+    hipLaunchKernelGGL(gs_transpose_small_kernel, dim3(gs_cdiv(h, 32), gs_cdiv(d, 32)), dim3(32, 8), 0, s, th + e->oW1, d, h, e->W1mT);
+    GS_LAUNCH_CHECK();
+    gs_gemm_desc g = mk(e->io.X, e->ldx, 1, e->W1mT, 1, d, e->H1full, h, e->N, h, d);
     g.bias = th + e->ob1;
     g.relu = 1;
     GS_TRY(gs_gemm_f32(&g, stream));

@@ -407,6 +407,7 @@ def test_sibling_methods_reduce_api(tmp_path):
                     "2", "--condense_model", "SGC", "--save_path", str(tmp_path)], standalone_mode=False)
         args.run_inter_eval = 1
         graph = get_dataset(args.dataset, args)
+        __import__('graphslim_amd.host', fromlist=['seed_everything']).seed_everything(args.seed)   # train_all.py:22 (the example script itself runs unseeded)
         reduced = cls(setting=args.setting, data=graph, args=args).reduce(graph, verbose=False)
         n = reduced.feat_syn.shape[0]
         if method != "doscond":
@@ -513,6 +514,7 @@ def test_gcn_condense_model_reduce_api(tmp_path):
     assert args.condense_model == "GCN" and args.dis_metric == "mse" and args.outer_loop == 3
     args.run_inter_eval = 1
     graph = get_dataset(args.dataset, args)
+    __import__('graphslim_amd.host', fromlist=['seed_everything']).seed_everything(args.seed)   # train_all.py:22 (the example script itself runs unseeded)
     reduced = DosCond(setting=args.setting, data=graph, args=args).reduce(graph, verbose=False)
     assert torch.isfinite(reduced.feat_syn).all() and torch.isfinite(reduced.adj_syn).all()
     adj = reduced.adj_syn.cpu()
