@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Whole jobs at the product configurations (examples/train_gcond.py's five calls, configs/gcond/*.json) on the
+dataset-shaped synthetic graphs: wall time of reduce (all epochs, checkpoints with intermediate evaluation) and of the final
+evaluation, and the accuracy.  usage: full_runs.py dataset:rate [...]"""
+import os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import graphslim  # noqa: F401
+from graphslim.config import cli
+from graphslim.condensation import GCond
+from graphslim.dataset import get_dataset
+from graphslim.evaluation.eval_agent import Evaluator
+from graphslim_amd.host import seed_everything
+
+for spec in sys.argv[1:]:
+    ds, rate = spec.split(":")
+    args = cli(["-D", ds, "-M", "gcond", "-R", rate, "-G", "0", "--save_path", tempfile.mkdtemp(prefix="gs_full_")], standalone_mode=False)
+    seed_everything(args.seed)
+    t0 = time.time(); graph = get_dataset(args.dataset, args); t1 = time.time()
+    agent = GCond(setting=args.setting, data=graph, args=args)
+    reduced = agent.reduce(graph, verbose=False); torch.cuda.synchronize(); t2 = time.time()
+    mean, std = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False); t3 = time.time()
+    print(f"FULL {ds} r={rate} setting={args.setting} N={graph.num_nodes} n'={agent.nnodes_syn} epochs={args.epochs} outer={args.outer_loop} "
+          f"inner={args.inner_loop}: data {t1 - t0:.1f}s  reduce {t2 - t1:.1f}s ({args.epochs * args.outer_loop} outer iterations, "
+          f"{(args.epochs * args.outer_loop) / (t2 - t1):.0f} it/s incl. checkpoints)  final eval ({args.run_eval} runs x {args.eval_epochs} epochs) "
+          f"{t3 - t2:.1f}s  acc {100 * mean:.2f} +/- {100 * std:.2f}", flush=True)
