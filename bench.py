@@ -218,6 +218,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # GS_DIST_BACKEND=gloo + GS_SHARE_DEVICE=1 lets several ranks share ONE GPU (RCCL refuses that): a functional check of
+    # this multi-process path on a single-GPU box; the numbers it prints are meaningless.
+    backend = os.environ.get("GS_DIST_BACKEND", "nccl")
+    if os.environ.get("GS_SHARE_DEVICE") == "1":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
@@ -225,7 +230,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     elif args.gpus > 1:
         raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     p = build_problem(args.workload, seed=1, scale=args.scale)
