@@ -630,10 +630,10 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
   if (part == 1) {
     e->fwd_cached = false;
     {  // U = X W0[:, :d]^T ; V = X W0[:, d:]^T
-      gs_gemm_desc g = mk(X, d, 1, pp + e->pW0, 1, 2L * d, e->U, Ph, n, Ph, d);
-      GS_TRY(gs_gemm_f32(&g, stream));
-      g.B = pp + e->pW0 + d; g.C = e->V;
-      GS_TRY(gs_gemm_f32(&g, stream));
+      gs_gemm_desc uv[2];
+      uv[0] = mk(X, d, 1, pp + e->pW0, 1, 2L * d, e->U, Ph, n, Ph, d);
+      uv[1] = uv[0]; uv[1].B = pp + e->pW0 + d; uv[1].C = e->V;
+      GS_TRY(gs_gemm_group_f32(uv, 2, stream));          // independent: one launch
     }
     hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 32)), dim3(1024), 0, s, e->U, e->V, pp + e->pb0, n, Ph, e->mu1,
                        e->is1, e->sumU, e->sumV);
@@ -817,17 +817,17 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     if (e->identity) return GS_OK;
     return gs_dense_gcn_norm_bwd(e->adj_raw, e->rnorm, e->dAn, n, e->d_adj, stream);
   }
-  {  // Q = A A ; rsq = Q 1
-    gs_gemm_desc g = mk(A, n, 1, A, n, 1, e->Q, n, n, n, n);
-    GS_TRY(gs_gemm_f32(&g, stream));
-    hipLaunchKernelGGL(gs_rowsum_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Q, n, n, e->rsq);
-  }
   const float* Hin = X;   // [n x F]
-  if (e->T == 2) {
-    gs_gemm_desc g = mk(X, d, 1, th + e->oW1, h, 1, e->H1s, h, n, h, d);
-    g.bias = th + e->ob1; g.relu = 1;
-    GS_TRY(gs_gemm_f32(&g, stream));
-    Hin = e->H1s;
+  {  // Q = A A ; rsq = Q 1 ; (T = 2) H1 = relu(X W1 + b1) — the two products are independent: one launch
+    gs_gemm_desc qh[2];
+    qh[0] = mk(A, n, 1, A, n, 1, e->Q, n, n, n, n);
+    if (e->T == 2) {
+      qh[1] = mk(X, d, 1, th + e->oW1, h, 1, e->H1s, h, n, h, d);
+      qh[1].bias = th + e->ob1; qh[1].relu = 1;
+      Hin = e->H1s;
+    }
+    GS_TRY(gs_gemm_group_f32(qh, e->T == 2 ? 2 : 1, stream));
+    hipLaunchKernelGGL(gs_rowsum_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Q, n, n, e->rsq);
   }
   {  // S = Q Hin ; Z = S Wl ; P, G
     gs_gemm_desc g = mk(e->Q, n, 1, Hin, F, 1, e->Ss, F, n, F, n);
@@ -846,21 +846,23 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   }
   const float* Dl = Dv + e->oWl;   // + c*P : d/d gWl_c
   if (Cl > 0) {
-    {  // last layer: gWl_c = S[lo:hi]^T G[lo:hi] ; gbl_c = rs[lo:hi]^T G[lo:hi]
-      gs_gemm_desc g = mk(e->Ss, 1, F, e->Gs, C, 1, gws + e->oWl, C, F, C, mx);
-      g.nb1 = Cl; g.offA = off_loF; g.offB = off_loC; g.Kb = ncls; g.sCb1 = P;
-      GS_TRY(gs_gemm_f32(&g, stream));
-      gs_gemm_desc gb = mk(e->rsq, 0, 1, e->Gs, C, 1, gws + e->obl, C, 1, C, mx);
-      gb.nb1 = Cl; gb.offA = off_lo; gb.offB = off_loC; gb.Kb = ncls; gb.sCb1 = P;
-      GS_TRY(gs_gemm_f32(&gb, stream));
-    }
     float* dH2 = e->T == 2 ? e->dH2 + c0 * n * C : nullptr; float* dHp = e->T == 2 ? e->dHp + c0 * n * h : nullptr;
     float* A1m = e->T == 2 ? e->A1m + c0 * n * h : nullptr; float* Bc = e->T == 2 ? e->Bc + c0 * n * C : nullptr;
+    {
+      // gWl_c, gbl_c and (T = 2) dH2_c = Q[lo:hi]^T G[lo:hi] only read G: one launch
+      gs_gemm_desc g3[3];
+      g3[0] = mk(e->Ss, 1, F, e->Gs, C, 1, gws + e->oWl, C, F, C, mx);
+      g3[0].nb1 = Cl; g3[0].offA = off_loF; g3[0].offB = off_loC; g3[0].Kb = ncls; g3[0].sCb1 = P;
+      g3[1] = mk(e->rsq, 0, 1, e->Gs, C, 1, gws + e->obl, C, 1, C, mx);
+      g3[1].nb1 = Cl; g3[1].offA = off_lo; g3[1].offB = off_loC; g3[1].Kb = ncls; g3[1].sCb1 = P;
+      if (e->T == 2) {
+        g3[2] = mk(e->Q, 1, n, e->Gs, C, 1, dH2, C, n, C, mx);
+        g3[2].nb1 = Cl; g3[2].offA = off_lon; g3[2].offB = off_loC; g3[2].Kb = ncls; g3[2].sCb1 = (long)n * C;
+      }
+      GS_TRY(gs_gemm_group_f32(g3, e->T == 2 ? 3 : 2, stream));
+    }
     if (e->T == 2) {
-      // dH2_c = Q[lo:hi]^T G[lo:hi]  [n x C] ; dHp_c = (dH2_c W2^T) * mask ; gW1_c = X^T dHp_c ; gb1_c = colsum
-      gs_gemm_desc a = mk(e->Q, 1, n, e->Gs, C, 1, dH2, C, n, C, mx);
-      a.nb1 = Cl; a.offA = off_lon; a.offB = off_loC; a.Kb = ncls; a.sCb1 = (long)n * C;
-      GS_TRY(gs_gemm_f32(&a, stream));
+      // dHp_c = (dH2_c W2^T) * mask ; gW1_c = X^T dHp_c ; gb1_c = colsum
       gs_gemm_desc b = mk(dH2, C, 1, Wl, 1, C, dHp, h, n, h, C);
       b.nb1 = Cl; b.sAb1 = (long)n * C; b.sCb1 = (long)n * h; b.mask = e->H1s; b.ldmask = h;
       GS_TRY(gs_gemm_f32(&b, stream));
@@ -883,24 +885,25 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     // ---- second-order backward, per-class part ------------------------------------------------------
     if (e->T == 2) {
       // A1m_c = (X D1_c + Db1_c) * mask ; dX slabs_c = dHp_c D1_c^T ; Bc = A1m_c W2
-      gs_gemm_desc a = mk(X, d, 1, Dv + e->oW1, h, 1, A1m, h, n, h, d);
-      a.nb1 = Cl; a.sBb1 = P; a.sCb1 = (long)n * h; a.bias = Dv + e->ob1; a.sbias_b1 = P; a.mask = e->H1s; a.ldmask = h;
-      GS_TRY(gs_gemm_f32(&a, stream));
-      gs_gemm_desc x = mk(dHp, h, 1, Dv + e->oW1, 1, h, e->slabs_x, d, n, d, h);
-      x.nb1 = Cl; x.sAb1 = (long)n * h; x.sBb1 = P; x.sCb1 = (long)n * d;
-      GS_TRY(gs_gemm_f32(&x, stream));
+      gs_gemm_desc ax[2];
+      ax[0] = mk(X, d, 1, Dv + e->oW1, h, 1, A1m, h, n, h, d);
+      ax[0].nb1 = Cl; ax[0].sBb1 = P; ax[0].sCb1 = (long)n * h; ax[0].bias = Dv + e->ob1; ax[0].sbias_b1 = P; ax[0].mask = e->H1s;
+      ax[0].ldmask = h;
+      ax[1] = mk(dHp, h, 1, Dv + e->oW1, 1, h, e->slabs_x, d, n, d, h);
+      ax[1].nb1 = Cl; ax[1].sAb1 = (long)n * h; ax[1].sBb1 = P; ax[1].sCb1 = (long)n * d;
+      GS_TRY(gs_gemm_group_f32(ax, 2, stream));          // independent of each other
       GS_TRY(gs_reduce_slabs_f32(e->d_feat, e->slabs_x, (long)n * d, Cl, (long)n * d, 0.f, stream));
       gs_gemm_desc b = mk(A1m, h, 1, Wl, C, 1, Bc, C, n, C, h);
       b.nb1 = Cl; b.sAb1 = (long)n * h; b.sCb1 = (long)n * C;
       GS_TRY(gs_gemm_f32(&b, stream));
       // dQ[lo:hi] = G[lo:hi] Bc_c^T
-      gs_gemm_desc q = mk(e->Gs, C, 1, Bc, 1, C, e->dQ, n, mx, n, C);
-      q.nb1 = Cl; q.offA = off_loC; q.Mb = ncls; q.sBb1 = (long)n * C; q.offC = off_lon;
-      GS_TRY(gs_gemm_f32(&q, stream));
+      gs_gemm_desc qu[2];
+      qu[0] = mk(e->Gs, C, 1, Bc, 1, C, e->dQ, n, mx, n, C);
+      qu[0].nb1 = Cl; qu[0].offA = off_loC; qu[0].Mb = ncls; qu[0].sBb1 = (long)n * C; qu[0].offC = off_lon;
       // Ug[lo:hi] = Q[lo:hi] Bc_c + S[lo:hi] D2_c
-      gs_gemm_desc u = mk(e->Q, n, 1, Bc, C, 1, e->Ug, C, mx, C, n);
-      u.nb1 = Cl; u.offA = off_lon; u.Mb = ncls; u.sBb1 = (long)n * C; u.offC = off_loC;
-      GS_TRY(gs_gemm_f32(&u, stream));
+      qu[1] = mk(e->Q, n, 1, Bc, C, 1, e->Ug, C, mx, C, n);
+      qu[1].nb1 = Cl; qu[1].offA = off_lon; qu[1].Mb = ncls; qu[1].sBb1 = (long)n * C; qu[1].offC = off_loC;
+      GS_TRY(gs_gemm_group_f32(qu, 2, stream));
       gs_gemm_desc u2 = mk(e->Ss, F, 1, Dl, C, 1, e->Ug, C, mx, C, F);
       u2.nb1 = Cl; u2.offA = off_loF; u2.Mb = ncls; u2.sBb1 = P; u2.offC = off_loC; u2.beta = 1.f;
       GS_TRY(gs_gemm_f32(&u2, stream));
@@ -924,17 +927,17 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     GS_TRY(gs_gemm_f32(&b, stream));
   }
   if (e->T == 1) {
-    gs_gemm_desc a = mk(e->Q, 1, n, e->dSs, d, 1, e->d_feat, d, n, d, n);   // dX = Q^T dS
-    GS_TRY(gs_gemm_f32(&a, stream));
-    gs_gemm_desc b = mk(e->dSs, d, 1, X, 1, d, e->dQ, n, n, n, d);          // dQ = dS X^T
-    GS_TRY(gs_gemm_f32(&b, stream));
+    gs_gemm_desc ab1[2];
+    ab1[0] = mk(e->Q, 1, n, e->dSs, d, 1, e->d_feat, d, n, d, n);   // dX = Q^T dS
+    ab1[1] = mk(e->dSs, d, 1, X, 1, d, e->dQ, n, n, n, d);          // dQ = dS X^T
+    GS_TRY(gs_gemm_group_f32(ab1, 2, stream));
   } else {
-    gs_gemm_desc a = mk(e->Q, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n);     // (Q^T dS) * mask
-    a.mask = e->H1s; a.ldmask = h;
-    GS_TRY(gs_gemm_f32(&a, stream));
-    gs_gemm_desc b = mk(e->dSs, h, 1, e->H1s, 1, h, e->dQ, n, n, n, h);     // dQ += dS H1^T
-    b.beta = 1.f;
-    GS_TRY(gs_gemm_f32(&b, stream));
+    gs_gemm_desc ab2[2];
+    ab2[0] = mk(e->Q, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n);     // (Q^T dS) * mask
+    ab2[0].mask = e->H1s; ab2[0].ldmask = h;
+    ab2[1] = mk(e->dSs, h, 1, e->H1s, 1, h, e->dQ, n, n, n, h);     // dQ += dS H1^T
+    ab2[1].beta = 1.f;
+    GS_TRY(gs_gemm_group_f32(ab2, 2, stream));
     gs_gemm_desc c = mk(e->dH1m, h, 1, th + e->oW1, 1, h, e->d_feat, d, n, d, h);   // dX += dH1m W1^T
     c.beta = 1.f;
     GS_TRY(gs_gemm_f32(&c, stream));
@@ -1045,10 +1048,10 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
   if (need_param_grads) {
     hipLaunchKernelGGL(gs_colsum_small_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->dU, n, Ph, g + e->pb0);
     GS_LAUNCH_CHECK();
-    gs_gemm_desc a = mk(e->dU, 1, Ph, X, d, 1, g + e->pW0, 2L * d, Ph, d, n);       // dW0[:, :d] = dU^T X
-    GS_TRY(gs_gemm_f32(&a, stream));
-    gs_gemm_desc b = mk(e->dV, 1, Ph, X, d, 1, g + e->pW0 + d, 2L * d, Ph, d, n);   // dW0[:, d:] = dV^T X
-    GS_TRY(gs_gemm_f32(&b, stream));
+    gs_gemm_desc w0[2];
+    w0[0] = mk(e->dU, 1, Ph, X, d, 1, g + e->pW0, 2L * d, Ph, d, n);       // dW0[:, :d] = dU^T X
+    w0[1] = mk(e->dV, 1, Ph, X, d, 1, g + e->pW0 + d, 2L * d, Ph, d, n);   // dW0[:, d:] = dV^T X
+    GS_TRY(gs_gemm_group_f32(w0, 2, stream));
   }
   if (need_feat_grad) {   // d_feat += dU W0[:, :d] + dV W0[:, d:]
     gs_gemm_desc a = mk(e->dU, Ph, 1, pp + e->pW0, 2L * d, 1, e->d_feat, d, n, d, Ph);
@@ -1099,12 +1102,20 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
       hipLaunchKernelGGL(gs_syn_softmax_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Zs, e->ones, th + e->obl,
                          e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, (float*)nullptr, e->Gs, 1);
       GS_LAUNCH_CHECK();
-      { gs_gemm_desc g = mk(e->S_in, 1, h, e->Gs, C, 1, e->g_model + e->oWl, C, h, C, n); GS_TRY(gs_gemm_f32(&g, stream)); }
-      { gs_gemm_desc g = mk(e->ones, 0, 1, e->Gs, C, 1, e->g_model + e->obl, C, 1, C, n); GS_TRY(gs_gemm_f32(&g, stream)); }   // gb2 = 1^T G
-      { gs_gemm_desc g = mk(e->Gs, C, 1, th + e->oWl, 1, C, e->dSs, h, n, h, C); GS_TRY(gs_gemm_f32(&g, stream)); }
+      {
+        gs_gemm_desc g3[3];
+        g3[0] = mk(e->S_in, 1, h, e->Gs, C, 1, e->g_model + e->oWl, C, h, C, n);         // gW2 = S2^T G
+        g3[1] = mk(e->ones, 0, 1, e->Gs, C, 1, e->g_model + e->obl, C, 1, C, n);         // gb2 = 1^T G
+        g3[2] = mk(e->Gs, C, 1, th + e->oWl, 1, C, e->dSs, h, n, h, C);                  // dS2 = G W2^T
+        GS_TRY(gs_gemm_group_f32(g3, 3, stream));
+      }
       { gs_gemm_desc g = mk(A, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n); g.mask = e->H1s; g.ldmask = h; GS_TRY(gs_gemm_f32(&g, stream)); }
-      { gs_gemm_desc g = mk(e->S1, 1, d, e->dH1m, h, 1, e->g_model + e->oW1, h, d, h, n); GS_TRY(gs_gemm_f32(&g, stream)); }
-      { gs_gemm_desc g = mk(e->ones, 0, 1, e->dH1m, h, 1, e->g_model + e->ob1, h, 1, h, n); GS_TRY(gs_gemm_f32(&g, stream)); }   // gb1 = 1^T dH1p (one launch)
+      {
+        gs_gemm_desc g2[2];
+        g2[0] = mk(e->S1, 1, d, e->dH1m, h, 1, e->g_model + e->oW1, h, d, h, n);         // gW1 = S1^T dH1p
+        g2[1] = mk(e->ones, 0, 1, e->dH1m, h, 1, e->g_model + e->ob1, h, 1, h, n);       // gb1 = 1^T dH1p
+        GS_TRY(gs_gemm_group_f32(g2, 2, stream));
+      }
       GS_TRY(gs_adam_step_f32(th, e->g_model, e->m_model, e->v_model, e->P, e->cfg.lr_model, 0.9f, 0.999f, 1e-8f, 0.f,
                               ++e->step_model, stream));
     }
@@ -1133,20 +1144,20 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
     hipLaunchKernelGGL(gs_syn_softmax_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Zs, e->rsq_in, th + e->obl,
                        e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, (float*)nullptr, e->Gs, 1);
     GS_LAUNCH_CHECK();
-    gs_gemm_desc gw = mk(e->S_in, 1, F, e->Gs, C, 1, e->g_model + e->oWl, C, F, C, n);
-    GS_TRY(gs_gemm_f32(&gw, stream));
-    gs_gemm_desc gb = mk(e->rsq_in, 0, 1, e->Gs, C, 1, e->g_model + e->obl, C, 1, C, n);
-    GS_TRY(gs_gemm_f32(&gb, stream));
+    // three products that only read G share a launch, then the two that only read dHp (gs_gemm_group_f32)
+    gs_gemm_desc g3[3];
+    g3[0] = mk(e->S_in, 1, F, e->Gs, C, 1, e->g_model + e->oWl, C, F, C, n);             // gWl = S^T G
+    g3[1] = mk(e->rsq_in, 0, 1, e->Gs, C, 1, e->g_model + e->obl, C, 1, C, n);           // gbl = rs^T G
+    g3[2] = mk(e->Gs, C, 1, th + e->oWl, 1, C, e->dSs, h, n, h, C);                      // dS = G W2^T   (T = 2)
+    GS_TRY(gs_gemm_group_f32(g3, e->T == 2 ? 3 : 2, stream));
     if (e->T == 2) {
-      gs_gemm_desc ds = mk(e->Gs, C, 1, th + e->oWl, 1, C, e->dSs, h, n, h, C);          // dS = G W2^T
-      GS_TRY(gs_gemm_f32(&ds, stream));
       gs_gemm_desc dh = mk(e->Qin, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n);             // (Q^T dS) * mask
       dh.mask = e->H1s; dh.ldmask = h;
       GS_TRY(gs_gemm_f32(&dh, stream));
-      gs_gemm_desc w1 = mk(X, 1, d, e->dH1m, h, 1, e->g_model + e->oW1, h, d, h, n);     // X^T dHp
-      GS_TRY(gs_gemm_f32(&w1, stream));
-      gs_gemm_desc b1g = mk(e->ones, 0, 1, e->dH1m, h, 1, e->g_model + e->ob1, h, 1, h, n);   // gb1 = 1^T dHp (one launch)
-      GS_TRY(gs_gemm_f32(&b1g, stream));
+      gs_gemm_desc g2[2];
+      g2[0] = mk(X, 1, d, e->dH1m, h, 1, e->g_model + e->oW1, h, d, h, n);               // gW1 = X^T dHp
+      g2[1] = mk(e->ones, 0, 1, e->dH1m, h, 1, e->g_model + e->ob1, h, 1, h, n);         // gb1 = 1^T dHp
+      GS_TRY(gs_gemm_group_f32(g2, 2, stream));
     }
     GS_TRY(gs_adam_step_f32(th, e->g_model, e->m_model, e->v_model, e->P, e->cfg.lr_model, 0.9f, 0.999f, 1e-8f, 0.f,
                             ++e->step_model, stream));

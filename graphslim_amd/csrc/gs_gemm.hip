@@ -413,11 +413,10 @@ __device__ __forceinline__ void small_frag(const float* __restrict__ rowp, long 
 }
 
 template <bool AVEC, bool BVEC>
-__global__ __launch_bounds__(256) void gs_gemm_small_kernel(gs_gemm_desc p) {
+__device__ __forceinline__ void gs_small_tile(const gs_gemm_desc& p, int bx, int by, int b, float (&red)[4][16][64]) {
   constexpr int QS = 8;   // q-steps (8 k each) per round
-  __shared__ float red[4][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
-  const int b = blockIdx.z, b1 = b / p.nb2, b2 = b - b1 * p.nb2;
+  const int b1 = b / p.nb2, b2 = b - b1 * p.nb2;
   int M = p.M, K = p.K;
   if (p.Mb) M = p.Mb[b1];
   if (p.Kb) K = p.Kb[b1];
@@ -426,8 +425,8 @@ __global__ __launch_bounds__(256) void gs_gemm_small_kernel(gs_gemm_desc p) {
     k_lo = b2 * p.kchunk;
     k_hi = min(K, k_lo + p.kchunk);
   }
-  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  if (m0 >= M) return;
+  const int m0 = by * 32, n0 = bx * 32;
+  if (m0 >= M || n0 >= p.N) return;
   const float* __restrict__ A = p.A + (long)b1 * p.sAb1 + (p.kchunk > 0 ? 0 : (long)b2 * p.sAb2) + (p.offA ? p.offA[b1] : 0);
   const float* __restrict__ B = p.B + (long)b1 * p.sBb1 + (p.kchunk > 0 ? 0 : (long)b2 * p.sBb2) + (p.offB ? p.offB[b1] : 0);
   float* __restrict__ C = p.C + (long)b1 * p.sCb1 + (long)b2 * p.sCb2 + (p.offC ? p.offC[b1] : 0);
@@ -491,6 +490,40 @@ __global__ __launch_bounds__(256) void gs_gemm_small_kernel(gs_gemm_desc p) {
     const int row = rbase + rr;
     if (row < M && col < p.N) C[(long)row * p.ldc + col] = v;
   }
+}
+
+template <bool AVEC, bool BVEC>
+__global__ __launch_bounds__(256) void gs_gemm_small_kernel(gs_gemm_desc p) {
+  __shared__ float red[4][16][64];
+  gs_small_tile<AVEC, BVEC>(p, blockIdx.x, blockIdx.y, blockIdx.z, red);
+}
+
+// Up to GS_GROUP_MAX independent latency-bound products in ONE launch (descriptors travel by value in the kernel arguments):
+// the synthetic side and the inner steps are chains of ~6 us launches, and products that do not depend on each other
+// (gW2, gb2 and dS of an inner step; U and V of the PGE; ...) need not pay that latency one after the other.
+// blockIdx.z enumerates (group, batch); x / y cover the largest tile grid of the group, the others exit at once.
+#define GS_GROUP_MAX 4
+struct gs_gemm_group_arg {
+  gs_gemm_desc d[GS_GROUP_MAX];
+  int z0[GS_GROUP_MAX + 1];   // first blockIdx.z of each group
+  int n;
+};
+
+__device__ __forceinline__ void gs_small_any(const gs_gemm_desc& p, int b, float (&red)[4][16][64]) {
+  const bool av = p.sAk == 1, bv = p.sBk == 1;   // block-uniform
+  if (av && bv) gs_small_tile<true, true>(p, blockIdx.x, blockIdx.y, b, red);
+  else if (av) gs_small_tile<true, false>(p, blockIdx.x, blockIdx.y, b, red);
+  else if (bv) gs_small_tile<false, true>(p, blockIdx.x, blockIdx.y, b, red);
+  else gs_small_tile<false, false>(p, blockIdx.x, blockIdx.y, b, red);
+}
+
+__global__ __launch_bounds__(256) void gs_gemm_small_group_kernel(gs_gemm_group_arg g) {
+  __shared__ float red[4][16][64];
+  const int z = blockIdx.z;
+  if (z < g.z0[1]) gs_small_any(g.d[0], z, red);
+  else if (z < g.z0[2]) gs_small_any(g.d[1], z - g.z0[1], red);
+  else if (z < g.z0[3]) gs_small_any(g.d[2], z - g.z0[2], red);
+  else gs_small_any(g.d[3], z - g.z0[3], red);
 }
 
 static long g_small_tiles = 8192;      // route to the small kernel when the 32x32 tile count is at most this ...
@@ -652,4 +685,40 @@ extern "C" int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream) {
     case 2: return launch_gemm<64, 64, 32, 32>(p, nbatch, s);
     default: return launch_gemm<128, 128, 64, 64>(p, nbatch, s);   // (128x64 / 64x128 at 4 waves/SIMD measured within +-5 %)
   }
+}
+
+// Independent products in one launch when every one of them is routed to the latency-oriented kernel; otherwise (or for a
+// single product) they are launched one after the other.  The caller guarantees that no product reads another's output.
+extern "C" int gs_gemm_group_f32(const gs_gemm_desc* descs, int n, gs_stream_t stream) {
+  if (n <= 0) return GS_OK;
+  if (!descs) GS_FAIL(GS_ERR_ARG, "gs_gemm_group_f32: null descriptors");
+  bool groupable = n > 1 && n <= GS_GROUP_MAX;
+  gs_gemm_group_arg g;
+  int gx = 1, gy = 1, z = 0;
+  if (groupable) {
+    for (int i = 0; i < n; ++i) {
+      gs_gemm_desc p = descs[i];
+      if (!p.A || !p.B || !p.C || p.K < 0) { groupable = false; break; }
+      if (p.nb1 < 1) p.nb1 = 1;
+      if (p.nb2 < 1) p.nb2 = 1;
+      const int nbatch = p.nb1 * p.nb2;
+      if (p.M <= 0 || p.N <= 0 || !small_route(p, nbatch)) { groupable = false; break; }
+      g.d[i] = p;
+      g.z0[i] = z;
+      z += nbatch;
+      gx = gx > gs_cdiv(p.N, 32) ? gx : gs_cdiv(p.N, 32);
+      gy = gy > gs_cdiv(p.M, 32) ? gy : gs_cdiv(p.M, 32);
+    }
+    if (z > 65535) groupable = false;
+  }
+  if (!groupable) {
+    for (int i = 0; i < n; ++i) GS_TRY(gs_gemm_f32(&descs[i], stream));
+    return GS_OK;
+  }
+  for (int i = n; i <= GS_GROUP_MAX; ++i) g.z0[i] = z;
+  for (int i = n; i < GS_GROUP_MAX; ++i) g.d[i] = g.d[0];
+  g.n = n;
+  hipLaunchKernelGGL(gs_gemm_small_group_kernel, dim3(gx, gy, z), dim3(256), 0, (hipStream_t)stream, g);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
 }

@@ -21,8 +21,8 @@ METRICS = {"ours": 0, "mse": 1, "cos": 2}
 # ------------------------------------------------------------------------------------------------
 
 
-def gemm(A, B, Cout, M, N, K, sA, sB, ldc, **kw):
-    """C = alpha * A*B (+...) with explicit element strides sA=(sAm,sAk), sB=(sBk,sBn); kw = other desc fields."""
+def gemm_desc(A, B, Cout, M, N, K, sA, sB, ldc, **kw):
+    """A filled GemmDesc (element strides sA=(sAm,sAk), sB=(sBk,sBn); kw = other descriptor fields) + the tensors it points to."""
     d = GemmDesc()
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
     d.M, d.N, d.K = M, N, K
@@ -31,13 +31,25 @@ def gemm(A, B, Cout, M, N, K, sA, sB, ldc, **kw):
     d.ldc = ldc
     d.nb1 = d.nb2 = 1
     d.alpha = 1.0
-    keep = []
+    keep = [A, B, Cout]
     for k, v in kw.items():
         if isinstance(v, torch.Tensor):
             keep.append(v)
             v = ptr(v)
         setattr(d, k, v)
+    return d, keep
+
+
+def gemm(A, B, Cout, M, N, K, sA, sB, ldc, **kw):
+    """C = alpha * A*B (+...) with explicit element strides sA=(sAm,sAk), sB=(sBk,sBn); kw = other desc fields."""
+    d, _keep = gemm_desc(A, B, Cout, M, N, K, sA, sB, ldc, **kw)
     check(_lib.lib().gs_gemm_f32(C.byref(d), stream()))
+
+
+def gemm_group(descs):
+    """Mutually independent products [(GemmDesc, keepalive), ...] in one launch when they are all latency-bound."""
+    arr = (GemmDesc * len(descs))(*[d for d, _ in descs])
+    check(_lib.lib().gs_gemm_group_f32(arr, len(descs), stream()))
 
 
 def spmm_csr(rowptr, col, val, X, F=None, out=None):

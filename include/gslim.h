@@ -85,6 +85,10 @@ int gs_gemm_set_small(long max_tiles, double max_gflop);
 int gs_gemm_tiles_m(const gs_gemm_desc* d);
 
 int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream);
+/* n mutually independent products (none reads another's output).  When all of them are latency-bound (see
+   gs_gemm_set_small) and n <= 4 they share ONE launch; otherwise they are launched one after the other.  Results are
+   bitwise those of n gs_gemm_f32 calls. */
+int gs_gemm_group_f32(const gs_gemm_desc* descs, int n, gs_stream_t stream);
 
 /* out[i] = beta*out[i] + sum_s slabs[s*slab_stride + i]  (fixed order: bitwise reproducible). */
 int gs_reduce_slabs_f32(float* out, const float* slabs, long n, int n_slabs, long slab_stride, float beta,

@@ -294,3 +294,35 @@ def test_spmm_csr_ragged_rows_and_nonfinite_row0(E):
         Xf = X.clone()
         Xf[0] = 0
         close(out, torch.from_numpy(m.astype(np.float64).toarray()) @ Xf.double())
+
+
+def test_grouped_small_gemms_equal_sequential_launches():
+    """gs_gemm_group_f32: independent latency-bound products in one launch are bitwise the products launched one by one
+    (different shapes, operand layouts, a batched one with per-batch extents, epilogues)."""
+    from graphslim_amd.engine import gemm_desc, gemm_group
+    torch.manual_seed(0)
+    n, d, h, Cc = 454, 128, 256, 40
+    A = torch.randn(n, n, device=DEV); X = torch.randn(n, d, device=DEV); H = torch.randn(n, h, device=DEV)
+    G = torch.randn(n, Cc, device=DEV); W = torch.randn(h, Cc, device=DEV); ones = torch.ones(n, device=DEV)
+    bias = torch.randn(h, device=DEV)
+    kb = torch.tensor([5, 0, 33], dtype=torch.int32, device=DEV)
+
+    def build(outs):
+        return [gemm_desc(H, G, outs[0], h, Cc, n, (1, h), (Cc, 1), Cc),                       # S^T G        (M,M)
+                gemm_desc(ones, G, outs[1], 1, Cc, n, (0, 1), (Cc, 1), Cc),                    # 1^T G        (M = 1)
+                gemm_desc(G, W, outs[2], n, h, Cc, (Cc, 1), (1, Cc), h, bias=bias, relu=1),    # G W^T + b    (K,K) + epilogue
+                gemm_desc(X, H, outs[3], d, h, 33, (1, d), (h, 1), h, nb1=3, Kb=kb, sAb1=40 * d, sBb1=40 * h, sCb1=d * h)]
+
+    def outs():
+        return [torch.full((h, Cc), 7.0, device=DEV), torch.full((1, Cc), 7.0, device=DEV), torch.full((n, h), 7.0, device=DEV),
+                torch.full((3, d, h), 7.0, device=DEV)]
+    o_seq, o_grp = outs(), outs()
+    for dsc, _ in build(o_seq):
+        gemm_group([(dsc, None)])                     # n = 1 -> plain launch
+    gemm_group(build(o_grp))
+    torch.cuda.synchronize()
+    for a, b in zip(o_seq, o_grp):
+        assert torch.equal(a, b)
+    ref = (H.double().T @ G.double()).float()
+    np.testing.assert_allclose(o_grp[0].cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    assert float(o_grp[3][1].abs().max()) == 0.0      # a batch with K = 0 writes zeros
