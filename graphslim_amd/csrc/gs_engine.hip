@@ -761,16 +761,15 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       gs_gemm_desc a = mk(A, 1, n, e->Tmat, h, 1, dHp, h, n, h, mx);
       a.nb1 = Cl; a.offA = off_lon; a.offB = off_loF; a.Kb = ncls; a.sCb1 = (long)n * h; a.mask = e->H1s; a.ldmask = h;
       GS_TRY(gs_gemm_f32(&a, stream));
-      gs_gemm_desc w1 = mk(e->S1, 1, d, dHp, h, 1, gws + e->oW1, h, d, h, n);
-      w1.nb1 = Cl; w1.sBb1 = (long)n * h; w1.sCb1 = P;
-      GS_TRY(gs_gemm_f32(&w1, stream));
+      gs_gemm_desc w3[3];
+      w3[0] = mk(e->S1, 1, d, dHp, h, 1, gws + e->oW1, h, d, h, n);
+      w3[0].nb1 = Cl; w3[0].sBb1 = (long)n * h; w3[0].sCb1 = P;
+      w3[1] = mk(S2, 1, h, e->Gs, C, 1, gws + e->oWl, C, h, C, mx);
+      w3[1].nb1 = Cl; w3[1].offA = off_loF; w3[1].offB = off_loC; w3[1].Kb = ncls; w3[1].sCb1 = P;
+      w3[2] = mk(e->ones, 0, 0, e->Gs, C, 1, gws + e->obl, C, 1, C, mx);
+      w3[2].nb1 = Cl; w3[2].offB = off_loC; w3[2].Kb = ncls; w3[2].sCb1 = P;
+      GS_TRY(gs_gemm_group_f32(w3, 3, stream));          // gW1_c, gW2_c, gb2_c: independent
       if (e->cfg.dis_metric != 0) GS_TRY(colsum_batched(e, dHp, (long)n * h, n, nullptr, h, Cl, gws + e->ob1, P, stream));
-      gs_gemm_desc w2 = mk(S2, 1, h, e->Gs, C, 1, gws + e->oWl, C, h, C, mx);
-      w2.nb1 = Cl; w2.offA = off_loF; w2.offB = off_loC; w2.Kb = ncls; w2.sCb1 = P;
-      GS_TRY(gs_gemm_f32(&w2, stream));
-      gs_gemm_desc gb = mk(e->ones, 0, 0, e->Gs, C, 1, gws + e->obl, C, 1, C, mx);
-      gb.nb1 = Cl; gb.offB = off_loC; gb.Kb = ncls; gb.sCb1 = P;
-      GS_TRY(gs_gemm_f32(&gb, stream));
       float* stats = e->stats + c0 * e->pd.total_cols * 3; float* ab = e->ab + c0 * e->pd.total_cols * 2;
       if (e->join_pending) { GS_HIP(hipStreamWaitEvent(s, e->ev_join, 0)); e->join_pending = false; }
       hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, Cl), dim3(256), 0, s, gwr, gws, P, e->pd, stats);
@@ -779,27 +778,26 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       hipLaunchKernelGGL(gs_dist_apply_kernel, dim3(gs_cdiv((long)Cl * P, 256)), dim3(256), 0, s, gwr, gws, P, e->pd, ab, Dv, Cl);
       GS_LAUNCH_CHECK();
       // A1m_c = (S1 D1_c + Db1_c) * mask ; dS1 slabs_c = dH1p_c D1_c^T ; dA[lo:hi] = T[lo:hi] A1m_c^T ; R[lo:hi] = A[lo:hi] A1m_c
-      gs_gemm_desc m1 = mk(e->S1, d, 1, Dv + e->oW1, h, 1, A1m, h, n, h, d);
-      m1.nb1 = Cl; m1.sBb1 = P; m1.sCb1 = (long)n * h; m1.bias = Dv + e->ob1; m1.sbias_b1 = P; m1.mask = e->H1s; m1.ldmask = h;
-      GS_TRY(gs_gemm_f32(&m1, stream));
-      gs_gemm_desc x = mk(dHp, h, 1, Dv + e->oW1, 1, h, e->slabs_x, d, n, d, h);
-      x.nb1 = Cl; x.sAb1 = (long)n * h; x.sBb1 = P; x.sCb1 = (long)n * d;
-      GS_TRY(gs_gemm_f32(&x, stream));
+      gs_gemm_desc mx2[2];
+      mx2[0] = mk(e->S1, d, 1, Dv + e->oW1, h, 1, A1m, h, n, h, d);
+      mx2[0].nb1 = Cl; mx2[0].sBb1 = P; mx2[0].sCb1 = (long)n * h; mx2[0].bias = Dv + e->ob1; mx2[0].sbias_b1 = P;
+      mx2[0].mask = e->H1s; mx2[0].ldmask = h;
+      mx2[1] = mk(dHp, h, 1, Dv + e->oW1, 1, h, e->slabs_x, d, n, d, h);
+      mx2[1].nb1 = Cl; mx2[1].sAb1 = (long)n * h; mx2[1].sBb1 = P; mx2[1].sCb1 = (long)n * d;
+      GS_TRY(gs_gemm_group_f32(mx2, 2, stream));
       GS_TRY(gs_reduce_slabs_f32(e->dS1, e->slabs_x, (long)n * d, Cl, (long)n * d, 0.f, stream));
-      gs_gemm_desc da = mk(e->Tmat, h, 1, A1m, 1, h, e->dAn, n, mx, n, h);
-      da.nb1 = Cl; da.offA = off_loF; da.Mb = ncls; da.sBb1 = (long)n * h; da.offC = off_lon;
-      GS_TRY(gs_gemm_f32(&da, stream));
-      gs_gemm_desc r = mk(A, n, 1, A1m, h, 1, e->Rmat, h, mx, h, n);
-      r.nb1 = Cl; r.offA = off_lon; r.Mb = ncls; r.sBb1 = (long)n * h; r.offC = off_loF;
-      GS_TRY(gs_gemm_f32(&r, stream));
+      gs_gemm_desc q4[4];                                   // four products with distinct outputs: one launch
+      q4[0] = mk(e->Tmat, h, 1, A1m, 1, h, e->dAn, n, mx, n, h);
+      q4[0].nb1 = Cl; q4[0].offA = off_loF; q4[0].Mb = ncls; q4[0].sBb1 = (long)n * h; q4[0].offC = off_lon;
+      q4[1] = mk(A, n, 1, A1m, h, 1, e->Rmat, h, mx, h, n);
+      q4[1].nb1 = Cl; q4[1].offA = off_lon; q4[1].Mb = ncls; q4[1].sBb1 = (long)n * h; q4[1].offC = off_loF;
       // Ug[lo:hi] = S2[lo:hi] D2_c  (+ R W2 below, + Db2 inside the V kernel)
-      gs_gemm_desc u = mk(S2, h, 1, Dl2, C, 1, e->Ug, C, mx, C, h);
-      u.nb1 = Cl; u.offA = off_loF; u.Mb = ncls; u.sBb1 = P; u.offC = off_loC;
-      GS_TRY(gs_gemm_f32(&u, stream));
+      q4[2] = mk(S2, h, 1, Dl2, C, 1, e->Ug, C, mx, C, h);
+      q4[2].nb1 = Cl; q4[2].offA = off_loF; q4[2].Mb = ncls; q4[2].sBb1 = P; q4[2].offC = off_loC;
       // dS2[lo:hi] = G[lo:hi] D2_c^T
-      gs_gemm_desc ds = mk(e->Gs, C, 1, Dl2, 1, C, e->dSs, h, mx, h, C);
-      ds.nb1 = Cl; ds.offA = off_loC; ds.Mb = ncls; ds.sBb1 = P; ds.offC = off_loF;
-      GS_TRY(gs_gemm_f32(&ds, stream));
+      q4[3] = mk(e->Gs, C, 1, Dl2, 1, C, e->dSs, h, mx, h, C);
+      q4[3].nb1 = Cl; q4[3].offA = off_loC; q4[3].Mb = ncls; q4[3].sBb1 = P; q4[3].offC = off_loF;
+      GS_TRY(gs_gemm_group_f32(q4, 4, stream));
     } else if (e->join_pending) {
       GS_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
       e->join_pending = false;
@@ -809,11 +807,19 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
                        e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->c_lo, e->c_hi, e->Vs, e->drs);
     GS_LAUNCH_CHECK();
     { gs_gemm_desc g = mk(e->Vs, C, 1, Wl, 1, C, e->dSs, h, n, h, C); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }    // dS2 += V W2^T
-    { gs_gemm_desc g = mk(e->dSs, h, 1, e->H1s, 1, h, e->dAn, n, n, n, h); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }  // dA += dS2 H1^T
-    { gs_gemm_desc g = mk(A, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n); g.mask = e->H1s; g.ldmask = h; GS_TRY(gs_gemm_f32(&g, stream)); }  // (A^T dS2)*mask
+    {
+      gs_gemm_desc g2[2];
+      g2[0] = mk(e->dSs, h, 1, e->H1s, 1, h, e->dAn, n, n, n, h); g2[0].beta = 1.f;                      // dA += dS2 H1^T
+      g2[1] = mk(A, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n); g2[1].mask = e->H1s; g2[1].ldmask = h;     // (A^T dS2)*mask
+      GS_TRY(gs_gemm_group_f32(g2, 2, stream));
+    }
     { gs_gemm_desc g = mk(e->dH1m, h, 1, W1, 1, h, e->dS1, d, n, d, h); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }   // dS1 += dH1p W1^T
-    { gs_gemm_desc g = mk(e->dS1, d, 1, X, 1, d, e->dAn, n, n, n, d); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }     // dA += dS1 X^T
-    { gs_gemm_desc g = mk(A, 1, n, e->dS1, d, 1, e->d_feat, d, n, d, n); GS_TRY(gs_gemm_f32(&g, stream)); }               // dX = A^T dS1
+    {
+      gs_gemm_desc g2[2];
+      g2[0] = mk(e->dS1, d, 1, X, 1, d, e->dAn, n, n, n, d); g2[0].beta = 1.f;     // dA += dS1 X^T
+      g2[1] = mk(A, 1, n, e->dS1, d, 1, e->d_feat, d, n, d, n);                    // dX = A^T dS1
+      GS_TRY(gs_gemm_group_f32(g2, 2, stream));
+    }
     if (e->identity) return GS_OK;
     return gs_dense_gcn_norm_bwd(e->adj_raw, e->rnorm, e->dAn, n, e->d_adj, stream);
   }
