@@ -493,21 +493,7 @@ __global__ __launch_bounds__(1024) void gs_pge_bn1_stats_kernel(const float* __r
   }
 }
 
-// A1[(r,c), k] = relu(g1 * (U[c,k] + V[r,k] + b0 - mu1) * is1 + be1)
-__global__ void gs_pge_make_a1_kernel(const float* __restrict__ U, const float* __restrict__ V, const float* __restrict__ b0,
-                                      const float* __restrict__ mu1, const float* __restrict__ is1,
-                                      const float* __restrict__ g1, const float* __restrict__ be1, int n, int Ph,
-                                      int r_lo, int nr, float* __restrict__ A1) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)nr * n * Ph) return;
-  const int k = (int)(idx % Ph);
-  const long pair = idx / Ph;
-  const int rl = (int)(pair / n), c = (int)(pair - (long)rl * n), r = r_lo + rl;
-  float x = (U[(long)c * Ph + k] + V[(long)r * Ph + k] + b0[k] - mu1[k]) * is1[k];
-  A1[idx] = fmaxf(fmaf(g1[k], x, be1[k]), 0.f);
-}
-
-// float4 variant (Ph % 4 == 0): one thread per 4 consecutive k
+// A1[(r,c), k] = relu(g1 * (U[c,k] + V[r,k] + b0 - mu1) * is1 + be1); Ph % 4 == 0: one thread per 4 consecutive k
 __global__ void gs_pge_make_a1_v4_kernel(const float* __restrict__ U, const float* __restrict__ V, const float* __restrict__ b0,
                                          const float* __restrict__ mu1, const float* __restrict__ is1,
                                          const float* __restrict__ g1, const float* __restrict__ be1, int n, int Ph, int r_lo,
@@ -803,23 +789,8 @@ __global__ void gs_sums_to_float_kernel(const double* __restrict__ sums, int nq,
   if (nq > 1 && out1) out1[k] = (float)sums[Ph + k];
   if (nq > 2 && out2) out2[k] = (float)sums[2 * Ph + k];
 }
-// dE2[row,k] = g2*is2 * (dy2 - dbe2/N - xh2*dg2/N)
-__global__ void gs_pge_bn2_bwd_kernel(const float* __restrict__ E2, const float* __restrict__ de3, const float* __restrict__ mu2,
-                                      const float* __restrict__ is2, const float* __restrict__ g2, const float* __restrict__ be2,
-                                      const float* __restrict__ w2, const float* __restrict__ dbe2,
-                                      const float* __restrict__ dg2, long rows, long total_rows, int Ph,
-                                      float* __restrict__ dE2) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * Ph) return;
-  const int k = (int)(idx % Ph);
-  const long r = idx / Ph;
-  float xh = (E2[idx] - mu2[k]) * is2[k];
-  float y = fmaf(g2[k], xh, be2[k]);
-  float dy = y > 0.f ? de3[r] * w2[k] : 0.f;
-  float invN = 1.f / (float)total_rows;
-  dE2[idx] = g2[k] * is2[k] * (dy - dbe2[k] * invN - xh * dg2[k] * invN);
-}
 
+// dE2[row,k] = g2*is2 * (dy2 - dbe2/N - xh2*dg2/N),  dy2 = de3[row] * w2[k] * [y2 > 0]   (BatchNorm-2 + layer-3 backward)
 __global__ void gs_pge_bn2_bwd_v4_kernel(const float* __restrict__ E2, const float* __restrict__ de3,
                                          const float* __restrict__ mu2, const float* __restrict__ is2,
                                          const float* __restrict__ g2, const float* __restrict__ be2,
