@@ -92,6 +92,10 @@ struct gs_gcond {
   gs_blocks blkbuf[2];
   int blk_cur;
   bool prefetched;
+  // in-situ timing of the dominant kernel (PGE layer-2 GEMM): event pairs recorded around its launches while probing
+  bool probing;
+  int probe_n;
+  hipEvent_t probe_ev[2 * 256];
   bool gcn;         // condense model GCN (2 layers) instead of SGC
   float *P0g, *T2r, *dT2r, *dH1r, *S1, *dS1, *Tmat, *Rmat;   // GCN-only scratch
   bool identity;    // structure-free variants (GCondX / DosCondX): adj_syn = I, no PGE
@@ -327,6 +331,8 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->aux = nullptr; e->ev_fork = e->ev_join = nullptr; e->join_pending = false;
   e->reuse_fwd = false; e->fwd_cached = false;
   e->blk_cur = 0; e->prefetched = false; e->identity = false;
+  e->probing = false; e->probe_n = 0;
+  for (int i = 0; i < 2 * 256; ++i) e->probe_ev[i] = nullptr;
   // the real-side branch is the longer of the two concurrent branches (kernel trace, r01): its stream gets the higher
   // priority so that its latency-bound kernels are not queued behind the PGE forward's big GEMM
   int prio_lo = 0, prio_hi = 0;
@@ -341,6 +347,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
 extern "C" void gs_gcond_destroy(gs_gcond* e) {
   if (!e) return;
   if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); }
+  for (int i = 0; i < 2 * 256; ++i) if (e->probe_ev[i]) (void)hipEventDestroy(e->probe_ev[i]);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   delete e;
@@ -652,7 +659,17 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       gs_gemm_desc g = mk(e->A1, Ph, 1, pp + e->pW1, 1, Ph, e->E2, Ph, (int)rows, Ph, Ph);     // E2 = A1 W1^T + b1
       g.bias = pp + e->pb1;
       g.colstat = e->statp;            // BN-2 batch statistics come out of the epilogue: no second pass over E2
+      const bool probe = e->probing && e->probe_n < 256;
+      if (probe) {
+        for (int q = 0; q < 2; ++q)
+          if (!e->probe_ev[2 * e->probe_n + q]) GS_HIP(hipEventCreate(&e->probe_ev[2 * e->probe_n + q]));
+        GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s));
+      }
       GS_TRY(gs_gemm_f32(&g, stream));
+      if (probe) {
+        GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n + 1], s));
+        e->probe_n++;
+      }
       reduce_parts(e, e->statp, gs_gemm_tiles_m(&g), 2, 2, s);
       GS_LAUNCH_CHECK();
     } else {
@@ -1260,6 +1277,30 @@ extern "C" int gs_gcond_outer_step_ex(gs_gcond* e, int step_pge, int step_feat, 
 extern "C" int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream) {
   const int pge_epoch = (epoch % 50 < 10);     // gcond.py:58-61
   return gs_gcond_outer_step_ex(e, pge_epoch, !pge_epoch, 1, 1, stream);
+}
+
+// In-situ timing of the dominant kernel: while on, HIP events are recorded on the launch stream around every PGE layer-2
+// GEMM (training forward and inference pass), up to 256 launches; reading synchronises the events and returns the summed
+// duration and the launch count since the probe was switched on.
+extern "C" int gs_gcond_probe(gs_gcond* e, int on) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  e->probing = on != 0;
+  if (on) e->probe_n = 0;
+  return GS_OK;
+}
+
+extern "C" int gs_gcond_probe_read(gs_gcond* e, double* total_ms, long* launches) {
+  if (!e || !total_ms || !launches) GS_FAIL(GS_ERR_ARG, "gs_gcond_probe_read: null argument");
+  double t = 0;
+  for (int i = 0; i < e->probe_n; ++i) {
+    float ms = 0.f;
+    GS_HIP(hipEventSynchronize(e->probe_ev[2 * i + 1]));
+    GS_HIP(hipEventElapsedTime(&ms, e->probe_ev[2 * i], e->probe_ev[2 * i + 1]));
+    t += ms;
+  }
+  *total_ms = t;
+  *launches = e->probe_n;
+  return GS_OK;
 }
 
 extern "C" int gs_gcond_read_loss(gs_gcond* e, double* loss_sum, long* steps, gs_stream_t stream) {

@@ -326,6 +326,15 @@ class GCondEngine:
     def stage_real_grads(self):
         check(self.L.gs_gcond_stage_real_grads(self.h, stream()))
 
+    def probe(self, on=True):
+        check(self.L.gs_gcond_probe(self.h, int(on)))
+
+    def probe_read(self):
+        """(summed duration [ms], launches) of the PGE layer-2 GEMM since probe(True)."""
+        t, k = C.c_double(), C.c_long()
+        check(self.L.gs_gcond_probe_read(self.h, C.byref(t), C.byref(k)))
+        return t.value, k.value
+
     def stage_real_async(self):
         check(self.L.gs_gcond_stage_real_async(self.h, stream()))
 

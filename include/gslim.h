@@ -226,6 +226,11 @@ int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* blocks, gs_stream_t stream
  * cached pass instead of recomputing it (bitwise the same values).  Off by default; call gs_gcond_invalidate_forward after
  * writing X~ or theta_PGE from the host.  gs_gcond_forward_cached returns 1 when the next step would adopt. */
 int gs_gcond_set_forward_reuse(gs_gcond* e, int on);
+/* In-situ timing of the dominant kernel (PGE layer-2 GEMM, 2 n'^2 Ph^2 FLOP per launch): while on, HIP events are recorded
+ * on the launch stream around each of its launches inside the outer steps (at most 256); _read synchronises them and
+ * returns the summed duration [ms] and the launch count since the probe was switched on.  bench.py's roofline uses it. */
+int gs_gcond_probe(gs_gcond* e, int on);
+int gs_gcond_probe_read(gs_gcond* e, double* total_ms, long* launches);
 int gs_gcond_invalidate_forward(gs_gcond* e);
 int gs_gcond_forward_cached(gs_gcond* e);
 int gs_gcond_adopt_cached_forward(gs_gcond* e, gs_stream_t stream);
