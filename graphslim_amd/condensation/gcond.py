@@ -44,7 +44,7 @@ class _GradMatch(GCondBase):
         nclass = data.nclass
         ranges = [tuple(self.syn_class_indices.get(c, (0, 0))) for c in range(nclass)]
         shapes = EngineShapes(features.shape[0], self.d, nclass, self.nnodes_syn, depth, args.hidden, self.pge_hidden,
-                              256, sizes[0], sizes[1], model=args.condense_model)
+                              256, sizes[0], sizes[1], model=args.condense_model, pge_chunks=self.pge_chunks)
         cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
         eng = self.engine = GCondEngine(shapes, features, csr, cls_ptr, np.concatenate(pools), labels_syn, ranges,
                                         lr_feat=args.lr_feat, lr_adj=args.lr_adj, lr_model=args.lr,

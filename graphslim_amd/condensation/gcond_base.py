@@ -25,8 +25,8 @@ class GCondBase:
         print(f"actual reduced size:{n}")
         self.feat_syn = torch.empty(n, d, device=self.device)
         self.pge_hidden = pge_hidden(args.dataset, args.reduction_rate)
-        if args.dataset == "reddit" and args.reduction_rate >= 0.01:
-            raise NotImplementedError("graphslim_amd: the 5-chunk PGE of reddit r >= 0.01 (parametrized_adj.py:41-55) is not built")
+        # parametrized_adj.py:41-55: reddit with r >= 0.01 runs the pair list through the PGE in 5 chunks (per-chunk BatchNorm)
+        self.pge_chunks = 5 if (args.dataset == "reddit" and args.reduction_rate >= 0.01) else 1
         self.pge_init = init_pge_params(d, self.pge_hidden)          # nn.Linear draws, constructor + reset order
         self.adj_syn = None
         print("adj_syn:", (n, n), "feat_syn:", self.feat_syn.shape)

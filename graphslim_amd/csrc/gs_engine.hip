@@ -58,7 +58,8 @@ struct gs_gcond {
       *drs, *dQ, *dAn, *d_adj, *d_feat, *dH2, *dHp, *A1m, *Bc, *dH1m, *slabs_x;
   // PGE
   float *U, *V, *mu1, *is1, *mu2, *is2, *sumU, *sumV, *A1, *E2, *e3, *de3, *dE2, *dY1, *rowsum_c, *colsum_r, *dU, *dV, *d_pge,
-      *slabs_w, *W1T, *W1mT;
+      *slabs_w, *W1T, *W1mT, *chunk_fwd, *chunk_bwd;   // chunked PGE: [chunk][mu1|is1|mu2|is2][Ph], [chunk][dw2|dbe2|dg2|dbe1|dg1][Ph]
+  int pge_chunks;
   double* parts;
   // inner loop
   float *adj_norm_in, *rnorm_in, *Qin, *rsq_in, *S_in, *g_model;
@@ -106,6 +107,7 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   e->N = c.n_nodes; e->d = c.d; e->ldx = c.ldx; e->C = c.nclass; e->n = c.n_syn; e->T = c.ntrans; e->h = c.hidden;
   e->Ph = c.pge_hidden; e->bcap = c.bcap; e->f1 = c.f1; e->f2 = c.f2; e->cap1 = c.bcap * (1 + c.f1);
   e->gcn = (c.condense_model == 1);
+  e->pge_chunks = c.pge_chunks > 1 ? c.pge_chunks : 1;
   if (e->gcn) e->T = 2;                       // GCN: two GraphConvolution layers, same parameter layout as SGC T = 2
   e->F = (e->T == 1) ? c.d : c.hidden;
   gs_pdesc& pd = e->pd;
@@ -206,6 +208,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->dE2 = w.take<float>(n2 * Ph); e->dY1 = w.take<float>(n2 * Ph);
   e->ar_marg = w.take<float>(2 * n * Ph);     // [rowsum_c | colsum_r] contiguous (one all-reduce)
   e->rowsum_c = e->ar_marg; e->colsum_r = e->ar_marg ? e->ar_marg + n * Ph : nullptr; e->dU = w.take<float>(n * Ph); e->W1T = w.take<float>(Ph * Ph); e->W1mT = w.take<float>(d * h);
+  e->chunk_fwd = w.take<float>((long)e->pge_chunks * 4 * Ph); e->chunk_bwd = w.take<float>((long)e->pge_chunks * 5 * Ph);
   e->dV = w.take<float>(n * Ph); e->d_pge = w.take<float>(e->Ppge); e->slabs_w = w.take<float>(e->nsplit_w * Ph * Ph);
   e->parts = w.take<double>((long)e->nblk_stats * 3 * Ph);
   e->sums = w.take<double>(3 * Ph);
@@ -441,6 +444,8 @@ extern "C" int gs_gcond_set_shard(gs_gcond* e, int c_lo, int c_hi, int r_lo, int
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   if (c_lo < 0 || c_hi < c_lo || c_hi > e->C || r_lo < 0 || r_hi < r_lo || r_hi > e->n)
     GS_FAIL(GS_ERR_ARG, "gs_gcond_set_shard: ranges out of bounds");
+  if (e->pge_chunks > 1 && (r_lo != 0 || r_hi != e->n))
+    GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond_set_shard: the chunked PGE (pge_chunks > 1) cannot be combined with pair-row sharding");
   e->c_lo = c_lo; e->c_hi = c_hi; e->r_lo = r_lo; e->r_hi = r_hi;
   return GS_OK;
 }
@@ -626,6 +631,125 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
 // stage: PGE forward (parametrized_adj.py:40-71) + dense_gcn_norm, in three parts so that ranks can exchange
 // (1 -> 2) the BN-2 column sums "ar_bn2" and (2 -> 3) the pre-sigmoid pair scores "e3".
 // ================================================================================================
+// ---- chunked PGE (parametrized_adj.py:41-55): np.array_split of the n'^2 flat pair indices into `pge_chunks` contiguous
+// chunks, each normalised by its own BatchNorm batch statistics -------------------------------------------------------
+static void chunk_range(const gs_gcond* e, int ch, long* k0, long* count) {
+  const long n2 = (long)e->n * e->n, q = n2 / e->pge_chunks, rem = n2 % e->pge_chunks;   // the first `rem` chunks get q + 1
+  *count = q + (ch < rem ? 1 : 0);
+  *k0 = (long)ch * q + (ch < rem ? ch : rem);
+}
+
+static int pge_forward_chunked(gs_gcond* e, gs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int n = e->n, d = e->d, Ph = e->Ph;
+  const float* X = e->io.feat_syn;
+  const float* pp = e->io.pge_params;
+  e->fwd_cached = false;
+  {
+    gs_gemm_desc uv[2];
+    uv[0] = mk(X, d, 1, pp + e->pW0, 1, 2L * d, e->U, Ph, n, Ph, d);
+    uv[1] = uv[0]; uv[1].B = pp + e->pW0 + d; uv[1].C = e->V;
+    GS_TRY(gs_gemm_group_f32(uv, 2, stream));
+  }
+  for (int ch = 0; ch < e->pge_chunks; ++ch) {
+    long k0, cnt;
+    chunk_range(e, ch, &k0, &cnt);
+    float* mu1 = e->chunk_fwd + ((long)ch * 4 + 0) * Ph; float* is1 = mu1 + Ph; float* mu2 = is1 + Ph; float* is2 = mu2 + Ph;
+    const int nblk = gs_cdiv(cnt, e->rows_per_block);
+    hipLaunchKernelGGL(gs_pge_chunk_e1_stats_kernel, dim3(nblk), dim3(256), 0, s, e->U, e->V, pp + e->pb0, n, Ph, k0, cnt,
+                       e->rows_per_block, e->parts);
+    reduce_parts(e, e->parts, nblk, 2, 2, s);
+    hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, cnt, Ph, mu1, is1);
+    hipLaunchKernelGGL(gs_pge_make_a1_flat_kernel, dim3(gs_cdiv(cnt * (Ph / 4), 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0, mu1,
+                       is1, pp + e->pg1, pp + e->pbe1, n, Ph, k0, cnt, e->A1 + k0 * Ph);
+    GS_LAUNCH_CHECK();
+    gs_gemm_desc g = mk(e->A1 + k0 * Ph, Ph, 1, pp + e->pW1, 1, Ph, e->E2 + k0 * Ph, Ph, (int)cnt, Ph, Ph);
+    g.bias = pp + e->pb1;
+    g.colstat = e->statp;
+    GS_TRY(gs_gemm_f32(&g, stream));
+    reduce_parts(e, e->statp, gs_gemm_tiles_m(&g), 2, 2, s);
+    hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, cnt, Ph, mu2, is2);
+    hipLaunchKernelGGL(gs_pge_layer3_kernel, dim3(gs_cdiv(cnt, 4)), dim3(256), 0, s, e->E2 + k0 * Ph, mu2, is2, pp + e->pg2,
+                       pp + e->pbe2, pp + e->pw2, pp + e->pb2, cnt, Ph, e->e3 + k0);
+    GS_LAUNCH_CHECK();
+  }
+  return GS_OK;
+}
+
+// parts 1 + 2 of the backward for the chunked PGE; leaves dU, dV (the sums of dE1 over r and over c) for part 3
+static int pge_backward_chunked(gs_gcond* e, int need_param_grads, gs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int n = e->n, Ph = e->Ph, nc = e->pge_chunks;
+  const long n2 = (long)n * n;
+  const float* pp = e->io.pge_params;
+  float* g = e->d_pge;
+  hipLaunchKernelGGL(gs_pge_adj_bwd_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, e->d_adj, e->adj_raw, n, e->de3);
+  for (int ch = 0; ch < nc; ++ch) {       // BN-2 / layer-3 backward, chunk by chunk
+    long k0, cnt;
+    chunk_range(e, ch, &k0, &cnt);
+    const float* mu2 = e->chunk_fwd + ((long)ch * 4 + 2) * Ph; const float* is2 = mu2 + Ph;
+    float* bw = e->chunk_bwd + (long)ch * 5 * Ph;     // dw2 | dbe2 | dg2 | dbe1 | dg1
+    const int nblk = gs_cdiv(cnt, e->rows_per_block);
+    hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(nblk), dim3(256), 0, s, e->E2 + k0 * Ph, e->de3 + k0, mu2, is2, pp + e->pg2,
+                       pp + e->pbe2, pp + e->pw2, cnt, Ph, e->rows_per_block, e->parts);
+    reduce_parts(e, e->parts, nblk, 3, 3, s);
+    hipLaunchKernelGGL(gs_sums_to_float_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, 3, Ph, bw, bw + Ph, bw + 2 * Ph);
+    hipLaunchKernelGGL(gs_pge_bn2_bwd_v4_kernel, dim3(gs_cdiv(gs_cdiv(cnt, 8) * (long)(Ph / 4), 256)), dim3(256), 0, s, e->E2 + k0 * Ph,
+                       e->de3 + k0, mu2, is2, pp + e->pg2, pp + e->pbe2, pp + e->pw2, bw + Ph, bw + 2 * Ph, cnt, cnt, Ph,
+                       e->dE2 + k0 * Ph);
+    GS_LAUNCH_CHECK();
+  }
+  if (need_param_grads) {
+    // the parameters are shared by the chunks: their gradients are sums over chunks
+    GS_TRY(gs_reduce_slabs_f32(g + e->pw2, e->chunk_bwd, Ph, nc, 5L * Ph, 0.f, stream));
+    GS_TRY(gs_reduce_slabs_f32(g + e->pbe2, e->chunk_bwd + Ph, Ph, nc, 5L * Ph, 0.f, stream));
+    GS_TRY(gs_reduce_slabs_f32(g + e->pg2, e->chunk_bwd + 2 * Ph, Ph, nc, 5L * Ph, 0.f, stream));
+    hipLaunchKernelGGL(gs_sum_kernel, dim3(1), dim3(1024), 0, s, e->de3, n2, g + e->pb2);
+    const int nblk = gs_cdiv(n2, e->rows_per_block);
+    const int nsplit = gs_cdiv(n2, e->kchunk_w);
+    gs_gemm_desc w = mk(e->dE2, 1, Ph, e->A1, Ph, 1, e->slabs_w, Ph, Ph, Ph, (int)n2);
+    w.nb2 = nsplit; w.kchunk = e->kchunk_w; w.sCb2 = (long)Ph * Ph;
+    GS_TRY(gs_gemm_f32(&w, stream));
+    GS_TRY(gs_reduce_slabs_f32(g + e->pW1, e->slabs_w, (long)Ph * Ph, nsplit, (long)Ph * Ph, 0.f, stream));
+    hipLaunchKernelGGL(gs_col_stats_kernel, dim3(nblk), dim3(256), 0, s, e->dE2, n2, Ph, e->rows_per_block, e->parts);
+    reduce_parts(e, e->parts, nblk, 2, 1, s);
+    hipLaunchKernelGGL(gs_sums_to_float_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, 1, Ph, g + e->pb1, (float*)nullptr,
+                       (float*)nullptr);
+    GS_LAUNCH_CHECK();
+  }
+  {  // dY1 = (dE2 W1) * [A1 > 0] over all pairs
+    hipLaunchKernelGGL(gs_transpose_small_kernel, dim3(gs_cdiv(Ph, 32), gs_cdiv(Ph, 32)), dim3(32, 8), 0, s, pp + e->pW1, Ph, Ph, e->W1T);
+    GS_LAUNCH_CHECK();
+    gs_gemm_desc a = mk(e->dE2, Ph, 1, e->W1T, 1, Ph, e->dY1, Ph, (int)n2, Ph, Ph);
+    a.mask = e->A1; a.ldmask = Ph;
+    GS_TRY(gs_gemm_f32(&a, stream));
+  }
+  for (int ch = 0; ch < nc; ++ch) {       // BN-1 backward, chunk by chunk, in place: dY1 becomes dE1
+    long k0, cnt;
+    chunk_range(e, ch, &k0, &cnt);
+    const float* mu1 = e->chunk_fwd + (long)ch * 4 * Ph; const float* is1 = mu1 + Ph;
+    float* bw = e->chunk_bwd + (long)ch * 5 * Ph;
+    const int nblk = gs_cdiv(cnt, e->rows_per_block);
+    hipLaunchKernelGGL(gs_pge_chunk_dy1_stats_kernel, dim3(nblk), dim3(256), 0, s, e->dY1 + k0 * Ph, e->U, e->V, pp + e->pb0, mu1, is1,
+                       n, Ph, k0, cnt, e->rows_per_block, e->parts);
+    reduce_parts(e, e->parts, nblk, 2, 2, s);
+    hipLaunchKernelGGL(gs_sums_to_float_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, 2, Ph, bw + 3 * Ph, bw + 4 * Ph,
+                       (float*)nullptr);
+    hipLaunchKernelGGL(gs_pge_chunk_bn1_bwd_kernel, dim3(gs_cdiv(cnt * Ph, 256)), dim3(256), 0, s, e->dY1 + k0 * Ph, e->U, e->V,
+                       pp + e->pb0, mu1, is1, pp + e->pg1, bw + 3 * Ph, bw + 4 * Ph, n, Ph, k0, cnt);
+    GS_LAUNCH_CHECK();
+  }
+  if (need_param_grads) {
+    GS_TRY(gs_reduce_slabs_f32(g + e->pbe1, e->chunk_bwd + 3 * Ph, Ph, nc, 5L * Ph, 0.f, stream));
+    GS_TRY(gs_reduce_slabs_f32(g + e->pg1, e->chunk_bwd + 4 * Ph, Ph, nc, 5L * Ph, 0.f, stream));
+  }
+  // dV[r] = sum_c dE1[(r, c)] ; dU[c] = sum_r dE1[(r, c)]
+  hipLaunchKernelGGL(gs_pge_marginal_r_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, 0, e->dV);
+  hipLaunchKernelGGL(gs_pge_marginal_c_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, n, e->dU);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int part, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   hipStream_t s = (hipStream_t)stream;
@@ -634,6 +758,7 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
   const float* X = e->io.feat_syn;
   const float* pp = e->io.pge_params;
   const int nblk = gs_cdiv(rows > 0 ? rows : 1, e->rows_per_block);
+  if (e->pge_chunks > 1 && part != 3) return part == 1 ? pge_forward_chunked(e, stream) : GS_OK;
   if (part == 1) {
     e->fwd_cached = false;
     {  // U = X W0[:, :d]^T ; V = X W0[:, d:]^T
@@ -1001,6 +1126,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
   float* g = e->d_pge;
   const float* de3l = e->de3 + (long)e->r_lo * n;
   const int nblk = gs_cdiv(rows > 0 ? rows : 1, e->rows_per_block);
+  if (e->pge_chunks > 1 && part != 3) return part == 1 ? pge_backward_chunked(e, need_param_grads, stream) : GS_OK;
   if (part == 1) {
     hipLaunchKernelGGL(gs_pge_adj_bwd_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, e->d_adj, e->adj_raw, n, e->de3);
     if (rows > 0) {
@@ -1062,11 +1188,13 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
     return GS_OK;
   }
   if (part != 3) GS_FAIL(GS_ERR_ARG, "gs_gcond_stage_pge_backward_part: part must be 1, 2 or 3");
+  if (e->pge_chunks == 1) {   // (the chunked backward has already left dU, dV and the BN-1 parameter gradients)
   hipLaunchKernelGGL(gs_pge_bn1_bwd_cols_kernel, dim3(gs_cdiv(Ph, 32)), dim3(1024), 0, s, e->U, e->V, e->rowsum_c, e->colsum_r,
                      pp + e->pb0, e->mu1, e->is1, n, Ph, g + e->pg1, g + e->pbe1);
   hipLaunchKernelGGL(gs_pge_bn1_bwd_uv_kernel, dim3(gs_cdiv((long)n * Ph, 256)), dim3(256), 0, s, e->U, e->V, e->rowsum_c,
                      e->colsum_r, pp + e->pb0, e->mu1, e->is1, pp + e->pg1, e->sumU, e->sumV, g + e->pg1, g + e->pbe1, n, Ph,
                      e->dU, e->dV);
+  }
   GS_LAUNCH_CHECK();
   if (need_param_grads) {
     hipLaunchKernelGGL(gs_colsum_small_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->dU, n, Ph, g + e->pb0);

@@ -999,3 +999,90 @@ __global__ void gs_kcount_kernel(const int* __restrict__ n1, int f2, int nclass,
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < nclass) kcount[c] = n1[c] * f2;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Chunked PGE (parametrized_adj.py:41-55: reddit with r >= 0.01 passes the n'^2 pairs through the MLP in 5 contiguous
+// chunks of the flat pair index, EACH with its own BatchNorm batch statistics).  The layer-1 decomposition still holds per
+// pair, but the closed forms over the full grid do not: statistics are reduced numerically over each chunk's pairs.
+// Pair k = r * n + c;  E1[k, j] = U[c, j] + V[r, j] + b0[j].
+// ------------------------------------------------------------------------------------------------
+// part[blk][0][j] = sum E1, part[blk][1][j] = sum E1^2 over the block's pairs (fp64)
+__global__ __launch_bounds__(256) void gs_pge_chunk_e1_stats_kernel(const float* __restrict__ U, const float* __restrict__ V,
+                                                                    const float* __restrict__ b0, int n, int Ph, long k0,
+                                                                    long count, int rows_per_block, double* __restrict__ part) {
+  const long p0 = (long)blockIdx.x * rows_per_block, p1 = min(count, p0 + rows_per_block);
+  for (int j = threadIdx.x; j < Ph; j += 256) {
+    double s = 0, s2 = 0;
+    const float b = b0[j];
+    for (long q = p0; q < p1; ++q) {
+      const long k = k0 + q;
+      const int r = (int)(k / n), c = (int)(k - (long)r * n);
+      const double x = (double)(U[(long)c * Ph + j] + V[(long)r * Ph + j] + b);
+      s += x;
+      s2 += x * x;
+    }
+    part[((long)blockIdx.x * 2 + 0) * Ph + j] = s;
+    part[((long)blockIdx.x * 2 + 1) * Ph + j] = s2;
+  }
+}
+// A1[k, j] for the chunk's pairs (A1 points at the chunk's first row); one thread per 4 consecutive j
+__global__ void gs_pge_make_a1_flat_kernel(const float* __restrict__ U, const float* __restrict__ V, const float* __restrict__ b0,
+                                           const float* __restrict__ mu1, const float* __restrict__ is1,
+                                           const float* __restrict__ g1, const float* __restrict__ be1, int n, int Ph, long k0,
+                                           long count, float* __restrict__ A1) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Q = Ph >> 2;
+  if (idx >= count * Q) return;
+  const int j = (int)(idx % Q) * 4;
+  const long q = idx / Q, k = k0 + q;
+  const int r = (int)(k / n), c = (int)(k - (long)r * n);
+  const float4 u = *reinterpret_cast<const float4*>(U + (long)c * Ph + j);
+  const float4 v = *reinterpret_cast<const float4*>(V + (long)r * Ph + j);
+  const float4 b = *reinterpret_cast<const float4*>(b0 + j), m = *reinterpret_cast<const float4*>(mu1 + j);
+  const float4 is = *reinterpret_cast<const float4*>(is1 + j), g = *reinterpret_cast<const float4*>(g1 + j);
+  const float4 be = *reinterpret_cast<const float4*>(be1 + j);
+  float4 o;
+  o.x = fmaxf(fmaf(g.x, (u.x + v.x + b.x - m.x) * is.x, be.x), 0.f);
+  o.y = fmaxf(fmaf(g.y, (u.y + v.y + b.y - m.y) * is.y, be.y), 0.f);
+  o.z = fmaxf(fmaf(g.z, (u.z + v.z + b.z - m.z) * is.z, be.z), 0.f);
+  o.w = fmaxf(fmaf(g.w, (u.w + v.w + b.w - m.w) * is.w, be.w), 0.f);
+  *reinterpret_cast<float4*>(A1 + q * Ph + j) = o;
+}
+// BN-1 backward statistics of a chunk: part[blk][0][j] = sum dY1 (-> d beta1), [1] = sum dY1 * xhat1 (-> d gamma1)
+__global__ __launch_bounds__(256) void gs_pge_chunk_dy1_stats_kernel(const float* __restrict__ dY1, const float* __restrict__ U,
+                                                                     const float* __restrict__ V, const float* __restrict__ b0,
+                                                                     const float* __restrict__ mu1, const float* __restrict__ is1,
+                                                                     int n, int Ph, long k0, long count, int rows_per_block,
+                                                                     double* __restrict__ part) {
+  const long p0 = (long)blockIdx.x * rows_per_block, p1 = min(count, p0 + rows_per_block);
+  for (int j = threadIdx.x; j < Ph; j += 256) {
+    double sb = 0, sg = 0;
+    const float b = b0[j], m = mu1[j], is = is1[j];
+    for (long q = p0; q < p1; ++q) {
+      const long k = k0 + q;
+      const int r = (int)(k / n), c = (int)(k - (long)r * n);
+      const float xh = (U[(long)c * Ph + j] + V[(long)r * Ph + j] + b - m) * is;
+      const float dy = dY1[q * Ph + j];
+      sb += (double)dy;
+      sg += (double)(dy * xh);
+    }
+    part[((long)blockIdx.x * 2 + 0) * Ph + j] = sb;
+    part[((long)blockIdx.x * 2 + 1) * Ph + j] = sg;
+  }
+}
+// dE1 = g1 * is1 * (dY1 - dbe1 / m - xhat1 * dg1 / m) in place over the chunk's pairs (m = pairs in the chunk)
+__global__ void gs_pge_chunk_bn1_bwd_kernel(float* __restrict__ dY1, const float* __restrict__ U, const float* __restrict__ V,
+                                            const float* __restrict__ b0, const float* __restrict__ mu1,
+                                            const float* __restrict__ is1, const float* __restrict__ g1,
+                                            const float* __restrict__ dbe1, const float* __restrict__ dg1, int n, int Ph, long k0,
+                                            long count) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= count * Ph) return;
+  const int j = (int)(idx % Ph);
+  const long q = idx / Ph, k = k0 + q;
+  const int r = (int)(k / n), c = (int)(k - (long)r * n);
+  const float xh = (U[(long)c * Ph + j] + V[(long)r * Ph + j] + b0[j] - mu1[j]) * is1[j];
+  const float m = (float)count;
+  dY1[idx] = g1[j] * is1[j] * (dY1[idx] - dbe1[j] / m - xh * dg1[j] / m);
+}
+

@@ -206,6 +206,7 @@ class EngineShapes:
     f1: int = 10
     f2: int = 5
     model: str = "SGC"     # condense model: SGC (ntrans transforms) or GCN (two layers)
+    pge_chunks: int = 1    # 5 = the chunked PGE of reddit r >= 0.01 (parametrized_adj.py:41-55)
 
 
 def model_param_count(d, hidden, nclass, ntrans):
@@ -251,7 +252,7 @@ class GCondEngine:
         self.adj_syn = torch.zeros(s.n_syn, s.n_syn, dtype=torch.float32, device=dev)
         cfg = GCondConfig(s.n_nodes, d, self.ldx, s.nclass, s.n_syn, s.ntrans, s.hidden, s.pge_hidden, s.bcap, s.f1, s.f2,
                           METRICS[dis_metric], inner_loop, lr_feat, lr_adj, lr_model, seed, 1 if external_blocks else 0,
-                          {"SGC": 0, "GCN": 1}[s.model])
+                          {"SGC": 0, "GCN": 1}[s.model], int(s.pge_chunks))
         nbytes = C.c_size_t()
         check(L.gs_gcond_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
         self.workspace_bytes = nbytes.value

@@ -190,6 +190,8 @@ typedef struct gs_gcond_config {
   uint64_t seed;
   int external_blocks;     /* 1: blocks are supplied with gs_gcond_set_blocks (parity mode)    */
   int condense_model;      /* 0 = SGC (models/sgc.py), 1 = 2-layer GCN (models/gcn.py): parameters laid out like SGC T = 2 */
+  int pge_chunks;          /* <= 1: one BatchNorm batch over all n'^2 pairs; 5: the chunked PGE of reddit r >= 0.01
+                              (parametrized_adj.py:41-55: np.array_split chunks, per-chunk batch statistics); not with row sharding */
 } gs_gcond_config;
 
 typedef struct gs_gcond_io {

@@ -237,22 +237,33 @@ def init_pge(nfeat, nhid, nlayers=3, dtype=torch.float32):
     return {"lin": lin, "bn": bns}
 
 
-def pge_forward(x, pge, eps=1e-5):
+def pge_forward(x, pge, eps=1e-5, n_chunks=1):
     """parametrized_adj.py:40-71.  Pair k = r*n + c -> [x_c || x_r] (meshgrid order :30-32);
-    BatchNorm always with batch statistics (biased variance); (A+A^T)/2, sigmoid, zero diag."""
+    BatchNorm always with batch statistics (biased variance); (A+A^T)/2, sigmoid, zero diag.
+    n_chunks = 5 is the reddit / r >= 0.01 branch (:41-55): the flat pair list goes through the layers in
+    np.array_split chunks, each normalised by its own batch statistics."""
     n = x.shape[0]
     lin, bn = pge["lin"], pge["bn"]
     idx_c = torch.arange(n).repeat(n)            # k % n
     idx_r = torch.arange(n).repeat_interleave(n)  # k // n
-    e = torch.cat([x[idx_c], x[idx_r]], dim=1)
     nl = len(lin) // 2
-    for i in range(nl):
-        e = e @ lin[2 * i].T + lin[2 * i + 1]
-        if i != nl - 1:
-            mu = e.mean(0)
-            var = e.var(0, unbiased=False)
-            e = (e - mu) / torch.sqrt(var + eps) * bn[2 * i] + bn[2 * i + 1]
-            e = F.relu(e)
+
+    def mlp(e):
+        for i in range(nl):
+            e = e @ lin[2 * i].T + lin[2 * i + 1]
+            if i != nl - 1:
+                mu = e.mean(0)
+                var = e.var(0, unbiased=False)
+                e = (e - mu) / torch.sqrt(var + eps) * bn[2 * i] + bn[2 * i + 1]
+                e = F.relu(e)
+        return e
+
+    if n_chunks > 1:
+        parts = [mlp(torch.cat([x[idx_c[torch.from_numpy(ix)]], x[idx_r[torch.from_numpy(ix)]]], dim=1))
+                 for ix in np.array_split(np.arange(n * n), n_chunks)]
+        e = torch.cat(parts)
+    else:
+        e = mlp(torch.cat([x[idx_c], x[idx_r]], dim=1))
     adj = e.reshape(n, n)
     adj = (adj + adj.T) / 2
     adj = torch.sigmoid(adj)

@@ -594,7 +594,34 @@ def g10():
     save("g10_files", **out)
 
 
+# ---------------------------------------------------------------- G11 chunked PGE -------------
+
+
+def g11():
+    """parametrized_adj.py:41-55: the reddit / reduction_rate >= 0.01 branch of PGE.forward (5 np.array_split chunks of the
+    pair list, per-chunk BatchNorm batch statistics), forward and gradients through a fixed linear functional."""
+    out = {}
+    n, d = 13, 6                       # 169 pairs -> chunks of 34, 34, 34, 34, 33
+    torch.manual_seed(21)
+    x = torch.randn(n, d, requires_grad=True)
+    args = args_obj(dataset="reddit", reduction_rate=0.01)
+    pge = PGE(nfeat=d, nnodes=n, device="cpu", args=args)
+    with torch.no_grad():
+        for b in pge.bns:              # non-trivial affine BN parameters
+            b.weight.copy_(torch.rand_like(b.weight) + 0.5)
+            b.bias.copy_(torch.randn_like(b.bias) * 0.2)
+    w = torch.randn(n, n)
+    adj = pge(x)
+    (adj * w).sum().backward()
+    out.update(x=np_(x), w=np_(w), adj=np_(adj), dx=np_(x.grad), nhid=np.array(pge.layers[0].weight.shape[0]))
+    for i, q in enumerate(pge.parameters()):
+        out[f"p{i}"] = np_(q)
+        out[f"dp{i}"] = np_(q.grad)
+    out["inference"] = np_(pge.inference(x.detach()))
+    save("g11_pge_chunked", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

@@ -606,3 +606,51 @@ def test_full_size_arxiv_properties():
     assert l1 == l2 and torch.equal(e1.feat_syn, e2.feat_syn) and torch.equal(e1.pge_params, e2.pge_params)
     a = e1.adj_syn
     assert torch.equal(a, a.T) and float(a.diagonal().abs().max()) == 0.0 and float(a.min()) >= 0.0 and float(a.max()) < 1.0
+
+
+@pytest.mark.parametrize("n,ph", [(13, 128), (37, 256)])
+def test_chunked_pge_forward_backward(golden_dir, n, ph):
+    """pge_chunks = 5 (parametrized_adj.py:41-55) on the engine: adjacency, d/dX~ and d/dtheta_PGE of a linear functional of
+    the raw adjacency against the oracle's autograd (the oracle itself is pinned by golden G11, n = 13: that case also
+    against the reference's own numbers)."""
+    d, C = 6, 3
+    torch.manual_seed(4)
+    labels_syn = np.sort(np.arange(n) % C)
+    ranges = [(int(np.searchsorted(labels_syn, c)), int(np.searchsorted(labels_syn, c, side="right"))) for c in range(C)]
+    from graphslim_amd.engine import EngineShapes, GCondEngine
+    sh = EngineShapes(50, d, C, n, 1, 8, ph, 8, 4, 3, pge_chunks=5)
+    eng = GCondEngine(sh, torch.randn(50, d), None, None, None, labels_syn, ranges, lr_feat=0.01, lr_adj=0.01, lr_model=0.01,
+                      inner_loop=0, dis_metric="ours", seed=1, external_blocks=True, device=DEV)
+    if n == 13:
+        g = load_golden(golden_dir, "g11_pge_chunked")
+        x0, w = T(g["x"]), T(g["w"])
+        params = [T(g[f"p{i}"]) for i in range(10)]
+    else:
+        x0, w = torch.randn(n, d), torch.randn(n, n)
+        pge = O.init_pge(d, ph)
+        params = list(pge["lin"]) + [torch.rand(ph) + 0.5, torch.randn(ph) * 0.2, torch.rand(ph) + 0.5, torch.randn(ph) * 0.2]
+    eng.set_feat(x0)
+    eng.set_pge(params)
+    eng.stage_pge_forward(False)
+    x = x0.clone().requires_grad_(True)
+    lin = [q.clone().requires_grad_(True) for q in params[:6]]
+    bn = [q.clone().requires_grad_(True) for q in params[6:]]
+    ref = O.pge_forward(x, {"lin": lin, "bn": bn}, n_chunks=5)
+    close(eng.buffer("adj_raw", (n, n)), ref.detach(), 2e-4, "chunked adj")
+    if n == 13:
+        close(eng.buffer("adj_raw", (n, n)), g["adj"], 2e-4, "chunked adj vs the reference")
+    (ref * w).sum().backward()
+    eng.view("d_adj").copy_(w.reshape(-1).to(DEV))
+    eng.view("d_feat").zero_()
+    eng.stage_pge_backward(True, True)
+    close(eng.buffer("d_feat", (n, d)), x.grad, 2e-3, "d X~ through the chunked PGE")
+    flat = eng.buffer("d_pge", (eng.pge_params.numel(),)).cpu()
+    off = 0
+    for i, q in enumerate(lin + bn):
+        got = flat[off:off + q.numel()].reshape(q.shape)
+        off += q.numel()
+        if i in (1, 3):
+            continue
+        close(got, q.grad, 3e-3, f"d theta_PGE[{i}]")
+    eng.stage_pge_forward(True)          # inference pass: same function
+    close(eng.adj_syn.cpu(), ref.detach(), 2e-4, "chunked inference")

@@ -223,3 +223,22 @@ def test_g9_fit_with_val_trace(golden_dir, setting):
         adj_t = O.csr_to_torch(*O.normalize_adj_sparse(a[np.ix_(idx_test, idx_test)]), len(idx_test))
         acc = O.eval_test(w, x[idx_test], adj_t, it, y[idx_test])
     assert abs(acc - float(g[f"{setting}_test"])) <= 1.0 / len(idx_test) + 1e-12
+
+
+def test_g11_chunked_pge(golden_dir):
+    """parametrized_adj.py:41-55 (reddit, r >= 0.01): five np.array_split chunks with per-chunk BatchNorm statistics."""
+    g = load(golden_dir, "g11_pge_chunked")
+    x = T(g["x"]).clone().requires_grad_(True)
+    lin = [T(g[f"p{i}"]).clone().requires_grad_(True) for i in range(6)]
+    bn = [T(g[f"p{i}"]).clone().requires_grad_(True) for i in range(6, 10)]
+    adj = O.pge_forward(x, {"lin": lin, "bn": bn}, n_chunks=5)
+    np.testing.assert_allclose(adj.detach().numpy(), g["adj"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g["inference"], g["adj"], rtol=0, atol=0)
+    (adj * T(g["w"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=1e-3, atol=1e-5)
+    for i, q in enumerate(lin + bn):
+        if i in (1, 3):      # biases in front of a batch-stat BatchNorm: exact-zero gradient, rounding noise on both sides
+            continue
+        np.testing.assert_allclose(q.grad.numpy(), g[f"dp{i}"], rtol=2e-3, atol=2e-5, err_msg=f"p{i}")
+    # and it is NOT the single-batch forward
+    assert np.abs(O.pge_forward(x.detach(), {"lin": [q.detach() for q in lin], "bn": [q.detach() for q in bn]}).numpy() - g["adj"]).max() > 1e-3
