@@ -50,6 +50,17 @@ class DeviceGraph:
         self.S = spmm_csr(*csr, X)                    # [hi - lo, pad4(d)]
         self._targets = {None: (csr, self.hi - self.lo)}
 
+    def target_t(self, idx):
+        """CSR of (A^[idx, :])^T  [n x n_target]: the backward product of the last aggregation when the loss is taken on the
+        rows `idx` (None = all rows) of the training graph.  Cached next to the forward CSR."""
+        key = ("T", None if idx is None else id(idx))
+        if key not in self._targets:
+            ids = np.arange(self.n) if idx is None else np.asarray(idx.cpu() if isinstance(idx, torch.Tensor) else idx)
+            sub_t = self._norm[ids].T.tocsr()
+            self._targets[key] = ((_i32(sub_t.indptr, self.device), _i32(sub_t.indices, self.device),
+                                   torch.as_tensor(sub_t.data, dtype=torch.float32).to(self.device)), len(ids), None, idx)
+        return self._targets[key][0]
+
     def target(self, idx):
         """CSR of the target rows `idx` (global ids; None = all rows) that fall into this rank's block, cached."""
         key = None if idx is None else id(idx)
@@ -178,6 +189,38 @@ class GCN:
         adam_step(self.P, g, opt["m"], opt["v"], opt["lr"], opt["step"], weight_decay=self.weight_decay)
         return lossr
 
+    def _train_step_graph(self, G, idx, labels_i32, opt):
+        """One optimisation step on an ORIGINAL graph (models/base.py:156-161 with reduced=False): loss on the rows `idx`
+        of Z = A^ (relu(S W1 + b1) W2) + b2, S = A^ X cached in `G` — so neither pass needs a width-d or width-h SpMM."""
+        W1, b1, W2, b2 = self.parameters()
+        d, h, Cn, ldc = self.nfeat, self.nhid, self.nclass, self.ldc
+        dev = self.device
+        L = _lib.lib()
+        N = G.S.shape[0]
+        H = torch.empty(N, h, device=dev)
+        gemm(G.S, W1, H, N, h, d, (G.S.stride(0), 1), (h, 1), h, bias=b1, relu=1)
+        T2 = torch.zeros(N, ldc, device=dev)
+        gemm(H, W2, T2, N, Cn, h, (h, 1), (Cn, 1), ldc)
+        csr, nt = G.target(idx)[0], G.target(idx)[1]
+        Z = torch.zeros(nt, ldc, device=dev)
+        spmm_csr(*csr, T2, F=ldc, out=Z)
+        check(L.gs_bias_act_f32(ptr(Z), ldc, ptr(b2), nt, Cn, 0, stream()))
+        Gz = torch.empty(nt, Cn, device=dev)
+        lossr = torch.empty(nt, device=dev)
+        check(L.gs_softmax_nll_grad_f32(ptr(Z), ldc, ptr(labels_i32), nt, Cn, ptr(Gz), ptr(lossr), stream()))
+        g = torch.empty_like(self.P)
+        gW1, gb1, gW2, gb2 = self._views(g)
+        check(L.gs_colsum_f32(ptr(Gz), Cn, nt, Cn, ptr(gb2), stream()))
+        dT2 = spmm_csr(*G.target_t(idx), Gz, F=Cn)                          # (A^[idx, :])^T G   [N, C]
+        gemm(H, dT2, gW2, h, Cn, N, (1, h), (Cn, 1), Cn)                     # H^T dT2
+        dH = torch.empty(N, h, device=dev)
+        gemm(dT2, W2, dH, N, h, Cn, (Cn, 1), (1, Cn), h, mask=H, ldmask=h)   # (dT2 W2^T) * [H > 0]
+        check(L.gs_colsum_f32(ptr(dH), h, N, h, ptr(gb1), stream()))
+        gemm(G.S, dH, gW1, d, h, N, (1, G.S.stride(0)), (h, 1), h)           # S^T dH
+        opt["step"] += 1
+        adam_step(self.P, g, opt["m"], opt["v"], opt["lr"], opt["step"], weight_decay=self.weight_decay)
+        return lossr
+
     def _new_opt(self, lr):
         return {"m": torch.zeros_like(self.P), "v": torch.zeros_like(self.P), "step": 0, "lr": lr}
 
@@ -216,14 +259,20 @@ class GCN:
                      final_output=False, best_val=None, **kwargs):
         """models/base.py:80-187 for the reduced-graph case: train on (adj_syn, feat_syn, labels_syn), validate on the
         full graph (trans) / validation graph (ind) every epoch, keep the best-validation weights."""
-        if not reduced:
-            raise NotImplementedError("graphslim_amd.GCN.fit_with_val: only reduced=True (GCond evaluation) is built")
         dev = self.device
         self.initialize()
-        adj = torch.as_tensor(data.adj_syn).to(dev, torch.float32).contiguous()
-        feat = torch.as_tensor(data.feat_syn).to(dev, torch.float32).contiguous()
-        labels = torch.as_tensor(data.labels_syn).to(dev).to(torch.int32)
-        adj, _ = dense_gcn_norm_fwd(adj)          # base.py:112 normalises the (dense) synthetic adjacency unconditionally
+        if reduced:
+            adj = torch.as_tensor(data.adj_syn).to(dev, torch.float32).contiguous()
+            feat = torch.as_tensor(data.feat_syn).to(dev, torch.float32).contiguous()
+            labels = torch.as_tensor(data.labels_syn).to(dev).to(torch.int32)
+            adj, _ = dense_gcn_norm_fwd(adj)          # base.py:112 normalises the (dense) synthetic adjacency unconditionally
+        else:
+            # base.py:91-96: the original graph — transductive: full graph, loss on output[idx_train]; inductive: train graph
+            if self.shard.world > 1:
+                raise NotImplementedError("graphslim_amd.GCN.fit_with_val(reduced=False) is not row-sharded")
+            Gt = self._graph_for(data, "full" if setting == "trans" else "train")
+            idx_loss = data.idx_train if setting == "trans" else None
+            labels = torch.as_tensor(data.labels_train).to(dev).to(torch.int32)
         if setting == "ind":
             G = self._graph_for(data, "val")
             idx_val, labels_val, n_val = self._targets(G, None, data.labels_val)
@@ -236,7 +285,7 @@ class GCN:
         for i in range(train_iters):
             if i == train_iters // 2 and self.lr > 0.001:           # base.py:153-154
                 opt = self._new_opt(self.lr * 0.1)
-            lossr = self._train_step_dense(feat, adj, labels, opt)
+            lossr = self._train_step_dense(feat, adj, labels, opt) if reduced else self._train_step_graph(Gt, idx_loss, labels, opt)
             if verbose and i % 100 == 0:
                 print("Epoch {}, training loss: {}".format(i, float(lossr.mean())))
             acc_val = self._accuracy(self._forward_graph(G, idx_val), labels_val, n_val)

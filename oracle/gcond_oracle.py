@@ -531,6 +531,34 @@ def fit_with_val(params, adj_syn, feat_syn, labels_syn, feat_full, adj_full_norm
     return float(best), best_w
 
 
+def fit_with_val_full(params, feat_train, adj_train_norm, idx_loss, labels_loss, feat_val, adj_val_norm, idx_val, labels_val,
+                      train_iters, lr=0.01, weight_decay=5e-4, trace=None):
+    """models/base.py:80-187 with reduced=False: the GCN is trained on the ORIGINAL graph (trans: full graph, loss on
+    output[idx_train]; ind: train sub-graph, loss on every row) and validated every epoch like the reduced case.
+    idx_loss = rows whose loss is taken (None = all rows)."""
+    params = [p.clone().requires_grad_(True) for p in params]
+    opt = Adam(params, lr, weight_decay)
+    best, best_w = 0.0, None
+    for i in range(train_iters):
+        if i == train_iters // 2 and lr > 0.001:
+            opt = Adam(params, lr * 0.1, weight_decay)
+        out = gcn_forward(feat_train, adj_train_norm, params)
+        loss = F.nll_loss(out if idx_loss is None else out[idx_loss], labels_loss)
+        g = torch.autograd.grad(loss, params)
+        opt.step(list(g))
+        with torch.no_grad():
+            o = gcn_forward(feat_val, adj_val_norm, params)
+            acc = accuracy(o if idx_val is None else o[idx_val], labels_val)
+            if trace is not None:
+                trace.append((float(loss), float(acc)))
+            if acc > best:
+                best = acc
+                best_w = [p.detach().clone() for p in params]
+    if best_w is None:
+        best_w = [p.detach().clone() for p in params]
+    return float(best), best_w
+
+
 def eval_test(params, feat_full, adj_full_norm, idx_test, labels_test):
     """models/base.py:190-225 (transductive)."""
     with torch.no_grad():

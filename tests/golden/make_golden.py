@@ -621,7 +621,52 @@ def g11():
     save("g11_pge_chunked", **out)
 
 
+# ---------------------------------------------------------------- G12 whole-graph fit_with_val -
+
+
+def g12():
+    """models/base.py:80-225 with reduced=False: the evaluation GCN trained on the ORIGINAL graph (whole-dataset baseline,
+    Evaluator.evaluate(reduced=False)), transductive (loss on output[idx_train]) and inductive (train sub-graph)."""
+    out = {}
+    n, nclass, d, hidden, iters = 140, 4, 9, 16, 30
+    a, x, y = make_graph(n, nclass, d, 6, seed=33)
+    data = FakeData(a, x, y, nclass, [8, 9, 10, 11], 35, 45, seed=6)
+    coo = a.tocoo()
+    out.update(a_row=coo.row, a_col=coo.col, x=x, y=y, idx_train=np_(data.idx_train), idx_val=np_(data.idx_val),
+               idx_test=np_(data.idx_test), meta=np.array([n, nclass, d, hidden, iters]))
+    for setting in ("trans", "ind"):
+        args = args_obj(hidden=hidden, setting=setting, lr=0.01, weight_decay=5e-4, dropout=0.0)
+        RU.seed_everything(11)
+        model = GCN(d, hidden, nclass, args, mode="eval")
+        accs, inits = [], []
+        base_metric = model.metric
+
+        def metric(o, l):
+            v = base_metric(o, l)
+            accs.append(float(v))
+            return v
+
+        model.metric = metric
+        base_init = model.initialize
+
+        def init_spy():
+            base_init()
+            inits.append([np_(p).copy() for p in model.parameters()])
+
+        model.initialize = init_spy
+        best = model.fit_with_val(data, train_iters=iters, normadj=True, verbose=False, setting=setting, reduced=False)
+        acc_test = model.test(data, setting=setting, verbose=False)
+        out[f"{setting}_val_trace"] = np.array(accs[:iters])
+        out[f"{setting}_best"] = np.array(best)
+        out[f"{setting}_test"] = np.array(float(acc_test))
+        for i, w in enumerate(inits[-1]):
+            out[f"{setting}_init{i}"] = w
+        for i, w in enumerate(model.parameters()):
+            out[f"{setting}_final{i}"] = np_(w)
+    save("g12_fit_full", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

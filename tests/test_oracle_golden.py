@@ -242,3 +242,32 @@ def test_g11_chunked_pge(golden_dir):
         np.testing.assert_allclose(q.grad.numpy(), g[f"dp{i}"], rtol=2e-3, atol=2e-5, err_msg=f"p{i}")
     # and it is NOT the single-batch forward
     assert np.abs(O.pge_forward(x.detach(), {"lin": [q.detach() for q in lin], "bn": [q.detach() for q in bn]}).numpy() - g["adj"]).max() > 1e-3
+
+
+@pytest.mark.parametrize("setting", ["trans", "ind"])
+def test_g12_whole_graph_fit_with_val(golden_dir, setting):
+    """models/base.py:80-225 with reduced=False (training on the original graph) replayed from the reference's initial
+    weights: validation trace, best-validation restore, test accuracy."""
+    g = load(golden_dir, "g12_fit_full")
+    n, nclass, d, hidden, iters = [int(v) for v in g["meta"]]
+    a = sp.coo_matrix((np.ones(len(g["a_row"])), (g["a_row"], g["a_col"])), shape=(n, n)).tocsr()
+    x, y = T(g["x"]), T(g["y"])
+    it, iv, ie = g["idx_train"], g["idx_val"], g["idx_test"]
+    norm = lambda m: O.csr_to_torch(*O.normalize_adj_sparse(m), m.shape[0])
+    init = [T(g[f"{setting}_init{i}"]) for i in range(4)]
+    trace = []
+    if setting == "trans":
+        A = norm(a)
+        best, w = O.fit_with_val_full(init, x, A, T(it), y[it], x, A, T(iv), y[iv], iters, lr=0.01, weight_decay=5e-4, trace=trace)
+        acc = O.eval_test(w, x, A, T(ie), y[ie])
+    else:
+        best, w = O.fit_with_val_full(init, x[it], norm(a[np.ix_(it, it)]), None, y[it], x[iv], norm(a[np.ix_(iv, iv)]), None, y[iv],
+                                      iters, lr=0.01, weight_decay=5e-4, trace=trace)
+        acc = O.eval_test(w, x[ie], norm(a[np.ix_(ie, ie)]), torch.arange(len(ie)), y[ie])
+    got, ref = np.array([t[1] for t in trace]), g[f"{setting}_val_trace"]
+    assert np.abs(got - ref).max() <= 1.0 / len(iv) + 1e-12
+    assert abs(best - float(g[f"{setting}_best"])) <= 1.0 / len(iv) + 1e-12
+    assert abs(acc - float(g[f"{setting}_test"])) <= 1.0 / len(ie) + 1e-12
+    if np.array_equal(got, ref):
+        for i in range(4):
+            np.testing.assert_allclose(w[i].numpy(), g[f"{setting}_final{i}"], rtol=1e-3, atol=1e-5)
