@@ -46,6 +46,22 @@ def gemm(A, B, Cout, M, N, K, sA, sB, ldc, **kw):
     check(_lib.lib().gs_gemm_f32(C.byref(d), stream()))
 
 
+def gemm_tn_splitk(A, lda, B, ldb, out, M, N, K, target_workgroups=768):
+    """out[M, N] = A[K, M]^T B[K, N] for a tall K (gradients of a full-graph layer: K = number of nodes): K is split into
+    slabs that fill the chip, each slab a partial product, summed in slab order (reproducible, no float atomics)."""
+    tiles = -(-M // 128) * -(-N // 128)
+    nsplit = max(1, min(target_workgroups // max(tiles, 1), -(-K // 256)))
+    kchunk = -(-(-(-K // nsplit)) // 16) * 16
+    nsplit = -(-K // kchunk)
+    if nsplit == 1:
+        gemm(A, B, out, M, N, K, (1, lda), (ldb, 1), N)
+        return out
+    slabs = torch.empty(nsplit, M, N, device=out.device, dtype=torch.float32)
+    gemm(A, B, slabs, M, N, K, (1, lda), (ldb, 1), N, nb2=nsplit, kchunk=kchunk, sCb2=M * N)
+    check(_lib.lib().gs_reduce_slabs_f32(ptr(out), ptr(slabs), M * N, nsplit, M * N, 0.0, stream()))
+    return out
+
+
 def gemm_group(descs):
     """Mutually independent products [(GemmDesc, keepalive), ...] in one launch when they are all latency-bound."""
     arr = (GemmDesc * len(descs))(*[d for d, _ in descs])

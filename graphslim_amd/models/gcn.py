@@ -13,7 +13,7 @@ import torch
 
 from .. import _lib, host
 from .._lib import check, ptr, stream
-from ..engine import adam_step, dense_gcn_norm_fwd, gemm, spmm_csr
+from ..engine import adam_step, dense_gcn_norm_fwd, gemm, gemm_tn_splitk, spmm_csr
 
 
 def _i32(a, device):
@@ -210,16 +210,22 @@ class GCN:
         check(L.gs_softmax_nll_grad_f32(ptr(Z), ldc, ptr(labels_i32), nt, Cn, ptr(Gz), ptr(lossr), stream()))
         g = torch.empty_like(self.P)
         gW1, gb1, gW2, gb2 = self._views(g)
-        check(L.gs_colsum_f32(ptr(Gz), Cn, nt, Cn, ptr(gb2), stream()))
+        ones = self._ones(max(N, nt))
+        gemm_tn_splitk(ones, 1, Gz, Cn, gb2, 1, Cn, nt)                       # 1^T G
         dT2 = spmm_csr(*G.target_t(idx), Gz, F=Cn)                          # (A^[idx, :])^T G   [N, C]
-        gemm(H, dT2, gW2, h, Cn, N, (1, h), (Cn, 1), Cn)                     # H^T dT2
+        gemm_tn_splitk(H, h, dT2, Cn, gW2, h, Cn, N)                          # H^T dT2   (K = N nodes: split-K slabs)
         dH = torch.empty(N, h, device=dev)
         gemm(dT2, W2, dH, N, h, Cn, (Cn, 1), (1, Cn), h, mask=H, ldmask=h)   # (dT2 W2^T) * [H > 0]
-        check(L.gs_colsum_f32(ptr(dH), h, N, h, ptr(gb1), stream()))
-        gemm(G.S, dH, gW1, d, h, N, (1, G.S.stride(0)), (h, 1), h)           # S^T dH
+        gemm_tn_splitk(ones, 1, dH, h, gb1, 1, h, N)                          # 1^T dH
+        gemm_tn_splitk(G.S, G.S.stride(0), dH, h, gW1, d, h, N)              # S^T dH
         opt["step"] += 1
         adam_step(self.P, g, opt["m"], opt["v"], opt["lr"], opt["step"], weight_decay=self.weight_decay)
         return lossr
+
+    def _ones(self, n):
+        if getattr(self, "_ones_buf", None) is None or self._ones_buf.numel() < n:
+            self._ones_buf = torch.ones(n, device=self.device)
+        return self._ones_buf
 
     def _new_opt(self, lr):
         return {"m": torch.zeros_like(self.P), "v": torch.zeros_like(self.P), "step": 0, "lr": lr}
