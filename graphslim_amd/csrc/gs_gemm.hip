@@ -695,6 +695,7 @@ extern "C" int gs_gemm_group_f32(const gs_gemm_desc* descs, int n, gs_stream_t s
   bool groupable = n > 1 && n <= GS_GROUP_MAX;
   gs_gemm_group_arg g;
   int gx = 1, gy = 1, z = 0;
+  long valid = 0;
   if (groupable) {
     for (int i = 0; i < n; ++i) {
       gs_gemm_desc p = descs[i];
@@ -706,10 +707,14 @@ extern "C" int gs_gemm_group_f32(const gs_gemm_desc* descs, int n, gs_stream_t s
       g.d[i] = p;
       g.z0[i] = z;
       z += nbatch;
+      valid += (long)gs_cdiv(p.N, 32) * gs_cdiv(p.M, 32) * nbatch;
       gx = gx > gs_cdiv(p.N, 32) ? gx : gs_cdiv(p.N, 32);
       gy = gy > gs_cdiv(p.M, 32) ? gy : gs_cdiv(p.M, 32);
     }
     if (z > 65535) groupable = false;
+    // the launch covers the LARGEST tile grid for every (product, batch): very unequal shapes would mostly launch workgroups
+    // that exit at once (measured: a 160x mismatch cost more than the launch it saved)
+    if ((long)gx * gy * z > 4 * valid) groupable = false;
   }
   if (!groupable) {
     for (int i = 0; i < n; ++i) GS_TRY(gs_gemm_f32(&descs[i], stream));
