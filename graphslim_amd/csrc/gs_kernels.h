@@ -837,11 +837,19 @@ __global__ __launch_bounds__(256) void gs_pge_marginal_r_kernel(const float* __r
   const int q = threadIdx.x % Q, g = threadIdx.x / Q;
   __shared__ float4 sh[256];
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g < G)
-    for (int c = g; c < n; c += G) {
-      const float4 v = *reinterpret_cast<const float4*>(dY1 + ((long)rl * n + c) * Ph + q * 4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  if (g < G) {
+    // 4 rows in flight per thread (clamped, unconditional loads; the tail is masked in the adds): the loop is a chain of
+    // dependent 16-byte loads otherwise and the kernel has only n' workgroups
+    for (int c0 = g; c0 < n; c0 += 4 * G) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = *reinterpret_cast<const float4*>(dY1 + ((long)rl * n + min(c0 + u * G, n - 1)) * Ph + q * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c0 + u * G < n) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
+  }
   sh[threadIdx.x] = s;
   __syncthreads();
   if (g == 0) {
@@ -859,11 +867,17 @@ __global__ __launch_bounds__(256) void gs_pge_marginal_c_kernel(const float* __r
   const int q = threadIdx.x % Q, g = threadIdx.x / Q;
   __shared__ float4 sh[256];
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g < G)
-    for (int r = g; r < nr; r += G) {
-      const float4 v = *reinterpret_cast<const float4*>(dY1 + ((long)r * n + c) * Ph + q * 4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  if (g < G) {
+    for (int r0 = g; r0 < nr; r0 += 4 * G) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = *reinterpret_cast<const float4*>(dY1 + ((long)min(r0 + u * G, nr - 1) * n + c) * Ph + q * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r0 + u * G < nr) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
+  }
   sh[threadIdx.x] = s;
   __syncthreads();
   if (g == 0) {
