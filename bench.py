@@ -31,6 +31,10 @@ WORKLOADS = {
     "cora": ("cora", 0.5, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
     # BASELINE.json configs[4]: inductive, train sub-graph, wide rows (d = 602) and fan-outs [15, 8]: the gather stress case
     "reddit": ("reddit", 0.001, 1, 256, 256, 10, 1, 0.1, 0.1, (15, 8)),
+    # the other BASELINE.json configs (parity-test cases at FULL size, tests/test_gpu_fullsize.py; not bench lines)
+    "cora-r0.25": ("cora", 0.25, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
+    "citeseer-r0.005": ("citeseer", 0.005, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
+    "pubmed-r0.005": ("pubmed", 0.005, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
 }
 
 
@@ -80,7 +84,9 @@ def init_state(p, eng, seed=1):
 def new_model(p, eng):
     from graphslim_amd.host import init_sgc_params
     d = p["data"].feat_full.shape[1]
-    eng.set_model(init_sgc_params(d, p["hidden"], p["data"].nclass, p["T"]))
+    theta = init_sgc_params(d, p["hidden"], p["data"].nclass, p["T"])
+    eng.set_model(theta)
+    return theta
 
 
 def run_steps(p, eng, k, cycle_len):
@@ -158,18 +164,32 @@ def blocks_to_batches(blk):
     return out
 
 
-def cpu_baseline(p, eng, timeout_s=300):
-    """The oracle (a CPU port of the reference path, pinned against reference golden vectors) on a bounded sample:
-    1 warm-up + 1 timed outer iteration of the same workload on the blocks the engine sampled.  Runs in a child
-    process (no GPU) with a hard time limit so that the default bench finishes within minutes."""
-    import subprocess
-    import tempfile
+def engine_match_loss(p, eng):
+    """One matching-loss evaluation on the HIP engine for a fresh theta and freshly sampled blocks (no update): returns
+    (loss, theta, batches) so that the CPU oracle can be run on EXACTLY the same inputs."""
+    theta = new_model(p, eng)
     eng.stage_sample()
     batches = blocks_to_batches(eng.get_blocks())
+    eng.stage_real_grads()
+    eng.stage_pge_forward(False)
+    eng.stage_syn_match()
+    eng.syn_finish()
+    return float(eng.buffer("loss")[0]), theta, batches
+
+
+def cpu_baseline(p, eng, timeout_s=300):
+    """The oracle (a CPU port of the reference path, pinned against reference golden vectors) on a bounded sample:
+    1 warm-up + 1 timed outer iteration of the same workload on the blocks the engine sampled, with the engine's own
+    (X~, theta_PGE, theta): its matching loss is compared with the engine's (`parity_rel_err`, gate 1e-4).  Runs in a
+    child process (no GPU) with a hard time limit so that the default bench finishes within minutes."""
+    import subprocess
+    import tempfile
+    loss_gpu, theta, batches = engine_match_loss(p, eng)
+    eng.read_loss()
     f = tempfile.NamedTemporaryFile(suffix=".pt", delete=False)
     f.close()
     torch.save({"batches": batches, "xs": eng.feat_syn.cpu(), "pge": [t.cpu().clone() for t in eng.get_pge()],
-                "workload": p["name"]}, f.name)
+                "theta": [t.cpu().clone() for t in theta], "workload": p["name"]}, f.name)
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", f.name], env=env,
@@ -177,7 +197,11 @@ def cpu_baseline(p, eng, timeout_s=300):
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if not line:
             return {"value": None, "unit": "outer-iters/s", "cores": None, "kind": "port", "sample": "failed: " + r.stderr[-300:]}
-        return json.loads(line[-1])
+        out = json.loads(line[-1])
+        loss_cpu = out.pop("match_loss")
+        out["match_loss_cpu"], out["match_loss_gpu"] = loss_cpu, loss_gpu
+        out["parity_rel_err"] = abs(loss_gpu - loss_cpu) / abs(loss_cpu)
+        return out
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "outer-iters/s", "cores": None, "kind": "port",
                 "sample": f"did not finish 2 outer iterations within {timeout_s} s"}
@@ -191,21 +215,21 @@ def cpu_baseline_child(path):
     ncores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(ncores)
     p = build_problem(blob["workload"], seed=1)
-    d = p["data"].feat_full.shape[1]
-    pge = blob["pge"]
-    st = O.GCondState(blob["xs"], {"lin": pge[:6], "bn": pge[6:]}, torch.from_numpy(p["labels_syn"]), p["ncd"],
-                      p["data"].nclass, p["lrf"], p["lra"], 0.01, "SGC", 2)
-    torch.manual_seed(0)
-    st.new_epoch(O.init_sgc(d, p["hidden"], p["data"].nclass, p["T"]))
     X, Y = p["data"].bench_feat, p["data"].bench_labels
-    times = []
-    for _ in range(2):
+    pge = blob["pge"]
+    times, loss = [], None
+    for _ in range(2):       # both passes start from the engine's state: the second one is the timed sample
+        st = O.GCondState(blob["xs"].clone(), {"lin": [t.clone() for t in pge[:6]], "bn": [t.clone() for t in pge[6:]]},
+                          torch.from_numpy(p["labels_syn"]), p["ncd"], p["data"].nclass, p["lrf"], p["lra"], 0.01, "SGC", 2)
+        st.new_epoch([t.clone() for t in blob["theta"]])
         t0 = time.perf_counter()
-        st.outer_iteration(10, blob["batches"], X, Y, p["inner"])
+        loss = st.outer_iteration(10, blob["batches"], X, Y, p["inner"])[0]
         times.append(time.perf_counter() - t0)
     print(json.dumps({"value": round(1.0 / times[-1], 4), "unit": "outer-iters/s", "cores": ncores, "kind": "port",
-                      "sample": "1 warm-up + 1 timed outer iteration of the same workload on identical engine-sampled "
-                                f"blocks (timed iteration {times[-1]:.2f} s; neighbour sampling excluded on the CPU side)"}))
+                      "match_loss": float(loss),
+                      "sample": "ONE timed outer iteration (after one warm-up iteration) of the same workload on the engine's own "
+                                f"sampled blocks, X~, theta_PGE and theta (timed iteration {times[-1]:.2f} s; a single sample: "
+                                "run-to-run spread on this host is about +-10 %; neighbour sampling excluded on the CPU side)"}))
 
 
 def main():
@@ -281,7 +305,7 @@ def main():
     eng.set_forward_reuse(False)
     eng.read_loss()
     if rank == 0:
-        units = args.steps * (world if getattr(eng, "replicas_only", False) else 1)
+        units = args.steps      # strong scaling: every rank works on the SAME iterations (classes / pair rows are sharded)
         out = {
             "metric": "GCond outer-loop iters/sec", "value": round(units / dt, 3), "unit": "outer-iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),

@@ -32,6 +32,11 @@ class _GradMatch(GCondBase):
             raise NotImplementedError("graphslim_amd: nlayers (propagations) must be 2")
         if getattr(args, "with_bn", False):
             raise NotImplementedError("graphslim_amd: with_bn is outside the built path")
+        if float(getattr(args, "dropout", 0.0) or 0.0) != 0.0:
+            # models/sgc.py:38-43 and models/base.py:51-78 apply F.dropout(training=True) inside train_class and the inner
+            # loop; the engine has no dropout stage, so a non-zero value must not be silently ignored
+            raise NotImplementedError("graphslim_amd: dropout != 0 in the condensation model is not built (the reference's "
+                                      "GCond configs all use dropout = 0, configs/gcond/*.json)")
         labels_syn = np.asarray(data.labels_syn)
         if args.setting == "trans":
             features, adj = data.feat_full, data.adj_full

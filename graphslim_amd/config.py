@@ -11,23 +11,35 @@ import click
 from .utils import accuracy, seed_everything  # noqa: F401
 
 
-class Obj(object):
-    def __init__(self, dict_):
-        self.__dict__.update(dict_)
+class Obj:
+    """The reference's attribute bag (config.py:17-24): `args.<flag>` for every option, free to grow derived fields.
+    Kept under the same name because downstream code type-checks nothing but user scripts may import it."""
+
+    def __init__(self, fields=None, **more):
+        vars(self).update(dict(fields or {}, **more))
 
     def __repr__(self):
-        return pformat(self.__dict__, compact=True)
+        return pformat(vars(self), compact=True)
 
 
 def dict2obj(d):
-    return json.loads(json.dumps(d), object_hook=Obj)
+    """Nested dicts -> nested attribute bags (the click kwargs are flat; JSON configs may nest)."""
+    if isinstance(d, dict):
+        return Obj({k: dict2obj(v) for k, v in d.items()})
+    if isinstance(d, (list, tuple)):
+        return [dict2obj(v) for v in d]
+    return d
+
+
+# options whose command-line value must survive the per-dataset JSON (config.py:30-34: only `init`, when it was given)
+_CLI_WINS_OVER_JSON = ("init",)
 
 
 def update_from_dict(obj, updates):
-    for key, value in updates.items():
-        if key in ["init"] and obj.init is not None:      # command line keeps priority for the init method
+    for name, value in updates.items():
+        if name in _CLI_WINS_OVER_JSON and getattr(obj, name, None) is not None:
             continue
-        setattr(obj, key, value)
+        setattr(obj, name, value)
 
 
 def setting_config(args):
@@ -126,26 +138,24 @@ _INITS = ["variation_neighborhoods", "variation_edges", "variation_cliques", "he
 @click.option("--attack", "-A", default=None, type=click.Choice(["random_adj", "metattack", "random_feat"]))
 @click.pass_context
 def cli(ctx, **kwargs):
-    """config.py:363-399."""
+    """config.py:363-399: flags -> device string -> per-method JSON -> setting_config -> explicit flags win -> log file + echo."""
     args = dict2obj(kwargs)
+    args.device = "cpu" if args.gpu_id < 0 else f"cuda:{args.gpu_id}"
     if args.gpu_id >= 0:
-        # the reference narrows CUDA_VISIBLE_DEVICES and then addresses cuda:<gpu_id>; keep its device string
-        args.device = f"cuda:{args.gpu_id}"
+        # upstream narrows CUDA_VISIBLE_DEVICES and still addresses cuda:<gpu_id>; here the id selects the device directly
         try:
             import torch
             torch.cuda.set_device(args.gpu_id)
         except Exception:
             pass
-    else:
-        args.device = "cpu"
-    path = args.save_path
-    args = method_config(args)
-    args = setting_config(args)
-    for key, value in ctx.params.items():
-        if ctx.get_parameter_source(key) == click.core.ParameterSource.COMMANDLINE:
-            setattr(args, key, value)
-    os.makedirs(f"{path}/logs/{args.method}", exist_ok=True)
-    logging.basicConfig(filename=f"{path}/logs/{args.method}/{args.dataset}_{args.reduction_rate}.log", level=logging.INFO,
+    log_root = args.save_path                       # read before the JSON / setting layers can touch it
+    args = setting_config(method_config(args))
+    given = [k for k in ctx.params if ctx.get_parameter_source(k) == click.core.ParameterSource.COMMANDLINE]
+    for k in given:                                 # what the user typed beats every config layer
+        setattr(args, k, ctx.params[k])
+    log_dir = os.path.join(log_root, "logs", str(args.method))
+    os.makedirs(log_dir, exist_ok=True)
+    logging.basicConfig(filename=os.path.join(log_dir, f"{args.dataset}_{args.reduction_rate}.log"), level=logging.INFO,
                         format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
     args.logger = logging.getLogger(__name__)
     table = _table(args)

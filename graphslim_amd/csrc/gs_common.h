@@ -37,7 +37,7 @@ void gs_set_error(const char* fmt, ...);
     if (r_ != GS_OK) return r_; \
   } while (0)
 
-static inline int gs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+__host__ __device__ static inline int gs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers ------------------------------------------------------------------------
 __device__ __forceinline__ float gs_wave_sum(float v) {

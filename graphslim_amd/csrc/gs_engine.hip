@@ -84,7 +84,7 @@ struct gs_gcond {
   // the real-side branch (sampling + class gradients) is independent of the synthetic-side branch until the
   // distance statistics: it runs on its own stream and joins through an event
   hipStream_t aux;
-  hipEvent_t ev_fork, ev_join;
+  hipEvent_t ev_fork, ev_join, ev_prefetch;   // ev_prefetch: the block set sampled ahead on aux is complete
   bool overlap, join_pending;
   // PGE.inference at the end of iteration i and the training forward of iteration i+1 are the same function of the
   // same (X~, theta_PGE): with reuse_fwd the second one is not recomputed (its activations are still in place)
@@ -331,7 +331,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->sample_step = 0;
   e->have_blocks = false;
   e->c_lo = 0; e->c_hi = e->C; e->r_lo = 0; e->r_hi = e->n;
-  e->aux = nullptr; e->ev_fork = e->ev_join = nullptr; e->join_pending = false;
+  e->aux = nullptr; e->ev_fork = e->ev_join = e->ev_prefetch = nullptr; e->join_pending = false;
   e->reuse_fwd = false; e->fwd_cached = false;
   e->blk_cur = 0; e->prefetched = false; e->identity = false;
   e->probing = false; e->probe_n = 0;
@@ -342,7 +342,8 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   e->overlap = (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, prio_hi) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess) &&
-               (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess);
+               (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess) &&
+               (hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming) == hipSuccess);
   *out = e;
   return GS_OK;
 }
@@ -353,6 +354,7 @@ extern "C" void gs_gcond_destroy(gs_gcond* e) {
   for (int i = 0; i < 2 * 256; ++i) if (e->probe_ev[i]) (void)hipEventDestroy(e->probe_ev[i]);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->ev_prefetch) (void)hipEventDestroy(e->ev_prefetch);
   delete e;
 }
 
@@ -371,7 +373,7 @@ extern "C" int gs_gcond_invalidate_forward(gs_gcond* e) {
 
 extern "C" int gs_gcond_set_overlap(gs_gcond* e, int on) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
-  e->overlap = on && e->aux && e->ev_fork && e->ev_join;
+  e->overlap = on && e->aux && e->ev_fork && e->ev_join && e->ev_prefetch;
   return GS_OK;
 }
 
@@ -489,6 +491,8 @@ extern "C" int gs_gcond_stage_sample(gs_gcond* e, gs_stream_t stream) {
     return GS_OK;
   }
   if (e->prefetched) {          // the set for this iteration was sampled ahead on the aux stream: adopt it
+    // whoever adopts it on another stream (a direct stage call, get_blocks, overlap switched off meanwhile) must see it complete
+    if ((hipStream_t)stream != e->aux && e->ev_prefetch) GS_HIP(hipStreamWaitEvent((hipStream_t)stream, e->ev_prefetch, 0));
     e->blk_cur ^= 1;
     e->blk = e->blkbuf[e->blk_cur];
     e->prefetched = false;
@@ -1358,6 +1362,7 @@ extern "C" int gs_gcond_stage_real_async(gs_gcond* e, gs_stream_t stream) {
     e->join_pending = true;
     if (!e->cfg.external_blocks) {   // sample the NEXT iteration's blocks behind this one's gradients (same RNG sequence)
       GS_TRY(sample_into(e, e->blk_cur ^ 1, (gs_stream_t)e->aux));
+      GS_HIP(hipEventRecord(e->ev_prefetch, e->aux));
       e->prefetched = true;
     }
   } else {

@@ -200,7 +200,19 @@ __global__ __launch_bounds__(256, gs_min_waves(BM, BN)) void gs_gemm_f32_kernel(
     k_lo = b2 * p.kchunk;
     k_hi = min(K, k_lo + p.kchunk);
   }
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // Tile of this workgroup.  The grid is flat in x (no 65 535 limit on the M-tile count: n'^2 / BM row tiles of the PGE
+  // products exceed it from n' ~ 2 900) and XCD-aware: workgroups are dealt round-robin over the 8 XCDs (ids b and b + 8
+  // share one), so XCD x gets the CONTIGUOUS chunk x of the tile sequence (n fastest) — the N tiles that share an A row
+  // block run on one XCD back to back and the second one finds the block in that XCD's L2 instead of pulling it through
+  // the fabric again (r01: the PGE layer-2 product fetched A twice).  Bijective for any tile count.
+  const int tn = (p.N + BN - 1) / BN;
+  int tile;
+  {
+    const int T = gridDim.x, L = blockIdx.x, xcd = L & 7, slot = L >> 3, q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int mt = tile / tn;
+  const int m0 = mt * BM, n0 = (tile - mt * tn) * BN;
   if (m0 >= M) return;
 
   const float* __restrict__ A = p.A + (long)b1 * p.sAb1 + (p.kchunk > 0 ? 0 : (long)b2 * p.sAb2) + (p.offA ? p.offA[b1] : 0);
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(256, gs_min_waves(BM, BN)) void gs_gemm_f32_kernel(
       }
   }
   if (has_stat) {
-    // per-block column sums of the written tile: colstat[(blockIdx.y*2 + q)*N + col], q = 0: sum, 1: sum of squares
+    // per-block column sums of the written tile: colstat[(m_tile*2 + q)*N + col], q = 0: sum, 1: sum of squares
     // (BatchNorm statistics without a second pass over C).  Reduce: lane halves -> waves along M (through LDS) -> global.
     constexpr int WAVES_M = BM / WM;
     __syncthreads();                       // the operand tiles are dead: reuse As as scratch
@@ -380,7 +392,7 @@ __global__ __launch_bounds__(256, gs_min_waves(BM, BN)) void gs_gemm_f32_kernel(
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < WAVES_M; ++w) t += red[(q * WAVES_M + w) * BN + cc];
-      if (n0 + cc < p.N) p.colstat[((long)blockIdx.y * 2 + q) * p.N + n0 + cc] = t;
+      if (n0 + cc < p.N) p.colstat[((long)mt * 2 + q) * p.N + n0 + cc] = t;
     }
   }
 }
@@ -608,7 +620,7 @@ extern "C" int gs_gemm_set_tuning(int bk_small, int bk_big) {
 
 template <int BM, int BN, int WM, int WN, int AM, int BMD, int BK>
 static int launch_gemm3(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
-  dim3 grid(gs_cdiv(p.N, BN), gs_cdiv(p.M, BM), nbatch);
+  dim3 grid((unsigned)((long)gs_cdiv(p.N, BN) * gs_cdiv(p.M, BM)), 1, nbatch);
   hipLaunchKernelGGL((gs_gemm_f32_kernel<BM, BN, WM, WN, AM, BMD, BK>), grid, dim3(256), 0, s, p);
   GS_LAUNCH_CHECK();
   return GS_OK;
@@ -616,7 +628,7 @@ static int launch_gemm3(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int AM, int BK>
 static int launch_gemm_bgen(const gs_gemm_desc& p, int nbatch, hipStream_t s) {
-  dim3 grid(gs_cdiv(p.N, BN), gs_cdiv(p.M, BM), nbatch);
+  dim3 grid((unsigned)((long)gs_cdiv(p.N, BN) * gs_cdiv(p.M, BM)), 1, nbatch);
   hipLaunchKernelGGL((gs_gemm_f32_kernel<BM, BN, WM, WN, AM, GS_MODE_M, BK, true>), grid, dim3(256), 0, s, p);
   GS_LAUNCH_CHECK();
   return GS_OK;
@@ -655,6 +667,19 @@ static int pick_tile(const gs_gemm_desc& p, int nbatch) {   // 0: 128x32, 1: 32x
   long tiles128 = (long)gs_cdiv(p.M, 128) * gs_cdiv(p.N, 128) * nbatch;
   if (p.M <= 64 || p.N <= 64 || tiles128 < 192) return 2;
   return 3;
+}
+
+// which kernel gs_gemm_f32 launches for this descriptor: 0 = 128x32 tile, 1 = 32x128, 2 = 64x64, 3 = 128x128 (the tile of the
+// PGE / H1full / edge products), 4 = the latency-oriented one-tile-per-workgroup kernel.  Lets the parity tests assert that a
+// shape really exercises the instantiation it is meant to cover.
+extern "C" int gs_gemm_route(const gs_gemm_desc* d) {
+  if (!d) return -1;
+  gs_gemm_desc p = *d;
+  if (p.nb1 < 1) p.nb1 = 1;
+  if (p.nb2 < 1) p.nb2 = 1;
+  const int nb = p.nb1 * p.nb2;
+  if (small_route(p, nb)) return 4;
+  return pick_tile(p, nb);
 }
 
 extern "C" int gs_gemm_tiles_m(const gs_gemm_desc* d) {

@@ -48,17 +48,55 @@ def get_dataset(name="cora", args=None, load_path=None):
     if raw is None:
         if name not in SHAPES:
             raise ValueError(f"dataset '{name}' is not available offline; known shapes: {sorted(SHAPES)}")
+        # No real files: the dataset-SHAPED synthetic generator.  Never silent: unless it was asked for
+        # (GRAPHSLIM_AMD_SYNTHETIC=1, or args.synthetic), say so loudly on stderr, in the warnings stream and in the run's
+        # log file; the returned GraphData carries .synthetic = True and the Evaluator tags its result lines with it.
+        asked = os.environ.get("GRAPHSLIM_AMD_SYNTHETIC", "") in ("1", "true", "yes") or bool(getattr(args, "synthetic", False))
+        if not asked:
+            import sys
+            import warnings
+            msg = (f"graphslim_amd: no data files for '{name}' under load_path={load_path!r}: condensing a SYNTHETIC "
+                   f"{name}-shaped graph (graphslim_amd/dataset/synthetic.py).  Accuracies are NOT {name} accuracies.  "
+                   "Set GRAPHSLIM_AMD_SYNTHETIC=1 to acknowledge, or put <name>.npz / the raw Planetoid / GraphSAINT files "
+                   "under --load_path.")
+            print("WARNING: " + msg, file=sys.stderr)
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
+            logger = getattr(args, "logger", None)
+            if logger is not None:
+                logger.warning(msg)
         raw = make_raw(name, seed=getattr(args, "seed", 1), scale=float(os.environ.get("GRAPHSLIM_AMD_SCALE", "1")))
-    data = splits(raw)
-    out = TransAndInd(data, name)
+    data = splits(raw, getattr(args, "split", "fixed"))
+    out = TransAndInd(data, name, bool(getattr(args, "pre_norm", True)))      # loader.py:85-87
+    out.synthetic = bool(getattr(raw, "synthetic", False))
     out.nclass = int(raw.y.max()) + 1
     if args is not None:
         args.nclass = out.nclass
+        args.synthetic_data = out.synthetic
     return out
 
 
-def splits(data):
-    """graphslim/dataset/utils.py:97-134 ('fixed' split): masks -> index tensors."""
+def splits(data, exp="fixed"):
+    """graphslim/dataset/utils.py:97-134.  A record that already carries masks keeps them whatever `exp` says (the
+    reference only looks at `exp` when there is no train_mask); otherwise class-wise random splits: 'random' = 20 / 30 /
+    rest per class, 'few' = 5 / 5 / rest, anything else = 80 % / 10 % / 10 % per class (torch.randperm per class, in
+    class order, like the reference)."""
+    if getattr(data, "train_mask", None) is None:
+        y = data.y.reshape(-1)
+        n = int(y.shape[0])
+        per = []
+        for c in range(int(y.max()) + 1):
+            idx = (y == c).nonzero().view(-1)
+            per.append(idx[torch.randperm(idx.size(0))])
+        if exp == "random":
+            cut = [(i[:20], i[20:50], i[50:]) for i in per]
+        elif exp == "few":
+            cut = [(i[:5], i[5:10], i[10:]) for i in per]
+        else:
+            cut = [(i[:int(i.shape[0] * 0.8)], i[int(i.shape[0] * 0.8):int(i.shape[0] * 0.9)], i[int(i.shape[0] * 0.9):]) for i in per]
+        for k, name in enumerate(("train_mask", "val_mask", "test_mask")):
+            m = torch.zeros(n, dtype=torch.bool)
+            m[torch.cat([c[k] for c in cut])] = True
+            setattr(data, name, m)
     data.idx_train = data.train_mask.nonzero().view(-1)
     data.idx_val = data.val_mask.nonzero().view(-1)
     data.idx_test = data.test_mask.nonzero().view(-1)

@@ -242,6 +242,14 @@ class GCondEngine:
             raise SystemExit("DC error: unknown distance function")     # condensation/utils.py:63
         L = _lib.lib()
         self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("graphslim_amd: the GCond engine needs a GPU device (there is no CPU fallback)")
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
+        # every later call launches on torch's CURRENT stream: that must be a stream of this engine's device
+        if torch.cuda.current_device() != self.dev.index:
+            raise RuntimeError(f"GCondEngine(device={self.dev}): make it the current device first (torch.cuda.set_device / "
+                               f"`with torch.cuda.device(...)`); current device is cuda:{torch.cuda.current_device()}")
         s = self.shapes = shapes
         dev = self.dev
         d = s.d
@@ -282,6 +290,13 @@ class GCondEngine:
         self.h = h
         self.L = L
 
+    def _s(self):
+        """torch's current stream — which must belong to this engine's device (an engine built for cuda:1 must
+        not be driven from cuda:0's stream)."""
+        if torch.cuda.current_device() != self.dev.index:
+            raise RuntimeError(f"GCondEngine on {self.dev} called while cuda:{torch.cuda.current_device()} is current")
+        return stream()
+
     def __del__(self):
         h = getattr(self, "h", None)
         if h:
@@ -295,7 +310,7 @@ class GCondEngine:
     # ---- parameter packing (nn.Module.parameters() order) ------------------------------------------
     def set_model(self, params):
         self.model_params.copy_(torch.cat([p.reshape(-1).float() for p in params]).to(self.dev))
-        check(self.L.gs_gcond_new_epoch(self.h, stream()))
+        check(self.L.gs_gcond_new_epoch(self.h, self._s()))
 
     def get_model(self):
         s, d = self.shapes, self.shapes.d
@@ -324,12 +339,12 @@ class GCondEngine:
         return bool(self.L.gs_gcond_forward_cached(self.h))
 
     def adopt_cached_forward(self):
-        check(self.L.gs_gcond_adopt_cached_forward(self.h, stream()))
+        check(self.L.gs_gcond_adopt_cached_forward(self.h, self._s()))
 
     # ---- stages -------------------------------------------------------------------------------------
     def set_blocks(self, blocks: BlockSet):
         b = blocks.struct()
-        check(self.L.gs_gcond_set_blocks(self.h, C.byref(b), stream()))
+        check(self.L.gs_gcond_set_blocks(self.h, C.byref(b), self._s()))
         self._blocks_keepalive = blocks
 
     def get_blocks(self) -> BlockSet:
@@ -338,10 +353,10 @@ class GCondEngine:
         return BlockSet.from_struct(b, self.dev)
 
     def stage_sample(self):
-        check(self.L.gs_gcond_stage_sample(self.h, stream()))
+        check(self.L.gs_gcond_stage_sample(self.h, self._s()))
 
     def stage_real_grads(self):
-        check(self.L.gs_gcond_stage_real_grads(self.h, stream()))
+        check(self.L.gs_gcond_stage_real_grads(self.h, self._s()))
 
     def probe(self, on=True):
         check(self.L.gs_gcond_probe(self.h, int(on)))
@@ -353,31 +368,31 @@ class GCondEngine:
         return t.value, k.value
 
     def stage_real_async(self):
-        check(self.L.gs_gcond_stage_real_async(self.h, stream()))
+        check(self.L.gs_gcond_stage_real_async(self.h, self._s()))
 
     def stage_pge_forward(self, inference=False):
-        check(self.L.gs_gcond_stage_pge_forward(self.h, int(inference), stream()))
+        check(self.L.gs_gcond_stage_pge_forward(self.h, int(inference), self._s()))
 
     def stage_syn_match(self):
-        check(self.L.gs_gcond_stage_syn_match(self.h, stream()))
+        check(self.L.gs_gcond_stage_syn_match(self.h, self._s()))
 
     def stage_pge_backward(self, need_param_grads=True, need_feat_grad=True):
-        check(self.L.gs_gcond_stage_pge_backward(self.h, int(need_param_grads), int(need_feat_grad), stream()))
+        check(self.L.gs_gcond_stage_pge_backward(self.h, int(need_param_grads), int(need_feat_grad), self._s()))
 
     def stage_update(self, epoch):
-        check(self.L.gs_gcond_stage_update(self.h, epoch, stream()))
+        check(self.L.gs_gcond_stage_update(self.h, epoch, self._s()))
 
     def stage_inner(self):
-        check(self.L.gs_gcond_stage_inner(self.h, stream()))
+        check(self.L.gs_gcond_stage_inner(self.h, self._s()))
 
     def outer_step(self, epoch):
-        check(self.L.gs_gcond_outer_step(self.h, epoch, stream()))
+        check(self.L.gs_gcond_outer_step(self.h, epoch, self._s()))
 
     def outer_step_ex(self, step_pge, step_feat, run_inference, run_inner):
-        check(self.L.gs_gcond_outer_step_ex(self.h, int(step_pge), int(step_feat), int(run_inference), int(run_inner), stream()))
+        check(self.L.gs_gcond_outer_step_ex(self.h, int(step_pge), int(step_feat), int(run_inference), int(run_inner), self._s()))
 
     def set_identity_structure(self, on=True):
-        check(self.L.gs_gcond_set_identity_structure(self.h, int(on), stream()))
+        check(self.L.gs_gcond_set_identity_structure(self.h, int(on), self._s()))
 
     def set_overlap(self, on):
         check(self.L.gs_gcond_set_overlap(self.h, int(on)))
@@ -387,16 +402,16 @@ class GCondEngine:
         check(self.L.gs_gcond_set_shard(self.h, c_lo, c_hi, r_lo, r_hi))
 
     def pge_forward_part(self, inference, part):
-        check(self.L.gs_gcond_stage_pge_forward_part(self.h, int(inference), part, stream()))
+        check(self.L.gs_gcond_stage_pge_forward_part(self.h, int(inference), part, self._s()))
 
     def pge_backward_part(self, need_param_grads, need_feat_grad, part):
-        check(self.L.gs_gcond_stage_pge_backward_part(self.h, int(need_param_grads), int(need_feat_grad), part, stream()))
+        check(self.L.gs_gcond_stage_pge_backward_part(self.h, int(need_param_grads), int(need_feat_grad), part, self._s()))
 
     def syn_finish(self):
-        check(self.L.gs_gcond_stage_syn_finish(self.h, stream()))
+        check(self.L.gs_gcond_stage_syn_finish(self.h, self._s()))
 
     def inner_steps(self):
-        check(self.L.gs_gcond_stage_inner_steps(self.h, stream()))
+        check(self.L.gs_gcond_stage_inner_steps(self.h, self._s()))
 
     def view(self, name, dtype=torch.float32):
         """Zero-copy torch view of a named engine buffer (the all-reduce buffers are exchanged in place)."""
@@ -406,7 +421,7 @@ class GCondEngine:
 
     def read_loss(self):
         s, k = C.c_double(), C.c_long()
-        check(self.L.gs_gcond_read_loss(self.h, C.byref(s), C.byref(k), stream()))
+        check(self.L.gs_gcond_read_loss(self.h, C.byref(s), C.byref(k), self._s()))
         return s.value, k.value
 
     def buffer(self, name, shape=None):

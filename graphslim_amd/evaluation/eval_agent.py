@@ -63,6 +63,8 @@ class Evaluator:
                 runs.set_postfix(test_acc=acc)
         res = shard.combine(args.run_eval, res, self.device if dist is not None and str(self.device).startswith("cuda") else "cpu")
         msg = f"Seed:{args.seed}, Test Mean Accuracy: {100 * res.mean():.2f} +/- {100 * res.std():.2f}"
+        if getattr(data, "synthetic", False):     # never report a synthetic stand-in under the real dataset's name alone
+            msg += f"  [SYNTHETIC {getattr(args, 'dataset', '?')}-shaped graph, not the real dataset]"
         if hasattr(args, "logger"):
             args.logger.info(msg)
         if verbose:

@@ -81,6 +81,9 @@ int gs_gemm_set_tuning(int bk_small, int bk_big);
    fetched straight from global memory): taken when the 32x32 tile count is <= max_tiles and the product is <= max_gflop
    (defaults 8192 / 1.5); max_tiles = 0 switches it off.  A measurement knob. */
 int gs_gemm_set_small(long max_tiles, double max_gflop);
+/* which kernel gs_gemm_f32 launches for this descriptor: 0 = 128x32 tile, 1 = 32x128, 2 = 64x64, 3 = 128x128, 4 = the
+   one-tile-per-workgroup latency kernel (test hook: parity tests assert the instantiation a shape exercises) */
+int gs_gemm_route(const gs_gemm_desc* d);
 /* number of M tiles gs_gemm_f32 will use for this descriptor (first dimension of colstat) */
 int gs_gemm_tiles_m(const gs_gemm_desc* d);
 

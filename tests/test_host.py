@@ -198,3 +198,38 @@ def test_graphsaint_raw_reader_and_get_dataset(tmp_path):
     # loader.py:113-119: features standardised with the TRAIN rows' statistics
     mu, sd = x[np.sort(perm[:150])].astype(np.float64).mean(0), x[np.sort(perm[:150])].astype(np.float64).std(0)
     np.testing.assert_allclose(data.feat_full.numpy(), (x - mu) / sd, rtol=1e-5, atol=1e-5)
+
+
+def test_synthetic_fallback_is_loud_and_marked(monkeypatch, capsys):
+    """get_dataset must never silently swap in the synthetic generator; split / pre_norm are passed through
+    like loader.py:85-87."""
+    import types
+    import warnings
+    from graphslim_amd.dataset.loader import get_dataset, splits
+    monkeypatch.setenv("GRAPHSLIM_AMD_SCALE", "1")
+    monkeypatch.delenv("GRAPHSLIM_AMD_SYNTHETIC", raising=False)
+    args = types.SimpleNamespace(seed=1, load_path=None, pre_norm=False, split="fixed")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        data = get_dataset("cora", args)
+    assert any("SYNTHETIC" in str(x.message) for x in w)
+    assert "SYNTHETIC" in capsys.readouterr().err
+    assert data.synthetic is True and args.synthetic_data is True
+    assert float(data.feat_full.sum(1).max()) > 1.5          # pre_norm = False: rows are NOT L1-normalised
+    monkeypatch.setenv("GRAPHSLIM_AMD_SYNTHETIC", "1")
+    args.pre_norm = True
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        data = get_dataset("cora", args)
+    assert not w and abs(float(data.feat_full.sum(1).max()) - 1.0) < 1e-5
+    # records without masks get the reference's class-wise random splits (dataset/utils.py:104-127)
+    raw = types.SimpleNamespace(y=torch.arange(300) % 3, num_nodes=300)
+    torch.manual_seed(0)
+    few = splits(raw, "few")
+    assert int(few.train_mask.sum()) == 15 and int(few.val_mask.sum()) == 15 and int(few.test_mask.sum()) == 270
+    raw = types.SimpleNamespace(y=torch.arange(300) % 3, num_nodes=300)
+    rnd = splits(raw, "random")
+    assert int(rnd.train_mask.sum()) == 60 and int(rnd.val_mask.sum()) == 90
+    raw = types.SimpleNamespace(y=torch.arange(300) % 3, num_nodes=300)
+    dft = splits(raw, "fixed")
+    assert int(dft.train_mask.sum()) == 240 and int(dft.val_mask.sum()) == 30 and int(dft.test_mask.sum()) == 30
