@@ -100,6 +100,9 @@ struct gs_gcond {
   bool gcn;         // condense model GCN (2 layers) instead of SGC
   float *P0g, *T2r, *dT2r, *dH1r, *S1, *dS1, *Tmat, *Rmat;   // GCN-only scratch
   bool identity;    // structure-free variants (GCondX / DosCondX): adj_syn = I, no PGE
+  // operand precision of the three row-panel products (E2 = A1 W1^T, dY1 = dE2 W1, H1full = X W1): gs_gemm_desc.prec
+  int operand_mode;
+  float *bsplit_main, *bsplit_aux;   // pre-split B operands (bf16 hi | lo) of the products on the main / the real-side stream
 };
 
 static void derive(gs_gcond* e, const gs_gcond_config& c) {
@@ -208,6 +211,8 @@ static size_t carve(gs_gcond* e, void* base) {
   e->dE2 = w.take<float>(n2 * Ph); e->dY1 = w.take<float>(n2 * Ph);
   e->ar_marg = w.take<float>(2 * n * Ph);     // [rowsum_c | colsum_r] contiguous (one all-reduce)
   e->rowsum_c = e->ar_marg; e->colsum_r = e->ar_marg ? e->ar_marg + n * Ph : nullptr; e->dU = w.take<float>(n * Ph); e->W1T = w.take<float>(Ph * Ph); e->W1mT = w.take<float>(d * h);
+  e->bsplit_main = w.take<float>(Ph * Ph);
+  e->bsplit_aux = w.take<float>((h > 0 ? h : 1) * d);
   e->chunk_fwd = w.take<float>((long)e->pge_chunks * 4 * Ph); e->chunk_bwd = w.take<float>((long)e->pge_chunks * 5 * Ph);
   e->dV = w.take<float>(n * Ph); e->d_pge = w.take<float>(e->Ppge); e->slabs_w = w.take<float>(e->nsplit_w * Ph * Ph);
   e->parts = w.take<double>((long)e->nblk_stats * 3 * Ph);
@@ -335,6 +340,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->reuse_fwd = false; e->fwd_cached = false;
   e->blk_cur = 0; e->prefetched = false; e->identity = false;
   e->probing = false; e->probe_n = 0;
+  e->operand_mode = 0;
   for (int i = 0; i < 2 * 256; ++i) e->probe_ev[i] = nullptr;
   // the real-side branch is the longer of the two concurrent branches (kernel trace, r01): its stream gets the higher
   // priority so that its latency-bound kernels are not queued behind the PGE forward's big GEMM
@@ -367,6 +373,16 @@ extern "C" int gs_gcond_set_forward_reuse(gs_gcond* e, int on) {
 
 extern "C" int gs_gcond_invalidate_forward(gs_gcond* e) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  e->fwd_cached = false;
+  return GS_OK;
+}
+
+// 0 = exact fp32 (default, the reference's precision), 1 = split bf16 x3, 2 = bf16 operands — for the three row-panel
+// products only (gs_gemm_desc.prec); everything else stays fp32.  Switchable at any time (A/B measurements).
+extern "C" int gs_gcond_set_operand_mode(gs_gcond* e, int mode) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  if (mode < 0 || mode > 2) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_operand_mode: mode must be 0 (fp32), 1 (bf16 x3) or 2 (bf16)");
+  e->operand_mode = mode;
   e->fwd_cached = false;
   return GS_OK;
 }
@@ -573,6 +589,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     gs_gemm_desc g = mk(e->io.X, e->ldx, 1, e->W1mT, 1, d, e->H1full, h, e->N, h, d);
     g.bias = th + e->ob1;
     g.relu = 1;
+    g.prec = e->operand_mode; g.scratch = e->bsplit_aux;
     GS_TRY(gs_gemm_f32(&g, stream));
     src = e->H1full;
     ld_src = h;
@@ -672,6 +689,7 @@ static int pge_forward_chunked(gs_gcond* e, gs_stream_t stream) {
     gs_gemm_desc g = mk(e->A1 + k0 * Ph, Ph, 1, pp + e->pW1, 1, Ph, e->E2 + k0 * Ph, Ph, (int)cnt, Ph, Ph);
     g.bias = pp + e->pb1;
     g.colstat = e->statp;
+    g.prec = e->operand_mode; g.scratch = e->bsplit_main;
     GS_TRY(gs_gemm_f32(&g, stream));
     reduce_parts(e, e->statp, gs_gemm_tiles_m(&g), 2, 2, s);
     hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, cnt, Ph, mu2, is2);
@@ -728,6 +746,7 @@ static int pge_backward_chunked(gs_gcond* e, int need_param_grads, gs_stream_t s
     GS_LAUNCH_CHECK();
     gs_gemm_desc a = mk(e->dE2, Ph, 1, e->W1T, 1, Ph, e->dY1, Ph, (int)n2, Ph, Ph);
     a.mask = e->A1; a.ldmask = Ph;
+    a.prec = e->operand_mode; a.scratch = e->bsplit_main;
     GS_TRY(gs_gemm_f32(&a, stream));
   }
   for (int ch = 0; ch < nc; ++ch) {       // BN-1 backward, chunk by chunk, in place: dY1 becomes dE1
@@ -790,6 +809,7 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       gs_gemm_desc g = mk(e->A1, Ph, 1, pp + e->pW1, 1, Ph, e->E2, Ph, (int)rows, Ph, Ph);     // E2 = A1 W1^T + b1
       g.bias = pp + e->pb1;
       g.colstat = e->statp;            // BN-2 batch statistics come out of the epilogue: no second pass over E2
+      g.prec = e->operand_mode; g.scratch = e->bsplit_main;
       const bool probe = e->probing && e->probe_n < 256;
       if (probe) {
         for (int q = 0; q < 2; ++q)
@@ -1185,6 +1205,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
         GS_LAUNCH_CHECK();
         gs_gemm_desc a = mk(e->dE2, Ph, 1, e->W1T, 1, Ph, e->dY1, Ph, (int)rows, Ph, Ph);
         a.mask = e->A1; a.ldmask = Ph;
+        a.prec = e->operand_mode; a.scratch = e->bsplit_main;
         GS_TRY(gs_gemm_f32(&a, stream));
       }
       hipLaunchKernelGGL(gs_pge_marginal_r_kernel, dim3(nr), dim3(256), 0, s, e->dY1, n, Ph, e->r_lo, e->colsum_r);

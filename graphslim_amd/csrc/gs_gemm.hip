@@ -296,12 +296,17 @@ __global__ __launch_bounds__(256, gs_min_waves(BM, BN)) void gs_gemm_f32_kernel(
 #endif
   if (fullM && fullN && fit32) {
     const unsigned ldc = (unsigned)p.ldc, ldm = (unsigned)p.ldmask;
+    // (the bias values are fetched BEFORE the first store: a load between the stores of two tiles would wait — vmcnt retires
+    // in order — for every store issued before it, i.e. a write round trip per tile)
+    float bvj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bvj[j] = has_bias ? p.bias[(long)b1 * p.sbias_b1 + n0 + wn0 + j * 32 + li] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const unsigned col = n0 + wn0 + j * 32 + li, row0 = m0 + wm0 + i * 32 + 4 * kh;
-        const float bv = has_bias ? p.bias[(long)b1 * p.sbias_b1 + col] : 0.f;
+        const float bv = bvj[j];
         const unsigned off = row0 * ldc + col;
         float v[16];
 #pragma unroll
@@ -538,6 +543,9 @@ __global__ __launch_bounds__(256) void gs_gemm_small_group_kernel(gs_gemm_group_
   else gs_small_any(g.d[3], z - g.z0[3], red);
 }
 
+bool gs_panel_eligible(const gs_gemm_desc& p);            // gs_panel.hip
+int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s);
+
 static long g_small_tiles = 8192;      // route to the small kernel when the 32x32 tile count is at most this ...
 static double g_small_gflop = 1.5;     // ... and the product is at most this many GFLOP
 
@@ -678,6 +686,7 @@ extern "C" int gs_gemm_route(const gs_gemm_desc* d) {
   if (p.nb1 < 1) p.nb1 = 1;
   if (p.nb2 < 1) p.nb2 = 1;
   const int nb = p.nb1 * p.nb2;
+  if (gs_panel_eligible(p)) return 5;
   if (small_route(p, nb)) return 4;
   return pick_tile(p, nb);
 }
@@ -685,6 +694,7 @@ extern "C" int gs_gemm_route(const gs_gemm_desc* d) {
 extern "C" int gs_gemm_tiles_m(const gs_gemm_desc* d) {
   if (!d) return 0;
   const int nb = (d->nb1 < 1 ? 1 : d->nb1) * (d->nb2 < 1 ? 1 : d->nb2);
+  if (gs_panel_eligible(*d)) return gs_cdiv(d->M, 128);
   static const int bm[4] = {128, 32, 64, 128};
   return gs_cdiv(d->M, bm[pick_tile(*d, nb)]);
 }
@@ -702,6 +712,7 @@ extern "C" int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream) {
   const int nbatch = p.nb1 * p.nb2;
   if ((long)nbatch > 65535) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: too many batches (%d)", nbatch);
   hipStream_t s = (hipStream_t)stream;
+  if (gs_panel_eligible(p)) return gs_panel_launch(p, s);
   if (small_route(p, nbatch)) return launch_small(p, nbatch, s);
   // tile choice: fill the 256 CUs; narrow outputs get the tall/flat tiles
   switch (pick_tile(p, nbatch)) {

@@ -1,0 +1,325 @@
+// Row-panel product for the three big dense contractions of the GCond iteration (VERDICT r01 "next" 2-4):
+//
+//     C[M x 256] = A[M x K] * B^T  (+ bias[n]) (relu) (* [mask > 0])        A: [M][lda] fp32, k contiguous
+//                                                                             B: [256][ldb] fp32, k contiguous
+//   PGE layer 2      E2  = A1  W1^T + b1     M = n'^2 = 206 116, K = 256     (parametrized_adj.py:57-64)  + BN-2 column sums
+//   PGE layer 2 bwd  dY1 = (dE2 W1) * [A1>0]                                  (autograd of the same layer)
+//   SGC transform    H1  = relu(X W1 + b1)   M = N = 169 343,    K = 128     (models/sgc.py:38-43)
+//
+// One workgroup = one 128-row panel over ALL 256 output columns, so A is read from HBM exactly once (the 128x128 tile read
+// it once per N tile); wave w owns rows [32w, 32w + 32) x 256 columns = 8 MFMA tiles of 32x32 (128 accumulator registers).
+//   * A never touches LDS: each lane loads 16 consecutive k of ITS row (4 x 16 B; the two half-waves share a 128-B line)
+//     straight into the MFMA fragment registers, one K block ahead.
+//   * B (<= 256 KB, L2-resident) is streamed through LDS in K blocks of 32 by direct-to-LDS loads (global_load_lds_dwordx4,
+//     no staging registers), double buffered, one barrier per K block.  The LDS image is lane-linear [256 rows][8 chunks of
+//     16 B]; bank conflicts are removed by XOR-ing the chunk index with (row >> 1) & 7 on the SOURCE address and on the read
+//     (the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-B slots).
+// Operand precision (gs_gemm_desc.prec):
+//   0  exact fp32          v_mfma_f32_32x32x2_f32 (k-ordered fmaf chain, the reference's arithmetic)
+//   1  split bf16 x3       A = Ah + Al, B = Bh + Bl in bf16 (2^-16 relative representation), C += Ah Bh + Ah Bl + Al Bh on
+//                          v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 MFMAs at 16x the fp32 rate -> HBM-bound
+//   2  bf16                C += Ah Bh only (BASELINE.json configs[1] "bf16": operands rounded to 8 significant bits)
+// B is pre-split once per call by a tiny kernel into [256][K/32][hi 32 | lo 32] bf16 (same 128 B per row and K block as the
+// fp32 image, so the staging code is shared).
+#include "gs_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* gs_lds_ptr;
+typedef __attribute__((address_space(1))) const void* gs_gbl_ptr;
+
+#define PN_BM 128
+
+struct gs_panel_args {
+  const float* A; long lda;
+  const void* B; long ldb_bytes;     // fp32 [256][ldb] or packed bf16 [256][K/32][64]
+  float* C; long ldc;
+  int M, K;
+  const float* bias;
+  int relu;
+  const float* mask; long ldmask;
+  float* colstat;                    // [tiles_m][2][256] or null
+  int dephase;                       // start-up delay (units of s_sleep 127 = 8 128 cycles) of workgroups 256..511, see the kernel
+  int krep, triage;                  // measurement hooks (gs_panel_debug): K loop repeated krep times; bit 0: no stores;
+  unsigned long long* trace;         // bit 1: per-workgroup [hw_id, xcc_id, t_start, t_loop_end, t_end] (s_memrealtime, 10 ns)
+};
+
+// Epilogue of one wave: 32 rows x 32 NT columns from the accumulators.  C/D layout of a 32x32 tile: col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+// No load may sit between the stores of two tiles: vmcnt retires in order, so waiting for such a load waits for every store
+// issued before it — a full write round trip per tile (17-37 us of the 70 us the first build of this kernel spent outside its
+// K loop, tools/trace_panel.py).  So the bias row is parked in LDS before the K loop (LDS reads count on lgkmcnt, not vmcnt) and
+// the code is branch-free per (HAS_MASK, FULL) instantiation.
+template <int NT, bool HAS_MASK, bool FULL>
+__device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32x16 (&acc)[NT], const float* sbias, int rbase,
+                                               int li, float (&cs1)[NT], float (&cs2)[NT]) {
+  const float floor_ = p.relu ? 0.f : -__builtin_inff();
+  // (mask variant: the 16 mask values of a tile are requested right before use — a two-tile ping-pong needs 32 more
+  // registers next to the 128 accumulators and spilled; its in-order wait on the previous tile's stores is the known cost
+  // of this variant)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = 32 * j + li;
+    float mk[16];
+    if (HAS_MASK) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = rbase + (r & 3) + 8 * (r >> 2);
+        mk[r] = p.mask[(long)(FULL ? rr : min(rr, p.M - 1)) * p.ldmask + col];
+      }
+    }
+    float v[16];
+    const float bvj = sbias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      v[r] = fmaxf(acc[j][r] + bvj, floor_);
+      if (HAS_MASK) v[r] = (mk[r] > 0.f) ? v[r] : 0.f;
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rr = rbase + (r & 3) + 8 * (r >> 2);
+      if (FULL || rr < p.M) {
+        p.C[(long)rr * p.ldc + col] = v[r];
+        s1 += v[r];
+        s2 = fmaf(v[r], v[r], s2);
+      }
+    }
+    cs1[j] = s1;
+    cs2[j] = s2;
+  }
+}
+
+template <int MODE, int NT>     // NT = output columns / 32: 8 (N = 256) or 4 (N = 128, the Planetoid PGE width)
+__global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) {
+  constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;   // bytes of one K block of B in LDS: N rows x 128 B
+  // (ONE __shared__ object: a second one beside a direct-to-LDS staging array can make hipcc drain vmcnt before every
+  // ds_read, cdna_hip_programming.md section 5 "three .s-level traps" (a)) — the bias row lives behind the two B stages
+  __shared__ __attribute__((aligned(16))) char smem[2 * PN_STAGE + PN_N * 4];
+  float* sbias = reinterpret_cast<float*>(smem + 2 * PN_STAGE);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * PN_BM;
+  const int row = m0 + wave * 32 + li;
+  const float* __restrict__ arow = p.A + (long)min(row, p.M - 1) * p.lda + 16 * h;
+  const char* __restrict__ Bb = (const char*)p.B;
+  const int nkb = p.K >> 5;
+  const int sw = (li >> 1) & 7;        // read-side swizzle of this lane's B rows (rows 32 j + li: (row >> 1) & 7 == (li >> 1) & 7)
+
+  auto stage_b = [&](int kb, int st) {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {       // N * 128 B = 4 NT pieces of 1 KiB (8 rows each): NT per wave
+      const int lrow = (wave * NT + q) * 8 + (lane >> 3);
+      const int logical = (lane & 7) ^ ((lrow >> 1) & 7);
+      const char* src = Bb + (long)lrow * p.ldb_bytes + kb * 128 + logical * 16;
+      __builtin_amdgcn_global_load_lds((gs_gbl_ptr)src, (gs_lds_ptr)(smem + st * PN_STAGE + (wave * NT + q) * 1024), 16, 0, 0);
+    }
+  };
+  auto load_a = [&](int kb, f32x4 (&dst)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4u t = *reinterpret_cast<const f32x4u*>(arow + kb * 32 + 4 * j);
+      dst[j] = f32x4{t.x, t.y, t.z, t.w};
+    }
+  };
+
+  // Two workgroups share a CU (2 waves per SIMD).  Started together they stay in lock step: both in their MFMA phase, then
+  // both in their prologue / epilogue with the matrix pipe idle.  Holding back the SECOND resident workgroup of each CU (ids
+  // 256..511 under the observed round-robin placement; only speed depends on that guess) by about half a solo tile lets the
+  // first one run alone at the full pipe rate meanwhile — nothing is lost — and from then on one workgroup's loads and stores
+  // overlap the other's MFMAs for the rest of the launch, because later workgroups start whenever a slot frees.
+  unsigned long long t_start = 0, t_loop = 0;
+  if (p.triage & 2) t_start = __builtin_amdgcn_s_memrealtime();
+  if (p.dephase > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < p.dephase; ++i) __builtin_amdgcn_s_sleep(127);
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // the bias row goes to LDS now and is read back in the epilogue: an LDS read counts on lgkmcnt, so it can sit between the
+  // stores of two tiles without waiting for them (a global load there would: vmcnt retires in order), and no register is held
+  // across the K loop
+  if (tid < PN_N) sbias[tid] = p.bias ? p.bias[tid] : 0.f;
+
+  f32x4 a_cur[4], a_nxt[4];
+  stage_b(0, 0);
+  load_a(0, a_cur);
+  const int nkb_run = nkb * p.krep;      // krep = 1 in the product; > 1 only in the loop-rate measurement
+  for (int kk = 0; kk < nkb_run; ++kk) {
+    const int kb = kk % nkb;
+    // B(kb) (direct-to-LDS, issued one block ago) has landed for every wave, and every wave is done reading the other stage
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kk + 1 < nkb_run) {
+      stage_b((kb + 1) % nkb, (kk + 1) & 1);
+      load_a((kb + 1) % nkb, a_nxt);
+    }
+    const char* __restrict__ bs = smem + (kk & 1) * PN_STAGE + li * 128;
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x4 b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4*>(bs + j * 4096 + (((4 * h + q) ^ sw) << 4));
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t >> 2][t & 3], b[t >> 2][t & 3], acc[j], 0, 0, 0);
+      }
+    } else {
+      bf16x8 ah[2], al[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = a_cur[2 * u + (e >> 2)][e & 3];
+          const __bf16 hb = (__bf16)x;
+          ah[u][e] = hb;
+          if constexpr (MODE == 1) al[u][e] = (__bf16)(x - (float)hb);
+        }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bs + j * 4096 + (((2 * h + u) ^ sw) << 4));
+          if constexpr (MODE == 1) {
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bs + j * 4096 + (((4 + 2 * h + u) ^ sw) << 4));
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], bh, acc[j], 0, 0, 0);     // small terms first
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bl, acc[j], 0, 0, 0);
+          }
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], bh, acc[j], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
+  }
+
+  if (p.triage & 2) t_loop = __builtin_amdgcn_s_memrealtime();
+  // epilogue: straight-line code per (mask?, interior panel?) combination — see panel_epilogue
+  const bool has_stat = p.colstat != nullptr;
+  const int rbase = m0 + wave * 32 + 4 * h;
+  const bool full = m0 + PN_BM <= p.M;
+  float cs1[NT], cs2[NT];
+  if (p.mask) {
+    if (full) panel_epilogue<NT, true, true>(p, acc, sbias, rbase, li, cs1, cs2);
+    else panel_epilogue<NT, true, false>(p, acc, sbias, rbase, li, cs1, cs2);
+  } else {
+    if (full) panel_epilogue<NT, false, true>(p, acc, sbias, rbase, li, cs1, cs2);
+    else panel_epilogue<NT, false, false>(p, acc, sbias, rbase, li, cs1, cs2);
+  }
+  if (has_stat) {
+    // per-panel column sums / sums of squares of the written rows: colstat[(panel * 2 + q) * N + col]
+    __syncthreads();                               // the B stages are dead: reuse them as scratch
+    float* red = reinterpret_cast<float*>(smem);   // [2][4 waves][N]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float a = cs1[j] + __shfl_xor(cs1[j], 32, 64), b = cs2[j] + __shfl_xor(cs2[j], 32, 64);
+      if (h == 0) {
+        red[(0 * 4 + wave) * PN_N + 32 * j + li] = a;
+        red[(1 * 4 + wave) * PN_N + 32 * j + li] = b;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * PN_N; c += 256) {
+      const int q = c / PN_N, cc = c % PN_N;
+      const float t = ((red[(q * 4 + 0) * PN_N + cc] + red[(q * 4 + 1) * PN_N + cc]) + red[(q * 4 + 2) * PN_N + cc]) +
+                      red[(q * 4 + 3) * PN_N + cc];
+      p.colstat[((long)blockIdx.x * 2 + q) * PN_N + cc] = t;
+    }
+  }
+  if ((p.triage & 2) && p.trace && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* o = p.trace + (long)blockIdx.x * 5;
+    o[0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, all 32 bits
+    o[1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
+    o[2] = t_start; o[3] = t_loop; o[4] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+// W [N][ldb] fp32 -> packed [N][K/32][hi 32 | lo 32] bf16 (lo = bf16(w - hi); all zeros are kept exact)
+__global__ void gs_panel_split_b_kernel(const float* __restrict__ W, long ldb, int N, int K, __bf16* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (row, k)
+  if (idx >= (long)N * K) return;
+  const int n = (int)(idx / K), k = (int)(idx % K);
+  const float w = W[(long)n * ldb + k];
+  const __bf16 hb = (__bf16)w;
+  const __bf16 lb = (__bf16)(w - (float)hb);
+  __bf16* o = out + ((long)n * (K >> 5) + (k >> 5)) * 64;
+  o[k & 31] = hb;
+  o[32 + (k & 31)] = lb;
+}
+
+static int g_panel_krep = 1, g_panel_triage = 0;
+extern "C" int gs_panel_debug(int krep, int triage) {      // measurement hook (tools/ab_panel.py), not part of the product ABI
+  g_panel_krep = krep < 1 ? 1 : krep;
+  g_panel_triage = triage;
+  return GS_OK;
+}
+static int g_panel_enabled = 1;
+static int g_panel_dephase = -1;      // -1: by mode and K (half a solo tile); >= 0: that many s_sleep(127)
+
+extern "C" int gs_gemm_set_panel_dephase(int n_sleeps) {
+  g_panel_dephase = n_sleeps;
+  return GS_OK;
+}
+
+extern "C" int gs_gemm_set_panel(int enable) {
+  g_panel_enabled = enable != 0;
+  return GS_OK;
+}
+
+// does gs_gemm_f32 hand this product to the panel kernel?
+bool gs_panel_eligible(const gs_gemm_desc& p) {
+  if (!g_panel_enabled) return false;
+  if ((p.N != 256 && p.N != 128) || p.K < 32 || (p.K & 31)) return false;
+  if (p.M < (p.prec != 0 ? 1 : 2048)) return false;   // exact fp32: a routing choice for big M; a split mode asked for: always honoured
+  if (p.nb1 > 1 || p.nb2 > 1 || p.kchunk > 0 || p.offA || p.offB || p.offC || p.Mb || p.Kb) return false;
+  if (p.gatherA_m || p.gatherA_k || p.gatherB_k || p.bgen_mask) return false;
+  if (p.sAk != 1 || p.sBk != 1 || p.alpha != 1.f || p.beta != 0.f) return false;
+  if ((p.sAm & 3) || (p.sBn & 3) || (((uintptr_t)p.A | (uintptr_t)p.B) & 15)) return false;
+  if (p.prec < 0 || p.prec > 2) return false;
+  if (p.prec != 0 && !p.scratch) return false;
+  return true;
+}
+
+template <int NT>
+static void panel_dispatch(const gs_gemm_desc& d, gs_panel_args& a, hipStream_t s) {
+  const dim3 grid(gs_cdiv(d.M, PN_BM)), block(256);
+  if (d.prec == 0) {
+    a.B = d.B; a.ldb_bytes = d.sBn * 4;
+    hipLaunchKernelGGL((gs_panel_gemm_kernel<0, NT>), grid, block, 0, s, a);
+  } else {
+    hipLaunchKernelGGL(gs_panel_split_b_kernel, dim3(gs_cdiv((long)d.N * d.K, 256)), dim3(256), 0, s, d.B, d.sBn, d.N, d.K,
+                       (__bf16*)d.scratch);
+    a.B = d.scratch; a.ldb_bytes = (long)d.K * 4;
+    if (d.prec == 1) hipLaunchKernelGGL((gs_panel_gemm_kernel<1, NT>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gs_panel_gemm_kernel<2, NT>), grid, block, 0, s, a);
+  }
+}
+
+int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s) {
+  gs_panel_args a;
+  a.A = d.A; a.lda = d.sAm;
+  a.C = d.C; a.ldc = d.ldc;
+  a.M = d.M; a.K = d.K;
+  a.bias = d.bias; a.relu = d.relu; a.mask = d.mask; a.ldmask = d.ldmask; a.colstat = d.colstat;
+  a.krep = g_panel_krep; a.triage = g_panel_triage;
+  a.trace = (g_panel_triage & 2) ? (unsigned long long*)d.scratch : nullptr;   // (trace runs use prec = 0: scratch is free)
+  {
+    // half of a solo tile's MFMA time: K/32 blocks x (N/32 tiles x 16 MFMAs x 64 cycles | x 6 MFMAs x 32 cycles) / 2
+    const long blk = (d.prec == 0) ? (long)(d.N / 32) * 16 * 64 : (long)(d.N / 32) * 6 * 32;
+    const long half = (long)(d.K / 32) * blk / 2;
+    a.dephase = g_panel_dephase >= 0 ? g_panel_dephase : (int)((half + 4064) / 8128);
+    if (gs_cdiv(d.M, PN_BM) <= 256) a.dephase = 0;
+  }
+  if (d.N == 256) panel_dispatch<8>(d, a, s);
+  else panel_dispatch<4>(d, a, s);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

@@ -394,6 +394,12 @@ class GCondEngine:
     def set_identity_structure(self, on=True):
         check(self.L.gs_gcond_set_identity_structure(self.h, int(on), self._s()))
 
+    OPERAND_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+    def set_operand_mode(self, mode):
+        """Operand precision of the three row-panel products (gs_gcond_set_operand_mode): 'f32' (default), 'bf16x3', 'bf16'."""
+        check(self.L.gs_gcond_set_operand_mode(self.h, self.OPERAND_MODES.get(mode, mode)))
+
     def set_overlap(self, on):
         check(self.L.gs_gcond_set_overlap(self.h, int(on)))
 

@@ -73,6 +73,12 @@ typedef struct gs_gemm_desc {
   const int* bgen_idx;
   const float* bgen_w;
   int bgen_div;
+  /* operand precision of the row-panel kernel (N == 256, both operands k-contiguous, unbatched, M >= 2048; other shapes
+     ignore it and compute in exact fp32): 0 = exact fp32 MFMA (default), 1 = split bf16 x3 (A = Ah + Al, B = Bh + Bl,
+     C += Al Bh + Ah Bl + Ah Bh, fp32 accumulate: ~2^-16 relative operand representation), 2 = bf16 operands (Ah Bh only).
+     prec != 0 needs `scratch`: N * K * 4 bytes of device memory for the pre-split B. */
+  int prec;
+  void* scratch;
 } gs_gemm_desc;
 
 /* K-tile depth (16 or 32) of the small tiles and of the 128x128 tile (0 = by operand mode); a measurement knob (defaults 32 / 0). */
@@ -81,8 +87,14 @@ int gs_gemm_set_tuning(int bk_small, int bk_big);
    fetched straight from global memory): taken when the 32x32 tile count is <= max_tiles and the product is <= max_gflop
    (defaults 8192 / 1.5); max_tiles = 0 switches it off.  A measurement knob. */
 int gs_gemm_set_small(long max_tiles, double max_gflop);
+/* route eligible products to the row-panel kernel (default 1); 0 sends them to the 128x128 tile (A/B measurements) */
+int gs_gemm_set_panel(int enable);
+/* start-up delay of the second resident workgroup of each CU in the row-panel kernel, in units of s_sleep(127) (8 128
+   cycles); -1 = chosen from the operand mode and K (half a solo tile; the default), 0 = off.  A measurement knob. */
+int gs_gemm_set_panel_dephase(int n_sleeps);
 /* which kernel gs_gemm_f32 launches for this descriptor: 0 = 128x32 tile, 1 = 32x128, 2 = 64x64, 3 = 128x128, 4 = the
-   one-tile-per-workgroup latency kernel (test hook: parity tests assert the instantiation a shape exercises) */
+   one-tile-per-workgroup latency kernel, 5 = the row-panel kernel (128 rows x all 256 columns per workgroup; PGE layer 2,
+   its backward and the SGC transform) — test hook: parity tests assert the instantiation a shape exercises */
 int gs_gemm_route(const gs_gemm_desc* d);
 /* number of M tiles gs_gemm_f32 will use for this descriptor (first dimension of colstat) */
 int gs_gemm_tiles_m(const gs_gemm_desc* d);
@@ -242,6 +254,10 @@ int gs_gcond_adopt_cached_forward(gs_gcond* e, gs_stream_t stream);
 /* gs_gcond_outer_step runs the real-side branch (sampling + class gradients) on an engine-owned second stream and joins
  * it by event before the distance statistics (default on; results are identical either way). */
 int gs_gcond_set_overlap(gs_gcond* e, int on);
+/* Operand precision of the three row-panel products of the iteration (PGE layer 2 forward, its backward dY1, the SGC
+ * transform H1 = relu(X W1 + b1)): 0 = exact fp32 (default = the reference's precision), 1 = split bf16 x3 with fp32
+ * accumulation, 2 = bf16 operands (BASELINE.json configs[1]).  See gs_gemm_desc.prec.  Everything else stays fp32. */
+int gs_gcond_set_operand_mode(gs_gcond* e, int mode);
 /* One outer-loop iteration; adds the matching loss to the device-side accumulator. */
 int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream);
 /* The sibling gradient-matching methods reuse train_class unchanged and differ in the update rule and in whether a

@@ -466,6 +466,12 @@ class GCondState:
             self.opt_pge.step(g_pge)
         else:
             self.opt_feat.step([g_feat])
+        adj_inner = self.inference_and_inner(inner_loop)
+        return loss.detach(), g_feat.detach(), [g.detach() for g in g_pge], adj_inner
+
+    def inference_and_inner(self, inner_loop):
+        """gcond.py:63-72: PGE.inference on the just-updated (X~, theta_PGE), dense_gcn_norm, `inner_loop` model steps.
+        Returns the raw inference adjacency."""
         with torch.no_grad():
             feat_inner = self.feat_syn.detach()
             adj_inner = pge_forward(feat_inner, {"lin": [p.detach() for p in self.pge["lin"]],
@@ -476,7 +482,7 @@ class GCondState:
             l_in = F.nll_loss(out, self.labels_syn)
             gm = torch.autograd.grad(l_in, self.model)
             self.opt_model.step(list(gm))
-        return loss.detach(), g_feat.detach(), [g.detach() for g in g_pge], adj_inner
+        return adj_inner
 
 
 # --------------------------------------------------------------------------------------------

@@ -6,7 +6,8 @@ reference's golden vectors), and ONE whole outer iteration is compared stage by 
   matching loss                    <= 1e-4 relative      (north_star gate)
   d loss / d X~  (direct + PGE)    <= 1e-3 of the tensor's max
   d loss / d theta_PGE, per tensor <= 1e-3 of the tensor's max
-  X~ after the Adam step, adj_syn of PGE.inference, theta after `inner_loop` SGC steps.
+  the Adam step on the stepped group (well-conditioned entries identical), then — continuing the oracle from the engine's
+  updated tensors — adj_syn of PGE.inference (2e-5 abs) and theta after `inner_loop` SGC steps.
 
 Configs: ogbn-arxiv r = 0.5 % (the bench workload: N = 169 343, n' = 454 — the 128x128 MFMA tile, BGEN edge product and the
 streaming PGE kernels run here, not the small-shape routes), Reddit r = 0.1 % inductive with fan-out [15, 8] and d = 602,
@@ -62,40 +63,56 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None):
     st = O.GCondState(xs0, {"lin": pge0[:6], "bn": pge0[6:]}, torch.from_numpy(p["labels_syn"]), p["ncd"], p["data"].nclass,
                       p["lrf"], p["lra"], 0.01, "SGC", 2)
     st.new_epoch([t.clone() for t in theta])
-    ref_loss, ref_gfeat, ref_gpge, adj_inner = st.outer_iteration(epoch, batches, p["data"].bench_feat, p["data"].bench_labels,
-                                                                  p["inner"])
+    ref_loss, ref_gfeat, ref_gpge, _ = st.outer_iteration(epoch, batches, p["data"].bench_feat, p["data"].bench_labels, 0)
     out = dict(loss=loss, ref_loss=float(ref_loss), rel_loss=abs(loss - float(ref_loss)) / abs(float(ref_loss)),
-               g_feat=rel_max(g_feat, ref_gfeat), g_pge=[], n=n, name=name)
+               g_feat=rel_max(g_feat, ref_gfeat), g_pge=[], n=n, name=name, epoch=epoch)
     o = 0
     for i, (shp, ref) in enumerate(zip(eng.pge_shapes(), ref_gpge)):
         k = int(np.prod(shp))
         if i not in (1, 3):    # biases of the Linear layers in front of a batch-statistics BatchNorm: mathematically zero gradient
             out["g_pge"].append((i, rel_max(g_pge[o:o + k].reshape(shp), ref)))
         o += k
-    out["adj"] = float((eng.adj_syn.cpu() - adj_inner).abs().max())
-    # Adam's first step is lr * g / (|g| + eps): entries whose gradient is ~0 have an ill-conditioned sign, so the updated
-    # tensors are compared by the FRACTION of entries that moved identically
-    lr = p["lrf"] if epoch % 50 >= 10 else p["lra"]
+    # ---- the Adam step.  Its first step is lr * g / (|g| + eps) ~ lr * sign(g): entries whose gradient lies below the fp32
+    # noise of the computation have an ill-conditioned sign, so the update is gated on the WELL-conditioned entries
+    # (|g| > 1e-3 max|g| of their tensor), which must move identically; the share of all entries that differ is reported.
     if epoch % 50 >= 10:
-        diff = (eng.feat_syn.cpu() - st.feat_syn.detach()).abs()
+        lr, new_e, new_o, refg = p["lrf"], eng.feat_syn.cpu(), st.feat_syn.detach(), [ref_gfeat]
     else:
-        diff = (eng.pge_params.cpu() - torch.cat([q.detach().reshape(-1) for q in st.pge_param_list()])).abs()
-    out["upd_bad_frac"] = float((diff > 0.02 * lr).double().mean())
+        lr, new_e = p["lra"], eng.pge_params.cpu()
+        new_o, refg = torch.cat([q.detach().reshape(-1) for q in st.pge_param_list()]), ref_gpge
+    # (the two Linear biases in front of a batch-statistics BatchNorm have a mathematically ZERO gradient: what Adam sees there
+    # is rounding noise, in the reference too — never well-conditioned)
+    noise = (1, 3) if len(refg) > 1 else ()
+    well = torch.cat([((g.abs() > 1e-3 * g.abs().max()) & (i not in noise)).reshape(-1) for i, g in enumerate(refg)])
+    diff = (new_e.reshape(-1) - new_o.reshape(-1)).abs()
+    out["upd_well_max"] = float(diff[well].max()) / lr
+    out["upd_any_frac"] = float((diff > 0.02 * lr).double().mean())
+    # ---- PGE.inference + inner steps: the oracle continues from the ENGINE's updated tensors, so that this stage is
+    # compared on identical inputs whatever the ill-conditioned signs did
+    with torch.no_grad():
+        if epoch % 50 >= 10:
+            st.feat_syn.copy_(new_e)
+        else:
+            for q, v in zip(st.pge_param_list(), eng.get_pge()):
+                q.copy_(v.cpu())
+    adj_inner = st.inference_and_inner(p["inner"])
+    out["adj"] = float((eng.adj_syn.cpu() - adj_inner).abs().max())
     mdiff = torch.cat([(a.cpu() - b.detach()).abs().reshape(-1) for a, b in zip(eng.get_model(), st.model)])
     out["model_bad_frac"] = float((mdiff > 0.02 * 0.01 * max(p["inner"], 1)).double().mean())
     out["model_max"] = float(mdiff.max())
     return out
 
 
-def check(r, adj_tol=2e-4):
+def check(r, adj_tol=2e-5):
     print(r)
     assert r["rel_loss"] <= 1e-4, r
     assert r["g_feat"] <= 1e-3, r
     for i, e in r["g_pge"]:
         assert e <= 1e-3, (i, e, r)
+    assert r["upd_well_max"] <= 1e-2, r          # well-conditioned entries: identical Adam move (in units of lr)
+    assert r["upd_any_frac"] <= 1e-2, r          # ill-conditioned signs are rare
     assert r["adj"] <= adj_tol, r
-    assert r["upd_bad_frac"] <= 2e-3, r
-    assert r["model_bad_frac"] <= 5e-3, r
+    assert r["model_bad_frac"] <= 1e-3, r
 
 
 @pytest.mark.parametrize("epoch", [10, 0])

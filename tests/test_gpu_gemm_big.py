@@ -12,6 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 BIG = 3     # gs_gemm_route code of the 128x128 tile
+PANEL = 5   # ... of the row-panel kernel that takes the PGE layer-2 / dY1 / H1full products since round 2
 
 
 @pytest.fixture(scope="module")
@@ -22,12 +23,26 @@ def E():
 
 @pytest.fixture()
 def no_small_route():
-    """Send everything to the tiled kernels for the duration of a test (gs_gemm_set_small is a documented tuning knob)."""
+    """Send everything to the tiled kernels for the duration of a test (gs_gemm_set_small / gs_gemm_set_panel are documented
+    tuning knobs)."""
     from graphslim_amd import _lib
     L = _lib.lib()
     L.gs_gemm_set_small(0, 0.0)
+    L.gs_gemm_set_panel(0)
     yield
     L.gs_gemm_set_small(8192, 1.5)
+    L.gs_gemm_set_panel(1)
+
+
+@pytest.fixture(params=[1, 0], ids=["panel", "tile128"])
+def panel(request):
+    """Run a test once with the row-panel kernel (the product path) and once with panel routing off, which sends the same
+    product to the 128x128 tile (still the kernel of every non-eligible big product)."""
+    from graphslim_amd import _lib
+    L = _lib.lib()
+    L.gs_gemm_set_panel(request.param)
+    yield PANEL if request.param else BIG
+    L.gs_gemm_set_panel(1)
 
 
 def route(E, *a, **kw):
@@ -66,7 +81,7 @@ def test_big_tile_all_layouts(E, no_small_route, M, N, K):
         close(Cd, ref, what=f"layout {name}")
 
 
-def test_pge_layer2_shape_exact(E):
+def test_pge_layer2_shape_exact(E, panel):
     """The product the roofline line is quoted on: E2[n'^2, Ph] = A1[n'^2, Ph] W1^T + b1 at n' = 454, Ph = 256, with the
     fused BatchNorm column statistics, and dY1 = (dE2 W1^T^T) * [A1 > 0] through the mask epilogue — against fp64."""
     from graphslim_amd import _lib
@@ -81,7 +96,7 @@ def test_pge_layer2_shape_exact(E):
     tiles = _lib.lib().gs_gemm_tiles_m(C.byref(d))
     stat = torch.full((tiles, 2, ph), float("nan"), device=DEV)
     out = torch.full((rows, ph), float("nan"), device=DEV)
-    assert route(E, a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph, bias=b1.to(DEV), colstat=stat) == BIG
+    assert route(E, a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph, bias=b1.to(DEV), colstat=stat) == panel
     E.gemm(a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph, bias=b1.to(DEV), colstat=stat)
     close(out, ref, what="E2")
     close(stat[:, 0].double().sum(0), ref.sum(0), rtol=1e-4, atol_scale=1e-5, what="column sums")
@@ -90,12 +105,12 @@ def test_pge_layer2_shape_exact(E):
     dE2 = torch.randn(rows, ph)
     W1T = W1.T.contiguous().to(DEV)
     out2 = torch.full((rows, ph), float("nan"), device=DEV)
-    assert route(E, dE2.to(DEV), W1T, out2, rows, ph, ph, (ph, 1), (1, ph), ph, mask=a, ldmask=ph) == BIG
+    assert route(E, dE2.to(DEV), W1T, out2, rows, ph, ph, (ph, 1), (1, ph), ph, mask=a, ldmask=ph) == panel
     E.gemm(dE2.to(DEV), W1T, out2, rows, ph, ph, (ph, 1), (1, ph), ph, mask=a, ldmask=ph)
     close(out2, (dE2.double() @ W1.double()) * (A1 > 0), what="dY1")
 
 
-def test_h1full_shape_bias_relu(E):
+def test_h1full_shape_bias_relu(E, panel):
     """H1full = relu(X W1 + b1) over all N = 169 343 nodes (d = 128 -> h = 256): the (K,K) tile with bias + relu, X rows
     padded to the engine's leading dimension."""
     N, d, h = 169343, 128, 256
@@ -103,7 +118,7 @@ def test_h1full_shape_bias_relu(E):
     X, W1, b1 = torch.randn(N, d), torch.randn(d, h) / 11, torch.randn(h)
     W1T = W1.T.contiguous().to(DEV)
     out = torch.full((N, h), float("nan"), device=DEV)
-    assert route(E, X.to(DEV), W1T, out, N, h, d, (d, 1), (1, d), h, bias=b1.to(DEV), relu=1) == BIG
+    assert route(E, X.to(DEV), W1T, out, N, h, d, (d, 1), (1, d), h, bias=b1.to(DEV), relu=1) == panel
     E.gemm(X.to(DEV), W1T, out, N, h, d, (d, 1), (1, d), h, bias=b1.to(DEV), relu=1)
     close(out, (X.double() @ W1.double() + b1.double()).clamp_min(0), what="H1full")
 

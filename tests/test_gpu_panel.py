@@ -1,0 +1,108 @@
+"""The row-panel kernel (csrc/gs_panel.hip) in its three operand precisions against fp64, and the measured error of each mode:
+   f32    exact fp32 MFMA                       gate 2e-5 relative (fp32 re-association only)
+   bf16x3 split bf16 x3, fp32 accumulate        gate 1e-4 of the output's max  (operands represented to 2^-16)
+   bf16   bf16 operands, fp32 accumulate        gate 2e-2 of the output's max  (operands rounded to 8 significant bits)
+Needs an MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MODES = {"f32": (0, 2e-5, 2e-6), "bf16x3": (1, 2e-4, 1e-4), "bf16": (2, 5e-2, 2e-2)}
+
+
+@pytest.fixture(scope="module")
+def E():
+    from graphslim_amd import engine
+    return engine
+
+
+def run(E, A, W, mode, **kw):
+    """C = A W^T (+...) through gs_gemm_f32 with desc.prec = mode; asserts the panel route."""
+    from graphslim_amd import _lib
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.full((M, N), float("nan"), device=DEV)
+    scratch = torch.empty(N * K, device=DEV)
+    d, keep = E.gemm_desc(A, W, out, M, N, K, (K, 1), (1, K), N, prec=mode, scratch=scratch, **kw)
+    assert _lib.lib().gs_gemm_route(C.byref(d)) == 5
+    _lib.check(_lib.lib().gs_gemm_f32(C.byref(d), _lib.stream()))
+    return out
+
+
+def err(got, ref):
+    ref = ref.double().cpu()
+    return float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("M,K", [(206116, 256), (169343, 128), (2048 + 5, 32), (4096, 64), (10007, 512)])
+def test_panel_against_fp64(E, mode, M, K):
+    code, rtol, gate = MODES[mode]
+    torch.manual_seed(M + K)
+    A, W, b = torch.randn(M, K), torch.randn(256, K) / np.sqrt(K), torch.randn(256)
+    ref = A.double() @ W.double().T + b.double()
+    out = run(E, A.to(DEV), W.to(DEV), code, bias=b.to(DEV))
+    e = err(out, ref)
+    print(f"panel {mode} M={M} K={K}: max|err| / max|ref| = {e:.3e}")
+    assert e <= gate, (mode, M, K, e)
+    if mode == "f32":
+        np.testing.assert_allclose(out.double().cpu().numpy(), ref.numpy(), rtol=rtol, atol=gate * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_panel_epilogues(E, mode):
+    """bias + relu, the mask epilogue (ReLU backward), fused column statistics, a row count that is not a panel multiple."""
+    from graphslim_amd import _lib
+    code, rtol, gate = MODES[mode]
+    M, K = 5000 + 37, 256
+    torch.manual_seed(3)
+    A, W, b, mask = torch.randn(M, K), torch.randn(256, K) / 16, torch.randn(256), torch.randn(M, 256)
+    ref = A.double() @ W.double().T
+    a, w = A.to(DEV), W.to(DEV)
+    out = run(E, a, w, code, bias=b.to(DEV), relu=1)
+    assert err(out, (ref + b.double()).clamp_min(0)) <= gate
+    out = run(E, a, w, code, mask=mask.to(DEV), ldmask=256)
+    assert err(out, ref * (mask > 0)) <= gate
+    d, _k = E.gemm_desc(a, w, a, M, 256, K, (K, 1), (1, K), 256)
+    tiles = _lib.lib().gs_gemm_tiles_m(C.byref(d))
+    assert tiles == -(-M // 128)
+    stat = torch.full((tiles, 2, 256), float("nan"), device=DEV)
+    out = run(E, a, w, code, bias=b.to(DEV), colstat=stat)
+    got = out.double().cpu()
+    # the statistics are those of the values the kernel WROTE (whatever the operand precision)
+    np.testing.assert_allclose(stat[:, 0].double().sum(0).cpu().numpy(), got.sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(stat[:, 1].double().sum(0).cpu().numpy(), (got * got).sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    assert err(out, ref + b.double()) <= gate
+
+
+def test_panel_f32_is_the_tile_kernel_up_to_reassociation(E):
+    """Panel routing on / off: the same fp32 product from the two kernels (different k order inside a K block)."""
+    from graphslim_amd import _lib
+    M, K = 20000, 256
+    torch.manual_seed(4)
+    A, W = torch.randn(M, K, device=DEV), torch.randn(256, K, device=DEV) / 16
+    o1 = run(E, A, W, 0)
+    _lib.lib().gs_gemm_set_panel(0)
+    try:
+        o2 = torch.empty_like(o1)
+        E.gemm(A, W, o2, M, 256, K, (K, 1), (1, K), 256)
+    finally:
+        _lib.lib().gs_gemm_set_panel(1)
+    assert float((o1 - o2).abs().max()) <= 2e-5 * float(o2.abs().max())
+
+
+def test_panel_needs_scratch_for_split_modes(E):
+    """prec != 0 without scratch is not panel-eligible: the product falls back to the exact fp32 tile (never silently to a
+    lower precision) — and ineligible shapes ignore prec."""
+    from graphslim_amd import _lib
+    A, W = torch.randn(4096, 256, device=DEV), torch.randn(256, 256, device=DEV)
+    out = torch.empty(4096, 256, device=DEV)
+    d, _ = E.gemm_desc(A, W, out, 4096, 256, 256, (256, 1), (1, 256), 256, prec=1)
+    assert _lib.lib().gs_gemm_route(C.byref(d)) != 5
+    _lib.check(_lib.lib().gs_gemm_f32(C.byref(d), _lib.stream()))
+    ref = A.double() @ W.double().T
+    assert err(out, ref) <= 2e-6

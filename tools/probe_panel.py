@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Launches only the row-panel kernel at the PGE layer-2 shape (5 x fp32, 5 x bf16x3, 5 x bf16) — for rocprofv3 --pmc passes."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphslim_amd import _lib  # noqa: E402
+from graphslim_amd.engine import gemm_desc  # noqa: E402
+
+dev = "cuda:0"
+L = _lib.lib()
+n, ph = 454, 256
+rows = n * n
+a = torch.randn(rows, ph, device=dev)
+w = torch.randn(ph, ph, device=dev) / 16
+b = torch.randn(ph, device=dev)
+out = torch.empty(rows, ph, device=dev)
+scratch = torch.empty(ph * ph, device=dev)
+stat = torch.empty(-(-rows // 128), 2, ph, device=dev)
+for prec in (0, 1, 2):
+    d, keep = gemm_desc(a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph, prec=prec, scratch=scratch, bias=b, colstat=stat)
+    assert L.gs_gemm_route(C.byref(d)) == 5
+    for _ in range(5):
+        _lib.check(L.gs_gemm_f32(C.byref(d), _lib.stream()))
+torch.cuda.synchronize()
+print("probe done", float(out[0, 0]))
