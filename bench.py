@@ -240,6 +240,8 @@ def main():
     ap.add_argument("--workload", default="ogbn-arxiv", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink N for smoke runs (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--operand-mode", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="operand precision of the row-panel products for the HEADLINE run (default: exact fp32)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -269,6 +271,7 @@ def main():
     from graphslim_amd import parallel
     eng = parallel.make_engine(p, dev, rank, world) if world > 1 else make_engine(p, dev)
     init_state(p, eng)
+    getattr(eng, "eng", eng).set_operand_mode(args.operand_mode)
 
     def barrier():
         if world > 1:

@@ -642,6 +642,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     if (fused) {   // B(k, :) = val0[k] * [H1full[col0[k]] > 0] * Y1[k / f2]
       gwd.B = Y1; gwd.sBb1 = (long)cap1 * h;
       gwd.bgen_mask = e->H1full; gwd.bgen_ldm = h; gwd.bgen_idx = b.col0; gwd.bgen_w = b.val0; gwd.bgen_div = f2;
+      gwd.prec = e->operand_mode;      // honoured by the dedicated edge kernel (gs_edge.hip); the tiled fallback is fp32
     }
     GS_TRY(gs_gemm_f32(&gwd, stream));
     GS_TRY(gs_reduce_slabs_batched_f32(gw + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, Cl, 0.f, stream));

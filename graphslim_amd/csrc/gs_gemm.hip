@@ -543,6 +543,8 @@ __global__ __launch_bounds__(256) void gs_gemm_small_group_kernel(gs_gemm_group_
   else gs_small_any(g.d[3], z - g.z0[3], red);
 }
 
+bool gs_edge_eligible(const gs_gemm_desc& p);             // gs_edge.hip
+int gs_edge_launch(const gs_gemm_desc& d, hipStream_t s);
 bool gs_panel_eligible(const gs_gemm_desc& p);            // gs_panel.hip
 int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s);
 
@@ -687,6 +689,7 @@ extern "C" int gs_gemm_route(const gs_gemm_desc* d) {
   if (p.nb2 < 1) p.nb2 = 1;
   const int nb = p.nb1 * p.nb2;
   if (gs_panel_eligible(p)) return 5;
+  if (gs_edge_eligible(p)) return 6;
   if (small_route(p, nb)) return 4;
   return pick_tile(p, nb);
 }
@@ -713,6 +716,7 @@ extern "C" int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream) {
   if ((long)nbatch > 65535) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: too many batches (%d)", nbatch);
   hipStream_t s = (hipStream_t)stream;
   if (gs_panel_eligible(p)) return gs_panel_launch(p, s);
+  if (gs_edge_eligible(p)) return gs_edge_launch(p, s);
   if (small_route(p, nbatch)) return launch_small(p, nbatch, s);
   // tile choice: fill the 256 CUs; narrow outputs get the tall/flat tiles
   switch (pick_tile(p, nbatch)) {

@@ -89,12 +89,14 @@ int gs_gemm_set_tuning(int bk_small, int bk_big);
 int gs_gemm_set_small(long max_tiles, double max_gflop);
 /* route eligible products to the row-panel kernel (default 1); 0 sends them to the 128x128 tile (A/B measurements) */
 int gs_gemm_set_panel(int enable);
+/* route the real-side edge product (generated B, gathered K, N == 256) to its dedicated kernel (default 1); 0 = 128x128 tile */
+int gs_gemm_set_edge_kernel(int enable);
 /* start-up delay of the second resident workgroup of each CU in the row-panel kernel, in units of s_sleep(127) (8 128
    cycles); -1 = chosen from the operand mode and K (half a solo tile; the default), 0 = off.  A measurement knob. */
 int gs_gemm_set_panel_dephase(int n_sleeps);
 /* which kernel gs_gemm_f32 launches for this descriptor: 0 = 128x32 tile, 1 = 32x128, 2 = 64x64, 3 = 128x128, 4 = the
    one-tile-per-workgroup latency kernel, 5 = the row-panel kernel (128 rows x all 256 columns per workgroup; PGE layer 2,
-   its backward and the SGC transform) — test hook: parity tests assert the instantiation a shape exercises */
+   its backward and the SGC transform), 6 = the real-side edge-product kernel — test hook: parity tests assert the instantiation a shape exercises */
 int gs_gemm_route(const gs_gemm_desc* d);
 /* number of M tiles gs_gemm_f32 will use for this descriptor (first dimension of colstat) */
 int gs_gemm_tiles_m(const gs_gemm_desc* d);

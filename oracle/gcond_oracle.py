@@ -675,3 +675,55 @@ def reduce_and_evaluate(adj_full, x, y, idx_train, idx_val, idx_test, nclass, *,
         accs.append(run_eval_gcn(feat_s, adj_eval, lab_s, g, hidden, nclass, eval_epochs)[1])
     out["eval_mean"], out["eval_std"] = float(np.mean(accs)), float(np.std(accs))
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# the sibling gradient-matching loops: same __init__ / train_class, different update rule.
+# --------------------------------------------------------------------------------------------
+
+SIBLING_RULES = {
+    # name: (identity structure, (step_pge, step_feat) as a function of ol, inner steps, inference at checkpoints only)
+    "doscond": (False, lambda ol: (True, True), False),            # doscond.py:40-50
+    "gcondx": (True, lambda ol: (False, not (ol % 5 < 1)), True),   # gcondx.py:44-66 (optimizer_pge has no gradient: no-op)
+    "doscondx": (True, lambda ol: (False, True), False),           # doscondx.py:42-49
+}
+
+
+def reduce_sibling(method, adj_full, x, y, idx_train, nclass, *, reduction_rate, hidden, ntrans, pge_hid, epochs, outer_loop,
+                   inner_loop, lr_feat, lr_adj, lr_model, seed, batch_fn, dis_metric="ours"):
+    """Restates DosCond / GCondX / DosCondX .reduce without checkpoints (doscond.py:18-67, gcondx.py:18-79,
+    doscondx.py:18-64) with the reference's RNG draw order (seed_everything -> PGE ctor -> Random init -> model ctor ->
+    model.initialize() per epoch).  `batch_fn(c, call_index)` supplies class c's sampled batch.  Returns the per-iteration
+    matching losses, the final X~, the final PGE parameters and the final PGE.inference adjacency (identity for the X
+    variants)."""
+    identity, rule, run_inner = SIBLING_RULES[method]
+    seed_everything(seed)
+    feat_full = torch.from_numpy(x).float()
+    labels_full = torch.from_numpy(y).long()
+    labels_train = y[idx_train]
+    labels_syn_np, ncd, _ = generate_labels_syn(labels_train, reduction_rate)
+    labels_syn = torch.from_numpy(labels_syn_np)
+    d = x.shape[1]
+    pge = init_pge_reference_order(d, pge_hid)
+    sel = random_init_indices(idx_train, labels_train, ncd)
+    st = GCondState(feat_full[sel], pge, labels_syn, ncd, nclass, lr_feat, lr_adj, lr_model, "SGC", 2)
+    init_sgc(d, hidden, nclass, ntrans)   # model constructor draw
+    calls, losses = 0, []
+    for it in range(epochs):
+        st.new_epoch(init_sgc(d, hidden, nclass, ntrans))
+        for ol in range(outer_loop):
+            batches = []
+            for c in range(nclass):
+                batches.append(batch_fn(c, calls))
+                calls += 1
+            sp_, sf_ = rule(ol)
+            l, _, _ = st.outer_iteration_ex(batches, feat_full, labels_full, inner_loop, step_pge=sp_, step_feat=sf_,
+                                            run_inference=False, run_inner=run_inner, identity=identity, dis_metric=dis_metric)
+            losses.append(float(l))
+    with torch.no_grad():
+        if identity:
+            adj = torch.eye(len(labels_syn_np))
+        else:
+            adj = pge_forward(st.feat_syn.detach(), {"lin": [p.detach() for p in st.pge["lin"]],
+                                                     "bn": [p.detach() for p in st.pge["bn"]]})
+    return dict(losses=losses, feat_syn=st.feat_syn.detach(), adj_syn=adj, state=st, labels_syn=labels_syn_np)

@@ -666,7 +666,56 @@ def g12():
     save("g12_fit_full", **out)
 
 
+# ---------------------------------------------------------------- G13 sibling methods ----------
+
+
+def g13():
+    """DosCond / GCondX / DosCondX .reduce of the reference (doscond.py:18-67, gcondx.py:18-79, doscondx.py:18-64) for 4 epochs
+    x 6 outer iterations (so that GCondX's `ol % 5 < 1` skip happens at ol = 0 and 5) without checkpoints: the matching loss
+    of every outer iteration, the final X~, PGE parameters and PGE.inference adjacency."""
+    from graphslim.condensation.doscond import DosCond
+    from graphslim.condensation.gcondx import GCondX
+    from graphslim.condensation.doscondx import DosCondX
+    out = {}
+    cases = {"doscond_t1": (DosCond, 1, "cora", 16), "doscond_t2": (DosCond, 2, "ogbn-arxiv", 12), "gcondx_t1": (GCondX, 1, "cora", 16),
+             "gcondx_t2": (GCondX, 2, "ogbn-arxiv", 12), "doscondx_t1": (DosCondX, 1, "cora", 16)}
+    for tag, (cls, T, dataset, hidden) in cases.items():
+        tmp = tempfile.mkdtemp(prefix="golden_")
+        try:
+            n, nclass, d = 90, 3, 8
+            a, x, y = make_graph(n, nclass, d, 5, seed=61)
+            data = FakeData(a, x, y, nclass, [8, 10, 14], 20, 30, seed=5, sizes=(4, 3))
+            args = args_obj(ntrans=T, hidden=hidden, reduction_rate=0.5, dataset=dataset, epochs=4, outer_loop=6, inner_loop=2,
+                            checkpoints=[], save_path=tmp, logger=CapLogger(), lr_feat=0.01, lr_adj=0.01, seed=1,
+                            method=cls.__name__.lower())
+            RU.seed_everything(args.seed)
+            agent = cls("trans", data, args)
+            losses = []
+            orig = agent.train_class
+
+            def spy(*a_, **k_):
+                l = orig(*a_, **k_)
+                losses.append(float(l))
+                return l
+
+            agent.train_class = spy
+            agent.reduce(data, verbose=False)
+            with torch.no_grad():
+                adj_inf = agent.pge.inference(agent.feat_syn) if cls is DosCond else torch.eye(agent.feat_syn.shape[0])
+            coo = a.tocoo()
+            out.update({f"{tag}_a_row": coo.row, f"{tag}_a_col": coo.col, f"{tag}_x": x, f"{tag}_y": y,
+                        f"{tag}_idx_train": np_(data.idx_train), f"{tag}_meta": np.array([n, nclass, d, hidden, T, 2, 4, 6]),
+                        f"{tag}_losses": np.array(losses), f"{tag}_feat_syn": np_(agent.feat_syn), f"{tag}_adj_syn": np_(adj_inf),
+                        f"{tag}_labels_syn": np.asarray(data.labels_syn)})
+            if cls is DosCond:      # (the X variants never touch the PGE)
+                for i, p in enumerate(agent.pge.parameters()):
+                    out[f"{tag}_pge{i}"] = np_(p)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    save("g13_siblings", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 BIG = 3     # gs_gemm_route code of the 128x128 tile
 PANEL = 5   # ... of the row-panel kernel that takes the PGE layer-2 / dY1 / H1full products since round 2
+EDGE = 6    # ... of the dedicated real-side edge-product kernel (csrc/gs_edge.hip)
 
 
 @pytest.fixture(scope="module")
@@ -177,11 +178,22 @@ def _edge_case(Cl, cap1, f2, Nn, d, h, seed):
     return X, H1, Y1, idx, w, kcount.to(torch.int32), K
 
 
-def test_generated_b_edge_product_d128_h256(E):
+@pytest.mark.parametrize("edge_kernel,prec", [(1, 0), (0, 0), (1, 1), (1, 2)], ids=["edge-f32", "tile128-f32", "edge-bf16x3", "edge-bf16"])
+def test_generated_b_edge_product_d128_h256(E, edge_kernel, prec):
     """The real-side first-layer gradient gW1_c = sum_e x_col(e) (x) (w_e [H1[col(e)] > 0] Y1[row(e)]) exactly as
     gs_gcond_stage_real_grads launches it at ogbn-arxiv sizes: gathered K, split-K slabs of 512, per-class K extents,
     B generated in the loader (BGEN) — and the same product with B materialised (plain gathered-K path)."""
     from graphslim_amd import _lib
+    _lib.lib().gs_gemm_set_edge_kernel(edge_kernel)
+    try:
+        _edge_product_case(E, EDGE if edge_kernel else BIG, prec)
+    finally:
+        _lib.lib().gs_gemm_set_edge_kernel(1)
+
+
+def _edge_product_case(E, want_route, prec):
+    from graphslim_amd import _lib
+    rtol, atol = {0: (1e-4, 1e-5), 1: (5e-4, 1e-4), 2: (1e-1, 2e-2)}[prec]
     Cl, cap1, f2, Nn, d, h = 5, 2816, 5, 20000, 128, 256
     X, H1, Y1, idx, w, kcount, K = _edge_case(Cl, cap1, f2, Nn, d, h, 9)
     kchunk = 512
@@ -197,13 +209,15 @@ def test_generated_b_edge_product_d128_h256(E):
     common = dict(gatherA_k=idxd, sGb1=K, nb1=Cl, nb2=nsplit, kchunk=kchunk, Kb=kcd, sCb1=nsplit * d * h, sCb2=d * h)
     # generated B
     slabs = torch.full((Cl, nsplit, d, h), float("nan"), device=DEV)
-    kw = dict(common, sBb1=cap1 * h, bgen_mask=H1d, bgen_ldm=h, bgen_idx=idxd, bgen_w=wd, bgen_div=f2)
-    assert route(E, Xd, Y1d, slabs, d, h, K, (1, d), (h, 1), h, **kw) == BIG
+    kw = dict(common, sBb1=cap1 * h, bgen_mask=H1d, bgen_ldm=h, bgen_idx=idxd, bgen_w=wd, bgen_div=f2, prec=prec)
+    assert route(E, Xd, Y1d, slabs, d, h, K, (1, d), (h, 1), h, **kw) == want_route
     E.gemm(Xd, Y1d, slabs, d, h, K, (1, d), (h, 1), h, **kw)
     out = torch.empty(Cl, d, h, device=DEV)
     _lib.check(_lib.lib().gs_reduce_slabs_batched_f32(_lib.ptr(out), d * h, _lib.ptr(slabs), d * h, nsplit, d * h, Cl, 0.0,
                                                       _lib.stream()))
-    close(out, ref, rtol=1e-4, atol_scale=1e-5, what="BGEN edge product")
+    close(out, ref, rtol=rtol, atol_scale=atol, what="BGEN edge product")
+    if prec != 0 or want_route != BIG:
+        return
     # materialised B (the path the 'mse' / 'cos' metrics take)
     Bmat = torch.zeros(Cl, K, h)
     for c in range(Cl):
