@@ -9,6 +9,7 @@
 #include "gs_kernels.h"
 
 extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int, long, int, float, gs_stream_t);
+int gs_reduce_slabs_active(float*, long, const float*, long, int, long, int, const int*, int, gs_stream_t);
 
 namespace {
 
@@ -645,7 +646,10 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       gwd.prec = e->operand_mode;      // honoured by the dedicated edge kernel (gs_edge.hip); the tiled fallback is fp32
     }
     GS_TRY(gs_gemm_f32(&gwd, stream));
-    GS_TRY(gs_reduce_slabs_batched_f32(gw + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, Cl, 0.f, stream));
+    if (((long)d * h) % 4 == 0 && P % 4 == 0 && e->oW1 % 4 == 0)   // 16-byte form that skips the slabs beyond each class's edge count
+      GS_TRY(gs_reduce_slabs_active(gw + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, Cl, kcount, e->kchunk_r, stream));
+    else
+      GS_TRY(gs_reduce_slabs_batched_f32(gw + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, Cl, 0.f, stream));
     if (!fused) GS_TRY(colsum_batched(e, Bmat, K * h, (int)K, kcount, h, Cl, gw + e->ob1, P, stream, e->colpart_r));
   }
   return GS_OK;

@@ -607,6 +607,33 @@ __global__ void gs_reduce_slabs_batched_kernel(float* __restrict__ out, long out
   o[i] = (beta != 0.f ? beta * o[i] : 0.f) + s;
 }
 
+// The same with 16-byte accesses and a per-batch count of slabs that can be non-zero: slabs at or beyond
+// ceil(kcount[b] / kchunk) hold exact zeros (their K range is empty) and are not read.  Same summation order as above.
+__global__ void gs_reduce_slabs_active_kernel(float* __restrict__ out, long out_stride, const float* __restrict__ slabs, long n4,
+                                              int ns, long slab_stride, const int* __restrict__ kcount, int kchunk) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int b = blockIdx.y;
+  const int na = min(ns, (kcount[b] + kchunk - 1) / kchunk);
+  const float4* sl = reinterpret_cast<const float4*>(slabs + (long)b * ns * slab_stride) + i;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < na; ++k) {
+    const float4 v = sl[(long)k * (slab_stride >> 2)];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(out + (long)b * out_stride)[i] = s;
+}
+
+// engine-internal (gs_engine.hip): n, slab_stride, out_stride multiples of 4, 16-byte aligned pointers
+int gs_reduce_slabs_active(float* out, long out_stride, const float* slabs, long n, int n_slabs, long slab_stride, int nbatch,
+                           const int* kcount, int kchunk, gs_stream_t stream) {
+  if (n <= 0 || nbatch <= 0) return GS_OK;
+  hipLaunchKernelGGL(gs_reduce_slabs_active_kernel, dim3(gs_cdiv(n >> 2, 256), nbatch), dim3(256), 0, (hipStream_t)stream, out,
+                     out_stride, slabs, n >> 2, n_slabs, slab_stride, kcount, kchunk);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 extern "C" int gs_reduce_slabs_batched_f32(float* out, long out_stride, const float* slabs, long n, int n_slabs,
                                            long slab_stride, int nbatch, float beta, gs_stream_t stream) {
   if (n <= 0 || nbatch <= 0) return GS_OK;

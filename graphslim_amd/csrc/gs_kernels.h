@@ -210,16 +210,67 @@ struct gs_pdesc {
   int total_cols;
 };
 
+typedef float gs_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
 __global__ __launch_bounds__(256) void gs_dist_stats_kernel(const float* __restrict__ gw_real, const float* __restrict__ gw_syn,
                                                             long P_total, gs_pdesc pd, float* __restrict__ stats /*[C][total_cols][3]*/) {
   const int p = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
   const int rows = pd.rows[p], cols = pd.cols[p];
   const float* R = gw_real + (long)c * P_total + pd.off[p];
   const float* S = gw_syn + (long)c * P_total + pd.off[p];
+  __shared__ float sh[3][256 * 4];
+  if ((cols & 3) == 0 && cols >= 16) {
+    // wide parameter (W1: d x h, Wl: h x C): a thread owns 4 adjacent columns (16-byte loads) and every (256 / (cols / 4))-th
+    // row; the row groups are summed through LDS in a fixed order.  (The first form walked all `rows` with one 4-byte load per
+    // step and thread: 37-51 us on the critical path right after the stream join.)
+    const int Q = cols >> 2;
+    int CB = 1;
+    while (CB < Q && CB < 256) CB <<= 1;
+    const int tx = tid % CB, ty = tid / CB, nty = 256 / CB;
+    for (int q0 = 0; q0 < Q; q0 += CB) {
+      const int q = q0 + tx;
+      float dot[4] = {0.f, 0.f, 0.f, 0.f}, nr2[4] = {0.f, 0.f, 0.f, 0.f}, ns2[4] = {0.f, 0.f, 0.f, 0.f};
+      if (q < Q)
+#pragma unroll 4
+        for (int i = ty; i < rows; i += nty) {
+          const gs_f32x4u r = *reinterpret_cast<const gs_f32x4u*>(R + (long)i * cols + 4 * q);
+          const gs_f32x4u s_ = *reinterpret_cast<const gs_f32x4u*>(S + (long)i * cols + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dot[e] = fmaf(r[e], s_[e], dot[e]);
+            nr2[e] = fmaf(r[e], r[e], nr2[e]);
+            ns2[e] = fmaf(s_[e], s_[e], ns2[e]);
+          }
+        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sh[0][tid * 4 + e] = dot[e];
+        sh[1][tid * 4 + e] = nr2[e];
+        sh[2][tid * 4 + e] = ns2[e];
+      }
+      __syncthreads();
+      if (ty == 0 && q < Q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = dot[e], b = nr2[e], d_ = ns2[e];
+          for (int g = 1; g < nty; ++g) {
+            a += sh[0][(g * CB + tx) * 4 + e];
+            b += sh[1][(g * CB + tx) * 4 + e];
+            d_ += sh[2][(g * CB + tx) * 4 + e];
+          }
+          float* st = stats + ((long)c * pd.total_cols + pd.col_off[p] + 4 * q + e) * 3;
+          st[0] = a;
+          st[1] = b;
+          st[2] = d_;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
   int CB = 1;
   while (CB < cols && CB < 256) CB <<= 1;
   const int tx = tid % CB, ty = tid / CB, nty = 256 / CB;
-  __shared__ float sh[3][256];
   for (int k0 = 0; k0 < cols; k0 += CB) {
     const int k = k0 + tx;
     float dot = 0.f, nr2 = 0.f, ns2 = 0.f;
