@@ -99,39 +99,55 @@ def run_steps(p, eng, k, cycle_len):
         eng.outer_step(0 if i * 5 < cycle_len else 10)
 
 
-def roofline(eng, insitu_ms, insitu_launches, reps=20):
-    """Dominant kernel: the PGE layer-2 contraction E2[n'^2, Ph] = A1[n'^2, Ph] W1^T on the fp32 matrix cores
-    (gs_gemm_f32_kernel<128,128,64,64,K,K>); algorithmic FLOPs = 2 n'^2 Ph^2 per launch.
-    `achieved` uses the IN-SITU duration: HIP events recorded by the engine on the launch stream around every launch of
-    that product inside the timed outer iterations (training forward — which shares the chip with the real-side stream —
-    and inference pass).  `isolated_launch_us` is the same kernel at the same shape launched back to back on an idle chip."""
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "pmc_panel_summary.json")
+
+
+def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20):
+    """Dominant kernel: the PGE layer-2 contraction E2[n'^2, Ph] = A1[n'^2, Ph] W1^T on the matrix cores — the row-panel
+    kernel gs_panel_gemm_kernel<0, 8> in the default exact-fp32 mode (csrc/gs_panel.hip); algorithmic FLOPs = 2 n'^2 Ph^2
+    per launch.  `achieved` uses the IN-SITU duration: HIP events recorded by the engine on the launch stream around every
+    launch of that product inside the timed outer iterations (training forward — which shares the chip with the real-side
+    stream — and inference pass).  `isolated_launch_us` is the same kernel at the same shape launched back to back on an
+    idle chip.  `traffic` cannot be sampled inside bench.py (PMC needs rocprofv3): it is read from the committed counter
+    summary of the same kernel at the same shape (`traffic_source`), FETCH_SIZE already doubled as the gfx950 calibration
+    requires (profiles/r02/copy_calib: every read pattern reports exactly half its bytes)."""
     from graphslim_amd.engine import gemm
     n, ph = eng.shapes.n_syn, eng.shapes.pge_hidden
     rows = n * n
     a = torch.randn(rows, ph, device=eng.dev)
     w = torch.randn(ph, ph, device=eng.dev)
     out = torch.empty(rows, ph, device=eng.dev)
+    scratch = torch.empty(ph * ph, device=eng.dev)
+    prec = {"f32": 0, "bf16x3": 1, "bf16": 2}[mode]
     for _ in range(3):
-        gemm(a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph)
+        gemm(a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph, prec=prec, scratch=scratch)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(reps):
-        gemm(a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph)
+        gemm(a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph, prec=prec, scratch=scratch)
     ev1.record()
     ev1.synchronize()
     iso = ev0.elapsed_time(ev1) / 1e3 / reps
     sec = insitu_ms / 1e3 / insitu_launches if insitu_launches else iso
     flops = 2.0 * rows * ph * ph
-    peak = 157.3      # TFLOP/s, fp32 matrix (MI355X_MICROARCH.md chip table)
-    ach = flops / sec / 1e12
-    # HBM traffic of this kernel at this shape from rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of
-    # tools/probe_gemm.py, profiles/r01/pmc_v4_*): 208 560 KiB fetched + 206 140 KiB written per launch = the algorithmic
-    # A-read + C-write (the 64-B row-segment loads of this kernel count 1:1 — the A operand is exactly 206 116 KiB — so
-    # no gfx950 x2 correction applies to this access pattern).  PMC cannot be sampled inside bench.py.
-    traffic = (208560 + 206140) * 1024 if (n, ph) == (454, 256) else None
-    return {"bound": "mfma", "kernel": "gs_gemm_f32_kernel<128,128,64,64,K,K> (PGE layer 2, fp32 MFMA 32x32x2)",
-            "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-            "avg_launch_us": round(sec * 1e6, 2), "launches_timed": int(insitu_launches), "flops_per_launch": flops,
+    traffic, src = None, None
+    kname = {"f32": "gs_panel_gemm_kernel<0, 8>", "bf16x3": "gs_panel_gemm_kernel<1, 8>", "bf16": "gs_panel_gemm_kernel<2, 8>"}[mode]
+    if (n, ph) == (454, 256) and os.path.exists(PMC_SUMMARY):
+        rec = json.load(open(PMC_SUMMARY)).get(kname)
+        if rec:
+            traffic, src = int(rec["hbm_bytes_per_launch"]), "profiles/r02/pmc_panel_summary.json"
+    if mode == "f32":
+        peak, bound, unit = 157.3, "mfma", "TFLOP/s"     # fp32 matrix peak (MI355X_MICROARCH.md chip table)
+        ach = flops / sec / 1e12
+    else:
+        # the split / bf16 modes are HBM-bound (3 or 1 bf16 MFMAs per product = 3/16 or 1/16 of the fp32 pipe time):
+        # algorithmic bytes = A read once + C written once (+ the 256 KB weight block)
+        peak, bound, unit = 8000.0, "hbm", "GB/s"
+        ach = (2.0 * rows * ph * 4 + ph * ph * 4) / sec / 1e9
+    return {"bound": bound, "kernel": f"{kname} (PGE layer 2: E2 = A1 W1^T + b1 with fused BN-2 column sums; {mode} operands)",
+            "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
+            "traffic_source": src, "avg_launch_us": round(sec * 1e6, 2), "launches_timed": int(insitu_launches),
+            "flops_per_launch": flops, "algorithmic_bytes_per_launch": 2.0 * rows * ph * 4 + ph * ph * 4,
             "isolated_launch_us": round(iso * 1e6, 2)}
 
 
@@ -240,6 +256,7 @@ def main():
     ap.add_argument("--workload", default="ogbn-arxiv", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink N for smoke runs (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of extra back-to-back iterations for the `sustained` field (0 = off)")
     ap.add_argument("--operand-mode", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="operand precision of the row-panel products for the HEADLINE run (default: exact fp32)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
@@ -284,12 +301,21 @@ def main():
     barrier()
     base = getattr(eng, "eng", eng)      # the engine behind a ShardedGCond
     base.probe(True)                     # event pairs around the dominant kernel's launches inside the timed steps
+    if world > 1:
+        eng.col.timing = True            # event pairs around every all-reduce: per-buffer communication time
     t0 = time.perf_counter()
     run_steps(p, eng, args.steps, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     probe_ms, probe_k = base.probe_read()
     base.probe(False)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        eng.col.timing = False
+        comm = {"n_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "per_buffer": eng.col.timing_report()}
+        comm["exchanges_per_step"] = round(sum(v["calls"] for v in comm["per_buffer"].values()) / max(args.steps, 1), 2)
+        comm["comm_us_per_step"] = round(sum(v["calls"] * v["avg_us"] for v in comm["per_buffer"].values()) / max(args.steps, 1), 1)
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -307,12 +333,45 @@ def main():
     dt_reuse = time.perf_counter() - t1
     eng.set_forward_reuse(False)
     eng.read_loss()
+    # opt-in operand precisions of the row-panel / edge products (VERDICT r01 row *J): same steps, same cadence, tagged dtype.
+    # NOT the headline: `value` is measured in args.operand_mode (default exact fp32 = the reference's precision).
+    modes = {}
+    for m in ("bf16x3", "bf16"):
+        if m == args.operand_mode or world > 1:
+            continue
+        base.set_operand_mode(m)
+        run_steps(p, eng, args.warmup, max(args.warmup, 1))
+        barrier()
+        tm = time.perf_counter()
+        run_steps(p, eng, args.steps, args.steps)
+        barrier()
+        dm = time.perf_counter() - tm
+        ls, kk = eng.read_loss()
+        modes[m] = {"value": round(args.steps / dm, 3), "unit": "outer-iters/s", "ms_per_step": round(1e3 * dm / args.steps, 3),
+                    "dtype": {"bf16x3": "split-bf16 x3 operands (hi*hi + hi*lo + lo*hi), f32 accumulate",
+                              "bf16": "bf16 operands, f32 accumulate"}[m],
+                    "applies_to": "PGE layer-2 forward, its backward dY1, H1 = relu(X W1 + b1), real-side edge product",
+                    "mean_match_loss": ls / max(kk, 1) / p['data'].nclass,
+                    "parity": "tests/test_gpu_operand_modes.py (oracle, full size)"}
+    base.set_operand_mode(args.operand_mode)
+    # sustained figure: the timed region of the driver's --steps 20 is ~50 ms, shorter than an SMI sampling period
+    sustained = None
+    if world == 1 and args.sustain_s > 0:
+        n_sus = max(int(args.sustain_s * args.steps / dt), args.steps)
+        barrier()
+        ts = time.perf_counter()
+        run_steps(p, eng, n_sus, n_sus)
+        barrier()
+        sustained = {"iters": n_sus, "seconds": round(time.perf_counter() - ts, 3),
+                     "value": round(n_sus / (time.perf_counter() - ts), 3), "unit": "outer-iters/s"}
+        eng.read_loss()
     if rank == 0:
         units = args.steps      # strong scaling: every rank works on the SAME iterations (classes / pair rows are sharded)
         out = {
             "metric": "GCond outer-loop iters/sec", "value": round(units / dt, 3), "unit": "outer-iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.operand_mode == "f32" else f"f32 with {args.operand_mode} MFMA operands", "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped synthetic graph, GCond r={p['rate']}, SGC T={p['T']} h={p['hidden']}, "
                                    f"PGE h={p['ph']}, n'={len(p['labels_syn'])}, seeds/class 256, fan-out {list(p['fan'])}, "
                                    f"inner_loop {p['inner']}, GPU sampler", "N": int(p['data'].bench_n),
@@ -320,7 +379,13 @@ def main():
                        "parallelism": getattr(eng, "parallelism", "single"),
                        "iters_per_sec_with_forward_reuse": round(args.steps / dt_reuse, 3)},
         }
-        out["roofline"] = roofline(eng, probe_ms, probe_k)
+        out["roofline"] = roofline(eng, probe_ms, probe_k, args.operand_mode)
+        if comm:
+            out["comm"] = comm
+        if modes:
+            out["operand_modes"] = modes
+        if sustained:
+            out["sustained"] = sustained
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(p, eng)
         print(json.dumps(out))

@@ -47,10 +47,32 @@ class Collective:
 
     def __init__(self, dist=None, group=None):
         self.dist, self.group = dist, group
+        self.timing = False          # bench.py --gpus N: event pairs around every exchange (per-buffer communication time)
+        self._events = []
 
-    def allreduce(self, t):
+    def allreduce(self, t, name=None):
         if self.dist is not None and self.dist.get_world_size(self.group) > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.timing and t.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+                e1.record()
+                self._events.append((name or "?", t.numel() * t.element_size(), e0, e1))
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def timing_report(self):
+        """{buffer: {"calls", "bytes", "avg_us"}} of the exchanges recorded since timing was switched on (synchronises)."""
+        out = {}
+        for name, nbytes, e0, e1 in self._events:
+            e1.synchronize()
+            r = out.setdefault(name, {"calls": 0, "bytes": nbytes, "total_us": 0.0})
+            r["calls"] += 1
+            r["total_us"] += e0.elapsed_time(e1) * 1e3
+        for r in out.values():
+            r["avg_us"] = round(r.pop("total_us") / max(r["calls"], 1), 2)
+        self._events = []
+        return out
 
 
 class ShardedGCond:
@@ -98,7 +120,7 @@ class ShardedGCond:
         for fn, buf in self.phases(epoch):
             fn()
             if buf is not None:
-                self.col.allreduce(self.v[buf])
+                self.col.allreduce(self.v[buf], buf)
 
 
 class RowShard:
