@@ -6,6 +6,9 @@ def create_reducer(name, setting, data, args, **kwargs):
     if key == "random":
         from ..sparsification.random import Random
         return Random(setting, data, args, **kwargs)
+    if key in ("kcenter", "herding"):
+        from ..sparsification.model_based import Herding, KCenter
+        return (KCenter if key == "kcenter" else Herding)(setting, data, args, **kwargs)
     if key in ("gcond", "doscond", "gcondx", "doscondx"):
         from .. import condensation as cd
         cls = {"gcond": cd.GCond, "doscond": cd.DosCond, "gcondx": cd.GCondX, "doscondx": cd.DosCondX}[key]

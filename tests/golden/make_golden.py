@@ -715,7 +715,33 @@ def g13():
     save("g13_siblings", **out)
 
 
+# ---------------------------------------------------------------- G14 k-center / herding -------
+
+
+def g14():
+    """KCenter.select / Herding.select of the reference (sparsification/kcenter.py:8-24, herding.py:8-26) on fixed embeddings,
+    including exact ties (duplicated rows) so that the first-occurrence tie-breaking of argsort / argmax / argmin is pinned."""
+    from graphslim.sparsification.kcenter import KCenter
+    from graphslim.sparsification.herding import Herding
+    rng = np.random.default_rng(7)
+    n, C = 400, 5
+    y = rng.integers(0, C, n)
+    idx_train = np.sort(rng.permutation(n)[:260])
+    labels_train = y[idx_train]
+    emb = rng.normal(size=(n, C)).astype(np.float32)
+    emb[idx_train[5]] = emb[idx_train[3]]                      # exact duplicates -> ties
+    emb[idx_train[40]] = emb[idx_train[41]]
+    ncd = {2: 3, 0: 7, 4: 1, 1: 12, 3: 20}                      # insertion order = iteration order
+    out = dict(emb=emb, idx_train=idx_train, labels_train=labels_train, ncd_keys=np.array(list(ncd.keys())),
+               ncd_vals=np.array(list(ncd.values())))
+    for name, cls in (("kcenter", KCenter), ("herding", Herding)):
+        agent = object.__new__(cls)
+        agent.num_class_dict, agent.idx_train, agent.labels_train = ncd, idx_train, labels_train
+        out[name] = np.asarray(agent.select(torch.from_numpy(emb)))
+    save("g14_coreset_select", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()

@@ -233,3 +233,14 @@ def test_synthetic_fallback_is_loud_and_marked(monkeypatch, capsys):
     raw = types.SimpleNamespace(y=torch.arange(300) % 3, num_nodes=300)
     dft = splits(raw, "fixed")
     assert int(dft.train_mask.sum()) == 240 and int(dft.val_mask.sum()) == 30 and int(dft.test_mask.sum()) == 30
+
+
+def test_g14_kcenter_and_herding_selection_match_the_reference(golden_dir):
+    """sparsification/kcenter.py:8-24, herding.py:8-26 (incl. first-occurrence tie-breaking on duplicated embeddings):
+    bit-exact node ids against the reference's own select() (golden G14)."""
+    from helpers import load_golden
+    from graphslim_amd.sparsification.model_based import herding_select, kcenter_select
+    g = load_golden(golden_dir, "g14_coreset_select")
+    ncd = {int(k): int(v) for k, v in zip(g["ncd_keys"], g["ncd_vals"])}
+    assert np.array_equal(kcenter_select(g["emb"], g["idx_train"], g["labels_train"], ncd), g["kcenter"])
+    assert np.array_equal(herding_select(g["emb"], g["idx_train"], g["labels_train"], ncd), g["herding"])
