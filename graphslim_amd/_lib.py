@@ -53,7 +53,7 @@ _lib = None
 
 # every symbol include/gslim.h declares (tests/test_abi.py checks the list against the header)
 SYMBOLS = [
-    "gs_version", "gs_last_error", "gs_gemm_f32", "gs_gemm_group_f32", "gs_gemm_tiles_m", "gs_gemm_route", "gs_gemm_set_tuning", "gs_gemm_set_small", "gs_gemm_set_panel", "gs_gemm_set_edge_kernel", "gs_gemm_set_panel_dephase", "gs_reduce_slabs_f32", "gs_reduce_slabs_batched_f32",
+    "gs_version", "gs_last_error", "gs_gemm_f32", "gs_gemm_group_f32", "gs_gemm_tiles_m", "gs_gemm_route", "gs_gemm_set_tuning", "gs_gemm_set_small", "gs_gemm_set_panel", "gs_gemm_set_edge_kernel", "gs_gemm_set_panel_narrow_tail", "gs_reduce_slabs_f32", "gs_reduce_slabs_batched_f32",
     "gs_spmm_csr_f32", "gs_gather_rows_f32", "gs_sample_blocks", "gs_dense_gcn_norm_fwd", "gs_dense_gcn_norm_bwd",
     "gs_adam_step_f32", "gs_gcond_workspace_bytes", "gs_gcond_create", "gs_gcond_destroy", "gs_gcond_new_epoch",
     "gs_gcond_set_blocks", "gs_gcond_outer_step", "gs_gcond_outer_step_ex", "gs_gcond_set_identity_structure", "gs_gcond_read_loss", "gs_gcond_stage_sample",
@@ -88,7 +88,7 @@ def lib():
     L.gs_gemm_set_small.argtypes = [l, C.c_double]
     L.gs_gemm_set_panel.argtypes = [i]
     L.gs_gemm_set_edge_kernel.argtypes = [i]
-    L.gs_gemm_set_panel_dephase.argtypes = [i]
+    L.gs_gemm_set_panel_narrow_tail.argtypes = [i]
     L.gs_reduce_slabs_f32.argtypes = [vp, vp, l, i, l, f, vp]
     L.gs_reduce_slabs_batched_f32.argtypes = [vp, l, vp, l, i, l, i, f, vp]
     L.gs_spmm_csr_f32.argtypes = [vp, vp, vp, i, vp, l, i, vp, l, vp]

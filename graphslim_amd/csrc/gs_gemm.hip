@@ -547,6 +547,7 @@ bool gs_edge_eligible(const gs_gemm_desc& p);             // gs_edge.hip
 int gs_edge_launch(const gs_gemm_desc& d, hipStream_t s);
 bool gs_panel_eligible(const gs_gemm_desc& p);            // gs_panel.hip
 int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s);
+int gs_panel_tiles(int M);
 
 static long g_small_tiles = 8192;      // route to the small kernel when the 32x32 tile count is at most this ...
 static double g_small_gflop = 1.5;     // ... and the product is at most this many GFLOP
@@ -724,7 +725,7 @@ extern "C" int gs_gemm_route(const gs_gemm_desc* d) {
 extern "C" int gs_gemm_tiles_m(const gs_gemm_desc* d) {
   if (!d) return 0;
   const int nb = (d->nb1 < 1 ? 1 : d->nb1) * (d->nb2 < 1 ? 1 : d->nb2);
-  if (gs_panel_eligible(*d)) return gs_cdiv(d->M, 128);
+  if (gs_panel_eligible(*d)) return gs_panel_tiles(d->M);
   static const int bm[4] = {128, 32, 64, 128};
   return gs_cdiv(d->M, bm[pick_tile(*d, nb)]);
 }

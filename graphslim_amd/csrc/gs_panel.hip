@@ -41,27 +41,27 @@ struct gs_panel_args {
   int relu;
   const float* mask; long ldmask;
   float* colstat;                    // [tiles_m][2][256] or null
-  int dephase;                       // start-up delay (units of s_sleep 127 = 8 128 cycles) of workgroups 256..511, see the kernel
+  int n_full;                        // workgroups [0, n_full) run 128-row tiles, the rest 32-row tiles (the last partial round)
   int krep, triage;                  // measurement hooks (gs_panel_debug): K loop repeated krep times; bit 0: no stores;
   unsigned long long* trace;         // bit 1: per-workgroup [hw_id, xcc_id, t_start, t_loop_end, t_end] (s_memrealtime, 10 ns)
 };
 
-// Epilogue of one wave: 32 rows x 32 NT columns from the accumulators.  C/D layout of a 32x32 tile: col = lane & 31,
+// Epilogue of one wave: its 32 rows x 32 NTW columns from the accumulators.  C/D layout of a 32x32 tile: col = lane & 31,
 // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
 // No load may sit between the stores of two tiles: vmcnt retires in order, so waiting for such a load waits for every store
 // issued before it — a full write round trip per tile (17-37 us of the 70 us the first build of this kernel spent outside its
 // K loop, tools/trace_panel.py).  So the bias row is parked in LDS before the K loop (LDS reads count on lgkmcnt, not vmcnt) and
 // the code is branch-free per (HAS_MASK, FULL) instantiation.
-template <int NT, bool HAS_MASK, bool FULL>
-__device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32x16 (&acc)[NT], const float* sbias, int rbase,
-                                               int li, float (&cs1)[NT], float (&cs2)[NT]) {
+template <int NTW, bool HAS_MASK, bool FULL>
+__device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32x16 (&acc)[NTW], const float* sbias, int rbase,
+                                               int col0, float (&cs1)[NTW], float (&cs2)[NTW]) {
   const float floor_ = p.relu ? 0.f : -__builtin_inff();
   // (mask variant: the 16 mask values of a tile are requested right before use — a two-tile ping-pong needs 32 more
   // registers next to the 128 accumulators and spilled; its in-order wait on the previous tile's stores is the known cost
   // of this variant)
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = 32 * j + li;
+  for (int j = 0; j < NTW; ++j) {
+    const int col = col0 + 32 * j;
     float mk[16];
     if (HAS_MASK) {
 #pragma unroll
@@ -92,18 +92,20 @@ __device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32
   }
 }
 
-template <int MODE, int NT>     // NT = output columns / 32: 8 (N = 256) or 4 (N = 128, the Planetoid PGE width)
-__global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) {
-  constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;   // bytes of one K block of B in LDS: N rows x 128 B
-  // (ONE __shared__ object: a second one beside a direct-to-LDS staging array can make hipcc drain vmcnt before every
-  // ds_read, cdna_hip_programming.md section 5 "three .s-level traps" (a)) — the bias row lives behind the two B stages
-  __shared__ __attribute__((aligned(16))) char smem[2 * PN_STAGE + PN_N * 4];
+// One tile.  WN = 1: 128 rows, wave w owns rows [32 w, 32 w + 32) x all N columns (NT MFMA tiles, the bulk of the launch).
+//            WN = 4: 32 rows, wave w owns all 32 rows x the N / 4 columns [32 NT w / 4, ...) — the LAST partial round of a
+// launch runs in these: 206 116 rows are 1 611 tiles of 128 rows on 512 workgroup slots = 3.15 rounds, and the 75 tiles of the
+// fourth round kept 75 CUs busy for a whole solo tile (43 us of 258) while 181 CUs idled; as 300 tiles of a quarter of the
+// work they take one short round on every CU.  Same arithmetic per output element either way (same k order).
+template <int MODE, int NT, int WN>
+__device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, int m0, int stat_row) {
+  constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128, NTW = NT / WN, ROWS = 128 / WN;
   float* sbias = reinterpret_cast<float*>(smem + 2 * PN_STAGE);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * PN_BM;
-  const int row = m0 + wave * 32 + li;
+  const int row = m0 + (WN == 1 ? wave * 32 : 0) + li;
+  const int j0 = WN == 1 ? 0 : wave * NTW;            // first N tile of this wave
   const float* __restrict__ arow = p.A + (long)min(row, p.M - 1) * p.lda + 16 * h;
   const char* __restrict__ Bb = (const char*)p.B;
   const int nkb = p.K >> 5;
@@ -126,19 +128,12 @@ __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) 
     }
   };
 
-  // Two workgroups share a CU (2 waves per SIMD).  Started together they stay in lock step: both in their MFMA phase, then
-  // both in their prologue / epilogue with the matrix pipe idle.  Holding back the SECOND resident workgroup of each CU (ids
-  // 256..511 under the observed round-robin placement; only speed depends on that guess) by about half a solo tile lets the
-  // first one run alone at the full pipe rate meanwhile — nothing is lost — and from then on one workgroup's loads and stores
-  // overlap the other's MFMAs for the rest of the launch, because later workgroups start whenever a slot frees.
   unsigned long long t_start = 0, t_loop = 0;
   if (p.triage & 2) t_start = __builtin_amdgcn_s_memrealtime();
-  if (p.dephase > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-    for (int i = 0; i < p.dephase; ++i) __builtin_amdgcn_s_sleep(127);
 
-  f32x16 acc[NT];
+  f32x16 acc[NTW];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int j = 0; j < NTW; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
@@ -160,10 +155,10 @@ __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) 
       stage_b((kb + 1) % nkb, (kk + 1) & 1);
       load_a((kb + 1) % nkb, a_nxt);
     }
-    const char* __restrict__ bs = smem + (kk & 1) * PN_STAGE + li * 128;
+    const char* __restrict__ bs = smem + (kk & 1) * PN_STAGE + li * 128 + j0 * 4096;
     if constexpr (MODE == 0) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
+      for (int j = 0; j < NTW; ++j) {
         f32x4 b[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4*>(bs + j * 4096 + (((4 * h + q) ^ sw) << 4));
@@ -183,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) 
           if constexpr (MODE == 1) al[u][e] = (__bf16)(x - (float)hb);
         }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
+      for (int j = 0; j < NTW; ++j) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bs + j * 4096 + (((2 * h + u) ^ sw) << 4));
@@ -201,36 +196,38 @@ __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) 
   }
 
   if (p.triage & 2) t_loop = __builtin_amdgcn_s_memrealtime();
-  // epilogue: straight-line code per (mask?, interior panel?) combination — see panel_epilogue
+  // epilogue: straight-line code per (mask?, interior tile?) combination — see panel_epilogue
   const bool has_stat = p.colstat != nullptr;
-  const int rbase = m0 + wave * 32 + 4 * h;
-  const bool full = m0 + PN_BM <= p.M;
-  float cs1[NT], cs2[NT];
+  const int rbase = m0 + (WN == 1 ? wave * 32 : 0) + 4 * h;
+  const int col0 = 32 * j0 + li;
+  const bool full = m0 + ROWS <= p.M;
+  float cs1[NTW], cs2[NTW];
   if (p.mask) {
-    if (full) panel_epilogue<NT, true, true>(p, acc, sbias, rbase, li, cs1, cs2);
-    else panel_epilogue<NT, true, false>(p, acc, sbias, rbase, li, cs1, cs2);
+    if (full) panel_epilogue<NTW, true, true>(p, acc, sbias, rbase, col0, cs1, cs2);
+    else panel_epilogue<NTW, true, false>(p, acc, sbias, rbase, col0, cs1, cs2);
   } else {
-    if (full) panel_epilogue<NT, false, true>(p, acc, sbias, rbase, li, cs1, cs2);
-    else panel_epilogue<NT, false, false>(p, acc, sbias, rbase, li, cs1, cs2);
+    if (full) panel_epilogue<NTW, false, true>(p, acc, sbias, rbase, col0, cs1, cs2);
+    else panel_epilogue<NTW, false, false>(p, acc, sbias, rbase, col0, cs1, cs2);
   }
   if (has_stat) {
-    // per-panel column sums / sums of squares of the written rows: colstat[(panel * 2 + q) * N + col]
+    // per-tile column sums / sums of squares of the written rows: colstat[(stat_row * 2 + q) * N + col]
     __syncthreads();                               // the B stages are dead: reuse them as scratch
-    float* red = reinterpret_cast<float*>(smem);   // [2][4 waves][N]
+    float* red = reinterpret_cast<float*>(smem);   // [2][WN == 1 ? 4 waves : 1][N]
+    constexpr int SL = WN == 1 ? 4 : 1;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
+    for (int j = 0; j < NTW; ++j) {
       const float a = cs1[j] + __shfl_xor(cs1[j], 32, 64), b = cs2[j] + __shfl_xor(cs2[j], 32, 64);
       if (h == 0) {
-        red[(0 * 4 + wave) * PN_N + 32 * j + li] = a;
-        red[(1 * 4 + wave) * PN_N + 32 * j + li] = b;
+        red[(0 * SL + (WN == 1 ? wave : 0)) * PN_N + col0 + 32 * j] = a;
+        red[(1 * SL + (WN == 1 ? wave : 0)) * PN_N + col0 + 32 * j] = b;
       }
     }
     __syncthreads();
     for (int c = tid; c < 2 * PN_N; c += 256) {
       const int q = c / PN_N, cc = c % PN_N;
-      const float t = ((red[(q * 4 + 0) * PN_N + cc] + red[(q * 4 + 1) * PN_N + cc]) + red[(q * 4 + 2) * PN_N + cc]) +
-                      red[(q * 4 + 3) * PN_N + cc];
-      p.colstat[((long)blockIdx.x * 2 + q) * PN_N + cc] = t;
+      float t = red[(q * SL + 0) * PN_N + cc];
+      if (WN == 1) t = ((t + red[(q * SL + 1) * PN_N + cc]) + red[(q * SL + 2) * PN_N + cc]) + red[(q * SL + 3) * PN_N + cc];
+      p.colstat[((long)stat_row * 2 + q) * PN_N + cc] = t;
     }
   }
   if ((p.triage & 2) && p.trace && tid == 0) {
@@ -240,6 +237,17 @@ __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) 
     o[1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));     // HW_REG_XCC_ID
     o[2] = t_start; o[3] = t_loop; o[4] = __builtin_amdgcn_s_memrealtime();
   }
+}
+
+template <int MODE, int NT>     // NT = output columns / 32: 8 (N = 256) or 4 (N = 128, the Planetoid PGE width)
+__global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) {
+  constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;   // bytes of one K block of B in LDS: N rows x 128 B
+  // (ONE __shared__ object: a second one beside a direct-to-LDS staging array can make hipcc drain vmcnt before every
+  // ds_read, cdna_hip_programming.md section 5 "three .s-level traps" (a)) — the bias row lives behind the two B stages
+  __shared__ __attribute__((aligned(16))) char smem[2 * PN_STAGE + PN_N * 4];
+  const int b = blockIdx.x;
+  if (b < p.n_full) panel_tile<MODE, NT, 1>(p, smem, b * PN_BM, b);
+  else panel_tile<MODE, NT, 4>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
 }
 
 // W [N][ldb] fp32 -> packed [N][K/32][hi 32 | lo 32] bf16 (lo = bf16(w - hi); all zeros are kept exact)
@@ -262,12 +270,6 @@ extern "C" int gs_panel_debug(int krep, int triage) {      // measurement hook (
   return GS_OK;
 }
 static int g_panel_enabled = 1;
-static int g_panel_dephase = -1;      // -1: by mode and K (half a solo tile); >= 0: that many s_sleep(127)
-
-extern "C" int gs_gemm_set_panel_dephase(int n_sleeps) {
-  g_panel_dephase = n_sleeps;
-  return GS_OK;
-}
 
 extern "C" int gs_gemm_set_panel(int enable) {
   g_panel_enabled = enable != 0;
@@ -288,9 +290,40 @@ bool gs_panel_eligible(const gs_gemm_desc& p) {
   return true;
 }
 
+static int g_panel_slots = 0;       // resident workgroups per launch: 2 per CU (registers: 2 waves / SIMD; LDS: 2 x 65 KB)
+static int g_panel_narrow = 1;      // finish the last partial round in 32-row tiles (0: 128-row tiles throughout)
+
+extern "C" int gs_gemm_set_panel_narrow_tail(int on) {
+  g_panel_narrow = on != 0;
+  return GS_OK;
+}
+
+// 128-row tiles for every FULL round of the chip, 32-row tiles for what is left
+static void panel_split(int M, int* n_full, int* n_narrow) {
+  if (g_panel_slots == 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    g_panel_slots = 2 * (cus > 0 ? cus : 256);
+  }
+  const int tiles = gs_cdiv(M, PN_BM);
+  int nf = g_panel_narrow ? (tiles / g_panel_slots) * g_panel_slots : tiles;
+  if ((long)nf * PN_BM > M) nf = M / PN_BM;
+  *n_full = nf;
+  *n_narrow = gs_cdiv((long)M - (long)nf * PN_BM, 32);
+}
+
+int gs_panel_tiles(int M) {
+  int nf, nn;
+  panel_split(M, &nf, &nn);
+  return nf + nn;
+}
+
 template <int NT>
 static void panel_dispatch(const gs_gemm_desc& d, gs_panel_args& a, hipStream_t s) {
-  const dim3 grid(gs_cdiv(d.M, PN_BM)), block(256);
+  int nf, nn;
+  panel_split(d.M, &nf, &nn);
+  a.n_full = nf;
+  const dim3 grid(nf + nn), block(256);
   if (d.prec == 0) {
     a.B = d.B; a.ldb_bytes = d.sBn * 4;
     hipLaunchKernelGGL((gs_panel_gemm_kernel<0, NT>), grid, block, 0, s, a);
@@ -311,13 +344,6 @@ int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s) {
   a.bias = d.bias; a.relu = d.relu; a.mask = d.mask; a.ldmask = d.ldmask; a.colstat = d.colstat;
   a.krep = g_panel_krep; a.triage = g_panel_triage;
   a.trace = (g_panel_triage & 2) ? (unsigned long long*)d.scratch : nullptr;   // (trace runs use prec = 0: scratch is free)
-  {
-    // half of a solo tile's MFMA time: K/32 blocks x (N/32 tiles x 16 MFMAs x 64 cycles | x 6 MFMAs x 32 cycles) / 2
-    const long blk = (d.prec == 0) ? (long)(d.N / 32) * 16 * 64 : (long)(d.N / 32) * 6 * 32;
-    const long half = (long)(d.K / 32) * blk / 2;
-    a.dephase = g_panel_dephase >= 0 ? g_panel_dephase : (int)((half + 4064) / 8128);
-    if (gs_cdiv(d.M, PN_BM) <= 256) a.dephase = 0;
-  }
   if (d.N == 256) panel_dispatch<8>(d, a, s);
   else panel_dispatch<4>(d, a, s);
   GS_LAUNCH_CHECK();

@@ -91,9 +91,8 @@ int gs_gemm_set_small(long max_tiles, double max_gflop);
 int gs_gemm_set_panel(int enable);
 /* route the real-side edge product (generated B, gathered K, N == 256) to its dedicated kernel (default 1); 0 = 128x128 tile */
 int gs_gemm_set_edge_kernel(int enable);
-/* start-up delay of the second resident workgroup of each CU in the row-panel kernel, in units of s_sleep(127) (8 128
-   cycles); -1 = chosen from the operand mode and K (half a solo tile; the default), 0 = off.  A measurement knob. */
-int gs_gemm_set_panel_dephase(int n_sleeps);
+/* the row-panel kernel finishes the last partial round of a launch in 32-row tiles (default 1); 0 = 128-row tiles throughout */
+int gs_gemm_set_panel_narrow_tail(int on);
 /* which kernel gs_gemm_f32 launches for this descriptor: 0 = 128x32 tile, 1 = 32x128, 2 = 64x64, 3 = 128x128, 4 = the
    one-tile-per-workgroup latency kernel, 5 = the row-panel kernel (128 rows x all 256 columns per workgroup; PGE layer 2,
    its backward and the SGC transform), 6 = the real-side edge-product kernel — test hook: parity tests assert the instantiation a shape exercises */

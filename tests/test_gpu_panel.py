@@ -69,7 +69,7 @@ def test_panel_epilogues(E, mode):
     assert err(out, ref * (mask > 0)) <= gate
     d, _k = E.gemm_desc(a, w, a, M, 256, K, (K, 1), (1, K), 256)
     tiles = _lib.lib().gs_gemm_tiles_m(C.byref(d))
-    assert tiles == -(-M // 128)
+    assert tiles == -(-M // 32)          # fewer rows than one round of the chip: the whole product runs in 32-row tiles
     stat = torch.full((tiles, 2, 256), float("nan"), device=DEV)
     out = run(E, a, w, code, bias=b.to(DEV), colstat=stat)
     got = out.double().cpu()
@@ -77,6 +77,31 @@ def test_panel_epilogues(E, mode):
     np.testing.assert_allclose(stat[:, 0].double().sum(0).cpu().numpy(), got.sum(0).numpy(), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(stat[:, 1].double().sum(0).cpu().numpy(), (got * got).sum(0).numpy(), rtol=1e-4, atol=1e-3)
     assert err(out, ref + b.double()) <= gate
+
+
+def test_panel_narrow_tail_is_bitwise_the_wide_tiles(E):
+    """The last partial round of a launch runs in 32-row tiles (4 waves side by side over the columns) instead of 128-row
+    tiles: same k order per output element, so the results and the summed column statistics are bitwise / reassociation
+    equal to the 128-row-tile launch; 206 116 rows = 3 full rounds of 512 tiles + 298 narrow tiles."""
+    from graphslim_amd import _lib
+    L = _lib.lib()
+    M, K = 206116, 256
+    torch.manual_seed(9)
+    A, W, b = torch.randn(M, K, device=DEV), torch.randn(256, K, device=DEV) / 16, torch.randn(256, device=DEV)
+    outs, stats = [], []
+    for narrow in (1, 0):
+        L.gs_gemm_set_panel_narrow_tail(narrow)
+        try:
+            d, _k = E.gemm_desc(A, W, A, M, 256, K, (K, 1), (1, K), 256)
+            tiles = L.gs_gemm_tiles_m(C.byref(d))
+            assert tiles == (3 * 512 + -(-(M - 3 * 512 * 128) // 32) if narrow else 1611)      # 1536 + 298
+            st = torch.zeros(tiles, 2, 256, device=DEV)
+            outs.append(run(E, A, W, 0, bias=b, colstat=st))
+            stats.append(st.double().sum(0))
+        finally:
+            L.gs_gemm_set_panel_narrow_tail(1)
+    assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(stats[0].cpu().numpy(), stats[1].cpu().numpy(), rtol=1e-6)
 
 
 def test_panel_f32_is_the_tile_kernel_up_to_reassociation(E):

@@ -33,17 +33,17 @@ def case(name, M, K, **kw):
     scratch = torch.empty(256 * K, device=dev)
     extra = {k: (v() if callable(v) else v) for k, v in kw.items()}
     res = {}
-    variants = [("tile128", 0, 0, 0), ("panel f32 nodelay", 1, 0, 0), ("panel f32", 1, 0, -1), ("panel f32 x2", 1, 0, 8),
-                ("panel bf16x3 nodelay", 1, 1, 0), ("panel bf16x3", 1, 1, -1), ("panel bf16", 1, 2, -1)]
+    variants = [("tile128", 0, 0, 0), ("panel f32 wide-tail", 1, 0, 0), ("panel f32", 1, 0, 1),
+                ("panel bf16x3 wide-tail", 1, 1, 0), ("panel bf16x3", 1, 1, 1), ("panel bf16", 1, 2, 1)]
     for rnd in range(3):
         for label, panel, prec, deph in variants:
             L.gs_gemm_set_panel(panel)
-            L.gs_gemm_set_panel_dephase(deph)
+            L.gs_gemm_set_panel_narrow_tail(deph)
             d, keep = gemm_desc(a, w, out, M, 256, K, (K, 1), (1, K), 256, prec=prec, scratch=scratch, **extra)
             t = timed(lambda: _lib.check(L.gs_gemm_f32(C.byref(d), _lib.stream())))
             res.setdefault(label, []).append(t)
     L.gs_gemm_set_panel(1)
-    L.gs_gemm_set_panel_dephase(-1)
+    L.gs_gemm_set_panel_narrow_tail(1)
     flops = 2.0 * M * 256 * K
     for label, ts in res.items():
         t = min(ts)

@@ -18,10 +18,10 @@ M, K = 454 * 454, 256
 a = torch.randn(M, K, device=dev)
 w = torch.randn(256, K, device=dev) / 16
 out = torch.empty(M, 256, device=dev)
-nt = -(-M // 128)
-for deph in (0, -1):
+nt = -(-M // 32)      # upper bound of the workgroup count (the tail runs 32-row tiles)
+for deph in (0, 1):
     trace = torch.zeros(nt * 5, dtype=torch.int64, device=dev)
-    L.gs_gemm_set_panel_dephase(deph)
+    L.gs_gemm_set_panel_narrow_tail(deph)
     L.gs_panel_debug(1, 2)
     d, keep = gemm_desc(a, w, out, M, 256, K, (K, 1), (1, K), 256, prec=0, scratch=trace)
     for _ in range(2):
@@ -29,14 +29,15 @@ for deph in (0, -1):
     torch.cuda.synchronize()
     L.gs_panel_debug(1, 0)
     t = trace.cpu().numpy().reshape(nt, 5)
+    t = t[t[:, 4] != 0]
     hw, xcc = t[:, 0], t[:, 1] & 0xF
     cu, sh, se = (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
     key = (xcc << 8) | (se << 5) | (sh << 4) | cu
     t0 = t[:, 2].min()
     st, lp, en = (t[:, 2] - t0) / 100.0, (t[:, 3] - t0) / 100.0, (t[:, 4] - t0) / 100.0     # us
-    print(f"--- dephase {deph}: {len(np.unique(key))} distinct CUs, kernel span {en.max():.1f} us")
+    print(f"--- narrow tail {deph}: {len(np.unique(key))} distinct CUs, kernel span {en.max():.1f} us")
     print("first 24 workgroups: id xcc se sh cu start loop_end end")
-    for b in list(range(12)) + list(range(256, 268)):
+    for b in list(range(6)) + list(range(256, 262)) + list(range(len(t) - 6, len(t))):
         print(f"  {b:5d} {xcc[b]:2d} {se[b]:2d} {sh[b]:2d} {cu[b]:3d}   {st[b]:7.1f} {lp[b]:7.1f} {en[b]:7.1f}")
     # which block ids share the CU of block 0 .. 3
     for b in range(4):
@@ -49,4 +50,4 @@ for deph in (0, -1):
     grid = np.arange(0, en.max(), 5.0)
     inloop = [(int(((st <= g) & (lp > g)).sum()), int(((lp <= g) & (en > g)).sum())) for g in grid]
     print("  t[us]: (#in K loop, #in epilogue)  " + "  ".join(f"{int(g)}:{a_}/{b_}" for g, (a_, b_) in zip(grid, inloop)))
-L.gs_gemm_set_panel_dephase(-1)
+L.gs_gemm_set_panel_narrow_tail(1)
