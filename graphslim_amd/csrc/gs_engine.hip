@@ -9,6 +9,7 @@
 #include "gs_kernels.h"
 
 extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int, long, int, float, gs_stream_t);
+extern "C" int gs_reduce_slabs_f32(float*, const float*, long, int, long, float, gs_stream_t);
 int gs_reduce_slabs_active(float*, long, const float*, long, int, long, int, const int*, int, gs_stream_t);
 
 namespace {
@@ -1213,9 +1214,25 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
         a.prec = e->operand_mode; a.scratch = e->bsplit_main;
         GS_TRY(gs_gemm_f32(&a, stream));
       }
-      hipLaunchKernelGGL(gs_pge_marginal_r_kernel, dim3(nr), dim3(256), 0, s, e->dY1, n, Ph, e->r_lo, e->colsum_r);
-      hipLaunchKernelGGL(gs_pge_marginal_c_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, nr, e->rowsum_c);
-      GS_LAUNCH_CHECK();
+      {
+        // both marginals in one pass over dY1; the partial sums live in `parts` (free here: its producers ran earlier on
+        // this stream), reduced in a fixed order
+        const int nrb = gs_cdiv(nr, GS_MARG_RR), ncb = gs_cdiv(n, GS_MARG_CC);
+        const size_t need = ((size_t)nrb * n + (size_t)ncb * nr) * Ph * sizeof(float);
+        const size_t have = (size_t)e->nblk_stats * 3 * Ph * sizeof(double);
+        if (Ph % 4 == 0 && Ph <= 1024 && need <= have) {
+          float* partU = reinterpret_cast<float*>(e->parts);
+          float* partV = partU + (size_t)nrb * n * Ph;
+          hipLaunchKernelGGL(gs_pge_marginals_fused_kernel, dim3(ncb, nrb), dim3(256), 0, s, e->dY1, n, Ph, nr, partU, partV);
+          GS_LAUNCH_CHECK();
+          GS_TRY(gs_reduce_slabs_f32(e->rowsum_c, partU, (long)n * Ph, nrb, (long)n * Ph, 0.f, stream));
+          GS_TRY(gs_reduce_slabs_f32(e->colsum_r + (long)e->r_lo * Ph, partV, (long)nr * Ph, ncb, (long)nr * Ph, 0.f, stream));
+        } else {
+          hipLaunchKernelGGL(gs_pge_marginal_r_kernel, dim3(nr), dim3(256), 0, s, e->dY1, n, Ph, e->r_lo, e->colsum_r);
+          hipLaunchKernelGGL(gs_pge_marginal_c_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, nr, e->rowsum_c);
+          GS_LAUNCH_CHECK();
+        }
+      }
     }
     return GS_OK;
   }

@@ -586,10 +586,44 @@ __global__ void gs_reduce_slabs_kernel(float* __restrict__ out, const float* __r
   out[i] = (beta != 0.f ? beta * out[i] : 0.f) + s;
 }
 
+// 16-byte form: four adjacent elements per thread, the slab loop unrolled so that 8 loads are in flight (the scalar form
+// above issued one dependent-looking 4-byte load per slab: 33 us for 40 slabs of 58 112 elements).  Same summation order.
+__global__ void gs_reduce_slabs_v4_kernel(float* __restrict__ out, const float* __restrict__ slabs, long n4, int ns,
+                                          long slab_stride4, float beta) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4* sl = reinterpret_cast<const float4*>(slabs) + i;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = 0;
+  for (; k + 8 <= ns; k += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = sl[(long)(k + u) * slab_stride4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  for (; k < ns; ++k) {
+    const float4 v = sl[(long)k * slab_stride4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float4* o = reinterpret_cast<float4*>(out) + i;
+  if (beta != 0.f) {
+    const float4 c = *o;
+    s.x += beta * c.x; s.y += beta * c.y; s.z += beta * c.z; s.w += beta * c.w;
+  }
+  *o = s;
+}
+
 extern "C" int gs_reduce_slabs_f32(float* out, const float* slabs, long n, int n_slabs, long slab_stride, float beta,
                                    gs_stream_t stream) {
   if (n <= 0) return GS_OK;
   if (!out || !slabs || n_slabs < 1) GS_FAIL(GS_ERR_ARG, "gs_reduce_slabs_f32: bad argument");
+  if ((n & 3) == 0 && (slab_stride & 3) == 0 && ((((uintptr_t)out) | ((uintptr_t)slabs)) & 15) == 0) {
+    hipLaunchKernelGGL(gs_reduce_slabs_v4_kernel, dim3(gs_cdiv(n >> 2, 256)), dim3(256), 0, (hipStream_t)stream, out, slabs, n >> 2,
+                       n_slabs, slab_stride >> 2, beta);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+  }
   hipLaunchKernelGGL(gs_reduce_slabs_kernel, dim3(gs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, slabs, n,
                      n_slabs, slab_stride, beta);
   GS_LAUNCH_CHECK();

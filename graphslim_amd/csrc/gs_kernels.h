@@ -939,6 +939,56 @@ __global__ __launch_bounds__(256) void gs_pge_marginal_c_kernel(const float* __r
     *reinterpret_cast<float4*>(rowsum_c + (long)c * Ph + q * 4) = s;
   }
 }
+// Both marginals in ONE pass over dY1 (the two kernels above read its 211 MB twice).  Block (cb, rb) owns pair rows
+// r in [16 rb, 16 rb + 16) x pair columns c in [64 cb, 64 cb + 64): a thread holds one float4 of k, walks the block's c with
+// stride G and keeps 16 running row sums; per c it writes the sum over its 16 r (partU[rb][c][k]), at the end the block
+// writes its 16 row sums over its 64 c (partV[cb][r][k]).  gs_reduce_slabs_f32 adds the partials in a fixed order.
+#define GS_MARG_RR 16
+#define GS_MARG_CC 64
+__global__ __launch_bounds__(256) void gs_pge_marginals_fused_kernel(const float* __restrict__ dY1, int n, int Ph, int nr,
+                                                                     float* __restrict__ partU /*[rb][n][Ph]*/,
+                                                                     float* __restrict__ partV /*[cb][nr][Ph]*/) {
+  const int cb = blockIdx.x, rb = blockIdx.y;
+  const int Q = Ph >> 2, G = 256 / Q;
+  const int q = threadIdx.x % Q, g = threadIdx.x / Q;
+  const int r0 = rb * GS_MARG_RR, c0 = cb * GS_MARG_CC;
+  const int c1 = min(n, c0 + GS_MARG_CC);
+  __shared__ float4 sh[256];
+  float4 accv[GS_MARG_RR];
+#pragma unroll
+  for (int u = 0; u < GS_MARG_RR; ++u) accv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g < G) {
+    for (int c = c0 + g; c < c1; c += G) {
+      float4 v[GS_MARG_RR];
+#pragma unroll
+      for (int u = 0; u < GS_MARG_RR; ++u)
+        v[u] = *reinterpret_cast<const float4*>(dY1 + ((long)min(r0 + u, nr - 1) * n + c) * Ph + q * 4);
+      float4 su = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < GS_MARG_RR; ++u)
+        if (r0 + u < nr) {
+          su.x += v[u].x; su.y += v[u].y; su.z += v[u].z; su.w += v[u].w;
+          accv[u].x += v[u].x; accv[u].y += v[u].y; accv[u].z += v[u].z; accv[u].w += v[u].w;
+        }
+      *reinterpret_cast<float4*>(partU + ((long)rb * n + c) * Ph + q * 4) = su;
+    }
+  }
+  // the G groups walked different c: add their row sums in group order
+  for (int u = 0; u < GS_MARG_RR; ++u) {
+    __syncthreads();
+    sh[threadIdx.x] = accv[u];
+    __syncthreads();
+    if (g == 0 && r0 + u < nr) {
+      float4 t = sh[q];
+      for (int w = 1; w < G; ++w) {
+        const float4 x = sh[w * Q + q];
+        t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+      }
+      *reinterpret_cast<float4*>(partV + ((long)cb * nr + r0 + u) * Ph + q * 4) = t;
+    }
+  }
+}
+
 // BN-1 backward from the marginals (see oracle/analytic.py:pge_bwd); block = 32 columns x 8 row groups
 __global__ __launch_bounds__(1024) void gs_pge_bn1_bwd_cols_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                                    const float* __restrict__ rowsum_c,

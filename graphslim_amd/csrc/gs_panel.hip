@@ -306,10 +306,10 @@ static void panel_split(int M, int* n_full, int* n_narrow) {
     g_panel_slots = 2 * (cus > 0 ? cus : 256);
   }
   const int tiles = gs_cdiv(M, PN_BM);
-  int nf = g_panel_narrow ? (tiles / g_panel_slots) * g_panel_slots : tiles;
-  if ((long)nf * PN_BM > M) nf = M / PN_BM;
+  const int nf = g_panel_narrow ? (tiles / g_panel_slots) * g_panel_slots : tiles;   // (a 128-row tile may be the ragged last one)
+  const long left = (long)M - (long)nf * PN_BM;
   *n_full = nf;
-  *n_narrow = gs_cdiv((long)M - (long)nf * PN_BM, 32);
+  *n_narrow = left > 0 ? gs_cdiv(left, 32) : 0;
 }
 
 int gs_panel_tiles(int M) {
