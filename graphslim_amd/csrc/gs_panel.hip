@@ -53,25 +53,33 @@ struct gs_panel_args {
 // K loop, tools/trace_panel.py).  So the bias row is parked in LDS before the K loop (LDS reads count on lgkmcnt, not vmcnt) and
 // the code is branch-free per (HAS_MASK, FULL) instantiation.
 template <int NTW, bool HAS_MASK, bool FULL>
-__device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32x16 (&acc)[NTW], const float* sbias, int rbase,
-                                               int col0, float (&cs1)[NTW], float (&cs2)[NTW]) {
+__device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32x16 (&acc)[NTW], const float* sbias, int m0,
+                                               int row_in_tile, int col0, float (&cs1)[NTW], float (&cs2)[NTW]) {
   const float floor_ = p.relu ? 0.f : -__builtin_inff();
+  // Addresses = a tile-uniform base (scalar registers) + a 32-bit per-lane offset + an immediate per N tile: one offset
+  // register per accumulator row instead of a 64-bit address pair per store (the pair form needed > 256 registers and
+  // spilled; a kernel that needs scratch memory also makes the runtime manage scratch per queue on the launch path).
+  float* __restrict__ Cb = p.C + (long)m0 * p.ldc;
+  const float* __restrict__ Mb = HAS_MASK ? p.mask + (long)m0 * p.ldmask : nullptr;
+  unsigned coff[16], moff[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const unsigned rt = (unsigned)(row_in_tile + (r & 3) + 8 * (r >> 2));      // row inside the tile
+    coff[r] = rt * (unsigned)p.ldc + (unsigned)col0;
+    if (HAS_MASK) moff[r] = (FULL ? rt : min(rt, (unsigned)(p.M - 1 - m0))) * (unsigned)p.ldmask + (unsigned)col0;
+  }
   // (mask variant: the 16 mask values of a tile are requested right before use — a two-tile ping-pong needs 32 more
-  // registers next to the 128 accumulators and spilled; its in-order wait on the previous tile's stores is the known cost
-  // of this variant)
+  // registers next to the 128 accumulators; its in-order wait on the previous tile's stores is the known cost of this
+  // variant)
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
-    const int col = col0 + 32 * j;
     float mk[16];
     if (HAS_MASK) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = rbase + (r & 3) + 8 * (r >> 2);
-        mk[r] = p.mask[(long)(FULL ? rr : min(rr, p.M - 1)) * p.ldmask + col];
-      }
+      for (int r = 0; r < 16; ++r) mk[r] = Mb[moff[r] + 32u * j];
     }
     float v[16];
-    const float bvj = sbias[col];
+    const float bvj = sbias[col0 + 32 * j];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       v[r] = fmaxf(acc[j][r] + bvj, floor_);
@@ -80,9 +88,8 @@ __device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int rr = rbase + (r & 3) + 8 * (r >> 2);
-      if (FULL || rr < p.M) {
-        p.C[(long)rr * p.ldc + col] = v[r];
+      if (FULL || m0 + row_in_tile + (r & 3) + 8 * (r >> 2) < p.M) {
+        Cb[coff[r] + 32u * j] = v[r];
         s1 += v[r];
         s2 = fmaf(v[r], v[r], s2);
       }
@@ -198,16 +205,16 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   if (p.triage & 2) t_loop = __builtin_amdgcn_s_memrealtime();
   // epilogue: straight-line code per (mask?, interior tile?) combination — see panel_epilogue
   const bool has_stat = p.colstat != nullptr;
-  const int rbase = m0 + (WN == 1 ? wave * 32 : 0) + 4 * h;
+  const int rit = (WN == 1 ? wave * 32 : 0) + 4 * h;      // first accumulator row of this lane inside the tile
   const int col0 = 32 * j0 + li;
   const bool full = m0 + ROWS <= p.M;
   float cs1[NTW], cs2[NTW];
   if (p.mask) {
-    if (full) panel_epilogue<NTW, true, true>(p, acc, sbias, rbase, col0, cs1, cs2);
-    else panel_epilogue<NTW, true, false>(p, acc, sbias, rbase, col0, cs1, cs2);
+    if (full) panel_epilogue<NTW, true, true>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+    else panel_epilogue<NTW, true, false>(p, acc, sbias, m0, rit, col0, cs1, cs2);
   } else {
-    if (full) panel_epilogue<NTW, false, true>(p, acc, sbias, rbase, col0, cs1, cs2);
-    else panel_epilogue<NTW, false, false>(p, acc, sbias, rbase, col0, cs1, cs2);
+    if (full) panel_epilogue<NTW, false, true>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+    else panel_epilogue<NTW, false, false>(p, acc, sbias, m0, rit, col0, cs1, cs2);
   }
   if (has_stat) {
     // per-tile column sums / sums of squares of the written rows: colstat[(stat_row * 2 + q) * N + col]
