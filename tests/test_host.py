@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import scipy.sparse as sp
 import torch
 
@@ -244,3 +245,27 @@ def test_g14_kcenter_and_herding_selection_match_the_reference(golden_dir):
     ncd = {int(k): int(v) for k, v in zip(g["ncd_keys"], g["ncd_vals"])}
     assert np.array_equal(kcenter_select(g["emb"], g["idx_train"], g["labels_train"], ncd), g["kcenter"])
     assert np.array_equal(herding_select(g["emb"], g["idx_train"], g["labels_train"], ncd), g["herding"])
+
+
+@pytest.mark.parametrize("rate,n", [("0.1", 14), ("0.5", 70)])
+def test_reads_condensed_graphs_written_by_the_reference(golden_dir, tmp_path, rate, n):
+    """tests/golden/ref_artifacts/adj_cora_{0.1,0.5}_1.pt are files the REFERENCE's own save_reduced wrote
+    (interface/reduced_graph/gcond/ upstream; the label / feat files next to them are corrupt archives upstream).  load_reduced
+    must read them as the reference does (dataset/utils.py:155-258): the adjacency as saved — dense fp32 [n', n'], the raw PGE
+    sigmoid output: symmetric, zero diagonal, entries in [0, 1) — with the reference's fall-backs for the missing feat / label
+    files; sparsify then applies args.threshold (dataset/utils.py:47-48)."""
+    import shutil
+    import types
+    from graphslim_amd.dataset.utils import load_reduced, sparsify
+    d = tmp_path / "reduced_graph" / "gcond"
+    d.mkdir(parents=True)
+    shutil.copy(os.path.join(golden_dir, "ref_artifacts", f"adj_cora_{rate}_1.pt"), d / f"adj_cora_{rate}_1.pt")
+    args = types.SimpleNamespace(save_path=str(tmp_path), method="gcond", dataset="cora", reduction_rate=float(rate), seed=1,
+                                 device="cpu", setting="trans", threshold=0.05)
+    data = types.SimpleNamespace(feat_full=torch.zeros(140, 3), feat_train=torch.zeros(140, 3), labels_train=torch.zeros(140, dtype=torch.long))
+    adj, feat, lab = load_reduced(args, data)
+    assert adj.dtype == torch.float32 and tuple(adj.shape) == (n, n)
+    assert torch.equal(adj, adj.T) and float(adj.diagonal().abs().max()) == 0.0 and 0.0 <= float(adj.min()) and float(adj.max()) < 1.0
+    assert feat is data.feat_full and lab is data.labels_train          # the reference's fall-backs
+    sp_ = sparsify("GCN", adj.clone(), args)
+    assert float(sp_[sp_ > 0].min()) >= 0.05 and int((sp_ > 0).sum()) == int((adj >= 0.05).sum())
