@@ -11,6 +11,8 @@
 extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int, long, int, float, gs_stream_t);
 extern "C" int gs_reduce_slabs_f32(float*, const float*, long, int, long, float, gs_stream_t);
 int gs_reduce_slabs_active(float*, long, const float*, long, int, long, int, const int*, int, gs_stream_t);
+int gs_panel_marginals(const float*, long, const float*, long, const float*, long, int, int, int, int, float*, float*, int, void*,
+                       hipStream_t);
 
 namespace {
 
@@ -1204,33 +1206,45 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
                            (float*)nullptr, (float*)nullptr);
         GS_LAUNCH_CHECK();
       }
-      {  // dY1 = (dE2 W1) * [A1 > 0].  W1 is transposed first (256 KB, one tiny launch) so that both operands are
-         // k-contiguous: the (K,K) form of the tiled kernel is ~10 % faster than (K,M) at this shape
+      {  // dY1 = (dE2 W1) * [A1 > 0] is needed only through its two marginals.  W1 is transposed first (256 KB, one tiny
+         // launch) so that both operands are k-contiguous.  Preferred route: the row-panel kernel's fused-marginals form
+         // (pair-patch tiles, gs_panel.hip) — dY1 is never materialised, its buffer holds the partial sums instead.
         hipLaunchKernelGGL(gs_transpose_small_kernel, dim3(gs_cdiv(Ph, 32), gs_cdiv(Ph, 32)), dim3(32, 8), 0, s, pp + e->pW1, Ph, Ph,
                            e->W1T);
         GS_LAUNCH_CHECK();
-        gs_gemm_desc a = mk(e->dE2, Ph, 1, e->W1T, 1, Ph, e->dY1, Ph, (int)rows, Ph, Ph);
-        a.mask = e->A1; a.ldmask = Ph;
-        a.prec = e->operand_mode; a.scratch = e->bsplit_main;
-        GS_TRY(gs_gemm_f32(&a, stream));
-      }
-      {
-        // both marginals in one pass over dY1; the partial sums live in `parts` (free here: its producers ran earlier on
-        // this stream), reduced in a fixed order
-        const int nrb = gs_cdiv(nr, GS_MARG_RR), ncb = gs_cdiv(n, GS_MARG_CC);
-        const size_t need = ((size_t)nrb * n + (size_t)ncb * nr) * Ph * sizeof(float);
-        const size_t have = (size_t)e->nblk_stats * 3 * Ph * sizeof(double);
-        if (Ph % 4 == 0 && Ph <= 1024 && need <= have) {
-          float* partU = reinterpret_cast<float*>(e->parts);
-          float* partV = partU + (size_t)nrb * n * Ph;
-          hipLaunchKernelGGL(gs_pge_marginals_fused_kernel, dim3(ncb, nrb), dim3(256), 0, s, e->dY1, n, Ph, nr, partU, partV);
-          GS_LAUNCH_CHECK();
+        const int nrb = gs_cdiv(nr, 16), ncb = gs_cdiv(n, 8);
+        float* partV = e->dY1;                                   // [ncb][nr][Ph]
+        float* partU = e->dY1 + (size_t)ncb * nr * Ph;           // [nrb][n][Ph]
+        int rc = GS_ERR_UNSUPPORTED;
+        if (((size_t)ncb * nr + (size_t)nrb * n) * Ph <= (size_t)n2 * Ph)
+          rc = gs_panel_marginals(e->dE2, Ph, e->W1T, Ph, e->A1, Ph, n, nr, Ph, Ph, partU, partV, e->operand_mode, e->bsplit_main, s);
+        if (rc == GS_OK) {
           GS_TRY(gs_reduce_slabs_f32(e->rowsum_c, partU, (long)n * Ph, nrb, (long)n * Ph, 0.f, stream));
           GS_TRY(gs_reduce_slabs_f32(e->colsum_r + (long)e->r_lo * Ph, partV, (long)nr * Ph, ncb, (long)nr * Ph, 0.f, stream));
+        } else if (rc != GS_ERR_UNSUPPORTED) {
+          return rc;
         } else {
-          hipLaunchKernelGGL(gs_pge_marginal_r_kernel, dim3(nr), dim3(256), 0, s, e->dY1, n, Ph, e->r_lo, e->colsum_r);
-          hipLaunchKernelGGL(gs_pge_marginal_c_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, nr, e->rowsum_c);
-          GS_LAUNCH_CHECK();
+          gs_gemm_desc a = mk(e->dE2, Ph, 1, e->W1T, 1, Ph, e->dY1, Ph, (int)rows, Ph, Ph);
+          a.mask = e->A1; a.ldmask = Ph;
+          a.prec = e->operand_mode; a.scratch = e->bsplit_main;
+          GS_TRY(gs_gemm_f32(&a, stream));
+          // both marginals in one pass over dY1; the partial sums live in `parts` (free here: its producers ran earlier on
+          // this stream), reduced in a fixed order
+          const int nrb2 = gs_cdiv(nr, GS_MARG_RR), ncb2 = gs_cdiv(n, GS_MARG_CC);
+          const size_t need = ((size_t)nrb2 * n + (size_t)ncb2 * nr) * Ph * sizeof(float);
+          const size_t have = (size_t)e->nblk_stats * 3 * Ph * sizeof(double);
+          if (Ph % 4 == 0 && Ph <= 1024 && need <= have) {
+            float* pU = reinterpret_cast<float*>(e->parts);
+            float* pV = pU + (size_t)nrb2 * n * Ph;
+            hipLaunchKernelGGL(gs_pge_marginals_fused_kernel, dim3(ncb2, nrb2), dim3(256), 0, s, e->dY1, n, Ph, nr, pU, pV);
+            GS_LAUNCH_CHECK();
+            GS_TRY(gs_reduce_slabs_f32(e->rowsum_c, pU, (long)n * Ph, nrb2, (long)n * Ph, 0.f, stream));
+            GS_TRY(gs_reduce_slabs_f32(e->colsum_r + (long)e->r_lo * Ph, pV, (long)nr * Ph, ncb2, (long)nr * Ph, 0.f, stream));
+          } else {
+            hipLaunchKernelGGL(gs_pge_marginal_r_kernel, dim3(nr), dim3(256), 0, s, e->dY1, n, Ph, e->r_lo, e->colsum_r);
+            hipLaunchKernelGGL(gs_pge_marginal_c_kernel, dim3(n), dim3(256), 0, s, e->dY1, n, Ph, nr, e->rowsum_c);
+            GS_LAUNCH_CHECK();
+          }
         }
       }
     }
@@ -1246,7 +1260,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
   }
   GS_LAUNCH_CHECK();
   if (need_param_grads) {
-    hipLaunchKernelGGL(gs_colsum_small_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->dU, n, Ph, g + e->pb0);
+    hipLaunchKernelGGL(gs_colsum_small_kernel, dim3(gs_cdiv(Ph, 64)), dim3(256), 0, s, e->dU, n, Ph, g + e->pb0);
     GS_LAUNCH_CHECK();
     gs_gemm_desc w0[2];
     w0[0] = mk(e->dU, 1, Ph, X, d, 1, g + e->pW0, 2L * d, Ph, d, n);       // dW0[:, :d] = dU^T X

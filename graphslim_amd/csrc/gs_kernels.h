@@ -1060,12 +1060,23 @@ __global__ void gs_pge_bn1_bwd_uv_kernel(const float* __restrict__ U, const floa
   dU[idx] = kk * (rowsum_c[idx] - (float)n * dbe1[k] / N - xr * dg1[k] / N);
   dV[idx] = kk * (colsum_r[idx] - (float)n * dbe1[k] / N - xc * dg1[k] / N);
 }
-__global__ void gs_colsum_small_kernel(const float* __restrict__ M, int rows, int cols, float* __restrict__ out) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= cols) return;
+// column sums of a small [rows x cols] matrix, fp64 accumulation.  One workgroup = 64 columns x 4 row groups: the first form
+// walked all rows in ONE thread per column (106 us for 454 x 256 on the critical path of the PGE epochs).
+__global__ __launch_bounds__(256) void gs_colsum_small_kernel(const float* __restrict__ M, int rows, int cols, float* __restrict__ out) {
+  const int k = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  __shared__ double sh[4][64];
   double s = 0;
-  for (int i = 0; i < rows; ++i) s += M[(long)i * cols + k];
-  out[k] = (float)s;
+  if (k < cols) {
+    int i = g;
+    for (; i + 12 < rows; i += 16) {            // 4 independent loads in flight
+      const float a = M[(long)i * cols + k], b = M[(long)(i + 4) * cols + k], c = M[(long)(i + 8) * cols + k], d = M[(long)(i + 12) * cols + k];
+      s += ((double)a + (double)b) + ((double)c + (double)d);
+    }
+    for (; i < rows; i += 4) s += M[(long)i * cols + k];
+  }
+  sh[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && k < cols) out[k] = (float)(((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x]);
 }
 __global__ void gs_fill_kernel(float* __restrict__ p, long n, float v) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -42,6 +42,10 @@ struct gs_panel_args {
   const float* mask; long ldmask;
   float* colstat;                    // [tiles_m][2][256] or null
   int n_full;                        // workgroups [0, n_full) run 128-row tiles, the rest 32-row tiles (the last partial round)
+  // fused-marginals form (gs_panel_marg_kernel): rows are the pairs (r, c) of an [nr x n] grid, a tile = 16 r x 8 c
+  int mg_n, mg_nr, mg_ncb;
+  float* partU;                      // [ceil(nr/16)][n][N]: sum over the tile's 16 r
+  float* partV;                      // [ceil(n/8)][nr][N]:  sum over the tile's 8 c
   int krep, triage;                  // measurement hooks (gs_panel_debug): K loop repeated krep times; bit 0: no stores;
   unsigned long long* trace;         // bit 1: per-workgroup [hw_id, xcc_id, t_start, t_loop_end, t_end] (s_memrealtime, 10 ns)
 };
@@ -99,19 +103,71 @@ __device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32
   }
 }
 
+// Fused-marginals epilogue (the PGE backward needs dY1 = (dE2 W1) * [A1 > 0] ONLY through its two marginals
+// colsum_r[r] = sum_c dY1[(r, c)] and rowsum_c[c] = sum_r dY1[(r, c)]): the tile's 128 rows are the pairs of a 16 r x 8 c patch
+// (row i of the tile = pair (16 rb + (i >> 3), 8 cb + (i & 7))), so that in the C/D layout (row = (reg & 3) + 8 (reg >> 2) +
+// 4 (lane >> 5) inside the wave's 32 rows) reg >> 2 is the r of the wave's 4 and (reg & 3) + 4 (lane >> 5) is the c of the 8:
+//   sum over c  = 4 registers + the other half-wave  -> partV[cb][r][col]   (written by the wave itself)
+//   sum over r  = 4 registers, then the 4 waves through LDS -> partU[rb][c][col]
+// dY1 (211 MB at ogbn-arxiv) is neither written nor read back; gs_reduce_slabs_f32 adds the partials in a fixed order.
+template <int NT>
+__device__ __forceinline__ void panel_epilogue_marg(const gs_panel_args& p, const f32x16 (&acc)[NT], char* smem, int rb, int cb,
+                                                    int wave, int li, int h) {
+  constexpr int N = 32 * NT;
+  const int n = p.mg_n, nr = p.mg_nr;
+  unsigned moff[16];
+  bool ok[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rl = 16 * rb + 4 * wave + (r >> 2), c = 8 * cb + (r & 3) + 4 * h;
+    ok[r] = rl < nr && c < n;
+    moff[r] = (unsigned)(min(rl, nr - 1) * n + min(c, n - 1)) * (unsigned)p.ldmask + (unsigned)li;
+  }
+  __syncthreads();                                   // every wave is done with the B stages: they become the [4][8][N] scratch
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float mk[16], v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mk[r] = p.mask[moff[r] + 32u * j];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = (ok[r] && mk[r] > 0.f) ? acc[j][r] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float sv = (v[4 * q] + v[4 * q + 1]) + (v[4 * q + 2] + v[4 * q + 3]);          // over this half-wave's 4 c
+      sv += __shfl_xor(sv, 32, 64);                                                   // + the other 4
+      const int rl = 16 * rb + 4 * wave + q;
+      if (h == 0 && rl < nr) p.partV[((long)cb * nr + rl) * N + 32 * j + li] = sv;
+      const float su = (v[q] + v[4 + q]) + (v[8 + q] + v[12 + q]);                    // over the wave's 4 r, c = 8 cb + q + 4 h
+      red[(wave * 8 + q + 4 * h) * N + 32 * j + li] = su;
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 8 * N; idx += 256) {
+    const int ci = idx / N, col = idx - ci * N, c = 8 * cb + ci;
+    const float t = ((red[(0 * 8 + ci) * N + col] + red[(1 * 8 + ci) * N + col]) + red[(2 * 8 + ci) * N + col]) + red[(3 * 8 + ci) * N + col];
+    if (c < n) p.partU[((long)rb * n + c) * N + col] = t;
+  }
+}
+
 // One tile.  WN = 1: 128 rows, wave w owns rows [32 w, 32 w + 32) x all N columns (NT MFMA tiles, the bulk of the launch).
 //            WN = 4: 32 rows, wave w owns all 32 rows x the N / 4 columns [32 NT w / 4, ...) — the LAST partial round of a
 // launch runs in these: 206 116 rows are 1 611 tiles of 128 rows on 512 workgroup slots = 3.15 rounds, and the 75 tiles of the
 // fourth round kept 75 CUs busy for a whole solo tile (43 us of 258) while 181 CUs idled; as 300 tiles of a quarter of the
 // work they take one short round on every CU.  Same arithmetic per output element either way (same k order).
-template <int MODE, int NT, int WN>
+template <int MODE, int NT, int WN, bool MARG = false>
 __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, int m0, int stat_row) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128, NTW = NT / WN, ROWS = 128 / WN;
+  static_assert(!MARG || WN == 1, "the fused-marginals form uses 128-row tiles");
   float* sbias = reinterpret_cast<float*>(smem + 2 * PN_STAGE);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
-  const int row = m0 + (WN == 1 ? wave * 32 : 0) + li;
+  int row = m0 + (WN == 1 ? wave * 32 : 0) + li;
+  if (MARG) {       // m0 = tile id: tile (rb, cb) holds the pairs (r, c), r in [16 rb, 16 rb + 16), c in [8 cb, 8 cb + 8)
+    const int rb = m0 / p.mg_ncb, cb = m0 - rb * p.mg_ncb, i = wave * 32 + li;
+    row = min(16 * rb + (i >> 3), p.mg_nr - 1) * p.mg_n + min(8 * cb + (i & 7), p.mg_n - 1);
+  }
   const int j0 = WN == 1 ? 0 : wave * NTW;            // first N tile of this wave
   const float* __restrict__ arow = p.A + (long)min(row, p.M - 1) * p.lda + 16 * h;
   const char* __restrict__ Bb = (const char*)p.B;
@@ -203,6 +259,10 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   }
 
   if (p.triage & 2) t_loop = __builtin_amdgcn_s_memrealtime();
+  if constexpr (MARG) {
+    panel_epilogue_marg<NT>(p, acc, smem, m0 / p.mg_ncb, m0 % p.mg_ncb, wave, li, h);
+    return;
+  }
   // epilogue: straight-line code per (mask?, interior tile?) combination — see panel_epilogue
   const bool has_stat = p.colstat != nullptr;
   const int rit = (WN == 1 ? wave * 32 : 0) + 4 * h;      // first accumulator row of this lane inside the tile
@@ -255,6 +315,13 @@ __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) 
   const int b = blockIdx.x;
   if (b < p.n_full) panel_tile<MODE, NT, 1>(p, smem, b * PN_BM, b);
   else panel_tile<MODE, NT, 4>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
+}
+
+template <int MODE, int NT>
+__global__ __launch_bounds__(256, 2) void gs_panel_marg_kernel(gs_panel_args p) {
+  constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * PN_STAGE + PN_N * 4];
+  panel_tile<MODE, NT, 1, true>(p, smem, blockIdx.x, 0);
 }
 
 // W [N][ldb] fp32 -> packed [N][K/32][hi 32 | lo 32] bf16 (lo = bf16(w - hi); all zeros are kept exact)
@@ -353,6 +420,46 @@ int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s) {
   a.trace = (g_panel_triage & 2) ? (unsigned long long*)d.scratch : nullptr;   // (trace runs use prec = 0: scratch is free)
   if (d.N == 256) panel_dispatch<8>(d, a, s);
   else panel_dispatch<4>(d, a, s);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+static int g_panel_marg = 1;
+extern "C" int gs_gemm_set_panel_marg(int on) {     // measurement knob: 0 = materialise dY1 and run the marginals kernel
+  g_panel_marg = on != 0;
+  return GS_OK;
+}
+
+// engine-internal: partU / partV of (dE2 [nr * n][K] x W^T [N][K]) * [mask > 0] without materialising the product.
+// Returns GS_ERR_UNSUPPORTED when the shape is not covered (the caller then takes the two-kernel route).
+int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, const float* mask, long ldmask, int n, int nr, int N,
+                       int K, float* partU, float* partV, int prec, void* scratch, hipStream_t s) {
+  if (!g_panel_marg || !g_panel_enabled || (N != 256 && N != 128) || K < 32 || (K & 31) || (lda & 3) || (ldw & 3)) return GS_ERR_UNSUPPORTED;
+  if ((double)nr * n * (double)ldmask >= 4294967296.0 || (prec != 0 && !scratch) || nr < 1) return GS_ERR_UNSUPPORTED;
+  if ((((uintptr_t)dE2 | (uintptr_t)W) & 15)) return GS_ERR_UNSUPPORTED;
+  gs_panel_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = dE2; a.lda = lda; a.M = nr * n; a.K = K;
+  a.mask = mask; a.ldmask = ldmask;
+  a.krep = 1;
+  a.mg_n = n; a.mg_nr = nr; a.mg_ncb = gs_cdiv(n, 8);
+  a.partU = partU; a.partV = partV;
+  const dim3 grid((unsigned)(gs_cdiv(nr, 16) * a.mg_ncb)), block(256);
+  if (prec == 0) {
+    a.B = W; a.ldb_bytes = ldw * 4;
+  } else {
+    hipLaunchKernelGGL(gs_panel_split_b_kernel, dim3(gs_cdiv((long)N * K, 256)), dim3(256), 0, s, W, ldw, N, K, (__bf16*)scratch);
+    a.B = scratch; a.ldb_bytes = (long)K * 4;
+  }
+#define GS_MARG_LAUNCH(MODE_)                                                                            \
+  do {                                                                                                   \
+    if (N == 256) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8>), grid, block, 0, s, a);            \
+    else hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 4>), grid, block, 0, s, a);                     \
+  } while (0)
+  if (prec == 0) GS_MARG_LAUNCH(0);
+  else if (prec == 1) GS_MARG_LAUNCH(1);
+  else GS_MARG_LAUNCH(2);
+#undef GS_MARG_LAUNCH
   GS_LAUNCH_CHECK();
   return GS_OK;
 }
