@@ -11,8 +11,9 @@
 extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int, long, int, float, gs_stream_t);
 extern "C" int gs_reduce_slabs_f32(float*, const float*, long, int, long, float, gs_stream_t);
 int gs_reduce_slabs_active(float*, long, const float*, long, int, long, int, const int*, int, gs_stream_t);
+struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; };
 int gs_panel_marginals(const float*, long, const float*, long, const float*, long, int, int, int, int, float*, float*, int, void*,
-                       hipStream_t);
+                       const gs_panel_gen*, hipStream_t);
 
 namespace {
 
@@ -107,6 +108,7 @@ struct gs_gcond {
   // operand precision of the three row-panel products (E2 = A1 W1^T, dY1 = dE2 W1, H1full = X W1): gs_gemm_desc.prec
   int operand_mode;
   float *bsplit_main, *bsplit_aux;   // pre-split B operands (bf16 hi | lo) of the products on the main / the real-side stream
+  float* gen_tab;                    // [Ph][8] folded BatchNorm-2 / layer-3 constants of the generated dE2 operand (gs_panel.hip)
 };
 
 static void derive(gs_gcond* e, const gs_gcond_config& c) {
@@ -217,6 +219,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->rowsum_c = e->ar_marg; e->colsum_r = e->ar_marg ? e->ar_marg + n * Ph : nullptr; e->dU = w.take<float>(n * Ph); e->W1T = w.take<float>(Ph * Ph); e->W1mT = w.take<float>(d * h);
   e->bsplit_main = w.take<float>(Ph * Ph);
   e->bsplit_aux = w.take<float>((h > 0 ? h : 1) * d);
+  e->gen_tab = w.take<float>(Ph * 8);
   e->chunk_fwd = w.take<float>((long)e->pge_chunks * 4 * Ph); e->chunk_bwd = w.take<float>((long)e->pge_chunks * 5 * Ph);
   e->dV = w.take<float>(n * Ph); e->d_pge = w.take<float>(e->Ppge); e->slabs_w = w.take<float>(e->nsplit_w * Ph * Ph);
   e->parts = w.take<double>((long)e->nblk_stats * 3 * Ph);
@@ -1190,6 +1193,29 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
     }
     GS_LAUNCH_CHECK();
     if (rows > 0) {
+      // Feature epochs need dE2 only as the first operand of the marginals product: the row-panel kernel then forms it in
+      // registers from E2 (generated A operand) and the 422 MB bn2_bwd pass is skipped.  PGE epochs (dW1, db1 read dE2 too)
+      // and shapes the generated form does not cover materialise it.
+      const int nrb0 = gs_cdiv(nr, 16), ncb0 = gs_cdiv(n, 8);
+      bool fused_done = false;
+      if (!need_param_grads && Ph <= 256) {
+        gs_panel_gen gen = {e->mu2, e->is2, pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, de3l, (long)n2, e->gen_tab};
+        hipLaunchKernelGGL(gs_transpose_small_kernel, dim3(gs_cdiv(Ph, 32), gs_cdiv(Ph, 32)), dim3(32, 8), 0, s, pp + e->pW1, Ph, Ph,
+                           e->W1T);
+        GS_LAUNCH_CHECK();
+        float* partV = e->dY1;
+        float* partU = e->dY1 + (size_t)ncb0 * nr * Ph;
+        const int rc = gs_panel_marginals(e->E2, Ph, e->W1T, Ph, e->A1, Ph, n, nr, Ph, Ph, partU, partV, e->operand_mode, e->bsplit_main,
+                                          &gen, s);
+        if (rc == GS_OK) {
+          GS_TRY(gs_reduce_slabs_f32(e->rowsum_c, partU, (long)n * Ph, nrb0, (long)n * Ph, 0.f, stream));
+          GS_TRY(gs_reduce_slabs_f32(e->colsum_r + (long)e->r_lo * Ph, partV, (long)nr * Ph, ncb0, (long)nr * Ph, 0.f, stream));
+          fused_done = true;
+        } else if (rc != GS_ERR_UNSUPPORTED) {
+          return rc;
+        }
+      }
+      if (fused_done) return GS_OK;
       hipLaunchKernelGGL(gs_pge_bn2_bwd_v4_kernel, dim3(gs_cdiv(gs_cdiv(rows, 8) * (long)(Ph / 4), 256)), dim3(256), 0, s, e->E2, de3l, e->mu2,
                          e->is2, pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, rows, n2, Ph, e->dE2);
       GS_LAUNCH_CHECK();
@@ -1217,7 +1243,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
         float* partU = e->dY1 + (size_t)ncb * nr * Ph;           // [nrb][n][Ph]
         int rc = GS_ERR_UNSUPPORTED;
         if (((size_t)ncb * nr + (size_t)nrb * n) * Ph <= (size_t)n2 * Ph)
-          rc = gs_panel_marginals(e->dE2, Ph, e->W1T, Ph, e->A1, Ph, n, nr, Ph, Ph, partU, partV, e->operand_mode, e->bsplit_main, s);
+          rc = gs_panel_marginals(e->dE2, Ph, e->W1T, Ph, e->A1, Ph, n, nr, Ph, Ph, partU, partV, e->operand_mode, e->bsplit_main, nullptr, s);
         if (rc == GS_OK) {
           GS_TRY(gs_reduce_slabs_f32(e->rowsum_c, partU, (long)n * Ph, nrb, (long)n * Ph, 0.f, stream));
           GS_TRY(gs_reduce_slabs_f32(e->colsum_r + (long)e->r_lo * Ph, partV, (long)nr * Ph, ncb, (long)nr * Ph, 0.f, stream));

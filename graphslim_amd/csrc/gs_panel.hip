@@ -46,6 +46,9 @@ struct gs_panel_args {
   int mg_n, mg_nr, mg_ncb;
   float* partU;                      // [ceil(nr/16)][n][N]: sum over the tile's 16 r
   float* partV;                      // [ceil(n/8)][nr][N]:  sum over the tile's 8 c
+  // generated A operand (AGEN): A holds E2; the operand is dE2 = BatchNorm-2 + layer-3 backward of it, formed in registers
+  const float* gen_c;                // [K][8]: per column k  {is2, -mu2 is2, g2, be2, g2 is2 w2, g2 is2 dbe2 / N, g2 is2 dg2 / N, 0}
+  const float* gen_d;                // [rows]: de3 of each pair row
   int krep, triage;                  // measurement hooks (gs_panel_debug): K loop repeated krep times; bit 0: no stores;
   unsigned long long* trace;         // bit 1: per-workgroup [hw_id, xcc_id, t_start, t_loop_end, t_end] (s_memrealtime, 10 ns)
 };
@@ -155,10 +158,11 @@ __device__ __forceinline__ void panel_epilogue_marg(const gs_panel_args& p, cons
 // launch runs in these: 206 116 rows are 1 611 tiles of 128 rows on 512 workgroup slots = 3.15 rounds, and the 75 tiles of the
 // fourth round kept 75 CUs busy for a whole solo tile (43 us of 258) while 181 CUs idled; as 300 tiles of a quarter of the
 // work they take one short round on every CU.  Same arithmetic per output element either way (same k order).
-template <int MODE, int NT, int WN, bool MARG = false>
+template <int MODE, int NT, int WN, bool MARG = false, bool AGEN = false>
 __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, int m0, int stat_row) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128, NTW = NT / WN, ROWS = 128 / WN;
   static_assert(!MARG || WN == 1, "the fused-marginals form uses 128-row tiles");
+  static_assert(!AGEN || MARG, "the generated A operand is used by the fused-marginals form only");
   float* sbias = reinterpret_cast<float*>(smem + 2 * PN_STAGE);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -204,6 +208,15 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   // stores of two tiles without waiting for them (a global load there would: vmcnt retires in order), and no register is held
   // across the K loop
   if (tid < PN_N) sbias[tid] = p.bias ? p.bias[tid] : 0.f;
+  // AGEN: the per-column constants of the operand transform sit behind the bias row ([K <= 256][8] floats), this lane's
+  // pair row has ONE upstream scalar (de3 of the pair)
+  const f32x4* __restrict__ gc = reinterpret_cast<const f32x4*>(smem + 2 * PN_STAGE + PN_N * 4);
+  float gen_d = 0.f;
+  if constexpr (AGEN) {
+    f32x4* gw = reinterpret_cast<f32x4*>(smem + 2 * PN_STAGE + PN_N * 4);
+    for (int i = tid; i < 2 * p.K; i += 256) gw[i] = reinterpret_cast<const f32x4*>(p.gen_c)[i];
+    gen_d = p.gen_d[min(row, p.M - 1)];
+  }
 
   f32x4 a_cur[4], a_nxt[4];
   stage_b(0, 0);
@@ -219,6 +232,19 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
       load_a((kb + 1) % nkb, a_nxt);
     }
     const char* __restrict__ bs = smem + (kk & 1) * PN_STAGE + li * 128 + j0 * 4096;
+    if constexpr (AGEN) {
+      // a_cur holds E2[row][k], k = 32 kb + 16 h + t: turn it into dE2 = g2 is2 (dy2 - dbe2 / N - xh2 dg2 / N) with
+      // xh2 = (E2 - mu2) is2, dy2 = de3 w2 [g2 xh2 + be2 > 0]   (gs_pge_bn2_bwd_v4_kernel, same arithmetic, constants folded)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int k = 32 * kb + 16 * h + t;
+        const f32x4 c0 = gc[2 * k], c1 = gc[2 * k + 1];
+        const float xh = fmaf(a_cur[t >> 2][t & 3], c0[0], c0[1]);
+        const float y = fmaf(c0[2], xh, c0[3]);
+        const float sel = y > 0.f ? gen_d * c1[0] : 0.f;
+        a_cur[t >> 2][t & 3] = fmaf(-xh, c1[2], sel - c1[1]);
+      }
+    }
     if constexpr (MODE == 0) {
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
@@ -317,11 +343,23 @@ __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) 
   else panel_tile<MODE, NT, 4>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
 }
 
-template <int MODE, int NT>
+template <int MODE, int NT, bool AGEN>
 __global__ __launch_bounds__(256, 2) void gs_panel_marg_kernel(gs_panel_args p) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;
-  __shared__ __attribute__((aligned(16))) char smem[2 * PN_STAGE + PN_N * 4];
-  panel_tile<MODE, NT, 1, true>(p, smem, blockIdx.x, 0);
+  __shared__ __attribute__((aligned(16))) char smem[2 * PN_STAGE + PN_N * 4 + (AGEN ? 256 * 32 : 0)];
+  panel_tile<MODE, NT, 1, true, AGEN>(p, smem, blockIdx.x, 0);
+}
+
+// gen_c[k][8] from the BatchNorm-2 / layer-3 quantities (one thread per column)
+__global__ void gs_panel_gen_consts_kernel(const float* __restrict__ mu2, const float* __restrict__ is2, const float* __restrict__ g2,
+                                           const float* __restrict__ be2, const float* __restrict__ w2, const float* __restrict__ dbe2,
+                                           const float* __restrict__ dg2, float invN, int K, float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const float gi = g2[k] * is2[k];
+  float* o = out + 8 * k;
+  o[0] = is2[k]; o[1] = -mu2[k] * is2[k]; o[2] = g2[k]; o[3] = be2[k];
+  o[4] = gi * w2[k]; o[5] = gi * dbe2[k] * invN; o[6] = gi * dg2[k] * invN; o[7] = 0.f;
 }
 
 // W [N][ldb] fp32 -> packed [N][K/32][hi 32 | lo 32] bf16 (lo = bf16(w - hi); all zeros are kept exact)
@@ -424,16 +462,24 @@ int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s) {
   return GS_OK;
 }
 
-static int g_panel_marg = 1;
-extern "C" int gs_gemm_set_panel_marg(int on) {     // measurement knob: 0 = materialise dY1 and run the marginals kernel
-  g_panel_marg = on != 0;
+static int g_panel_marg = 2;
+// measurement knob: 0 = materialise dY1 and run the marginals kernel, 1 = fused marginals on a materialised dE2,
+// 2 (default) = fused marginals with dE2 generated from E2 in the operand path where it applies
+extern "C" int gs_gemm_set_panel_marg(int level) {
+  g_panel_marg = level < 0 ? 0 : (level > 2 ? 2 : level);
   return GS_OK;
 }
 
 // engine-internal: partU / partV of (dE2 [nr * n][K] x W^T [N][K]) * [mask > 0] without materialising the product.
 // Returns GS_ERR_UNSUPPORTED when the shape is not covered (the caller then takes the two-kernel route).
+// With `gen` (7 device arrays mu2, is2, g2, be2, w2, dbe2, dg2 of length K, de3 per pair row, total pair rows N_total and an
+// [K][8] float scratch table) the first operand is E2 and dE2 is formed inside the kernel (no dE2 pass, no dE2 buffer).
+struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; };
+
 int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, const float* mask, long ldmask, int n, int nr, int N,
-                       int K, float* partU, float* partV, int prec, void* scratch, hipStream_t s) {
+                       int K, float* partU, float* partV, int prec, void* scratch, const gs_panel_gen* gen, hipStream_t s) {
+  // (generated operand: fp32 at N = 256 — the bf16 conversions next to it need more than 256 registers there — any mode at N = 128)
+  if (gen && (g_panel_marg < 2 || K > 256 || !gen->table || (N == 256 && prec != 0))) return GS_ERR_UNSUPPORTED;
   if (!g_panel_marg || !g_panel_enabled || (N != 256 && N != 128) || K < 32 || (K & 31) || (lda & 3) || (ldw & 3)) return GS_ERR_UNSUPPORTED;
   if ((double)nr * n * (double)ldmask >= 4294967296.0 || (prec != 0 && !scratch) || nr < 1) return GS_ERR_UNSUPPORTED;
   if ((((uintptr_t)dE2 | (uintptr_t)W) & 15)) return GS_ERR_UNSUPPORTED;
@@ -444,6 +490,11 @@ int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, con
   a.krep = 1;
   a.mg_n = n; a.mg_nr = nr; a.mg_ncb = gs_cdiv(n, 8);
   a.partU = partU; a.partV = partV;
+  if (gen) {
+    hipLaunchKernelGGL(gs_panel_gen_consts_kernel, dim3(gs_cdiv(K, 64)), dim3(64), 0, s, gen->mu2, gen->is2, gen->g2, gen->be2, gen->w2,
+                       gen->dbe2, gen->dg2, 1.f / (float)gen->total_rows, K, gen->table);
+    a.gen_c = gen->table; a.gen_d = gen->de3;
+  }
   const dim3 grid((unsigned)(gs_cdiv(nr, 16) * a.mg_ncb)), block(256);
   if (prec == 0) {
     a.B = W; a.ldb_bytes = ldw * 4;
@@ -451,10 +502,12 @@ int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, con
     hipLaunchKernelGGL(gs_panel_split_b_kernel, dim3(gs_cdiv((long)N * K, 256)), dim3(256), 0, s, W, ldw, N, K, (__bf16*)scratch);
     a.B = scratch; a.ldb_bytes = (long)K * 4;
   }
-#define GS_MARG_LAUNCH(MODE_)                                                                            \
-  do {                                                                                                   \
-    if (N == 256) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8>), grid, block, 0, s, a);            \
-    else hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 4>), grid, block, 0, s, a);                     \
+#define GS_MARG_LAUNCH(MODE_)                                                                                        \
+  do {                                                                                                               \
+    if (N == 256 && gen) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, true>), grid, block, 0, s, a);           \
+    else if (N == 256) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, false>), grid, block, 0, s, a);            \
+    else if (gen) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 4, true>), grid, block, 0, s, a);                  \
+    else hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 4, false>), grid, block, 0, s, a);                          \
   } while (0)
   if (prec == 0) GS_MARG_LAUNCH(0);
   else if (prec == 1) GS_MARG_LAUNCH(1);

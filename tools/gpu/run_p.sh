@@ -14,7 +14,7 @@ eng = bench.make_engine(p, "cuda:0"); bench.init_state(p, eng); bench.new_model(
 for mode in ("f32", "bf16x3"):
     eng.set_operand_mode(mode)
     for rnd in range(2):
-        for on in (0, 1):
+        for on in (0, 1, 2):
             L.gs_gemm_set_panel_marg(on)
             for _ in range(5): eng.outer_step(10)
             torch.cuda.synchronize(); t0 = time.perf_counter()
