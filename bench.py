@@ -103,51 +103,51 @@ PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "pmc_panel_summary.json")
 
 
 def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20):
-    """Dominant kernel: the PGE layer-2 contraction E2[n'^2, Ph] = A1[n'^2, Ph] W1^T on the matrix cores — the row-panel
-    kernel gs_panel_gemm_kernel<0, 8> in the default exact-fp32 mode (csrc/gs_panel.hip); algorithmic FLOPs = 2 n'^2 Ph^2
-    per launch.  `achieved` uses the IN-SITU duration: HIP events recorded by the engine on the launch stream around every
-    launch of that product inside the timed outer iterations (training forward — which shares the chip with the real-side
-    stream — and inference pass).  `isolated_launch_us` is the same kernel at the same shape launched back to back on an
-    idle chip.  `traffic` cannot be sampled inside bench.py (PMC needs rocprofv3): it is read from the committed counter
-    summary of the same kernel at the same shape (`traffic_source`), FETCH_SIZE already doubled as the gfx950 calibration
-    requires (profiles/r02/copy_calib: every read pattern reports exactly half its bytes)."""
-    from graphslim_amd.engine import gemm
+    """Dominant kernel: the PGE layer-2 contraction E2[n'^2, Ph] = A1[n'^2, Ph] W1^T + b1 on the matrix cores — the row-panel
+    kernel with the generated A1 operand, gs_panel_fwdgen_kernel<0, 8> in the default exact-fp32 mode (csrc/gs_panel.hip);
+    algorithmic FLOPs = 2 n'^2 Ph^2 per launch.  `achieved` uses the IN-SITU duration: HIP events recorded by the engine on
+    the launch stream around every launch of that product inside the timed outer iterations (training forward — which shares
+    the chip with the real-side stream — and inference pass).  `isolated_launch_us` is the same launch, bracketed the same
+    way, with nothing else on the chip (the PGE forward's first part run back to back).  `traffic` cannot be sampled inside
+    bench.py (PMC needs rocprofv3): it is read from the committed counter summary of the same kernel at the same shape
+    (`traffic_source`), FETCH_SIZE already doubled as the gfx950 calibration requires (profiles/r02/copy_calib: every read
+    pattern reports exactly half its bytes)."""
     n, ph = eng.shapes.n_syn, eng.shapes.pge_hidden
     rows = n * n
-    a = torch.randn(rows, ph, device=eng.dev)
-    w = torch.randn(ph, ph, device=eng.dev)
-    out = torch.empty(rows, ph, device=eng.dev)
-    scratch = torch.empty(ph * ph, device=eng.dev)
-    prec = {"f32": 0, "bf16x3": 1, "bf16": 2}[mode]
+    base = getattr(eng, "eng", eng)
     for _ in range(3):
-        gemm(a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph, prec=prec, scratch=scratch)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
+        base.pge_forward_part(False, 1)
+    torch.cuda.synchronize()
+    base.probe(True)
     for _ in range(reps):
-        gemm(a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph, prec=prec, scratch=scratch)
-    ev1.record()
-    ev1.synchronize()
-    iso = ev0.elapsed_time(ev1) / 1e3 / reps
+        base.pge_forward_part(False, 1)
+    torch.cuda.synchronize()
+    iso_ms, iso_k = base.probe_read()
+    base.probe(False)
+    iso = iso_ms / 1e3 / max(iso_k, 1)
     sec = insitu_ms / 1e3 / insitu_launches if insitu_launches else iso
     flops = 2.0 * rows * ph * ph
     traffic, src = None, None
-    kname = {"f32": "gs_panel_gemm_kernel<0, 8>", "bf16x3": "gs_panel_gemm_kernel<1, 8>", "bf16": "gs_panel_gemm_kernel<2, 8>"}[mode]
+    kname = {"f32": "gs_panel_fwdgen_kernel<0, 8>", "bf16x3": "gs_panel_fwdgen_kernel<1, 8>", "bf16": "gs_panel_fwdgen_kernel<2, 8>"}[mode]
+    if ph != 256 or n < 128:
+        kname = "PGE layer-2 product (row-panel / tile route of this shape)"
     if (n, ph) == (454, 256) and os.path.exists(PMC_SUMMARY):
         rec = json.load(open(PMC_SUMMARY)).get(kname)
         if rec:
             traffic, src = int(rec["hbm_bytes_per_launch"]), "profiles/r02/pmc_panel_summary.json"
+    # algorithmic bytes: E2 written once; U, V (n' x Ph each) and the weight block read once — A1 is formed in registers
+    alg_bytes = rows * ph * 4.0 + (2 * n * ph + ph * ph + ph) * 4.0
     if mode == "f32":
         peak, bound, unit = 157.3, "mfma", "TFLOP/s"     # fp32 matrix peak (MI355X_MICROARCH.md chip table)
         ach = flops / sec / 1e12
     else:
-        # the split / bf16 modes are HBM-bound (3 or 1 bf16 MFMAs per product = 3/16 or 1/16 of the fp32 pipe time):
-        # algorithmic bytes = A read once + C written once (+ the 256 KB weight block)
+        # the split / bf16 modes need 3/16 or 1/16 of the fp32 pipe time: the launch is bounded by its E2 write stream
         peak, bound, unit = 8000.0, "hbm", "GB/s"
-        ach = (2.0 * rows * ph * 4 + ph * ph * 4) / sec / 1e9
-    return {"bound": bound, "kernel": f"{kname} (PGE layer 2: E2 = A1 W1^T + b1 with fused BN-2 column sums; {mode} operands)",
+        ach = alg_bytes / sec / 1e9
+    return {"bound": bound, "kernel": f"{kname} (PGE layer 2: E2 = A1(U, V) W1^T + b1 with fused BN-2 column sums; {mode} operands)",
             "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
             "traffic_source": src, "avg_launch_us": round(sec * 1e6, 2), "launches_timed": int(insitu_launches),
-            "flops_per_launch": flops, "algorithmic_bytes_per_launch": 2.0 * rows * ph * 4 + ph * ph * 4,
+            "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
             "isolated_launch_us": round(iso * 1e6, 2)}
 
 

@@ -12,8 +12,13 @@ extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int
 extern "C" int gs_reduce_slabs_f32(float*, const float*, long, int, long, float, gs_stream_t);
 int gs_reduce_slabs_active(float*, long, const float*, long, int, long, int, const int*, int, gs_stream_t);
 struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; };
+struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; };
 int gs_panel_marginals(const float*, long, const float*, long, const float*, long, int, int, int, int, float*, float*, int, void*,
-                       const gs_panel_gen*, hipStream_t);
+                       const gs_panel_gen*, const gs_panel_a1*, hipStream_t);
+int gs_panel_forward_a1(const gs_panel_a1*, int, int, const float*, long, const float*, float*, long, int, int, float*, int, void*,
+                        hipStream_t);
+int gs_panel_tiles(int);
+int gs_panel_a1_table(const gs_panel_a1*, int, hipStream_t);
 
 namespace {
 
@@ -108,6 +113,8 @@ struct gs_gcond {
   // operand precision of the three row-panel products (E2 = A1 W1^T, dY1 = dE2 W1, H1full = X W1): gs_gemm_desc.prec
   int operand_mode;
   float *bsplit_main, *bsplit_aux;   // pre-split B operands (bf16 hi | lo) of the products on the main / the real-side stream
+  float* a1_tab;                     // [Ph][8] layer-0 bias / BatchNorm-1 constants of the generated A1 operand and mask (gs_panel.hip)
+  bool a1_valid;                     // A1 holds the activations of the current U, V (false: the forward formed them in registers only)
   float* gen_tab;                    // [Ph][8] folded BatchNorm-2 / layer-3 constants of the generated dE2 operand (gs_panel.hip)
 };
 
@@ -220,6 +227,8 @@ static size_t carve(gs_gcond* e, void* base) {
   e->bsplit_main = w.take<float>(Ph * Ph);
   e->bsplit_aux = w.take<float>((h > 0 ? h : 1) * d);
   e->gen_tab = w.take<float>(Ph * 8);
+  e->a1_tab = w.take<float>(Ph * 8);
+  e->a1_valid = false;
   e->chunk_fwd = w.take<float>((long)e->pge_chunks * 4 * Ph); e->chunk_bwd = w.take<float>((long)e->pge_chunks * 5 * Ph);
   e->dV = w.take<float>(n * Ph); e->d_pge = w.take<float>(e->Ppge); e->slabs_w = w.take<float>(e->nsplit_w * Ph * Ph);
   e->parts = w.take<double>((long)e->nblk_stats * 3 * Ph);
@@ -786,6 +795,32 @@ static int pge_backward_chunked(gs_gcond* e, int need_param_grads, gs_stream_t s
   return GS_OK;
 }
 
+// the layer-1 activations as a function of U, V (this rank's pair rows start at r_lo) — see gs_panel_a1 in gs_panel.hip
+static gs_panel_a1 pge_a1(const gs_gcond* e) {
+  const float* pp = e->io.pge_params;
+  return gs_panel_a1{e->U, e->V + (long)e->r_lo * e->Ph, (long)e->Ph, pp + e->pb0, e->mu1, e->is1, pp + e->pg1, pp + e->pbe1, e->a1_tab};
+}
+
+// materialise A1 of the current U, V for this rank's pair rows if the forward did not (products that read it as an operand)
+static int ensure_a1(gs_gcond* e, hipStream_t s) {
+  const int n = e->n, Ph = e->Ph, nr = e->r_hi - e->r_lo;
+  const long rows = (long)nr * n;
+  const float* pp = e->io.pge_params;
+  if (e->a1_valid || rows <= 0) return GS_OK;
+  if (Ph == 256)
+    hipLaunchKernelGGL((gs_pge_make_a1_v5_kernel<64>), dim3(gs_cdiv(n, 4 * 8), nr), dim3(256), 0, s, e->U, e->V, pp + e->pb0, e->mu1,
+                       e->is1, pp + e->pg1, pp + e->pbe1, n, e->r_lo, nr, e->A1);
+  else if (Ph == 128)
+    hipLaunchKernelGGL((gs_pge_make_a1_v5_kernel<32>), dim3(gs_cdiv(n, 8 * 8), nr), dim3(256), 0, s, e->U, e->V, pp + e->pb0, e->mu1,
+                       e->is1, pp + e->pg1, pp + e->pbe1, n, e->r_lo, nr, e->A1);
+  else
+    hipLaunchKernelGGL(gs_pge_make_a1_v4_kernel, dim3(gs_cdiv(rows * (Ph / 4), 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0,
+                       e->mu1, e->is1, pp + e->pg1, pp + e->pbe1, n, Ph, e->r_lo, nr, e->A1);
+  GS_LAUNCH_CHECK();
+  e->a1_valid = true;
+  return GS_OK;
+}
+
 extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int part, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   hipStream_t s = (hipStream_t)stream;
@@ -793,7 +828,6 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
   const long n2 = (long)n * n, rows = (long)nr * n;
   const float* X = e->io.feat_syn;
   const float* pp = e->io.pge_params;
-  const int nblk = gs_cdiv(rows > 0 ? rows : 1, e->rows_per_block);
   if (e->pge_chunks > 1 && part != 3) return part == 1 ? pge_forward_chunked(e, stream) : GS_OK;
   if (part == 1) {
     e->fwd_cached = false;
@@ -807,32 +841,40 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
                        e->is1, e->sumU, e->sumV);
     GS_LAUNCH_CHECK();
     if (rows > 0) {
-      if (Ph == 256)
-        hipLaunchKernelGGL((gs_pge_make_a1_v5_kernel<64>), dim3(gs_cdiv(n, 4 * 8), nr), dim3(256), 0, s, e->U, e->V, pp + e->pb0, e->mu1,
-                           e->is1, pp + e->pg1, pp + e->pbe1, n, e->r_lo, nr, e->A1);
-      else if (Ph == 128)
-        hipLaunchKernelGGL((gs_pge_make_a1_v5_kernel<32>), dim3(gs_cdiv(n, 8 * 8), nr), dim3(256), 0, s, e->U, e->V, pp + e->pb0, e->mu1,
-                           e->is1, pp + e->pg1, pp + e->pbe1, n, e->r_lo, nr, e->A1);
-      else
-        hipLaunchKernelGGL(gs_pge_make_a1_v4_kernel, dim3(gs_cdiv(rows * (Ph / 4), 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0,
-                           e->mu1, e->is1, pp + e->pg1, pp + e->pbe1, n, Ph, e->r_lo, nr, e->A1);
-      GS_LAUNCH_CHECK();
-      gs_gemm_desc g = mk(e->A1, Ph, 1, pp + e->pW1, 1, Ph, e->E2, Ph, (int)rows, Ph, Ph);     // E2 = A1 W1^T + b1
-      g.bias = pp + e->pb1;
-      g.colstat = e->statp;            // BN-2 batch statistics come out of the epilogue: no second pass over E2
-      g.prec = e->operand_mode; g.scratch = e->bsplit_main;
+      // E2 = A1 W1^T + b1.  Preferred: A1 is formed in the product's operand path from U, V (gs_panel_forward_a1) and is not
+      // written — feature epochs never read it (the backward regenerates the [A1 > 0] mask the same way); PGE epochs
+      // materialise it lazily for dW1 (ensure_a1).
+      const gs_panel_a1 a1 = pge_a1(e);
+      GS_TRY(gs_panel_a1_table(&a1, Ph, s));       // read by this forward and by the backward's regenerated mask
       const bool probe = e->probing && e->probe_n < 256;
       if (probe) {
         for (int q = 0; q < 2; ++q)
           if (!e->probe_ev[2 * e->probe_n + q]) GS_HIP(hipEventCreate(&e->probe_ev[2 * e->probe_n + q]));
-        GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s));
       }
-      GS_TRY(gs_gemm_f32(&g, stream));
+      e->a1_valid = false;
+      int tiles = 0;
+      if (probe) GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s));
+      const int rc = gs_panel_forward_a1(&a1, n, nr, pp + e->pW1, Ph, pp + e->pb1, e->E2, Ph, Ph, Ph, e->statp, e->operand_mode,
+                                         e->bsplit_main, s);
+      if (rc == GS_OK) {
+        tiles = gs_panel_tiles((int)rows);
+      } else if (rc != GS_ERR_UNSUPPORTED) {
+        return rc;
+      } else {
+        GS_TRY(ensure_a1(e, s));
+        gs_gemm_desc g = mk(e->A1, Ph, 1, pp + e->pW1, 1, Ph, e->E2, Ph, (int)rows, Ph, Ph);
+        g.bias = pp + e->pb1;
+        g.colstat = e->statp;            // BN-2 batch statistics come out of the epilogue: no second pass over E2
+        g.prec = e->operand_mode; g.scratch = e->bsplit_main;
+        if (probe) GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s));
+        GS_TRY(gs_gemm_f32(&g, stream));
+        tiles = gs_gemm_tiles_m(&g);
+      }
       if (probe) {
         GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n + 1], s));
         e->probe_n++;
       }
-      reduce_parts(e, e->statp, gs_gemm_tiles_m(&g), 2, 2, s);
+      reduce_parts(e, e->statp, tiles, 2, 2, s);
       GS_LAUNCH_CHECK();
     } else {
       GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 2 * Ph, s));
@@ -1205,8 +1247,9 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
         GS_LAUNCH_CHECK();
         float* partV = e->dY1;
         float* partU = e->dY1 + (size_t)ncb0 * nr * Ph;
-        const int rc = gs_panel_marginals(e->E2, Ph, e->W1T, Ph, e->A1, Ph, n, nr, Ph, Ph, partU, partV, e->operand_mode, e->bsplit_main,
-                                          &gen, s);
+        const gs_panel_a1 a1 = pge_a1(e);
+        const int rc = gs_panel_marginals(e->E2, Ph, e->W1T, Ph, e->a1_valid ? e->A1 : nullptr, Ph, n, nr, Ph, Ph, partU, partV,
+                                          e->operand_mode, e->bsplit_main, &gen, &a1, s);
         if (rc == GS_OK) {
           GS_TRY(gs_reduce_slabs_f32(e->rowsum_c, partU, (long)n * Ph, nrb0, (long)n * Ph, 0.f, stream));
           GS_TRY(gs_reduce_slabs_f32(e->colsum_r + (long)e->r_lo * Ph, partV, (long)nr * Ph, ncb0, (long)nr * Ph, 0.f, stream));
@@ -1221,6 +1264,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
       GS_LAUNCH_CHECK();
       if (need_param_grads) {
         // dW1 = dE2^T A1  (K = local pair rows split into slabs, fixed-order reduce) ; db1 = colsum(dE2)   [partials]
+        GS_TRY(ensure_a1(e, s));
         const int nsplit = gs_cdiv(rows, e->kchunk_w);
         gs_gemm_desc w = mk(e->dE2, 1, Ph, e->A1, Ph, 1, e->slabs_w, Ph, Ph, Ph, (int)rows);
         w.nb2 = nsplit; w.kchunk = e->kchunk_w; w.sCb2 = (long)Ph * Ph;
@@ -1242,14 +1286,18 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
         float* partV = e->dY1;                                   // [ncb][nr][Ph]
         float* partU = e->dY1 + (size_t)ncb * nr * Ph;           // [nrb][n][Ph]
         int rc = GS_ERR_UNSUPPORTED;
-        if (((size_t)ncb * nr + (size_t)nrb * n) * Ph <= (size_t)n2 * Ph)
-          rc = gs_panel_marginals(e->dE2, Ph, e->W1T, Ph, e->A1, Ph, n, nr, Ph, Ph, partU, partV, e->operand_mode, e->bsplit_main, nullptr, s);
+        if (((size_t)ncb * nr + (size_t)nrb * n) * Ph <= (size_t)n2 * Ph) {
+          const gs_panel_a1 a1 = pge_a1(e);
+          rc = gs_panel_marginals(e->dE2, Ph, e->W1T, Ph, e->a1_valid ? e->A1 : nullptr, Ph, n, nr, Ph, Ph, partU, partV,
+                                  e->operand_mode, e->bsplit_main, nullptr, &a1, s);
+        }
         if (rc == GS_OK) {
           GS_TRY(gs_reduce_slabs_f32(e->rowsum_c, partU, (long)n * Ph, nrb, (long)n * Ph, 0.f, stream));
           GS_TRY(gs_reduce_slabs_f32(e->colsum_r + (long)e->r_lo * Ph, partV, (long)nr * Ph, ncb, (long)nr * Ph, 0.f, stream));
         } else if (rc != GS_ERR_UNSUPPORTED) {
           return rc;
         } else {
+          GS_TRY(ensure_a1(e, s));
           gs_gemm_desc a = mk(e->dE2, Ph, 1, e->W1T, 1, Ph, e->dY1, Ph, (int)rows, Ph, Ph);
           a.mask = e->A1; a.ldmask = Ph;
           a.prec = e->operand_mode; a.scratch = e->bsplit_main;

@@ -49,6 +49,11 @@ struct gs_panel_args {
   // generated A operand (AGEN): A holds E2; the operand is dE2 = BatchNorm-2 + layer-3 backward of it, formed in registers
   const float* gen_c;                // [K][8]: per column k  {is2, -mu2 is2, g2, be2, g2 is2 w2, g2 is2 dbe2 / N, g2 is2 dg2 / N, 0}
   const float* gen_d;                // [rows]: de3 of each pair row
+  // generated layer-1 activations: A1[(r, c)][k] = relu(g1 ((U[c][k] + V[r][k] + b0 - mu1) is1) + be1), the arithmetic of
+  // gs_pge_make_a1_v5_kernel.  FGEN: the A operand of the forward product is formed from U, V (A is not read).  MGEN: the
+  // [A1 > 0] mask of the fused-marginals epilogue is recomputed from them (mask is not read).
+  const float* a1_U; const float* a1_V; long a1_ld;     // U [n][ld], V already offset to this rank's first pair row r
+  const float* a1_c;                 // [Ph][8]: per column {b0, mu1, is1, g1, be1, 0, 0, 0}
   int krep, triage;                  // measurement hooks (gs_panel_debug): K loop repeated krep times; bit 0: no stores;
   unsigned long long* trace;         // bit 1: per-workgroup [hw_id, xcc_id, t_start, t_loop_end, t_end] (s_memrealtime, 10 ns)
 };
@@ -113,28 +118,64 @@ __device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32
 //   sum over c  = 4 registers + the other half-wave  -> partV[cb][r][col]   (written by the wave itself)
 //   sum over r  = 4 registers, then the 4 waves through LDS -> partU[rb][c][col]
 // dY1 (211 MB at ogbn-arxiv) is neither written nor read back; gs_reduce_slabs_f32 adds the partials in a fixed order.
-template <int NT>
+template <int NT, bool MGEN>
 __device__ __forceinline__ void panel_epilogue_marg(const gs_panel_args& p, const f32x16 (&acc)[NT], char* smem, int rb, int cb,
                                                     int wave, int li, int h) {
   constexpr int N = 32 * NT;
   const int n = p.mg_n, nr = p.mg_nr;
-  unsigned moff[16];
+  unsigned moff[MGEN ? 1 : 16], uoff[4], voff[4];
   bool ok[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int rl = 16 * rb + 4 * wave + (r >> 2), c = 8 * cb + (r & 3) + 4 * h;
     ok[r] = rl < nr && c < n;
-    moff[r] = (unsigned)(min(rl, nr - 1) * n + min(c, n - 1)) * (unsigned)p.ldmask + (unsigned)li;
+    if constexpr (!MGEN) moff[r] = (unsigned)(min(rl, nr - 1) * n + min(c, n - 1)) * (unsigned)p.ldmask + (unsigned)li;
+  }
+  if constexpr (MGEN) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uoff[q] = (unsigned)min(8 * cb + q + 4 * h, n - 1) * (unsigned)p.a1_ld + (unsigned)li;
+      voff[q] = (unsigned)min(16 * rb + 4 * wave + q, nr - 1) * (unsigned)p.a1_ld + (unsigned)li;
+    }
   }
   __syncthreads();                                   // every wave is done with the B stages: they become the [4][8][N] scratch
   float* red = reinterpret_cast<float*>(smem);
+  // MGEN: the layer-1 constants of the N output columns go behind the scratch ([N][8] floats); the U / V values of the next
+  // N tile are requested BEFORE this tile's partial sums are stored (a load issued after a store waits for it: vmcnt retires
+  // in order)
+  const f32x4* __restrict__ a1c = reinterpret_cast<const f32x4*>(smem + 32 * N * 4);
+  float un[4], vn[4];
+  if constexpr (MGEN) {
+    f32x4* w = reinterpret_cast<f32x4*>(smem + 32 * N * 4);
+    for (int i = threadIdx.x; i < 2 * N; i += 256) w[i] = reinterpret_cast<const f32x4*>(p.a1_c)[i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { un[q] = p.a1_U[uoff[q]]; vn[q] = p.a1_V[voff[q]]; }
+    __syncthreads();
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    float mk[16], v[16];
+    float v[16];
+    if constexpr (MGEN) {
+      float uc[4], vc[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mk[r] = p.mask[moff[r] + 32u * j];
+      for (int q = 0; q < 4; ++q) { uc[q] = un[q]; vc[q] = vn[q]; }
+      if (j + 1 < NT) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = (ok[r] && mk[r] > 0.f) ? acc[j][r] : 0.f;
+        for (int q = 0; q < 4; ++q) { un[q] = p.a1_U[uoff[q] + 32u * (j + 1)]; vn[q] = p.a1_V[voff[q] + 32u * (j + 1)]; }
+      }
+      const f32x4 c0 = a1c[2 * (32 * j + li)], c1 = a1c[2 * (32 * j + li) + 1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {       // register r: r index (r >> 2) of the wave's 4, c index (r & 3) of the half-wave's 4
+        const float x = ((uc[r & 3] + vc[r >> 2]) + c0[0]) - c0[1];
+        v[r] = (ok[r] && fmaf(c0[3], x * c0[2], c1[0]) > 0.f) ? acc[j][r] : 0.f;
+      }
+    } else {
+      float mk[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mk[r] = p.mask[moff[r] + 32u * j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = (ok[r] && mk[r] > 0.f) ? acc[j][r] : 0.f;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       float sv = (v[4 * q] + v[4 * q + 1]) + (v[4 * q + 2] + v[4 * q + 3]);          // over this half-wave's 4 c
@@ -158,11 +199,13 @@ __device__ __forceinline__ void panel_epilogue_marg(const gs_panel_args& p, cons
 // launch runs in these: 206 116 rows are 1 611 tiles of 128 rows on 512 workgroup slots = 3.15 rounds, and the 75 tiles of the
 // fourth round kept 75 CUs busy for a whole solo tile (43 us of 258) while 181 CUs idled; as 300 tiles of a quarter of the
 // work they take one short round on every CU.  Same arithmetic per output element either way (same k order).
-template <int MODE, int NT, int WN, bool MARG = false, bool AGEN = false>
+template <int MODE, int NT, int WN, bool MARG = false, bool AGEN = false, bool MGEN = false, bool FGEN = false>
 __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, int m0, int stat_row) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128, NTW = NT / WN, ROWS = 128 / WN;
   static_assert(!MARG || WN == 1, "the fused-marginals form uses 128-row tiles");
-  static_assert(!AGEN || MARG, "the generated A operand is used by the fused-marginals form only");
+  static_assert(!AGEN || MARG, "the generated dE2 operand is used by the fused-marginals form only");
+  static_assert(!MGEN || MARG, "the regenerated mask belongs to the fused-marginals epilogue");
+  static_assert(!FGEN || !MARG, "the generated A1 operand is used by the forward product only");
   float* sbias = reinterpret_cast<float*>(smem + 2 * PN_STAGE);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,6 +217,12 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   }
   const int j0 = WN == 1 ? 0 : wave * NTW;            // first N tile of this wave
   const float* __restrict__ arow = p.A + (long)min(row, p.M - 1) * p.lda + 16 * h;
+  int rsel = 0;                                        // FGEN: which of the tile's two V rows this lane's pair row uses
+  if constexpr (FGEN) {     // pair row (r, c) = (row / n, row % n): the lane streams U[c]; V[r] (<= 2 distinct r per tile) sits in LDS
+    const int rr = min(row, p.M - 1), r = rr / p.mg_n;
+    arow = p.a1_U + (long)(rr - r * p.mg_n) * p.a1_ld + 16 * h;
+    rsel = r - m0 / p.mg_n;
+  }
   const char* __restrict__ Bb = (const char*)p.B;
   const int nkb = p.K >> 5;
   const int sw = (li >> 1) & 7;        // read-side swizzle of this lane's B rows (rows 32 j + li: (row >> 1) & 7 == (li >> 1) & 7)
@@ -218,6 +267,19 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
     gen_d = p.gen_d[min(row, p.M - 1)];
   }
 
+  // FGEN: [K][8] layer-1 constants behind the bias row, then the V rows of the tile's (at most two) r
+  const float* __restrict__ vs = reinterpret_cast<const float*>(smem + 2 * PN_STAGE + PN_N * 4 + 256 * 32);
+  if constexpr (FGEN) {
+    f32x4* gw = reinterpret_cast<f32x4*>(smem + 2 * PN_STAGE + PN_N * 4);
+    for (int i = tid; i < 2 * p.K; i += 256) gw[i] = reinterpret_cast<const f32x4*>(p.a1_c)[i];
+    f32x4* vw = reinterpret_cast<f32x4*>(smem + 2 * PN_STAGE + PN_N * 4 + 256 * 32);
+    const int kq = p.K >> 2, r0 = m0 / p.mg_n;
+    for (int i = tid; i < 2 * kq; i += 256) {
+      const int q = i >= kq;
+      vw[i] = *reinterpret_cast<const f32x4*>(p.a1_V + (long)min(r0 + q, p.mg_nr - 1) * p.a1_ld + 4 * (i - q * kq));
+    }
+  }
+
   f32x4 a_cur[4], a_nxt[4];
   stage_b(0, 0);
   load_a(0, a_cur);
@@ -243,6 +305,21 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
         const float y = fmaf(c0[2], xh, c0[3]);
         const float sel = y > 0.f ? gen_d * c1[0] : 0.f;
         a_cur[t >> 2][t & 3] = fmaf(-xh, c1[2], sel - c1[1]);
+      }
+    }
+    if constexpr (FGEN) {
+      // a_cur holds U[c][k], k = 32 kb + 16 h + t: turn it into A1[(r, c)][k] (gs_pge_make_a1_v5_kernel, same arithmetic)
+      const float* __restrict__ vk = vs + rsel * p.K + 32 * kb + 16 * h;
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(vk + 4 * t4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int k = 32 * kb + 16 * h + 4 * t4 + t;
+          const f32x4 c0 = gc[2 * k], c1 = gc[2 * k + 1];
+          const float x = ((a_cur[t4][t] + vv[t]) + c0[0]) - c0[1];
+          a_cur[t4][t] = fmaxf(fmaf(c0[3], x * c0[2], c1[0]), 0.f);
+        }
       }
     }
     if constexpr (MODE == 0) {
@@ -286,7 +363,7 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
 
   if (p.triage & 2) t_loop = __builtin_amdgcn_s_memrealtime();
   if constexpr (MARG) {
-    panel_epilogue_marg<NT>(p, acc, smem, m0 / p.mg_ncb, m0 % p.mg_ncb, wave, li, h);
+    panel_epilogue_marg<NT, MGEN>(p, acc, smem, m0 / p.mg_ncb, m0 % p.mg_ncb, wave, li, h);
     return;
   }
   // epilogue: straight-line code per (mask?, interior tile?) combination — see panel_epilogue
@@ -343,11 +420,30 @@ __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) 
   else panel_tile<MODE, NT, 4>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
 }
 
-template <int MODE, int NT, bool AGEN>
+template <int MODE, int NT, bool AGEN, bool MGEN>
 __global__ __launch_bounds__(256, 2) void gs_panel_marg_kernel(gs_panel_args p) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;
   __shared__ __attribute__((aligned(16))) char smem[2 * PN_STAGE + PN_N * 4 + (AGEN ? 256 * 32 : 0)];
-  panel_tile<MODE, NT, 1, true, AGEN>(p, smem, blockIdx.x, 0);
+  panel_tile<MODE, NT, 1, true, AGEN, MGEN>(p, smem, blockIdx.x, 0);
+}
+
+// forward product with the generated A1 operand: E2 = A1(U, V) W1^T + b1 (+ BN-2 column sums); same tiling as gs_panel_gemm_kernel
+template <int MODE, int NT>
+__global__ __launch_bounds__(256, 2) void gs_panel_fwdgen_kernel(gs_panel_args p) {
+  constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * PN_STAGE + PN_N * 4 + 256 * 32 + 2 * 256 * 4];
+  const int b = blockIdx.x;
+  if (b < p.n_full) panel_tile<MODE, NT, 1, false, false, false, true>(p, smem, b * PN_BM, b);
+  else panel_tile<MODE, NT, 4, false, false, false, true>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
+}
+
+// a1_c[k][8] from the layer-0 bias and the BatchNorm-1 quantities (one thread per column)
+__global__ void gs_panel_a1_consts_kernel(const float* __restrict__ b0, const float* __restrict__ mu1, const float* __restrict__ is1,
+                                          const float* __restrict__ g1, const float* __restrict__ be1, int K, float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float* o = out + 8 * k;
+  o[0] = b0[k]; o[1] = mu1[k]; o[2] = is1[k]; o[3] = g1[k]; o[4] = be1[k]; o[5] = o[6] = o[7] = 0.f;
 }
 
 // gen_c[k][8] from the BatchNorm-2 / layer-3 quantities (one thread per column)
@@ -475,9 +571,71 @@ extern "C" int gs_gemm_set_panel_marg(int level) {
 // With `gen` (7 device arrays mu2, is2, g2, be2, w2, dbe2, dg2 of length K, de3 per pair row, total pair rows N_total and an
 // [K][8] float scratch table) the first operand is E2 and dE2 is formed inside the kernel (no dE2 pass, no dE2 buffer).
 struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; };
+// Layer-1 activations as a function of U [n][ld], V [n][ld] (V + r_lo * ld is passed), the layer-0 bias and the BatchNorm-1
+// quantities (5 arrays of the hidden width) and an [width][8] float scratch table: with `a1` the marginals' [A1 > 0] mask is
+// recomputed from them (`mask` may be null), and gs_panel_forward_a1 forms the A operand of E2 = A1 W1^T + b1 from them.
+struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; };
+
+static int g_panel_a1gen = 1;
+// measurement knob: 0 = always materialise A1 (round-2 first form), 1 (default) = generate it in the operand / mask path
+extern "C" int gs_gemm_set_panel_a1gen(int on) {
+  g_panel_a1gen = on != 0;
+  return GS_OK;
+}
+
+// fills a1->table for `width` hidden columns: call once per (theta_PGE, BatchNorm-1 statistics) — i.e. after every
+// gs_pge_bn1_stats — before gs_panel_forward_a1 / gs_panel_marginals use the descriptor
+int gs_panel_a1_table(const gs_panel_a1* a1, int width, hipStream_t s) {
+  if (!a1 || !a1->table) return GS_ERR_ARG;
+  hipLaunchKernelGGL(gs_panel_a1_consts_kernel, dim3(gs_cdiv(width, 64)), dim3(64), 0, s, a1->b0, a1->mu1, a1->is1, a1->g1, a1->be1,
+                     width, a1->table);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// engine-internal: E2 [nr * n][N] = A1 W^T + bias with A1 generated from `a1` (K = its width), column statistics per tile as in
+// gs_gemm_desc.colstat ([gs_panel_tiles(nr * n)][2][N]).  GS_ERR_UNSUPPORTED when the shape is not covered (the caller then
+// materialises A1 and takes the plain product).
+int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, long ldw, const float* bias, float* C, long ldc, int N,
+                        int K, float* colstat, int prec, void* scratch, hipStream_t s) {
+  if (!g_panel_a1gen || !g_panel_enabled || !a1 || !a1->table || n < 128 || nr < 1) return GS_ERR_UNSUPPORTED;   // (<= 2 r per tile)
+  if ((N != 256 && N != 128) || K < 32 || K > 256 || (K & 31) || (ldw & 3) || (a1->ld & 3)) return GS_ERR_UNSUPPORTED;
+  if ((double)nr * n * (double)ldc >= 4294967296.0 || (prec != 0 && !scratch) || prec < 0 || prec > 2) return GS_ERR_UNSUPPORTED;
+  if ((((uintptr_t)a1->U | (uintptr_t)a1->V | (uintptr_t)W) & 15)) return GS_ERR_UNSUPPORTED;
+  gs_panel_args a;
+  memset(&a, 0, sizeof(a));
+  a.M = nr * n; a.K = K; a.C = C; a.ldc = ldc; a.bias = bias; a.colstat = colstat; a.krep = 1;
+  a.mg_n = n; a.mg_nr = nr;
+  a.a1_U = a1->U; a.a1_V = a1->V; a.a1_ld = a1->ld; a.a1_c = a1->table;
+  a.A = a1->U; a.lda = a1->ld;
+  int nf, nn;
+  panel_split(a.M, &nf, &nn);
+  a.n_full = nf;
+  const dim3 grid(nf + nn), block(256);
+  if (prec == 0) {
+    a.B = W; a.ldb_bytes = ldw * 4;
+  } else {
+    hipLaunchKernelGGL(gs_panel_split_b_kernel, dim3(gs_cdiv((long)N * K, 256)), dim3(256), 0, s, W, ldw, N, K, (__bf16*)scratch);
+    a.B = scratch; a.ldb_bytes = (long)K * 4;
+  }
+#define GS_FWD_LAUNCH(MODE_)                                                                    \
+  do {                                                                                          \
+    if (N == 256) hipLaunchKernelGGL((gs_panel_fwdgen_kernel<MODE_, 8>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((gs_panel_fwdgen_kernel<MODE_, 4>), grid, block, 0, s, a);          \
+  } while (0)
+  if (prec == 0) GS_FWD_LAUNCH(0);
+  else if (prec == 1) GS_FWD_LAUNCH(1);
+  else GS_FWD_LAUNCH(2);
+#undef GS_FWD_LAUNCH
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
 
 int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, const float* mask, long ldmask, int n, int nr, int N,
-                       int K, float* partU, float* partV, int prec, void* scratch, const gs_panel_gen* gen, hipStream_t s) {
+                       int K, float* partU, float* partV, int prec, void* scratch, const gs_panel_gen* gen, const gs_panel_a1* a1,
+                       hipStream_t s) {
+  if (a1 && (!g_panel_a1gen || !a1->table || (a1->ld & 3))) a1 = nullptr;
+  if (!a1 && !mask) return GS_ERR_UNSUPPORTED;
   // (generated operand: fp32 at N = 256 — the bf16 conversions next to it need more than 256 registers there — any mode at N = 128)
   if (gen && (g_panel_marg < 2 || K > 256 || !gen->table || (N == 256 && prec != 0))) return GS_ERR_UNSUPPORTED;
   if (!g_panel_marg || !g_panel_enabled || (N != 256 && N != 128) || K < 32 || (K & 31) || (lda & 3) || (ldw & 3)) return GS_ERR_UNSUPPORTED;
@@ -495,6 +653,9 @@ int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, con
                        gen->dbe2, gen->dg2, 1.f / (float)gen->total_rows, K, gen->table);
     a.gen_c = gen->table; a.gen_d = gen->de3;
   }
+  if (a1) {
+    a.a1_U = a1->U; a.a1_V = a1->V; a.a1_ld = a1->ld; a.a1_c = a1->table;
+  }
   const dim3 grid((unsigned)(gs_cdiv(nr, 16) * a.mg_ncb)), block(256);
   if (prec == 0) {
     a.B = W; a.ldb_bytes = ldw * 4;
@@ -504,10 +665,14 @@ int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, con
   }
 #define GS_MARG_LAUNCH(MODE_)                                                                                        \
   do {                                                                                                               \
-    if (N == 256 && gen) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, true>), grid, block, 0, s, a);           \
-    else if (N == 256) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, false>), grid, block, 0, s, a);            \
-    else if (gen) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 4, true>), grid, block, 0, s, a);                  \
-    else hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 4, false>), grid, block, 0, s, a);                          \
+    if (N == 256 && gen && a1) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, true, true>), grid, block, 0, s, a);       \
+    else if (N == 256 && gen) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, true, false>), grid, block, 0, s, a);       \
+    else if (N == 256 && a1) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, false, true>), grid, block, 0, s, a);        \
+    else if (N == 256) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, false, false>), grid, block, 0, s, a);             \
+    else if (gen && a1) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 4, true, true>), grid, block, 0, s, a);              \
+    else if (gen) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 4, true, false>), grid, block, 0, s, a);                   \
+    else if (a1) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 4, false, true>), grid, block, 0, s, a);                    \
+    else hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 4, false, false>), grid, block, 0, s, a);                           \
   } while (0)
   if (prec == 0) GS_MARG_LAUNCH(0);
   else if (prec == 1) GS_MARG_LAUNCH(1);

@@ -131,3 +131,42 @@ def test_panel_needs_scratch_for_split_modes(E):
     _lib.check(_lib.lib().gs_gemm_f32(C.byref(d), _lib.stream()))
     ref = A.double() @ W.double().T
     assert err(out, ref) <= 2e-6
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("param_grads", [False, True])
+def test_generated_a1_operand_and_mask_are_bitwise_the_materialised_form(mode, param_grads):
+    """PGE forward with A1 formed in the operand path of E2 = A1 W1^T + b1 (gs_panel_fwdgen_kernel) and the [A1 > 0] mask of the
+    fused marginals recomputed from U, V — against the same engine with A1 materialised by gs_pge_make_a1 (knob
+    gs_gemm_set_panel_a1gen(0)): same arithmetic per element and same k order, so pair scores, d/dX~ and d/dtheta_PGE must be
+    IDENTICAL, in feature epochs (dE2 generated too) and PGE epochs (A1 materialised lazily for dW1)."""
+    import bench
+    from graphslim_amd import _lib
+    L = _lib.lib()
+    p = bench.build_problem("ogbn-arxiv", seed=1)
+    got = {}
+    for on in (1, 0):
+        L.gs_gemm_set_panel_a1gen(on)
+        try:
+            eng = bench.make_engine(p, DEV)
+            eng.set_operand_mode(mode)
+            bench.init_state(p, eng)
+            torch.manual_seed(123)
+            bench.new_model(p, eng)
+            eng.stage_sample()
+            eng.stage_real_grads()
+            eng.stage_pge_forward(False)
+            eng.stage_syn_match()
+            eng.syn_finish()
+            eng.stage_pge_backward(param_grads, True)
+            torch.cuda.synchronize()
+            n, d = eng.feat_syn.shape
+            got[on] = (eng.buffer("e3").clone(), eng.buffer("d_feat").clone(), eng.buffer("d_pge").clone())
+            del eng
+        finally:
+            L.gs_gemm_set_panel_a1gen(1)
+    assert torch.isfinite(got[1][0]).all() and got[1][1].abs().max() > 0
+    for a, b, what in zip(got[1], got[0], ("pair scores e3", "d_feat", "d_pge")):
+        if what == "d_pge" and not param_grads:
+            continue
+        assert torch.equal(a, b), (what, float((a - b).abs().max()), float(b.abs().max()))

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Launches only the row-panel kernel at the PGE layer-2 shape (5 x fp32, 5 x bf16x3, 5 x bf16) — for rocprofv3 --pmc passes."""
+"""Launches the row-panel kernels at the PGE layer-2 shape — for rocprofv3 --pmc passes: the plain product (5 x fp32,
+5 x bf16x3, 5 x bf16), then, through an ogbn-arxiv-shaped engine, the forward with the generated A1 operand
+(gs_panel_fwdgen_kernel) and the fused-marginals backward with generated dE2 / regenerated mask (gs_panel_marg_kernel),
+5 x per operand mode."""
 import ctypes as C
 import os
 import sys
@@ -26,4 +29,19 @@ for prec in (0, 1, 2):
     for _ in range(5):
         _lib.check(L.gs_gemm_f32(C.byref(d), _lib.stream()))
 torch.cuda.synchronize()
-print("probe done", float(out[0, 0]))
+del a, out
+import bench  # noqa: E402
+p = bench.build_problem("ogbn-arxiv", seed=1)
+eng = bench.make_engine(p, dev)
+bench.init_state(p, eng)
+bench.new_model(p, eng)
+eng.outer_step(10)
+for mode in ("f32", "bf16x3", "bf16"):
+    eng.set_operand_mode(mode)
+    for _ in range(5):
+        eng.pge_forward_part(False, 1)
+        eng.pge_forward_part(False, 2)
+        eng.pge_backward_part(False, True, 1)
+        eng.pge_backward_part(False, True, 2)
+torch.cuda.synchronize()
+print("probe done")
