@@ -53,13 +53,13 @@ _lib = None
 
 # every symbol include/gslim.h declares (tests/test_abi.py checks the list against the header)
 SYMBOLS = [
-    "gs_version", "gs_last_error", "gs_gemm_f32", "gs_gemm_group_f32", "gs_gemm_tiles_m", "gs_gemm_route", "gs_gemm_set_tuning", "gs_gemm_set_small", "gs_gemm_set_panel", "gs_gemm_set_edge_kernel", "gs_gemm_set_panel_narrow_tail", "gs_reduce_slabs_f32", "gs_reduce_slabs_batched_f32",
+    "gs_version", "gs_last_error", "gs_gemm_f32", "gs_gemm_group_f32", "gs_gemm_tiles_m", "gs_gemm_route", "gs_gemm_set_tuning", "gs_gemm_set_small", "gs_gemm_set_panel", "gs_gemm_set_edge_kernel", "gs_gemm_set_panel_narrow_tail", "gs_gemm_set_panel_marg", "gs_gemm_set_panel_a1gen", "gs_panel_debug", "gs_reduce_slabs_f32", "gs_reduce_slabs_batched_f32",
     "gs_spmm_csr_f32", "gs_gather_rows_f32", "gs_sample_blocks", "gs_dense_gcn_norm_fwd", "gs_dense_gcn_norm_bwd",
     "gs_adam_step_f32", "gs_gcond_workspace_bytes", "gs_gcond_create", "gs_gcond_destroy", "gs_gcond_new_epoch",
     "gs_gcond_set_blocks", "gs_gcond_outer_step", "gs_gcond_outer_step_ex", "gs_gcond_set_identity_structure", "gs_gcond_read_loss", "gs_gcond_stage_sample",
     "gs_gcond_stage_real_grads", "gs_gcond_stage_real_async", "gs_gcond_stage_pge_forward", "gs_gcond_stage_syn_match",
     "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer",
-    "gs_gcond_get_blocks", "gs_gcond_set_shard", "gs_gcond_set_overlap", "gs_gcond_set_operand_mode", "gs_gcond_set_forward_reuse", "gs_gcond_probe", "gs_gcond_probe_read", "gs_gcond_invalidate_forward",
+    "gs_gcond_get_blocks", "gs_gcond_set_shard", "gs_gcond_set_overlap", "gs_gcond_set_folded_reductions", "gs_gcond_set_operand_mode", "gs_gcond_set_forward_reuse", "gs_gcond_probe", "gs_gcond_probe_read", "gs_gcond_invalidate_forward",
     "gs_gcond_forward_cached", "gs_gcond_adopt_cached_forward", "gs_gcond_stage_pge_forward_part", "gs_gcond_stage_pge_backward_part",
     "gs_gcond_stage_syn_finish", "gs_gcond_stage_inner_steps", "gs_bias_act_f32", "gs_log_softmax_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
 ]
@@ -89,6 +89,9 @@ def lib():
     L.gs_gemm_set_panel.argtypes = [i]
     L.gs_gemm_set_edge_kernel.argtypes = [i]
     L.gs_gemm_set_panel_narrow_tail.argtypes = [i]
+    L.gs_gemm_set_panel_marg.argtypes = [i]
+    L.gs_gemm_set_panel_a1gen.argtypes = [i]
+    L.gs_panel_debug.argtypes = [i, i]
     L.gs_reduce_slabs_f32.argtypes = [vp, vp, l, i, l, f, vp]
     L.gs_reduce_slabs_batched_f32.argtypes = [vp, l, vp, l, i, l, i, f, vp]
     L.gs_spmm_csr_f32.argtypes = [vp, vp, vp, i, vp, l, i, vp, l, vp]

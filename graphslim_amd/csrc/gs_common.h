@@ -39,6 +39,16 @@ void gs_set_error(const char* fmt, ...);
 
 __host__ __device__ static inline int gs_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// One row [8] of the constants table of the generated dE2 operand (gs_panel.hip, panel_tile<..., AGEN>): per hidden column
+// {is2, -mu2 is2, g2, be2, g2 is2 w2, g2 is2 dbe2 / N, g2 is2 dg2 / N, 0}.  Written by gs_panel_gen_consts_kernel or, in the
+// engine's backward, by gs_pge_bwd_prep_kernel — ONE definition so that both produce the same bits.
+__device__ static inline void gs_panel_gen_row(float mu2, float is2, float g2, float be2, float w2, float dbe2, float dg2, float invN,
+                                               float* o) {
+  const float gi = g2 * is2;
+  o[0] = is2; o[1] = -mu2 * is2; o[2] = g2; o[3] = be2;
+  o[4] = gi * w2; o[5] = gi * dbe2 * invN; o[6] = gi * dg2 * invN; o[7] = 0.f;
+}
+
 // ---- device helpers ------------------------------------------------------------------------
 __device__ __forceinline__ float gs_wave_sum(float v) {
 #pragma unroll

@@ -11,14 +11,13 @@
 extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int, long, int, float, gs_stream_t);
 extern "C" int gs_reduce_slabs_f32(float*, const float*, long, int, long, float, gs_stream_t);
 int gs_reduce_slabs_active(float*, long, const float*, long, int, long, int, const int*, int, gs_stream_t);
-struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; };
+struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; int table_ready; };
 struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; };
 int gs_panel_marginals(const float*, long, const float*, long, const float*, long, int, int, int, int, float*, float*, int, void*,
                        const gs_panel_gen*, const gs_panel_a1*, hipStream_t);
 int gs_panel_forward_a1(const gs_panel_a1*, int, int, const float*, long, const float*, float*, long, int, int, float*, int, void*,
                         hipStream_t);
 int gs_panel_tiles(int);
-int gs_panel_a1_table(const gs_panel_a1*, int, hipStream_t);
 
 namespace {
 
@@ -113,6 +112,7 @@ struct gs_gcond {
   // operand precision of the three row-panel products (E2 = A1 W1^T, dY1 = dE2 W1, H1full = X W1): gs_gemm_desc.prec
   int operand_mode;
   float *bsplit_main, *bsplit_aux;   // pre-split B operands (bf16 hi | lo) of the products on the main / the real-side stream
+  int bn2_slices, l3_slices;         // slices of e->sums2 the consumer of a deferred last reduction stage adds up (1: e->sums is final)
   float* a1_tab;                     // [Ph][8] layer-0 bias / BatchNorm-1 constants of the generated A1 operand and mask (gs_panel.hip)
   bool a1_valid;                     // A1 holds the activations of the current U, V (false: the forward formed them in registers only)
   float* gen_tab;                    // [Ph][8] folded BatchNorm-2 / layer-3 constants of the generated dE2 operand (gs_panel.hip)
@@ -229,6 +229,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->gen_tab = w.take<float>(Ph * 8);
   e->a1_tab = w.take<float>(Ph * 8);
   e->a1_valid = false;
+  e->bn2_slices = e->l3_slices = 1;
   e->chunk_fwd = w.take<float>((long)e->pge_chunks * 4 * Ph); e->chunk_bwd = w.take<float>((long)e->pge_chunks * 5 * Ph);
   e->dV = w.take<float>(n * Ph); e->d_pge = w.take<float>(e->Ppge); e->slabs_w = w.take<float>(e->nsplit_w * Ph * Ph);
   e->parts = w.take<double>((long)e->nblk_stats * 3 * Ph);
@@ -442,7 +443,9 @@ extern "C" int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* b, gs_stream_t 
 
 // sums[q][k] = sum over nblk partial blocks (fp64, fixed order): two stages so that the first one fills the chip
 template <class T>
-static void reduce_parts(gs_gcond* e, const T* part, int nblk, int nq, int nq_out, hipStream_t s) {
+static int reduce_parts(gs_gcond* e, const T* part, int nblk, int nq, int nq_out, hipStream_t s, bool defer_last = false) {
+  // Returns the number of slices left in e->sums2 ([slice][nq][Ph]) when `defer_last` asks for the second stage to be folded
+  // into the consumer (gs_sum_slices, same order = same bits), else 1 with the result in e->sums.
   const int Ph = e->Ph;
   const int S = nblk > 64 ? 32 : 1;
   dim3 g1(gs_cdiv(Ph, 32), nq_out, S), g2(gs_cdiv(Ph, 32), nq_out, 1);
@@ -452,7 +455,9 @@ static void reduce_parts(gs_gcond* e, const T* part, int nblk, int nq, int nq_ou
   else
     hipLaunchKernelGGL(gs_sum_parts_f32_kernel, g1, dim3(256), 0, s, (const float*)part, nblk, nq, Ph, out1);
   // stage 1 writes [slice][nq_out... laid out with stride nq]: it used nq as the row stride of its OUTPUT too
+  if (S > 1 && defer_last) return S;
   if (S > 1) hipLaunchKernelGGL(gs_sum_parts_kernel, g2, dim3(256), 0, s, (const double*)e->sums2, S, nq, Ph, e->sums);
+  return 1;
 }
 
 // column sums of nbatch [rows x cols] matrices: chunked partials + fixed-order reduce (no atomics)
@@ -486,6 +491,14 @@ extern "C" int gs_gcond_set_shard(gs_gcond* e, int c_lo, int c_hi, int r_lo, int
 
 static inline bool sharded_c(const gs_gcond* e) { return e->c_lo != 0 || e->c_hi != e->C; }
 static inline bool sharded_r(const gs_gcond* e) { return e->r_lo != 0 || e->r_hi != e->n; }
+
+static int g_defer_last_stage = 1;
+// measurement knob: 1 (default) = the last stage of the BN-2 / layer-3 statistics reductions is folded into its consumer
+// launch (unsharded engines); 0 = separate launch.  Same bits either way.
+extern "C" int gs_gcond_set_folded_reductions(int on) {
+  g_defer_last_stage = on != 0;
+  return GS_OK;
+}
 
 // gs_blocks view of the classes [c_lo, c_hi)
 static gs_blocks blocks_view(const gs_gcond* e) {
@@ -702,7 +715,7 @@ static int pge_forward_chunked(gs_gcond* e, gs_stream_t stream) {
     hipLaunchKernelGGL(gs_pge_chunk_e1_stats_kernel, dim3(nblk), dim3(256), 0, s, e->U, e->V, pp + e->pb0, n, Ph, k0, cnt,
                        e->rows_per_block, e->parts);
     reduce_parts(e, e->parts, nblk, 2, 2, s);
-    hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, cnt, Ph, mu1, is1);
+    hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, 1, cnt, Ph, mu1, is1);
     hipLaunchKernelGGL(gs_pge_make_a1_flat_kernel, dim3(gs_cdiv(cnt * (Ph / 4), 256)), dim3(256), 0, s, e->U, e->V, pp + e->pb0, mu1,
                        is1, pp + e->pg1, pp + e->pbe1, n, Ph, k0, cnt, e->A1 + k0 * Ph);
     GS_LAUNCH_CHECK();
@@ -712,7 +725,7 @@ static int pge_forward_chunked(gs_gcond* e, gs_stream_t stream) {
     g.prec = e->operand_mode; g.scratch = e->bsplit_main;
     GS_TRY(gs_gemm_f32(&g, stream));
     reduce_parts(e, e->statp, gs_gemm_tiles_m(&g), 2, 2, s);
-    hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, cnt, Ph, mu2, is2);
+    hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, 1, cnt, Ph, mu2, is2);
     hipLaunchKernelGGL(gs_pge_layer3_kernel, dim3(gs_cdiv(cnt, 4)), dim3(256), 0, s, e->E2 + k0 * Ph, mu2, is2, pp + e->pg2,
                        pp + e->pbe2, pp + e->pw2, pp + e->pb2, cnt, Ph, e->e3 + k0);
     GS_LAUNCH_CHECK();
@@ -838,14 +851,13 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       GS_TRY(gs_gemm_group_f32(uv, 2, stream));          // independent: one launch
     }
     hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 32)), dim3(1024), 0, s, e->U, e->V, pp + e->pb0, n, Ph, e->mu1,
-                       e->is1, e->sumU, e->sumV);
+                       e->is1, e->sumU, e->sumV, pp + e->pg1, pp + e->pbe1, e->a1_tab);   // (+ the table of the generated A1)
     GS_LAUNCH_CHECK();
     if (rows > 0) {
       // E2 = A1 W1^T + b1.  Preferred: A1 is formed in the product's operand path from U, V (gs_panel_forward_a1) and is not
       // written — feature epochs never read it (the backward regenerates the [A1 > 0] mask the same way); PGE epochs
       // materialise it lazily for dW1 (ensure_a1).
       const gs_panel_a1 a1 = pge_a1(e);
-      GS_TRY(gs_panel_a1_table(&a1, Ph, s));       // read by this forward and by the backward's regenerated mask
       const bool probe = e->probing && e->probe_n < 256;
       if (probe) {
         for (int q = 0; q < 2; ++q)
@@ -874,15 +886,18 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
         GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n + 1], s));
         e->probe_n++;
       }
-      reduce_parts(e, e->statp, tiles, 2, 2, s);
+      // (unsharded: the last reduction stage is folded into gs_bn2_from_sums; sharded ranks exchange e->sums in between)
+      e->bn2_slices = reduce_parts(e, e->statp, tiles, 2, 2, s, g_defer_last_stage && !sharded_r(e));
       GS_LAUNCH_CHECK();
     } else {
       GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 2 * Ph, s));
+      e->bn2_slices = 1;
     }
     return GS_OK;
   }
   if (part == 2) {
-    hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, n2, Ph, e->mu2, e->is2);
+    hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->bn2_slices > 1 ? e->sums2 : e->sums,
+                       e->bn2_slices, n2, Ph, e->mu2, e->is2);
     if (sharded_r(e)) GS_HIP(hipMemsetAsync(e->e3, 0, sizeof(float) * n2, s));
     if (rows > 0) {
       float* e3o = e->e3 + (long)e->r_lo * n;
@@ -1218,16 +1233,22 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
       else
         hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(nblk), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2, pp + e->pg2,
                            pp + e->pbe2, pp + e->pw2, rows, Ph, e->rows_per_block, e->parts);
-      reduce_parts(e, e->parts, nblk, 3, 3, s);
+      e->l3_slices = reduce_parts(e, e->parts, nblk, 3, 3, s, g_defer_last_stage && !sharded_r(e));
     } else {
       GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 3 * Ph, s));
+      e->l3_slices = 1;
     }
     GS_LAUNCH_CHECK();
     return GS_OK;
   }
   if (part == 2) {
-    hipLaunchKernelGGL(gs_sums_to_float_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->sums, 3, Ph, g + e->pw2, g + e->pbe2,
-                       g + e->pg2);
+    // one launch: the layer-3 statistics as floats (dw2, dbe2, dg2), the constants table of the generated dE2 operand where
+    // that form applies (feature epochs), and W1^T
+    const bool want_gen = !need_param_grads && Ph <= 256 && rows > 0;
+    hipLaunchKernelGGL(gs_pge_bwd_prep_kernel, dim3(gs_cdiv(Ph, 32), gs_cdiv(Ph, 32)), dim3(32, 8), 0, s,
+                       e->l3_slices > 1 ? e->sums2 : e->sums, e->l3_slices, Ph, g + e->pw2, g + e->pbe2, g + e->pg2, e->mu2, e->is2,
+                       pp + e->pg2, pp + e->pbe2, pp + e->pw2, 1.f / (float)n2, want_gen ? e->gen_tab : (float*)nullptr, pp + e->pW1,
+                       e->W1T);
     if (sharded_r(e)) GS_HIP(hipMemsetAsync(e->ar_marg, 0, sizeof(float) * 2 * (long)n * Ph, s));
     if (need_param_grads) {
       hipLaunchKernelGGL(gs_sum_kernel, dim3(1), dim3(1024), 0, s, e->de3, n2, g + e->pb2);   // db2 = sum de3 (replicated)
@@ -1240,11 +1261,8 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
       // and shapes the generated form does not cover materialise it.
       const int nrb0 = gs_cdiv(nr, 16), ncb0 = gs_cdiv(n, 8);
       bool fused_done = false;
-      if (!need_param_grads && Ph <= 256) {
-        gs_panel_gen gen = {e->mu2, e->is2, pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, de3l, (long)n2, e->gen_tab};
-        hipLaunchKernelGGL(gs_transpose_small_kernel, dim3(gs_cdiv(Ph, 32), gs_cdiv(Ph, 32)), dim3(32, 8), 0, s, pp + e->pW1, Ph, Ph,
-                           e->W1T);
-        GS_LAUNCH_CHECK();
+      if (want_gen) {
+        gs_panel_gen gen = {e->mu2, e->is2, pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, de3l, (long)n2, e->gen_tab, 1};
         float* partV = e->dY1;
         float* partU = e->dY1 + (size_t)ncb0 * nr * Ph;
         const gs_panel_a1 a1 = pge_a1(e);
@@ -1276,12 +1294,9 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
                            (float*)nullptr, (float*)nullptr);
         GS_LAUNCH_CHECK();
       }
-      {  // dY1 = (dE2 W1) * [A1 > 0] is needed only through its two marginals.  W1 is transposed first (256 KB, one tiny
-         // launch) so that both operands are k-contiguous.  Preferred route: the row-panel kernel's fused-marginals form
-         // (pair-patch tiles, gs_panel.hip) — dY1 is never materialised, its buffer holds the partial sums instead.
-        hipLaunchKernelGGL(gs_transpose_small_kernel, dim3(gs_cdiv(Ph, 32), gs_cdiv(Ph, 32)), dim3(32, 8), 0, s, pp + e->pW1, Ph, Ph,
-                           e->W1T);
-        GS_LAUNCH_CHECK();
+      {  // dY1 = (dE2 W1) * [A1 > 0] is needed only through its two marginals (W1^T from the prep launch above: both
+         // operands k-contiguous).  Preferred route: the row-panel kernel's fused-marginals form (pair-patch tiles,
+         // gs_panel.hip) — dY1 is never materialised, its buffer holds the partial sums instead.
         const int nrb = gs_cdiv(nr, 16), ncb = gs_cdiv(n, 8);
         float* partV = e->dY1;                                   // [ncb][nr][Ph]
         float* partU = e->dY1 + (size_t)ncb * nr * Ph;           // [nrb][n][Ph]

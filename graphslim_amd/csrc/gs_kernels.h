@@ -490,7 +490,11 @@ __global__ __launch_bounds__(256) void gs_make_bmat_kernel(const int* __restrict
 __global__ __launch_bounds__(1024) void gs_pge_bn1_stats_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                                 const float* __restrict__ b0, int n, int Ph,
                                                                 float* __restrict__ mu1, float* __restrict__ is1,
-                                                                float* __restrict__ sumU, float* __restrict__ sumV) {
+                                                                float* __restrict__ sumU, float* __restrict__ sumV,
+                                                                const float* __restrict__ g1, const float* __restrict__ be1,
+                                                                float* __restrict__ a1_tab) {
+  // a1_tab (optional): [Ph][8] = {b0, mu1, is1, g1, be1, 0, 0, 0} per column — the constants of the generated layer-1
+  // activations (gs_panel.hip, gs_panel_a1), written here so that no separate table launch is needed
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int k = min(blockIdx.x * 32 + tx, Ph - 1);
   __shared__ double sh[2][GS_BN1_RG][32];
@@ -541,6 +545,10 @@ __global__ __launch_bounds__(1024) void gs_pge_bn1_stats_kernel(const float* __r
     is1[k] = (float)(1.0 / sqrt(vu / n + vv / n + 1e-5));
     sumU[k] = (float)su;
     sumV[k] = (float)sv;
+    if (a1_tab) {
+      float* o = a1_tab + 8 * k;
+      o[0] = b0[k]; o[1] = mu1[k]; o[2] = is1[k]; o[3] = g1[k]; o[4] = be1[k]; o[5] = o[6] = o[7] = 0.f;
+    }
   }
 }
 
@@ -616,11 +624,24 @@ __global__ __launch_bounds__(256) void gs_col_stats_kernel(const float* __restri
   }
 }
 // mean / inverse std of BN-2 from the (all-reduced) column sums:  sums = [sum x | sum x^2], fp64
-__global__ void gs_bn2_from_sums_kernel(const double* __restrict__ sums, long rows, int Ph, float* __restrict__ mu2,
+// sum of `slices` partial sums laid out [slice][nq][Ph], in the order gs_sum_parts_kernel adds them (8 strided groups, then
+// the groups in order) — so a consumer that folds the last reduction stage into itself gives the bits of the two-launch form
+__device__ __forceinline__ double gs_sum_slices(const double* __restrict__ p, int slices, int nq, int Ph, int q, int k) {
+  if (slices <= 1) return p[(long)q * Ph + k];
+  double v[32];          // (reduce_parts leaves at most 32 slices) all loads in flight at once, then the fixed-order adds
+#pragma unroll
+  for (int b = 0; b < 32; ++b) v[b] = b < slices ? p[((long)b * nq + q) * Ph + k] : 0.0;
+  double t = 0;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) t += ((v[g] + v[g + 8]) + v[g + 16]) + v[g + 24];
+  return t;
+}
+
+__global__ void gs_bn2_from_sums_kernel(const double* __restrict__ sums, int slices, long rows, int Ph, float* __restrict__ mu2,
                                         float* __restrict__ is2) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= Ph) return;
-  double m = sums[k] / rows, v = sums[Ph + k] / rows - m * m;
+  double m = gs_sum_slices(sums, slices, 2, Ph, 0, k) / rows, v = gs_sum_slices(sums, slices, 2, Ph, 1, k) / rows - m * m;
   if (v < 0) v = 0;
   mu2[k] = (float)m;
   is2[k] = (float)(1.0 / sqrt(v + 1e-5));
@@ -1040,6 +1061,36 @@ __global__ void gs_transpose_small_kernel(const float* __restrict__ in, int rows
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     const int c = c0 + j, r = r0 + threadIdx.x;
     if (c < cols && r < rows) out[(long)c * rows + r] = t[threadIdx.x][j];
+  }
+}
+// PGE backward, start of part 2 — ONE launch for what were four: the last stage of the layer-3 statistics reduction
+// (sums -> dw2, dbe2, dg2 as floats), the constants table of the generated dE2 operand (optional), and W1^T (both operands
+// of the marginals product k-contiguous).  grid (ceil(Ph/32), ceil(Ph/32)), block (32, 8): every block transposes one 32x32
+// tile of W1; the blocks of row 0 also finish 32 columns of the statistics.
+__global__ void gs_pge_bwd_prep_kernel(const double* __restrict__ sums, int slices, int Ph, float* __restrict__ dw2,
+                                       float* __restrict__ dbe2, float* __restrict__ dg2, const float* __restrict__ mu2,
+                                       const float* __restrict__ is2, const float* __restrict__ g2, const float* __restrict__ be2,
+                                       const float* __restrict__ w2, float invN, float* __restrict__ gen_table,
+                                       const float* __restrict__ W1, float* __restrict__ W1T) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    t[j][threadIdx.x] = (r < Ph && c < Ph) ? W1[(long)r * Ph + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (c < Ph && r < Ph) W1T[(long)c * Ph + r] = t[threadIdx.x][j];
+  }
+  if (blockIdx.y == 0 && threadIdx.y == 0) {
+    const int k = c0 + threadIdx.x;
+    if (k < Ph) {
+      const float a = (float)gs_sum_slices(sums, slices, 3, Ph, 0, k), b = (float)gs_sum_slices(sums, slices, 3, Ph, 1, k),
+                  c = (float)gs_sum_slices(sums, slices, 3, Ph, 2, k);
+      dw2[k] = a; dbe2[k] = b; dg2[k] = c;
+      if (gen_table) gs_panel_gen_row(mu2[k], is2[k], g2[k], be2[k], w2[k], b, c, invN, gen_table + 8 * k);
+    }
   }
 }
 __global__ void gs_pge_bn1_bwd_uv_kernel(const float* __restrict__ U, const float* __restrict__ V,

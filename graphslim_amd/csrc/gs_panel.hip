@@ -452,10 +452,7 @@ __global__ void gs_panel_gen_consts_kernel(const float* __restrict__ mu2, const 
                                            const float* __restrict__ dg2, float invN, int K, float* __restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
-  const float gi = g2[k] * is2[k];
-  float* o = out + 8 * k;
-  o[0] = is2[k]; o[1] = -mu2[k] * is2[k]; o[2] = g2[k]; o[3] = be2[k];
-  o[4] = gi * w2[k]; o[5] = gi * dbe2[k] * invN; o[6] = gi * dg2[k] * invN; o[7] = 0.f;
+  gs_panel_gen_row(mu2[k], is2[k], g2[k], be2[k], w2[k], dbe2[k], dg2[k], invN, out + 8 * k);
 }
 
 // W [N][ldb] fp32 -> packed [N][K/32][hi 32 | lo 32] bf16 (lo = bf16(w - hi); all zeros are kept exact)
@@ -570,7 +567,8 @@ extern "C" int gs_gemm_set_panel_marg(int level) {
 // Returns GS_ERR_UNSUPPORTED when the shape is not covered (the caller then takes the two-kernel route).
 // With `gen` (7 device arrays mu2, is2, g2, be2, w2, dbe2, dg2 of length K, de3 per pair row, total pair rows N_total and an
 // [K][8] float scratch table) the first operand is E2 and dE2 is formed inside the kernel (no dE2 pass, no dE2 buffer).
-struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; };
+// (table_ready: the caller has filled `table` already — the engine's gs_pge_bwd_prep_kernel does, saving a launch)
+struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; int table_ready; };
 // Layer-1 activations as a function of U [n][ld], V [n][ld] (V + r_lo * ld is passed), the layer-0 bias and the BatchNorm-1
 // quantities (5 arrays of the hidden width) and an [width][8] float scratch table: with `a1` the marginals' [A1 > 0] mask is
 // recomputed from them (`mask` may be null), and gs_panel_forward_a1 forms the A operand of E2 = A1 W1^T + b1 from them.
@@ -649,8 +647,9 @@ int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, con
   a.mg_n = n; a.mg_nr = nr; a.mg_ncb = gs_cdiv(n, 8);
   a.partU = partU; a.partV = partV;
   if (gen) {
-    hipLaunchKernelGGL(gs_panel_gen_consts_kernel, dim3(gs_cdiv(K, 64)), dim3(64), 0, s, gen->mu2, gen->is2, gen->g2, gen->be2, gen->w2,
-                       gen->dbe2, gen->dg2, 1.f / (float)gen->total_rows, K, gen->table);
+    if (!gen->table_ready)
+      hipLaunchKernelGGL(gs_panel_gen_consts_kernel, dim3(gs_cdiv(K, 64)), dim3(64), 0, s, gen->mu2, gen->is2, gen->g2, gen->be2, gen->w2,
+                         gen->dbe2, gen->dg2, 1.f / (float)gen->total_rows, K, gen->table);
     a.gen_c = gen->table; a.gen_d = gen->de3;
   }
   if (a1) {

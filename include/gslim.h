@@ -93,6 +93,17 @@ int gs_gemm_set_panel(int enable);
 int gs_gemm_set_edge_kernel(int enable);
 /* the row-panel kernel finishes the last partial round of a launch in 32-row tiles (default 1); 0 = 128-row tiles throughout */
 int gs_gemm_set_panel_narrow_tail(int on);
+/* PGE backward marginals (engine-internal product dY1 = (dE2 W1) * [A1 > 0], needed only through its row / column sums):
+   0 = materialise dY1 and reduce it, 1 = sums fused into the row-panel product's epilogue on a materialised dE2,
+   2 (default) = as 1 with dE2 formed from E2 in the operand path where it applies (feature epochs).  A measurement knob. */
+int gs_gemm_set_panel_marg(int level);
+/* PGE layer-1 activations A1 = relu(BN1(U[c] + V[r] + b0)): 1 (default) = formed from U, V inside the layer-2 product's
+   operand path and inside the marginals' mask (A1 is written only when dW1 needs it); 0 = always materialised first.
+   Both forms give bitwise the same results (tests/test_gpu_panel.py).  A measurement knob. */
+int gs_gemm_set_panel_a1gen(int on);
+/* row-panel kernel measurement hooks (tools/trace_panel.py): the K loop repeated krep times; triage bit 0 = no stores,
+   bit 1 = per-workgroup placement / timing trace into desc.scratch.  krep = 1, triage = 0 restores the product path. */
+int gs_panel_debug(int krep, int triage);
 /* which kernel gs_gemm_f32 launches for this descriptor: 0 = 128x32 tile, 1 = 32x128, 2 = 64x64, 3 = 128x128, 4 = the
    one-tile-per-workgroup latency kernel, 5 = the row-panel kernel (128 rows x all 256 columns per workgroup; PGE layer 2,
    its backward and the SGC transform), 6 = the real-side edge-product kernel — test hook: parity tests assert the instantiation a shape exercises */
@@ -259,6 +270,9 @@ int gs_gcond_set_overlap(gs_gcond* e, int on);
  * transform H1 = relu(X W1 + b1)): 0 = exact fp32 (default = the reference's precision), 1 = split bf16 x3 with fp32
  * accumulation, 2 = bf16 operands (BASELINE.json configs[1]).  See gs_gemm_desc.prec.  Everything else stays fp32. */
 int gs_gcond_set_operand_mode(gs_gcond* e, int mode);
+/* 1 (default): unsharded engines fold the last stage of the BatchNorm-2 / layer-3 statistics reductions into the consuming
+   launch (two launches fewer per PGE pass); 0 = separate launches.  Bitwise the same results.  A measurement knob. */
+int gs_gcond_set_folded_reductions(int on);
 /* One outer-loop iteration; adds the matching loss to the device-side accumulator. */
 int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream);
 /* The sibling gradient-matching methods reuse train_class unchanged and differ in the update rule and in whether a

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Solo duration of every stage of one outer iteration (each stage run back to back on an otherwise idle chip, no profiler):
+what the iteration would cost with no overlap, where the launch-latency floor sits (launches per stage are listed), and how
+much the two-stream overlap hides.  usage: stage_times.py [workload] [operand mode]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "ogbn-arxiv"
+mode = sys.argv[2] if len(sys.argv) > 2 else "f32"
+if os.environ.get("GS_SMALL"):      # routing sweep: "max_tiles,max_gflop" of the latency-oriented 32x32 kernel
+    import ctypes as C
+    from graphslim_amd import _lib
+    t, g = os.environ["GS_SMALL"].split(",")
+    _lib.lib().gs_gemm_set_small(C.c_long(int(t)), C.c_double(float(g)))
+p = bench.build_problem(name, seed=1)
+eng = bench.make_engine(p, "cuda:0")
+eng.set_operand_mode(mode)
+bench.init_state(p, eng)
+bench.new_model(p, eng)
+for _ in range(3):
+    eng.outer_step(10)
+torch.cuda.synchronize()
+
+
+def timed(fn, reps=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e6
+
+
+stages = [
+    ("sample (next blocks)", eng.stage_sample),
+    ("real-side gradients", eng.stage_real_grads),
+    ("PGE forward (training)", lambda: eng.stage_pge_forward(False)),
+    ("synthetic match forward", eng.stage_syn_match),
+    ("distance + second-order backward", eng.syn_finish),
+    ("PGE backward (feature epoch)", lambda: eng.stage_pge_backward(False, True)),
+    ("PGE backward (PGE epoch)", lambda: eng.stage_pge_backward(True, True)),
+    ("Adam (feature epoch)", lambda: eng.stage_update(10)),
+    ("PGE forward (inference)", lambda: eng.stage_pge_forward(True)),
+    ("inner SGC steps", eng.stage_inner),
+]
+tot = 0.0
+for label, fn in stages:
+    us = timed(fn)
+    if "PGE epoch" not in label and "sample" not in label:
+        tot += us
+    print(f"{label:36s} {us:8.1f} us")
+print(f"sum of the feature-epoch stages (no overlap, sampling excluded): {tot:.1f} us")
+it = timed(lambda: eng.outer_step(10), 40)
+print(f"outer_step (feature epoch, two streams + prefetched sampling): {it:.1f} us")
