@@ -25,6 +25,13 @@ class _GradMatch(GCondBase):
     @verbose_time_memory
     def reduce(self, data, verbose=True):
         args = self.args
+        if args.condense_model == "APPNP":
+            # The reference cannot run this either: gcond_base.py:220 hands model(...) the LIST of sampled blocks and
+            # APPNP.forward (models/appnp.py:57-63) multiplies that list with a tensor — TypeError in the first train_class
+            # call (golden G15 records it, tests/test_host.py).  APPNP is an evaluation backbone there (eval_agent.py, nas_eval.py).
+            raise NotImplementedError("graphslim_amd: condense_model = 'APPNP' has no reference behaviour to match — upstream's "
+                                      "train_class raises TypeError (\"unsupported operand type(s) for @: 'list' and 'Tensor'\", "
+                                      "models/appnp.py:63) on the sampled block list; use SGC or GCN")
         if args.condense_model not in ("SGC", "GCN"):
             raise NotImplementedError(f"graphslim_amd: condense_model must be SGC or GCN (got {args.condense_model})")
         depth = 2 if args.condense_model == "GCN" else args.ntrans      # models/gcn.py:8-23 vs models/sgc.py:16-35

@@ -16,7 +16,7 @@ struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *
 int gs_panel_marginals(const float*, long, const float*, long, const float*, long, int, int, int, int, float*, float*, int, void*,
                        const gs_panel_gen*, const gs_panel_a1*, hipStream_t);
 int gs_panel_forward_a1(const gs_panel_a1*, int, int, const float*, long, const float*, float*, long, int, int, float*, int, void*,
-                        hipStream_t);
+                        unsigned long long*, hipStream_t);
 int gs_panel_tiles(int);
 
 namespace {
@@ -106,6 +106,7 @@ struct gs_gcond {
   bool probing;
   int probe_n;
   hipEvent_t probe_ev[2 * 256];
+  unsigned long long* probe_span;    // [256][2] device ticks (s_memrealtime): first workgroup start / last workgroup end of each probed launch
   bool gcn;         // condense model GCN (2 layers) instead of SGC
   float *P0g, *T2r, *dT2r, *dH1r, *S1, *dS1, *Tmat, *Rmat;   // GCN-only scratch
   bool identity;    // structure-free variants (GCondX / DosCondX): adj_syn = I, no PGE
@@ -226,6 +227,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->rowsum_c = e->ar_marg; e->colsum_r = e->ar_marg ? e->ar_marg + n * Ph : nullptr; e->dU = w.take<float>(n * Ph); e->W1T = w.take<float>(Ph * Ph); e->W1mT = w.take<float>(d * h);
   e->bsplit_main = w.take<float>(Ph * Ph);
   e->bsplit_aux = w.take<float>((h > 0 ? h : 1) * d);
+  e->probe_span = w.take<unsigned long long>(2 * 256);
   e->gen_tab = w.take<float>(Ph * 8);
   e->a1_tab = w.take<float>(Ph * 8);
   e->a1_valid = false;
@@ -867,7 +869,7 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       int tiles = 0;
       if (probe) GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s));
       const int rc = gs_panel_forward_a1(&a1, n, nr, pp + e->pW1, Ph, pp + e->pb1, e->E2, Ph, Ph, Ph, e->statp, e->operand_mode,
-                                         e->bsplit_main, s);
+                                         e->bsplit_main, probe ? e->probe_span + 2 * e->probe_n : nullptr, s);
       if (rc == GS_OK) {
         tiles = gs_panel_tiles((int)rows);
       } else if (rc != GS_ERR_UNSUPPORTED) {
@@ -1566,7 +1568,31 @@ extern "C" int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream) {
 extern "C" int gs_gcond_probe(gs_gcond* e, int on) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   e->probing = on != 0;
-  if (on) e->probe_n = 0;
+  if (on) {
+    e->probe_n = 0;
+    // every slot: start = max u64 (atomicMin target), end = 0 (atomicMax target)
+    unsigned long long init[2 * 256];
+    for (int i = 0; i < 256; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+    GS_HIP(hipMemcpy(e->probe_span, init, sizeof(init), hipMemcpyHostToDevice));
+  }
+  return GS_OK;
+}
+
+// Device-side spans of the probed launches: (last workgroup's end tick - first workgroup's start tick) summed over the launches
+// that recorded one, in ms (s_memrealtime counts at 100 MHz).  The HIP-event bracket of gs_gcond_probe_read also contains the
+// time the launch waited for compute units held by the other stream's resident workgroups; this span does not, and is the
+// figure a rocprofv3 kernel trace reports as the kernel's duration.
+extern "C" int gs_gcond_probe_read_spans(gs_gcond* e, double* total_ms, long* launches) {
+  if (!e || !total_ms || !launches) GS_FAIL(GS_ERR_ARG, "gs_gcond_probe_read_spans: null argument");
+  unsigned long long h[2 * 256];
+  GS_HIP(hipDeviceSynchronize());
+  GS_HIP(hipMemcpy(h, e->probe_span, sizeof(h), hipMemcpyDeviceToHost));
+  double t = 0;
+  long k = 0;
+  for (int i = 0; i < e->probe_n; ++i)
+    if (h[2 * i + 1] > h[2 * i] && h[2 * i] != ~0ull) { t += (double)(h[2 * i + 1] - h[2 * i]) * 1e-5; ++k; }
+  *total_ms = t;
+  *launches = k;
   return GS_OK;
 }
 

@@ -54,6 +54,8 @@ struct gs_panel_args {
   // [A1 > 0] mask of the fused-marginals epilogue is recomputed from them (mask is not read).
   const float* a1_U; const float* a1_V; long a1_ld;     // U [n][ld], V already offset to this rank's first pair row r
   const float* a1_c;                 // [Ph][8]: per column {b0, mu1, is1, g1, be1, 0, 0, 0}
+  unsigned long long* span;          // optional [2]: device-side launch span — min over workgroups of the start tick, max of the
+                                     // end tick (s_memrealtime, 100 MHz); see gs_gcond_probe
   int krep, triage;                  // measurement hooks (gs_panel_debug): K loop repeated krep times; bit 0: no stores;
   unsigned long long* trace;         // bit 1: per-workgroup [hw_id, xcc_id, t_start, t_loop_end, t_end] (s_memrealtime, 10 ns)
 };
@@ -246,6 +248,7 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
 
   unsigned long long t_start = 0, t_loop = 0;
   if (p.triage & 2) t_start = __builtin_amdgcn_s_memrealtime();
+  if (p.span && tid == 0) atomicMin(p.span, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 
   f32x16 acc[NTW];
 #pragma unroll
@@ -400,6 +403,10 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
       p.colstat[((long)stat_row * 2 + q) * PN_N + cc] = t;
     }
   }
+  if (p.span && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    atomicMax(p.span + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
   if ((p.triage & 2) && p.trace && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned long long* o = p.trace + (long)blockIdx.x * 5;
@@ -543,6 +550,7 @@ static void panel_dispatch(const gs_gemm_desc& d, gs_panel_args& a, hipStream_t 
 
 int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s) {
   gs_panel_args a;
+  memset(&a, 0, sizeof(a));
   a.A = d.A; a.lda = d.sAm;
   a.C = d.C; a.ldc = d.ldc;
   a.M = d.M; a.K = d.K;
@@ -595,7 +603,7 @@ int gs_panel_a1_table(const gs_panel_a1* a1, int width, hipStream_t s) {
 // gs_gemm_desc.colstat ([gs_panel_tiles(nr * n)][2][N]).  GS_ERR_UNSUPPORTED when the shape is not covered (the caller then
 // materialises A1 and takes the plain product).
 int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, long ldw, const float* bias, float* C, long ldc, int N,
-                        int K, float* colstat, int prec, void* scratch, hipStream_t s) {
+                        int K, float* colstat, int prec, void* scratch, unsigned long long* span, hipStream_t s) {
   if (!g_panel_a1gen || !g_panel_enabled || !a1 || !a1->table || n < 128 || nr < 1) return GS_ERR_UNSUPPORTED;   // (<= 2 r per tile)
   if ((N != 256 && N != 128) || K < 32 || K > 256 || (K & 31) || (ldw & 3) || (a1->ld & 3)) return GS_ERR_UNSUPPORTED;
   if ((double)nr * n * (double)ldc >= 4294967296.0 || (prec != 0 && !scratch) || prec < 0 || prec > 2) return GS_ERR_UNSUPPORTED;
@@ -606,6 +614,7 @@ int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, lo
   a.mg_n = n; a.mg_nr = nr;
   a.a1_U = a1->U; a.a1_V = a1->V; a.a1_ld = a1->ld; a.a1_c = a1->table;
   a.A = a1->U; a.lda = a1->ld;
+  a.span = span;
   int nf, nn;
   panel_split(a.M, &nf, &nn);
   a.n_full = nf;

@@ -367,6 +367,14 @@ class GCondEngine:
         check(self.L.gs_gcond_probe_read(self.h, C.byref(t), C.byref(k)))
         return t.value, k.value
 
+    def probe_read_spans(self):
+        """(summed device-side span [ms], launches) of the same launches: first workgroup start .. last workgroup end, i.e. the
+        kernel's duration as a kernel trace reports it (the event bracket of probe_read also contains queueing behind the other
+        stream's resident workgroups).  Synchronises the device."""
+        t, k = C.c_double(), C.c_long()
+        check(self.L.gs_gcond_probe_read_spans(self.h, C.byref(t), C.byref(k)))
+        return t.value, k.value
+
     def stage_real_async(self):
         check(self.L.gs_gcond_stage_real_async(self.h, self._s()))
 

@@ -741,7 +741,35 @@ def g14():
     save("g14_coreset_select", **out)
 
 
+def g15():
+    """What the reference does with condense_model = 'APPNP' inside train_class (SURVEY section 8 f4 lists APPNP as a condense
+    backbone): gcond_base.py:220 calls model(input_real, adjs) with the LIST of sampled blocks, and APPNP.forward
+    (models/appnp.py:57-63) multiplies that list with a tensor.  The fixture records the outcome (exception type and message)
+    so that the scope fence in graphslim_amd/condensation/gcond.py is pinned to the reference's behaviour, not to an opinion."""
+    from graphslim.models import APPNP
+    global ref_model
+    keep = ref_model
+
+    def with_appnp(kind, nfeat, nhid, nclass, args, mode="train"):
+        return APPNP(nfeat, nhid, nclass, args, mode) if kind == "APPNP" else keep(kind, nfeat, nhid, nclass, args, mode)
+
+    ref_model = with_appnp
+    outcome = {}
+    try:
+        for tag, T in (("t1", 1), ("t2", 2)):
+            out = {}
+            try:
+                run_train_class(tag, 60, 3, 8, 16, T, 0.5, "cora", out, kind="APPNP")
+                outcome[tag] = ("ok", repr(float(out[f"{tag}_loss"])))
+            except Exception as e:      # noqa: BLE001 — the fixture IS the exception
+                outcome[tag] = (type(e).__name__, str(e))
+    finally:
+        ref_model = keep
+    save("g15_appnp_condense", **{f"{k}_{q}": np.array(v[i]) for k, v in outcome.items() for i, q in enumerate(("type", "message"))})
+    print("g15:", outcome)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()

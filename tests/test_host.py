@@ -269,3 +269,19 @@ def test_reads_condensed_graphs_written_by_the_reference(golden_dir, tmp_path, r
     assert feat is data.feat_full and lab is data.labels_train          # the reference's fall-backs
     sp_ = sparsify("GCN", adj.clone(), args)
     assert float(sp_[sp_ > 0].min()) >= 0.05 and int((sp_ > 0).sum()) == int((adj >= 0.05).sum())
+
+
+def test_g15_appnp_condense_model_is_fenced_like_the_reference_fails(golden_dir):
+    """SURVEY section 8 f4 names APPNP as a condense backbone, but upstream's own train_class cannot run it: golden G15 is the
+    outcome of the reference's GCondBase.train_class with models.APPNP (TypeError at models/appnp.py:63, for ntrans 1 and 2).
+    The package therefore refuses the value, and says why, instead of inventing a behaviour."""
+    from helpers import load_golden
+    from graphslim_amd.condensation.gcond import GCond
+    g = load_golden(golden_dir, "g15_appnp_condense")
+    for tag in ("t1", "t2"):
+        assert str(g[f"{tag}_type"]) == "TypeError"
+        assert "'list' and 'Tensor'" in str(g[f"{tag}_message"])
+    agent = GCond.__new__(GCond)
+    agent.args = type("A", (), {"condense_model": "APPNP", "verbose": False})()
+    with pytest.raises(NotImplementedError, match="TypeError"):
+        agent.reduce(None, verbose=False)
