@@ -6,10 +6,14 @@ export TMPDIR=/tmp
 O=gpurun_out/prof
 mkdir -p $O
 nproc > $O/host.txt; lscpu | grep "Model name" >> $O/host.txt
+timeout 900 python -m pytest tests -q -m gpu > $O/tests_gpu_all.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_operand_modes.py tests/test_gpu_panel.py -q -m gpu -s > $O/tests_fullsize.log 2>&1
 timeout 600 python bench.py > $O/bench_arxiv.json 2> $O/bench_arxiv.err
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_arxiv_driver_args.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --sustain-s 0 > $O/bench_under_rocprof.json 2>/dev/null
 cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/bench_arxiv_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python3 bench.py --no-cpu-baseline --sustain-s 0 > $O/bench_default_under_rocprof.json 2>/dev/null
+cp $(ls $O/kt2/*/*kernel_stats.csv | head -1) $O/bench_default_kernel_stats.csv; rm -rf $O/kt2
 f=$(ls $O/kt/*/*kernel_trace.csv | head -1); python3 tools/timeline_csv.py $f 190 > $O/timeline_f32_noreuse.txt 2>/dev/null
 rm -rf $O/kt
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -25,6 +29,7 @@ find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -dele
 timeout 300 python tools/stage_times.py ogbn-arxiv f32 2>/dev/null | grep -v "^/opt" > $O/stage_times.txt
 timeout 300 python tools/stage_times.py ogbn-arxiv bf16x3 2>/dev/null | grep -v "^/opt" >> $O/stage_times.txt
 timeout 600 python tools/ab_pge_forms.py > $O/ab_pge_forms.txt 2>&1
+timeout 300 python tools/host_issue.py > $O/host_issue.txt 2>&1
 timeout 300 python tools/ab_panel.py > $O/ab_panel.txt 2>&1
 timeout 300 python tools/ab_bgen.py > $O/ab_edge.txt 2>&1
 timeout 600 python bench.py --workload reddit --no-cpu-baseline > $O/bench_reddit.json 2>/dev/null
