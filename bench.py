@@ -33,6 +33,8 @@ WORKLOADS = {
     "reddit": ("reddit", 0.001, 1, 256, 256, 10, 1, 0.1, 0.1, (15, 8)),
     # the other BASELINE.json configs (parity-test cases at FULL size, tests/test_gpu_fullsize.py; not bench lines)
     "cora-r0.25": ("cora", 0.25, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
+    # n' = 140 with the Planetoid PGE width 128: the generated / fused PGE forms at N = 128 (4 MFMA column tiles per wave)
+    "cora-r1.0": ("cora", 1.0, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
     "citeseer-r0.005": ("citeseer", 0.005, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
     "pubmed-r0.005": ("pubmed", 0.005, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
 }

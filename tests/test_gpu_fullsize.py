@@ -126,6 +126,14 @@ def test_reddit_r0001_inductive_full_size():
     check(run_config("reddit", 10))
 
 
+@pytest.mark.parametrize("epoch", [10, 0])
+def test_cora_r10_full_size_generated_forms_at_width_128(epoch):
+    """Not a BASELINE config: cora at r = 1.0 gives n' = 140 >= 128 with the Planetoid PGE width 128, i.e. the generated-A1
+    forward, the fused marginals with the regenerated mask and (feature epochs) the generated dE2 in their N = 128 instantiations
+    — against the oracle like the configs above."""
+    check(run_config("cora-r1.0", epoch), adj_tol=1e-3 if epoch == 0 else 2e-4)
+
+
 def test_cora_r025_full_size():
     """BASELINE configs[1] in its fp32 form (the bf16 operand mode of the same config: test_gpu_operand_modes.py)."""
     check(run_config("cora-r0.25", 10))

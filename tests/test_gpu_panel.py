@@ -133,17 +133,20 @@ def test_panel_needs_scratch_for_split_modes(E):
     assert err(out, ref) <= 2e-6
 
 
+@pytest.mark.parametrize("workload", ["ogbn-arxiv", "cora-r1.0"])
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("param_grads", [False, True])
-def test_generated_a1_operand_and_mask_are_bitwise_the_materialised_form(mode, param_grads):
+def test_generated_a1_operand_and_mask_are_bitwise_the_materialised_form(mode, param_grads, workload):
     """PGE forward with A1 formed in the operand path of E2 = A1 W1^T + b1 (gs_panel_fwdgen_kernel) and the [A1 > 0] mask of the
     fused marginals recomputed from U, V — against the same engine with A1 materialised by gs_pge_make_a1 (knob
     gs_gemm_set_panel_a1gen(0)): same arithmetic per element and same k order, so pair scores, d/dX~ and d/dtheta_PGE must be
-    IDENTICAL, in feature epochs (dE2 generated too) and PGE epochs (A1 materialised lazily for dW1)."""
+    IDENTICAL, in feature epochs (dE2 generated too) and PGE epochs (A1 materialised lazily for dW1).  ogbn-arxiv: n' = 454,
+    PGE width 256 (8 column tiles per wave); cora at r = 1.0: n' = 140, PGE width 128 (4 column tiles, d = 1433)."""
     import bench
     from graphslim_amd import _lib
     L = _lib.lib()
-    p = bench.build_problem("ogbn-arxiv", seed=1)
+    p = bench.build_problem(workload, seed=1)
+    assert len(p["labels_syn"]) >= 128
     got = {}
     for on in (1, 0):
         L.gs_gemm_set_panel_a1gen(on)
