@@ -97,9 +97,12 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
         h = (int)((uint32_t)pick * 2654435761u >> 22);
         while (s_hash[h] != -1) h = (h + 1) & 1023;
         s_hash[h] = pick;
-        s_seed[ns++] = pool[pick];
+        s_seed[ns++] = pick;      // pool INDEX: the pool itself is read by all threads below (no global-load latency inside
+                                  // this serial loop: 256 dependent round trips were most of the kernel's 183 us)
       }
     }
+    __syncthreads();
+    if (tid < B) s_seed[tid] = pool[s_seed[tid]];
   }
   __syncthreads();
 
