@@ -4,6 +4,7 @@
 // its check against autograd).  All classes are processed together: the real-side blocks live in
 // class-major fixed-capacity arrays, the synthetic side uses grouped GEMMs over the contiguous row
 // range of each class.  Everything stays resident in HBM; the host only launches.
+#include <cstdlib>
 #include <new>
 
 #include "gs_kernels.h"
@@ -153,7 +154,15 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   e->pW0 = 0; e->pb0 = Ph * 2 * d; e->pW1 = e->pb0 + Ph; e->pb1 = e->pW1 + Ph * Ph; e->pw2 = e->pb1 + Ph;
   e->pb2 = e->pw2 + Ph; e->pg1 = e->pb2 + 1; e->pbe1 = e->pg1 + Ph; e->pg2 = e->pbe1 + Ph; e->pbe2 = e->pg2 + Ph;
   e->Ppge = e->pbe2 + Ph;
-  e->kchunk_r = 512;    // ~23 slabs per class at arxiv sizes: 1 840 workgroups for 768 resident slots (1 024 left a 25 %-full second round: 667 vs 528 us, tools/probe_bgen.py)
+  // K-slab length of the real-side edge product (one workgroup per class, slab and 128-feature tile; 2 resident per CU = 512
+  // slots).  1 024-edge slabs when they still fill the chip in ONE round (ogbn-arxiv: 40 classes x <= 14 slabs; in situ
+  // -12 us fp32 / -33 us bf16x3 per iteration against 512, half the slab traffic), else 512 (few classes: keep the slots
+  // busy); 768 and 1 408 measured worse at arxiv (a part-filled second round / idle slots), tools/gpu/run_kc.sh.
+  e->kchunk_r = (long)e->C * gs_cdiv((long)e->cap1 * e->f2, 1024) * gs_cdiv(e->d, 128) >= 400 ? 1024 : 512;
+  if (const char* kc = getenv("GS_KCHUNK_R")) {      // measurement override (tools)
+    const int v = atoi(kc);
+    if (v >= 64 && v % 16 == 0) e->kchunk_r = v;
+  }
   e->nsplit_r = gs_cdiv((long)e->cap1 * e->f2, e->kchunk_r);
   // dW1 = dE2^T A1 over K = n'^2 pair rows: Ph/128 x Ph/128 output tiles per slab; aim at one full round of the 768
   // resident 128x128 workgroups (2 048 gave 404 workgroups at n' = 454: half the chip idle)
