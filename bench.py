@@ -136,7 +136,8 @@ def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20, span=None):
     sec = span[0] / 1e3 / span[1] if span and span[1] else bracket
     flops = 2.0 * rows * ph * ph
     traffic, src = None, None
-    kname = {"f32": "gs_panel_fwdgen_kernel<0, 8>", "bf16x3": "gs_panel_fwdgen_kernel<1, 8>", "bf16": "gs_panel_fwdgen_kernel<2, 8>"}[mode]
+    kname = {"f32": "gs_panel_fwdgen_kernel<0, 8>", "bf16x3": "gs_panel_fwdgen_kernel<1, 8>", "bf16": "gs_panel_fwdgen_kernel<2, 8>",
+             "bf16x6": "gs_panel_fwdgen_kernel<3, 8>"}[mode]
     if ph != 256 or n < 128:
         kname = "PGE layer-2 product (row-panel / tile route of this shape)"
     if (n, ph) == (454, 256) and os.path.exists(PMC_SUMMARY):
@@ -269,7 +270,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink N for smoke runs (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of extra back-to-back iterations for the `sustained` field (0 = off)")
-    ap.add_argument("--operand-mode", default="f32", choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--operand-mode", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
                     help="operand precision of the row-panel products for the HEADLINE run (default: exact fp32)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -349,7 +350,7 @@ def main():
     # opt-in operand precisions of the row-panel / edge products (VERDICT r01 row *J): same steps, same cadence, tagged dtype.
     # NOT the headline: `value` is measured in args.operand_mode (default exact fp32 = the reference's precision).
     modes = {}
-    for m in ("bf16x3", "bf16"):
+    for m in ("bf16x6", "bf16x3", "bf16"):
         if m == args.operand_mode or world > 1:
             continue
         base.set_operand_mode(m)
@@ -361,9 +362,11 @@ def main():
         dm = time.perf_counter() - tm
         ls, kk = eng.read_loss()
         modes[m] = {"value": round(args.steps / dm, 3), "unit": "outer-iters/s", "ms_per_step": round(1e3 * dm / args.steps, 3),
-                    "dtype": {"bf16x3": "split-bf16 x3 operands (hi*hi + hi*lo + lo*hi), f32 accumulate",
+                    "dtype": {"bf16x6": "f32 operands split EXACTLY into three bf16 parts (8 + 8 + 8 bits), 6 bf16 MFMA products "
+                                        "(the 3 dropped cross terms <= 2^-23 of a product), f32 accumulate: fp32-level error",
+                              "bf16x3": "split-bf16 x3 operands (hi*hi + hi*lo + lo*hi), f32 accumulate",
                               "bf16": "bf16 operands, f32 accumulate"}[m],
-                    "applies_to": "PGE layer-2 forward, its backward dY1, H1 = relu(X W1 + b1), real-side edge product",
+                    "applies_to": "PGE layer-2 forward, its backward (fused marginals), H1 = relu(X W1 + b1), real-side edge product",
                     "mean_match_loss": ls / max(kk, 1) / p['data'].nclass,
                     "parity": "tests/test_gpu_operand_modes.py (oracle, full size)"}
     base.set_operand_mode(args.operand_mode)

@@ -13,8 +13,8 @@
 //     B generated in registers, both operands written to a double-buffered LDS image [k][m] / [k][n] (row pad 4 floats:
 //     conflict-free ds_write_b128 and ds_read_b32), ONE barrier per K step;
 //   * partial products go to slabs [class][slab][d][h] reduced in a fixed order by gs_reduce_slabs_batched_f32 (no atomics).
-// Operand precision as in gs_panel.hip: 0 exact fp32 (v_mfma_f32_32x32x2_f32), 1 split bf16 x3, 2 bf16 (operands converted
-// when the fragments are read; fp32 accumulation).
+// Operand precision as in gs_panel.hip: 0 exact fp32 (v_mfma_f32_32x32x2_f32), 1 split bf16 x3, 2 bf16, 3 the EXACT three-way
+// bf16 split with six products (operands converted when the fragments are read; fp32 accumulation).
 #include "gs_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -110,6 +110,34 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
 #pragma unroll
           for (int t = 0; t < 8; ++t) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc[j], 0, 0, 0);
         }
+      } else if constexpr (MODE == 3) {
+        bf16x8 ah, am, al;                                                     // x = h + m + l exactly (8 + 8 + 8 bits)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float x = as[(8 * h + t) * EG_LDA];
+          const __bf16 hb = (__bf16)x;
+          const float r1 = x - (float)hb;
+          const __bf16 mb = (__bf16)r1;
+          ah[t] = hb; am[t] = mb; al[t] = (__bf16)(r1 - (float)mb);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          bf16x8 bh, bm, bl;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const float x = bs[(8 * h + t) * EG_LDB + 32 * j];
+            const __bf16 hb = (__bf16)x;
+            const float r1 = x - (float)hb;
+            const __bf16 mb = (__bf16)r1;
+            bh[t] = hb; bm[t] = mb; bl[t] = (__bf16)(r1 - (float)mb);
+          }
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);     // small terms first
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+        }
       } else {
         bf16x8 ah, al;                                                         // lane half h supplies k = 8 h .. 8 h + 7
 #pragma unroll
@@ -166,7 +194,7 @@ bool gs_edge_eligible(const gs_gemm_desc& p) {
   if (p.gatherA_k != p.bgen_idx) return false;                 // one source id per edge feeds both the X row and the mask row
   if (p.alpha != 1.f || p.beta != 0.f || p.bias || p.relu || p.mask || p.colstat || p.offA || p.offB || p.offC || p.Mb) return false;
   if (p.gatherA_m || p.gatherB_k || p.sAb1 != 0 || p.sAb2 != 0 || p.sBb2 != 0) return false;
-  if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.bgen_mask) & 15) || p.prec < 0 || p.prec > 2) return false;
+  if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.bgen_mask) & 15) || p.prec < 0 || p.prec > 3) return false;
   return true;
 }
 
@@ -181,7 +209,8 @@ int gs_edge_launch(const gs_gemm_desc& d, hipStream_t s) {
   const dim3 grid(d.nb2, d.nb1, gs_cdiv(d.M, 128)), block(256);
   if (d.prec == 0) hipLaunchKernelGGL((gs_edge_gemm_kernel<0>), grid, block, 0, s, a);
   else if (d.prec == 1) hipLaunchKernelGGL((gs_edge_gemm_kernel<1>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((gs_edge_gemm_kernel<2>), grid, block, 0, s, a);
+  else if (d.prec == 2) hipLaunchKernelGGL((gs_edge_gemm_kernel<2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gs_edge_gemm_kernel<3>), grid, block, 0, s, a);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

@@ -234,8 +234,8 @@ static size_t carve(gs_gcond* e, void* base) {
   e->dE2 = w.take<float>(n2 * Ph); e->dY1 = w.take<float>(n2 * Ph);
   e->ar_marg = w.take<float>(2 * n * Ph);     // [rowsum_c | colsum_r] contiguous (one all-reduce)
   e->rowsum_c = e->ar_marg; e->colsum_r = e->ar_marg ? e->ar_marg + n * Ph : nullptr; e->dU = w.take<float>(n * Ph); e->W1T = w.take<float>(Ph * Ph); e->W1mT = w.take<float>(d * h);
-  e->bsplit_main = w.take<float>(Ph * Ph);
-  e->bsplit_aux = w.take<float>((h > 0 ? h : 1) * d);
+  e->bsplit_main = w.take<float>(Ph * Ph * 3 / 2 + 16);             // pre-split B images: 4 B (modes 1, 2) or 6 B (mode 3) per element
+  e->bsplit_aux = w.take<float>((h > 0 ? h : 1) * d * 3 / 2 + 16);
   e->probe_span = w.take<unsigned long long>(2 * 256);
   e->gen_tab = w.take<float>(Ph * 8);
   e->a1_tab = w.take<float>(Ph * 8);
@@ -409,7 +409,8 @@ extern "C" int gs_gcond_invalidate_forward(gs_gcond* e) {
 // products only (gs_gemm_desc.prec); everything else stays fp32.  Switchable at any time (A/B measurements).
 extern "C" int gs_gcond_set_operand_mode(gs_gcond* e, int mode) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
-  if (mode < 0 || mode > 2) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_operand_mode: mode must be 0 (fp32), 1 (bf16 x3) or 2 (bf16)");
+  if (mode < 0 || mode > 3)
+    GS_FAIL(GS_ERR_ARG, "gs_gcond_set_operand_mode: mode must be 0 (fp32), 1 (2-way bf16 split, 3 products), 2 (bf16) or 3 (exact 3-way bf16 split, 6 products)");
   e->operand_mode = mode;
   e->fwd_cached = false;
   return GS_OK;

@@ -196,6 +196,41 @@ __device__ __forceinline__ void panel_epilogue_marg(const gs_panel_args& p, cons
   }
 }
 
+// In-place transform of a lane's 16 A elements (k = 32 kb + 16 h + t) for the generated-operand forms.
+//   AGEN: a holds E2[row][k] -> dE2 = g2 is2 (dy2 - dbe2 / N - xh2 dg2 / N), xh2 = (E2 - mu2) is2, dy2 = de3 w2 [g2 xh2 + be2 > 0]
+//         (gs_pge_bn2_bwd_v4_kernel, same arithmetic, constants folded into the [K][8] table gc)
+//   FGEN: a holds U[c][k]   -> A1[(r, c)][k] = relu(g1 ((U[c][k] + V[r][k] + b0 - mu1) is1) + be1)   (gs_pge_make_a1_v5_kernel,
+//         same arithmetic; V rows in LDS at vs, constants table gc)
+template <bool AGEN, bool FGEN>
+__device__ __forceinline__ void panel_transform_a(const gs_panel_args& p, f32x4 (&a)[4], const f32x4* __restrict__ gc,
+                                                  const float* __restrict__ vs, float gen_d, int rsel, int kb, int h) {
+  if constexpr (AGEN) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int k = 32 * kb + 16 * h + t;
+      const f32x4 c0 = gc[2 * k], c1 = gc[2 * k + 1];
+      const float xh = fmaf(a[t >> 2][t & 3], c0[0], c0[1]);
+      const float y = fmaf(c0[2], xh, c0[3]);
+      const float sel = y > 0.f ? gen_d * c1[0] : 0.f;
+      a[t >> 2][t & 3] = fmaf(-xh, c1[2], sel - c1[1]);
+    }
+  }
+  if constexpr (FGEN) {
+    const float* __restrict__ vk = vs + rsel * p.K + 32 * kb + 16 * h;
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(vk + 4 * t4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int k = 32 * kb + 16 * h + 4 * t4 + t;
+        const f32x4 c0 = gc[2 * k], c1 = gc[2 * k + 1];
+        const float x = ((a[t4][t] + vv[t]) + c0[0]) - c0[1];
+        a[t4][t] = fmaxf(fmaf(c0[3], x * c0[2], c1[0]), 0.f);
+      }
+    }
+  }
+}
+
 // One tile.  WN = 1: 128 rows, wave w owns rows [32 w, 32 w + 32) x all N columns (NT MFMA tiles, the bulk of the launch).
 //            WN = 4: 32 rows, wave w owns all 32 rows x the N / 4 columns [32 NT w / 4, ...) — the LAST partial round of a
 // launch runs in these: 206 116 rows are 1 611 tiles of 128 rows on 512 workgroup slots = 3.15 rounds, and the 75 tiles of the
@@ -284,6 +319,67 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   }
 
   f32x4 a_cur[4], a_nxt[4];
+
+  if constexpr (MODE == 3) {
+    // ---- exact three-way bf16 split, six products (see the header comment of this file) -------------------------------
+    // One loop step = a 16-k SUB-block: B sub-stage = N rows x 96 B = [h | m | l planes] x [k half 0 | k half 1] x 8 bf16; a
+    // 32-k block of A (16 k per lane, as in the other modes) spans two sub-blocks u = 0, 1 whose MFMAs take the lane's
+    // elements [8 u, 8 u + 8).  Slot of piece p in LDS row r: (p + 3 ((r >> 3) & 1)) % 6 — conflict-free 16-B reads.
+    auto stage_b3 = [&](int sb, int st) {
+      constexpr int PW3 = 3 * NT / 4;      // 1-KiB pieces per wave: 6 N / 64 lanes / 4 waves
+#pragma unroll
+      for (int q = 0; q < PW3; ++q) {
+        const int g = (wave * PW3 + q) * 64 + lane;
+        const int lrow = g / 6, slot = g - lrow * 6;
+        const int piece = (slot + 3 * ((lrow >> 3) & 1)) % 6;
+        const char* src = Bb + (long)lrow * p.ldb_bytes + sb * 96 + piece * 16;
+        __builtin_amdgcn_global_load_lds((gs_gbl_ptr)src, (gs_lds_ptr)(smem + st * PN_STAGE + (wave * PW3 + q) * 1024), 16, 0, 0);
+      }
+    };
+    const int sh3 = 3 * ((li >> 3) & 1);
+    int boff[3];                           // byte offset of this lane's (plane P, k half h) piece inside its LDS row
+#pragma unroll
+    for (int P = 0; P < 3; ++P) boff[P] = ((2 * P + h + sh3) % 6) * 16;
+    const int nsb = 2 * nkb, nsb_run = nsb * p.krep;
+    stage_b3(0, 0);
+    load_a(0, a_cur);
+    for (int ss = 0; ss < nsb_run; ++ss) {
+      const int sb = ss % nsb, u = sb & 1, kb = sb >> 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (ss + 1 < nsb_run) stage_b3((sb + 1) % nsb, (ss + 1) & 1);
+      if (u == 0) {
+        if (ss + 2 < nsb_run) load_a(((sb + 2) % nsb) >> 1, a_nxt);
+        panel_transform_a<AGEN, FGEN>(p, a_cur, gc, vs, gen_d, rsel, kb, h);
+      }
+      bf16x8 ah, am, al;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = u == 0 ? a_cur[e >> 2][e & 3] : a_cur[2 + (e >> 2)][e & 3];
+        const __bf16 hb = (__bf16)x;
+        const float r1 = x - (float)hb;
+        const __bf16 mb = (__bf16)r1;
+        ah[e] = hb; am[e] = mb; al[e] = (__bf16)(r1 - (float)mb);
+      }
+      const char* __restrict__ bs3 = smem + (ss & 1) * PN_STAGE + (32 * j0 + li) * 96;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bs3 + j * (32 * 96) + boff[0]);
+        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bs3 + j * (32 * 96) + boff[1]);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bs3 + j * (32 * 96) + boff[2]);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);     // small terms first
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+      }
+      if (u == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
+      }
+    }
+  } else {
   stage_b(0, 0);
   load_a(0, a_cur);
   const int nkb_run = nkb * p.krep;      // krep = 1 in the product; > 1 only in the loop-rate measurement
@@ -297,34 +393,7 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
       load_a((kb + 1) % nkb, a_nxt);
     }
     const char* __restrict__ bs = smem + (kk & 1) * PN_STAGE + li * 128 + j0 * 4096;
-    if constexpr (AGEN) {
-      // a_cur holds E2[row][k], k = 32 kb + 16 h + t: turn it into dE2 = g2 is2 (dy2 - dbe2 / N - xh2 dg2 / N) with
-      // xh2 = (E2 - mu2) is2, dy2 = de3 w2 [g2 xh2 + be2 > 0]   (gs_pge_bn2_bwd_v4_kernel, same arithmetic, constants folded)
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int k = 32 * kb + 16 * h + t;
-        const f32x4 c0 = gc[2 * k], c1 = gc[2 * k + 1];
-        const float xh = fmaf(a_cur[t >> 2][t & 3], c0[0], c0[1]);
-        const float y = fmaf(c0[2], xh, c0[3]);
-        const float sel = y > 0.f ? gen_d * c1[0] : 0.f;
-        a_cur[t >> 2][t & 3] = fmaf(-xh, c1[2], sel - c1[1]);
-      }
-    }
-    if constexpr (FGEN) {
-      // a_cur holds U[c][k], k = 32 kb + 16 h + t: turn it into A1[(r, c)][k] (gs_pge_make_a1_v5_kernel, same arithmetic)
-      const float* __restrict__ vk = vs + rsel * p.K + 32 * kb + 16 * h;
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) {
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(vk + 4 * t4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int k = 32 * kb + 16 * h + 4 * t4 + t;
-          const f32x4 c0 = gc[2 * k], c1 = gc[2 * k + 1];
-          const float x = ((a_cur[t4][t] + vv[t]) + c0[0]) - c0[1];
-          a_cur[t4][t] = fmaxf(fmaf(c0[3], x * c0[2], c1[0]), 0.f);
-        }
-      }
-    }
+    panel_transform_a<AGEN, FGEN>(p, a_cur, gc, vs, gen_d, rsel, kb, h);
     if constexpr (MODE == 0) {
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
@@ -362,6 +431,7 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
+  }
   }
 
   if (p.triage & 2) t_loop = __builtin_amdgcn_s_memrealtime();
@@ -475,6 +545,36 @@ __global__ void gs_panel_split_b_kernel(const float* __restrict__ W, long ldb, i
   o[32 + (k & 31)] = lb;
 }
 
+// W [N][ldb] fp32 -> the image of the exact three-way split: [N][K/16 sub-blocks][plane h, m, l][k half 0, 1][8] bf16, where the
+// sub-block of k is 2 (k >> 5) + ((k >> 3) & 1), its half (k >> 4) & 1, its element k & 7 (the order panel_tile<3, ...> consumes).
+// h = bf16(w), m = bf16(w - h), l = bf16(w - h - m): 8 + 8 + 8 significant bits = the 24 of an fp32, so h + m + l == w exactly.
+__global__ void gs_panel_split_b3_kernel(const float* __restrict__ W, long ldb, int N, int K, __bf16* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (row, k)
+  if (idx >= (long)N * K) return;
+  const int n = (int)(idx / K), k = (int)(idx % K);
+  const float w = W[(long)n * ldb + k];
+  const __bf16 hb = (__bf16)w;
+  const float r1 = w - (float)hb;
+  const __bf16 mb = (__bf16)r1;
+  const __bf16 lb = (__bf16)(r1 - (float)mb);
+  const int sb = 2 * (k >> 5) + ((k >> 3) & 1), half = (k >> 4) & 1, e = k & 7;
+  __bf16* o = out + ((long)n * (K >> 4) + sb) * 48 + half * 8 + e;
+  o[0] = hb; o[16] = mb; o[32] = lb;
+}
+
+// pre-split image of B for the operand mode (no-op for exact fp32); returns the row pitch in bytes
+static long panel_prepare_b(const float* W, long ldw, int N, int K, int prec, void* scratch, hipStream_t s, const void** Bout) {
+  if (prec == 0) { *Bout = W; return ldw * 4; }
+  const dim3 grid(gs_cdiv((long)N * K, 256)), block(256);
+  *Bout = scratch;
+  if (prec == 3) {
+    hipLaunchKernelGGL(gs_panel_split_b3_kernel, grid, block, 0, s, W, ldw, N, K, (__bf16*)scratch);
+    return (long)K * 6;
+  }
+  hipLaunchKernelGGL(gs_panel_split_b_kernel, grid, block, 0, s, W, ldw, N, K, (__bf16*)scratch);
+  return (long)K * 4;
+}
+
 static int g_panel_krep = 1, g_panel_triage = 0;
 extern "C" int gs_panel_debug(int krep, int triage) {      // measurement hook (tools/ab_panel.py), not part of the product ABI
   g_panel_krep = krep < 1 ? 1 : krep;
@@ -497,7 +597,7 @@ bool gs_panel_eligible(const gs_gemm_desc& p) {
   if (p.gatherA_m || p.gatherA_k || p.gatherB_k || p.bgen_mask) return false;
   if (p.sAk != 1 || p.sBk != 1 || p.alpha != 1.f || p.beta != 0.f) return false;
   if ((p.sAm & 3) || (p.sBn & 3) || (((uintptr_t)p.A | (uintptr_t)p.B) & 15)) return false;
-  if (p.prec < 0 || p.prec > 2) return false;
+  if (p.prec < 0 || p.prec > 3) return false;
   if (p.prec != 0 && !p.scratch) return false;
   return true;
 }
@@ -536,16 +636,11 @@ static void panel_dispatch(const gs_gemm_desc& d, gs_panel_args& a, hipStream_t 
   panel_split(d.M, &nf, &nn);
   a.n_full = nf;
   const dim3 grid(nf + nn), block(256);
-  if (d.prec == 0) {
-    a.B = d.B; a.ldb_bytes = d.sBn * 4;
-    hipLaunchKernelGGL((gs_panel_gemm_kernel<0, NT>), grid, block, 0, s, a);
-  } else {
-    hipLaunchKernelGGL(gs_panel_split_b_kernel, dim3(gs_cdiv((long)d.N * d.K, 256)), dim3(256), 0, s, d.B, d.sBn, d.N, d.K,
-                       (__bf16*)d.scratch);
-    a.B = d.scratch; a.ldb_bytes = (long)d.K * 4;
-    if (d.prec == 1) hipLaunchKernelGGL((gs_panel_gemm_kernel<1, NT>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gs_panel_gemm_kernel<2, NT>), grid, block, 0, s, a);
-  }
+  a.ldb_bytes = panel_prepare_b(d.B, d.sBn, d.N, d.K, d.prec, d.scratch, s, &a.B);
+  if (d.prec == 0) hipLaunchKernelGGL((gs_panel_gemm_kernel<0, NT>), grid, block, 0, s, a);
+  else if (d.prec == 1) hipLaunchKernelGGL((gs_panel_gemm_kernel<1, NT>), grid, block, 0, s, a);
+  else if (d.prec == 2) hipLaunchKernelGGL((gs_panel_gemm_kernel<2, NT>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gs_panel_gemm_kernel<3, NT>), grid, block, 0, s, a);
 }
 
 int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s) {
@@ -606,7 +701,7 @@ int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, lo
                         int K, float* colstat, int prec, void* scratch, unsigned long long* span, hipStream_t s) {
   if (!g_panel_a1gen || !g_panel_enabled || !a1 || !a1->table || n < 128 || nr < 1) return GS_ERR_UNSUPPORTED;   // (<= 2 r per tile)
   if ((N != 256 && N != 128) || K < 32 || K > 256 || (K & 31) || (ldw & 3) || (a1->ld & 3)) return GS_ERR_UNSUPPORTED;
-  if ((double)nr * n * (double)ldc >= 4294967296.0 || (prec != 0 && !scratch) || prec < 0 || prec > 2) return GS_ERR_UNSUPPORTED;
+  if ((double)nr * n * (double)ldc >= 4294967296.0 || (prec != 0 && !scratch) || prec < 0 || prec > 3) return GS_ERR_UNSUPPORTED;
   if ((((uintptr_t)a1->U | (uintptr_t)a1->V | (uintptr_t)W) & 15)) return GS_ERR_UNSUPPORTED;
   gs_panel_args a;
   memset(&a, 0, sizeof(a));
@@ -619,12 +714,7 @@ int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, lo
   panel_split(a.M, &nf, &nn);
   a.n_full = nf;
   const dim3 grid(nf + nn), block(256);
-  if (prec == 0) {
-    a.B = W; a.ldb_bytes = ldw * 4;
-  } else {
-    hipLaunchKernelGGL(gs_panel_split_b_kernel, dim3(gs_cdiv((long)N * K, 256)), dim3(256), 0, s, W, ldw, N, K, (__bf16*)scratch);
-    a.B = scratch; a.ldb_bytes = (long)K * 4;
-  }
+  a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);
 #define GS_FWD_LAUNCH(MODE_)                                                                    \
   do {                                                                                          \
     if (N == 256) hipLaunchKernelGGL((gs_panel_fwdgen_kernel<MODE_, 8>), grid, block, 0, s, a); \
@@ -632,7 +722,8 @@ int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, lo
   } while (0)
   if (prec == 0) GS_FWD_LAUNCH(0);
   else if (prec == 1) GS_FWD_LAUNCH(1);
-  else GS_FWD_LAUNCH(2);
+  else if (prec == 2) GS_FWD_LAUNCH(2);
+  else GS_FWD_LAUNCH(3);
 #undef GS_FWD_LAUNCH
   GS_LAUNCH_CHECK();
   return GS_OK;
@@ -643,8 +734,9 @@ int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, con
                        hipStream_t s) {
   if (a1 && (!g_panel_a1gen || !a1->table || (a1->ld & 3))) a1 = nullptr;
   if (!a1 && !mask) return GS_ERR_UNSUPPORTED;
-  // (generated operand: fp32 at N = 256 — the bf16 conversions next to it need more than 256 registers there — any mode at N = 128)
-  if (gen && (g_panel_marg < 2 || K > 256 || !gen->table || (N == 256 && prec != 0))) return GS_ERR_UNSUPPORTED;
+  // (generated operand: modes 0 and 3 at N = 256 — the up-front bf16 conversions of modes 1 and 2 next to it need more than 256
+  // registers there — any mode at N = 128)
+  if (gen && (g_panel_marg < 2 || K > 256 || !gen->table || (N == 256 && (prec == 1 || prec == 2)))) return GS_ERR_UNSUPPORTED;
   if (!g_panel_marg || !g_panel_enabled || (N != 256 && N != 128) || K < 32 || (K & 31) || (lda & 3) || (ldw & 3)) return GS_ERR_UNSUPPORTED;
   if ((double)nr * n * (double)ldmask >= 4294967296.0 || (prec != 0 && !scratch) || nr < 1) return GS_ERR_UNSUPPORTED;
   if ((((uintptr_t)dE2 | (uintptr_t)W) & 15)) return GS_ERR_UNSUPPORTED;
@@ -665,16 +757,11 @@ int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, con
     a.a1_U = a1->U; a.a1_V = a1->V; a.a1_ld = a1->ld; a.a1_c = a1->table;
   }
   const dim3 grid((unsigned)(gs_cdiv(nr, 16) * a.mg_ncb)), block(256);
-  if (prec == 0) {
-    a.B = W; a.ldb_bytes = ldw * 4;
-  } else {
-    hipLaunchKernelGGL(gs_panel_split_b_kernel, dim3(gs_cdiv((long)N * K, 256)), dim3(256), 0, s, W, ldw, N, K, (__bf16*)scratch);
-    a.B = scratch; a.ldb_bytes = (long)K * 4;
-  }
+  a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);
 #define GS_MARG_LAUNCH(MODE_)                                                                                        \
   do {                                                                                                               \
-    if (N == 256 && gen && a1) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, true, true>), grid, block, 0, s, a);       \
-    else if (N == 256 && gen) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, true, false>), grid, block, 0, s, a);       \
+    if (N == 256 && gen && a1) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, (MODE_ == 0 || MODE_ == 3), true>), grid, block, 0, s, a); \
+    else if (N == 256 && gen) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, (MODE_ == 0 || MODE_ == 3), false>), grid, block, 0, s, a); \
     else if (N == 256 && a1) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, false, true>), grid, block, 0, s, a);        \
     else if (N == 256) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, false, false>), grid, block, 0, s, a);             \
     else if (gen && a1) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 4, true, true>), grid, block, 0, s, a);              \
@@ -684,7 +771,8 @@ int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, con
   } while (0)
   if (prec == 0) GS_MARG_LAUNCH(0);
   else if (prec == 1) GS_MARG_LAUNCH(1);
-  else GS_MARG_LAUNCH(2);
+  else if (prec == 2) GS_MARG_LAUNCH(2);
+  else GS_MARG_LAUNCH(3);
 #undef GS_MARG_LAUNCH
   GS_LAUNCH_CHECK();
   return GS_OK;

@@ -402,10 +402,11 @@ class GCondEngine:
     def set_identity_structure(self, on=True):
         check(self.L.gs_gcond_set_identity_structure(self.h, int(on), self._s()))
 
-    OPERAND_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2}
+    OPERAND_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x6": 3}
 
     def set_operand_mode(self, mode):
-        """Operand precision of the three row-panel products (gs_gcond_set_operand_mode): 'f32' (default), 'bf16x3', 'bf16'."""
+        """Operand form of the row-panel products (gs_gcond_set_operand_mode): 'f32' (default, fp32 MFMA), 'bf16x6' (exact
+        three-way bf16 split, 6 bf16 MFMAs, fp32 accumulate: fp32-level error), 'bf16x3' (two-way split, 3 MFMAs), 'bf16'."""
         check(self.L.gs_gcond_set_operand_mode(self.h, self.OPERAND_MODES.get(mode, mode)))
 
     def set_overlap(self, on):

@@ -75,8 +75,12 @@ typedef struct gs_gemm_desc {
   int bgen_div;
   /* operand precision of the row-panel kernel (N == 256, both operands k-contiguous, unbatched, M >= 2048; other shapes
      ignore it and compute in exact fp32): 0 = exact fp32 MFMA (default), 1 = split bf16 x3 (A = Ah + Al, B = Bh + Bl,
-     C += Al Bh + Ah Bl + Ah Bh, fp32 accumulate: ~2^-16 relative operand representation), 2 = bf16 operands (Ah Bh only).
-     prec != 0 needs `scratch`: N * K * 4 bytes of device memory for the pre-split B. */
+     C += Al Bh + Ah Bl + Ah Bh, fp32 accumulate: ~2^-16 relative operand representation), 2 = bf16 operands (Ah Bh only),
+     3 = EXACT three-way split (x = h + m + l with 8 + 8 + 8 significant bits = the 24 of an fp32, so the operands are
+     represented exactly; C += Al Bh + Ah Bl + Am Bm + Am Bh + Ah Bm + Ah Bh on the bf16 MFMA with fp32 accumulation: the three
+     dropped cross terms are <= 2^-23 of a product, the size of fp32's own rounding — measured error against fp64 equal to
+     the fp32 MFMA's, tests/test_gpu_panel.py; 6 MFMAs at 16x the fp32 rate).
+     prec != 0 needs `scratch`: N * K * 4 bytes (modes 1, 2) or N * K * 6 bytes (mode 3) of device memory for the pre-split B. */
   int prec;
   void* scratch;
 } gs_gemm_desc;

@@ -2,6 +2,8 @@
    f32    exact fp32 MFMA                       gate 2e-5 relative (fp32 re-association only)
    bf16x3 split bf16 x3, fp32 accumulate        gate 1e-4 of the output's max  (operands represented to 2^-16)
    bf16   bf16 operands, fp32 accumulate        gate 2e-2 of the output's max  (operands rounded to 8 significant bits)
+   bf16x6 EXACT 3-way bf16 split, 6 products    the fp32 gate (2e-6): the operands are represented exactly (8 + 8 + 8 bits),
+          fp32 accumulate                       the dropped cross terms are <= 2^-23 of a product
 Needs an MI355X."""
 import ctypes as C
 
@@ -11,7 +13,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-MODES = {"f32": (0, 2e-5, 2e-6), "bf16x3": (1, 2e-4, 1e-4), "bf16": (2, 5e-2, 2e-2)}
+MODES = {"f32": (0, 2e-5, 2e-6), "bf16x3": (1, 2e-4, 1e-4), "bf16": (2, 5e-2, 2e-2), "bf16x6": (3, 2e-5, 2e-6)}
 
 
 @pytest.fixture(scope="module")
@@ -26,7 +28,7 @@ def run(E, A, W, mode, **kw):
     M, K = A.shape
     N = W.shape[0]
     out = torch.full((M, N), float("nan"), device=DEV)
-    scratch = torch.empty(N * K, device=DEV)
+    scratch = torch.empty(N * K * 3 // 2 + 16, device=DEV)      # 4 B (modes 1, 2) or 6 B (mode 3) per element of B
     d, keep = E.gemm_desc(A, W, out, M, N, K, (K, 1), (1, K), N, prec=mode, scratch=scratch, **kw)
     assert _lib.lib().gs_gemm_route(C.byref(d)) == 5
     _lib.check(_lib.lib().gs_gemm_f32(C.byref(d), _lib.stream()))
@@ -173,3 +175,31 @@ def test_generated_a1_operand_and_mask_are_bitwise_the_materialised_form(mode, p
         if what == "d_pge" and not param_grads:
             continue
         assert torch.equal(a, b), (what, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("M,K,N", [(206116, 256, 256), (169343, 128, 256), (19600, 128, 128)])
+def test_exact_three_way_split_has_the_error_of_the_fp32_mfma(E, M, K, N):
+    """Operand mode 3 ('bf16x6') against fp64 next to the native fp32 MFMA on the same operands, at the bench shapes: the split
+    represents every fp32 operand exactly (h + m + l == x, checked here on the host), the six bf16 products are exact in fp32,
+    and what is dropped (Am Bl + Al Bm + Al Bl) is <= 2^-23 of a product — so the result must be as close to fp64 as the fp32
+    pipe's (whose own rounding is 2^-24 per multiply-add).  Gate: max error <= 1.5 x the fp32 kernel's (+ one ulp of slack),
+    mean error <= 1.5 x."""
+    torch.manual_seed(M + K + N)
+    A = torch.randn(M, K) * torch.exp(torch.randn(M, 1))         # rows of very different scale
+    W, b = torch.randn(N, K) / np.sqrt(K), torch.randn(N)
+    # the split itself: three bf16 parts reproduce the fp32 value bit for bit
+    h = A.bfloat16().float()
+    m = (A - h).bfloat16().float()
+    l = (A - h - m).bfloat16().float()
+    assert torch.equal((h + m) + l, A)
+    ref = A.double() @ W.double().T + b.double()
+    scale = float(ref.abs().max())
+    errs = {}
+    for mode in ("f32", "bf16x6"):
+        out = run(E, A.to(DEV), W.to(DEV), MODES[mode][0], bias=b.to(DEV)).double().cpu()
+        d = (out - ref).abs()
+        errs[mode] = (float(d.max()) / scale, float(d.mean()) / scale)
+    print(f"M={M} K={K} N={N}: max / mean error over max|ref|  fp32 MFMA {errs['f32'][0]:.3e} / {errs['f32'][1]:.3e}   "
+          f"3-way split {errs['bf16x6'][0]:.3e} / {errs['bf16x6'][1]:.3e}")
+    assert errs["bf16x6"][0] <= 1.5 * errs["f32"][0] + 1.2e-7, errs
+    assert errs["bf16x6"][1] <= 1.5 * errs["f32"][1], errs
