@@ -30,11 +30,12 @@ def case(name, M, K, **kw):
     a = torch.randn(M, K, device=dev)
     w = torch.randn(256, K, device=dev) / K ** 0.5
     out = torch.empty(M, 256, device=dev)
-    scratch = torch.empty(256 * K, device=dev)
+    scratch = torch.empty(256 * K * 3 // 2 + 16, device=dev)
     extra = {k: (v() if callable(v) else v) for k, v in kw.items()}
     res = {}
     variants = [("tile128", 0, 0, 0), ("panel f32 wide-tail", 1, 0, 0), ("panel f32", 1, 0, 1),
-                ("panel bf16x3 wide-tail", 1, 1, 0), ("panel bf16x3", 1, 1, 1), ("panel bf16", 1, 2, 1)]
+                ("panel bf16x6 (exact split)", 1, 3, 1), ("panel bf16x3 wide-tail", 1, 1, 0), ("panel bf16x3", 1, 1, 1),
+                ("panel bf16", 1, 2, 1)]
     for rnd in range(3):
         for label, panel, prec, deph in variants:
             L.gs_gemm_set_panel(panel)
@@ -47,7 +48,7 @@ def case(name, M, K, **kw):
     flops = 2.0 * M * 256 * K
     for label, ts in res.items():
         t = min(ts)
-        print(f"{name:28s} {label:22s} min {t:7.1f} us  median {sorted(ts)[1]:7.1f} us   {flops / t / 1e6:7.1f} TFLOP/s   "
+        print(f"{name:28s} {label:26s} min {t:7.1f} us  median {sorted(ts)[1]:7.1f} us   {flops / t / 1e6:7.1f} TFLOP/s   "
               f"{(M * K + M * 256) * 4 / t / 1e6:5.2f} TB/s (A read + C write)")
 
 
@@ -59,8 +60,8 @@ def looprate():
     a = torch.randn(M, K, device=dev)
     w = torch.randn(256, K, device=dev) / 16
     out = torch.empty(M, 256, device=dev)
-    scratch = torch.empty(256 * K, device=dev)
-    for prec in (0, 1):
+    scratch = torch.empty(256 * K * 3 // 2 + 16, device=dev)
+    for prec in (0, 3, 1):
         for tri in (0, 1):
             ts = []
             for R in (1, 2, 3):

@@ -38,7 +38,7 @@ def reset():
     L.gs_gcond_set_folded_reductions(1)
 
 
-for mode in ("f32", "bf16x3", "bf16"):
+for mode in ("f32", "bf16x6", "bf16x3", "bf16"):
     eng.set_operand_mode(mode)
     for rnd in range(2):
         for label, setup in (("round-2 first form: dY1 materialised, A1 materialised", lambda: (L.gs_gemm_set_panel_marg(0), L.gs_gemm_set_panel_a1gen(0))),

@@ -27,6 +27,7 @@ python3 tools/make_pmc_summary.py $O/pmc_bench_FETCH_SIZE $O/pmc_bench_WRITE_SIZ
 python3 tools/pmc_summary.py $O/pmc_panel_sq $O/pmc_panel_grbm > $O/pmc_panel_sq_summary.txt
 find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -delete
 timeout 300 python tools/stage_times.py ogbn-arxiv f32 2>/dev/null | grep -v "^/opt" > $O/stage_times.txt
+timeout 300 python tools/stage_times.py ogbn-arxiv bf16x6 2>/dev/null | grep -v "^/opt" >> $O/stage_times.txt
 timeout 300 python tools/stage_times.py ogbn-arxiv bf16x3 2>/dev/null | grep -v "^/opt" >> $O/stage_times.txt
 timeout 600 python tools/ab_pge_forms.py > $O/ab_pge_forms.txt 2>&1
 timeout 300 python tools/host_issue.py > $O/host_issue.txt 2>&1

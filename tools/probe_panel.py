@@ -21,9 +21,9 @@ a = torch.randn(rows, ph, device=dev)
 w = torch.randn(ph, ph, device=dev) / 16
 b = torch.randn(ph, device=dev)
 out = torch.empty(rows, ph, device=dev)
-scratch = torch.empty(ph * ph, device=dev)
+scratch = torch.empty(ph * ph * 3 // 2 + 16, device=dev)
 stat = torch.empty(-(-rows // 128), 2, ph, device=dev)
-for prec in (0, 1, 2):
+for prec in (0, 3, 1, 2):
     d, keep = gemm_desc(a, w, out, rows, ph, ph, (ph, 1), (1, ph), ph, prec=prec, scratch=scratch, bias=b, colstat=stat)
     assert L.gs_gemm_route(C.byref(d)) == 5
     for _ in range(5):
@@ -36,7 +36,7 @@ eng = bench.make_engine(p, dev)
 bench.init_state(p, eng)
 bench.new_model(p, eng)
 eng.outer_step(10)
-for mode in ("f32", "bf16x3", "bf16"):
+for mode in ("f32", "bf16x6", "bf16x3", "bf16"):
     eng.set_operand_mode(mode)
     for _ in range(5):
         eng.pge_forward_part(False, 1)
