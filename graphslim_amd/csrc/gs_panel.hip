@@ -66,7 +66,7 @@ struct gs_panel_args {
 // issued before it — a full write round trip per tile (17-37 us of the 70 us the first build of this kernel spent outside its
 // K loop, tools/trace_panel.py).  So the bias row is parked in LDS before the K loop (LDS reads count on lgkmcnt, not vmcnt) and
 // the code is branch-free per (HAS_MASK, FULL) instantiation.
-template <int NTW, bool HAS_MASK, bool FULL>
+template <int NTW, bool HAS_MASK, bool FULL, int BS = 1>
 __device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32x16 (&acc)[NTW], const float* sbias, int m0,
                                                int row_in_tile, int col0, float (&cs1)[NTW], float (&cs2)[NTW]) {
   const float floor_ = p.relu ? 0.f : -__builtin_inff();
@@ -93,7 +93,7 @@ __device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32
       for (int r = 0; r < 16; ++r) mk[r] = Mb[moff[r] + 32u * j];
     }
     float v[16];
-    const float bvj = sbias[col0 + 32 * j];
+    const float bvj = sbias[(col0 + 32 * j) * BS];      // (BS = 8: the bias sits in slot 7 of the mode-3 constants table)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       v[r] = fmaxf(acc[j][r] + bvj, floor_);
@@ -201,7 +201,7 @@ __device__ __forceinline__ void panel_epilogue_marg(const gs_panel_args& p, cons
 //         (gs_pge_bn2_bwd_v4_kernel, same arithmetic, constants folded into the [K][8] table gc)
 //   FGEN: a holds U[c][k]   -> A1[(r, c)][k] = relu(g1 ((U[c][k] + V[r][k] + b0 - mu1) is1) + be1)   (gs_pge_make_a1_v5_kernel,
 //         same arithmetic; V rows in LDS at vs, constants table gc)
-template <bool AGEN, bool FGEN>
+template <bool AGEN, bool FGEN, bool VTAB = false>
 __device__ __forceinline__ void panel_transform_a(const gs_panel_args& p, f32x4 (&a)[4], const f32x4* __restrict__ gc,
                                                   const float* __restrict__ vs, float gen_d, int rsel, int kb, int h) {
   if constexpr (AGEN) {
@@ -215,7 +215,16 @@ __device__ __forceinline__ void panel_transform_a(const gs_panel_args& p, f32x4 
       a[t >> 2][t & 3] = fmaf(-xh, c1[2], sel - c1[1]);
     }
   }
-  if constexpr (FGEN) {
+  if constexpr (FGEN && VTAB) {       // mode 3: the two V rows of the tile ride in slots 5 / 6 of the constants table
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int k = 32 * kb + 16 * h + t;
+      const f32x4 c0 = gc[2 * k], c1 = gc[2 * k + 1];
+      const float x = ((a[t >> 2][t & 3] + (rsel ? c1[2] : c1[1])) + c0[0]) - c0[1];
+      a[t >> 2][t & 3] = fmaxf(fmaf(c0[3], x * c0[2], c1[0]), 0.f);
+    }
+  }
+  if constexpr (FGEN && !VTAB) {
     const float* __restrict__ vk = vs + rsel * p.K + 32 * kb + 16 * h;
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
@@ -243,7 +252,12 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   static_assert(!AGEN || MARG, "the generated dE2 operand is used by the fused-marginals form only");
   static_assert(!MGEN || MARG, "the regenerated mask belongs to the fused-marginals epilogue");
   static_assert(!FGEN || !MARG, "the generated A1 operand is used by the forward product only");
-  float* sbias = reinterpret_cast<float*>(smem + 2 * PN_STAGE);
+  // LDS: modes 0-2  [2 B stages of N x 128 B][bias N floats][constants table K x 8 floats (AGEN / FGEN)][2 V rows (FGEN)]
+  //      mode 3     [3 B sub-stages of N x 96 B][ONE table of 256 x 8 floats: generated-operand constants in slots 0-4 (0-6),
+  //                  the tile's two V rows in slots 5 / 6 (FGEN), the bias in slot 7] — 72 + 8 = 80 KB at N = 256: exactly two
+  //                  workgroups per CU with a prefetch distance of two sub-stages
+  constexpr int S3 = PN_N * 96, OFF_X = MODE == 3 ? 3 * S3 : 2 * PN_STAGE, BS = MODE == 3 ? 8 : 1;
+  float* sbias = reinterpret_cast<float*>(smem + OFF_X) + (MODE == 3 ? 7 : 0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
@@ -294,20 +308,42 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   // the bias row goes to LDS now and is read back in the epilogue: an LDS read counts on lgkmcnt, so it can sit between the
   // stores of two tiles without waiting for them (a global load there would: vmcnt retires in order), and no register is held
   // across the K loop
-  if (tid < PN_N) sbias[tid] = p.bias ? p.bias[tid] : 0.f;
+  if constexpr (MODE != 3) {
+    if (tid < PN_N) sbias[tid] = p.bias ? p.bias[tid] : 0.f;
+  }
   // AGEN: the per-column constants of the operand transform sit behind the bias row ([K <= 256][8] floats), this lane's
   // pair row has ONE upstream scalar (de3 of the pair)
-  const f32x4* __restrict__ gc = reinterpret_cast<const f32x4*>(smem + 2 * PN_STAGE + PN_N * 4);
+  const f32x4* __restrict__ gc = reinterpret_cast<const f32x4*>(smem + OFF_X + (MODE == 3 ? 0 : PN_N * 4));
   float gen_d = 0.f;
-  if constexpr (AGEN) {
+  if constexpr (AGEN) gen_d = p.gen_d[min(row, p.M - 1)];
+  if constexpr (MODE == 3) {
+    // one pass writes the whole table: thread i owns half-row i (row k = i >> 1): no two threads touch the same 16 bytes
+    f32x4* gw = reinterpret_cast<f32x4*>(smem + OFF_X);
+    const float* __restrict__ tab = AGEN ? p.gen_c : (FGEN ? p.a1_c : nullptr);
+    const int r0 = FGEN ? m0 / p.mg_n : 0;
+    for (int i = tid; i < 512; i += 256) {
+      const int k = i >> 1;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if ((AGEN || FGEN) && k < p.K) t = reinterpret_cast<const f32x4*>(tab)[i];
+      if (i & 1) {
+        if constexpr (FGEN) {
+          if (k < p.K) {
+            t[1] = p.a1_V[(long)min(r0, p.mg_nr - 1) * p.a1_ld + k];
+            t[2] = p.a1_V[(long)min(r0 + 1, p.mg_nr - 1) * p.a1_ld + k];
+          }
+        }
+        if constexpr (!MARG) t[3] = (p.bias && k < PN_N) ? p.bias[k] : 0.f;
+      }
+      gw[i] = t;
+    }
+  } else if constexpr (AGEN) {
     f32x4* gw = reinterpret_cast<f32x4*>(smem + 2 * PN_STAGE + PN_N * 4);
     for (int i = tid; i < 2 * p.K; i += 256) gw[i] = reinterpret_cast<const f32x4*>(p.gen_c)[i];
-    gen_d = p.gen_d[min(row, p.M - 1)];
   }
 
   // FGEN: [K][8] layer-1 constants behind the bias row, then the V rows of the tile's (at most two) r
   const float* __restrict__ vs = reinterpret_cast<const float*>(smem + 2 * PN_STAGE + PN_N * 4 + 256 * 32);
-  if constexpr (FGEN) {
+  if constexpr (FGEN && MODE != 3) {
     f32x4* gw = reinterpret_cast<f32x4*>(smem + 2 * PN_STAGE + PN_N * 4);
     for (int i = tid; i < 2 * p.K; i += 256) gw[i] = reinterpret_cast<const f32x4*>(p.a1_c)[i];
     f32x4* vw = reinterpret_cast<f32x4*>(smem + 2 * PN_STAGE + PN_N * 4 + 256 * 32);
@@ -333,25 +369,39 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
         const int lrow = g / 6, slot = g - lrow * 6;
         const int piece = (slot + 3 * ((lrow >> 3) & 1)) % 6;
         const char* src = Bb + (long)lrow * p.ldb_bytes + sb * 96 + piece * 16;
-        __builtin_amdgcn_global_load_lds((gs_gbl_ptr)src, (gs_lds_ptr)(smem + st * PN_STAGE + (wave * PW3 + q) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gs_gbl_ptr)src, (gs_lds_ptr)(smem + st * S3 + (wave * PW3 + q) * 1024), 16, 0, 0);
       }
     };
     const int sh3 = 3 * ((li >> 3) & 1);
     int boff[3];                           // byte offset of this lane's (plane P, k half h) piece inside its LDS row
 #pragma unroll
     for (int P = 0; P < 3; ++P) boff[P] = ((2 * P + h + sh3) % 6) * 16;
+    // Ring of three sub-stages, prefetch distance two: a 16-k step is ~0.7 us of MFMA time, less than the L2 -> LDS latency
+    // (the one-step-ahead form ran this loop at 136 us per pass against an MFMA floor of 64).  vmcnt retires in order; the
+    // issue order inside a step is [A fragments of the next 32-k block (u == 0)] then [sub-stage ss + 2], so
+    //   top of step ss:   sub-stage ss has landed when at most (PW3 + (u == 1 ? 4 : 0)) newer loads are outstanding
+    //   end of a u == 1 step: the A fragments (issued one step ago) have landed when at most 2 PW3 newer loads are outstanding
+    // (0 once nothing newer has been issued: the last step).
+    constexpr int PW3c = 3 * NT / 4;
     const int nsb = 2 * nkb, nsb_run = nsb * p.krep;
-    stage_b3(0, 0);
     load_a(0, a_cur);
+    stage_b3(0, 0);
+    if (nsb_run > 1) stage_b3(1 % nsb, 1);
+    int slot = 0;
     for (int ss = 0; ss < nsb_run; ++ss) {
       const int sb = ss % nsb, u = sb & 1, kb = sb >> 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (ss + 1 < nsb_run) stage_b3((sb + 1) % nsb, (ss + 1) & 1);
+      if (ss + 1 >= nsb_run) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (u == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW3c + 4) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW3c) : "memory");
+      // (a bare barrier: __syncthreads() carries a workgroup-scope release fence, which the compiler lowers to vmcnt(0) and
+      // would drain the two prefetched sub-stages at every step; LDS visibility of the direct-to-LDS loads is what the vmcnt
+      // above waits for, this wave's own LDS reads of the stage about to be overwritten are done once lgkmcnt is 0)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (u == 0) {
         if (ss + 2 < nsb_run) load_a(((sb + 2) % nsb) >> 1, a_nxt);
-        panel_transform_a<AGEN, FGEN>(p, a_cur, gc, vs, gen_d, rsel, kb, h);
       }
+      if (ss + 2 < nsb_run) stage_b3((sb + 2) % nsb, slot == 0 ? 2 : slot - 1);      // slot of ss + 2 = (slot + 2) % 3
+      if (u == 0) panel_transform_a<AGEN, FGEN, true>(p, a_cur, gc, vs, gen_d, rsel, kb, h);
       bf16x8 ah, am, al;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -361,12 +411,19 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
         const __bf16 mb = (__bf16)r1;
         ah[e] = hb; am[e] = mb; al[e] = (__bf16)(r1 - (float)mb);
       }
-      const char* __restrict__ bs3 = smem + (ss & 1) * PN_STAGE + (32 * j0 + li) * 96;
+      const char* __restrict__ bs3 = smem + slot * S3 + (32 * j0 + li) * 96;
+      // B fragments one tile ahead of the MFMAs that consume them (the six MFMAs of a tile are 192 cycles: too short to hide an
+      // LDS read issued right in front of them)
+      bf16x8 bq[2][3];
+#pragma unroll
+      for (int P = 0; P < 3; ++P) bq[0][P] = *reinterpret_cast<const bf16x8*>(bs3 + boff[P]);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bs3 + j * (32 * 96) + boff[0]);
-        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bs3 + j * (32 * 96) + boff[1]);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bs3 + j * (32 * 96) + boff[2]);
+        if (j + 1 < NTW) {
+#pragma unroll
+          for (int P = 0; P < 3; ++P) bq[(j + 1) & 1][P] = *reinterpret_cast<const bf16x8*>(bs3 + (j + 1) * (32 * 96) + boff[P]);
+        }
+        const bf16x8 bh = bq[j & 1][0], bm = bq[j & 1][1], bl = bq[j & 1][2];
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);     // small terms first
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
@@ -375,9 +432,11 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
       }
       if (u == 1) {
+        if (ss + 1 < nsb_run) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW3c) : "memory");
 #pragma unroll
         for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
       }
+      slot = slot == 2 ? 0 : slot + 1;
     }
   } else {
   stage_b(0, 0);
@@ -446,11 +505,11 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   const bool full = m0 + ROWS <= p.M;
   float cs1[NTW], cs2[NTW];
   if (p.mask) {
-    if (full) panel_epilogue<NTW, true, true>(p, acc, sbias, m0, rit, col0, cs1, cs2);
-    else panel_epilogue<NTW, true, false>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+    if (full) panel_epilogue<NTW, true, true, BS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+    else panel_epilogue<NTW, true, false, BS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
   } else {
-    if (full) panel_epilogue<NTW, false, true>(p, acc, sbias, m0, rit, col0, cs1, cs2);
-    else panel_epilogue<NTW, false, false>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+    if (full) panel_epilogue<NTW, false, true, BS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+    else panel_epilogue<NTW, false, false, BS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
   }
   if (has_stat) {
     // per-tile column sums / sums of squares of the written rows: colstat[(stat_row * 2 + q) * N + col]
@@ -491,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) 
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;   // bytes of one K block of B in LDS: N rows x 128 B
   // (ONE __shared__ object: a second one beside a direct-to-LDS staging array can make hipcc drain vmcnt before every
   // ds_read, cdna_hip_programming.md section 5 "three .s-level traps" (a)) — the bias row lives behind the two B stages
-  __shared__ __attribute__((aligned(16))) char smem[2 * PN_STAGE + PN_N * 4];
+  __shared__ __attribute__((aligned(16))) char smem[MODE == 3 ? 3 * PN_N * 96 + 8192 : 2 * PN_STAGE + PN_N * 4];
   const int b = blockIdx.x;
   if (b < p.n_full) panel_tile<MODE, NT, 1>(p, smem, b * PN_BM, b);
   else panel_tile<MODE, NT, 4>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
@@ -500,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) 
 template <int MODE, int NT, bool AGEN, bool MGEN>
 __global__ __launch_bounds__(256, 2) void gs_panel_marg_kernel(gs_panel_args p) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;
-  __shared__ __attribute__((aligned(16))) char smem[2 * PN_STAGE + PN_N * 4 + (AGEN ? 256 * 32 : 0)];
+  __shared__ __attribute__((aligned(16))) char smem[MODE == 3 ? 3 * PN_N * 96 + 8192 : 2 * PN_STAGE + PN_N * 4 + (AGEN ? 256 * 32 : 0)];
   panel_tile<MODE, NT, 1, true, AGEN, MGEN>(p, smem, blockIdx.x, 0);
 }
 
@@ -508,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void gs_panel_marg_kernel(gs_panel_args p) 
 template <int MODE, int NT>
 __global__ __launch_bounds__(256, 2) void gs_panel_fwdgen_kernel(gs_panel_args p) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;
-  __shared__ __attribute__((aligned(16))) char smem[2 * PN_STAGE + PN_N * 4 + 256 * 32 + 2 * 256 * 4];
+  __shared__ __attribute__((aligned(16))) char smem[MODE == 3 ? 3 * PN_N * 96 + 8192 : 2 * PN_STAGE + PN_N * 4 + 256 * 32 + 2 * 256 * 4];
   const int b = blockIdx.x;
   if (b < p.n_full) panel_tile<MODE, NT, 1, false, false, false, true>(p, smem, b * PN_BM, b);
   else panel_tile<MODE, NT, 4, false, false, false, true>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
