@@ -573,15 +573,6 @@ __global__ __launch_bounds__(256, 2) void gs_panel_fwdgen_kernel(gs_panel_args p
   else panel_tile<MODE, NT, 4, false, false, false, true>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
 }
 
-// a1_c[k][8] from the layer-0 bias and the BatchNorm-1 quantities (one thread per column)
-__global__ void gs_panel_a1_consts_kernel(const float* __restrict__ b0, const float* __restrict__ mu1, const float* __restrict__ is1,
-                                          const float* __restrict__ g1, const float* __restrict__ be1, int K, float* __restrict__ out) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
-  float* o = out + 8 * k;
-  o[0] = b0[k]; o[1] = mu1[k]; o[2] = is1[k]; o[3] = g1[k]; o[4] = be1[k]; o[5] = o[6] = o[7] = 0.f;
-}
-
 // gen_c[k][8] from the BatchNorm-2 / layer-3 quantities (one thread per column)
 __global__ void gs_panel_gen_consts_kernel(const float* __restrict__ mu2, const float* __restrict__ is2, const float* __restrict__ g2,
                                            const float* __restrict__ be2, const float* __restrict__ w2, const float* __restrict__ dbe2,
@@ -732,24 +723,15 @@ extern "C" int gs_gemm_set_panel_marg(int level) {
 // (table_ready: the caller has filled `table` already — the engine's gs_pge_bwd_prep_kernel does, saving a launch)
 struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; int table_ready; };
 // Layer-1 activations as a function of U [n][ld], V [n][ld] (V + r_lo * ld is passed), the layer-0 bias and the BatchNorm-1
-// quantities (5 arrays of the hidden width) and an [width][8] float scratch table: with `a1` the marginals' [A1 > 0] mask is
-// recomputed from them (`mask` may be null), and gs_panel_forward_a1 forms the A operand of E2 = A1 W1^T + b1 from them.
+// quantities (5 arrays of the hidden width) and the [width][8] float constants table {b0, mu1, is1, g1, be1, 0, 0, 0} per column,
+// which the CALLER fills (the engine's gs_pge_bn1_stats_kernel writes it next to mu1 / is1): with `a1` the marginals' [A1 > 0]
+// mask is recomputed from them (`mask` may be null), and gs_panel_forward_a1 forms the A operand of E2 = A1 W1^T + b1 from them.
 struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; };
 
 static int g_panel_a1gen = 1;
 // measurement knob: 0 = always materialise A1 (round-2 first form), 1 (default) = generate it in the operand / mask path
 extern "C" int gs_gemm_set_panel_a1gen(int on) {
   g_panel_a1gen = on != 0;
-  return GS_OK;
-}
-
-// fills a1->table for `width` hidden columns: call once per (theta_PGE, BatchNorm-1 statistics) — i.e. after every
-// gs_pge_bn1_stats — before gs_panel_forward_a1 / gs_panel_marginals use the descriptor
-int gs_panel_a1_table(const gs_panel_a1* a1, int width, hipStream_t s) {
-  if (!a1 || !a1->table) return GS_ERR_ARG;
-  hipLaunchKernelGGL(gs_panel_a1_consts_kernel, dim3(gs_cdiv(width, 64)), dim3(64), 0, s, a1->b0, a1->mu1, a1->is1, a1->g1, a1->be1,
-                     width, a1->table);
-  GS_LAUNCH_CHECK();
   return GS_OK;
 }
 
