@@ -160,6 +160,25 @@ def sgc_forward(x, adj, params, nlayers=2):
     return F.log_softmax(x, dim=1)
 
 
+BN_EPS = 1e-5
+
+
+def sgc_bn_forward(x, adj, params, nlayers=2):
+    """models/sgc.py:27-33,37-57 with with_bn and ntrans = 2, as GCond runs it: check_bn (gcond_base.py:261-285) puts the
+    BatchNorm1d between the two transforms into eval mode before every train_class and inner step, and nothing ever runs it in
+    training mode in between, so its running statistics stay (0, 1) and it is the per-column affine map
+    y = x / sqrt(1 + eps) * weight + bias with TRAINABLE weight / bias.  params = [W1, b1, W2, b2, bn.weight, bn.bias]
+    (nn.Module.parameters() order: layers first, then bns)."""
+    w1, b1, w2, b2, g, be = params
+    x = x @ w1 + b1
+    x = x / torch.sqrt(torch.tensor(1.0 + BN_EPS, dtype=x.dtype)) * g + be
+    x = F.relu(x)
+    x = x @ w2 + b2
+    for i in range(nlayers):
+        x = _prop(adj[i] if isinstance(adj, (list, tuple)) else adj, x)
+    return F.log_softmax(x, dim=1)
+
+
 def gcn_forward(x, adj, params):
     """models/base.py:51-78 + layers.py:36-51: per layer adj @ (x@W) + b, relu between."""
     nl = len(params) // 2
@@ -326,6 +345,8 @@ def block_to_torch(block, dtype=torch.float32):
 def model_forward(kind, x, adj, params, nlayers):
     if kind == "SGC":
         return sgc_forward(x, adj, params, nlayers)
+    if kind == "SGC_BN":
+        return sgc_bn_forward(x, adj, params, nlayers)
     return gcn_forward(x, adj, params)
 
 

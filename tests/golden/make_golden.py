@@ -769,7 +769,81 @@ def g15():
     print("g15:", outcome)
 
 
+def g16():
+    """with_bn (gcond_base.py:261-285 check_bn, models/sgc.py:27-33,40): SGC with ntrans = 2 and a BatchNorm1d between the two
+    transforms.  GCond.reduce calls check_bn before every train_class (gcond.py:50), which puts every BatchNorm module into eval
+    mode — running statistics (0, 1 after model.initialize()) — while its weight / bias stay trainable parameters of the model:
+    train_class (loss, gradients at the X~ / A^ / theta_PGE interfaces) and two inner steps (gcond.py:63-72, torch Adam) with
+    BatchNorm weight / bias moved away from (1, 0) so that the affine map matters."""
+    out = {}
+    tag, n, nclass, d, hidden, T, rate = "bn", 80, 4, 6, 12, 2, 0.4
+    a, x, y = make_graph(n, nclass, d, 5, seed=43)
+    per = [max(6, n // (4 * nclass)) + 2 * c for c in range(nclass)]
+    data = FakeData(a, x, y, nclass, per, 10, 10, seed=2, sizes=(4, 3))
+    args = args_obj(ntrans=T, hidden=hidden, reduction_rate=rate, dataset="ogbn-arxiv", condense_model="SGC", with_bn=True,
+                    inner_loop=2, lr=0.01)
+    torch.manual_seed(63)
+    np.random.seed(63)
+    agent = GCondBase("trans", data, args)
+    n_syn = agent.nnodes_syn
+    with torch.no_grad():
+        agent.feat_syn.copy_(torch.randn(n_syn, d))
+    features, adj, labels = RU.to_tensor(data.feat_full, data.adj_full, label=data.labels_full, device="cpu")
+    adj = RU.normalize_adj_tensor(adj, sparse=True)
+    labels_syn = RU.to_tensor(label=data.labels_syn, device="cpu")
+    model = ref_model("SGC", d, hidden, nclass, args)
+    model.initialize()
+    with torch.no_grad():
+        model.bns[0].weight.copy_(1.0 + 0.3 * torch.randn(hidden))
+        model.bns[0].bias.copy_(0.2 * torch.randn(hidden))
+    model.train()
+    adj_syn = agent.pge(agent.feat_syn)
+    agent.adj_syn = RU.normalize_adj_tensor(adj_syn, sparse=False)
+    model = agent.check_bn(model)
+    assert not model.bns[0].training
+    calls0 = data.calls
+    loss = agent.train_class(model, adj, features, labels, labels_syn, args)
+    agent.optimizer_feat.zero_grad()
+    agent.optimizer_pge.zero_grad()
+    g_adjn = torch.autograd.grad(loss, agent.adj_syn, retain_graph=True)[0]
+    loss.backward()
+    coo = a.tocoo()
+    out.update({
+        f"{tag}_a_row": coo.row, f"{tag}_a_col": coo.col, f"{tag}_x": x, f"{tag}_y": y,
+        f"{tag}_idx_train": np_(data.idx_train), f"{tag}_meta": np.array([n, nclass, d, hidden, T, calls0]),
+        f"{tag}_rate": np.array(rate), f"{tag}_sizes": np.array((4, 3)), f"{tag}_labels_syn": np_(labels_syn),
+        f"{tag}_feat_syn": np_(agent.feat_syn), f"{tag}_loss": np_(loss), f"{tag}_dfeat": np_(agent.feat_syn.grad),
+        f"{tag}_adj_syn": np_(adj_syn), f"{tag}_adj_norm": np_(agent.adj_syn), f"{tag}_dadj_norm": np_(g_adjn),
+    })
+    names = [k for k, _ in model.named_parameters()]
+    out[f"{tag}_param_names"] = np.array(names)
+    for i, p in enumerate(model.parameters()):
+        out[f"{tag}_theta{i}"] = np_(p).copy()          # (a copy: the inner steps below update the parameters in place)
+    for i, p in enumerate(agent.pge.parameters()):
+        out[f"{tag}_pge{i}"], out[f"{tag}_dpge{i}"] = np_(p), np_(p.grad)
+    # inner steps exactly as gcond.py:63-72 (theta_PGE and X~ as they are: the optimisers above were not stepped)
+    optimizer_model = torch.optim.Adam(list(model.parameters()), lr=args.lr)
+    feat_inner = agent.feat_syn.detach()
+    adj_inner = agent.pge.inference(feat_inner)
+    adj_inner_norm = RU.normalize_adj_tensor(adj_inner, sparse=False)
+    losses = []
+    for _ in range(args.inner_loop):
+        optimizer_model.zero_grad()
+        o = model.forward(feat_inner, adj_inner_norm)
+        li = torch.nn.functional.nll_loss(o, labels_syn)
+        li.backward()
+        optimizer_model.step()
+        losses.append(float(li))
+    out[f"{tag}_adj_inner"] = np_(adj_inner)
+    out[f"{tag}_inner_losses"] = np.array(losses)
+    for i, p in enumerate(model.parameters()):
+        out[f"{tag}_theta_after{i}"] = np_(p)
+    out[f"{tag}_bn_running"] = np.stack([np_(model.bns[0].running_mean), np_(model.bns[0].running_var)])
+    save("g16_with_bn", **out)
+    print("g16:", names, float(loss), losses)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     for w in which:
         globals()[w]()

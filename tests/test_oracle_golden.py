@@ -146,6 +146,52 @@ def test_g7_train_class(golden_dir, tag, kind, metric):
             close(p.grad.numpy(), ref)
 
 
+def test_g16_with_bn_train_class_and_inner_steps(golden_dir):
+    """with_bn (gcond_base.py:261-285, models/sgc.py:27-33): the reference's train_class on an SGC with an eval-mode BatchNorm
+    between its two transforms (trainable weight / bias away from (1, 0)), and two inner steps with torch Adam."""
+    g = load(golden_dir, "g16_with_bn")
+    tag = "bn"
+    assert [str(v) for v in g["bn_param_names"]] == ["layers.0.weight", "layers.0.bias", "layers.1.weight", "layers.1.bias",
+                                                      "bns.0.weight", "bns.0.bias"]
+    np.testing.assert_array_equal(g["bn_bn_running"], np.stack([np.zeros(12, np.float32), np.ones(12, np.float32)]))
+    batches, (n, nclass, d, hidden, t) = rebuild_batches(g, tag)
+    theta = [T(g[f"{tag}_theta{i}"]).requires_grad_(True) for i in range(6)]
+    ps = [T(g[f"{tag}_pge{i}"]).requires_grad_(True) for i in range(10)]
+    pge = {"lin": ps[:6], "bn": ps[6:]}
+    feat_syn = T(g[f"{tag}_feat_syn"]).requires_grad_(True)
+    labels_syn = T(g[f"{tag}_labels_syn"])
+    _, ncd, _ = O.generate_labels_syn(g[f"{tag}_y"][g[f"{tag}_idx_train"]], float(g[f"{tag}_rate"]))
+    adj_norm = O.dense_gcn_norm(O.pge_forward(feat_syn, pge))
+    adj_norm.retain_grad()
+    loss = O.train_class("SGC_BN", theta, batches, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), feat_syn, adj_norm, labels_syn, ncd, nclass,
+                         2, "ours")
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(g[f"{tag}_loss"]), rtol=1e-4)
+
+    def close(a, ref, rtol=2e-3):
+        np.testing.assert_allclose(a, ref, rtol=rtol, atol=1e-4 * np.abs(ref).max())
+
+    close(adj_norm.grad.numpy(), g[f"{tag}_dadj_norm"])
+    close(feat_syn.grad.numpy(), g[f"{tag}_dfeat"])
+    for i, p in enumerate(ps):
+        ref = g[f"{tag}_dpge{i}"]
+        if np.abs(ref).max() > 1e-6:
+            close(p.grad.numpy(), ref)
+    # inner steps (gcond.py:63-72)
+    th = [T(g[f"{tag}_theta{i}"]).requires_grad_(True) for i in range(6)]
+    opt = O.Adam(th, 0.01)
+    with torch.no_grad():
+        adj_in = O.dense_gcn_norm(O.pge_forward(feat_syn.detach(), pge))
+    np.testing.assert_allclose(O.pge_forward(feat_syn.detach(), pge).detach().numpy(), g[f"{tag}_adj_inner"], rtol=1e-5, atol=1e-6)
+    for it in range(2):
+        out = O.model_forward("SGC_BN", feat_syn.detach(), adj_in, th, 2)
+        li = torch.nn.functional.nll_loss(out, labels_syn)
+        np.testing.assert_allclose(float(li), float(g[f"{tag}_inner_losses"][it]), rtol=1e-5)
+        opt.step(torch.autograd.grad(li, th))
+    for i, q in enumerate(th):
+        np.testing.assert_allclose(q.detach().numpy(), g[f"{tag}_theta_after{i}"], rtol=1e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("tag", ["cora_like", "arxiv_like"])
 def test_g8_full_reduce_and_evaluate(golden_dir, tag):
     """Replays a whole reference run (GCond.__init__ + reduce + intermediate evals + Evaluator.evaluate)."""
