@@ -40,7 +40,7 @@ class GCondConfig(C.Structure):
                 ("ntrans", C.c_int), ("hidden", C.c_int), ("pge_hidden", C.c_int), ("bcap", C.c_int), ("f1", C.c_int),
                 ("f2", C.c_int), ("dis_metric", C.c_int), ("inner_loop", C.c_int),
                 ("lr_feat", C.c_float), ("lr_adj", C.c_float), ("lr_model", C.c_float), ("seed", C.c_uint64),
-                ("external_blocks", C.c_int), ("condense_model", C.c_int), ("pge_chunks", C.c_int)]
+                ("external_blocks", C.c_int), ("condense_model", C.c_int), ("pge_chunks", C.c_int), ("with_bn", C.c_int)]
 
 
 class GCondIO(C.Structure):

@@ -37,8 +37,12 @@ class _GradMatch(GCondBase):
         depth = 2 if args.condense_model == "GCN" else args.ntrans      # models/gcn.py:8-23 vs models/sgc.py:16-35
         if args.nlayers != 2:
             raise NotImplementedError("graphslim_amd: nlayers (propagations) must be 2")
-        if getattr(args, "with_bn", False):
-            raise NotImplementedError("graphslim_amd: with_bn is outside the built path")
+        with_bn = bool(getattr(args, "with_bn", False))
+        if with_bn and not (args.condense_model == "SGC" and args.ntrans == 2 and args.dis_metric == "ours"):
+            # models/sgc.py:27-33 puts BatchNorm layers between transforms only (ntrans >= 2); built for the shipped depth.  Their
+            # weight / bias are 1-D parameters: distance 0 under 'ours' (utils.py:98-101), but part of the mse / cos distances,
+            # whose second-order terms are not built.  GCN + with_bn (models/gcn.py:14-22) is not built either.
+            raise NotImplementedError("graphslim_amd: with_bn is built for condense_model SGC with ntrans = 2 and dis_metric 'ours'")
         if float(getattr(args, "dropout", 0.0) or 0.0) != 0.0:
             # models/sgc.py:38-43 and models/base.py:51-78 apply F.dropout(training=True) inside train_class and the inner
             # loop; the engine has no dropout stage, so a non-zero value must not be silently ignored
@@ -56,7 +60,7 @@ class _GradMatch(GCondBase):
         nclass = data.nclass
         ranges = [tuple(self.syn_class_indices.get(c, (0, 0))) for c in range(nclass)]
         shapes = EngineShapes(features.shape[0], self.d, nclass, self.nnodes_syn, depth, args.hidden, self.pge_hidden,
-                              256, sizes[0], sizes[1], model=args.condense_model, pge_chunks=self.pge_chunks)
+                              256, sizes[0], sizes[1], model=args.condense_model, pge_chunks=self.pge_chunks, with_bn=with_bn)
         cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
         eng = self.engine = GCondEngine(shapes, features, csr, cls_ptr, np.concatenate(pools), labels_syn, ranges,
                                         lr_feat=args.lr_feat, lr_adj=args.lr_adj, lr_model=args.lr,
@@ -71,11 +75,20 @@ class _GradMatch(GCondBase):
         outer_loop, inner_loop = self.get_loops(args)
         loss_avg, best_val = 0, 0
         init_sgc_params(self.d, args.hidden, nclass, depth)                 # model constructor draw (gcond.py:38)
+
+        def fresh_model():
+            """model.initialize() (models/base.py:44-49): Linear layers re-drawn; with_bn: BatchNorm reset to weight 1, bias 0 and
+            running statistics (0, 1) — no RNG draw — which check_bn then freezes in eval mode (gcond_base.py:261-285)."""
+            th = init_sgc_params(self.d, args.hidden, nclass, depth)
+            if with_bn:
+                th = th + [torch.ones(args.hidden), torch.zeros(args.hidden)]
+            return th
+
         labels_t = torch.from_numpy(labels_syn).to(self.device)
         run_inner = self.inner_steps and inner_loop > 0
         run_inf = self.inference_each_step and not self.identity_structure
         for it in trange(args.epochs):
-            eng.set_model(init_sgc_params(self.d, args.hidden, nclass, depth))         # gcond.py:42-45
+            eng.set_model(fresh_model())                                               # gcond.py:42-45
             for ol in range(outer_loop):
                 step_pge, step_feat = self.rule(it, ol)
                 eng.outer_step_ex(step_pge, step_feat, run_inf, run_inner)

@@ -115,6 +115,11 @@ struct gs_gcond {
   int operand_mode;
   float *bsplit_main, *bsplit_aux;   // pre-split B operands (bf16 hi | lo) of the products on the main / the real-side stream
   int bn2_slices, l3_slices;         // slices of e->sums2 the consumer of a deferred last reduction stage adds up (1: e->sums is final)
+  // with_bn (SGC, ntrans = 2, 'ours'): theta = [W1, b1, W2, b2, bn.weight, bn.bias]; every stage reads the FOLDED parameters
+  // theta_eff = [W1 diag(s), b1 s + bn.bias, W2, b2] (gs_bn_fold_kernel), refreshed whenever theta changes
+  bool with_bn;
+  long og, obeta, P_base;            // offsets of bn.weight / bn.bias inside theta; parameter count without them
+  float *theta_eff, *bn_s2;          // [P], [h]: s_j^2 for the distance statistics of the W1 gradient columns
   float* a1_tab;                     // [Ph][8] layer-0 bias / BatchNorm-1 constants of the generated A1 operand and mask (gs_panel.hip)
   bool a1_valid;                     // A1 holds the activations of the current U, V (false: the forward formed them in registers only)
   float* gen_tab;                    // [Ph][8] folded BatchNorm-2 / layer-3 constants of the generated dE2 operand (gs_panel.hip)
@@ -146,6 +151,16 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
     pd.rows[1] = e->h; pd.cols[1] = 1; pd.off[1] = e->ob1; pd.is_bias[1] = 1;
     pd.rows[2] = e->h; pd.cols[2] = e->C; pd.off[2] = e->oWl; pd.is_bias[2] = 0;
     pd.rows[3] = e->C; pd.cols[3] = 1; pd.off[3] = e->obl; pd.is_bias[3] = 1;
+  }
+  e->P_base = e->P;
+  e->with_bn = c.with_bn != 0;
+  e->og = e->obeta = 0;
+  if (e->with_bn) {      // nn.Module.parameters() order: layers.*, then bns.0.weight, bns.0.bias (models/sgc.py:27-35)
+    e->og = e->P; e->obeta = e->P + e->h;
+    e->P += 2L * e->h;
+    pd.rows[4] = e->h; pd.cols[4] = 1; pd.off[4] = e->og; pd.is_bias[4] = 1;        // 1-D: distance 0 under 'ours' (utils.py:98-101)
+    pd.rows[5] = e->h; pd.cols[5] = 1; pd.off[5] = e->obeta; pd.is_bias[5] = 1;
+    pd.nparams = 6;
   }
   int co = 0;
   for (int p = 0; p < pd.nparams; ++p) { pd.col_off[p] = co; co += pd.cols[p]; }
@@ -237,6 +252,8 @@ static size_t carve(gs_gcond* e, void* base) {
   e->bsplit_main = w.take<float>(Ph * Ph * 3 / 2 + 16);             // pre-split B images: 4 B (modes 1, 2) or 6 B (mode 3) per element
   e->bsplit_aux = w.take<float>((h > 0 ? h : 1) * d * 3 / 2 + 16);
   e->probe_span = w.take<unsigned long long>(2 * 256);
+  e->theta_eff = e->with_bn ? w.take<float>(P) : nullptr;
+  e->bn_s2 = e->with_bn ? w.take<float>(h) : nullptr;
   e->gen_tab = w.take<float>(Ph * 8);
   e->a1_tab = w.take<float>(Ph * 8);
   e->a1_valid = false;
@@ -279,6 +296,9 @@ static int check_cfg(const gs_gcond_config* c) {
   if (c->bcap < 1 || c->bcap > 256 || c->f1 < 1 || c->f1 > 16 || c->f2 < 1 || c->f2 > 16)
     GS_FAIL(GS_ERR_ARG, "gs_gcond: bcap in [1,256], fan-outs in [1,16]");
   if (c->dis_metric < 0 || c->dis_metric > 2) GS_FAIL(GS_ERR_ARG, "DC error: unknown distance function");
+  if (c->with_bn && (c->condense_model != 0 || c->ntrans != 2 || c->dis_metric != 0))
+    GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: with_bn is built for condense_model SGC with ntrans = 2 and dis_metric 'ours' (the BatchNorm "
+                                "weight / bias are 1-D parameters: distance 0 there; mse / cos would need their second-order terms)");
   if (c->inner_loop < 0) GS_FAIL(GS_ERR_ARG, "gs_gcond: negative inner_loop");
   return GS_OK;
 }
@@ -422,9 +442,22 @@ extern "C" int gs_gcond_set_overlap(gs_gcond* e, int on) {
   return GS_OK;
 }
 
+// the parameters the stages compute with: theta itself, or its BatchNorm-folded image (with_bn)
+static inline const float* model_th(const gs_gcond* e) { return e->with_bn ? e->theta_eff : e->io.model_params; }
+
+// with_bn: theta_eff / s^2 from the current theta (after every upload and every Adam step on theta)
+static int refresh_folded_model(gs_gcond* e, hipStream_t s) {
+  if (!e->with_bn) return GS_OK;
+  hipLaunchKernelGGL(gs_bn_fold_kernel, dim3(gs_cdiv(e->P_base, 256)), dim3(256), 0, s, e->io.model_params, e->d, e->h, e->oW1, e->ob1,
+                     e->og, e->obeta, e->P_base, e->theta_eff, e->bn_s2);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 extern "C" int gs_gcond_new_epoch(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "gs_gcond_new_epoch: null engine");
   hipStream_t s = (hipStream_t)stream;
+  GS_TRY(refresh_folded_model(e, s));          // (the caller has just written a fresh theta)
   GS_HIP(hipMemsetAsync(e->m_model, 0, sizeof(float) * e->P, s));
   GS_HIP(hipMemsetAsync(e->v_model, 0, sizeof(float) * e->P, s));
   e->step_model = 0;
@@ -589,7 +622,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   float* P0 = e->P0 + c0 * cap1 * F; float* rs0 = e->rs0 + c0 * cap1;
   float* Sr = e->Sr + c0 * bcap * F; float* rsr = e->rsr + c0 * bcap;
   float* Zr = e->Zr + c0 * bcap * C; float* gw = e->gw_real + c0 * P;
-  const float* th = e->io.model_params;
+  const float* th = model_th(e);
   if (e->gcn) {
     // GCN (layers.py:36-51), propagate-first: P0 = A0 X_g ; H1 = relu(P0 W1 + b1) ; Z = A1 (H1 W2) + b2
     float* P0g = e->P0g + c0 * cap1 * d; float* H1r = e->Y1 + c0 * cap1 * h; float* T2r = e->T2r + c0 * cap1 * C;
@@ -975,7 +1008,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   const long P = e->P, c0 = e->c_lo;
   const bool part = sharded_c(e);
   const float* X = e->io.feat_syn;
-  const float* th = e->io.model_params;
+  const float* th = model_th(e);
   const float* A = e->adj_norm;
   const float* Wl = th + e->oWl;
   const float* bl = th + e->obl;
@@ -1022,7 +1055,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       if (e->join_pending) { GS_HIP(hipStreamWaitEvent(s, e->ev_join, 0)); e->join_pending = false; }
       hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, Cl), dim3(256), 0, s, gwr, gws, P, e->pd, stats);
       hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(Cl), dim3(256), 0, s, stats, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
-                         e->io.syn_hi + c0, n, ab, e->loss_c + c0);
+                         e->io.syn_hi + c0, n, ab, e->loss_c + c0, (const float*)e->bn_s2);
       hipLaunchKernelGGL(gs_dist_apply_kernel, dim3(gs_cdiv((long)Cl * P, 256)), dim3(256), 0, s, gwr, gws, P, e->pd, ab, Dv, Cl);
       GS_LAUNCH_CHECK();
       // A1m_c = (S1 D1_c + Db1_c) * mask ; dS1 slabs_c = dH1p_c D1_c^T ; dA[lo:hi] = T[lo:hi] A1m_c^T ; R[lo:hi] = A[lo:hi] A1m_c
@@ -1133,7 +1166,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     float* stats = e->stats + c0 * e->pd.total_cols * 3; float* ab = e->ab + c0 * e->pd.total_cols * 2;
     hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, Cl), dim3(256), 0, s, gwr, gws, P, e->pd, stats);
     hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(Cl), dim3(256), 0, s, stats, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
-                       e->io.syn_hi + c0, n, ab, e->loss_c + c0);
+                       e->io.syn_hi + c0, n, ab, e->loss_c + c0, (const float*)e->bn_s2);
     hipLaunchKernelGGL(gs_dist_apply_kernel, dim3(gs_cdiv((long)Cl * P, 256)), dim3(256), 0, s, gwr, gws, P, e->pd, ab, Dv, Cl);
     GS_LAUNCH_CHECK();
     // ---- second-order backward, per-class part ------------------------------------------------------
@@ -1406,7 +1439,8 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
   const int C = e->C, n = e->n, d = e->d, h = e->h, F = e->F;
   if (e->cfg.inner_loop == 0) return GS_OK;
   const float* X = e->io.feat_syn;
-  float* th = e->io.model_params;
+  float* th_true = e->io.model_params;                 // Adam steps these ...
+  const float* th = model_th(e);                       // ... the products read these (the BatchNorm-folded image under with_bn)
   const float* A = e->adj_norm_in;
   if (e->gcn) {   // oracle/analytic.py:gcn_dense_grad
     { gs_gemm_desc g = mk(A, n, 1, X, d, 1, e->S1, d, n, d, n); GS_TRY(gs_gemm_f32(&g, stream)); }      // S1 = A X: once per outer iteration
@@ -1431,7 +1465,7 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
         g2[1] = mk(e->ones, 0, 1, e->dH1m, h, 1, e->g_model + e->ob1, h, 1, h, n);       // gb1 = 1^T dH1p
         GS_TRY(gs_gemm_group_f32(g2, 2, stream));
       }
-      GS_TRY(gs_adam_step_f32(th, e->g_model, e->m_model, e->v_model, e->P, e->cfg.lr_model, 0.9f, 0.999f, 1e-8f, 0.f,
+      GS_TRY(gs_adam_step_f32(th_true, e->g_model, e->m_model, e->v_model, e->P, e->cfg.lr_model, 0.9f, 0.999f, 1e-8f, 0.f,
                               ++e->step_model, stream));
     }
     return GS_OK;
@@ -1474,8 +1508,14 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
       g2[1] = mk(e->ones, 0, 1, e->dH1m, h, 1, e->g_model + e->ob1, h, 1, h, n);         // gb1 = 1^T dHp
       GS_TRY(gs_gemm_group_f32(g2, 2, stream));
     }
-    GS_TRY(gs_adam_step_f32(th, e->g_model, e->m_model, e->v_model, e->P, e->cfg.lr_model, 0.9f, 0.999f, 1e-8f, 0.f,
+    if (e->with_bn) {      // gradients of the folded model -> gradients of [W1, b1, W2, b2, bn.weight, bn.bias]
+      hipLaunchKernelGGL(gs_bn_unfold_grads_kernel, dim3(gs_cdiv(h, 32)), dim3(256), 0, s, e->g_model, th_true, e->dH1m, e->H1s, n, d, h,
+                         e->oW1, e->ob1, e->og, e->obeta);
+      GS_LAUNCH_CHECK();
+    }
+    GS_TRY(gs_adam_step_f32(th_true, e->g_model, e->m_model, e->v_model, e->P, e->cfg.lr_model, 0.9f, 0.999f, 1e-8f, 0.f,
                             ++e->step_model, stream));
+    GS_TRY(refresh_folded_model(e, s));
   }
   return GS_OK;
 }

@@ -302,10 +302,15 @@ __global__ __launch_bounds__(256) void gs_dist_stats_kernel(const float* __restr
 
 // per class: loss_c and per-column (alpha, beta) with D = alpha*r + beta*s, both scaled by coeff_c.
 // metric 0 'ours' (utils.py:33-39,86-104), 1 'mse' (:41-49), 2 'cos' (:51-60).
+// colscale2 (optional, with_bn): s_j^2 per column of parameter 0 (W1).  The engine then works with the folded weight W1' = W1 diag(s)
+// (s = bn.weight / sqrt(1 + eps)), whose gradient columns are 1 / s_j times the true ones: the statistics of the TRUE gradients are
+// s_j^2 times those of the folded ones (the 1e-6 on the norm product makes the cosine distance not exactly scale-free), and
+// d loss / d gw_syn' = s_j * d loss / d gw_syn = s_j^2 (a r' + b s').
 __global__ __launch_bounds__(256) void gs_dist_finalize_kernel(const float* __restrict__ stats, gs_pdesc pd, int metric,
                                                                const int* __restrict__ syn_lo, const int* __restrict__ syn_hi,
                                                                int n_syn, float* __restrict__ ab /*[C][total_cols][2]*/,
-                                                               float* __restrict__ loss_c /*[C]*/) {
+                                                               float* __restrict__ loss_c /*[C]*/,
+                                                               const float* __restrict__ colscale2 = nullptr) {
   const int c = blockIdx.x, tid = threadIdx.x;
   const int nc = syn_hi[c] - syn_lo[c];
   const float coeff = (float)nc / (float)n_syn;     // gcond_base.py:237
@@ -317,6 +322,8 @@ __global__ __launch_bounds__(256) void gs_dist_finalize_kernel(const float* __re
     for (int k = tid; k < pd.cols[p]; k += 256) {
       const int ci = pd.col_off[p] + k;
       float dot = st[ci * 3], nr2 = st[ci * 3 + 1], ns2 = st[ci * 3 + 2];
+      const float sc2 = (colscale2 && p == 0) ? colscale2[k] : 1.f;
+      dot *= sc2; nr2 *= sc2; ns2 *= sc2;
       if (metric == 0) {
         float a = 0.f, b = 0.f;
         if (!pd.is_bias[p]) {
@@ -326,8 +333,8 @@ __global__ __launch_bounds__(256) void gs_dist_finalize_kernel(const float* __re
           a = -1.f / q;
           b = ns > 0.f ? dot * nr / (ns * q * q) : 0.f;
         }
-        o[ci * 2] = a * coeff;
-        o[ci * 2 + 1] = b * coeff;
+        o[ci * 2] = a * coeff * sc2;
+        o[ci * 2 + 1] = b * coeff * sc2;
       } else if (metric == 1) {
         l += (double)ns2 - 2.0 * (double)dot + (double)nr2;
         o[ci * 2] = -2.f * coeff;
@@ -378,6 +385,58 @@ __global__ void gs_dist_apply_kernel(const float* __restrict__ gw_real, const fl
   const int k = (int)((e - pd.off[p]) % pd.cols[p]);
   const float* o = ab + ((long)c * pd.total_cols + pd.col_off[p] + k) * 2;
   D[idx] = o[0] * gw_real[idx] + o[1] * gw_syn[idx];
+}
+
+// with_bn (gcond_base.py:261-285 check_bn, models/sgc.py:27-33): the BatchNorm1d between the two SGC transforms always runs in
+// eval mode with its initial running statistics (0, 1), i.e. y = x * s + beta with s = bn.weight / sqrt(1 + eps).  It is folded
+// into the first transform: W1' = W1 diag(s), b1' = b1 * s + beta — every stage then runs on theta' = [W1', b1', W2, b2] as if
+// there were no BatchNorm.  theta = [W1 (d x h), b1 (h), W2 (h x C), b2 (C), bn.weight (h), bn.bias (h)].
+__global__ void gs_bn_fold_kernel(const float* __restrict__ theta, int d, int h, long oW1, long ob1, long og, long obeta, long P_base,
+                                  float* __restrict__ theta_eff, float* __restrict__ s2) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P_base) return;
+  const float rs = 1.f / sqrtf(1.f + 1e-5f);
+  float v = theta[idx];
+  if (idx >= oW1 && idx < oW1 + (long)d * h) {
+    const int j = (int)((idx - oW1) % h);
+    v *= theta[og + j] * rs;
+  } else if (idx >= ob1 && idx < ob1 + h) {
+    const int j = (int)(idx - ob1);
+    const float sj = theta[og + j] * rs;
+    v = v * sj + theta[obeta + j];
+    s2[j] = sj * sj;
+  }
+  theta_eff[idx] = v;
+}
+
+// inner-step gradients of the folded model -> gradients of the true parameters (in place on g; g has room for bn.weight / bn.bias):
+//   gW1[:, j] = gW1'[:, j] s_j ; gb1_j = gb1'_j s_j ; g bn.bias_j = gb1'_j ;
+//   g bn.weight_j = sum_i dpre'_ij pre_ij / sqrt(1 + eps) = sum_i dH1_ij (H1_ij - beta_j) / bn.weight_j
+// (dH1 is already masked by the ReLU, so H1 = pre' wherever dH1 != 0).  One block per 32 hidden columns.
+__global__ __launch_bounds__(256) void gs_bn_unfold_grads_kernel(float* __restrict__ g, const float* __restrict__ theta,
+                                                                 const float* __restrict__ dH1, const float* __restrict__ H1, int n,
+                                                                 int d, int h, long oW1, long ob1, long og, long obeta) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + tx;
+  const float rs = 1.f / sqrtf(1.f + 1e-5f);
+  __shared__ double sh[8][32];
+  double acc = 0.0;
+  const float gam = j < h ? theta[og + j] : 1.f, bet = j < h ? theta[obeta + j] : 0.f;
+  if (j < h)
+    for (int i = ty; i < n; i += 8) acc += (double)dH1[(long)i * h + j] * (double)(H1[(long)i * h + j] - bet);
+  sh[ty][tx] = acc;
+  __syncthreads();
+  if (j >= h) return;
+  const float sj = gam * rs;
+  for (int i = ty; i < d; i += 8) g[oW1 + (long)i * h + j] *= sj;
+  if (ty == 0) {
+    double t = 0.0;
+    for (int q = 0; q < 8; ++q) t += sh[q][tx];
+    const float gb = g[ob1 + j];
+    g[obeta + j] = gb;
+    g[og + j] = (float)(t / (double)gam);
+    g[ob1 + j] = gb * sj;
+  }
 }
 
 // loss_total += sum_c loss_c (fixed order);  also keeps the last value in loss_last

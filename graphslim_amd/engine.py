@@ -223,6 +223,7 @@ class EngineShapes:
     f2: int = 5
     model: str = "SGC"     # condense model: SGC (ntrans transforms) or GCN (two layers)
     pge_chunks: int = 1    # 5 = the chunked PGE of reddit r >= 0.01 (parametrized_adj.py:41-55)
+    with_bn: bool = False  # SGC ntrans = 2 with an (always eval-mode) BatchNorm1d between the transforms (models/sgc.py:27-33)
 
 
 def model_param_count(d, hidden, nclass, ntrans):
@@ -268,7 +269,7 @@ class GCondEngine:
         self.labels_syn = i32(labels_syn)
         self.syn_lo = i32([r[0] for r in syn_ranges])
         self.syn_hi = i32([r[1] for r in syn_ranges])
-        self.P = model_param_count(d, s.hidden, s.nclass, 2 if s.model == "GCN" else s.ntrans)
+        self.P = model_param_count(d, s.hidden, s.nclass, 2 if s.model == "GCN" else s.ntrans) + (2 * s.hidden if s.with_bn else 0)
         self.Ppge = pge_param_count(d, s.pge_hidden)
         self.feat_syn = torch.zeros(s.n_syn, d, dtype=torch.float32, device=dev)
         self.pge_params = torch.zeros(self.Ppge, dtype=torch.float32, device=dev)
@@ -276,7 +277,7 @@ class GCondEngine:
         self.adj_syn = torch.zeros(s.n_syn, s.n_syn, dtype=torch.float32, device=dev)
         cfg = GCondConfig(s.n_nodes, d, self.ldx, s.nclass, s.n_syn, s.ntrans, s.hidden, s.pge_hidden, s.bcap, s.f1, s.f2,
                           METRICS[dis_metric], inner_loop, lr_feat, lr_adj, lr_model, seed, 1 if external_blocks else 0,
-                          {"SGC": 0, "GCN": 1}[s.model], int(s.pge_chunks))
+                          {"SGC": 0, "GCN": 1}[s.model], int(s.pge_chunks), 1 if s.with_bn else 0)
         nbytes = C.c_size_t()
         check(L.gs_gcond_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
         self.workspace_bytes = nbytes.value
@@ -315,6 +316,8 @@ class GCondEngine:
     def get_model(self):
         s, d = self.shapes, self.shapes.d
         shp = [(d, s.nclass), (s.nclass,)] if (s.ntrans == 1 and s.model == "SGC") else [(d, s.hidden), (s.hidden,), (s.hidden, s.nclass), (s.nclass,)]
+        if s.with_bn:
+            shp += [(s.hidden,), (s.hidden,)]          # bns.0.weight, bns.0.bias
         return _split(self.model_params, shp)
 
     def pge_shapes(self):

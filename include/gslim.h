@@ -223,6 +223,10 @@ typedef struct gs_gcond_config {
   int condense_model;      /* 0 = SGC (models/sgc.py), 1 = 2-layer GCN (models/gcn.py): parameters laid out like SGC T = 2 */
   int pge_chunks;          /* <= 1: one BatchNorm batch over all n'^2 pairs; 5: the chunked PGE of reddit r >= 0.01
                               (parametrized_adj.py:41-55: np.array_split chunks, per-chunk batch statistics); not with row sharding */
+  int with_bn;             /* 1: SGC (ntrans = 2) with a BatchNorm1d between its transforms (models/sgc.py:27-33), which GCond
+                              always runs in eval mode with its initial running statistics (gcond_base.py:261-285 check_bn,
+                              gcond.py:50): a per-column affine map with TRAINABLE weight / bias.  model_params then is
+                              [W1, b1, W2, b2, bn.weight (h), bn.bias (h)] (nn.Module.parameters() order); dis_metric 0 only */
 } gs_gcond_config;
 
 typedef struct gs_gcond_io {
@@ -238,7 +242,7 @@ typedef struct gs_gcond_io {
   float* feat_syn;         /* [n_syn][d]   learnable X~                                        */
   float* pge_params;       /* flat, nn.Module.parameters() order: W0[Ph][2d] b0[Ph] W1[Ph][Ph] b1[Ph]
                               w2[Ph] b2[1] bn1.weight[Ph] bn1.bias[Ph] bn2.weight[Ph] bn2.bias[Ph] */
-  float* model_params;     /* flat: T=1: W[d][C] b[C];  T=2: W1[d][h] b1[h] W2[h][C] b2[C]      */
+  float* model_params;     /* flat: T=1: W[d][C] b[C];  T=2: W1[d][h] b1[h] W2[h][C] b2[C] (+ bn.weight[h] bn.bias[h] with with_bn) */
   float* adj_syn;          /* [n_syn][n_syn] raw PGE output of the last inference pass (gcond.py:64,77) */
   void* workspace;
   size_t workspace_bytes;  /* >= gs_gcond_workspace_bytes(cfg)                                 */

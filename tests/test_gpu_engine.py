@@ -22,9 +22,9 @@ def close(got, ref, rtol=1e-3, what=""):
 
 
 def make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, x, f1, f2, bcap=32, metric="ours", inner=2, lrs=(0.01, 0.01, 0.01),
-                csr=None, pools=None, external=True, seed=1, model="SGC"):
+                csr=None, pools=None, external=True, seed=1, model="SGC", with_bn=False):
     from graphslim_amd.engine import EngineShapes, GCondEngine
-    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, ph, bcap, f1, f2, model=model)
+    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, ph, bcap, f1, f2, model=model, with_bn=with_bn)
     cls_ptr = cls_nodes = None
     if pools is not None:
         cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
@@ -82,6 +82,54 @@ def test_train_class_against_reference_golden(golden_dir, tag, metric):
         if np.abs(ref).max() > 1e-6:        # Linear biases in front of a batch-stat BatchNorm: exactly-zero gradient
             close(dp[o:o + k].reshape(shp), ref, 2e-3, f"d theta_PGE[{i}]")
         o += k
+
+
+def test_with_bn_against_reference_golden(golden_dir):
+    """G16 (gcond_base.py:261-285 check_bn, models/sgc.py:27-33): SGC with an eval-mode BatchNorm1d between its two transforms,
+    bn.weight / bn.bias away from (1, 0).  The engine folds the affine map into the first transform (gs_bn_fold_kernel), prices
+    the W1 gradient columns at their true scale in the distance statistics, and un-folds the inner-step gradients: real-side
+    gradients, loss, d loss / d A^, d loss / d X~, d loss / d theta_PGE and the parameters after two inner steps of the reference."""
+    from graphslim_amd.engine import BlockSet
+    g = load_golden(golden_dir, "g16_with_bn")
+    tag = "bn"
+    batches, (n, nclass, d, hidden, t), _ = rebuild_batches(g, tag)
+    labels_syn = g[f"{tag}_labels_syn"]
+    _, ncd, ranges = O.generate_labels_syn(g[f"{tag}_y"][g[f"{tag}_idx_train"]], float(g[f"{tag}_rate"]))
+    ranges = [tuple(ranges[c]) for c in range(nclass)]
+    ph = g[f"{tag}_pge2"].shape[0]
+    f1, f2 = [int(s) for s in g[f"{tag}_sizes"]]
+    eng = make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, with_bn=True, inner=2)
+    eng.set_feat(T(g[f"{tag}_feat_syn"]))
+    eng.set_pge([T(g[f"{tag}_pge{i}"]) for i in range(10)])
+    theta = [T(g[f"{tag}_theta{i}"]) for i in range(6)]
+    eng.set_model(theta)
+    eng.set_blocks(BlockSet.from_batches(batches, 32, f1, f2, DEV))
+    eng.stage_real_grads()
+    eng.stage_pge_forward(False)
+    close(eng.buffer("adj_norm", (len(labels_syn), -1)), g[f"{tag}_adj_norm"], 2e-5, "adj_norm")
+    eng.stage_syn_match()
+    eng.syn_finish()
+    loss = float(eng.buffer("loss")[0])
+    assert abs(loss - float(g[f"{tag}_loss"])) <= 1e-4 * abs(float(g[f"{tag}_loss"])), (loss, float(g[f"{tag}_loss"]))
+    close(eng.buffer("d_adj_norm", (len(labels_syn), -1)), g[f"{tag}_dadj_norm"], 1e-3, "d loss / d A^")
+    eng.stage_pge_backward(True, True)
+    close(eng.buffer("d_feat", (len(labels_syn), d)), g[f"{tag}_dfeat"], 1e-3, "d loss / d X~")
+    dp = eng.buffer("d_pge")
+    o = 0
+    for i, shp in enumerate(eng.pge_shapes()):
+        k = int(np.prod(shp))
+        ref = g[f"{tag}_dpge{i}"]
+        if np.abs(ref).max() > 1e-6:
+            close(dp[o:o + k].reshape(shp), ref, 2e-3, f"d theta_PGE[{i}]")
+        o += k
+    # PGE.inference + two inner steps (neither optimiser of the outer problem is stepped, as in the golden)
+    eng.stage_inner()
+    close(eng.adj_syn.cpu(), g[f"{tag}_adj_inner"], 2e-5, "inference adjacency")
+    for i, q in enumerate(eng.get_model()):
+        close(q.cpu(), g[f"{tag}_theta_after{i}"], 2e-3, f"theta[{i}] after two inner steps")
+    # mse / cos would need the second-order terms of the 1-D BatchNorm parameters: refused, not silently wrong
+    with pytest.raises(RuntimeError):
+        make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, with_bn=True, metric="mse")
 
 
 def _problem(t, seed, n=400, nclass=5, d=12, hidden=24, ph=16, rate=0.25, f1=4, f2=3, bcap=16):
