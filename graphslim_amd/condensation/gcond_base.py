@@ -5,6 +5,7 @@ import torch
 
 from ..dataset.utils import save_reduced
 from ..host import generate_labels_syn, init_pge_params, pge_hidden
+from ..models.gcn import evaluation_args
 from ..models.gcn import GCN
 from ..reduction import create_reducer
 
@@ -73,7 +74,7 @@ class GCondBase:
         args, data = self.args, self.data
         if args.eval_model not in _EVAL_MODELS:
             raise NotImplementedError(f"graphslim_amd evaluates with GCN only (got {args.eval_model})")
-        model = _EVAL_MODELS[args.eval_model](data.feat_syn.shape[1], args.hidden, data.nclass, args, mode="eval")
+        model = _EVAL_MODELS[args.eval_model](data.feat_syn.shape[1], args.hidden, data.nclass, evaluation_args(args), mode="eval")
         acc_val = model.fit_with_val(data, train_iters=iters, normadj=True, verbose=False, setting=setting, reduced=True,
                                      best_val=best_val)
         acc_test = model.test(data, setting=setting, verbose=False)

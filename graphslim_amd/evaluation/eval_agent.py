@@ -5,7 +5,7 @@ from tqdm import trange
 
 from ..dataset.utils import get_syn_data
 from ..host import seed_everything
-from ..models.gcn import GCN
+from ..models.gcn import GCN, evaluation_args
 from ..parallel import RowShard, RunShard, active_dist
 
 _MODELS = {"GCN": GCN}
@@ -27,7 +27,7 @@ class Evaluator:
             raise NotImplementedError(f"graphslim_amd evaluates with GCN only (got {model_type})")
         if verbose:
             print(f"======= testing {model_type}")
-        model = _MODELS[model_type](data.feat_full.shape[1], args.hidden, data.nclass, args, mode=mode)
+        model = _MODELS[model_type](data.feat_full.shape[1], args.hidden, data.nclass, evaluation_args(args), mode=mode)
         best_acc_val = model.fit_with_val(data, train_iters=args.eval_epochs, normadj=True, verbose=verbose,
                                           setting=args.setting, reduced=reduced)
         acc_test = model.test(data, setting=args.setting, verbose=False)

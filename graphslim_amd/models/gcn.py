@@ -75,6 +75,28 @@ class DeviceGraph:
         return self._targets[key]
 
 
+_warned_bn = False
+
+
+def evaluation_args(args):
+    """args for the evaluation model.  with_bn reaches it through the shared args upstream, where the evaluation GCN then fails
+    on the condensed graph (golden G17): a run with --with_bn could never pass its first checkpoint.  Here the condensation
+    model honours with_bn and the evaluation GCN is built WITHOUT BatchNorm, announced once."""
+    global _warned_bn
+    if not getattr(args, "with_bn", False):
+        return args
+    if not _warned_bn:
+        _warned_bn = True
+        msg = ("graphslim_amd: with_bn applies to the condensation model only; the evaluation GCN runs without BatchNorm "
+               "(upstream's raises RuntimeError on a condensed graph, models/base.py:65)")
+        log = getattr(args, "logger", None)
+        (log.warning if log is not None else print)(msg)
+    import copy
+    out = copy.copy(args)
+    out.with_bn = False
+    return out
+
+
 class GCN:
     """2-layer GCN: per layer adj @ (x @ W) + b, ReLU between, log_softmax (models/base.py:51-78)."""
 
@@ -82,7 +104,13 @@ class GCN:
         if getattr(args, "nlayers", 2) != 2:
             raise NotImplementedError("graphslim_amd.GCN: only nlayers = 2 (the GCond evaluation configuration)")
         if getattr(args, "with_bn", False):
-            raise NotImplementedError("graphslim_amd.GCN: with_bn is outside the built path")
+            # The reference's evaluation GCN cannot run with_bn on a condensed graph: GraphConvolution.forward returns a 3-D
+            # tensor [1, n', hidden] for a dense adjacency (layers.py:41-47) and BatchNorm1d(hidden) rejects it — RuntimeError in
+            # the first fit_with_val(reduced=True) forward (golden G17 records it).  with_bn is built for the condensation model
+            # (graphslim_amd/condensation/gcond.py); the evaluation callers pass evaluation_args(args) (below), which drops it.
+            raise NotImplementedError("graphslim_amd.GCN: with_bn has no reference behaviour to match in the evaluation model — "
+                                      "upstream raises RuntimeError ('running_mean should contain n_syn elements not hidden', "
+                                      "models/base.py:65 after layers.py:41-47) on the condensed graph")
         if not str(args.device).startswith("cuda"):
             raise RuntimeError("graphslim_amd has no CPU path: run with a GPU (-G 0)")
         self.args = args

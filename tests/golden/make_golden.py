@@ -843,7 +843,39 @@ def g16():
     print("g16:", names, float(loss), losses)
 
 
+def g17():
+    """What the reference's evaluation model does with with_bn on a CONDENSED graph (models/base.py:156-161 inside
+    fit_with_val(reduced=True), which every checkpoint of GCond.reduce and Evaluator.evaluate run): GraphConvolution.forward
+    returns a 3-D tensor [1, n', hidden] for a dense adjacency (layers.py:41-47: the final `x.view(-1, ...)` is discarded), so
+    BatchNorm1d(hidden) sees n' channels.  The fixture records the outcome (exception type and message), so that the scope
+    fence in graphslim_amd/models/gcn.py is pinned to the reference's behaviour.  Same data as G9."""
+    n, nclass, d, hidden, ns, iters = 120, 4, 10, 16, 12, 40
+    a, x, y = make_graph(n, nclass, d, 6, seed=91)
+    data = FakeData(a, x, y, nclass, [6, 8, 10, 12], 30, 40, seed=9)
+    rng = np.random.default_rng(5)
+    pick = rng.permutation(len(data.idx_train))[:ns]
+    data.feat_syn = data.feat_train[pick].clone()
+    data.labels_syn = data.labels_train[pick].clone()
+    raw = rng.random((ns, ns)).astype(np.float32)
+    adj_syn = torch.from_numpy((raw + raw.T) / 2)
+    adj_syn[adj_syn < 0.35] = 0
+    adj_syn.fill_diagonal_(0)
+    data.adj_syn = adj_syn
+    args = args_obj(hidden=hidden, setting="trans", lr=0.01, dropout=0.0, with_bn=True)
+    RU.seed_everything(7)
+    model = GCN(d, hidden, nclass, args, mode="eval")
+    try:
+        best = model.fit_with_val(data, train_iters=iters, normadj=True, verbose=False, setting="trans", reduced=True)
+        outcome = ("ok", repr(float(best)))
+    except Exception as e:      # noqa: BLE001 — the fixture IS the exception
+        outcome = (type(e).__name__, str(e))
+    save("g17_eval_gcn_with_bn", type=np.array(outcome[0]), message=np.array(outcome[1]), n_syn=np.array(ns), hidden=np.array(hidden),
+         param_names=np.array([k for k, _ in model.named_parameters()]))
+    print("g17:", outcome)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16",
+                             "g17"]
     for w in which:
         globals()[w]()

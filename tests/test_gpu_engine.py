@@ -573,6 +573,31 @@ def test_gcn_condense_model_reduce_api(tmp_path):
     assert 0.0 <= mean <= 1.0
 
 
+def test_with_bn_reduce_api(tmp_path):
+    """`--with_bn` through the reference's own entry points: GCond.reduce with an SGC (ntrans = 2) condensation model that carries
+    the eval-mode BatchNorm (gcond_base.py:261-285), checkpoints and the final Evaluator run with the evaluation GCN built
+    without BatchNorm (upstream's fails there, golden G17).  Sanity of the whole path; parity is test_with_bn_against_reference_golden."""
+    import graphslim  # noqa: F401
+    from graphslim.config import cli
+    from graphslim.condensation import GCond
+    from graphslim.dataset import get_dataset
+    from graphslim.evaluation.eval_agent import Evaluator
+    args = cli(["-D", "cora", "-M", "gcond", "-R", "0.5", "-G", "0", "--epochs", "12", "--eval_epochs", "30", "--run_eval", "2",
+                "--with_bn", "--ntrans", "2", "--save_path", str(tmp_path)], standalone_mode=False)
+    assert args.with_bn and args.condense_model == "SGC" and args.ntrans == 2
+    args.run_inter_eval, args.checkpoints, args.outer_loop, args.inner_loop = 1, [5, 11], 3, 2
+    graph = get_dataset(args.dataset, args)
+    __import__('graphslim_amd.host', fromlist=['seed_everything']).seed_everything(args.seed)
+    agent = GCond(setting=args.setting, data=graph, args=args)
+    reduced = agent.reduce(graph, verbose=False)
+    assert torch.isfinite(reduced.feat_syn).all() and torch.isfinite(reduced.adj_syn).all()
+    th = agent.engine.get_model()
+    assert len(th) == 6 and th[4].shape == (args.hidden,) and torch.isfinite(th[4]).all()
+    assert float((th[4] - 1).abs().max()) > 0 and float(th[5].abs().max()) > 0      # bn.weight / bn.bias were trained by the inner steps
+    mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
+    assert 0.0 <= mean <= 1.0
+
+
 def test_full_size_arxiv_properties():
     """BASELINE.json configs[3] at FULL size (N = 169 343, n' = 454, C = 40), where the CPU oracle needs seconds per
     iteration: size-independent properties instead of an oracle comparison —

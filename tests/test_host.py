@@ -285,3 +285,18 @@ def test_g15_appnp_condense_model_is_fenced_like_the_reference_fails(golden_dir)
     agent.args = type("A", (), {"condense_model": "APPNP", "verbose": False})()
     with pytest.raises(NotImplementedError, match="TypeError"):
         agent.reduce(None, verbose=False)
+
+
+def test_g17_evaluation_gcn_with_bn_is_fenced_like_the_reference_fails(golden_dir):
+    """with_bn reaches the evaluation model through the shared args (eval_agent.py, gcond_base.py:287-340), but upstream's GCN
+    cannot run it on a condensed graph: golden G17 is the outcome of the reference's fit_with_val(reduced=True) — a RuntimeError
+    from BatchNorm1d on the 3-D activations of GraphConvolution (layers.py:41-47).  The package refuses and says why; the
+    condensation side of with_bn is built (golden G16, tests/test_gpu_engine.py)."""
+    from helpers import load_golden
+    from graphslim_amd.models.gcn import GCN
+    g = load_golden(golden_dir, "g17_eval_gcn_with_bn")
+    assert str(g["type"]) == "RuntimeError"
+    assert str(g["message"]) == f"running_mean should contain {int(g['n_syn'])} elements not {int(g['hidden'])}"
+    args = type("A", (), {"nlayers": 2, "with_bn": True, "device": "cuda:0"})()
+    with pytest.raises(NotImplementedError, match="RuntimeError"):
+        GCN(10, 16, 4, args, mode="eval")
