@@ -96,6 +96,7 @@ struct gs_gcond {
   hipStream_t aux;
   hipEvent_t ev_fork, ev_join, ev_prefetch;   // ev_prefetch: the block set sampled ahead on aux is complete
   bool overlap, join_pending;
+  bool overlap_sampling_only;        // level 2 of gs_gcond_set_overlap: the second stream only samples the NEXT iteration's blocks
   // PGE.inference at the end of iteration i and the training forward of iteration i+1 are the same function of the
   // same (X~, theta_PGE): with reuse_fwd the second one is not recomputed (its activations are still in place)
   bool reuse_fwd, fwd_cached;
@@ -398,6 +399,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
                (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming) == hipSuccess);
+  e->overlap_sampling_only = false;
   *out = e;
   return GS_OK;
 }
@@ -439,6 +441,7 @@ extern "C" int gs_gcond_set_operand_mode(gs_gcond* e, int mode) {
 extern "C" int gs_gcond_set_overlap(gs_gcond* e, int on) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   e->overlap = on && e->aux && e->ev_fork && e->ev_join && e->ev_prefetch;
+  e->overlap_sampling_only = e->overlap && on == 2;
   return GS_OK;
 }
 
@@ -1550,7 +1553,20 @@ extern "C" int gs_gcond_set_identity_structure(gs_gcond* e, int on, gs_stream_t 
 // (the join is taken by the first stage that reads gw_real); also samples the NEXT iteration's blocks behind them.
 extern "C" int gs_gcond_stage_real_async(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
-  if (e->overlap) {
+  if (e->overlap && e->overlap_sampling_only) {
+    // level 2: the real-side gradients stay on the caller's stream; the second stream only samples the NEXT iteration's blocks
+    // (into the other block buffer) while they run
+    hipStream_t s = (hipStream_t)stream;
+    GS_TRY(gs_gcond_stage_sample(e, stream));              // adopts the set sampled during the previous iteration
+    if (!e->cfg.external_blocks) {
+      GS_HIP(hipEventRecord(e->ev_fork, s));
+      GS_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+      GS_TRY(sample_into(e, e->blk_cur ^ 1, (gs_stream_t)e->aux));
+      GS_HIP(hipEventRecord(e->ev_prefetch, e->aux));
+      e->prefetched = true;
+    }
+    GS_TRY(gs_gcond_stage_real_grads(e, stream));
+  } else if (e->overlap) {
     hipStream_t s = (hipStream_t)stream;
     GS_HIP(hipEventRecord(e->ev_fork, s));
     GS_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
