@@ -4,7 +4,6 @@
 // its check against autograd).  All classes are processed together: the real-side blocks live in
 // class-major fixed-capacity arrays, the synthetic side uses grouped GEMMs over the contiguous row
 // range of each class.  Everything stays resident in HBM; the host only launches.
-#include <cstdlib>
 #include <new>
 
 #include "gs_kernels.h"
@@ -173,12 +172,9 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   // K-slab length of the real-side edge product (one workgroup per class, slab and 128-feature tile; 2 resident per CU = 512
   // slots).  1 024-edge slabs when they still fill the chip in ONE round (ogbn-arxiv: 40 classes x <= 14 slabs; in situ
   // -12 us fp32 / -33 us bf16x3 per iteration against 512, half the slab traffic), else 512 (few classes: keep the slots
-  // busy); 768 and 1 408 measured worse at arxiv (a part-filled second round / idle slots), tools/gpu/run_kc.sh.
+  // busy); 768 and 1 408 measured worse at arxiv (a part-filled second round / idle slots): 706 / 758 us for the real-side stage
+  // against 670 (512) and 660 (1 024).
   e->kchunk_r = (long)e->C * gs_cdiv((long)e->cap1 * e->f2, 1024) * gs_cdiv(e->d, 128) >= 400 ? 1024 : 512;
-  if (const char* kc = getenv("GS_KCHUNK_R")) {      // measurement override (tools)
-    const int v = atoi(kc);
-    if (v >= 64 && v % 16 == 0) e->kchunk_r = v;
-  }
   e->nsplit_r = gs_cdiv((long)e->cap1 * e->f2, e->kchunk_r);
   // dW1 = dE2^T A1 over K = n'^2 pair rows: Ph/128 x Ph/128 output tiles per slab; aim at one full round of the 768
   // resident 128x128 workgroups (2 048 gave 404 workgroups at n' = 454: half the chip idle)
