@@ -66,6 +66,16 @@ class _GradMatch(GCondBase):
                                         lr_feat=args.lr_feat, lr_adj=args.lr_adj, lr_model=args.lr,
                                         inner_loop=args.inner_loop, dis_metric=args.dis_metric, seed=args.seed,
                                         device=self.device)
+        if getattr(args, "neighbour_mode", "sampled") == "full":
+            # extension (SURVEY section 8e "mode F"; loader.py:204 keeps `sizes = [-1, -1]` commented out): exact 2-hop full
+            # neighbourhoods for SGC with one transform — two row-sharded full-graph SpMMs once per job
+            if not (args.condense_model == "SGC" and args.ntrans == 1):
+                raise NotImplementedError("graphslim_amd: neighbour_mode = 'full' is built for condense_model SGC with ntrans = 1")
+            from ..parallel import RowShard, active_dist
+            from .full_neighbour import full_neighbour_operators
+            S_full, rs_full, dt = full_neighbour_operators(csr, features, self.device, RowShard(active_dist()))
+            eng.set_full_neighbour(S_full, rs_full)
+            args.logger.info("full-neighbour operators A^ A^ X, A^ A^ 1: %.1f ms" % (1e3 * dt))
         eng.set_feat(torch.as_tensor(feat_init))
         eng.set_pge(self.pge_init)
         if self.identity_structure:

@@ -117,6 +117,9 @@ struct gs_gcond {
   int bn2_slices, l3_slices;         // slices of e->sums2 the consumer of a deferred last reduction stage adds up (1: e->sums is final)
   // with_bn (SGC, ntrans = 2, 'ours'): theta = [W1, b1, W2, b2, bn.weight, bn.bias]; every stage reads the FOLDED parameters
   // theta_eff = [W1 diag(s), b1 s + bn.bias, W2, b2] (gs_bn_fold_kernel), refreshed whenever theta changes
+  // full-neighbour mode (SGC, ntrans = 1; gs_gcond_set_full_neighbour): S_full = A^ A^ X and rs_full = A^ A^ 1 of the whole graph,
+  // computed once by the caller (X never changes): the real-side class gradient needs their seed rows only
+  const float* S_full; long ldS; const float* rs_full;
   bool with_bn;
   long og, obeta, P_base;            // offsets of bn.weight / bn.bias inside theta; parameter count without them
   float *theta_eff, *bn_s2;          // [P], [h]: s_j^2 for the distance statistics of the W1 gradient columns
@@ -386,6 +389,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->blk_cur = 0; e->prefetched = false; e->identity = false;
   e->probing = false; e->probe_n = 0;
   e->operand_mode = 0;
+  e->S_full = nullptr; e->ldS = 0; e->rs_full = nullptr;
   for (int i = 0; i < 2 * 256; ++i) e->probe_ev[i] = nullptr;
   // the real-side branch is the longer of the two concurrent branches (kernel trace, r01): its stream gets the higher
   // priority so that its latency-bound kernels are not queued behind the PGE forward's big GEMM
@@ -438,6 +442,22 @@ extern "C" int gs_gcond_set_overlap(gs_gcond* e, int on) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   e->overlap = on && e->aux && e->ev_fork && e->ev_join && e->ev_prefetch;
   e->overlap_sampling_only = e->overlap && on == 2;
+  return GS_OK;
+}
+
+// Full-neighbour mode (loader.py:204 `sizes = [-1, -1]`, commented out upstream; SURVEY section 8e "mode F"): with SGC and ONE
+// transform the model is linear up to the softmax, so the 2-hop full-neighbourhood block product of a seed is row `seed` of
+// S_full = A^ (A^ X) — a constant of the whole job, computed once (row-sharded over the ranks: graphslim_amd/parallel.py) —
+// and its bias factor row `seed` of rs_full = A^ (A^ 1).  With the pointers set, sampling draws the seeds only and the
+// real-side stage gathers their rows; NULL returns to neighbour sampling.  The arrays stay owned by the caller.
+extern "C" int gs_gcond_set_full_neighbour(gs_gcond* e, const float* S_full, long ld, const float* rs_full) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  if (S_full && (e->gcn || e->T != 1))
+    GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond_set_full_neighbour: built for SGC with ntrans = 1 (with a ReLU between two transforms the "
+                                "backward needs one full-graph SpMM per class and iteration, DESIGN.md section 6)");
+  if (S_full && (!rs_full || ld < e->d)) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_full_neighbour: bad argument");
+  e->S_full = S_full; e->ldS = ld; e->rs_full = S_full ? rs_full : nullptr;
+  e->prefetched = false;           // a set sampled ahead belongs to the other mode
   return GS_OK;
 }
 
@@ -555,7 +575,7 @@ static gs_blocks blocks_view(const gs_gcond* e) {
 }
 
 int gs_sample_blocks_ex(const int*, const int*, const float*, int, const int*, const int*, int*, const gs_blocks*, uint64_t,
-                        uint32_t, int, gs_stream_t);
+                        uint32_t, int, gs_stream_t, int);
 
 // ================================================================================================
 // stage: sampling
@@ -567,7 +587,8 @@ static int sample_into(gs_gcond* e, int which, gs_stream_t stream) {
     gs_blocks b = blocks_view(e);
     e->blk = keep;
     GS_TRY(gs_sample_blocks_ex(e->io.rowptr, e->io.col, e->io.val, e->N, e->io.cls_ptr + e->c_lo, e->io.cls_nodes,
-                               e->marker + (long)e->c_lo * e->N, &b, e->cfg.seed, e->sample_step, e->c_lo, stream));
+                               e->marker + (long)e->c_lo * e->N, &b, e->cfg.seed, e->sample_step, e->c_lo, stream,
+                               e->S_full != nullptr));
   }
   e->sample_step++;
   return GS_OK;
@@ -667,9 +688,14 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     src = e->H1full;
     ld_src = h;
   }
+  if (e->S_full) {      // full-neighbour mode: S_c = S_full[seeds of class c], rs_c = rs_full[seeds]
+    hipLaunchKernelGGL(gs_gather_seed_rows_kernel, dim3(gs_cdiv((long)Cl * bcap, 4)), dim3(256), 0, s, e->S_full, e->ldS, e->rs_full,
+                       b.nid1, cap1, b.n_seed, bcap, F, Sr, rsr, Cl);
+  } else {
   // hop 2 (outermost): frontier rows <- global sources;  hop 1: seeds <- frontier
   launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, src, ld_src, nullptr, F, P0, rs0, Cl, s);
   launch_ell(b.col1, b.val1, b.n_seed, bcap, f1, cap1, P0, F, rs0, F, Sr, rsr, Cl, s);
+  }
   GS_LAUNCH_CHECK();
   {  // Z = S Wl  (all classes at once), then G in place
     gs_gemm_desc g = mk(Sr, F, 1, th + e->oWl, C, 1, Zr, C, Cl * bcap, C, F);

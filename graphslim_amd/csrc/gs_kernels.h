@@ -439,6 +439,28 @@ __global__ __launch_bounds__(256) void gs_bn_unfold_grads_kernel(float* __restri
   }
 }
 
+// full-neighbour mode: Sr[c][b][:] = S_full[nid[c][b]][:F], rsr[c][b] = rs_full[nid[c][b]] for b < n_seed[c], zeros beyond
+// (one wave per (class, seed slot))
+__global__ __launch_bounds__(256) void gs_gather_seed_rows_kernel(const float* __restrict__ S_full, long ldS,
+                                                                  const float* __restrict__ rs_full, const int* __restrict__ nid,
+                                                                  int cap1, const int* __restrict__ n_seed, int bcap, int F,
+                                                                  float* __restrict__ Sr, float* __restrict__ rsr, int C) {
+  const int lane = threadIdx.x & 63;
+  const long w = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (w >= (long)C * bcap) return;
+  const int c = (int)(w / bcap), b = (int)(w - (long)c * bcap);
+  float* out = Sr + w * F;
+  if (b >= n_seed[c]) {
+    for (int k = lane; k < F; k += 64) out[k] = 0.f;
+    if (lane == 0) rsr[w] = 0.f;
+    return;
+  }
+  const long v = nid[(long)c * cap1 + b];
+  const float* src = S_full + v * ldS;
+  for (int k = lane; k < F; k += 64) out[k] = src[k];
+  if (lane == 0) rsr[w] = rs_full[v];
+}
+
 // loss_total += sum_c loss_c (fixed order);  also keeps the last value in loss_last
 __global__ void gs_loss_accum_kernel(const float* __restrict__ loss_c, int C, double* __restrict__ loss_sum,
                                      float* __restrict__ loss_last, long* __restrict__ steps) {

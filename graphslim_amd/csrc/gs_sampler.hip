@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
                                                              const float* __restrict__ val, int n_nodes,
                                                              const int* __restrict__ cls_ptr,
                                                              const int* __restrict__ cls_nodes, int* marker,
-                                                             gs_blocks blk, uint64_t seed, uint32_t step, int class_key0) {
+                                                             gs_blocks blk, uint64_t seed, uint32_t step, int class_key0,
+                                                             int seeds_only) {
   const int c = blockIdx.x, tid = threadIdx.x;
   const int ckey = class_key0 + c;   // RNG key = global class id (a class shard draws what the full run draws)
   const int bcap = blk.bcap, f1 = blk.f1, cap1 = blk.cap1;
@@ -106,6 +107,11 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
   }
   __syncthreads();
 
+  if (seeds_only) {      // full-neighbour mode (gs_gcond_set_full_neighbour): only the seed draw is used — same seeds as the sampled mode
+    if (tid < B) blk.nid1[(long)c * cap1 + tid] = s_seed[tid];
+    if (tid == 0) { blk.n_seed[c] = B; blk.n1[c] = B; }
+    return;
+  }
   // ---- hop 1: thread b samples the neighbours of seed b ------------------------------------------
   int k = 0, e0 = 0, v = 0;
   if (tid < B) {
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256) void gs_sample_hop2_kernel(const int* __restri
 
 int gs_sample_blocks_ex(const int* rowptr, const int* col, const float* val, int n_nodes, const int* cls_ptr,
                         const int* cls_nodes, int* marker, const gs_blocks* out, uint64_t seed, uint32_t step, int class_key0,
-                        gs_stream_t stream) {
+                        gs_stream_t stream, int seeds_only) {
   if (!rowptr || !col || !val || !cls_ptr || !cls_nodes || !marker || !out) GS_FAIL(GS_ERR_ARG, "gs_sample_blocks: null pointer");
   const gs_blocks& b = *out;
   if (b.bcap < 1 || b.bcap > GS_MAX_BCAP) GS_FAIL(GS_ERR_ARG, "gs_sample_blocks: bcap must be in [1, %d]", GS_MAX_BCAP);
@@ -238,7 +244,11 @@ int gs_sample_blocks_ex(const int* rowptr, const int* col, const float* val, int
   if (b.C < 1) return GS_OK;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gs_sample_hop1_kernel, dim3(b.C), dim3(256), 0, s, rowptr, col, val, n_nodes, cls_ptr, cls_nodes,
-                     marker, b, seed, step, class_key0);
+                     marker, b, seed, step, class_key0, seeds_only);
+  if (seeds_only) {
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+  }
   hipLaunchKernelGGL(gs_sample_hop2_kernel, dim3(gs_cdiv(b.cap1, 256), b.C), dim3(256), 0, s, rowptr, col, val, b, seed,
                      step, class_key0);
   GS_LAUNCH_CHECK();
@@ -248,5 +258,5 @@ int gs_sample_blocks_ex(const int* rowptr, const int* col, const float* val, int
 extern "C" int gs_sample_blocks(const int* rowptr, const int* col, const float* val, int n_nodes, const int* cls_ptr,
                                 const int* cls_nodes, int* marker, const gs_blocks* out, uint64_t seed, uint32_t step,
                                 gs_stream_t stream) {
-  return gs_sample_blocks_ex(rowptr, col, val, n_nodes, cls_ptr, cls_nodes, marker, out, seed, step, 0, stream);
+  return gs_sample_blocks_ex(rowptr, col, val, n_nodes, cls_ptr, cls_nodes, marker, out, seed, step, 0, stream, 0);
 }

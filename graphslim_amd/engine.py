@@ -412,6 +412,17 @@ class GCondEngine:
         three-way bf16 split, 6 bf16 MFMAs, fp32 accumulate: fp32-level error), 'bf16x3' (two-way split, 3 MFMAs), 'bf16'."""
         check(self.L.gs_gcond_set_operand_mode(self.h, self.OPERAND_MODES.get(mode, mode)))
 
+    def set_full_neighbour(self, S_full=None, rs_full=None):
+        """Full-neighbour mode for SGC with ntrans = 1 (gs_gcond_set_full_neighbour): S_full [N, ld >= d] = A^ A^ X and
+        rs_full [N] = A^ A^ 1 (graphslim_amd/condensation/full_neighbour.py); None returns to neighbour sampling.  The tensors are
+        kept alive by the engine object."""
+        self._full_nb = (S_full, rs_full)
+        if S_full is None:
+            check(self.L.gs_gcond_set_full_neighbour(self.h, None, 0, None))
+        else:
+            assert S_full.is_contiguous() and rs_full.is_contiguous() and S_full.shape[0] == self.shapes.n_nodes
+            check(self.L.gs_gcond_set_full_neighbour(self.h, ptr(S_full), S_full.stride(0), ptr(rs_full)))
+
     def set_overlap(self, on):
         check(self.L.gs_gcond_set_overlap(self.h, int(on)))
 

@@ -284,6 +284,14 @@ int gs_gcond_set_overlap(gs_gcond* e, int on);
  * transform H1 = relu(X W1 + b1)): 0 = exact fp32 (default = the reference's precision), 1 = split bf16 x3 with fp32
  * accumulation, 2 = bf16 operands (BASELINE.json configs[1]).  See gs_gemm_desc.prec.  Everything else stays fp32. */
 int gs_gcond_set_operand_mode(gs_gcond* e, int mode);
+/* Full-neighbour mode (dataset/loader.py:204 `sizes = [-1, -1]`, commented out upstream; SURVEY section 8e "mode F") for SGC with
+ * ntrans = 1: the model is linear up to the softmax, so the 2-hop full-neighbourhood block product of a seed is row `seed` of
+ * S_full [n_nodes][ld] = A^ (A^ X) and its bias factor row `seed` of rs_full [n_nodes] = A^ (A^ 1) — constants of the whole job
+ * that the caller computes once with gs_spmm_csr_f32 (row-sharded over the ranks of a node, graphslim_amd/parallel.py) and keeps
+ * alive.  With them set, sampling draws the class seeds only (the same seeds as the sampled mode) and the real-side stage
+ * gathers their rows; NULL returns to neighbour sampling.  GS_ERR_UNSUPPORTED for ntrans = 2 / GCN (a ReLU between the
+ * transforms would need one full-graph SpMM per class and iteration in the backward). */
+int gs_gcond_set_full_neighbour(gs_gcond* e, const float* S_full, long ld, const float* rs_full);
 /* 1 (default): unsharded engines fold the last stage of the BatchNorm-2 / layer-3 statistics reductions into the consuming
    launch (two launches fewer per PGE pass); 0 = separate launches.  Bitwise the same results.  A measurement knob. */
 int gs_gcond_set_folded_reductions(int on);

@@ -598,6 +598,81 @@ def test_with_bn_reduce_api(tmp_path):
     assert 0.0 <= mean <= 1.0
 
 
+def test_full_neighbour_mode_against_the_oracle_on_full_blocks():
+    """Full-neighbour mode (SURVEY section 8e "mode F"; loader.py:204 `sizes = [-1, -1]`) for SGC with one transform: the engine
+    draws the class seeds, gathers rows of S_full = A^ A^ X / rs_full = A^ A^ 1 (computed once with gs_spmm_csr_f32) — against the
+    oracle's train_class on the 2-hop FULL-neighbourhood blocks of the same seeds (oracle.sample_blocks with fan-out -1):
+    real-side gradients per class, matching loss, d loss / d X~, and two whole outer iterations.  Also: the row-sharded
+    precompute (two and three row blocks) is bitwise the single-block one, and ntrans = 2 is refused."""
+    from graphslim_amd.condensation.full_neighbour import full_neighbour_operators
+    from graphslim_amd.engine import spmm_csr
+    from graphslim_amd.parallel import RowShard
+    p = _problem(1, seed=31, n=600, nclass=5, d=12, bcap=16)
+    eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 1, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"], p["f2"],
+                      bcap=p["bcap"], inner=2, csr=p["csr"], pools=p["pools"], external=False, seed=5)
+    S_full, rs_full, _ = full_neighbour_operators(p["csr"], torch.as_tensor(p["x"]), DEV)
+    # the operators themselves against scipy-free dense arithmetic
+    rp, col, val = p["csr"]
+    A = torch.zeros(p["n"], p["n"], dtype=torch.float64)
+    rows = np.repeat(np.arange(p["n"]), np.diff(rp))
+    A[torch.as_tensor(rows), torch.as_tensor(col)] = torch.as_tensor(val).double()
+    ref_S = A @ (A @ torch.as_tensor(p["x"]).double())
+    close(S_full[:, :p["d"]].cpu(), ref_S, 2e-5, "A^ A^ X")
+    close(rs_full.cpu(), (A @ A.sum(1)), 2e-5, "A^ A^ 1")
+    # row-sharded precompute: per-block products concatenated == the single-block result, bit for bit
+    for world in (2, 3):
+        cur = S_full.new_zeros(S_full.shape)
+        cur[:, :p["d"]] = torch.as_tensor(p["x"]).to(DEV)
+        cur[:, p["d"]] = 1.0
+        for _ in range(2):
+            parts = []
+            for lo, hi in RowShard.split_rows(rp, world):
+                i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32).to(DEV)
+                parts.append(spmm_csr(i32(rp[lo:hi + 1] - rp[lo]), i32(col[rp[lo]:rp[hi]]),
+                                      torch.as_tensor(np.ascontiguousarray(val[rp[lo]:rp[hi]])).to(DEV), cur, F=cur.shape[1]))
+            cur = torch.cat(parts)
+        assert torch.equal(cur, S_full), world
+    eng.set_full_neighbour(S_full, rs_full)
+    eng.set_feat(p["xs"])
+    eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
+    st = O.GCondState(p["xs"].clone(), {"lin": [t.clone() for t in p["pge"]["lin"]], "bn": [t.clone() for t in p["pge"]["bn"]]},
+                      torch.as_tensor(p["labels_syn"]), p["ncd"], p["nclass"], 0.01, 0.01, 0.01, "SGC", 2)
+    eng.set_model(p["theta"])
+    st.new_epoch([t.clone() for t in p["theta"]])
+    for epoch in (10, 0):
+        eng.stage_sample()
+        blk = eng.get_blocks()
+        nseed, nid = blk.n_seed.cpu().numpy(), blk.nid1.cpu().numpy()
+        batches = []
+        for c in range(p["nclass"]):
+            seeds = nid[c, :nseed[c]]
+            assert len(set(seeds.tolist())) == len(seeds) and set(seeds.tolist()) <= set(p["pools"][c].tolist())
+            batches.append(O.sample_blocks(*p["csr"], seeds, [-1, -1], np.random.default_rng(0)))
+        eng.stage_real_grads()
+        gw = eng.buffer("gw_real", (p["nclass"], -1))
+        for c in range(p["nclass"]):
+            th = [q.detach().clone().requires_grad_(True) for q in st.model]
+            ref, _ = O.class_real_grads("SGC", th, torch.as_tensor(p["x"]), torch.as_tensor(p["y"]), batches[c], 2)
+            close(gw[c], torch.cat([r.reshape(-1) for r in ref]), 2e-4, f"gw_real class {c}")
+        eng.stage_pge_forward(False)
+        eng.stage_syn_match()
+        eng.syn_finish()
+        loss = float(eng.buffer("loss")[0])
+        eng.stage_pge_backward(True, True)
+        g_feat = eng.buffer("d_feat", tuple(p["xs"].shape)).clone()
+        eng.stage_update(epoch)
+        eng.stage_inner()
+        ref_loss, ref_gfeat, _, _ = st.outer_iteration(epoch, batches, torch.as_tensor(p["x"]), torch.as_tensor(p["y"]), 2)
+        assert abs(loss - float(ref_loss)) <= 1e-4 * abs(float(ref_loss)), (epoch, loss, float(ref_loss))
+        close(g_feat, ref_gfeat, 1e-3, "d loss / d X~")
+        close(eng.feat_syn.cpu(), st.feat_syn.detach(), 2e-3, "X~ after the step")
+    # a ReLU between two transforms breaks the linearity the mode rests on
+    e2 = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 2, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"], p["f2"],
+                     bcap=p["bcap"], csr=p["csr"], pools=p["pools"], external=False)
+    with pytest.raises(RuntimeError):
+        e2.set_full_neighbour(S_full, rs_full)
+
+
 def test_full_size_arxiv_properties():
     """BASELINE.json configs[3] at FULL size (N = 169 343, n' = 454, C = 40), where the CPU oracle needs seconds per
     iteration: size-independent properties instead of an oracle comparison —
