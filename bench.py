@@ -272,6 +272,9 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of extra back-to-back iterations for the `sustained` field (0 = off)")
     ap.add_argument("--operand-mode", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
                     help="operand precision of the row-panel products for the HEADLINE run (default: exact fp32)")
+    ap.add_argument("--full-neighbour", action="store_true",
+                    help="SGC ntrans = 1 workloads (cora, reddit): exact 2-hop full neighbourhoods (SURVEY 8e mode F) — S_full = A^ A^ X "
+                         "by row-sharded SpMM once before the timed region, seed-row gathers per iteration; not the headline")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -302,6 +305,23 @@ def main():
     eng = parallel.make_engine(p, dev, rank, world) if world > 1 else make_engine(p, dev)
     init_state(p, eng)
     getattr(eng, "eng", eng).set_operand_mode(args.operand_mode)
+    full_nb = None
+    if args.full_neighbour:
+        if p["T"] != 1:
+            raise SystemExit("--full-neighbour: SGC with ntrans = 1 only (workloads cora, reddit)")
+        from graphslim_amd.condensation.full_neighbour import full_neighbour_operators
+        from graphslim_amd.parallel import RowShard, active_dist
+        for _ in range(2):      # (second pass: warm)
+            S_full, rs_full, dt_ops = full_neighbour_operators(p["csr"], p["data"].bench_feat, dev, RowShard(active_dist()))
+        getattr(eng, "eng", eng).set_full_neighbour(S_full, rs_full)
+        nnz, n_nodes, ldw = int(p["csr"][0][-1]), int(p["data"].bench_n), S_full.shape[1]
+        # per hop: CSR (rowptr 4 B/row, col + val 8 B/nnz) + one gathered operand row per non-zero + one output row per row
+        gathered = 2 * (nnz * (8 + 4 * ldw) + n_nodes * (4 + 4 * ldw))
+        full_nb = {"operators_ms": round(1e3 * dt_ops, 3), "spmm_width": ldw, "nnz": nnz,
+                   "gathered_bytes": gathered, "gather_rate_TBps": round(gathered / dt_ops / 1e12, 3),
+                   "note": "two hops of gs_spmm_csr_f32 over this rank's row block (+ all-gather when sharded), OUTSIDE the timed steps: "
+                           "X is constant for the whole job; the gathered operand rows are served by the caches, the compulsory HBM "
+                           "traffic is the CSR once and the operand / result once per hop"}
 
     def barrier():
         if world > 1:
@@ -402,7 +422,10 @@ def main():
             out["operand_modes"] = modes
         if sustained:
             out["sustained"] = sustained
-        if not args.no_cpu_baseline and world == 1:
+        if full_nb:
+            out["full_neighbour"] = full_nb
+            out["config"]["workload"] += ", FULL 2-hop neighbourhoods (mode F)"
+        if not args.no_cpu_baseline and world == 1 and not args.full_neighbour:      # (the oracle leg replays SAMPLED blocks)
             out["cpu_baseline"] = cpu_baseline(p, eng)
         print(json.dumps(out))
     if world > 1:

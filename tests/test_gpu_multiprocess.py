@@ -83,3 +83,22 @@ def test_bench_multi_rank_path_over_gloo_sharing_one_gpu():
 def test_bench_two_ranks_over_rccl():
     d = _bench(2, {"GS_DIST_BACKEND": "nccl"})
     _check_line(d, 2)
+
+
+def test_bench_full_neighbour_mode_one_and_two_ranks():
+    """`bench.py --workload reddit --full-neighbour` (SURVEY 8e mode F, BASELINE configs[4] shape at reduced scale): single rank, then
+    two ranks over gloo sharing the GPU — the row-sharded S_full = A^ A^ X precompute with its all-gather, then class-parallel
+    outer iterations on seed-row gathers.  Same seeds, same operators: the two runs must report the same mean matching loss."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--sustain-s", "0", "--workload", "reddit", "--scale", "0.2",
+              "--full-neighbour"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *common], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    one = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert one["full_neighbour"]["operators_ms"] > 0 and "mode F" in one["config"]["workload"]
+    two = _bench(2, {"GS_DIST_BACKEND": "gloo", "GS_SHARE_DEVICE": "1"}, extra_args=["--workload", "reddit", "--scale", "0.2",
+                                                                                     "--full-neighbour"])
+    assert two["n_gpus"] == 2 and two["full_neighbour"]["operators_ms"] > 0
+    a, b = one["config"]["mean_match_loss"], two["config"]["mean_match_loss"]
+    assert abs(a - b) <= 1e-4 * abs(a), (a, b)
