@@ -673,6 +673,30 @@ def test_full_neighbour_mode_against_the_oracle_on_full_blocks():
         e2.set_full_neighbour(S_full, rs_full)
 
 
+def test_full_neighbour_reduce_api(tmp_path):
+    """args.neighbour_mode = 'full' through GCond.reduce + Evaluator.evaluate on the cora-shaped config (SGC, ntrans = 1): the run
+    must condense to a graph that evaluates at least as well as chance by a wide margin, like the sampled mode does; ntrans = 2 is
+    refused with the reason."""
+    import graphslim  # noqa: F401
+    from graphslim.config import cli
+    from graphslim.condensation import GCond
+    from graphslim.dataset import get_dataset
+    from graphslim.evaluation.eval_agent import Evaluator
+    args = cli(["-D", "cora", "-M", "gcond", "-R", "0.5", "-G", "0", "--epochs", "30", "--eval_epochs", "100", "--run_eval", "2",
+                "--save_path", str(tmp_path)], standalone_mode=False)
+    assert args.ntrans == 1 and args.condense_model == "SGC"
+    args.run_inter_eval, args.checkpoints, args.neighbour_mode = 1, [29], "full"
+    graph = get_dataset(args.dataset, args)
+    __import__('graphslim_amd.host', fromlist=['seed_everything']).seed_everything(args.seed)
+    reduced = GCond(setting=args.setting, data=graph, args=args).reduce(graph, verbose=False)
+    assert torch.isfinite(reduced.feat_syn).all() and torch.isfinite(reduced.adj_syn).all()
+    mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
+    assert mean > 2.0 / graph.nclass, mean
+    args.ntrans = 2
+    with pytest.raises(NotImplementedError, match="ntrans = 1"):
+        GCond(setting=args.setting, data=graph, args=args).reduce(graph, verbose=False)
+
+
 def test_full_size_arxiv_properties():
     """BASELINE.json configs[3] at FULL size (N = 169 343, n' = 454, C = 40), where the CPU oracle needs seconds per
     iteration: size-independent properties instead of an oracle comparison —
