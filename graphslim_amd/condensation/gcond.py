@@ -76,6 +76,10 @@ class _GradMatch(GCondBase):
             S_full, rs_full, dt = full_neighbour_operators(csr, features, self.device, RowShard(active_dist()))
             eng.set_full_neighbour(S_full, rs_full)
             args.logger.info("full-neighbour operators A^ A^ X, A^ A^ 1: %.1f ms" % (1e3 * dt))
+        if getattr(args, "operand_mode", "f32") != "f32":
+            # extension: operand form of the large contractions on the bf16 matrix pipe; "bf16x6" is the exact
+            # three-way split with fp32-level error
+            eng.set_operand_mode(args.operand_mode)
         eng.set_feat(torch.as_tensor(feat_init))
         eng.set_pge(self.pge_init)
         if self.identity_structure:
