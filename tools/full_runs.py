@@ -21,6 +21,9 @@ for spec in sys.argv[1:]:
     for m in ("bf16x6", "bf16x3", "bf16"):
         if m in opt:
             args.operand_mode = m
+    for o in opt:
+        if o.startswith("seed"):
+            args.seed = int(o[4:])
     seed_everything(args.seed)
     t0 = time.time(); graph = get_dataset(args.dataset, args); t1 = time.time()
     agent = GCond(setting=args.setting, data=graph, args=args)
@@ -32,7 +35,7 @@ for spec in sys.argv[1:]:
     wmean, wstd = Evaluator(args).evaluate(graph, model_type="GCN", verbose=False, reduced=False)   # whole-dataset baseline
     args.run_eval = keep
     t5 = time.time()
-    print(f"FULL {ds}{' [full-neighbour mode]' if 'full' in opt else ''}{' [operand mode ' + args.operand_mode + ']' if getattr(args, 'operand_mode', 'f32') != 'f32' else ''} r={rate} setting={args.setting} N={graph.num_nodes} n'={agent.nnodes_syn} epochs={args.epochs} outer={args.outer_loop} "
+    print(f"FULL seed={args.seed} {ds}{' [full-neighbour mode]' if 'full' in opt else ''}{' [operand mode ' + args.operand_mode + ']' if getattr(args, 'operand_mode', 'f32') != 'f32' else ''} r={rate} setting={args.setting} N={graph.num_nodes} n'={agent.nnodes_syn} epochs={args.epochs} outer={args.outer_loop} "
           f"inner={args.inner_loop}: data {t1 - t0:.1f}s  reduce {t2 - t1:.1f}s ({args.epochs * args.outer_loop} outer iterations, "
           f"{(args.epochs * args.outer_loop) / (t2 - t1):.0f} it/s incl. checkpoints)  final eval ({args.run_eval} runs x {args.eval_epochs} epochs) "
           f"{t3 - t2:.1f}s  acc {100 * mean:.2f} +/- {100 * std:.2f}  | GCN trained on the ORIGINAL graph (3 runs, {t5 - t4:.1f}s): "
