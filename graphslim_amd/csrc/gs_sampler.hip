@@ -81,25 +81,69 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
   if (npool <= bcap) {
     if (tid < B) s_seed[tid] = pool[tid];
   } else {
-    for (int i = tid; i < 1024; i += 256) s_hash[i] = -1;
+    // A uniform B-subset of the pool by ALL 256 threads (the first form drew it with Floyd's algorithm on thread 0: 256 dependent
+    // steps, most of the kernel's time): every pool index i gets the key (hash(seed, step, class, i), i); the B smallest keys
+    // are the batch — a uniform subset because the keys are i.i.d. and ties are broken by the index.  Selection without a
+    // sort: histogram of the top 12 key bits, the bin T in which the B-th smallest falls, every index below T, and the
+    // (need) smallest of bin T by rank among the (few) members of that bin.  Seeds keep ascending pool order.
+    int* hist = s_g;                               // 4096 bins (s_g / s_sel are not in use yet)
+    int* cand = s_sel;                             // members of bin T: [2 m] = (key, index) pairs, m <= 2048
+    for (int i = tid; i < 4096; i += 256) hist[i] = 0;
     __syncthreads();
-    if (tid == 0) {
-      int ns = 0;
-      for (int j = npool - B; j < npool; ++j) {
-        int t = (int)gs_rand_below(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)ns, (uint32_t)(j + 1));
-        // membership test in an open-addressing set
-        int h = (int)((uint32_t)t * 2654435761u >> 22);
-        bool found = false;
-        while (s_hash[h] != -1) {
-          if (s_hash[h] == t) { found = true; break; }
-          h = (h + 1) & 1023;
+    const int per = (npool + 255) / 256, i_lo = min(tid * per, npool), i_hi = min(i_lo + per, npool);
+    for (int i = i_lo; i < i_hi; ++i) atomicAdd(&hist[gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i) >> 20], 1);
+    __syncthreads();
+    int hsum = 0;
+    for (int q = 0; q < 16; ++q) hsum += hist[tid * 16 + q];
+    int htot = 0;
+    int hbase = block_excl_scan_256(hsum, s_tmp, &htot);          // elements in the bins in front of this thread's 16
+    if (hbase < B && hbase + hsum >= B) {                         // the crossing lies in this thread's bins (exactly one thread)
+      int acc = hbase;
+      for (int q = 0; q < 16; ++q) {
+        const int hq = hist[tid * 16 + q];
+        if (acc + hq >= B) { s_hash[0] = tid * 16 + q; s_hash[1] = acc; s_hash[2] = 0; break; }
+        acc += hq;
+      }
+    }
+    __syncthreads();
+    const int Tbin = s_hash[0], below = s_hash[1], need = B - below;
+    for (int i = i_lo; i < i_hi; ++i) {
+      const uint32_t key = gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i);
+      if ((int)(key >> 20) == Tbin) {
+        const int slot = atomicAdd(&s_hash[2], 1);
+        if (slot < 2048) { cand[2 * slot] = (int)key; cand[2 * slot + 1] = i; }
+      }
+    }
+    __syncthreads();
+    const int m = min(s_hash[2], 2048);
+    for (int a = tid; a < m; a += 256) {            // rank of candidate a among the members of bin T (m is ~ npool / 4096)
+      const uint32_t ka = (uint32_t)cand[2 * a];
+      const int ia = cand[2 * a + 1];
+      int rank = 0;
+      for (int q = 0; q < m; ++q) {
+        const uint32_t kq = (uint32_t)cand[2 * q];
+        rank += (kq < ka) || (kq == ka && cand[2 * q + 1] < ia);
+      }
+      if (rank >= need) cand[2 * a + 1] = -1;       // not taken
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int pass = 0; pass < 2; ++pass) {          // count, then write in ascending pool order
+      int base = 0;
+      if (pass == 1) {
+        int tot = 0;
+        base = block_excl_scan_256(mine, s_tmp, &tot);
+        mine = 0;
+      }
+      for (int i = i_lo; i < i_hi; ++i) {
+        const int bin = (int)(gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i) >> 20);
+        bool take = bin < Tbin;
+        if (bin == Tbin)
+          for (int q = 0; q < m; ++q) take |= (cand[2 * q + 1] == i);
+        if (take) {
+          if (pass == 1 && base + mine < B) s_seed[base + mine] = i;
+          ++mine;
         }
-        int pick = found ? j : t;
-        h = (int)((uint32_t)pick * 2654435761u >> 22);
-        while (s_hash[h] != -1) h = (h + 1) & 1023;
-        s_hash[h] = pick;
-        s_seed[ns++] = pick;      // pool INDEX: the pool itself is read by all threads below (no global-load latency inside
-                                  // this serial loop: 256 dependent round trips were most of the kernel's 183 us)
       }
     }
     __syncthreads();
