@@ -874,8 +874,54 @@ def g17():
     print("g17:", outcome)
 
 
+# ---------------------------------------------------------------- G18 MSGC ---------------------
+
+
+def g18():
+    """MSGC.__init__ + reduce of the reference (msgc.py:18-130,178-236): batch_adj sparse structures over the same synthetic
+    nodes, the edge MLP with training-mode BatchNorm, train_class on the [B, n', n'] batch.  3 epochs x 4 outer iterations, T = 1
+    and 2, with a checkpoint at the last epoch (the window averages it hands to the evaluation, msgc.py:126-130)."""
+    from graphslim.condensation.msgc import MSGC
+    out = {}
+    for tag, T, dataset, hidden, B in (("t1", 1, "cora", 16, 3), ("t2", 2, "ogbn-arxiv", 12, 2)):
+        tmp = tempfile.mkdtemp(prefix="golden_")
+        try:
+            n, nclass, d = 90, 3, 8
+            a, x, y = make_graph(n, nclass, d, 5, seed=71)
+            data = FakeData(a, x, y, nclass, [8, 10, 14], 20, 30, seed=6, sizes=(4, 3))
+            epochs, outer, inner = 3, 4, 2
+            args = args_obj(ntrans=T, hidden=hidden, reduction_rate=0.5, dataset=dataset, epochs=epochs, outer_loop=outer,
+                            inner_loop=inner, checkpoints=[epochs - 1], save_path=tmp, logger=CapLogger(), lr_feat=0.01, lr_adj=0.01,
+                            seed=1, method="msgc", batch_adj=B, run_inter_eval=1, eval_epochs=5)
+            RU.seed_everything(args.seed)
+            agent = MSGC("trans", data, args)
+            losses = []
+            orig = agent.train_class
+
+            def spy(*a_, **k_):
+                l = orig(*a_, **k_)
+                losses.append(float(l))
+                return l
+
+            agent.train_class = spy
+            agent.reduce(data, verbose=False)
+            coo = a.tocoo()
+            out.update({f"{tag}_a_row": coo.row, f"{tag}_a_col": coo.col, f"{tag}_x": x, f"{tag}_y": y,
+                        f"{tag}_idx_train": np_(data.idx_train), f"{tag}_meta": np.array([n, nclass, d, hidden, T, inner, epochs, outer, B]),
+                        f"{tag}_losses": np.array(losses), f"{tag}_feat_syn": np_(agent.feat_syn).copy(),
+                        f"{tag}_y_syn": np_(agent.y_syn), f"{tag}_rows": np_(agent.rows), f"{tag}_cols": np_(agent.cols),
+                        f"{tag}_batch": np_(agent.batch), f"{tag}_adj": np_(agent.get_adj_t_syn()).copy(),
+                        f"{tag}_best_x": np_(data.feat_syn).copy(), f"{tag}_best_adj": np_(data.adj_syn).copy(),
+                        f"{tag}_labels_out": np_(data.labels_syn)})
+            for i, p in enumerate(agent.pge.parameters()):
+                out[f"{tag}_pge{i}"] = np_(p).copy()
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    save("g18_msgc", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16",
-                             "g17"]
+                             "g17", "g18"]
     for w in which:
         globals()[w]()

@@ -352,3 +352,42 @@ def test_g13_sibling_methods_replay_the_reference(golden_dir, tag):
             diff = np.abs(p.detach().numpy() - g[f"{tag}_pge{i}"])
             tol = 1e-3 + 1e-3 * np.abs(g[f"{tag}_pge{i}"])
             assert (diff > tol).mean() <= 2e-4 and diff.max() <= 0.02, (i, (diff > tol).mean(), diff.max())
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_g18_msgc_replays_the_reference(golden_dir, tag):
+    """G18: the reference's own MSGC.__init__ + reduce (msgc.py:18-130,178-236; 3 epochs x 4 outer iterations, batch_adj 3 / 2):
+    pins oracle/msgc_oracle.py — label allocation, the greedy edge lists incl. their randperm tie breaks (bit exact), the
+    per-iteration matching losses on the batched structure, final X~, edge-MLP parameters, the normalised [B, n', n'] batch and
+    the window averages a checkpoint hands to the evaluation."""
+    from oracle import msgc_oracle as M
+    g = load(golden_dir, "g18_msgc")
+    n, nclass, d, hidden, t, inner, epochs, outer, B = [int(v) for v in g[f"{tag}_meta"]]
+    a = sp.coo_matrix((np.ones(len(g[f"{tag}_a_row"])), (g[f"{tag}_a_row"], g[f"{tag}_a_col"])), shape=(n, n)).tocsr()
+    csr = O.normalize_adj_sparse(a)
+    idx_train, y = g[f"{tag}_idx_train"], g[f"{tag}_y"]
+    labels_train = y[idx_train]
+
+    def batch_fn(c, call):
+        rng = np.random.default_rng(100000 + call)
+        batch = rng.permutation(idx_train[labels_train == c])[:256]
+        return O.sample_blocks(*csr, batch, [4, 3], rng)
+
+    out = M.reduce_msgc(a, g[f"{tag}_x"], y, idx_train, nclass, reduction_rate=0.5, hidden=hidden, ntrans=t, epochs=epochs,
+                        outer_loop=outer, inner_loop=inner, batch_adj=B, lr_feat=0.01, lr_adj=0.01, lr_model=0.01, seed=1,
+                        batch_fn=batch_fn)
+    np.testing.assert_array_equal(out["y_syn"].numpy(), g[f"{tag}_y_syn"])
+    for k in ("rows", "cols", "batch"):
+        np.testing.assert_array_equal(out[k].numpy(), g[f"{tag}_{k}"])
+    np.testing.assert_allclose(np.array(out["losses"]), g[f"{tag}_losses"], rtol=2e-4)
+    np.testing.assert_allclose(out["feat_syn"].numpy(), g[f"{tag}_feat_syn"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(out["adj"].numpy(), g[f"{tag}_adj"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(out["best_x"].numpy(), g[f"{tag}_best_x"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(out["best_adj"].numpy(), g[f"{tag}_best_adj"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_array_equal(np.tile(out["y_syn"].numpy(), B), g[f"{tag}_labels_out"])
+    for i, p in enumerate(out["params"]):
+        if i in (1, 5):
+            continue         # biases in front of a batch-statistics BatchNorm: zero gradient up to rounding (see test_g8)
+        diff = np.abs(p.numpy() - g[f"{tag}_pge{i}"])
+        tol = 1e-3 + 1e-3 * np.abs(g[f"{tag}_pge{i}"])
+        assert (diff > tol).mean() <= 2e-4 and diff.max() <= 0.02, (i, (diff > tol).mean(), diff.max())
