@@ -71,6 +71,8 @@ def method_config(args):
         args._method_config_keys = set(conf.keys())
     except Exception:
         print("No config file found or error in json format, please use method_config(args)")
+    if args.method in ["msgc"]:
+        args.batch_adj = 16                        # config.py:252-253
     return args
 
 
@@ -135,6 +137,7 @@ _INITS = ["variation_neighborhoods", "variation_edges", "variation_cliques", "he
 @click.option("--activation", default="relu", show_default=True)
 @click.option("--alpha", default=0.1, show_default=True)
 @click.option("--ptb_r", "-P", default=0.25, show_default=True)
+@click.option("--batch_adj", default=1, show_default=True, help="batch size for msgc")
 @click.option("--attack", "-A", default=None, type=click.Choice(["random_adj", "metattack", "random_feat"]))
 @click.pass_context
 def cli(ctx, **kwargs):

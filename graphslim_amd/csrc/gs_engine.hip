@@ -1571,6 +1571,26 @@ extern "C" int gs_gcond_set_identity_structure(gs_gcond* e, int on, gs_stream_t 
   return GS_OK;
 }
 
+// Structure supplied by the caller (MSGC, condensation/msgc.py:98,109: the adjacency comes from an edge-list generator outside
+// the engine, graphslim_amd/structure.py): `adj` [n'][n'] is the raw symmetric structure WITHOUT self loops.  inference = 0: it
+// becomes the structure train_class differentiates — gs_gcond_stage_syn_match then leaves d loss / d adj in buffer "d_adj" and
+// the direct feature gradient in "d_feat"; inference = 1: it becomes the structure of the inner model steps
+// (gs_gcond_stage_inner_steps) and is copied to io.adj_syn.  The PGE stages are not run in this mode; the caller drives the
+// iteration stage by stage and owns the optimiser steps of X~ and of its generator.
+extern "C" int gs_gcond_set_structure(gs_gcond* e, const float* adj, int inference, gs_stream_t stream) {
+  if (!e || !adj) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_structure: null argument");
+  if (e->identity) GS_FAIL(GS_ERR_STATE, "gs_gcond_set_structure: the engine is in identity-structure mode");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t bytes = sizeof(float) * (size_t)e->n * e->n;
+  e->fwd_cached = false;
+  if (inference) {
+    if (adj != e->io.adj_syn) GS_HIP(hipMemcpyAsync(e->io.adj_syn, adj, bytes, hipMemcpyDeviceToDevice, s));
+    return gs_dense_gcn_norm_fwd(e->io.adj_syn, e->n, e->adj_norm_in, e->rnorm_in, stream);
+  }
+  GS_HIP(hipMemcpyAsync(e->adj_raw, adj, bytes, hipMemcpyDeviceToDevice, s));
+  return gs_dense_gcn_norm_fwd(e->adj_raw, e->n, e->adj_norm, e->rnorm, stream);
+}
+
 // Sampling + real-side class gradients of this rank's classes, forked onto the engine's second stream when overlap is on
 // (the join is taken by the first stage that reads gw_real); also samples the NEXT iteration's blocks behind them.
 extern "C" int gs_gcond_stage_real_async(gs_gcond* e, gs_stream_t stream) {

@@ -1,0 +1,273 @@
+// Edge-list structure generator of MSGC ("Multiple sparse graphs condensation", graphslim/condensation/msgc.py:31-39,224-236):
+// an MLP with training-mode BatchNorm that scores every directed edge of `batch_adj` sparse structures over the same synthetic
+// nodes, scattered into a dense adjacency and symmetrised.  The MLP's matrix products run through gs_gemm_f32; this file holds
+// the gather / BatchNorm / score / scatter kernels around them, forward and backward, all HBM-bound row streams:
+//   * one wave per edge row, lanes over the hidden units (coalesced 256-B row segments);
+//   * column statistics in two deterministic stages (fp64 partials per row chunk, then a fixed-order sum) — no float atomics;
+//   * scatter-adds onto nodes are segment sums over a host-built edge permutation (fixed order, reproducible).
+#include <hip/hip_runtime.h>
+
+#include "../../include/gslim.h"
+#include "gs_common.h"
+
+namespace {
+
+constexpr int SG_MAX_CHUNKS = 1024;   // row chunks of the two-stage column statistics (scratch: 2 * SG_MAX_CHUNKS * F doubles)
+
+inline int sg_chunks(long E) {
+  long c = gs_cdiv(E, 256);
+  return (int)(c < 1 ? 1 : (c > SG_MAX_CHUNKS ? SG_MAX_CHUNKS : c));
+}
+
+// out[e][k] = U[rows[e]][k] + V[cols[e]][k] + bias[k]
+__global__ __launch_bounds__(256) void sg_pair_sum_kernel(const float* __restrict__ U, const float* __restrict__ V, long ld,
+                                                          const float* __restrict__ bias, const int* __restrict__ rows,
+                                                          const int* __restrict__ cols, long E, int F, float* __restrict__ out,
+                                                          long ldo) {
+  const int lane = threadIdx.x & 63;
+  const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (e >= E) return;
+  const float* u = U + (long)rows[e] * ld;
+  const float* v = V + (long)cols[e] * ld;
+  float* o = out + e * ldo;
+  for (int k = lane; k < F; k += 64) o[k] = (u[k] + v[k]) + (bias ? bias[k] : 0.f);
+}
+
+// Stage 1 of the column statistics.  MODE 0: (sum x, sum x^2).  MODE 1: (sum dz, sum dz * xhat) with dz = dY * [Y > 0],
+// xhat = (x - mu) * istd.  grid (cdiv(F, 64), chunks), block 256 = 64 columns x 4 row lanes.
+template <int MODE>
+__global__ __launch_bounds__(256) void sg_colstats_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ dY,
+                                                          long lddy, const float* __restrict__ Y, long ldy,
+                                                          const float* __restrict__ mu, const float* __restrict__ istd, long E, int F,
+                                                          int chunks, double* __restrict__ part) {
+  __shared__ double sh[2][4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const long per = gs_cdiv(E, (long)chunks);
+  const long r0 = (long)blockIdx.y * per;
+  const long r1 = r0 + per < E ? r0 + per : E;
+  double a = 0.0, b = 0.0;
+  if (col < F) {
+    const float m = MODE == 1 ? mu[col] : 0.f, is = MODE == 1 ? istd[col] : 0.f;
+    for (long r = r0 + rl; r < r1; r += 4) {
+      const float x = X[r * ldx + col];
+      if (MODE == 0) {
+        a += (double)x;
+        b += (double)x * (double)x;
+      } else {
+        const float dz = Y[r * ldy + col] > 0.f ? dY[r * lddy + col] : 0.f;
+        a += (double)dz;
+        b += (double)dz * (double)((x - m) * is);
+      }
+    }
+  }
+  sh[0][rl][threadIdx.x & 63] = a;
+  sh[1][rl][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (rl == 0 && col < F) {
+    const int c = threadIdx.x & 63;
+    part[((long)blockIdx.y * 2 + 0) * F + col] = ((sh[0][0][c] + sh[0][1][c]) + sh[0][2][c]) + sh[0][3][c];
+    part[((long)blockIdx.y * 2 + 1) * F + col] = ((sh[1][0][c] + sh[1][1][c]) + sh[1][2][c]) + sh[1][3][c];
+  }
+}
+
+// Stage 2, MODE 0: mean and 1/sqrt(biased variance + eps) (nn.BatchNorm1d in training mode normalises with the biased variance).
+__global__ void sg_bn_finish_kernel(const double* __restrict__ part, int chunks, long E, int F, float eps, float* __restrict__ mu,
+                                    float* __restrict__ istd) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= F) return;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < chunks; ++c) { s += part[((long)c * 2 + 0) * F + col]; q += part[((long)c * 2 + 1) * F + col]; }
+  const double m = s / (double)E;
+  double var = q / (double)E - m * m;
+  if (var < 0.0) var = 0.0;
+  mu[col] = (float)m;
+  istd[col] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// Stage 2, MODE 1: the two sums as floats: dbe = sum dz, dg = sum dz * xhat
+__global__ void sg_bwd_finish_kernel(const double* __restrict__ part, int chunks, int F, float* __restrict__ dbe,
+                                     float* __restrict__ dg) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= F) return;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < chunks; ++c) { s += part[((long)c * 2 + 0) * F + col]; q += part[((long)c * 2 + 1) * F + col]; }
+  dbe[col] = (float)s;
+  dg[col] = (float)q;
+}
+
+// Y = relu(g * (x - mu) * istd + be)
+__global__ __launch_bounds__(256) void sg_bn_relu_apply_kernel(const float* __restrict__ X, long ldx, long E, int F,
+                                                               const float* __restrict__ mu, const float* __restrict__ istd,
+                                                               const float* __restrict__ g, const float* __restrict__ be,
+                                                               float* __restrict__ Y, long ldy) {
+  const int lane = threadIdx.x & 63;
+  const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (e >= E) return;
+  for (int k = lane; k < F; k += 64) {
+    const float xh = (X[e * ldx + k] - mu[k]) * istd[k];
+    Y[e * ldy + k] = fmaxf(fmaf(g[k], xh, be[k]), 0.f);
+  }
+}
+
+// dX = g * istd * (dz - mean(dz) - xhat * mean(dz * xhat));  dX may alias dY
+__global__ __launch_bounds__(256) void sg_bn_relu_bwd_apply_kernel(const float* dY, long lddy, const float* __restrict__ Y, long ldy,
+                                                                   const float* __restrict__ X, long ldx, long E, int F,
+                                                                   const float* __restrict__ mu, const float* __restrict__ istd,
+                                                                   const float* __restrict__ g, const float* __restrict__ dbe,
+                                                                   const float* __restrict__ dg, float* dX, long lddx) {
+  const int lane = threadIdx.x & 63;
+  const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (e >= E) return;
+  const float inv = 1.f / (float)E;
+  for (int k = lane; k < F; k += 64) {
+    const float xh = (X[e * ldx + k] - mu[k]) * istd[k];
+    const float dz = Y[e * ldy + k] > 0.f ? dY[e * lddy + k] : 0.f;
+    dX[e * lddx + k] = g[k] * istd[k] * (dz - dbe[k] * inv - xh * (dg[k] * inv));
+  }
+}
+
+// s[e] = sigmoid(A[e] . w + b)
+__global__ __launch_bounds__(256) void sg_score_kernel(const float* __restrict__ A, long ld, const float* __restrict__ w,
+                                                       const float* __restrict__ b, long E, int F, float* __restrict__ s) {
+  const int lane = threadIdx.x & 63;
+  const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (e >= E) return;
+  float acc = 0.f;
+  for (int k = lane; k < F; k += 64) acc = fmaf(A[e * ld + k], w[k], acc);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) s[e] = 1.f / (1.f + expf(-(acc + b[0])));
+}
+
+// M[pr[e]][pc[e]] = s[e]   (index assignment: duplicate (r, c) pairs carry identical scores — same inputs, same statistics)
+__global__ void sg_scatter_kernel(const float* __restrict__ s, const int* __restrict__ pr, const int* __restrict__ pc, long E, int n,
+                                  float* __restrict__ M) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E) M[(long)pr[e] * n + pc[e]] = s[e];
+}
+
+// adj = (M + M^T) / 2
+__global__ void sg_symmetrise_kernel(const float* __restrict__ M, int n, float* __restrict__ adj) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * n) return;
+  const long r = idx / n, c = idx % n;
+  adj[idx] = (M[c * n + r] + M[idx]) / 2.f;
+}
+
+// dlogit[e] = (dA[r][c] + dA[c][r]) / 2 * s (1 - s);  dA2[e][k] = dlogit[e] * w[k]
+__global__ __launch_bounds__(256) void sg_score_bwd_kernel(const float* __restrict__ dA, const int* __restrict__ pr,
+                                                           const int* __restrict__ pc, const float* __restrict__ s,
+                                                           const float* __restrict__ w, long E, int n, int F,
+                                                           float* __restrict__ dlogit, float* __restrict__ dA2, long ld) {
+  const int lane = threadIdx.x & 63;
+  const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (e >= E) return;
+  const long r = pr[e], c = pc[e];
+  const float se = s[e];
+  const float dl = (dA[r * n + c] + dA[c * n + r]) / 2.f * (se * (1.f - se));
+  if (lane == 0) dlogit[e] = dl;
+  for (int k = lane; k < F; k += 64) dA2[e * ld + k] = dl * w[k];
+}
+
+// out[i][k] = sum_{j in [ptr[i], ptr[i+1])} Xe[perm[j]][k]  (fixed order)
+__global__ __launch_bounds__(256) void sg_segment_sum_kernel(const float* __restrict__ Xe, long ld, const int* __restrict__ ptr,
+                                                             const int* __restrict__ perm, int n, int F, float* __restrict__ out,
+                                                             long ldo) {
+  const int lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n) return;
+  const int j0 = ptr[i], j1 = ptr[i + 1];
+  for (int k = lane; k < F; k += 64) {
+    float acc = 0.f;
+    for (int j = j0; j < j1; ++j) acc += Xe[(long)perm[j] * ld + k];
+    out[i * ldo + k] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int gs_edge_pair_sum_f32(const float* U, const float* V, long ld, const float* bias, const int* rows, const int* cols,
+                                    long E, int F, float* out, long ldo, gs_stream_t stream) {
+  if (E <= 0) return GS_OK;
+  if (!U || !V || !rows || !cols || !out || F <= 0 || ld < F || ldo < F) GS_FAIL(GS_ERR_ARG, "gs_edge_pair_sum_f32: bad argument");
+  hipLaunchKernelGGL(sg_pair_sum_kernel, dim3(gs_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream, U, V, ld, bias, rows, cols, E, F, out,
+                     ldo);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" size_t gs_bn_scratch_bytes(int F) { return sizeof(double) * 2 * (size_t)SG_MAX_CHUNKS * (size_t)(F > 0 ? F : 0); }
+
+extern "C" int gs_bn_relu_fwd_f32(const float* X, long ldx, long E, int F, const float* g, const float* be, float eps, float* Y,
+                                  long ldy, float* mu, float* istd, void* scratch, gs_stream_t stream) {
+  if (!X || !g || !be || !Y || !mu || !istd || !scratch || E <= 0 || F <= 0 || ldx < F || ldy < F)
+    GS_FAIL(GS_ERR_ARG, "gs_bn_relu_fwd_f32: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = sg_chunks(E);
+  double* part = (double*)scratch;
+  hipLaunchKernelGGL((sg_colstats_kernel<0>), dim3(gs_cdiv(F, 64), chunks), dim3(256), 0, s, X, ldx, (const float*)nullptr, 0L,
+                     (const float*)nullptr, 0L, (const float*)nullptr, (const float*)nullptr, E, F, chunks, part);
+  hipLaunchKernelGGL(sg_bn_finish_kernel, dim3(gs_cdiv(F, 64)), dim3(64), 0, s, part, chunks, E, F, eps, mu, istd);
+  hipLaunchKernelGGL(sg_bn_relu_apply_kernel, dim3(gs_cdiv(E, 4)), dim3(256), 0, s, X, ldx, E, F, mu, istd, g, be, Y, ldy);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_bn_relu_bwd_f32(const float* dY, long lddy, const float* Y, long ldy, const float* X, long ldx, long E, int F,
+                                  const float* mu, const float* istd, const float* g, float* dX, long lddx, float* dg, float* dbe,
+                                  void* scratch, gs_stream_t stream) {
+  if (!dY || !Y || !X || !mu || !istd || !g || !dX || !dg || !dbe || !scratch || E <= 0 || F <= 0 || lddy < F || ldy < F || ldx < F ||
+      lddx < F)
+    GS_FAIL(GS_ERR_ARG, "gs_bn_relu_bwd_f32: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = sg_chunks(E);
+  double* part = (double*)scratch;
+  hipLaunchKernelGGL((sg_colstats_kernel<1>), dim3(gs_cdiv(F, 64), chunks), dim3(256), 0, s, X, ldx, dY, lddy, Y, ldy, mu, istd, E, F,
+                     chunks, part);
+  hipLaunchKernelGGL(sg_bwd_finish_kernel, dim3(gs_cdiv(F, 64)), dim3(64), 0, s, part, chunks, F, dbe, dg);
+  hipLaunchKernelGGL(sg_bn_relu_bwd_apply_kernel, dim3(gs_cdiv(E, 4)), dim3(256), 0, s, dY, lddy, Y, ldy, X, ldx, E, F, mu, istd, g,
+                     dbe, dg, dX, lddx);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_edge_score_f32(const float* A, long ld, const float* w, const float* b, long E, int F, float* s,
+                                 gs_stream_t stream) {
+  if (E <= 0) return GS_OK;
+  if (!A || !w || !b || !s || F <= 0 || ld < F) GS_FAIL(GS_ERR_ARG, "gs_edge_score_f32: bad argument");
+  hipLaunchKernelGGL(sg_score_kernel, dim3(gs_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream, A, ld, w, b, E, F, s);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_edge_scatter_sym_f32(const float* s, const int* pr, const int* pc, long E, int n, float* M, float* adj,
+                                       gs_stream_t stream) {
+  if (!M || !adj || n <= 0 || (E > 0 && (!s || !pr || !pc))) GS_FAIL(GS_ERR_ARG, "gs_edge_scatter_sym_f32: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  GS_HIP(hipMemsetAsync(M, 0, sizeof(float) * (size_t)n * n, st));
+  if (E > 0) hipLaunchKernelGGL(sg_scatter_kernel, dim3(gs_cdiv(E, 256)), dim3(256), 0, st, s, pr, pc, E, n, M);
+  hipLaunchKernelGGL(sg_symmetrise_kernel, dim3(gs_cdiv((long)n * n, 256)), dim3(256), 0, st, M, n, adj);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_edge_score_bwd_f32(const float* dA, const int* pr, const int* pc, const float* s, const float* w, long E, int n,
+                                     int F, float* dlogit, float* dA2, long ld, gs_stream_t stream) {
+  if (E <= 0) return GS_OK;
+  if (!dA || !pr || !pc || !s || !w || !dlogit || !dA2 || n <= 0 || F <= 0 || ld < F)
+    GS_FAIL(GS_ERR_ARG, "gs_edge_score_bwd_f32: bad argument");
+  hipLaunchKernelGGL(sg_score_bwd_kernel, dim3(gs_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream, dA, pr, pc, s, w, E, n, F, dlogit,
+                     dA2, ld);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_segment_sum_rows_f32(const float* Xe, long ld, const int* ptr, const int* perm, int n, int F, float* out, long ldo,
+                                       gs_stream_t stream) {
+  if (n <= 0) return GS_OK;
+  if (!Xe || !ptr || !perm || !out || F <= 0 || ld < F || ldo < F) GS_FAIL(GS_ERR_ARG, "gs_segment_sum_rows_f32: bad argument");
+  hipLaunchKernelGGL(sg_segment_sum_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, Xe, ld, ptr, perm, n, F, out, ldo);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}

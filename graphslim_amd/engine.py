@@ -309,9 +309,14 @@ class GCondEngine:
             self.h = None
 
     # ---- parameter packing (nn.Module.parameters() order) ------------------------------------------
-    def set_model(self, params):
+    def set_model(self, params, keep_optimizer=False):
+        """Fresh theta.  keep_optimizer: the model's Adam moments and step count carry over (MSGC builds its model optimiser once,
+        msgc.py:90, and re-draws the weights in place every epoch); default: a fresh optimiser per epoch (gcond.py:42-45)."""
+        if keep_optimizer and self.shapes.with_bn:
+            raise NotImplementedError("keep_optimizer with with_bn")
         self.model_params.copy_(torch.cat([p.reshape(-1).float() for p in params]).to(self.dev))
-        check(self.L.gs_gcond_new_epoch(self.h, self._s()))
+        if not keep_optimizer:
+            check(self.L.gs_gcond_new_epoch(self.h, self._s()))
 
     def get_model(self):
         s, d = self.shapes, self.shapes.d
@@ -404,6 +409,11 @@ class GCondEngine:
 
     def set_identity_structure(self, on=True):
         check(self.L.gs_gcond_set_identity_structure(self.h, int(on), self._s()))
+
+    def set_structure(self, adj, inference=False):
+        """Structure supplied by the caller (gs_gcond_set_structure): raw symmetric [n_syn, n_syn] without self loops."""
+        assert adj.is_contiguous() and tuple(adj.shape) == (self.shapes.n_syn, self.shapes.n_syn)
+        check(self.L.gs_gcond_set_structure(self.h, ptr(adj), int(inference), self._s()))
 
     OPERAND_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x6": 3}
 

@@ -120,3 +120,60 @@ def seed_everything(seed):
     np.random.seed(seed)
     torch.manual_seed(seed)
     os.environ["PYTHONHASHSEED"] = str(seed)
+
+
+# ---- MSGC (graphslim/condensation/msgc.py) ------------------------------------------------------------------------
+
+
+def msgc_labels(labels_train, n_syn, nclass):
+    """msgc.py:41-64: every class gets one row, floor(rate_c (n' - C)) more, and the remainder goes one row at a time to the
+    class whose share is smallest relative to its rate.  float32 arithmetic, as upstream computes it with torch.
+    Returns (y_syn int64 [n'] class-major, counts int64 [C])."""
+    lab = np.asarray(labels_train).astype(np.int64)
+    rate = (np.bincount(lab, minlength=nclass).astype(np.float32) / np.float32(len(lab))).astype(np.float32)
+    each = (np.floor(np.float32(n_syn - nclass) * rate) + np.float32(1)).astype(np.float32)
+    for _ in range(int(np.float32(n_syn) - each.sum(dtype=np.float32))):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            more = (each / each.sum(dtype=np.float32)).astype(np.float32) / rate
+        each[int(np.argmin(more))] += 1
+    each = each.astype(np.int64)
+    return np.repeat(np.arange(nclass, dtype=np.int64), each), each
+
+
+def msgc_edges(y_syn, nclass, batch_size):
+    """msgc.py:178-222 reset_adj_batch.  Per structure, node r gets (at most) one link into every class c: among the other
+    nodes of c the one with the fewest links towards class y[r] so far; ties are broken by torch.randperm on the global torch
+    generator (the only RNG draw, same order as upstream), and a class is skipped once r holds more than one link into it.
+    Both directions of a link are stored.  Returns (rows, cols, batch) int64."""
+    y = np.asarray(y_syn).astype(np.int64)
+    n = len(y)
+    members = [np.nonzero(y == c)[0] for c in range(nclass)]
+    rows, cols, batch = [], [], []
+    for b in range(batch_size):
+        links = np.zeros((n, nclass), dtype=np.float32)
+        row, col = [], []
+        for r in range(n):
+            for c in range(nclass):
+                cand = members[c][members[c] != r]
+                if len(cand) == 0 or links[r, c] > 1:
+                    continue
+                coef = links[cand, y[r]]
+                tied = cand[coef == coef.min()]
+                pick = int(tied[0]) if len(tied) == 1 else int(tied[int(torch.randperm(len(tied))[0])])
+                links[r, c] += 1
+                links[pick, y[r]] += 1
+                row += [r, pick]
+                col += [pick, r]
+        rows.append(np.asarray(row, dtype=np.int64))
+        cols.append(np.asarray(col, dtype=np.int64))
+        batch.append(np.full(len(row), b, dtype=np.int64))
+    return np.concatenate(rows), np.concatenate(cols), np.concatenate(batch)
+
+
+def init_edge_mlp_params(nfeat, nhid=256):
+    """msgc.py:31-39 nn.Sequential(Linear(2d, h), BatchNorm1d, ReLU, Linear(h, h), BatchNorm1d, ReLU, Linear(h, 1)):
+    nn.Linear default draws in constructor order; parameters() order [W0, b0, bn1.w, bn1.b, W1, b1, bn2.w, bn2.b, w2, b2]."""
+    w0, b0 = _nn_linear(2 * nfeat, nhid)
+    w1, b1 = _nn_linear(nhid, nhid)
+    w2, b2 = _nn_linear(nhid, 1)
+    return [w0, b0, torch.ones(nhid), torch.zeros(nhid), w1, b1, torch.ones(nhid), torch.zeros(nhid), w2, b2]

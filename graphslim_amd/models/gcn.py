@@ -299,6 +299,13 @@ class GCN:
             adj = torch.as_tensor(data.adj_syn).to(dev, torch.float32).contiguous()
             feat = torch.as_tensor(data.feat_syn).to(dev, torch.float32).contiguous()
             labels = torch.as_tensor(data.labels_syn).to(dev).to(torch.int32)
+            if adj.dim() == 3:
+                # MSGC hands over B structures over the same nodes (msgc.py:126-130): GraphConvolution broadcasts the batch and
+                # flattens it (layers.py:41-47), i.e. one block-diagonal graph of B n' nodes with the features repeated;
+                # normalize_adj_tensor normalises structure by structure (utils.py:416-422) = the blocks of that graph
+                nb = adj.shape[0]
+                adj = torch.block_diag(*adj).contiguous()
+                feat = feat.repeat(nb, 1).contiguous()
             adj, _ = dense_gcn_norm_fwd(adj)          # base.py:112 normalises the (dense) synthetic adjacency unconditionally
         else:
             # base.py:91-96: the original graph — transductive: full graph, loss on output[idx_train]; inductive: train graph

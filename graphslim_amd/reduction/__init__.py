@@ -9,8 +9,11 @@ def create_reducer(name, setting, data, args, **kwargs):
     if key in ("kcenter", "herding"):
         from ..sparsification.model_based import Herding, KCenter
         return (KCenter if key == "kcenter" else Herding)(setting, data, args, **kwargs)
-    if key in ("gcond", "doscond", "gcondx", "doscondx"):
+    if key == "averaging":
+        from ..coarsening.averaging import Average
+        return Average(setting, data, args, **kwargs)
+    if key in ("gcond", "doscond", "gcondx", "doscondx", "msgc"):
         from .. import condensation as cd
-        cls = {"gcond": cd.GCond, "doscond": cd.DosCond, "gcondx": cd.GCondX, "doscondx": cd.DosCondX}[key]
+        cls = {"gcond": cd.GCond, "doscond": cd.DosCond, "gcondx": cd.GCondX, "doscondx": cd.DosCondX, "msgc": cd.MSGC}[key]
         return cls(setting, data, args, **kwargs)
     raise NotImplementedError(f"graphslim_amd builds the GCond path only; reducer '{name}' is out of scope (SURVEY.md §8)")

@@ -1,0 +1,163 @@
+"""Edge-list structure generator of MSGC (graphslim/condensation/msgc.py:31-39 `self.pge`, :178-222 reset_adj_batch,
+:224-236 get_adj_t_syn), forward and backward, composed from libgslim_hip.so calls: gs_gemm_f32 for the MLP's products and the
+row kernels of csrc/gs_structgen.hip around them.  No autograd and no torch arithmetic: torch owns the device buffers only.
+
+The `batch_adj` structures over the same n' nodes are laid out as ONE block-diagonal graph of B n' nodes whose rows are grouped
+by class (class c: structure 0's nodes of c, structure 1's, ...), which is the layout the matching engine wants
+(gs_gcond_io.labels_syn "grouped by class"); a permutation of rows leaves train_class unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+from .engine import adam_step, gemm, gemm_tn_splitk
+
+BN_EPS = 1e-5
+
+
+class BatchLayout:
+    """Positions of (structure b, node i) in the class-grouped block-diagonal graph."""
+
+    def __init__(self, y_syn, nclass, batch_size):
+        y = np.asarray(y_syn).astype(np.int64)
+        n = len(y)
+        assert np.all(np.diff(y) >= 0), "y_syn must be class-major (msgc.py:55-61)"
+        counts = np.bincount(y, minlength=nclass)
+        starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        self.n, self.B, self.nclass = n, batch_size, nclass
+        self.n_big = n * batch_size
+        pos = np.empty((batch_size, n), dtype=np.int64)
+        for c in range(nclass):
+            for b in range(batch_size):
+                i = np.arange(starts[c], starts[c] + counts[c])
+                pos[b, i] = batch_size * starts[c] + b * counts[c] + (i - starts[c])
+        self.pos = pos                                                   # [B, n] -> row of the big graph
+        self.node_of_pos = np.empty(self.n_big, dtype=np.int64)
+        self.node_of_pos[pos.reshape(-1)] = np.tile(np.arange(n), batch_size)
+        self.labels_big = y[self.node_of_pos]
+        self.ranges = [(int(batch_size * starts[c]), int(batch_size * (starts[c] + counts[c]))) for c in range(nclass)]
+        self.counts = counts
+
+
+def _segments(keys, n):
+    """(ptr [n+1], perm) such that perm[ptr[i]:ptr[i+1]] lists the positions with key i in ascending position order."""
+    perm = np.argsort(keys, kind="stable")
+    ptr_ = np.concatenate([[0], np.cumsum(np.bincount(keys, minlength=n))])
+    return ptr_.astype(np.int32), perm.astype(np.int32)
+
+
+class EdgeStructureGenerator:
+    """theta = [W0 (h, 2d), b0, bn1.weight, bn1.bias, W1 (h, h), b1, bn2.weight, bn2.bias, w2 (1, h), b2] — nn.Sequential's
+    parameters() order — kept as one flat device tensor with its gradient and Adam moments."""
+
+    def __init__(self, params, d, rows, cols, batch, layout: BatchLayout, lr, device, hidden=256):
+        self.L = _lib.lib()
+        self.dev = torch.device(device)
+        self.d, self.h, self.lay = d, hidden, layout
+        h = hidden
+        self.shapes = [(h, 2 * d), (h,), (h,), (h,), (h, h), (h,), (h,), (h,), (1, h), (1,)]
+        self.theta = torch.cat([p.reshape(-1).float() for p in params]).to(self.dev).contiguous()
+        assert self.theta.numel() == sum(int(np.prod(s)) for s in self.shapes)
+        self.grad = torch.zeros_like(self.theta)
+        self.m, self.v = torch.zeros_like(self.theta), torch.zeros_like(self.theta)
+        self.lr, self.step_count = lr, 0
+        rows, cols, batch = (np.asarray(a).astype(np.int64) for a in (rows, cols, batch))
+        self.E = E = len(rows)
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32).to(self.dev)
+        self.rows, self.cols = i32(rows), i32(cols)
+        self.pr, self.pc = i32(layout.pos[batch, rows]), i32(layout.pos[batch, cols])
+        self.seg_r = tuple(i32(a) for a in _segments(rows, layout.n))
+        self.seg_c = tuple(i32(a) for a in _segments(cols, layout.n))
+        self.seg_node = tuple(i32(a) for a in _segments(layout.node_of_pos, layout.n))
+        self.node_of_pos = i32(layout.node_of_pos)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+        n, nb = layout.n, layout.n_big
+        self.U, self.V, self.dU, self.dV = f(n, h), f(n, h), f(n, h), f(n, h)
+        self.E0, self.A1, self.E2, self.A2, self.dA = f(E, h), f(E, h), f(E, h), f(E, h), f(E, h)
+        self.mu1, self.is1, self.mu2, self.is2 = f(h), f(h), f(h), f(h)
+        self.s, self.dlogit = f(E), f(E)
+        self.M, self.adj = f(nb, nb), f(nb, nb)
+        self.dX = f(n, d)
+        self.scratch = torch.empty(self.L.gs_bn_scratch_bytes(h), dtype=torch.uint8, device=self.dev)
+
+    def views(self, flat=None):
+        flat = self.theta if flat is None else flat
+        out, o = [], 0
+        for shp in self.shapes:
+            k = int(np.prod(shp))
+            out.append(flat[o:o + k].view(shp))
+            o += k
+        return out
+
+    def forward(self, X):
+        """X [n', d] (contiguous) -> raw symmetric structure [B n', B n'] without self loops (msgc.py:225-228)."""
+        L, h, d, E, n = self.L, self.h, self.d, self.E, self.lay.n
+        w0, b0, g1, be1, w1, b1, g2, be2, w2, b2 = self.views()
+        self.X = X
+        gemm(X, w0, self.U, n, h, d, (d, 1), (1, 2 * d), h)                               # U = X W0[:, :d]^T
+        gemm(X, w0[:, d:], self.V, n, h, d, (d, 1), (1, 2 * d), h)                        # V = X W0[:, d:]^T
+        check(L.gs_edge_pair_sum_f32(ptr(self.U), ptr(self.V), h, ptr(b0), ptr(self.rows), ptr(self.cols), E, h, ptr(self.E0), h,
+                                     stream()))
+        check(L.gs_bn_relu_fwd_f32(ptr(self.E0), h, E, h, ptr(g1), ptr(be1), BN_EPS, ptr(self.A1), h, ptr(self.mu1), ptr(self.is1),
+                                   ptr(self.scratch), stream()))
+        gemm(self.A1, w1, self.E2, E, h, h, (h, 1), (1, h), h, bias=b1)                   # E2 = A1 W1^T + b1
+        check(L.gs_bn_relu_fwd_f32(ptr(self.E2), h, E, h, ptr(g2), ptr(be2), BN_EPS, ptr(self.A2), h, ptr(self.mu2), ptr(self.is2),
+                                   ptr(self.scratch), stream()))
+        check(L.gs_edge_score_f32(ptr(self.A2), h, ptr(w2), ptr(b2), E, h, ptr(self.s), stream()))
+        check(L.gs_edge_scatter_sym_f32(ptr(self.s), ptr(self.pr), ptr(self.pc), E, self.lay.n_big, ptr(self.M), ptr(self.adj),
+                                        stream()))
+        return self.adj
+
+    def backward(self, d_adj, accumulate_dx=False):
+        """d loss / d adj [B n', B n'] of the LAST forward -> self.grad (flat, parameter order) and self.dX [n', d]
+        (accumulate_dx: added to what self.dX already holds — the direct feature gradient folded over the B copies)."""
+        L, h, d, E, n = self.L, self.h, self.d, self.E, self.lay.n
+        w0, b0, g1, be1, w1, b1, g2, be2, w2, b2 = self.views()
+        gw0, gb0, gg1, gbe1, gw1, gb1, gg2, gbe2, gw2, gb2 = self.views(self.grad)
+        X = self.X
+        check(L.gs_edge_score_bwd_f32(ptr(d_adj), ptr(self.pr), ptr(self.pc), ptr(self.s), ptr(w2), E, self.lay.n_big, h,
+                                      ptr(self.dlogit), ptr(self.dA), h, stream()))
+        gemm_tn_splitk(self.A2, h, self.dlogit, 1, gw2, h, 1, E)                          # dw2 = A2^T dlogit
+        check(L.gs_colsum_f32(ptr(self.dlogit), 1, E, 1, ptr(gb2), stream()))
+        check(L.gs_bn_relu_bwd_f32(ptr(self.dA), h, ptr(self.A2), h, ptr(self.E2), h, E, h, ptr(self.mu2), ptr(self.is2), ptr(g2),
+                                   ptr(self.dA), h, ptr(gg2), ptr(gbe2), ptr(self.scratch), stream()))         # dA := dE2
+        gemm_tn_splitk(self.dA, h, self.A1, h, gw1, h, h, E)                              # dW1 = dE2^T A1
+        check(L.gs_colsum_f32(ptr(self.dA), h, E, h, ptr(gb1), stream()))
+        gemm(self.dA, w1, self.E2, E, h, h, (h, 1), (h, 1), h)                            # dA1 = dE2 W1   (E2 is free now)
+        check(L.gs_bn_relu_bwd_f32(ptr(self.E2), h, ptr(self.A1), h, ptr(self.E0), h, E, h, ptr(self.mu1), ptr(self.is1), ptr(g1),
+                                   ptr(self.E2), h, ptr(gg1), ptr(gbe1), ptr(self.scratch), stream()))         # E2 := dE0
+        check(L.gs_colsum_f32(ptr(self.E2), h, E, h, ptr(gb0), stream()))
+        for seg, out in ((self.seg_r, self.dU), (self.seg_c, self.dV)):
+            check(L.gs_segment_sum_rows_f32(ptr(self.E2), h, ptr(seg[0]), ptr(seg[1]), n, h, ptr(out), h, stream()))
+        gemm(self.dU, X, gw0, h, d, n, (1, h), (d, 1), 2 * d)                             # dW0[:, :d] = dU^T X
+        gemm(self.dV, X, gw0[:, d:], h, d, n, (1, h), (d, 1), 2 * d)                      # dW0[:, d:] = dV^T X
+        gemm(self.dU, w0, self.dX, n, d, h, (h, 1), (2 * d, 1), d, beta=1.0 if accumulate_dx else 0.0)   # dX (+)= dU W0[:, :d] + dV W0[:, d:]
+        gemm(self.dV, w0[:, d:], self.dX, n, d, h, (h, 1), (2 * d, 1), d, beta=1.0)
+        return self.grad, self.dX
+
+    def adam_step(self):
+        self.step_count += 1
+        adam_step(self.theta, self.grad, self.m, self.v, self.lr, self.step_count)
+
+    # ---- moving between the n' nodes and the B n' rows of the block-diagonal graph ------------------
+    def tile(self, X, out):
+        """out[p] = X[node(p)]."""
+        check(self.L.gs_gather_rows_f32(ptr(X), X.stride(0), ptr(self.node_of_pos), self.lay.n_big, self.d, ptr(out), out.stride(0),
+                                        stream()))
+        return out
+
+    def fold(self, d_big, out):
+        """out[i] = sum over the B rows of node i (the gradient of tile)."""
+        check(self.L.gs_segment_sum_rows_f32(ptr(d_big), d_big.stride(0), ptr(self.seg_node[0]), ptr(self.seg_node[1]), self.lay.n,
+                                             self.d, ptr(out), out.stride(0), stream()))
+        return out
+
+    def batched(self, big):
+        """[B n', B n'] block-diagonal (class-grouped rows) -> [B, n', n'] in node order (index shuffling only)."""
+        pos = torch.as_tensor(self.lay.pos, device=big.device)
+        return big[pos[:, :, None], pos[:, None, :]].contiguous()

@@ -201,6 +201,39 @@ int gs_count_correct(const float* Z, long ldz, int C, const int* idx, const int*
                      gs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Edge-list structure generator (MSGC, graphslim/condensation/msgc.py:31-39 self.pge = nn.Sequential(Linear, BatchNorm1d, ReLU,
+ * Linear, BatchNorm1d, ReLU, Linear) applied to cat(x[rows], x[cols]) and msgc.py:224-236 get_adj_t_syn).  The matrix products of
+ * the MLP are gs_gemm_f32 calls; these are the row kernels around them, forward and backward.  Host-side composition:
+ * graphslim_amd/structure.py.  All of them are deterministic (no float atomics).
+ * ------------------------------------------------------------------------------------------- */
+/* out[e][k] = U[rows[e]][k] + V[cols[e]][k] + bias[k]: layer 0 on the concatenated pair as two node-level products
+ * U = X W0[:, :d]^T, V = X W0[:, d:]^T (the same factorisation as the dense PGE, parametrized_adj.py:57-63). */
+int gs_edge_pair_sum_f32(const float* U, const float* V, long ld, const float* bias, const int* rows, const int* cols, long E, int F,
+                         float* out, long ldo, gs_stream_t stream);
+/* Bytes of the `scratch` argument of the two BatchNorm calls below for F columns. */
+size_t gs_bn_scratch_bytes(int F);
+/* nn.BatchNorm1d in TRAINING mode followed by ReLU over E rows: mu = column mean, istd = 1/sqrt(biased variance + eps),
+ * Y = relu(g (X - mu) istd + be).  mu, istd [F] are outputs (the backward needs them). */
+int gs_bn_relu_fwd_f32(const float* X, long ldx, long E, int F, const float* g, const float* be, float eps, float* Y, long ldy,
+                       float* mu, float* istd, void* scratch, gs_stream_t stream);
+/* Its backward: dz = dY [Y > 0]; dbe = sum dz; dg = sum dz xhat; dX = g istd (dz - dbe/E - xhat dg/E).  dX may alias dY. */
+int gs_bn_relu_bwd_f32(const float* dY, long lddy, const float* Y, long ldy, const float* X, long ldx, long E, int F,
+                       const float* mu, const float* istd, const float* g, float* dX, long lddx, float* dg, float* dbe,
+                       void* scratch, gs_stream_t stream);
+/* s[e] = sigmoid(A[e] . w + b[0])  (the last Linear(hidden, 1) + torch.sigmoid, msgc.py:226-227). */
+int gs_edge_score_f32(const float* A, long ld, const float* w, const float* b, long E, int F, float* s, gs_stream_t stream);
+/* adj = (M + M^T) / 2 with M[pr[e]][pc[e]] = s[e] on zeros (msgc.py:225-228; M is [n][n] scratch).  Positions pr / pc may be
+ * any relabelling of (structure, node) pairs onto the rows of one block-diagonal [n][n] matrix. */
+int gs_edge_scatter_sym_f32(const float* s, const int* pr, const int* pc, long E, int n, float* M, float* adj, gs_stream_t stream);
+/* Backward of the two calls above: dlogit[e] = (dA[r][c] + dA[c][r]) / 2 * s (1 - s); dA2[e][k] = dlogit[e] w[k]. */
+int gs_edge_score_bwd_f32(const float* dA, const int* pr, const int* pc, const float* s, const float* w, long E, int n, int F,
+                          float* dlogit, float* dA2, long ld, gs_stream_t stream);
+/* out[i][k] = sum over j in [ptr[i], ptr[i+1]) of Xe[perm[j]][k], in that order: the scatter-add of edge rows onto their
+ * end points (backward of the gathers x[rows], x[cols]) as a reproducible segment sum over a host-built permutation. */
+int gs_segment_sum_rows_f32(const float* Xe, long ld, const int* ptr, const int* perm, int n, int F, float* out, long ldo,
+                            gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The GCond engine: one object per GPU holding the learnable synthetic graph (X~, PGE), the
  * per-epoch SGC model and all scratch.  One gs_gcond_outer_step == one iteration of the loop body
  * condensation/gcond.py:47-72 (PGE forward + dense_gcn_norm, train_class over all classes
@@ -303,6 +336,12 @@ int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream);
 int gs_gcond_outer_step_ex(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_stream_t stream);
 /* adj_syn = I (no PGE): GCondX / DosCondX. */
 int gs_gcond_set_identity_structure(gs_gcond* e, int on, gs_stream_t stream);
+/* Structure supplied by the caller instead of the engine's dense PGE (MSGC, msgc.py:98,109): adj [n_syn][n_syn] raw, symmetric,
+ * no self loops.  inference = 0: the structure gs_gcond_stage_syn_match differentiates (it leaves d loss / d adj in buffer
+ * "d_adj" and the direct feature gradient in "d_feat"); inference = 1: the structure of gs_gcond_stage_inner_steps, also copied
+ * to io.adj_syn.  The caller drives the iteration stage by stage (sample / real grads / syn_match / syn_finish / inner steps)
+ * and owns the optimiser steps of X~ and of its generator; the PGE stages are not run. */
+int gs_gcond_set_structure(gs_gcond* e, const float* adj, int inference, gs_stream_t stream);
 /* Synchronises `stream`; returns the accumulated loss and the outer-step count since the last reset
  * (host pointers) and resets both.  This is the loss_avg bookkeeping of gcond.py:52,74. */
 int gs_gcond_read_loss(gs_gcond* e, double* loss_sum, long* steps, gs_stream_t stream);

@@ -21,7 +21,7 @@ def L():
 def test_header_symbols_are_exported(L):
     from graphslim_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "gslim.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(gs_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|size_t|const char\*)\s+(gs_\w+)\s*\(", hdr, flags=re.M))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s

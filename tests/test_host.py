@@ -300,3 +300,29 @@ def test_g17_evaluation_gcn_with_bn_is_fenced_like_the_reference_fails(golden_di
     args = type("A", (), {"nlayers": 2, "with_bn": True, "device": "cuda:0"})()
     with pytest.raises(NotImplementedError, match="RuntimeError"):
         GCN(10, 16, 4, args, mode="eval")
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_g18_msgc_host_allocation_is_bit_exact(golden_dir, tag):
+    """MSGC's host-side preparation (msgc.py:41-64 labels, :178-222 greedy edge lists with randperm tie breaks) in the product's
+    numpy form against the reference's own run: bit-exact integers, with the reference's RNG draw order."""
+    from graphslim_amd import host as H
+    from graphslim_amd.structure import BatchLayout
+    g = load_golden(golden_dir, "g18_msgc")
+    n, nclass, d, hidden, t, inner, epochs, outer, B = [int(v) for v in g[f"{tag}_meta"]]
+    y, idx = g[f"{tag}_y"], g[f"{tag}_idx_train"]
+    H.seed_everything(1)
+    y_syn, each = H.msgc_labels(y[idx], int(len(idx) * 0.5), nclass)
+    np.testing.assert_array_equal(y_syn, g[f"{tag}_y_syn"])
+    assert each.sum() == len(y_syn) == int(len(idx) * 0.5) and each.min() >= 1
+    H.init_edge_mlp_params(d)
+    H.init_sgc_params(d, hidden, nclass, t)
+    rows, cols, batch = H.msgc_edges(y_syn, nclass, B)
+    for got, key in ((rows, "rows"), (cols, "cols"), (batch, "batch")):
+        np.testing.assert_array_equal(got, g[f"{tag}_{key}"])
+    # the class-grouped block-diagonal layout: a bijection whose class ranges are contiguous and B times the per-structure counts
+    lay = BatchLayout(y_syn, nclass, B)
+    assert sorted(lay.pos.reshape(-1).tolist()) == list(range(B * len(y_syn)))
+    assert [hi - lo for lo, hi in lay.ranges] == (B * each).tolist()
+    assert np.array_equal(lay.labels_big, np.repeat(np.arange(nclass), B * each))
+    assert np.array_equal(np.tile(y_syn, B), g[f"{tag}_labels_out"])
