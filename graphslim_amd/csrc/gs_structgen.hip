@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int SG_MAX_CHUNKS = 1024;   // row chunks of the two-stage column statistics (scratch: 2 * SG_MAX_CHUNKS * F doubles)
+constexpr int SG_MAX_CHUNKS = 256;    // row chunks of the two-stage column statistics (scratch: 2 * SG_MAX_CHUNKS * F doubles)
 
 inline int sg_chunks(long E) {
   long c = gs_cdiv(E, 256);
@@ -71,13 +71,31 @@ __global__ __launch_bounds__(256) void sg_colstats_kernel(const float* __restric
   }
 }
 
-// Stage 2, MODE 0: mean and 1/sqrt(biased variance + eps) (nn.BatchNorm1d in training mode normalises with the biased variance).
-__global__ void sg_bn_finish_kernel(const double* __restrict__ part, int chunks, long E, int F, float eps, float* __restrict__ mu,
-                                    float* __restrict__ istd) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= F) return;
+// Stage 2: the chunk partials of column `col` summed by 4 lanes over contiguous quarters of the chunks, combined in lane order
+// (block = 64 columns x 4 lanes).  Returns the two totals to lane 0 of every column.
+__device__ __forceinline__ void sg_sum_parts(const double* __restrict__ part, int chunks, int F, int col, double* s_out, double* q_out) {
+  __shared__ double sh[2][4][64];
+  const int c = threadIdx.x & 63, l = threadIdx.x >> 6;
+  const int per = (chunks + 3) >> 2;
+  int c0 = l * per, c1 = c0 + per;
+  if (c1 > chunks) c1 = chunks;
   double s = 0.0, q = 0.0;
-  for (int c = 0; c < chunks; ++c) { s += part[((long)c * 2 + 0) * F + col]; q += part[((long)c * 2 + 1) * F + col]; }
+  if (col < F)
+    for (int k = c0; k < c1; ++k) { s += part[((long)k * 2 + 0) * F + col]; q += part[((long)k * 2 + 1) * F + col]; }
+  sh[0][l][c] = s;
+  sh[1][l][c] = q;
+  __syncthreads();
+  *s_out = ((sh[0][0][c] + sh[0][1][c]) + sh[0][2][c]) + sh[0][3][c];
+  *q_out = ((sh[1][0][c] + sh[1][1][c]) + sh[1][2][c]) + sh[1][3][c];
+}
+
+// MODE 0: mean and 1/sqrt(biased variance + eps) (nn.BatchNorm1d in training mode normalises with the biased variance).
+__global__ __launch_bounds__(256) void sg_bn_finish_kernel(const double* __restrict__ part, int chunks, long E, int F, float eps,
+                                                           float* __restrict__ mu, float* __restrict__ istd) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s, q;
+  sg_sum_parts(part, chunks, F, col, &s, &q);
+  if (col >= F || threadIdx.x >= 64) return;
   const double m = s / (double)E;
   double var = q / (double)E - m * m;
   if (var < 0.0) var = 0.0;
@@ -85,15 +103,24 @@ __global__ void sg_bn_finish_kernel(const double* __restrict__ part, int chunks,
   istd[col] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// Stage 2, MODE 1: the two sums as floats: dbe = sum dz, dg = sum dz * xhat
-__global__ void sg_bwd_finish_kernel(const double* __restrict__ part, int chunks, int F, float* __restrict__ dbe,
-                                     float* __restrict__ dg) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= F) return;
-  double s = 0.0, q = 0.0;
-  for (int c = 0; c < chunks; ++c) { s += part[((long)c * 2 + 0) * F + col]; q += part[((long)c * 2 + 1) * F + col]; }
+// MODE 1: the two sums as floats: dbe = sum dz, dg = sum dz * xhat
+__global__ __launch_bounds__(256) void sg_bwd_finish_kernel(const double* __restrict__ part, int chunks, int F, float* __restrict__ dbe,
+                                                            float* __restrict__ dg) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s, q;
+  sg_sum_parts(part, chunks, F, col, &s, &q);
+  if (col >= F || threadIdx.x >= 64) return;
   dbe[col] = (float)s;
   dg[col] = (float)q;
+}
+
+// plain column sum: out[k] = sum x
+__global__ __launch_bounds__(256) void sg_sum_finish_kernel(const double* __restrict__ part, int chunks, int F, float* __restrict__ out) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s, q;
+  sg_sum_parts(part, chunks, F, col, &s, &q);
+  if (col >= F || threadIdx.x >= 64) return;
+  out[col] = (float)s;
 }
 
 // Y = relu(g * (x - mu) * istd + be)
@@ -170,19 +197,34 @@ __global__ __launch_bounds__(256) void sg_score_bwd_kernel(const float* __restri
   for (int k = lane; k < F; k += 64) dA2[e * ld + k] = dl * w[k];
 }
 
-// out[i][k] = sum_{j in [ptr[i], ptr[i+1])} Xe[perm[j]][k]  (fixed order)
+// out[i][k] = sum_{j in [ptr[i], ptr[i+1])} Xe[perm[j]][k].  One workgroup per (node, 64-column chunk); the segment is cut into
+// four contiguous quarters, one per wave, each summed in order, and the four partial sums are added in wave order: a fixed
+// summation tree, reproducible from run to run.
 __global__ __launch_bounds__(256) void sg_segment_sum_kernel(const float* __restrict__ Xe, long ld, const int* __restrict__ ptr,
                                                              const int* __restrict__ perm, int n, int F, float* __restrict__ out,
                                                              long ldo) {
-  const int lane = threadIdx.x & 63;
-  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (i >= n) return;
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x;
+  const int k = blockIdx.y * 64 + lane;
   const int j0 = ptr[i], j1 = ptr[i + 1];
-  for (int k = lane; k < F; k += 64) {
-    float acc = 0.f;
-    for (int j = j0; j < j1; ++j) acc += Xe[(long)perm[j] * ld + k];
-    out[i * ldo + k] = acc;
+  const int len = j1 - j0, q = (len + 3) >> 2;
+  int a = j0 + w * q, b = a + q;
+  if (a > j1) a = j1;
+  if (b > j1) b = j1;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  if (k < F) {
+    int j = a;
+    for (; j + 4 <= b; j += 4) {       // four independent loads in flight; added in index order below
+      const float x0 = Xe[(long)perm[j] * ld + k], x1 = Xe[(long)perm[j + 1] * ld + k];
+      const float x2 = Xe[(long)perm[j + 2] * ld + k], x3 = Xe[(long)perm[j + 3] * ld + k];
+      acc0 += x0; acc1 += x1; acc2 += x2; acc3 += x3;
+    }
+    for (; j < b; ++j) acc0 += Xe[(long)perm[j] * ld + k];
   }
+  sh[w][lane] = (acc0 + acc1) + (acc2 + acc3);
+  __syncthreads();
+  if (w == 0 && k < F) out[(long)i * ldo + k] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
 }
 
 }  // namespace
@@ -208,7 +250,7 @@ extern "C" int gs_bn_relu_fwd_f32(const float* X, long ldx, long E, int F, const
   double* part = (double*)scratch;
   hipLaunchKernelGGL((sg_colstats_kernel<0>), dim3(gs_cdiv(F, 64), chunks), dim3(256), 0, s, X, ldx, (const float*)nullptr, 0L,
                      (const float*)nullptr, 0L, (const float*)nullptr, (const float*)nullptr, E, F, chunks, part);
-  hipLaunchKernelGGL(sg_bn_finish_kernel, dim3(gs_cdiv(F, 64)), dim3(64), 0, s, part, chunks, E, F, eps, mu, istd);
+  hipLaunchKernelGGL(sg_bn_finish_kernel, dim3(gs_cdiv(F, 64)), dim3(256), 0, s, part, chunks, E, F, eps, mu, istd);
   hipLaunchKernelGGL(sg_bn_relu_apply_kernel, dim3(gs_cdiv(E, 4)), dim3(256), 0, s, X, ldx, E, F, mu, istd, g, be, Y, ldy);
   GS_LAUNCH_CHECK();
   return GS_OK;
@@ -225,7 +267,7 @@ extern "C" int gs_bn_relu_bwd_f32(const float* dY, long lddy, const float* Y, lo
   double* part = (double*)scratch;
   hipLaunchKernelGGL((sg_colstats_kernel<1>), dim3(gs_cdiv(F, 64), chunks), dim3(256), 0, s, X, ldx, dY, lddy, Y, ldy, mu, istd, E, F,
                      chunks, part);
-  hipLaunchKernelGGL(sg_bwd_finish_kernel, dim3(gs_cdiv(F, 64)), dim3(64), 0, s, part, chunks, F, dbe, dg);
+  hipLaunchKernelGGL(sg_bwd_finish_kernel, dim3(gs_cdiv(F, 64)), dim3(256), 0, s, part, chunks, F, dbe, dg);
   hipLaunchKernelGGL(sg_bn_relu_bwd_apply_kernel, dim3(gs_cdiv(E, 4)), dim3(256), 0, s, dY, lddy, Y, ldy, X, ldx, E, F, mu, istd, g,
                      dbe, dg, dX, lddx);
   GS_LAUNCH_CHECK();
@@ -267,7 +309,20 @@ extern "C" int gs_segment_sum_rows_f32(const float* Xe, long ld, const int* ptr,
                                        gs_stream_t stream) {
   if (n <= 0) return GS_OK;
   if (!Xe || !ptr || !perm || !out || F <= 0 || ld < F || ldo < F) GS_FAIL(GS_ERR_ARG, "gs_segment_sum_rows_f32: bad argument");
-  hipLaunchKernelGGL(sg_segment_sum_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, Xe, ld, ptr, perm, n, F, out, ldo);
+  hipLaunchKernelGGL(sg_segment_sum_kernel, dim3(n, gs_cdiv(F, 64)), dim3(256), 0, (hipStream_t)stream, Xe, ld, ptr, perm, n, F, out,
+                     ldo);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_colsum_tall_f32(const float* X, long ld, long E, int F, float* out, void* scratch, gs_stream_t stream) {
+  if (!X || !out || !scratch || E <= 0 || F <= 0 || ld < F) GS_FAIL(GS_ERR_ARG, "gs_colsum_tall_f32: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = sg_chunks(E);
+  double* part = (double*)scratch;
+  hipLaunchKernelGGL((sg_colstats_kernel<0>), dim3(gs_cdiv(F, 64), chunks), dim3(256), 0, s, X, ld, (const float*)nullptr, 0L,
+                     (const float*)nullptr, 0L, (const float*)nullptr, (const float*)nullptr, E, F, chunks, part);
+  hipLaunchKernelGGL(sg_sum_finish_kernel, dim3(gs_cdiv(F, 64)), dim3(256), 0, s, part, chunks, F, out);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

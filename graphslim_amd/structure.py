@@ -123,15 +123,16 @@ class EdgeStructureGenerator:
         check(L.gs_edge_score_bwd_f32(ptr(d_adj), ptr(self.pr), ptr(self.pc), ptr(self.s), ptr(w2), E, self.lay.n_big, h,
                                       ptr(self.dlogit), ptr(self.dA), h, stream()))
         gemm_tn_splitk(self.A2, h, self.dlogit, 1, gw2, h, 1, E)                          # dw2 = A2^T dlogit
-        check(L.gs_colsum_f32(ptr(self.dlogit), 1, E, 1, ptr(gb2), stream()))
+        check(L.gs_colsum_tall_f32(ptr(self.dlogit), 1, E, 1, ptr(gb2), ptr(self.scratch), stream()))
         check(L.gs_bn_relu_bwd_f32(ptr(self.dA), h, ptr(self.A2), h, ptr(self.E2), h, E, h, ptr(self.mu2), ptr(self.is2), ptr(g2),
                                    ptr(self.dA), h, ptr(gg2), ptr(gbe2), ptr(self.scratch), stream()))         # dA := dE2
         gemm_tn_splitk(self.dA, h, self.A1, h, gw1, h, h, E)                              # dW1 = dE2^T A1
-        check(L.gs_colsum_f32(ptr(self.dA), h, E, h, ptr(gb1), stream()))
-        gemm(self.dA, w1, self.E2, E, h, h, (h, 1), (h, 1), h)                            # dA1 = dE2 W1   (E2 is free now)
+        check(L.gs_colsum_tall_f32(ptr(self.dA), h, E, h, ptr(gb1), ptr(self.scratch), stream()))
+        w1t = w1.t().contiguous()                                                        # (a 256 x 256 copy: B with contiguous k -> row-panel kernel)
+        gemm(self.dA, w1t, self.E2, E, h, h, (h, 1), (1, h), h)                           # dA1 = dE2 W1   (E2 is free now)
         check(L.gs_bn_relu_bwd_f32(ptr(self.E2), h, ptr(self.A1), h, ptr(self.E0), h, E, h, ptr(self.mu1), ptr(self.is1), ptr(g1),
                                    ptr(self.E2), h, ptr(gg1), ptr(gbe1), ptr(self.scratch), stream()))         # E2 := dE0
-        check(L.gs_colsum_f32(ptr(self.E2), h, E, h, ptr(gb0), stream()))
+        check(L.gs_colsum_tall_f32(ptr(self.E2), h, E, h, ptr(gb0), ptr(self.scratch), stream()))
         for seg, out in ((self.seg_r, self.dU), (self.seg_c, self.dV)):
             check(L.gs_segment_sum_rows_f32(ptr(self.E2), h, ptr(seg[0]), ptr(seg[1]), n, h, ptr(out), h, stream()))
         gemm(self.dU, X, gw0, h, d, n, (1, h), (d, 1), 2 * d)                             # dW0[:, :d] = dU^T X

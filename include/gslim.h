@@ -220,6 +220,9 @@ int gs_bn_relu_fwd_f32(const float* X, long ldx, long E, int F, const float* g, 
 int gs_bn_relu_bwd_f32(const float* dY, long lddy, const float* Y, long ldy, const float* X, long ldx, long E, int F,
                        const float* mu, const float* istd, const float* g, float* dX, long lddx, float* dg, float* dbe,
                        void* scratch, gs_stream_t stream);
+/* out[k] = sum over E rows of X[e][k] for a TALL X (E >> F): per-chunk fp64 partial sums, then a fixed-order sum (the same two
+ * stages as the BatchNorm statistics; gs_colsum_f32 walks the rows with one workgroup per 32 columns).  scratch as above. */
+int gs_colsum_tall_f32(const float* X, long ld, long E, int F, float* out, void* scratch, gs_stream_t stream);
 /* s[e] = sigmoid(A[e] . w + b[0])  (the last Linear(hidden, 1) + torch.sigmoid, msgc.py:226-227). */
 int gs_edge_score_f32(const float* A, long ld, const float* w, const float* b, long E, int F, float* s, gs_stream_t stream);
 /* adj = (M + M^T) / 2 with M[pr[e]][pc[e]] = s[e] on zeros (msgc.py:225-228; M is [n][n] scratch).  Positions pr / pc may be
