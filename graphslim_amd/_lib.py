@@ -63,7 +63,7 @@ SYMBOLS = [
     "gs_gcond_forward_cached", "gs_gcond_adopt_cached_forward", "gs_gcond_stage_pge_forward_part", "gs_gcond_stage_pge_backward_part",
     "gs_gcond_stage_syn_finish", "gs_gcond_stage_inner_steps", "gs_bias_act_f32", "gs_log_softmax_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
     "gs_edge_pair_sum_f32", "gs_bn_scratch_bytes", "gs_bn_relu_fwd_f32", "gs_bn_relu_bwd_f32", "gs_edge_score_f32",
-    "gs_edge_scatter_sym_f32", "gs_edge_score_bwd_f32", "gs_segment_sum_rows_f32", "gs_colsum_tall_f32", "gs_gcond_set_structure",
+    "gs_edge_scatter_sym_f32", "gs_edge_score_bwd_f32", "gs_segment_sum_rows_f32", "gs_colsum_tall_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
 ]
 
 
@@ -138,6 +138,7 @@ def lib():
     L.gs_gcond_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_long)]
     L.gs_gcond_get_blocks.argtypes = [vp, C.POINTER(Blocks)]
     L.gs_gcond_set_structure.argtypes = [vp, vp, i, vp]
+    L.gs_gcond_set_block_structure.argtypes = [vp, vp, i, i, vp]
     L.gs_edge_pair_sum_f32.argtypes = [vp, vp, l, vp, vp, vp, l, i, vp, l, vp]
     L.gs_bn_scratch_bytes.argtypes = [i]
     L.gs_bn_scratch_bytes.restype = C.c_size_t

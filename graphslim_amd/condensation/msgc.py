@@ -39,13 +39,18 @@ class MSGCLoop:
         self.x = torch.as_tensor(feat_init).to(eng.dev, torch.float32).contiguous()
         self.m_x, self.v_x, self.step_x = torch.zeros_like(self.x), torch.zeros_like(self.x), 0
         self.gen.tile(self.x, eng.feat_syn)
+        eng.set_block_structure(lay.pos)          # the B structures are disconnected blocks: per-block A^ A^ and dA^ products
         self.d_adj, self.d_feat_big = eng.view("d_adj").view(nb, nb), eng.view("d_feat").view(nb, d)
         self.adj_inner_norm = eng.view("adj_norm_inner").view(nb, nb)
+        self.fwd_valid = False        # the generator holds a forward pass of the current (X~, theta)
 
     def step(self, it):
         eng, gen, x = self.eng, self.gen, self.x
         eng.stage_real_async()
-        eng.set_structure(gen.forward(x), inference=False)                        # :98 get_adj_t_syn
+        # :98 get_adj_t_syn — the same function of the same (X~, theta) as the previous iteration's :111 call: its structure and
+        # activations are still in place (bitwise the values a second pass would produce)
+        adj = gen.adj if self.fwd_valid else gen.forward(x)
+        eng.set_structure(adj, inference=False)
         eng.stage_syn_match()                                                     # :100 train_class
         eng.syn_finish()
         if it % 50 < 10:                                                          # :105-108
@@ -58,6 +63,7 @@ class MSGCLoop:
             adam_step(x, gen.dX, self.m_x, self.v_x, self.lr_feat, self.step_x)
             gen.tile(x, eng.feat_syn)
         eng.set_structure(gen.forward(x), inference=True)                         # :111
+        self.fwd_valid = True
         eng.inner_steps()                                                         # :113-118
 
     def inner_structure(self):

@@ -415,6 +415,19 @@ class GCondEngine:
         assert adj.is_contiguous() and tuple(adj.shape) == (self.shapes.n_syn, self.shapes.n_syn)
         check(self.L.gs_gcond_set_structure(self.h, ptr(adj), int(inference), self._s()))
 
+    def set_block_structure(self, pos=None):
+        """The synthetic graph as B disconnected blocks (gs_gcond_set_block_structure): pos [B, n_block] rows of the blocks' nodes
+        (numpy / tensor); None returns to dense products.  Index array and scratch are kept alive by the engine object."""
+        if pos is None:
+            check(self.L.gs_gcond_set_block_structure(self.h, None, 0, 0, None))
+            self._blk = None
+            return
+        pos = torch.as_tensor(np.ascontiguousarray(pos), dtype=torch.int32).to(self.dev)
+        B, nb = pos.shape
+        scratch = torch.empty(3 * B * nb * nb, dtype=torch.float32, device=self.dev)
+        self._blk = (pos, scratch)
+        check(self.L.gs_gcond_set_block_structure(self.h, ptr(pos), B, nb, ptr(scratch)))
+
     OPERAND_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x6": 3}
 
     def set_operand_mode(self, mode):

@@ -247,3 +247,33 @@ def test_msgc_reduce_api(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "reduced_graph", "msgc", "adj_cora_0.25_1.pt"))
     mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
     assert mean > 0.3, mean
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_block_products_equal_the_dense_products(golden_dir, tag):
+    """gs_gcond_set_block_structure: the per-block A^ A^ and dQ A^^T + A^^T dQ products give the iteration the dense products give
+    (the structural zeros left out of the sums: same values up to the summation order) — loss, generator gradients, X~ after
+    a feature epoch, the model after the inner steps."""
+    from graphslim_amd import host as H
+    g = load_golden(golden_dir, "g18_msgc")
+    outs = []
+    for blocks_on in (True, False):
+        s = _golden_setup(g, tag)
+        n, nclass, d, hidden, t, inner, epochs, outer, B = s["meta"]
+        eng, loop = s["eng"], s["loop"]
+        if not blocks_on:
+            eng.set_block_structure(None)
+        torch.manual_seed(11)
+        eng.set_model(H.init_sgc_params(d, hidden, nclass, t))
+        _, blocks = _blocks(s, 0)
+        eng.set_blocks(blocks)
+        loop.step(10)
+        outs.append((float(eng.buffer("loss")[0]), loop.gen.grad.cpu().clone(), loop.gen.dX.cpu().clone(), loop.x.cpu().clone(),
+                     torch.cat([p.reshape(-1) for p in eng.get_model()]).cpu(), loop.inner_structure().cpu()))
+    a, b = outs
+    assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0])
+    for k in (1, 2):
+        assert float((a[k] - b[k]).abs().max()) <= 2e-5 * float(b[k].abs().max()) + 1e-9, k
+    np.testing.assert_allclose(a[3].numpy(), b[3].numpy(), atol=1e-6)
+    np.testing.assert_allclose(a[4].numpy(), b[4].numpy(), atol=1e-5)
+    np.testing.assert_allclose(a[5].numpy(), b[5].numpy(), atol=1e-6)
