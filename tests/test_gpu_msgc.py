@@ -277,3 +277,52 @@ def test_block_products_equal_the_dense_products(golden_dir, tag):
     np.testing.assert_allclose(a[3].numpy(), b[3].numpy(), atol=1e-6)
     np.testing.assert_allclose(a[4].numpy(), b[4].numpy(), atol=1e-5)
     np.testing.assert_allclose(a[5].numpy(), b[5].numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize("name,B", [("cora", 16), ("cora-r0.25", 16)])
+def test_full_size_iteration_against_the_oracle(name, B):
+    """MSGC at the reference's cora configuration at FULL size (configs/msgc/cora.json: T = 1, batch_adj = 16; d = 1 433, C = 7,
+    n' = 70 / 35 -> 1 120 / 560 rows, ~15 k / 7 k directed edges through the width-256 edge MLP) on blocks drawn by the HIP sampler:
+    those very blocks go to oracle.MSGCState — matching loss 1e-4, d loss / d X~ and d loss / d theta of the edge MLP 1e-3 of the
+    tensor's max, the structure of the inner steps."""
+    import bench
+    from graphslim_amd import host as H
+    from graphslim_amd.condensation.msgc import MSGCLoop
+    from graphslim_amd.engine import EngineShapes, GCondEngine
+    from graphslim_amd.structure import BatchLayout
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    p = bench.build_problem(name)
+    data = p["data"]
+    d, nclass = data.feat_full.shape[1], data.nclass
+    n_syn = int(data.feat_train.shape[0] * p["rate"])
+    H.seed_everything(3)
+    y_syn, each = H.msgc_labels(data.labels_train.numpy(), n_syn, nclass)
+    params = H.init_edge_mlp_params(d)
+    rows, cols, batch = H.msgc_edges(y_syn, nclass, B)
+    lay = BatchLayout(y_syn, nclass, B)
+    sh = EngineShapes(data.bench_n, d, nclass, lay.n_big, 1, p["hidden"], 4, 256, 10, 5)
+    cls_ptr = np.concatenate([[0], np.cumsum([len(q) for q in p["pools"]])])
+    inner = 3
+    eng = GCondEngine(sh, data.bench_feat, p["csr"], cls_ptr, np.concatenate(p["pools"]), lay.labels_big, lay.ranges, lr_feat=1e-4,
+                      lr_adj=1e-4, lr_model=0.01, inner_loop=inner, seed=1, device=DEV)
+    sel = H.random_init_indices(data.idx_train.numpy(), data.labels_train.numpy(), {c: int(k) for c, k in enumerate(each)})
+    x0 = data.bench_feat[sel].clone()
+    loop = MSGCLoop(eng, params, rows, cols, batch, lay, x0, 1e-4, 1e-4)
+    model = H.init_sgc_params(d, p["hidden"], nclass, 1)
+    eng.set_model(model)
+    loop.step(10)                                               # a feature epoch: every gradient is formed
+    batches = bench.blocks_to_batches(eng.get_blocks())         # the block set this iteration ran on
+    st = M.MSGCState(x0, params, torch.from_numpy(y_syn), torch.from_numpy(each), nclass,
+                     *(torch.from_numpy(a) for a in (rows, cols, batch)), B, 1e-4, 1e-4, 0.01, model)
+    loss, g_x, g_p, adj_in = st.outer_iteration(10, batches, data.bench_feat, data.bench_labels.long(), inner)
+    got = float(eng.buffer("loss")[0])
+    assert abs(got - float(loss)) <= 1e-4 * abs(float(loss)), (got, float(loss))
+    assert float((loop.gen.dX.cpu() - g_x).abs().max()) <= 1e-3 * float(g_x.abs().max())
+    for i, (a, b) in enumerate(zip((v.cpu() for v in loop.gen.views(loop.gen.grad)), g_p)):
+        if i in (1, 5):
+            continue
+        assert float((a - b.reshape(a.shape)).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-12, (i, float((a - b.reshape(a.shape)).abs().max()), float(b.abs().max()))
+    # lr 1e-4 Adam step on X~: entries whose gradient is above the fp32 noise floor move identically
+    big = g_x.abs() > 1e-3 * g_x.abs().max()
+    assert float((loop.x.cpu() - st.feat_syn.detach())[big].abs().max()) <= 2e-6
+    np.testing.assert_allclose(loop.inner_structure().cpu().numpy(), adj_in.numpy(), atol=1e-4)
