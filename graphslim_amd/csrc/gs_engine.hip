@@ -129,7 +129,7 @@ struct gs_gcond {
   // block structure (gs_gcond_set_block_structure): the synthetic graph is `blk_B` disconnected blocks of `blk_n` rows each
   // (MSGC's batch of structures); blk_pos[b][i] = row of node i of block b.  The n'^3 products (A^ A^, dQ A^^T + A^^T dQ) then
   // run as blk_B small products on gathered blocks.  Caller-owned scratch: 3 blk_B blk_n^2 floats.
-  const int* blk_pos; int blk_B, blk_n; float *blk_A, *blk_X, *blk_Y;
+  const int* blk_pos; int blk_B, blk_n; float *blk_A, *blk_X, *blk_Y, *blk_F1, *blk_F2;
 };
 
 static void derive(gs_gcond* e, const gs_gcond_config& c) {
@@ -394,7 +394,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->probing = false; e->probe_n = 0;
   e->operand_mode = 0;
   e->S_full = nullptr; e->ldS = 0; e->rs_full = nullptr;
-  e->blk_pos = nullptr; e->blk_B = e->blk_n = 0; e->blk_A = e->blk_X = e->blk_Y = nullptr;
+  e->blk_pos = nullptr; e->blk_B = e->blk_n = 0; e->blk_A = e->blk_X = e->blk_Y = e->blk_F1 = e->blk_F2 = nullptr;
   for (int i = 0; i < 2 * 256; ++i) e->probe_ev[i] = nullptr;
   // the real-side branch is the longer of the two concurrent branches (kernel trace, r01): its stream gets the higher
   // priority so that its latency-bound kernels are not queued behind the PGE forward's big GEMM
@@ -1076,6 +1076,37 @@ static int block_dadj(gs_gcond* e, const float* A, const float* dQ, float* dAn, 
   return block_scatter(e, e->blk_Y, dAn, s);
 }
 
+// Y[pos[b][i]][k] = Yb[b][i][k] (times [mask > 0] when a mask is given: the ReLU derivative, like gs_gemm_desc.mask)
+__global__ __launch_bounds__(256) void gs_block_scatter_rows_kernel(const float* __restrict__ Yb, const int* __restrict__ pos, long rows,
+                                                                    int F, float* __restrict__ Y, long ldy,
+                                                                    const float* __restrict__ mask, long ldm) {
+  const int lane = threadIdx.x & 63;
+  const long r = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= rows) return;
+  const long p = pos[r];
+  for (int k = lane; k < F; k += 64) {
+    float v = Yb[r * F + k];
+    if (mask && !(mask[p * ldm + k] > 0.f)) v = 0.f;
+    Y[p * ldy + k] = v;
+  }
+}
+
+// Y = Qm X (or Qm^T X) for a block-structured Qm whose gathered blocks [B][n_b][n_b] are in `Qb`: rows of X gathered per block,
+// B small products, rows scattered back.  X, Y: [n][F] with row stride F.
+static int block_apply(gs_gcond* e, const float* Qb, bool transpose, const float* X, int F, float* Y, const float* mask, long ldm,
+                       gs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = e->blk_n, B = e->blk_B;
+  GS_TRY(gs_gather_rows_f32(X, F, e->blk_pos, e->n, F, e->blk_F1, F, stream));
+  gs_gemm_desc g = transpose ? mk(Qb, 1, nb, e->blk_F1, F, 1, e->blk_F2, F, nb, F, nb) : mk(Qb, nb, 1, e->blk_F1, F, 1, e->blk_F2, F, nb, F, nb);
+  g.nb1 = B; g.sAb1 = (long)nb * nb; g.sBb1 = g.sCb1 = (long)nb * F;
+  GS_TRY(gs_gemm_f32(&g, stream));
+  hipLaunchKernelGGL(gs_block_scatter_rows_kernel, dim3(gs_cdiv((long)e->n, 4)), dim3(256), 0, s, e->blk_F2, e->blk_pos, (long)e->n, F, Y,
+                     (long)F, mask, ldm);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 extern "C" int gs_gcond_forward_cached(gs_gcond* e) { return e && e->reuse_fwd && e->fwd_cached ? 1 : 0; }
 
 extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_t stream) {
@@ -1211,8 +1242,12 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     hipLaunchKernelGGL(gs_rowsum_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Q, n, n, e->rsq);
   }
   {  // S = Q Hin ; Z = S Wl ; P, G
-    gs_gemm_desc g = mk(e->Q, n, 1, Hin, F, 1, e->Ss, F, n, F, n);
-    GS_TRY(gs_gemm_f32(&g, stream));
+    if (e->blk_pos) {
+      GS_TRY(block_apply(e, e->blk_X, false, Hin, F, e->Ss, nullptr, 0, stream));      // blk_X holds the blocks of Q (block_square)
+    } else {
+      gs_gemm_desc g = mk(e->Q, n, 1, Hin, F, 1, e->Ss, F, n, F, n);
+      GS_TRY(gs_gemm_f32(&g, stream));
+    }
     gs_gemm_desc z = mk(e->Ss, F, 1, Wl, C, 1, e->Zs, C, n, C, F);
     GS_TRY(gs_gemm_f32(&z, stream));
     hipLaunchKernelGGL(gs_syn_softmax_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Zs, e->rsq, bl, e->io.labels_syn,
@@ -1311,14 +1346,24 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     gs_gemm_desc ab1[2];
     ab1[0] = mk(e->Q, 1, n, e->dSs, d, 1, e->d_feat, d, n, d, n);   // dX = Q^T dS
     ab1[1] = mk(e->dSs, d, 1, X, 1, d, e->dQ, n, n, n, d);          // dQ = dS X^T
-    GS_TRY(gs_gemm_group_f32(ab1, 2, stream));
+    if (e->blk_pos) {
+      GS_TRY(block_apply(e, e->blk_X, true, e->dSs, d, e->d_feat, nullptr, 0, stream));
+      GS_TRY(gs_gemm_f32(&ab1[1], stream));
+    } else {
+      GS_TRY(gs_gemm_group_f32(ab1, 2, stream));
+    }
   } else {
     gs_gemm_desc ab2[2];
     ab2[0] = mk(e->Q, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n);     // (Q^T dS) * mask
     ab2[0].mask = e->H1s; ab2[0].ldmask = h;
     ab2[1] = mk(e->dSs, h, 1, e->H1s, 1, h, e->dQ, n, n, n, h);     // dQ += dS H1^T
     ab2[1].beta = 1.f;
-    GS_TRY(gs_gemm_group_f32(ab2, 2, stream));
+    if (e->blk_pos) {
+      GS_TRY(block_apply(e, e->blk_X, true, e->dSs, h, e->dH1m, e->H1s, h, stream));
+      GS_TRY(gs_gemm_f32(&ab2[1], stream));
+    } else {
+      GS_TRY(gs_gemm_group_f32(ab2, 2, stream));
+    }
     gs_gemm_desc c = mk(e->dH1m, h, 1, th + e->oW1, 1, h, e->d_feat, d, n, d, h);   // dX += dH1m W1^T
     c.beta = 1.f;
     GS_TRY(gs_gemm_f32(&c, stream));
@@ -1576,8 +1621,12 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
     hipLaunchKernelGGL(gs_rowsum_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Qin, n, n, e->rsq_in);
     GS_LAUNCH_CHECK();
     if (e->T == 1) {   // S = Q X does not depend on theta: once per outer iteration
-      gs_gemm_desc sg = mk(e->Qin, n, 1, X, d, 1, e->S_in, d, n, d, n);
-      GS_TRY(gs_gemm_f32(&sg, stream));
+      if (e->blk_pos) {
+        GS_TRY(block_apply(e, e->blk_X, false, X, d, e->S_in, nullptr, 0, stream));
+      } else {
+        gs_gemm_desc sg = mk(e->Qin, n, 1, X, d, 1, e->S_in, d, n, d, n);
+        GS_TRY(gs_gemm_f32(&sg, stream));
+      }
     }
   }
   for (int it = 0; it < e->cfg.inner_loop; ++it) {
@@ -1585,8 +1634,12 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
       gs_gemm_desc a = mk(X, d, 1, th + e->oW1, h, 1, e->H1s, h, n, h, d);
       a.bias = th + e->ob1; a.relu = 1;
       GS_TRY(gs_gemm_f32(&a, stream));
-      gs_gemm_desc b = mk(e->Qin, n, 1, e->H1s, h, 1, e->S_in, h, n, h, n);
-      GS_TRY(gs_gemm_f32(&b, stream));
+      if (e->blk_pos) {
+        GS_TRY(block_apply(e, e->blk_X, false, e->H1s, h, e->S_in, nullptr, 0, stream));
+      } else {
+        gs_gemm_desc b = mk(e->Qin, n, 1, e->H1s, h, 1, e->S_in, h, n, h, n);
+        GS_TRY(gs_gemm_f32(&b, stream));
+      }
     }
     gs_gemm_desc z = mk(e->S_in, F, 1, th + e->oWl, C, 1, e->Zs, C, n, C, F);
     GS_TRY(gs_gemm_f32(&z, stream));
@@ -1600,9 +1653,13 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
     g3[2] = mk(e->Gs, C, 1, th + e->oWl, 1, C, e->dSs, h, n, h, C);                      // dS = G W2^T   (T = 2)
     GS_TRY(gs_gemm_group_f32(g3, e->T == 2 ? 3 : 2, stream));
     if (e->T == 2) {
-      gs_gemm_desc dh = mk(e->Qin, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n);             // (Q^T dS) * mask
-      dh.mask = e->H1s; dh.ldmask = h;
-      GS_TRY(gs_gemm_f32(&dh, stream));
+      if (e->blk_pos) {
+        GS_TRY(block_apply(e, e->blk_X, true, e->dSs, h, e->dH1m, e->H1s, h, stream));  // (Q^T dS) * mask
+      } else {
+        gs_gemm_desc dh = mk(e->Qin, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n);           // (Q^T dS) * mask
+        dh.mask = e->H1s; dh.ldmask = h;
+        GS_TRY(gs_gemm_f32(&dh, stream));
+      }
       gs_gemm_desc g2[2];
       g2[0] = mk(X, 1, d, e->dH1m, h, 1, e->g_model + e->oW1, h, d, h, n);               // gW1 = X^T dHp
       g2[1] = mk(e->ones, 0, 1, e->dH1m, h, 1, e->g_model + e->ob1, h, 1, h, n);         // gb1 = 1^T dHp
@@ -1650,7 +1707,9 @@ extern "C" int gs_gcond_set_identity_structure(gs_gcond* e, int on, gs_stream_t 
 // block-diagonal graph whose rows are grouped by class): pos [B][n_block] (device, int32) = row of node i of block b, a bijection
 // onto [0, n_syn).  The three n_syn^3 products of an iteration (A^ A^ for train_class and for the inner steps, dQ A^^T + A^^T dQ)
 // then run per block: 2 B n_block^3 FLOP each instead of 2 (B n_block)^3 — 767 -> 3 GFLOP at ogbn-arxiv r = 0.5 %, B = 16.
-// Values: the same sums with the structural zeros left out (other summation order).  scratch: 3 B n_block^2 floats, caller-owned;
+// So do the products of A^ A^ with [n_syn x F] matrices that do not go class by class (rows gathered per block).
+// Values: the same sums with the structural zeros left out (other summation order).  scratch: 3 B n_block^2 + 2 n_syn max(d, hidden)
+// floats, caller-owned;
 // pos = NULL returns to dense products.  SGC only.
 extern "C" int gs_gcond_set_block_structure(gs_gcond* e, const int* pos, int B, int n_block, float* scratch) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
@@ -1659,7 +1718,8 @@ extern "C" int gs_gcond_set_block_structure(gs_gcond* e, const int* pos, int B, 
   if (B < 1 || n_block < 1 || (long)B * n_block != e->n || !scratch) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_block_structure: bad argument");
   e->blk_pos = pos; e->blk_B = B; e->blk_n = n_block;
   const size_t bs = (size_t)B * n_block * n_block;
-  e->blk_A = scratch; e->blk_X = scratch + bs; e->blk_Y = scratch + 2 * bs;
+  const size_t fs = (size_t)e->n * (size_t)(e->d > e->h ? e->d : e->h);
+  e->blk_A = scratch; e->blk_X = scratch + bs; e->blk_Y = scratch + 2 * bs; e->blk_F1 = scratch + 3 * bs; e->blk_F2 = e->blk_F1 + fs;
   return GS_OK;
 }
 

@@ -424,7 +424,7 @@ class GCondEngine:
             return
         pos = torch.as_tensor(np.ascontiguousarray(pos), dtype=torch.int32).to(self.dev)
         B, nb = pos.shape
-        scratch = torch.empty(3 * B * nb * nb, dtype=torch.float32, device=self.dev)
+        scratch = torch.empty(3 * B * nb * nb + 2 * B * nb * max(self.shapes.d, self.shapes.hidden), dtype=torch.float32, device=self.dev)
         self._blk = (pos, scratch)
         check(self.L.gs_gcond_set_block_structure(self.h, ptr(pos), B, nb, ptr(scratch)))
 

@@ -347,8 +347,9 @@ int gs_gcond_set_identity_structure(gs_gcond* e, int on, gs_stream_t stream);
 int gs_gcond_set_structure(gs_gcond* e, const float* adj, int inference, gs_stream_t stream);
 /* The synthetic graph is B disconnected blocks of n_block rows (MSGC's batch of structures as one block-diagonal graph): pos
  * [B][n_block] int32 on the device = row of node i of block b (a bijection onto [0, n_syn)).  The n_syn^3 products of an iteration
- * (A^ A^ twice, dQ A^^T + A^^T dQ) then run per block — 2 B n_block^3 instead of 2 (B n_block)^3 FLOP each.  scratch: 3 B n_block^2
- * floats, caller-owned and kept alive; pos = NULL returns to dense products.  GS_ERR_UNSUPPORTED for the GCN model. */
+ * (A^ A^ twice, dQ A^^T + A^^T dQ) then run per block — 2 B n_block^3 instead of 2 (B n_block)^3 FLOP each — and so do the products of
+ * A^ A^ with [n_syn x F] matrices outside the class-by-class terms.  scratch: 3 B n_block^2 + 2 n_syn max(d, hidden) floats,
+ * caller-owned and kept alive; pos = NULL returns to dense products.  GS_ERR_UNSUPPORTED for the GCN model. */
 int gs_gcond_set_block_structure(gs_gcond* e, const int* pos, int B, int n_block, float* scratch);
 /* Synchronises `stream`; returns the accumulated loss and the outer-step count since the last reset
  * (host pointers) and resets both.  This is the loss_avg bookkeeping of gcond.py:52,74. */
