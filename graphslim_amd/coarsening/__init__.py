@@ -1,1 +1,2 @@
 from .averaging import Average  # noqa: F401
+from .clustering import Cluster  # noqa: F401

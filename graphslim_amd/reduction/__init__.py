@@ -12,6 +12,9 @@ def create_reducer(name, setting, data, args, **kwargs):
     if key == "averaging":
         from ..coarsening.averaging import Average
         return Average(setting, data, args, **kwargs)
+    if key == "clustering":
+        from ..coarsening.clustering import Cluster
+        return Cluster(setting, data, args, **kwargs)
     if key in ("gcond", "doscond", "gcondx", "doscondx", "msgc"):
         from .. import condensation as cd
         cls = {"gcond": cd.GCond, "doscond": cd.DosCond, "gcondx": cd.GCondX, "doscondx": cd.DosCondX, "msgc": cd.MSGC}[key]

@@ -76,7 +76,24 @@ ts.__getattr__ = lambda name: MagicMock(name="torch_sparse." + name)  # non-arit
 ts.__path__ = []
 sys.modules["torch_sparse"] = ts
 
-ROOTS = {"torch_geometric", "torch_scatter", "deeprobust", "networkit", "ogb", "pygsp", "dgl", "gdown",
+
+
+def _scatter_mean(src, index, dim=0):
+    """Functional stand-in for torch_scatter.scatter_mean(src, index, dim=0) (absent wheel): out[k] = mean of the rows with index k."""
+    assert dim == 0
+    k = int(index.max()) + 1
+    out = torch.zeros(k, *src.shape[1:], dtype=src.dtype).index_add_(0, index, src)
+    cnt = torch.zeros(k, dtype=src.dtype).index_add_(0, index, torch.ones(len(index), dtype=src.dtype)).clamp(min=1)
+    return out / cnt.view(-1, *([1] * (src.dim() - 1)))
+
+
+tsc = types.ModuleType("torch_scatter")
+tsc.scatter_mean = _scatter_mean
+tsc.__getattr__ = lambda name: MagicMock(name="torch_scatter." + name)
+tsc.__path__ = []
+sys.modules["torch_scatter"] = tsc
+
+ROOTS = {"torch_geometric", "deeprobust", "networkit", "ogb", "pygsp", "dgl", "gdown",
          "wandb", "pyfpgrowth", "skfuzzy"}
 
 
@@ -920,8 +937,33 @@ def g18():
     save("g18_msgc", **out)
 
 
+# ---------------------------------------------------------------- G19 averaging / clustering initialisers
+
+
+def g19():
+    """coarsening/averaging.py:33-71 and coarsening/clustering.py:36-76 (BisectingKMeans(random_state=0) per class + cluster means)
+    run by the reference on a small train set, stand-alone (prepare_select labels) and with preset class-major labels (the way
+    MSGC calls them through GCondBase.init)."""
+    from graphslim.coarsening.averaging import Average
+    from graphslim.coarsening.clustering import Cluster
+    n, nclass, d = 150, 3, 6
+    a, x, y = make_graph(n, nclass, d, 5, seed=81)
+    out = {"x": x, "y": y}
+    for tag, preset in (("alone", False), ("preset", True)):
+        for name, cls in (("averaging", Average), ("clustering", Cluster)):
+            data = FakeData(a, x, y, nclass, [12, 16, 20], 20, 30, seed=7)
+            if preset:
+                data.labels_syn = torch.from_numpy(np.repeat(np.arange(nclass), [3, 4, 5]))
+            args = args_obj(reduction_rate=0.25, save_path=None, method=name)
+            red = cls("trans", data, args).reduce(data, verbose=False, save=False)
+            out[f"{tag}_{name}_feat"] = np_(red.feat_syn).copy()
+            out[f"{tag}_{name}_labels"] = np.asarray(red.labels_syn)
+            out["idx_train"] = np_(data.idx_train)
+    save("g19_inits", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16",
-                             "g17", "g18"]
+                             "g17", "g18", "g19"]
     for w in which:
         globals()[w]()

@@ -326,3 +326,23 @@ def test_full_size_iteration_against_the_oracle(name, B):
     big = g_x.abs() > 1e-3 * g_x.abs().max()
     assert float((loop.x.cpu() - st.feat_syn.detach())[big].abs().max()) <= 2e-6
     np.testing.assert_allclose(loop.inner_structure().cpu().numpy(), adj_in.numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize("preset", [False, True])
+def test_g19_averaging_and_clustering_initialisers(golden_dir, preset):
+    """--init averaging / clustering (coarsening/averaging.py:33-71, clustering.py:36-76) against the reference's own output
+    (golden G19): class means / BisectingKMeans(random_state = 0) cluster means, stand-alone and with MSGC-style preset labels."""
+    import types
+    from graphslim_amd.coarsening import Average, Cluster
+    g = load_golden(golden_dir, "g19_inits")
+    x, y, idx = g["x"], g["y"], g["idx_train"]
+    tag = "preset" if preset else "alone"
+    for name, cls in (("averaging", Average), ("clustering", Cluster)):
+        data = types.SimpleNamespace(feat_train=torch.from_numpy(x[idx]), labels_train=torch.from_numpy(y[idx]), nclass=3)
+        if preset:
+            data.labels_syn = torch.from_numpy(np.repeat(np.arange(3), [3, 4, 5]))
+        args = types.SimpleNamespace(device=DEV, reduction_rate=0.25, method=name)
+        red = cls("trans", data, args).reduce(data, verbose=False, save=False)
+        np.testing.assert_array_equal(np.asarray(red.labels_syn), g[f"{tag}_{name}_labels"])
+        np.testing.assert_allclose(red.feat_syn.numpy(), g[f"{tag}_{name}_feat"], atol=2e-6, err_msg=name)
+        assert torch.equal(red.adj_syn, torch.eye(len(red.labels_syn)))
