@@ -74,6 +74,7 @@ ts.SparseTensor = SparseTensor
 ts.matmul = _matmul
 ts.__getattr__ = lambda name: MagicMock(name="torch_sparse." + name)  # non-arithmetic names
 ts.__path__ = []
+ts.tensor = types.SimpleNamespace(SparseTensor=SparseTensor)      # models/ignr.py:14 tests isinstance(mx, torch_sparse.tensor.SparseTensor)
 sys.modules["torch_sparse"] = ts
 
 
@@ -962,8 +963,66 @@ def g19():
     save("g19_inits", **out)
 
 
+# ---------------------------------------------------------------- G20 SGDD ---------------------
+
+
+def g20():
+    """SGDD.__init__ + reduce of the reference (sgdd.py:17-105, models/ignr.py:95-213): the IGNR structure generator (two coupled
+    towers, training-mode BatchNorm for the matched structure, running statistics for the inner steps' structure) and the
+    optimal-transport regulariser.  12 epochs x 2 outer iterations: 10 structure epochs and 2 feature epochs; opt_scale at the
+    shipped citeseer / pubmed value (T = 1) and 100x that (T = 2) so that the regulariser's gradient is visible in the replay."""
+    from graphslim.condensation.sgdd import SGDD
+    out = {}
+    for tag, T, dataset, hidden, scale in (("t1", 1, "cora", 16, 1e-9), ("t2", 2, "ogbn-arxiv", 12, 1e-7)):
+        tmp = tempfile.mkdtemp(prefix="golden_")
+        try:
+            n, nclass, d = 90, 3, 8
+            a, x, y = make_graph(n, nclass, d, 5, seed=91)
+            data = FakeData(a, x, y, nclass, [8, 10, 14], 20, 30, seed=8, sizes=(4, 3))
+            epochs, outer, inner, mx = 12, 2, 2, 40
+            args = args_obj(ntrans=T, hidden=hidden, reduction_rate=0.5, dataset=dataset, epochs=epochs, outer_loop=outer,
+                            inner_loop=inner, checkpoints=[], save_path=tmp, logger=CapLogger(), lr_feat=0.01, lr_adj=0.01,
+                            seed=1, method="sgdd", mx_size=mx, opt_scale=scale, ep_ratio=0.5, sinkhorn_iter=10)
+            RU.seed_everything(args.seed)
+            agent = SGDD("trans", data, args)
+            losses, regs = [], []
+            orig, orig_reg = agent.train_class, agent.pge.opt_loss
+
+            def spy(*a_, **k_):
+                l = orig(*a_, **k_)
+                losses.append(float(l))
+                return l
+
+            def spy_reg(adj):
+                r = orig_reg(adj)
+                regs.append(float(r))
+                return r
+
+            agent.train_class, agent.pge.opt_loss = spy, spy_reg
+            agent.reduce(data, verbose=False)
+            with torch.no_grad():
+                adj_inf = agent.pge.inference(agent.feat_syn.detach())
+            coo = a.tocoo()
+            out.update({f"{tag}_a_row": coo.row, f"{tag}_a_col": coo.col, f"{tag}_x": x, f"{tag}_y": y,
+                        f"{tag}_idx_train": np_(data.idx_train),
+                        f"{tag}_meta": np.array([n, nclass, d, hidden, T, inner, epochs, outer, mx]), f"{tag}_opt_scale": np.array(scale),
+                        f"{tag}_losses": np.array(losses), f"{tag}_regs": np.array(regs), f"{tag}_feat_syn": np_(agent.feat_syn).copy(),
+                        f"{tag}_adj": np_(adj_inf).copy(), f"{tag}_labels_syn": np.asarray(data.labels_syn),
+                        f"{tag}_Lx_inv": np_(agent.pge.Lx_inv).copy()})
+            names = [k for k, _ in agent.pge.named_parameters()]
+            out[f"{tag}_param_names"] = np.array(names)
+            for i, (k, p) in enumerate(agent.pge.named_parameters()):
+                out[f"{tag}_p{i}"] = np_(p).copy()
+            bns = [m for m in agent.pge.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+            for i, m in enumerate(bns):
+                out[f"{tag}_rm{i}"], out[f"{tag}_rv{i}"] = np_(m.running_mean).copy(), np_(m.running_var).copy()
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    save("g20_sgdd", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16",
-                             "g17", "g18", "g19"]
+                             "g17", "g18", "g19", "g20"]
     for w in which:
         globals()[w]()

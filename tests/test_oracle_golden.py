@@ -391,3 +391,41 @@ def test_g18_msgc_replays_the_reference(golden_dir, tag):
         diff = np.abs(p.numpy() - g[f"{tag}_pge{i}"])
         tol = 1e-3 + 1e-3 * np.abs(g[f"{tag}_pge{i}"])
         assert (diff > tol).mean() <= 2e-4 and diff.max() <= 0.02, (i, (diff > tol).mean(), diff.max())
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_g20_sgdd_replays_the_reference(golden_dir, tag):
+    """G20: the reference's own SGDD.__init__ + reduce (sgdd.py:17-105, models/ignr.py:95-213; 12 epochs x 2 iterations = 10
+    structure epochs + 2 feature epochs): pins oracle/sgdd_oracle.py — the IGNR draw order, both BatchNorm modes with their
+    running statistics, the optimal-transport regulariser value of every iteration, matching losses, final X~ / parameters /
+    inference structure."""
+    from oracle import sgdd_oracle as S
+    g = load(golden_dir, "g20_sgdd")
+    n, nclass, d, hidden, t, inner, epochs, outer, mx = [int(v) for v in g[f"{tag}_meta"]]
+    a = sp.coo_matrix((np.ones(len(g[f"{tag}_a_row"])), (g[f"{tag}_a_row"], g[f"{tag}_a_col"])), shape=(n, n)).tocsr()
+    csr = O.normalize_adj_sparse(a)
+    idx_train, y = g[f"{tag}_idx_train"], g[f"{tag}_y"]
+    labels_train = y[idx_train]
+
+    def batch_fn(c, call):
+        rng = np.random.default_rng(100000 + call)
+        batch = rng.permutation(idx_train[labels_train == c])[:256]
+        return O.sample_blocks(*csr, batch, [4, 3], rng)
+
+    out = S.reduce_sgdd(a, g[f"{tag}_x"], y, idx_train, nclass, reduction_rate=0.5, hidden=hidden, ntrans=t, epochs=epochs,
+                        outer_loop=outer, inner_loop=inner, mx_size=mx, opt_scale=float(g[f"{tag}_opt_scale"]), ep_ratio=0.5,
+                        lr_feat=0.01, lr_adj=0.01, lr_model=0.01, seed=1, batch_fn=batch_fn)
+    np.testing.assert_array_equal(out["labels_syn"], g[f"{tag}_labels_syn"])
+    np.testing.assert_allclose(out["state"].Lx_inv.numpy(), g[f"{tag}_Lx_inv"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(np.array(out["losses"]), g[f"{tag}_losses"], rtol=2e-3)
+    np.testing.assert_allclose(np.array(out["regs"]), g[f"{tag}_regs"], rtol=2e-2)
+    # four Adam steps of lr 0.01 on X~: an entry whose gradient sits at the rounding level may take a step of the other sign
+    dx = np.abs(out["feat_syn"].numpy() - g[f"{tag}_feat_syn"])
+    assert (dx > 5e-4 + 1e-3 * np.abs(g[f"{tag}_feat_syn"])).mean() <= 0.02 and dx.max() <= 0.02, ((dx > 5e-4).mean(), dx.max())
+    np.testing.assert_allclose(out["adj"].numpy(), g[f"{tag}_adj"], atol=5e-3)
+    for i, key in enumerate(["c0", "c1", "x0", "x1"]):
+        # the running mean contains the layer's bias, whose exact gradient is zero in front of a batch-statistics BatchNorm: Adam turns
+        # its rounding-level gradient into +-lr steps on both sides (24 iterations x lr 0.01), independently
+        drm = np.abs(out["running"][key][0].numpy() - g[f"{tag}_rm{i}"])
+        assert (drm > 3e-2).mean() <= 0.03 and drm.max() <= 0.1, (key, (drm > 3e-2).mean(), drm.max())
+        np.testing.assert_allclose(out["running"][key][1].numpy(), g[f"{tag}_rv{i}"], rtol=5e-2, atol=5e-3)
