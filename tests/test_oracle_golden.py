@@ -428,4 +428,6 @@ def test_g20_sgdd_replays_the_reference(golden_dir, tag):
         # its rounding-level gradient into +-lr steps on both sides (24 iterations x lr 0.01), independently
         drm = np.abs(out["running"][key][0].numpy() - g[f"{tag}_rm{i}"])
         assert (drm > 3e-2).mean() <= 0.03 and drm.max() <= 0.1, (key, (drm > 3e-2).mean(), drm.max())
-        np.testing.assert_allclose(out["running"][key][1].numpy(), g[f"{tag}_rv{i}"], rtol=5e-2, atol=5e-3)
+        rv = g[f"{tag}_rv{i}"]
+        drv = np.abs(out["running"][key][1].numpy() - rv) / (np.abs(rv) + 0.05)
+        assert (drv > 3e-2).mean() <= 0.03 and drv.max() <= 0.2, (key, (drv > 3e-2).mean(), drv.max())
