@@ -227,6 +227,93 @@ __global__ __launch_bounds__(256) void sg_segment_sum_kernel(const float* __rest
   if (w == 0 && k < F) out[(long)i * ldo + k] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
 }
 
+
+// ---- IGNR pieces (SGDD, graphslim/models/ignr.py:151-177) ---------------------------------------------------------------
+// z = a * b  (ignr.py:167 `x = x * c`)
+__global__ __launch_bounds__(256) void sg_mul_kernel(const float* __restrict__ a, const float* __restrict__ b, long total,
+                                                     float* __restrict__ z) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) z[i] = a[i] * b[i];
+}
+
+// backward of z = a * b: da = dz * b;  db = (acc ? db : 0) + dz * a.   da may alias dz.
+__global__ __launch_bounds__(256) void sg_mul_bwd_kernel(const float* dz, const float* __restrict__ a, const float* __restrict__ b,
+                                                         long total, float* da, float* __restrict__ db, int acc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float g = dz[i];
+  const float vb = g * a[i];
+  db[i] = acc ? db[i] + vb : vb;
+  da[i] = g * b[i];
+}
+
+// e3[e] = wa * (A[e] . ua + ba[0]) + wb * (B[e] . ub + bb[0])   (ignr.py:161-170: the two Linear(nfeat, 1) heads mixed by ep_ratio)
+__global__ __launch_bounds__(256) void sg_mix_heads_kernel(const float* __restrict__ A, const float* __restrict__ ua,
+                                                           const float* __restrict__ ba, float wa, const float* __restrict__ B,
+                                                           const float* __restrict__ ub, const float* __restrict__ bb, float wb,
+                                                           long E, int F, float* __restrict__ e3) {
+  const int lane = threadIdx.x & 63;
+  const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (e >= E) return;
+  float sa = 0.f, sb = 0.f;
+  for (int k = lane; k < F; k += 64) { sa = fmaf(A[e * F + k], ua[k], sa); sb = fmaf(B[e * F + k], ub[k], sb); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+  if (lane == 0) e3[e] = wa * (sa + ba[0]) + wb * (sb + bb[0]);
+}
+
+// dA[e][k] = wa * de3[e] * ua[k];  dB[e][k] = wb * de3[e] * ub[k];  sa[e] = wa * de3[e];  sb[e] = wb * de3[e] (the heads' own
+// upstream gradients: d ua = A^T sa, d ba = sum sa, ...)
+__global__ __launch_bounds__(256) void sg_mix_heads_bwd_kernel(const float* __restrict__ de3, const float* __restrict__ ua, float wa,
+                                                               const float* __restrict__ ub, float wb, long E, int F,
+                                                               float* __restrict__ dA, float* __restrict__ dB, float* __restrict__ sa,
+                                                               float* __restrict__ sb) {
+  const int lane = threadIdx.x & 63;
+  const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (e >= E) return;
+  const float g = de3[e];
+  if (lane == 0) { sa[e] = wa * g; sb[e] = wb * g; }
+  for (int k = lane; k < F; k += 64) { dA[e * F + k] = wa * g * ua[k]; dB[e * F + k] = wb * g * ub[k]; }
+}
+
+// adj = sigmoid((e3 + e3^T) / 2) with a zero diagonal (ignr.py:174-177)
+__global__ void sg_sym_sigmoid_kernel(const float* __restrict__ e3, int n, float* __restrict__ adj) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * n) return;
+  const long i = idx / n, j = idx % n;
+  adj[idx] = i == j ? 0.f : 1.f / (1.f + expf(-(e3[idx] + e3[j * n + i]) / 2.f));
+}
+
+// its backward: de3[i][j] = (dA[i][j] + dA[j][i]) / 2 * a (1 - a) off the diagonal (a is symmetric), 0 on it
+__global__ void sg_sym_sigmoid_bwd_kernel(const float* __restrict__ dA, const float* __restrict__ adj, int n, float* __restrict__ de3) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * n) return;
+  const long i = idx / n, j = idx % n;
+  const float a = adj[idx];
+  de3[idx] = i == j ? 0.f : (dA[idx] + dA[j * n + i]) / 2.f * (a * (1.f - a));
+}
+
+// nn.BatchNorm1d bookkeeping: running <- (1 - momentum) running + momentum (batch mean, UNBIASED batch variance)
+__global__ void sg_bn_running_kernel(const float* __restrict__ mu, const float* __restrict__ istd, long E, float eps, float momentum,
+                                     int F, float* __restrict__ rm, float* __restrict__ rv) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= F) return;
+  const float is = istd[k];
+  float var = 1.f / (is * is) - eps;               // the biased batch variance the forward normalised with
+  if (var < 0.f) var = 0.f;
+  if (E > 1) var = var * ((float)E / (float)(E - 1));
+  rm[k] = (1.f - momentum) * rm[k] + momentum * mu[k];
+  rv[k] = (1.f - momentum) * rv[k] + momentum * var;
+}
+
+__global__ void sg_bn_eval_consts_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float eps, int F,
+                                         float* __restrict__ mu, float* __restrict__ istd) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= F) return;
+  mu[k] = rm[k];
+  istd[k] = 1.f / sqrtf(rv[k] + eps);
+}
+
 }  // namespace
 
 extern "C" int gs_edge_pair_sum_f32(const float* U, const float* V, long ld, const float* bias, const int* rows, const int* cols,
@@ -323,6 +410,78 @@ extern "C" int gs_colsum_tall_f32(const float* X, long ld, long E, int F, float*
   hipLaunchKernelGGL((sg_colstats_kernel<0>), dim3(gs_cdiv(F, 64), chunks), dim3(256), 0, s, X, ld, (const float*)nullptr, 0L,
                      (const float*)nullptr, 0L, (const float*)nullptr, (const float*)nullptr, E, F, chunks, part);
   hipLaunchKernelGGL(sg_sum_finish_kernel, dim3(gs_cdiv(F, 64)), dim3(256), 0, s, part, chunks, F, out);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_mul_f32(const float* a, const float* b, long total, float* z, gs_stream_t stream) {
+  if (total <= 0) return GS_OK;
+  if (!a || !b || !z) GS_FAIL(GS_ERR_ARG, "gs_mul_f32: null argument");
+  hipLaunchKernelGGL(sg_mul_kernel, dim3(gs_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a, b, total, z);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_mul_bwd_f32(const float* dz, const float* a, const float* b, long total, float* da, float* db, int accumulate_db,
+                              gs_stream_t stream) {
+  if (total <= 0) return GS_OK;
+  if (!dz || !a || !b || !da || !db) GS_FAIL(GS_ERR_ARG, "gs_mul_bwd_f32: null argument");
+  hipLaunchKernelGGL(sg_mul_bwd_kernel, dim3(gs_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dz, a, b, total, da, db,
+                     accumulate_db);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_mix_heads_f32(const float* A, const float* ua, const float* ba, float wa, const float* B, const float* ub,
+                                const float* bb, float wb, long E, int F, float* e3, gs_stream_t stream) {
+  if (E <= 0) return GS_OK;
+  if (!A || !ua || !ba || !B || !ub || !bb || !e3 || F <= 0) GS_FAIL(GS_ERR_ARG, "gs_mix_heads_f32: bad argument");
+  hipLaunchKernelGGL(sg_mix_heads_kernel, dim3(gs_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream, A, ua, ba, wa, B, ub, bb, wb, E, F, e3);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_mix_heads_bwd_f32(const float* de3, const float* ua, float wa, const float* ub, float wb, long E, int F, float* dA,
+                                    float* dB, float* sa, float* sb, gs_stream_t stream) {
+  if (E <= 0) return GS_OK;
+  if (!de3 || !ua || !ub || !dA || !dB || !sa || !sb || F <= 0) GS_FAIL(GS_ERR_ARG, "gs_mix_heads_bwd_f32: bad argument");
+  hipLaunchKernelGGL(sg_mix_heads_bwd_kernel, dim3(gs_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream, de3, ua, wa, ub, wb, E, F, dA, dB,
+                     sa, sb);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_sym_sigmoid_f32(const float* e3, int n, float* adj, gs_stream_t stream) {
+  if (!e3 || !adj || n <= 0) GS_FAIL(GS_ERR_ARG, "gs_sym_sigmoid_f32: bad argument");
+  hipLaunchKernelGGL(sg_sym_sigmoid_kernel, dim3(gs_cdiv((long)n * n, 256)), dim3(256), 0, (hipStream_t)stream, e3, n, adj);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_sym_sigmoid_bwd_f32(const float* dA, const float* adj, int n, float* de3, gs_stream_t stream) {
+  if (!dA || !adj || !de3 || n <= 0) GS_FAIL(GS_ERR_ARG, "gs_sym_sigmoid_bwd_f32: bad argument");
+  hipLaunchKernelGGL(sg_sym_sigmoid_bwd_kernel, dim3(gs_cdiv((long)n * n, 256)), dim3(256), 0, (hipStream_t)stream, dA, adj, n, de3);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_bn_running_update_f32(const float* mu, const float* istd, long E, int F, float eps, float momentum, float* running_mean,
+                                        float* running_var, gs_stream_t stream) {
+  if (!mu || !istd || !running_mean || !running_var || F <= 0 || E <= 0) GS_FAIL(GS_ERR_ARG, "gs_bn_running_update_f32: bad argument");
+  hipLaunchKernelGGL(sg_bn_running_kernel, dim3(gs_cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, mu, istd, E, eps, momentum, F,
+                     running_mean, running_var);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_bn_relu_eval_f32(const float* X, long ldx, long E, int F, const float* g, const float* be, float eps,
+                                   const float* running_mean, const float* running_var, float* Y, long ldy, float* mu, float* istd,
+                                   gs_stream_t stream) {
+  if (!X || !g || !be || !running_mean || !running_var || !Y || !mu || !istd || E <= 0 || F <= 0 || ldx < F || ldy < F)
+    GS_FAIL(GS_ERR_ARG, "gs_bn_relu_eval_f32: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sg_bn_eval_consts_kernel, dim3(gs_cdiv(F, 64)), dim3(64), 0, s, running_mean, running_var, eps, F, mu, istd);
+  hipLaunchKernelGGL(sg_bn_relu_apply_kernel, dim3(gs_cdiv(E, 4)), dim3(256), 0, s, X, ldx, E, F, mu, istd, g, be, Y, ldy);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

@@ -162,3 +162,165 @@ class EdgeStructureGenerator:
         """[B n', B n'] block-diagonal (class-grouped rows) -> [B, n', n'] in node order (index shuffling only)."""
         pos = torch.as_tensor(self.lay.pos, device=big.device)
         return big[pos[:, :, None], pos[:, None, :]].contiguous()
+
+
+# ==================================================================================================================================
+# IGNR graphon learner of SGDD (graphslim/models/ignr.py:95-213)
+# ==================================================================================================================================
+
+IGNR_ORDER = (["P"] + [f"c{l}_{k}" for l in range(2) for k in ("w", "b", "g", "be")] + ["c2_w", "c2_b"]
+              + [f"x{l}_{k}" for l in range(2) for k in ("w", "b", "g", "be")] + ["x2_w", "x2_b", "out_w", "out_b"])
+BN_MOMENTUM = 0.1
+
+
+def pair_grid(n):
+    """ignr.py:46-71 get_mgrid(n): coordinates of the ordered pair (i, j), i slow, in [-1, 1]^2 (float32 arithmetic as upstream)."""
+    g = np.stack(np.mgrid[:n, :n], axis=-1)[None, ...].astype(np.float32)
+    g[0, :, :, 0] = g[0, :, :, 0] / (n - 1)
+    g[0, :, :, 1] = g[0, :, :, 1] / (n - 1)
+    g -= 0.5
+    g *= 2.0
+    return torch.from_numpy(g).view(-1, 2).to(torch.float32)
+
+
+class IGNRGenerator:
+    """theta in nn.Module.parameters() order (IGNR_ORDER: the transport plan P, tower net0 = "c" on cat(x_i, x_j), tower net1 = "x" on
+    the pair grid, the unused `output` head) as one flat device tensor with gradient and Adam moments; running BatchNorm statistics
+    for the eval-mode (inference) pass.  forward / backward are chains of libgslim_hip.so calls."""
+
+    def __init__(self, params, d, n, ep_ratio, lr, device, nfeat=128):
+        self.L = _lib.lib()
+        self.dev = torch.device(device)
+        self.d, self.n, self.h, self.ep, self.lr = d, n, nfeat, float(ep_ratio), lr
+        self.E = E = n * n
+        h = nfeat
+        self.mx = params["P"].shape[0]
+        shp = {"P": (self.mx, n), "out_w": (1, h), "out_b": (1,), "c2_w": (1, h), "c2_b": (1,), "x2_w": (1, h), "x2_b": (1,),
+               "c0_w": (h, 2 * d), "x0_w": (h, 2), "c1_w": (h, h), "x1_w": (h, h)}
+        for t in "cx":
+            for l in range(2):
+                for k in ("b", "g", "be"):
+                    shp[f"{t}{l}_{k}"] = (h,)
+        self.shapes = [shp[k] for k in IGNR_ORDER]
+        self.theta = torch.cat([params[k].reshape(-1).float() for k in IGNR_ORDER]).to(self.dev).contiguous()
+        assert self.theta.numel() == sum(int(np.prod(s)) for s in self.shapes)
+        self.grad = torch.zeros_like(self.theta)
+        self.m, self.v, self.step_count = torch.zeros_like(self.theta), torch.zeros_like(self.theta), 0
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32).to(self.dev)
+        ii, jj = np.repeat(np.arange(n), n), np.tile(np.arange(n), n)
+        self.rows, self.cols = i32(ii), i32(jj)
+        self.seg_r, self.seg_c = tuple(i32(a) for a in _segments(ii, n)), tuple(i32(a) for a in _segments(jj, n))
+        self.grid = pair_grid(n).to(self.dev).contiguous()
+        self.U, self.V, self.dU, self.dV = f(n, h), f(n, h), f(n, h), f(n, h)
+        names = ["C0p", "C0", "X0p", "X0", "Z0", "C1p", "C1", "X1p", "X1", "Z1", "G1", "G2", "G3"]
+        for k in names:
+            setattr(self, k, f(E, h))
+        self.stat = {k: (f(h), f(h)) for k in ("c0", "c1", "x0", "x1")}           # (mu, istd) of the last pass
+        self.run = {k: (torch.zeros(h, device=self.dev), torch.ones(h, device=self.dev)) for k in ("c0", "c1", "x0", "x1")}
+        self.e3, self.de3, self.sx, self.sc = f(E), f(E), f(E), f(E)
+        self.adj = f(n, n)
+        self.dX = f(n, d)
+        self.scratch = torch.empty(self.L.gs_bn_scratch_bytes(h), dtype=torch.uint8, device=self.dev)
+
+    def views(self, flat=None):
+        flat = self.theta if flat is None else flat
+        out, o = {}, 0
+        for k, shp in zip(IGNR_ORDER, self.shapes):
+            cnt = int(np.prod(shp))
+            out[k] = flat[o:o + cnt].view(shp)
+            o += cnt
+        return out
+
+    def _bn(self, key, Xp, Y, p, train):
+        L, h, E = self.L, self.h, self.E
+        mu, istd = self.stat[key]
+        if train:
+            check(L.gs_bn_relu_fwd_f32(ptr(Xp), h, E, h, ptr(p[key + "_g"]), ptr(p[key + "_be"]), BN_EPS, ptr(Y), h, ptr(mu), ptr(istd),
+                                       ptr(self.scratch), stream()))
+            check(L.gs_bn_running_update_f32(ptr(mu), ptr(istd), E, h, BN_EPS, BN_MOMENTUM, ptr(self.run[key][0]), ptr(self.run[key][1]),
+                                             stream()))
+        else:
+            check(L.gs_bn_relu_eval_f32(ptr(Xp), h, E, h, ptr(p[key + "_g"]), ptr(p[key + "_be"]), BN_EPS, ptr(self.run[key][0]),
+                                        ptr(self.run[key][1]), ptr(Y), h, ptr(mu), ptr(istd), stream()))
+
+    def forward(self, X, train=True):
+        """X [n', d] -> raw structure [n', n'] (ignr.py:151-177).  train: batch statistics (and the running ones move); else the
+        running statistics (PGE.inference's counterpart, ignr.py:211-213)."""
+        L, h, d, E, n = self.L, self.h, self.d, self.E, self.n
+        p = self.views()
+        self.X, self.trained = X, train
+        gemm(X, p["c0_w"], self.U, n, h, d, (d, 1), (1, 2 * d), h)
+        gemm(X, p["c0_w"][:, d:], self.V, n, h, d, (d, 1), (1, 2 * d), h)
+        check(L.gs_edge_pair_sum_f32(ptr(self.U), ptr(self.V), h, ptr(p["c0_b"]), ptr(self.rows), ptr(self.cols), E, h, ptr(self.C0p), h,
+                                     stream()))
+        self._bn("c0", self.C0p, self.C0, p, train)
+        gemm(self.grid, p["x0_w"], self.X0p, E, h, 2, (2, 1), (1, 2), h, bias=p["x0_b"])
+        self._bn("x0", self.X0p, self.X0, p, train)
+        check(L.gs_mul_f32(ptr(self.X0), ptr(self.C0), E * h, ptr(self.Z0), stream()))
+        gemm(self.C0, p["c1_w"], self.C1p, E, h, h, (h, 1), (1, h), h, bias=p["c1_b"])
+        self._bn("c1", self.C1p, self.C1, p, train)
+        gemm(self.Z0, p["x1_w"], self.X1p, E, h, h, (h, 1), (1, h), h, bias=p["x1_b"])
+        self._bn("x1", self.X1p, self.X1, p, train)
+        check(L.gs_mul_f32(ptr(self.X1), ptr(self.C1), E * h, ptr(self.Z1), stream()))
+        check(L.gs_mix_heads_f32(ptr(self.Z1), ptr(p["x2_w"]), ptr(p["x2_b"]), 1.0 - self.ep, ptr(self.C1), ptr(p["c2_w"]), ptr(p["c2_b"]),
+                                 self.ep, E, h, ptr(self.e3), stream()))
+        check(L.gs_sym_sigmoid_f32(ptr(self.e3), n, ptr(self.adj), stream()))
+        return self.adj
+
+    def _bn_bwd(self, key, dY, Y, Xp, p, g, dX):
+        mu, istd = self.stat[key]
+        check(self.L.gs_bn_relu_bwd_f32(ptr(dY), self.h, ptr(Y), self.h, ptr(Xp), self.h, self.E, self.h, ptr(mu), ptr(istd),
+                                        ptr(p[key + "_g"]), ptr(dX), self.h, ptr(g[key + "_g"]), ptr(g[key + "_be"]), ptr(self.scratch),
+                                        stream()))
+
+    def backward(self, d_adj, accumulate_dx=False):
+        """d loss / d adj [n', n'] of the LAST training-mode forward -> self.grad (P's slot is left alone: the transport plan only
+        enters the regulariser) and self.dX."""
+        assert self.trained, "backward needs a training-mode forward"
+        L, h, d, E, n = self.L, self.h, self.d, self.E, self.n
+        p, g = self.views(), self.views(self.grad)
+        X, S = self.X, self.scratch
+        tall = lambda M, cols, out: check(L.gs_colsum_tall_f32(ptr(M), cols, E, cols, ptr(out), ptr(S), stream()))
+        check(L.gs_sym_sigmoid_bwd_f32(ptr(d_adj), ptr(self.adj), n, ptr(self.de3), stream()))
+        # heads: dZ1 = (1 - ep) de3 (x) w_x2 -> G1 ; dC1 (direct) = ep de3 (x) w_c2 -> G2
+        check(L.gs_mix_heads_bwd_f32(ptr(self.de3), ptr(p["x2_w"]), 1.0 - self.ep, ptr(p["c2_w"]), self.ep, E, h, ptr(self.G1), ptr(self.G2),
+                                     ptr(self.sx), ptr(self.sc), stream()))
+        gemm_tn_splitk(self.Z1, h, self.sx, 1, g["x2_w"], h, 1, E)                           # d w_x2 = Z1^T ((1 - ep) de3)
+        gemm_tn_splitk(self.C1, h, self.sc, 1, g["c2_w"], h, 1, E)                           # d w_c2 = C1^T (ep de3)
+        tall(self.sx, 1, g["x2_b"])
+        tall(self.sc, 1, g["c2_b"])
+        # coupling 1: Z1 = X1 * C1
+        check(L.gs_mul_bwd_f32(ptr(self.G1), ptr(self.X1), ptr(self.C1), E * h, ptr(self.G1), ptr(self.G2), 1, stream()))   # G1 = dX1, G2 = dC1
+        # x tower, layer 1
+        self._bn_bwd("x1", self.G1, self.X1, self.X1p, p, g, self.G1)                        # G1 = dX1p
+        gemm_tn_splitk(self.G1, h, self.Z0, h, g["x1_w"], h, h, E)
+        tall(self.G1, h, g["x1_b"])
+        w = p["x1_w"].t().contiguous()
+        gemm(self.G1, w, self.G3, E, h, h, (h, 1), (1, h), h)                                # G3 = dZ0 = dX1p W_x1
+        # c tower, layer 1
+        self._bn_bwd("c1", self.G2, self.C1, self.C1p, p, g, self.G2)                        # G2 = dC1p
+        gemm_tn_splitk(self.G2, h, self.C0, h, g["c1_w"], h, h, E)
+        tall(self.G2, h, g["c1_b"])
+        w = p["c1_w"].t().contiguous()
+        gemm(self.G2, w, self.G1, E, h, h, (h, 1), (1, h), h)                                # G1 = dC0 (through layer 1)
+        # coupling 0: Z0 = X0 * C0
+        check(L.gs_mul_bwd_f32(ptr(self.G3), ptr(self.X0), ptr(self.C0), E * h, ptr(self.G3), ptr(self.G1), 1, stream()))   # G3 = dX0, G1 = dC0
+        # x tower, layer 0 (input: the constant grid)
+        self._bn_bwd("x0", self.G3, self.X0, self.X0p, p, g, self.G3)
+        gemm_tn_splitk(self.G3, h, self.grid, 2, g["x0_w"], h, 2, E)
+        tall(self.G3, h, g["x0_b"])
+        # c tower, layer 0: pre-activation = U[i] + V[j] + b
+        self._bn_bwd("c0", self.G1, self.C0, self.C0p, p, g, self.G1)
+        tall(self.G1, h, g["c0_b"])
+        for seg, out in ((self.seg_r, self.dU), (self.seg_c, self.dV)):
+            check(L.gs_segment_sum_rows_f32(ptr(self.G1), h, ptr(seg[0]), ptr(seg[1]), n, h, ptr(out), h, stream()))
+        gemm(self.dU, X, g["c0_w"], h, d, n, (1, h), (d, 1), 2 * d)
+        gemm(self.dV, X, g["c0_w"][:, d:], h, d, n, (1, h), (d, 1), 2 * d)
+        gemm(self.dU, p["c0_w"], self.dX, n, d, h, (h, 1), (2 * d, 1), d, beta=1.0 if accumulate_dx else 0.0)
+        gemm(self.dV, p["c0_w"][:, d:], self.dX, n, d, h, (h, 1), (2 * d, 1), d, beta=1.0)
+        return self.grad, self.dX
+
+    def adam_step(self):
+        self.step_count += 1
+        adam_step(self.theta, self.grad, self.m, self.v, self.lr, self.step_count)

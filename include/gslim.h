@@ -237,6 +237,34 @@ int gs_segment_sum_rows_f32(const float* Xe, long ld, const int* ptr, const int*
                             gs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * IGNR graphon learner of SGDD (graphslim/models/ignr.py:95-177): two MLP towers over all n'^2 ordered pairs — net0 on
+ * cat(x_i, x_j), net1 on the pair's grid coordinates — coupled by element-wise products, mixed by ep_ratio, symmetrised,
+ * squashed.  Composed from gs_gemm_f32, the BatchNorm / pair-sum / segment-sum calls above and these (graphslim_amd/structure.py).
+ * ------------------------------------------------------------------------------------------- */
+int gs_mul_f32(const float* a, const float* b, long total, float* z, gs_stream_t stream);                      /* z = a * b (ignr.py:167) */
+/* backward of z = a * b: da = dz * b (da may alias dz); db = dz * a, added to db when accumulate_db */
+int gs_mul_bwd_f32(const float* dz, const float* a, const float* b, long total, float* da, float* db, int accumulate_db,
+                   gs_stream_t stream);
+/* e3[e] = wa (A[e] . ua + ba[0]) + wb (B[e] . ub + bb[0]): the two Linear(nfeat, 1) heads and `(1 - ep_ratio) x + ep_ratio c`
+ * (ignr.py:161-170); A, B: [E][F] contiguous */
+int gs_mix_heads_f32(const float* A, const float* ua, const float* ba, float wa, const float* B, const float* ub, const float* bb,
+                     float wb, long E, int F, float* e3, gs_stream_t stream);
+/* backward: dA[e][k] = wa de3[e] ua[k], dB likewise; sa[e] = wa de3[e], sb[e] = wb de3[e] (then d ua = A^T sa, d ba = sum sa, ...) */
+int gs_mix_heads_bwd_f32(const float* de3, const float* ua, float wa, const float* ub, float wb, long E, int F, float* dA, float* dB,
+                         float* sa, float* sb, gs_stream_t stream);
+/* adj = sigmoid((e3 + e3^T) / 2), zero diagonal (ignr.py:174-177; the PGE's final stage, parametrized_adj.py:66-70) and its backward */
+int gs_sym_sigmoid_f32(const float* e3, int n, float* adj, gs_stream_t stream);
+int gs_sym_sigmoid_bwd_f32(const float* dA, const float* adj, int n, float* de3, gs_stream_t stream);
+/* nn.BatchNorm1d running statistics after a training-mode pass (momentum 0.1 upstream; unbiased batch variance) from the mu / istd
+ * gs_bn_relu_fwd_f32 returned */
+int gs_bn_running_update_f32(const float* mu, const float* istd, long E, int F, float eps, float momentum, float* running_mean,
+                             float* running_var, gs_stream_t stream);
+/* EVAL-mode BatchNorm1d + ReLU: Y = relu(g (X - running_mean) / sqrt(running_var + eps) + be) (ignr.py:151-152,211-213: the
+ * inference structure); mu / istd [F] receive the constants used */
+int gs_bn_relu_eval_f32(const float* X, long ldx, long E, int F, const float* g, const float* be, float eps, const float* running_mean,
+                        const float* running_var, float* Y, long ldy, float* mu, float* istd, gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The GCond engine: one object per GPU holding the learnable synthetic graph (X~, PGE), the
  * per-epoch SGC model and all scratch.  One gs_gcond_outer_step == one iteration of the loop body
  * condensation/gcond.py:47-72 (PGE forward + dense_gcn_norm, train_class over all classes
