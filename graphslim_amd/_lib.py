@@ -64,7 +64,8 @@ SYMBOLS = [
     "gs_gcond_stage_syn_finish", "gs_gcond_stage_inner_steps", "gs_bias_act_f32", "gs_log_softmax_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
     "gs_edge_pair_sum_f32", "gs_bn_scratch_bytes", "gs_bn_relu_fwd_f32", "gs_bn_relu_bwd_f32", "gs_edge_score_f32",
     "gs_edge_scatter_sym_f32", "gs_edge_score_bwd_f32", "gs_segment_sum_rows_f32", "gs_colsum_tall_f32", "gs_mul_f32", "gs_mul_bwd_f32", "gs_mix_heads_f32", "gs_mix_heads_bwd_f32", "gs_sym_sigmoid_f32",
-    "gs_sym_sigmoid_bwd_f32", "gs_bn_running_update_f32", "gs_bn_relu_eval_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
+    "gs_sym_sigmoid_bwd_f32", "gs_bn_running_update_f32", "gs_bn_relu_eval_f32", "gs_ot_spectrum_f32", "gs_ot_value_f32",
+    "gs_scale_cols_f32", "gs_ot_divdiff_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
 ]
 
 
@@ -154,6 +155,10 @@ def lib():
     L.gs_sym_sigmoid_bwd_f32.argtypes = [vp, vp, i, vp, vp]
     L.gs_bn_running_update_f32.argtypes = [vp, vp, l, i, f, f, vp, vp, vp]
     L.gs_bn_relu_eval_f32.argtypes = [vp, l, l, i, vp, vp, f, vp, vp, vp, l, vp, vp, vp]
+    L.gs_ot_spectrum_f32.argtypes = [vp, i, f, vp, vp]
+    L.gs_ot_value_f32.argtypes = [vp, vp, i, f, vp, vp, vp, vp]
+    L.gs_scale_cols_f32.argtypes = [vp, vp, i, i, vp, vp]
+    L.gs_ot_divdiff_f32.argtypes = [vp, vp, vp, vp, vp, vp, i, vp]
     L.gs_edge_score_f32.argtypes = [vp, l, vp, vp, l, i, vp, vp]
     L.gs_edge_scatter_sym_f32.argtypes = [vp, vp, vp, l, i, vp, vp, vp]
     L.gs_edge_score_bwd_f32.argtypes = [vp, vp, vp, vp, vp, l, i, i, vp, vp, l, vp]

@@ -314,6 +314,89 @@ __global__ void sg_bn_eval_consts_kernel(const float* __restrict__ rm, const flo
   istd[k] = 1.f / sqrtf(rv[k] + eps);
 }
 
+
+// ---- optimal-transport regulariser of SGDD (graphslim/models/ignr.py:30-41,184-209) in the eigenbasis of the symmetric structure ----
+// adj = Q diag(lam) Q^T.  torch.svd gives U = Q, S = |lam|, V = Q sign(lam), so U f(S) V^T = Q diag(sign(lam) f(|lam|)) Q^T:
+//   Ly_inv_rt = Q diag(g) Q^T,  g_i = sign(lam_i) |lam_i|^-1/2;   Ly_inv = Q diag(1 / lam_i) Q^T
+// with the entries whose singular value EQUALS the smallest one zeroed when that one is below 0.009 (ignr.py:32-38).
+// One workgroup: out[0..n) = g, [n..2n) = g' (derivative, 0 where zeroed), [2n..3n) = d(1/lam)/dlam = -1/lam^2 (0 where zeroed),
+// [3n] = trace(Ly_inv).
+__global__ __launch_bounds__(256) void sg_ot_spectrum_kernel(const float* __restrict__ lam, int n, float sv_eps, float* __restrict__ out) {
+  __shared__ float red[256];
+  float mn = INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) mn = fminf(mn, fabsf(lam[i]));
+  red[threadIdx.x] = mn;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const float smin = red[0];
+  __syncthreads();
+  float tr = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float l = lam[i], sa = fabsf(l);
+    const bool keep = !(smin < sv_eps) || sa > smin;
+    const float sg = l < 0.f ? -1.f : 1.f;
+    const float inv = keep ? 1.f / sa : 0.f;
+    out[i] = sg * sqrtf(inv);
+    out[n + i] = keep ? -0.5f * inv * sqrtf(inv) : 0.f;      // d/dlam [sign |lam|^-1/2] = -1/2 |lam|^-3/2
+    out[2 * n + i] = keep ? -inv * inv : 0.f;                // d/dlam [1 / lam]
+    tr += sg * inv;
+  }
+  red[threadIdx.x] = tr;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[3 * n] = red[0];
+}
+
+// value = | trace * n - 2 sum sqrt(max(mu, 2e-20)) |  (ignr.py:205-208); acc[0] += value;  dmu_k = scale * sign * (-1 / sqrt(mu_k))
+// (0 where clamped);  out[n] = scale * sign * n = d / d trace.   One workgroup.
+__global__ __launch_bounds__(256) void sg_ot_value_kernel(const float* __restrict__ mu, const float* __restrict__ trace, int n, float scale,
+                                                          float* __restrict__ dmu, float* __restrict__ value, double* __restrict__ acc) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += sqrtf(fmaxf(mu[i], 2e-20f));
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float inner = trace[0] * (float)n - 2.f * red[0];
+  const float sg = inner < 0.f ? -1.f : (inner > 0.f ? 1.f : 0.f);
+  for (int i = threadIdx.x; i < n; i += 256) dmu[i] = mu[i] > 2e-20f ? -scale * sg / sqrtf(mu[i]) : 0.f;
+  if (threadIdx.x == 0) {
+    dmu[n] = scale * sg * (float)n;
+    value[0] = fabsf(inner);
+    if (acc) acc[0] += (double)fabsf(inner);
+  }
+}
+
+// B[i][k] = A[i][k] * v[k]
+__global__ void sg_scale_cols_kernel(const float* __restrict__ A, const float* __restrict__ v, int rows, int cols, float* __restrict__ B) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < (long)rows * cols) B[idx] = A[idx] * v[idx % cols];
+}
+
+// K[i][j] <- F(lam_i, lam_j) K[i][j] + [i == j] dtr[0] hp[i]:   F = (g_i - g_j) / (lam_i - lam_j), or g'(lam_i) on the diagonal and
+// for numerically equal eigenvalues (Daleckii-Krein: the derivative of the matrix function Q diag(g(lam)) Q^T in the eigenbasis)
+__global__ void sg_ot_divdiff_kernel(float* __restrict__ K, const float* __restrict__ lam, const float* __restrict__ g,
+                                     const float* __restrict__ gp, const float* __restrict__ hp, const float* __restrict__ dtr, int n) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * n) return;
+  const int i = idx / n, j = idx % n;
+  const float li = lam[i], lj = lam[j];
+  const float den = li - lj;
+  float F;
+  if (i == j || fabsf(den) <= 1e-6f * fmaxf(fabsf(li), fabsf(lj))) F = 0.5f * (gp[i] + gp[j]);
+  else F = (g[i] - g[j]) / den;
+  K[idx] = F * K[idx] + (i == j ? dtr[0] * hp[i] : 0.f);
+}
+
 }  // namespace
 
 extern "C" int gs_edge_pair_sum_f32(const float* U, const float* V, long ld, const float* bias, const int* rows, const int* cols,
@@ -482,6 +565,36 @@ extern "C" int gs_bn_relu_eval_f32(const float* X, long ldx, long E, int F, cons
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(sg_bn_eval_consts_kernel, dim3(gs_cdiv(F, 64)), dim3(64), 0, s, running_mean, running_var, eps, F, mu, istd);
   hipLaunchKernelGGL(sg_bn_relu_apply_kernel, dim3(gs_cdiv(E, 4)), dim3(256), 0, s, X, ldx, E, F, mu, istd, g, be, Y, ldy);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_ot_spectrum_f32(const float* lam, int n, float sv_eps, float* out, gs_stream_t stream) {
+  if (!lam || !out || n <= 0) GS_FAIL(GS_ERR_ARG, "gs_ot_spectrum_f32: bad argument");
+  hipLaunchKernelGGL(sg_ot_spectrum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lam, n, sv_eps, out);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_ot_value_f32(const float* mu, const float* trace, int n, float scale, float* dmu, float* value, double* acc,
+                               gs_stream_t stream) {
+  if (!mu || !trace || !dmu || !value || n <= 0) GS_FAIL(GS_ERR_ARG, "gs_ot_value_f32: bad argument");
+  hipLaunchKernelGGL(sg_ot_value_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mu, trace, n, scale, dmu, value, acc);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_scale_cols_f32(const float* A, const float* v, int rows, int cols, float* B, gs_stream_t stream) {
+  if (!A || !v || !B || rows <= 0 || cols <= 0) GS_FAIL(GS_ERR_ARG, "gs_scale_cols_f32: bad argument");
+  hipLaunchKernelGGL(sg_scale_cols_kernel, dim3(gs_cdiv((long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, A, v, rows, cols, B);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_ot_divdiff_f32(float* K, const float* lam, const float* g, const float* gp, const float* hp, const float* dtr, int n,
+                                 gs_stream_t stream) {
+  if (!K || !lam || !g || !gp || !hp || !dtr || n <= 0) GS_FAIL(GS_ERR_ARG, "gs_ot_divdiff_f32: bad argument");
+  hipLaunchKernelGGL(sg_ot_divdiff_kernel, dim3(gs_cdiv((long)n * n, 256)), dim3(256), 0, (hipStream_t)stream, K, lam, g, gp, hp, dtr, n);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

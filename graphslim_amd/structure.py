@@ -9,6 +9,7 @@ by class (class c: structure 0's nodes of c, structure 1's, ...), which is the l
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -324,3 +325,122 @@ class IGNRGenerator:
     def adam_step(self):
         self.step_count += 1
         adam_step(self.theta, self.grad, self.m, self.v, self.lr, self.step_count)
+
+
+# ==================================================================================================================================
+# optimal-transport regulariser of SGDD (graphslim/models/ignr.py:13-41,184-209)
+# ==================================================================================================================================
+
+
+class _SymEig:
+    """Symmetric eigen-decomposition on the GPU: rocSOLVER's ssyevd, the library call behind torch.linalg.eigh (which upstream calls,
+    ignr.py:201) — bound directly with ctypes from the copies PyTorch-ROCm has already loaded."""
+
+    _inst = None
+
+    def __init__(self):
+        libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+        self.blas = C.CDLL(os.path.join(libdir, "librocblas.so"))
+        self.solver = C.CDLL(os.path.join(libdir, "librocsolver.so"))
+        self.handle = C.c_void_p()
+        if self.blas.rocblas_create_handle(C.byref(self.handle)) != 0:
+            raise RuntimeError("rocblas_create_handle failed")
+        self.solver.rocsolver_ssyevd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p]
+        self.blas.rocblas_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+
+    @classmethod
+    def get(cls):
+        if cls._inst is None:
+            cls._inst = cls()
+        return cls._inst
+
+    def eigh(self, A, lam, work, info):
+        """In place: A [n, n] symmetric (row-major; its lower triangle is read, like torch.linalg.eigh's default UPLO = 'L') ->
+        A[k] = k-th eigenvector (ROWS of the row-major buffer = columns of the column-major matrix the library fills),
+        lam ascending."""
+        n = A.shape[0]
+        if self.blas.rocblas_set_stream(self.handle, stream()) != 0:
+            raise RuntimeError("rocblas_set_stream failed")
+        EVECT_ORIGINAL, FILL_UPPER = 211, 121          # column-major upper triangle == row-major lower triangle
+        rc = self.solver.rocsolver_ssyevd(self.handle, EVECT_ORIGINAL, FILL_UPPER, n, ptr(A), n, ptr(lam), ptr(work), ptr(info))
+        if rc != 0:
+            raise RuntimeError(f"rocsolver_ssyevd failed (status {rc})")
+
+
+class TransportRegulariser:
+    """opt_loss(adj) = | tr(Ly_inv) n' - 2 sum_k sqrt(eig_k(Ly_inv_rt P^T Lx_inv P Ly_inv_rt)) |  (ignr.py:184-209) and its gradient
+    wrt the structure and the transport plan P, in closed form (no autograd): eigen-decompositions by rocSOLVER, products by
+    gs_gemm_f32, spectrum functions by csrc/gs_structgen.hip.  Lx_inv [mx, mx] is the constant pseudo-inverse of the real
+    adjacency's corner (ignr.py:13-27, computed once on the host)."""
+
+    SV_EPS = 0.009
+
+    def __init__(self, Lx_inv, n, device):
+        self.L = _lib.lib()
+        self.dev = torch.device(device)
+        self.n, self.mx = n, Lx_inv.shape[0]
+        self.Lx_inv = torch.as_tensor(Lx_inv).to(self.dev, torch.float32).contiguous()
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+        n, mx = self.n, self.mx
+        self.Qr, self.Wr = f(n, n), f(n, n)                    # eigenvectors as ROWS
+        self.lam, self.mu, self.work = f(n), f(n), f(n)
+        self.info = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.spec = f(3 * n + 1)
+        self.R, self.M, self.T = f(n, n), f(n, n), f(n, n)
+        self.T1, self.T2, self.dT1 = f(mx, n), f(mx, n), f(mx, n)
+        self.dmu = f(n + 1)
+        self.value = f(1)
+        self.acc = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.eig = _SymEig.get()
+
+    def forward_backward(self, adj, P, scale, d_adj, dP):
+        """value of opt_loss(adj) (device scalar self.value, also added to self.acc) and, for the term `scale * opt_loss` of the
+        total loss: d_adj += its gradient wrt adj (n', n'), dP = its gradient wrt P (mx, n')."""
+        L, n, mx = self.L, self.n, self.mx
+        s = stream()
+        # adj = Q diag(lam) Q^T
+        self.Qr.copy_(adj)
+        self.eig.eigh(self.Qr, self.lam, self.work, self.info)
+        check(L.gs_ot_spectrum_f32(ptr(self.lam), n, self.SV_EPS, ptr(self.spec), s))
+        g, gp, hp, tr = self.spec[:n], self.spec[n:2 * n], self.spec[2 * n:3 * n], self.spec[3 * n:]
+        # R = Ly_inv_rt = Q diag(g) Q^T = Qr^T diag(g) Qr:  T = diag(g) Qr (rows scaled) -> via columns of Qr^T ... rows: scale_cols on Qr^T
+        check(L.gs_scale_cols_f32(ptr(self.Qr.t().contiguous()), ptr(g), n, n, ptr(self.T), s))        # T[i][k] = Q[i][k] g_k
+        gemm(self.T, self.Qr, self.R, n, n, n, (n, 1), (n, 1), n)                                        # R = T Qr  (Qr[k][j] = Q[j][k])
+        gemm(P, self.R, self.T1, mx, n, n, (n, 1), (n, 1), n)                                            # T1 = P R
+        gemm(self.Lx_inv, self.T1, self.T2, mx, n, mx, (mx, 1), (n, 1), n)                               # T2 = Lx_inv T1
+        gemm(self.T1, self.T2, self.M, n, n, mx, (1, n), (n, 1), n)                                      # M = T1^T T2
+        self.Wr.copy_(self.M)
+        self.eig.eigh(self.Wr, self.mu, self.work, self.info)
+        check(L.gs_ot_value_f32(ptr(self.mu), ptr(tr), n, float(scale), ptr(self.dmu), ptr(self.value), ptr(self.acc), s))
+        if scale <= 0:
+            return self.value
+        # dM = W diag(dmu) W^T
+        check(L.gs_scale_cols_f32(ptr(self.Wr.t().contiguous()), ptr(self.dmu), n, n, ptr(self.T), s))  # T[i][k] = W[i][k] dmu_k
+        gemm(self.T, self.Wr, self.M, n, n, n, (n, 1), (n, 1), n)                                        # M := dM
+        gemm(self.T2, self.M, self.dT1, mx, n, n, (n, 1), (n, 1), n, alpha=2.0)                          # dT1 = 2 Lx_inv T1 dM
+        gemm(self.dT1, self.R, dP, mx, n, n, (n, 1), (n, 1), n)                                          # dP = dT1 R   (R symmetric)
+        gemm(P, self.dT1, self.M, n, n, mx, (1, n), (n, 1), n)                                           # dR = P^T dT1 -> M
+        # K = Q^T dR Q = Qr dR Qr^T
+        gemm(self.Qr, self.M, self.T, n, n, n, (n, 1), (n, 1), n)                                        # T = Qr dR
+        gemm(self.T, self.Qr, self.M, n, n, n, (n, 1), (1, n), n)                                        # M = T Qr^T = K
+        check(L.gs_ot_divdiff_f32(ptr(self.M), ptr(self.lam), ptr(g), ptr(gp), ptr(hp), ptr(self.dmu[n:]), n, s))
+        # d adj += Q K' Q^T = Qr^T K' Qr
+        gemm(self.Qr, self.M, self.T, n, n, n, (1, n), (n, 1), n)                                        # T = Qr^T K'
+        gemm(self.T, self.Qr, d_adj, n, n, n, (n, 1), (n, 1), n, beta=1.0)                               # d_adj += T Qr
+        return self.value
+
+
+def pinv_corner(adj_corner):
+    """ignr.py:13-27 mx_inv on the host, once per job (like the scipy normalisation of the real adjacency): pseudo-inverse through
+    torch.svd in float32 (the call upstream makes); the singular values EQUAL to the smallest one are zeroed when that one is below
+    0.009.  (Only those: a corner with several vanishing singular values gets their rounding-level reciprocals, upstream too.)"""
+    a = torch.as_tensor(np.asarray(adj_corner.todense() if hasattr(adj_corner, "todense") else adj_corner, dtype=np.float32))
+    U, D, V = torch.svd(a)
+    d_min = torch.min(D)
+    if d_min < 0.009:
+        d1 = torch.zeros_like(D)
+        d1[D > d_min] = 1 / D[D > d_min]
+    else:
+        d1 = 1 / D
+    return (U @ d1.diag() @ V.t()).numpy()

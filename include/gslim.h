@@ -265,6 +265,25 @@ int gs_bn_relu_eval_f32(const float* X, long ldx, long E, int F, const float* g,
                         const float* running_var, float* Y, long ldy, float* mu, float* istd, gs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Optimal-transport regulariser of SGDD (graphslim/models/ignr.py:30-41 mx_inv_sqrt, :184-209 opt_loss), evaluated in the
+ * eigenbasis of the symmetric structure: adj = Q diag(lam) Q^T, so torch.svd's U f(S) V^T is Q diag(sign(lam) f(|lam|)) Q^T.  The
+ * two symmetric eigen-decompositions are library calls (rocSOLVER ssyevd, bound in graphslim_amd/structure.py); the products are
+ * gs_gemm_f32; these are the spectrum functions around them.
+ * ------------------------------------------------------------------------------------------- */
+/* out[0..n) = g_i = sign(lam_i) |lam_i|^-1/2 (Ly_inv_rt's spectrum), [n..2n) = g'_i, [2n..3n) = d(1/lam_i)/dlam_i, [3n] = trace(Ly_inv);
+ * entries whose |lam| equals the smallest one are zeroed when that one is below sv_eps (0.009 upstream, ignr.py:32-38). */
+int gs_ot_spectrum_f32(const float* lam, int n, float sv_eps, float* out, gs_stream_t stream);
+/* value[0] = |trace[0] n - 2 sum sqrt(max(mu_k, 2e-20))| (ignr.py:205-208); acc[0] += value (may be NULL);
+ * dmu[k] = scale sign(.) (-1 / sqrt(mu_k)) (0 where clamped), dmu[n] = scale sign(.) n = d value / d trace.  dmu: n + 1 floats. */
+int gs_ot_value_f32(const float* mu, const float* trace, int n, float scale, float* dmu, float* value, double* acc, gs_stream_t stream);
+/* B[i][k] = A[i][k] v[k] */
+int gs_scale_cols_f32(const float* A, const float* v, int rows, int cols, float* B, gs_stream_t stream);
+/* K[i][j] <- F_ij K[i][j] + [i == j] dtr[0] hp[i] with the divided differences F_ij = (g_i - g_j) / (lam_i - lam_j) (g'_i on the
+ * diagonal and for equal eigenvalues): the derivative of Q diag(g(lam)) Q^T in the eigenbasis (Daleckii-Krein). */
+int gs_ot_divdiff_f32(float* K, const float* lam, const float* g, const float* gp, const float* hp, const float* dtr, int n,
+                      gs_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The GCond engine: one object per GPU holding the learnable synthetic graph (X~, PGE), the
  * per-epoch SGC model and all scratch.  One gs_gcond_outer_step == one iteration of the loop body
  * condensation/gcond.py:47-72 (PGE forward + dense_gcn_norm, train_class over all classes

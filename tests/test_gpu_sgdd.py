@@ -63,3 +63,36 @@ def test_ignr_generator_against_fp64_autograd(n, d):
         ref_eval = S.ignr_structure(x64.detach(), {k: v.detach() for k, v in p64.items()}, run, 0.4, train=False)
     np.testing.assert_allclose(adj_eval.numpy(), ref_eval.numpy(), atol=1e-5)
     assert float((adj_eval - adj).abs().max()) > 1e-3          # the two BatchNorm modes give different structures
+
+
+@pytest.mark.parametrize("n,mx,seed", [(14, 9, 0), (37, 40, 1), (60, 25, 2)])
+def test_transport_regulariser_against_fp64_autograd(n, mx, seed):
+    """opt_loss (ignr.py:184-209) and its gradient wrt the structure and the transport plan: closed form in the eigenbasis
+    (rocSOLVER ssyevd + gs_gemm_f32 + spectrum kernels) against fp64 autograd through the reference's own formula — torch.svd,
+    U f(S) V^T, torch.linalg.eigh — on a structure the IGNR produces (symmetric, zero diagonal, entries in (0, 1))."""
+    from graphslim_amd.structure import TransportRegulariser, pinv_corner
+    torch.manual_seed(seed)
+    raw = torch.rand(n, n, dtype=torch.float64)
+    adj = torch.sigmoid(2 * (raw + raw.T) - 2)
+    adj = adj - torch.diag(torch.diag(adj))
+    c = (torch.rand(mx, mx) < 0.3).double()
+    corner = torch.triu(c, 1) + torch.triu(c, 1).T + 3 * torch.eye(mx, dtype=torch.float64)      # full rank: a well-defined pseudo-inverse
+    Lx_inv = S.mx_inv(corner)
+    np.testing.assert_allclose(pinv_corner(corner.numpy()), S.mx_inv(corner.float()).numpy(), atol=1e-5)
+    P = torch.rand(mx, n, dtype=torch.float64)
+    a64, p64 = adj.clone().requires_grad_(True), P.clone().requires_grad_(True)
+    val = S.opt_loss(a64, p64, Lx_inv)
+    ga, gp = torch.autograd.grad(val, [a64, p64])
+    ga = (ga + ga.T) / 2                                        # the structure only moves along symmetric directions
+    reg = TransportRegulariser(Lx_inv.float(), n, DEV)
+    d_adj = torch.zeros(n, n, device=DEV)
+    dP = torch.zeros(mx, n, device=DEV)
+    scale = 1e-3
+    reg.forward_backward(adj.float().to(DEV).contiguous(), P.float().to(DEV).contiguous(), scale, d_adj, dP)
+    assert abs(float(reg.value) - float(val)) <= 2e-3 * abs(float(val)), (float(reg.value), float(val))
+    got_a = d_adj.cpu().double() / scale
+    got_a = (got_a + got_a.T) / 2
+    assert float((got_a - ga).abs().max()) <= 2e-2 * float(ga.abs().max()), (float((got_a - ga).abs().max()), float(ga.abs().max()))
+    got_p = dP.cpu().double() / scale
+    assert float((got_p - gp).abs().max()) <= 2e-2 * float(gp.abs().max()), (float((got_p - gp).abs().max()), float(gp.abs().max()))
+    assert float(reg.acc) == pytest.approx(float(reg.value), rel=1e-6)
