@@ -9,6 +9,6 @@ import graphslim_amd
 
 __version__ = graphslim_amd.__version__
 for _name in ("config", "utils", "host", "dataset", "dataset.loader", "dataset.utils", "dataset.synthetic", "condensation",
-              "condensation.gcond", "condensation.gcond_base", "condensation.doscond", "condensation.gcondx", "condensation.msgc", "coarsening", "coarsening.averaging", "coarsening.clustering", "structure", "evaluation", "evaluation.eval_agent", "evaluation.utils",
+              "condensation.gcond", "condensation.gcond_base", "condensation.doscond", "condensation.gcondx", "condensation.msgc", "condensation.sgdd", "coarsening", "coarsening.averaging", "coarsening.clustering", "structure", "evaluation", "evaluation.eval_agent", "evaluation.utils",
               "models", "models.gcn", "sparsification", "sparsification.random", "reduction"):
     sys.modules[f"graphslim.{_name}"] = importlib.import_module(f"graphslim_amd.{_name}")

@@ -137,6 +137,7 @@ _INITS = ["variation_neighborhoods", "variation_edges", "variation_cliques", "he
 @click.option("--activation", default="relu", show_default=True)
 @click.option("--alpha", default=0.1, show_default=True)
 @click.option("--ptb_r", "-P", default=0.25, show_default=True)
+@click.option("--mx_size", default=100, show_default=True, help="for gcsntk methods, avoid SVD error")
 @click.option("--batch_adj", default=1, show_default=True, help="batch size for msgc")
 @click.option("--attack", "-A", default=None, type=click.Choice(["random_adj", "metattack", "random_feat"]))
 @click.pass_context

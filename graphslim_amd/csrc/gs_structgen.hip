@@ -368,7 +368,21 @@ __global__ __launch_bounds__(256) void sg_ot_value_kernel(const float* __restric
   }
   const float inner = trace[0] * (float)n - 2.f * red[0];
   const float sg = inner < 0.f ? -1.f : (inner > 0.f ? 1.f : 0.f);
-  for (int i = threadIdx.x; i < n; i += 256) dmu[i] = mu[i] > 2e-20f ? -scale * sg / sqrtf(mu[i]) : 0.f;
+  __syncthreads();
+  // Structurally zero eigenvalues (a zeroed singular value of the structure, or fewer corner rows than nodes, make the product
+  // singular) come out of an fp32 decomposition as +-rounding noise.  Upstream's clamp(min=2e-20) gives them zero gradient when
+  // the noise is negative and -1/sqrt(noise) when it is positive; here everything below 1e-6 of the largest eigenvalue counts as
+  // clamped, which is the exact-arithmetic gradient.
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, mu[i]);
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const float thr = fmaxf(2e-20f, 1e-6f * red[0]);
+  for (int i = threadIdx.x; i < n; i += 256) dmu[i] = mu[i] > thr ? -scale * sg / sqrtf(mu[i]) : 0.f;
   if (threadIdx.x == 0) {
     dmu[n] = scale * sg * (float)n;
     value[0] = fabsf(inner);

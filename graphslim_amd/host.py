@@ -177,3 +177,27 @@ def init_edge_mlp_params(nfeat, nhid=256):
     w1, b1 = _nn_linear(nhid, nhid)
     w2, b2 = _nn_linear(nhid, 1)
     return [w0, b0, torch.ones(nhid), torch.zeros(nhid), w1, b1, torch.ones(nhid), torch.zeros(nhid), w2, b2]
+
+
+# ---- SGDD (graphslim/condensation/sgdd.py, graphslim/models/ignr.py) ----------------------------------------------------------
+
+
+def init_ignr_params(nfeat, nnodes, mx_size, hidden=128):
+    """GraphonLearner.__init__ + reset_parameters (ignr.py:95-149) in the reference's RNG draw order: the six nn.Linear of net0
+    (2 nfeat -> hidden -> hidden -> 1) and net1 (2 -> hidden -> hidden -> 1) in constructor order, the transport plan P ~ U(0, 1)
+    [mx_size, nnodes], the unused `output` Linear; then reset_parameters() re-draws every Linear in module order — P keeps its first
+    draw.  Returns {name: tensor} with the names of graphslim_amd/structure.py::IGNR_ORDER."""
+    dims = [(2 * nfeat, hidden), (hidden, hidden), (hidden, 1), (2, hidden), (hidden, hidden), (hidden, 1)]
+    for fi, fo in dims:
+        _nn_linear(fi, fo)
+    P = torch.empty(mx_size, nnodes).uniform_(0, 1)
+    _nn_linear(hidden, 1)
+    lin = [_nn_linear(fi, fo) for fi, fo in dims]
+    out = _nn_linear(hidden, 1)
+    p = {"P": P, "out_w": out[0], "out_b": out[1]}
+    for t, base in (("c", 0), ("x", 3)):
+        for l in range(3):
+            p[f"{t}{l}_w"], p[f"{t}{l}_b"] = lin[base + l]
+        for l in range(2):
+            p[f"{t}{l}_g"], p[f"{t}{l}_be"] = torch.ones(hidden), torch.zeros(hidden)
+    return p

@@ -15,8 +15,8 @@ def create_reducer(name, setting, data, args, **kwargs):
     if key == "clustering":
         from ..coarsening.clustering import Cluster
         return Cluster(setting, data, args, **kwargs)
-    if key in ("gcond", "doscond", "gcondx", "doscondx", "msgc"):
+    if key in ("gcond", "doscond", "gcondx", "doscondx", "msgc", "sgdd"):
         from .. import condensation as cd
-        cls = {"gcond": cd.GCond, "doscond": cd.DosCond, "gcondx": cd.GCondX, "doscondx": cd.DosCondX, "msgc": cd.MSGC}[key]
+        cls = {"gcond": cd.GCond, "doscond": cd.DosCond, "gcondx": cd.GCondX, "doscondx": cd.DosCondX, "msgc": cd.MSGC, "sgdd": cd.SGDD}[key]
         return cls(setting, data, args, **kwargs)
     raise NotImplementedError(f"graphslim_amd builds the GCond path only; reducer '{name}' is out of scope (SURVEY.md §8)")

@@ -380,7 +380,12 @@ class TransportRegulariser:
         self.L = _lib.lib()
         self.dev = torch.device(device)
         self.n, self.mx = n, Lx_inv.shape[0]
-        self.Lx_inv = torch.as_tensor(Lx_inv).to(self.dev, torch.float32).contiguous()
+        Lx_host = torch.as_tensor(np.asarray(Lx_inv, dtype=np.float32))
+        self.Lx_inv = Lx_host.to(self.dev).contiguous()
+        # torch.svd's pseudo-inverse of a rank-deficient corner is NOT symmetric in its rounding-level components (U and V span the
+        # null space with unrelated bases); eigh reads M's lower triangle and its backward hands a symmetric dM to both triangles,
+        # so d/dT1 [T1^T Lx_inv T1] = (Lx_inv + Lx_inv^T) T1 dM.  The sum is formed once on the host.
+        self.Lx_sym = (Lx_host + Lx_host.t()).to(self.dev).contiguous()
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
         n, mx = self.n, self.mx
         self.Qr, self.Wr = f(n, n), f(n, n)                    # eigenvectors as ROWS
@@ -418,7 +423,8 @@ class TransportRegulariser:
         # dM = W diag(dmu) W^T
         check(L.gs_scale_cols_f32(ptr(self.Wr.t().contiguous()), ptr(self.dmu), n, n, ptr(self.T), s))  # T[i][k] = W[i][k] dmu_k
         gemm(self.T, self.Wr, self.M, n, n, n, (n, 1), (n, 1), n)                                        # M := dM
-        gemm(self.T2, self.M, self.dT1, mx, n, n, (n, 1), (n, 1), n, alpha=2.0)                          # dT1 = 2 Lx_inv T1 dM
+        gemm(self.Lx_sym, self.T1, self.T2, mx, n, mx, (mx, 1), (n, 1), n)                               # T2 := (Lx_inv + Lx_inv^T) T1
+        gemm(self.T2, self.M, self.dT1, mx, n, n, (n, 1), (n, 1), n)                                     # dT1 = (Lx_inv + Lx_inv^T) T1 dM
         gemm(self.dT1, self.R, dP, mx, n, n, (n, 1), (n, 1), n)                                          # dP = dT1 R   (R symmetric)
         gemm(P, self.dT1, self.M, n, n, mx, (1, n), (n, 1), n)                                           # dR = P^T dT1 -> M
         # K = Q^T dR Q = Qr dR Qr^T

@@ -96,3 +96,140 @@ def test_transport_regulariser_against_fp64_autograd(n, mx, seed):
     got_p = dP.cpu().double() / scale
     assert float((got_p - gp).abs().max()) <= 2e-2 * float(gp.abs().max()), (float((got_p - gp).abs().max()), float(gp.abs().max()))
     assert float(reg.acc) == pytest.approx(float(reg.value), rel=1e-6)
+
+
+def _golden_setup(g, tag):
+    from graphslim_amd import host as H
+    from graphslim_amd.condensation.sgdd import SGDDLoop
+    from graphslim_amd.engine import EngineShapes, GCondEngine
+    n, nclass, d, hidden, t, inner, epochs, outer, mx = [int(v) for v in g[f"{tag}_meta"]]
+    a = sp.coo_matrix((np.ones(len(g[f"{tag}_a_row"])), (g[f"{tag}_a_row"], g[f"{tag}_a_col"])), shape=(n, n)).tocsr()
+    x, y, idx_train = g[f"{tag}_x"], g[f"{tag}_y"], g[f"{tag}_idx_train"]
+    labels_train = y[idx_train]
+    scale = float(g[f"{tag}_opt_scale"])
+    H.seed_everything(1)
+    labels_syn, ncd, ranges = H.generate_labels_syn(labels_train, 0.5)
+    assert np.array_equal(labels_syn, g[f"{tag}_labels_syn"])
+    params = H.init_ignr_params(d, len(labels_syn), mx)
+    sel = H.random_init_indices(idx_train, labels_train, ncd)
+    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, 4, 32, 4, 3)
+    eng = GCondEngine(sh, torch.from_numpy(x), None, None, None, labels_syn, [tuple(ranges[c]) for c in range(nclass)], lr_feat=0.01,
+                      lr_adj=0.01, lr_model=0.01, inner_loop=inner, external_blocks=True, device=DEV)
+    eng.set_feat(torch.from_numpy(x[sel]))
+    loop = SGDDLoop(eng, params, g[f"{tag}_Lx_inv"], 0.5, scale, 0.01, 0.01)
+    H.init_sgc_params(d, hidden, nclass, t)                       # model constructor draw
+    return dict(a=a, x=x, y=y, idx_train=idx_train, labels_train=labels_train, csr=H.normalize_adj_sparse(a), labels_syn=labels_syn,
+                ncd=ncd, params=params, sel=sel, eng=eng, loop=loop, scale=scale, meta=(n, nclass, d, hidden, t, inner, epochs, outer, mx))
+
+
+def _blocks(s, calls):
+    from graphslim_amd.engine import BlockSet
+    nclass = s["meta"][1]
+    batches = []
+    for c in range(nclass):
+        rng = np.random.default_rng(100000 + calls + c)
+        batches.append(O.sample_blocks(*s["csr"], rng.permutation(s["idx_train"][s["labels_train"] == c])[:256], [4, 3], rng))
+    return batches, BlockSet.from_batches(batches, 32, 4, 3, DEV)
+
+
+@pytest.mark.parametrize("tag,epoch", [("t1", 0), ("t1", 10), ("t2", 0), ("t2", 10)])
+def test_one_outer_iteration_against_the_oracle(golden_dir, tag, epoch):
+    """sgdd.py:64-95 once (a structure epoch and a feature epoch): matching loss, regulariser value, d total / d X~ and d total / d theta
+    of the IGNR incl. the transport plan, the inference structure, the model after the inner steps."""
+    from graphslim_amd import host as H
+    g = load_golden(golden_dir, "g20_sgdd")
+    s = _golden_setup(g, tag)
+    n, nclass, d, hidden, t, inner, epochs, outer, mx = s["meta"]
+    eng, loop = s["eng"], s["loop"]
+    model = H.init_sgc_params(d, hidden, nclass, t)
+    eng.set_model(model)
+    st = S.SGDDState(torch.from_numpy(s["x"][s["sel"]]), s["params"], torch.from_numpy(s["labels_syn"]), s["ncd"], nclass,
+                     torch.from_numpy(g[f"{tag}_Lx_inv"]), 0.01, 0.01, 0.01, 0.5, s["scale"])
+    st.new_epoch(model)
+    batches, blocks = _blocks(s, 0)
+    eng.set_blocks(blocks)
+    loop.step(epoch)
+    ml, reg, g_x, g_p, adj_in = st.outer_iteration(epoch, batches, torch.from_numpy(s["x"]), torch.from_numpy(s["y"]).long(), inner)
+    assert abs(float(eng.buffer("loss")[0]) - float(ml)) <= 1e-4 * abs(float(ml))
+    assert abs(float(loop.reg.value) - float(reg)) <= 5e-3 * abs(float(reg)), (float(loop.reg.value), float(reg))
+    got = {k: v.cpu() for k, v in loop.gen.views(loop.gen.grad).items()}
+    # the transport plan's gradient is the regulariser's alone; fp32 autograd through torch.svd's backward (1 / (s_i^2 - s_j^2) terms)
+    # is not a usable reference for it: compare with fp64 autograd of the same formula at the same structure
+    p64 = {k: v.double() for k, v in s["params"].items()}
+    P64 = p64["P"].clone().requires_grad_(True)
+    adj64 = S.ignr_structure(torch.from_numpy(s["x"][s["sel"]]).double(), p64, {k: [v[0].double(), v[1].double()] for k, v in S.new_running().items()}, 0.5, True)
+    gP = torch.autograd.grad(s["scale"] * S.opt_loss(adj64, P64, torch.from_numpy(g[f"{tag}_Lx_inv"]).double()), P64)[0]
+    g_p = dict(g_p, P=gP.float())
+    for k, b in g_p.items():
+        if k in ("out_w", "out_b") or (k.endswith("_b") and k[1] in "01"):
+            continue          # the unused head; zero-gradient biases in front of batch-statistics BatchNorm
+        tol = 3e-2 if k == "P" else 2e-3      # P's gradient is the regulariser's alone: fp32 eigen-decompositions of ill-conditioned spectra
+        err = float((got[k] - b.reshape(got[k].shape)).abs().max())
+        assert err <= tol * float(b.abs().max()) + 1e-12, (k, err, float(b.abs().max()))
+    if epoch % 50 >= 10:
+        assert float((loop.gen.dX.cpu() - g_x).abs().max()) <= 2e-3 * float(g_x.abs().max())
+        np.testing.assert_allclose(eng.feat_syn.cpu().numpy(), st.feat_syn.detach().numpy(), atol=2e-5)
+        np.testing.assert_allclose(loop.adj_inner.cpu().numpy(), adj_in.numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_replay_of_the_reference_sgdd_run(golden_dir, tag):
+    """Golden G20: the reference's own SGDD.__init__ + reduce (12 epochs x 2 outer iterations: 10 structure epochs + 2 feature
+    epochs) replayed on the HIP engine + IGNR + regulariser with the reference's RNG draw order and the same deterministic blocks."""
+    from graphslim_amd import host as H
+    g = load_golden(golden_dir, "g20_sgdd")
+    s = _golden_setup(g, tag)
+    n, nclass, d, hidden, t, inner, epochs, outer, mx = s["meta"]
+    eng, loop = s["eng"], s["loop"]
+    calls, losses, regs = 0, [], []
+    for it in range(epochs):
+        eng.set_model(H.init_sgc_params(d, hidden, nclass, t))
+        for _ in range(outer):
+            _, blocks = _blocks(s, calls)
+            calls += nclass
+            eng.set_blocks(blocks)
+            loop.step(it)
+            losses.append(float(eng.buffer("loss")[0]))
+            regs.append(float(loop.reg.value))
+    np.testing.assert_allclose(np.array(losses), g[f"{tag}_losses"], rtol=5e-3)
+    np.testing.assert_allclose(np.array(regs), g[f"{tag}_regs"], rtol=3e-2)
+    dx = np.abs(eng.feat_syn.cpu().numpy() - g[f"{tag}_feat_syn"])
+    assert (dx > 5e-4 + 1e-3 * np.abs(g[f"{tag}_feat_syn"])).mean() <= 0.02 and dx.max() <= 0.02, ((dx > 5e-4).mean(), dx.max())
+    np.testing.assert_allclose(loop.adj_inner.cpu().numpy(), g[f"{tag}_adj"], atol=8e-3)
+    for i, key in enumerate(["c0", "c1", "x0", "x1"]):
+        rv = g[f"{tag}_rv{i}"]
+        drv = np.abs(loop.gen.run[key][1].cpu().numpy() - rv) / (np.abs(rv) + 0.05)
+        assert (drv > 3e-2).mean() <= 0.03 and drv.max() <= 0.2, (key, (drv > 3e-2).mean(), drv.max())
+
+
+def test_sgdd_reduce_api(tmp_path):
+    """`-M sgdd` end to end through the reference's entry points with the shipped configs/sgdd/cora.json (opt_scale 1e-11, ep_ratio
+    0.5, mx_size 200): cli -> get_dataset -> SGDD(...).reduce (checkpoints incl. intermediate evaluation) -> Evaluator.evaluate."""
+    import graphslim  # noqa: F401
+    from graphslim.config import cli
+    from graphslim.condensation import SGDD
+    from graphslim.dataset import get_dataset
+    from graphslim.evaluation.eval_agent import Evaluator
+    from graphslim_amd.host import seed_everything
+    args = cli(["-D", "cora", "-M", "sgdd", "-R", "0.25", "-G", "0", "--epochs", "20", "--outer_loop", "2", "--inner_loop", "2",
+                "--eval_epochs", "40", "--run_eval", "2", "--save_path", str(tmp_path)], standalone_mode=False)
+    assert args.opt_scale == 1e-11 and args.ep_ratio == 0.5 and args.mx_size == 200
+    # the JSON's epochs = 600 fixed the checkpoint schedule before the explicit --epochs 20 was applied (config.py:231-234,385-389,
+    # upstream too): name the checkpoints of the short run
+    args.checkpoints = [9, 19]
+    args.run_inter_eval = 1
+    graph = get_dataset(args.dataset, args)
+    seed_everything(args.seed)
+    agent = SGDD(setting=args.setting, data=graph, args=args)
+    reduced = agent.reduce(graph, verbose=False)
+    n = reduced.feat_syn.shape[0]
+    adj = reduced.adj_syn.cpu()
+    assert tuple(adj.shape) == (n, n) and torch.isfinite(adj).all() and torch.equal(adj, adj.T)
+    assert 0 <= float(adj.min()) and float(adj.max()) < 1 and float(adj.diagonal().abs().max()) == 0
+    assert os.path.exists(os.path.join(str(tmp_path), "reduced_graph", "sgdd", "adj_cora_0.25_1.pt"))
+    P = agent.loop.gen.views()["P"].cpu()
+    assert tuple(P.shape) == (200, n) and float((P - agent.ignr_init["P"]).abs().max()) > 0      # the transport plan was trained
+    mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
+    # 40 Adam steps of size 1e-4 from a dense sigmoid structure: still the noisy early phase of this config (upstream runs 600
+    # epochs; whole-job accuracy: profiles/r02/full_runs_sgdd.txt) — only sanity here, parity is covered by the tests above
+    assert 0.0 <= mean <= 1.0

@@ -3,20 +3,20 @@
 dataset-shaped synthetic graphs: wall time of reduce (all epochs, checkpoints with intermediate evaluation) and of the final
 evaluation, and the accuracy.  usage: full_runs.py dataset:rate[:full][:bf16x6|:bf16x3|:bf16][:msgc][:seedN] [...]   (":full" =
 args.neighbour_mode = "full", the exact 2-hop neighbourhoods of SURVEY 8e mode F, one-transform configs only; ":bf16x6" etc. =
-args.operand_mode; ":msgc" = the MSGC method with configs/msgc/*.json instead of GCond)"""
+args.operand_mode; ":msgc" / ":sgdd" = the MSGC / SGDD method with configs/<method>/*.json instead of GCond)"""
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import graphslim  # noqa: F401
 from graphslim.config import cli
-from graphslim.condensation import GCond, MSGC
+from graphslim.condensation import GCond, MSGC, SGDD
 from graphslim.dataset import get_dataset
 from graphslim.evaluation.eval_agent import Evaluator
 from graphslim_amd.host import seed_everything
 
 for spec in sys.argv[1:]:
     ds, rate, *opt = spec.split(":")
-    method = "msgc" if "msgc" in opt else "gcond"
+    method = "msgc" if "msgc" in opt else ("sgdd" if "sgdd" in opt else "gcond")
     args = cli(["-D", ds, "-M", method, "-R", rate, "-G", "0", "--save_path", tempfile.mkdtemp(prefix="gs_full_")], standalone_mode=False)
     if "full" in opt:
         args.neighbour_mode = "full"
@@ -28,7 +28,7 @@ for spec in sys.argv[1:]:
             args.seed = int(o[4:])
     seed_everything(args.seed)
     t0 = time.time(); graph = get_dataset(args.dataset, args); t1 = time.time()
-    agent = (MSGC if method == "msgc" else GCond)(setting=args.setting, data=graph, args=args)
+    agent = {"msgc": MSGC, "sgdd": SGDD, "gcond": GCond}[method](setting=args.setting, data=graph, args=args)
     reduced = agent.reduce(graph, verbose=False); torch.cuda.synchronize(); t2 = time.time()
     mean, std = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False); t3 = time.time()
     t4 = time.time()
