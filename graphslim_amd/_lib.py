@@ -65,7 +65,7 @@ SYMBOLS = [
     "gs_edge_pair_sum_f32", "gs_bn_scratch_bytes", "gs_bn_relu_fwd_f32", "gs_bn_relu_bwd_f32", "gs_edge_score_f32",
     "gs_edge_scatter_sym_f32", "gs_edge_score_bwd_f32", "gs_segment_sum_rows_f32", "gs_colsum_tall_f32", "gs_mul_f32", "gs_mul_bwd_f32", "gs_mix_heads_f32", "gs_mix_heads_bwd_f32", "gs_sym_sigmoid_f32",
     "gs_sym_sigmoid_bwd_f32", "gs_bn_running_update_f32", "gs_bn_relu_eval_f32", "gs_ot_spectrum_f32", "gs_ot_value_f32",
-    "gs_scale_cols_f32", "gs_ot_divdiff_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
+    "gs_scale_cols_f32", "gs_ot_divdiff_f32", "gs_clamp_finite_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
 ]
 
 
@@ -158,6 +158,7 @@ def lib():
     L.gs_ot_spectrum_f32.argtypes = [vp, i, f, vp, vp]
     L.gs_ot_value_f32.argtypes = [vp, vp, i, f, vp, vp, vp, vp]
     L.gs_scale_cols_f32.argtypes = [vp, vp, i, i, vp, vp]
+    L.gs_clamp_finite_f32.argtypes = [vp, l, f, vp]
     L.gs_ot_divdiff_f32.argtypes = [vp, vp, vp, vp, vp, vp, i, vp]
     L.gs_edge_score_f32.argtypes = [vp, l, vp, vp, l, i, vp, vp]
     L.gs_edge_scatter_sym_f32.argtypes = [vp, vp, vp, l, i, vp, vp, vp]

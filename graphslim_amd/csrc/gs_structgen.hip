@@ -390,6 +390,14 @@ __global__ __launch_bounds__(256) void sg_ot_value_kernel(const float* __restric
   }
 }
 
+// x <- clamp(x, -bound, bound), NaN -> 0
+__global__ void sg_clamp_finite_kernel(float* __restrict__ x, long n, float bound) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  x[i] = v != v ? 0.f : fminf(fmaxf(v, -bound), bound);
+}
+
 // B[i][k] = A[i][k] * v[k]
 __global__ void sg_scale_cols_kernel(const float* __restrict__ A, const float* __restrict__ v, int rows, int cols, float* __restrict__ B) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -609,6 +617,14 @@ extern "C" int gs_ot_divdiff_f32(float* K, const float* lam, const float* g, con
                                  gs_stream_t stream) {
   if (!K || !lam || !g || !gp || !hp || !dtr || n <= 0) GS_FAIL(GS_ERR_ARG, "gs_ot_divdiff_f32: bad argument");
   hipLaunchKernelGGL(sg_ot_divdiff_kernel, dim3(gs_cdiv((long)n * n, 256)), dim3(256), 0, (hipStream_t)stream, K, lam, g, gp, hp, dtr, n);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+extern "C" int gs_clamp_finite_f32(float* x, long n, float bound, gs_stream_t stream) {
+  if (n <= 0) return GS_OK;
+  if (!x || !(bound > 0.f)) GS_FAIL(GS_ERR_ARG, "gs_clamp_finite_f32: bad argument");
+  hipLaunchKernelGGL(sg_clamp_finite_kernel, dim3(gs_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, bound);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

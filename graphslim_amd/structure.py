@@ -416,6 +416,9 @@ class TransportRegulariser:
         gemm(self.Lx_inv, self.T1, self.T2, mx, n, mx, (mx, 1), (n, 1), n)                               # T2 = Lx_inv T1
         gemm(self.T1, self.T2, self.M, n, n, mx, (1, n), (n, 1), n)                                      # M = T1^T T2
         self.Wr.copy_(self.M)
+        # fp32 overflow guard: with a rank-deficient corner (Lx_inv entries up to 1e14 measured) and a near-singular structure the
+        # product can exceed the fp32 range; upstream's eigh would then see inf / NaN and the whole job turns NaN
+        check(L.gs_clamp_finite_f32(ptr(self.Wr), n * n, 1e15, s))       # (the decomposition squares and sums the entries)
         self.eig.eigh(self.Wr, self.mu, self.work, self.info)
         check(L.gs_ot_value_f32(ptr(self.mu), ptr(tr), n, float(scale), ptr(self.dmu), ptr(self.value), ptr(self.acc), s))
         if scale <= 0:
@@ -433,7 +436,10 @@ class TransportRegulariser:
         check(L.gs_ot_divdiff_f32(ptr(self.M), ptr(self.lam), ptr(g), ptr(gp), ptr(hp), ptr(self.dmu[n:]), n, s))
         # d adj += Q K' Q^T = Qr^T K' Qr
         gemm(self.Qr, self.M, self.T, n, n, n, (1, n), (n, 1), n)                                        # T = Qr^T K'
-        gemm(self.T, self.Qr, d_adj, n, n, n, (n, 1), (n, 1), n, beta=1.0)                               # d_adj += T Qr
+        gemm(self.T, self.Qr, self.M, n, n, n, (n, 1), (n, 1), n)                                        # M = T Qr = the term's d / d adj
+        check(L.gs_clamp_finite_f32(ptr(self.M), n * n, 1e30, s))
+        check(L.gs_clamp_finite_f32(ptr(dP), dP.numel(), 1e30, s))
+        check(L.gs_reduce_slabs_f32(ptr(d_adj), ptr(self.M), n * n, 1, n * n, 1.0, s))                   # d_adj += M  (one slab, beta = 1)
         return self.value
 
 

@@ -276,6 +276,9 @@ int gs_ot_spectrum_f32(const float* lam, int n, float sv_eps, float* out, gs_str
 /* value[0] = |trace[0] n - 2 sum sqrt(max(mu_k, 2e-20))| (ignr.py:205-208); acc[0] += value (may be NULL);
  * dmu[k] = scale sign(.) (-1 / sqrt(mu_k)) (0 where clamped), dmu[n] = scale sign(.) n = d value / d trace.  dmu: n + 1 floats. */
 int gs_ot_value_f32(const float* mu, const float* trace, int n, float scale, float* dmu, float* value, double* acc, gs_stream_t stream);
+/* x <- clamp(x, -bound, bound), NaN -> 0: keeps an fp32 overflow of the regulariser's products (a rank-deficient corner's pseudo-
+ * inverse holds reciprocals of rounding-level singular values, 1e14 measured) from reaching the eigen-decomposition as inf / NaN */
+int gs_clamp_finite_f32(float* x, long n, float bound, gs_stream_t stream);
 /* B[i][k] = A[i][k] v[k] */
 int gs_scale_cols_f32(const float* A, const float* v, int rows, int cols, float* B, gs_stream_t stream);
 /* K[i][j] <- F_ij K[i][j] + [i == j] dtr[0] hp[i] with the divided differences F_ij = (g_i - g_j) / (lam_i - lam_j) (g'_i on the
