@@ -136,7 +136,7 @@ class MSGC(GCondBase):
                                         dis_metric=args.dis_metric, seed=args.seed, device=self.device)
         loop = self.loop = MSGCLoop(eng, self.pge_init, self.rows, self.cols, self.batch, lay, feat_init, args.lr_feat, args.lr_adj,
                                     hidden=self.edge_hidden_channels)
-        gen, dev = loop.gen, eng.dev
+        dev = eng.dev
         y_rep = self.y_syn.repeat(B).to(dev)
         best_val = 0
         args.window = args.patience = 20                                                  # :87

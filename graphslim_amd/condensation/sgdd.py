@@ -37,6 +37,7 @@ class SGDDLoop:
         eng.stage_syn_match()                                                     # :69 train_class
         eng.syn_finish()
         if self.reg is not None:                                                  # :70-74 loss += opt_scale * opt_loss
+            # (run on a second stream beside train_class it gains nothing: the library's eigen-decomposition blocks the host, measured)
             self.reg.forward_backward(adj, gen.views()["P"], self.opt_scale, self.d_adj, gen.views(gen.grad)["P"])
         if it % 50 < 10:                                                          # :80-83
             gen.backward(self.d_adj)

@@ -401,7 +401,8 @@ class TransportRegulariser:
 
     def forward_backward(self, adj, P, scale, d_adj, dP):
         """value of opt_loss(adj) (device scalar self.value, also added to self.acc) and, for the term `scale * opt_loss` of the
-        total loss: d_adj += its gradient wrt adj (n', n'), dP = its gradient wrt P (mx, n')."""
+        total loss: d_adj += its gradient wrt adj (n', n'; d_adj = None: left in self.M for a later add_to), dP = its gradient wrt
+        P (mx, n')."""
         L, n, mx = self.L, self.n, self.mx
         s = stream()
         # adj = Q diag(lam) Q^T
@@ -439,8 +440,14 @@ class TransportRegulariser:
         gemm(self.T, self.Qr, self.M, n, n, n, (n, 1), (n, 1), n)                                        # M = T Qr = the term's d / d adj
         check(L.gs_clamp_finite_f32(ptr(self.M), n * n, 1e30, s))
         check(L.gs_clamp_finite_f32(ptr(dP), dP.numel(), 1e30, s))
-        check(L.gs_reduce_slabs_f32(ptr(d_adj), ptr(self.M), n * n, 1, n * n, 1.0, s))                   # d_adj += M  (one slab, beta = 1)
+        if d_adj is not None:
+            self.add_to(d_adj)
         return self.value
+
+    def add_to(self, d_adj):
+        """d_adj += the term's gradient wrt the structure (left in self.M by forward_backward): one slab, beta = 1."""
+        n = self.n
+        check(self.L.gs_reduce_slabs_f32(ptr(d_adj), ptr(self.M), n * n, 1, n * n, 1.0, stream()))
 
 
 def pinv_corner(adj_corner):

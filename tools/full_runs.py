@@ -26,6 +26,8 @@ for spec in sys.argv[1:]:
     for o in opt:
         if o.startswith("seed"):
             args.seed = int(o[4:])
+        if o.startswith("optscale"):          # SGDD: override configs/sgdd/<dataset>.json's opt_scale (":optscale0" = no regulariser)
+            args.opt_scale = float(o[8:])
     seed_everything(args.seed)
     t0 = time.time(); graph = get_dataset(args.dataset, args); t1 = time.time()
     agent = {"msgc": MSGC, "sgdd": SGDD, "gcond": GCond}[method](setting=args.setting, data=graph, args=args)
