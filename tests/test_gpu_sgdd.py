@@ -233,3 +233,29 @@ def test_sgdd_reduce_api(tmp_path):
     # 40 Adam steps of size 1e-4 from a dense sigmoid structure: still the noisy early phase of this config (upstream runs 600
     # epochs; whole-job accuracy: profiles/r02/full_runs_sgdd.txt) — only sanity here, parity is covered by the tests above
     assert 0.0 <= mean <= 1.0
+
+
+@pytest.mark.parametrize("method", ["msgc", "sgdd"])
+def test_inductive_setting_runs_end_to_end(tmp_path, method):
+    """The inductive branch (train sub-graph, local seed ids, sgdd.py:41-43 / msgc.py:71-73; flickr-shaped synthetic graph, fan-outs
+    [15, 8]) of the two structure-generator siblings through cli -> reduce -> Evaluator with the shipped flickr configs."""
+    import graphslim  # noqa: F401
+    from graphslim.config import cli
+    from graphslim.condensation import MSGC, SGDD
+    from graphslim.dataset import get_dataset
+    from graphslim.evaluation.eval_agent import Evaluator
+    from graphslim_amd.host import seed_everything
+    args = cli(["-D", "flickr", "-M", method, "-R", "0.001", "-G", "0", "--epochs", "12", "--outer_loop", "2", "--eval_epochs", "30",
+                "--run_eval", "1", "--save_path", str(tmp_path)], standalone_mode=False)
+    assert args.setting == "ind" and args.ntrans == 2
+    args.checkpoints = [11]
+    args.run_inter_eval = 1
+    graph = get_dataset(args.dataset, args)
+    seed_everything(args.seed)
+    agent = {"msgc": MSGC, "sgdd": SGDD}[method](setting=args.setting, data=graph, args=args)
+    reduced = agent.reduce(graph, verbose=False)
+    n = int(graph.feat_train.shape[0] * 0.001) if method == "msgc" else reduced.feat_syn.shape[0]
+    assert torch.isfinite(reduced.feat_syn).all() and torch.isfinite(reduced.adj_syn).all()
+    assert tuple(reduced.adj_syn.shape) == ((16, n, n) if method == "msgc" else (n, n))
+    mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
+    assert 0.0 <= mean <= 1.0
