@@ -326,3 +326,22 @@ def test_g18_msgc_host_allocation_is_bit_exact(golden_dir, tag):
     assert [hi - lo for lo, hi in lay.ranges] == (B * each).tolist()
     assert np.array_equal(lay.labels_big, np.repeat(np.arange(nclass), B * each))
     assert np.array_equal(np.tile(y_syn, B), g[f"{tag}_labels_out"])
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_g20_ignr_draw_order(golden_dir, tag):
+    """SGDD's RNG draw order on the host (ignr.py:95-149: six Linear, P, `output`, then reset_parameters() over every Linear):
+    the `output` head is drawn LAST and never receives a gradient, so its final value in the reference's run is its initial
+    draw — bit-exact here; P moves by at most lr per structure-epoch step from its U(0, 1) draw."""
+    g = load_golden(golden_dir, "g20_sgdd")
+    n, nclass, d, hidden, t, inner, epochs, outer, mx = [int(v) for v in g[f"{tag}_meta"]]
+    H.seed_everything(1)
+    labels_syn, _, _ = H.generate_labels_syn(g[f"{tag}_y"][g[f"{tag}_idx_train"]], 0.5)
+    p = H.init_ignr_params(d, len(labels_syn), mx)
+    names = list(g[f"{tag}_param_names"])
+    np.testing.assert_array_equal(p["out_w"].numpy(), g[f"{tag}_p{names.index('output.weight')}"])
+    np.testing.assert_array_equal(p["out_b"].numpy(), g[f"{tag}_p{names.index('output.bias')}"])
+    P_final = g[f"{tag}_p{names.index('P')}"]
+    steps = 10 * outer                                  # structure epochs: it % 50 < 10
+    assert p["P"].shape == P_final.shape and float(np.abs(p["P"].numpy() - P_final).max()) <= 0.01 * steps * 1.25
+    assert 0 <= float(p["P"].min()) and float(p["P"].max()) <= 1
