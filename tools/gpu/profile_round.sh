@@ -14,7 +14,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- pyt
 cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/bench_arxiv_kernel_stats.csv
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python3 bench.py --no-cpu-baseline --sustain-s 0 > $O/bench_default_under_rocprof.json 2>/dev/null
 cp $(ls $O/kt2/*/*kernel_stats.csv | head -1) $O/bench_default_kernel_stats.csv; rm -rf $O/kt2
-f=$(ls $O/kt/*/*kernel_trace.csv | head -1); python3 tools/timeline_csv.py $f 190 > $O/timeline_f32_noreuse.txt 2>/dev/null
+f=$(ls $O/kt/*/*kernel_trace.csv | head -1); python3 tools/timeline_csv.py $f 30 > $O/timeline_f32_noreuse.txt 2>/dev/null; python3 tools/timeline_csv.py $f 190 > $O/timeline_f32_reuse.txt 2>/dev/null
 rm -rf $O/kt
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_bench_$c -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain-s 0 > /dev/null 2>&1
