@@ -345,3 +345,40 @@ def test_g20_ignr_draw_order(golden_dir, tag):
     steps = 10 * outer                                  # structure epochs: it % 50 < 10
     assert p["P"].shape == P_final.shape and float(np.abs(p["P"].numpy() - P_final).max()) <= 0.01 * steps * 1.25
     assert 0 <= float(p["P"].min()) and float(p["P"].max()) <= 1
+
+
+@pytest.mark.parametrize("counts,B,seed", [([1, 1, 1], 2, 0), ([1, 4, 2], 3, 1), ([3, 3, 3, 3], 2, 2), ([2, 7], 4, 3), ([5], 2, 4),
+                                            ([1, 9, 1, 6, 2], 2, 5)])
+def test_msgc_edge_lists_numpy_form_equals_the_torch_restatement(counts, B, seed):
+    """msgc.py:178-222 in the product's numpy form against the oracle's line-by-line torch restatement (itself pinned by G18) on
+    label layouts the golden does not hold: singleton classes (no partner inside the class), one class only, many ties — same
+    randperm draws, bit-equal edge lists."""
+    import torch
+    from oracle import msgc_oracle as M
+    y = np.repeat(np.arange(len(counts)), counts)
+    torch.manual_seed(seed)
+    a = H.msgc_edges(y, len(counts), B)
+    torch.manual_seed(seed)
+    b = M.msgc_edges(torch.from_numpy(y), len(counts), B)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v.numpy())
+    rows, cols, batch = a
+    assert np.all(rows != cols) and len(rows) % 2 == 0
+    # both directions of every link are present within each structure
+    for s in range(B):
+        m = batch == s
+        assert set(zip(rows[m].tolist(), cols[m].tolist())) == set(zip(cols[m].tolist(), rows[m].tolist()))
+
+
+@pytest.mark.parametrize("n_syn,seed", [(7, 0), (12, 1), (40, 2), (41, 3)])
+def test_msgc_label_allocation_equals_the_torch_restatement(n_syn, seed):
+    """msgc.py:41-64 (float32 torch arithmetic upstream) in numpy float32 against the oracle's torch form on skewed class counts."""
+    from oracle import msgc_oracle as M
+    rng = np.random.default_rng(seed)
+    nclass = 5
+    lab = rng.choice(nclass, size=300, p=[0.5, 0.25, 0.15, 0.07, 0.03])
+    y, each = H.msgc_labels(lab, n_syn, nclass)
+    y2, each2 = M.msgc_labels(lab, n_syn, nclass)
+    np.testing.assert_array_equal(y, y2.numpy())
+    np.testing.assert_array_equal(each, each2.numpy())
+    assert each.sum() == n_syn and each.min() >= 1
