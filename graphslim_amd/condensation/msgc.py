@@ -58,7 +58,7 @@ class MSGCLoop:
             gen.adam_step()
         else:
             gen.fold(self.d_feat_big, gen.dX)                                     # through the B copies of X~ ...
-            gen.backward(self.d_adj, accumulate_dx=True)                          # ... plus through the edge MLP
+            gen.backward(self.d_adj, accumulate_dx=True, param_grads=False)                          # ... plus through the edge MLP
             self.step_x += 1
             adam_step(x, gen.dX, self.m_x, self.v_x, self.lr_feat, self.step_x)
             gen.tile(x, eng.feat_syn)

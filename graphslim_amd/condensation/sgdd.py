@@ -44,7 +44,7 @@ class SGDDLoop:
             gen.adam_step()
         else:
             gen.dX.copy_(self.d_feat)                                             # the direct feature gradient (device copy) ...
-            gen.backward(self.d_adj, accumulate_dx=True)                          # ... plus the one through the structure
+            gen.backward(self.d_adj, accumulate_dx=True, param_grads=False)                          # ... plus the one through the structure
             self.step_x += 1
             adam_step(x, gen.dX, self.m_x, self.v_x, self.lr_feat, self.step_x)
         self.adj_inner = gen.forward(x, train=False)                              # :85 self.pge.inference (eval-mode BatchNorm)

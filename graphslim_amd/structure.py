@@ -114,30 +114,36 @@ class EdgeStructureGenerator:
                                         stream()))
         return self.adj
 
-    def backward(self, d_adj, accumulate_dx=False):
+    def backward(self, d_adj, accumulate_dx=False, param_grads=True):
         """d loss / d adj [B n', B n'] of the LAST forward -> self.grad (flat, parameter order) and self.dX [n', d]
-        (accumulate_dx: added to what self.dX already holds — the direct feature gradient folded over the B copies)."""
+        (accumulate_dx: added to what self.dX already holds — the direct feature gradient folded over the B copies).
+        param_grads = False (feature epochs: only X~ is stepped, msgc.py:105-108, and zero_grad() discards the rest unread): the
+        weight / bias gradient products are skipped; the BatchNorm sums the input gradient needs are still formed."""
         L, h, d, E, n = self.L, self.h, self.d, self.E, self.lay.n
         w0, b0, g1, be1, w1, b1, g2, be2, w2, b2 = self.views()
         gw0, gb0, gg1, gbe1, gw1, gb1, gg2, gbe2, gw2, gb2 = self.views(self.grad)
         X = self.X
         check(L.gs_edge_score_bwd_f32(ptr(d_adj), ptr(self.pr), ptr(self.pc), ptr(self.s), ptr(w2), E, self.lay.n_big, h,
                                       ptr(self.dlogit), ptr(self.dA), h, stream()))
-        gemm_tn_splitk(self.A2, h, self.dlogit, 1, gw2, h, 1, E)                          # dw2 = A2^T dlogit
-        check(L.gs_colsum_tall_f32(ptr(self.dlogit), 1, E, 1, ptr(gb2), ptr(self.scratch), stream()))
+        if param_grads:
+            gemm_tn_splitk(self.A2, h, self.dlogit, 1, gw2, h, 1, E)                      # dw2 = A2^T dlogit
+            check(L.gs_colsum_tall_f32(ptr(self.dlogit), 1, E, 1, ptr(gb2), ptr(self.scratch), stream()))
         check(L.gs_bn_relu_bwd_f32(ptr(self.dA), h, ptr(self.A2), h, ptr(self.E2), h, E, h, ptr(self.mu2), ptr(self.is2), ptr(g2),
                                    ptr(self.dA), h, ptr(gg2), ptr(gbe2), ptr(self.scratch), stream()))         # dA := dE2
-        gemm_tn_splitk(self.dA, h, self.A1, h, gw1, h, h, E)                              # dW1 = dE2^T A1
-        check(L.gs_colsum_tall_f32(ptr(self.dA), h, E, h, ptr(gb1), ptr(self.scratch), stream()))
+        if param_grads:
+            gemm_tn_splitk(self.dA, h, self.A1, h, gw1, h, h, E)                          # dW1 = dE2^T A1
+            check(L.gs_colsum_tall_f32(ptr(self.dA), h, E, h, ptr(gb1), ptr(self.scratch), stream()))
         w1t = w1.t().contiguous()                                                        # (a 256 x 256 copy: B with contiguous k -> row-panel kernel)
         gemm(self.dA, w1t, self.E2, E, h, h, (h, 1), (1, h), h)                           # dA1 = dE2 W1   (E2 is free now)
         check(L.gs_bn_relu_bwd_f32(ptr(self.E2), h, ptr(self.A1), h, ptr(self.E0), h, E, h, ptr(self.mu1), ptr(self.is1), ptr(g1),
                                    ptr(self.E2), h, ptr(gg1), ptr(gbe1), ptr(self.scratch), stream()))         # E2 := dE0
-        check(L.gs_colsum_tall_f32(ptr(self.E2), h, E, h, ptr(gb0), ptr(self.scratch), stream()))
+        if param_grads:
+            check(L.gs_colsum_tall_f32(ptr(self.E2), h, E, h, ptr(gb0), ptr(self.scratch), stream()))
         for seg, out in ((self.seg_r, self.dU), (self.seg_c, self.dV)):
             check(L.gs_segment_sum_rows_f32(ptr(self.E2), h, ptr(seg[0]), ptr(seg[1]), n, h, ptr(out), h, stream()))
-        gemm(self.dU, X, gw0, h, d, n, (1, h), (d, 1), 2 * d)                             # dW0[:, :d] = dU^T X
-        gemm(self.dV, X, gw0[:, d:], h, d, n, (1, h), (d, 1), 2 * d)                      # dW0[:, d:] = dV^T X
+        if param_grads:
+            gemm(self.dU, X, gw0, h, d, n, (1, h), (d, 1), 2 * d)                         # dW0[:, :d] = dU^T X
+            gemm(self.dV, X, gw0[:, d:], h, d, n, (1, h), (d, 1), 2 * d)                  # dW0[:, d:] = dV^T X
         gemm(self.dU, w0, self.dX, n, d, h, (h, 1), (2 * d, 1), d, beta=1.0 if accumulate_dx else 0.0)   # dX (+)= dU W0[:, :d] + dV W0[:, d:]
         gemm(self.dV, w0[:, d:], self.dX, n, d, h, (h, 1), (2 * d, 1), d, beta=1.0)
         return self.grad, self.dX
@@ -275,9 +281,10 @@ class IGNRGenerator:
                                         ptr(p[key + "_g"]), ptr(dX), self.h, ptr(g[key + "_g"]), ptr(g[key + "_be"]), ptr(self.scratch),
                                         stream()))
 
-    def backward(self, d_adj, accumulate_dx=False):
+    def backward(self, d_adj, accumulate_dx=False, param_grads=True):
         """d loss / d adj [n', n'] of the LAST training-mode forward -> self.grad (P's slot is left alone: the transport plan only
-        enters the regulariser) and self.dX."""
+        enters the regulariser) and self.dX.  param_grads = False (feature epochs, sgdd.py:80-83): the weight / bias gradient
+        products are skipped."""
         assert self.trained, "backward needs a training-mode forward"
         L, h, d, E, n = self.L, self.h, self.d, self.E, self.n
         p, g = self.views(), self.views(self.grad)
@@ -287,37 +294,43 @@ class IGNRGenerator:
         # heads: dZ1 = (1 - ep) de3 (x) w_x2 -> G1 ; dC1 (direct) = ep de3 (x) w_c2 -> G2
         check(L.gs_mix_heads_bwd_f32(ptr(self.de3), ptr(p["x2_w"]), 1.0 - self.ep, ptr(p["c2_w"]), self.ep, E, h, ptr(self.G1), ptr(self.G2),
                                      ptr(self.sx), ptr(self.sc), stream()))
-        gemm_tn_splitk(self.Z1, h, self.sx, 1, g["x2_w"], h, 1, E)                           # d w_x2 = Z1^T ((1 - ep) de3)
-        gemm_tn_splitk(self.C1, h, self.sc, 1, g["c2_w"], h, 1, E)                           # d w_c2 = C1^T (ep de3)
-        tall(self.sx, 1, g["x2_b"])
-        tall(self.sc, 1, g["c2_b"])
+        if param_grads:
+            gemm_tn_splitk(self.Z1, h, self.sx, 1, g["x2_w"], h, 1, E)                       # d w_x2 = Z1^T ((1 - ep) de3)
+            gemm_tn_splitk(self.C1, h, self.sc, 1, g["c2_w"], h, 1, E)                       # d w_c2 = C1^T (ep de3)
+            tall(self.sx, 1, g["x2_b"])
+            tall(self.sc, 1, g["c2_b"])
         # coupling 1: Z1 = X1 * C1
         check(L.gs_mul_bwd_f32(ptr(self.G1), ptr(self.X1), ptr(self.C1), E * h, ptr(self.G1), ptr(self.G2), 1, stream()))   # G1 = dX1, G2 = dC1
         # x tower, layer 1
         self._bn_bwd("x1", self.G1, self.X1, self.X1p, p, g, self.G1)                        # G1 = dX1p
-        gemm_tn_splitk(self.G1, h, self.Z0, h, g["x1_w"], h, h, E)
-        tall(self.G1, h, g["x1_b"])
+        if param_grads:
+            gemm_tn_splitk(self.G1, h, self.Z0, h, g["x1_w"], h, h, E)
+            tall(self.G1, h, g["x1_b"])
         w = p["x1_w"].t().contiguous()
         gemm(self.G1, w, self.G3, E, h, h, (h, 1), (1, h), h)                                # G3 = dZ0 = dX1p W_x1
         # c tower, layer 1
         self._bn_bwd("c1", self.G2, self.C1, self.C1p, p, g, self.G2)                        # G2 = dC1p
-        gemm_tn_splitk(self.G2, h, self.C0, h, g["c1_w"], h, h, E)
-        tall(self.G2, h, g["c1_b"])
+        if param_grads:
+            gemm_tn_splitk(self.G2, h, self.C0, h, g["c1_w"], h, h, E)
+            tall(self.G2, h, g["c1_b"])
         w = p["c1_w"].t().contiguous()
         gemm(self.G2, w, self.G1, E, h, h, (h, 1), (1, h), h)                                # G1 = dC0 (through layer 1)
         # coupling 0: Z0 = X0 * C0
         check(L.gs_mul_bwd_f32(ptr(self.G3), ptr(self.X0), ptr(self.C0), E * h, ptr(self.G3), ptr(self.G1), 1, stream()))   # G3 = dX0, G1 = dC0
         # x tower, layer 0 (input: the constant grid)
-        self._bn_bwd("x0", self.G3, self.X0, self.X0p, p, g, self.G3)
-        gemm_tn_splitk(self.G3, h, self.grid, 2, g["x0_w"], h, 2, E)
-        tall(self.G3, h, g["x0_b"])
+        if param_grads:        # (the grid is a constant input: nothing flows further down this tower)
+            self._bn_bwd("x0", self.G3, self.X0, self.X0p, p, g, self.G3)
+            gemm_tn_splitk(self.G3, h, self.grid, 2, g["x0_w"], h, 2, E)
+            tall(self.G3, h, g["x0_b"])
         # c tower, layer 0: pre-activation = U[i] + V[j] + b
         self._bn_bwd("c0", self.G1, self.C0, self.C0p, p, g, self.G1)
-        tall(self.G1, h, g["c0_b"])
+        if param_grads:
+            tall(self.G1, h, g["c0_b"])
         for seg, out in ((self.seg_r, self.dU), (self.seg_c, self.dV)):
             check(L.gs_segment_sum_rows_f32(ptr(self.G1), h, ptr(seg[0]), ptr(seg[1]), n, h, ptr(out), h, stream()))
-        gemm(self.dU, X, g["c0_w"], h, d, n, (1, h), (d, 1), 2 * d)
-        gemm(self.dV, X, g["c0_w"][:, d:], h, d, n, (1, h), (d, 1), 2 * d)
+        if param_grads:
+            gemm(self.dU, X, g["c0_w"], h, d, n, (1, h), (d, 1), 2 * d)
+            gemm(self.dV, X, g["c0_w"][:, d:], h, d, n, (1, h), (d, 1), 2 * d)
         gemm(self.dU, p["c0_w"], self.dX, n, d, h, (h, 1), (2 * d, 1), d, beta=1.0 if accumulate_dx else 0.0)
         gemm(self.dV, p["c0_w"][:, d:], self.dX, n, d, h, (h, 1), (2 * d, 1), d, beta=1.0)
         return self.grad, self.dX

@@ -145,8 +145,8 @@ def test_one_outer_iteration_against_the_oracle(golden_dir, tag, epoch):
     assert abs(float(eng.buffer("loss")[0]) - float(loss)) <= 1e-4 * abs(float(loss))
     got_p = [v.cpu() for v in loop.gen.views(loop.gen.grad)]
     for i, (a, b) in enumerate(zip(got_p, g_p)):
-        if i in (1, 5):
-            continue          # zero-gradient biases in front of batch-statistics BatchNorm
+        if i in (1, 5) or epoch % 50 >= 10:
+            continue          # zero-gradient biases in front of batch-statistics BatchNorm; feature epochs skip the unread parameter gradients
         np.testing.assert_allclose(a.numpy(), b.reshape(a.shape).numpy(), atol=1e-3 * float(b.abs().max()) + 1e-9, err_msg=f"theta {i}")
     if epoch % 50 >= 10:
         np.testing.assert_allclose(loop.gen.dX.cpu().numpy(), g_x.numpy(), atol=1e-3 * float(g_x.abs().max()))
@@ -279,8 +279,8 @@ def test_block_products_equal_the_dense_products(golden_dir, tag):
     np.testing.assert_allclose(a[5].numpy(), b[5].numpy(), atol=1e-6)
 
 
-@pytest.mark.parametrize("name,B", [("cora", 16), ("cora-r0.25", 16)])
-def test_full_size_iteration_against_the_oracle(name, B):
+@pytest.mark.parametrize("name,B,epoch", [("cora", 16, 10), ("cora", 16, 0), ("cora-r0.25", 16, 10)])
+def test_full_size_iteration_against_the_oracle(name, B, epoch):
     """MSGC at the reference's cora configuration at FULL size (configs/msgc/cora.json: T = 1, batch_adj = 16; d = 1 433, C = 7,
     n' = 70 / 35 -> 1 120 / 560 rows, ~15 k / 7 k directed edges through the width-256 edge MLP) on blocks drawn by the HIP sampler:
     those very blocks go to oracle.MSGCState — matching loss 1e-4, d loss / d X~ and d loss / d theta of the edge MLP 1e-3 of the
@@ -310,18 +310,21 @@ def test_full_size_iteration_against_the_oracle(name, B):
     loop = MSGCLoop(eng, params, rows, cols, batch, lay, x0, 1e-4, 1e-4)
     model = H.init_sgc_params(d, p["hidden"], nclass, 1)
     eng.set_model(model)
-    loop.step(10)                                               # a feature epoch: every gradient is formed
+    loop.step(epoch)                                            # a feature epoch (d / d X~, the Adam step) or a structure epoch (d / d theta)
     batches = bench.blocks_to_batches(eng.get_blocks())         # the block set this iteration ran on
     st = M.MSGCState(x0, params, torch.from_numpy(y_syn), torch.from_numpy(each), nclass,
                      *(torch.from_numpy(a) for a in (rows, cols, batch)), B, 1e-4, 1e-4, 0.01, model)
-    loss, g_x, g_p, adj_in = st.outer_iteration(10, batches, data.bench_feat, data.bench_labels.long(), inner)
+    loss, g_x, g_p, adj_in = st.outer_iteration(epoch, batches, data.bench_feat, data.bench_labels.long(), inner)
     got = float(eng.buffer("loss")[0])
     assert abs(got - float(loss)) <= 1e-4 * abs(float(loss)), (got, float(loss))
+    if epoch % 50 < 10:
+        for i, (a, b) in enumerate(zip((v.cpu() for v in loop.gen.views(loop.gen.grad)), g_p)):
+            if i in (1, 5):
+                continue
+            assert float((a - b.reshape(a.shape)).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-12, (i, float((a - b.reshape(a.shape)).abs().max()), float(b.abs().max()))
+        assert torch.equal(loop.x.cpu(), x0)                    # X~ is not stepped in a structure epoch
+        return
     assert float((loop.gen.dX.cpu() - g_x).abs().max()) <= 1e-3 * float(g_x.abs().max())
-    for i, (a, b) in enumerate(zip((v.cpu() for v in loop.gen.views(loop.gen.grad)), g_p)):
-        if i in (1, 5):
-            continue
-        assert float((a - b.reshape(a.shape)).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-12, (i, float((a - b.reshape(a.shape)).abs().max()), float(b.abs().max()))
     # lr 1e-4 Adam step on X~: entries whose gradient is above the fp32 noise floor move identically
     big = g_x.abs() > 1e-3 * g_x.abs().max()
     assert float((loop.x.cpu() - st.feat_syn.detach())[big].abs().max()) <= 2e-6

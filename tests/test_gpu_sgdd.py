@@ -161,8 +161,8 @@ def test_one_outer_iteration_against_the_oracle(golden_dir, tag, epoch):
     gP = torch.autograd.grad(s["scale"] * S.opt_loss(adj64, P64, torch.from_numpy(g[f"{tag}_Lx_inv"]).double()), P64)[0]
     g_p = dict(g_p, P=gP.float())
     for k, b in g_p.items():
-        if k in ("out_w", "out_b") or (k.endswith("_b") and k[1] in "01"):
-            continue          # the unused head; zero-gradient biases in front of batch-statistics BatchNorm
+        if k in ("out_w", "out_b") or (k.endswith("_b") and k[1] in "01") or (epoch % 50 >= 10 and k != "P"):
+            continue          # the unused head; zero-gradient biases in front of batch-statistics BatchNorm; feature epochs skip the unread parameter gradients
         tol = 3e-2 if k == "P" else 2e-3      # P's gradient is the regulariser's alone: fp32 eigen-decompositions of ill-conditioned spectra
         err = float((got[k] - b.reshape(got[k].shape)).abs().max())
         assert err <= tol * float(b.abs().max()) + 1e-12, (k, err, float(b.abs().max()))
