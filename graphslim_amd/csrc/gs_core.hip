@@ -14,7 +14,7 @@ void gs_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gs_last_error(void) { return g_err; }
-extern "C" int gs_version(void) { return 100; }
+extern "C" int gs_version(void) { return 200; }   // 100 * round + revision: round 2 added the panel / edge kernels, operand modes, the structure generators
 
 // ------------------------------------------------------------------------------------------------
 // CSR SpMM:  Y[i,:] = sum_e val[e] * X[col[e],:]
