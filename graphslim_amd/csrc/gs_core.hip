@@ -224,6 +224,50 @@ __global__ void gs_norm_bwd_dr_kernel(const float* __restrict__ adj, const float
   }
 }
 
+// Large n (a block-diagonal batch of structures: MSGC, 7 264 rows at ogbn-arxiv): the kernel above walks column i with stride n
+// (0.88 ms measured at n = 7 264).  Here the row part runs one workgroup per row and the column part as per-chunk partial sums
+// with the columns across the lanes (coalesced), added up in chunk order: ddeg_i = -r_i^3 / 2 (row_i + sum_c part[c][i]).
+constexpr int GS_NORM_CHUNKS = 32;
+
+__global__ __launch_bounds__(256) void gs_norm_bwd_rows_kernel(const float* __restrict__ adj, const float* __restrict__ r,
+                                                               const float* __restrict__ dA, int n, float* __restrict__ rowpart) {
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < n; j += blockDim.x)
+    s += dA[(long)i * n + j] * (adj[(long)i * n + j] + (i == j ? 1.f : 0.f)) * r[j];
+  __shared__ float red[4];
+  s = gs_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) rowpart[i] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void gs_norm_bwd_cols_kernel(const float* __restrict__ adj, const float* __restrict__ r,
+                                                               const float* __restrict__ dA, int n, float* __restrict__ part) {
+  __shared__ float sh[4][64];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int per = gs_cdiv(n, GS_NORM_CHUNKS);
+  const int j0 = blockIdx.y * per, j1 = j0 + per < n ? j0 + per : n;
+  float s = 0.f;
+  if (i < n)
+    for (int j = j0 + rl; j < j1; j += 4) s += dA[(long)j * n + i] * (adj[(long)j * n + i] + (i == j ? 1.f : 0.f)) * r[j];
+  sh[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && i < n) {
+    const int c = threadIdx.x & 63;
+    part[(long)blockIdx.y * n + i] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+  }
+}
+
+__global__ void gs_norm_bwd_ddeg_kernel(const float* __restrict__ r, const float* __restrict__ part, int n, float* __restrict__ ddeg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = ddeg[i];                       // the row part
+  for (int c = 0; c < GS_NORM_CHUNKS; ++c) s += part[(long)c * n + i];
+  const float ri = r[i];
+  ddeg[i] = -0.5f * s * ri * ri * ri;
+}
+
 __global__ void gs_norm_bwd_out_kernel(const float* __restrict__ r, const float* __restrict__ dA,
                                        const float* __restrict__ ddeg, int n, float* __restrict__ dadj) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -240,7 +284,13 @@ extern "C" int gs_dense_gcn_norm_bwd(const float* adj, const float* r, const flo
   // d deg is staged in the first n floats of d_adj's last row region?  no: use d_adj itself as scratch is unsafe;
   // the [n] vector lives at the tail of r (caller allocates r with 2n floats: r[0..n) = deg^-1/2, r[n..2n) scratch).
   float* ddeg = const_cast<float*>(r) + n;
-  hipLaunchKernelGGL(gs_norm_bwd_dr_kernel, dim3(n), dim3(256), 0, s, adj, r, d_adj_norm, n, ddeg);
+  if (n > 2048) {      // d_adj's head holds the column partials until ddeg is complete (d_adj is written last, below)
+    hipLaunchKernelGGL(gs_norm_bwd_rows_kernel, dim3(n), dim3(256), 0, s, adj, r, d_adj_norm, n, ddeg);
+    hipLaunchKernelGGL(gs_norm_bwd_cols_kernel, dim3(gs_cdiv(n, 64), GS_NORM_CHUNKS), dim3(256), 0, s, adj, r, d_adj_norm, n, d_adj);
+    hipLaunchKernelGGL(gs_norm_bwd_ddeg_kernel, dim3(gs_cdiv(n, 256)), dim3(256), 0, s, r, (const float*)d_adj, n, ddeg);
+  } else {
+    hipLaunchKernelGGL(gs_norm_bwd_dr_kernel, dim3(n), dim3(256), 0, s, adj, r, d_adj_norm, n, ddeg);
+  }
   hipLaunchKernelGGL(gs_norm_bwd_out_kernel, dim3(gs_cdiv((long)n * n, 256)), dim3(256), 0, s, r, d_adj_norm, ddeg, n,
                      d_adj);
   GS_LAUNCH_CHECK();

@@ -161,9 +161,10 @@ def test_gather_rows(E):
     assert torch.equal(out.cpu(), X[idx.long()])
 
 
-def test_dense_gcn_norm_fwd_bwd(E):
+@pytest.mark.parametrize("n", [93, 2300])
+def test_dense_gcn_norm_fwd_bwd(E, n):
+    """n = 2 300 takes the large-n backward (row part + per-chunk column partials: a block-diagonal batch of structures, MSGC)."""
     torch.manual_seed(0)
-    n = 93
     adj = torch.rand(n, n)
     adj = ((adj + adj.T) / 2).fill_diagonal_(0)
     adj[5, :] = 0
