@@ -8,6 +8,10 @@ e = _SymEig.get()
 has = hasattr(e.solver, "rocsolver_ssyevdj")
 print("ssyevdj available:", has)
 e.solver.rocsolver_ssyevdj.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+import os
+if os.environ.get("GS_EIG_PREALLOC"):
+    e.blas.rocblas_set_device_memory_size.argtypes = [C.c_void_p, C.c_size_t]
+    print("rocblas_set_device_memory_size ->", e.blas.rocblas_set_device_memory_size(e.handle, int(os.environ["GS_EIG_PREALLOC"]) << 20))
 for n in (70, 153, 454):
     a = torch.randn(n, n, device="cuda"); a = (a + a.T) / 2
     lam, work, info = torch.empty(n, device="cuda"), torch.empty(n, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
