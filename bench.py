@@ -25,81 +25,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {
-    # name: (dataset shape, rate, ntrans, hidden, pge_hidden, outer_loop, inner_loop, lr_feat, lr_adj, fan-outs)
-    "ogbn-arxiv": ("ogbn-arxiv", 0.005, 2, 256, 256, 20, 3, 0.01, 0.01, (10, 5)),
-    "cora": ("cora", 0.5, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
-    # BASELINE.json configs[4]: inductive, train sub-graph, wide rows (d = 602) and fan-outs [15, 8]: the gather stress case
-    "reddit": ("reddit", 0.001, 1, 256, 256, 10, 1, 0.1, 0.1, (15, 8)),
-    # the other BASELINE.json configs (parity-test cases at FULL size, tests/test_gpu_fullsize.py; not bench lines)
-    "cora-r0.25": ("cora", 0.25, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
-    # n' = 140 with the Planetoid PGE width 128: the generated / fused PGE forms at N = 128 (4 MFMA column tiles per wave)
-    "cora-r1.0": ("cora", 1.0, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
-    "citeseer-r0.005": ("citeseer", 0.005, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
-    "pubmed-r0.005": ("pubmed", 0.005, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
-}
-
-
-def build_problem(name, seed=1, scale=1.0):
-    from graphslim_amd.dataset.loader import TransAndInd, splits
-    from graphslim_amd.dataset.synthetic import make_raw
-    from graphslim_amd.host import generate_labels_syn, normalize_adj_sparse
-    shape, rate, T, hidden, ph, outer, inner, lrf, lra, fan = WORKLOADS[name]
-    raw = splits(make_raw(shape, seed=seed, scale=scale))
-    data = TransAndInd(raw, shape)
-    labels_train = data.labels_train.numpy()
-    labels_syn, ncd, ranges = generate_labels_syn(labels_train, rate)
-    setting = "ind" if shape in ("reddit", "flickr") else "trans"
-    if setting == "ind":      # gcond.py:25-27: the inductive setting condenses the TRAIN sub-graph
-        csr = normalize_adj_sparse(data.adj_train)
-        data.bench_feat, data.bench_labels, data.bench_n = data.feat_train, data.labels_train, data.feat_train.shape[0]
-    else:
-        csr = normalize_adj_sparse(data.adj_full)
-        data.bench_feat, data.bench_labels, data.bench_n = data.feat_full, data.labels_full, data.num_nodes
-    pools = data.class_pools(setting)
-    return dict(data=data, labels_syn=labels_syn, ncd=ncd, ranges=[tuple(ranges[c]) for c in range(data.nclass)], csr=csr,
-                pools=pools, T=T, hidden=hidden, ph=ph, outer=outer, inner=inner, lrf=lrf, lra=lra, fan=fan, rate=rate, name=name)
-
-
-def make_engine(p, device, bcap=256):
-    from graphslim_amd.engine import EngineShapes, GCondEngine
-    d = p["data"].feat_full.shape[1]
-    sh = EngineShapes(p["data"].bench_n, d, p["data"].nclass, len(p["labels_syn"]), p["T"], p["hidden"], p["ph"], bcap,
-                      p["fan"][0], p["fan"][1])
-    cls_ptr = np.concatenate([[0], np.cumsum([len(q) for q in p["pools"]])])
-    eng = GCondEngine(sh, p["data"].bench_feat, p["csr"], cls_ptr, np.concatenate(p["pools"]), p["labels_syn"], p["ranges"],
-                      lr_feat=p["lrf"], lr_adj=p["lra"], lr_model=0.01, inner_loop=p["inner"], seed=1, device=device)
-    return eng
-
-
-def init_state(p, eng, seed=1):
-    """X~ = features of randomly picked train nodes per class (sparsification/random.py:9-17); PGE as nn.Linear/BN default."""
-    from graphslim_amd.host import init_pge_params, random_init_indices
-    np.random.seed(seed)
-    torch.manual_seed(seed)
-    ids = p["data"].idx_train.numpy() if p["data"].bench_n == p["data"].num_nodes else np.arange(p["data"].bench_n)
-    sel = random_init_indices(ids, p["data"].labels_train.numpy(), p["ncd"])
-    eng.set_feat(p["data"].bench_feat[sel])
-    eng.set_pge(init_pge_params(p["data"].feat_full.shape[1], p["ph"]))
-
-
-def new_model(p, eng):
-    from graphslim_amd.host import init_sgc_params
-    d = p["data"].feat_full.shape[1]
-    theta = init_sgc_params(d, p["hidden"], p["data"].nclass, p["T"])
-    eng.set_model(theta)
-    return theta
-
-
-def run_steps(p, eng, k, cycle_len):
-    """k outer iterations with the job's own mix and cadence: the first 20 % are PGE-update iterations (epoch % 50 < 10,
-    gcond.py:58-61), the rest feature-update iterations, and theta is re-drawn and uploaded every `outer_loop` iterations —
-    an epoch of the real job is `outer_loop` consecutive iterations on one theta (gcond.py:42-47)."""
-    for i in range(k):
-        if i % p["outer"] == 0:
-            new_model(p, eng)
-        eng.outer_step(0 if i * 5 < cycle_len else 10)
-
+from graphslim_amd.workloads import (WORKLOADS, blocks_to_batches, build_problem, init_state, make_engine, new_model,  # noqa: E402,F401
+                                      run_steps)
 
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "pmc_panel_summary.json")
 
@@ -162,35 +89,6 @@ def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20, span=None):
             "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
             "isolated_launch_us": round(iso * 1e6, 2),
             "isolated_span_us": round(iso_span_ms / max(iso_span_k, 1) * 1e3, 2) if iso_span_k else None}
-
-
-def blocks_to_batches(blk):
-    f = {k: getattr(blk, k).cpu().numpy() for k in blk.FIELDS}
-    out = []
-    for c in range(blk.C):
-        B, n1 = int(f["n_seed"][c]), int(f["n1"][c])
-        nid1 = f["nid1"][c, :n1]
-        v0, c0g = f["val0"][c, :n1].reshape(-1), f["col0"][c, :n1].reshape(-1)
-        keep = v0 != 0
-        rows0 = np.repeat(np.arange(n1), blk.f2)[keep]
-        uniq, inv = np.unique(np.concatenate([nid1, c0g[keep]]), return_inverse=True)
-        # targets first, then the new sources in first-seen order
-        pos = -np.ones(int(uniq.max()) + 1, dtype=np.int64)
-        pos[nid1] = np.arange(n1)
-        rest = c0g[keep][pos[c0g[keep]] < 0]
-        _, first = np.unique(rest, return_index=True)
-        new = rest[np.sort(first)]
-        pos[new] = n1 + np.arange(len(new))
-        n_id = np.concatenate([nid1, new])
-        rp0 = np.concatenate([[0], np.cumsum(np.bincount(rows0, minlength=n1))])
-        blk0 = (rp0, pos[c0g[keep]], v0[keep].astype(np.float32), (n1, len(n_id)))
-        v1, c1 = f["val1"][c, :B].reshape(-1), f["col1"][c, :B].reshape(-1)
-        k1 = v1 != 0
-        rows1 = np.repeat(np.arange(B), blk.f1)[k1]
-        rp1 = np.concatenate([[0], np.cumsum(np.bincount(rows1, minlength=B))])
-        blk1 = (rp1, c1[k1].astype(np.int64), v1[k1].astype(np.float32), (B, n1))
-        out.append((B, n_id, [blk0, blk1]))
-    return out
 
 
 def engine_match_loss(p, eng):
@@ -334,8 +232,11 @@ def main():
     barrier()
     base = getattr(eng, "eng", eng)      # the engine behind a ShardedGCond
     base.probe(True)                     # event pairs around the dominant kernel's launches inside the timed steps
-    if world > 1:
-        eng.col.timing = True            # event pairs around every all-reduce: per-buffer communication time
+    if world > 1:                        # event pairs around every exchange: per-join communication time
+        if eng.driver == "python":
+            eng.col.timing = True
+        else:
+            eng.comm.set_timing(True)
     t0 = time.perf_counter()
     run_steps(p, eng, args.steps, args.steps)
     barrier()
@@ -346,8 +247,16 @@ def main():
     comm = None
     if world > 1:
         import torch.distributed as dist
-        eng.col.timing = False
-        comm = {"n_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "per_buffer": eng.col.timing_report()}
+        if eng.driver == "python":
+            eng.col.timing = False
+            per, transport = eng.col.timing_report(), "torch.distributed all_reduce per buffer (host-side phase list)"
+        else:
+            per = eng.comm.timing_report()
+            eng.comm.set_timing(False)
+            transport = {"rccl": "ncclAllReduce issued inside libgslim_hip.so (gs_comm)",
+                         "callback": "gs_comm callback -> torch.distributed all_reduce"}.get(eng.comm.kind, eng.comm.kind)
+        comm = {"n_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "driver": eng.driver,
+                "host_calls_per_step": 1 if eng.driver != "python" else None, "transport": transport, "per_buffer": per}
         comm["exchanges_per_step"] = round(sum(v["calls"] for v in comm["per_buffer"].values()) / max(args.steps, 1), 2)
         comm["comm_us_per_step"] = round(sum(v["calls"] * v["avg_us"] for v in comm["per_buffer"].values()) / max(args.steps, 1), 1)
     if world > 1:

@@ -66,7 +66,13 @@ SYMBOLS = [
     "gs_edge_scatter_sym_f32", "gs_edge_score_bwd_f32", "gs_segment_sum_rows_f32", "gs_colsum_tall_f32", "gs_mul_f32", "gs_mul_bwd_f32", "gs_mix_heads_f32", "gs_mix_heads_bwd_f32", "gs_sym_sigmoid_f32",
     "gs_sym_sigmoid_bwd_f32", "gs_bn_running_update_f32", "gs_bn_relu_eval_f32", "gs_ot_spectrum_f32", "gs_ot_value_f32",
     "gs_scale_cols_f32", "gs_ot_divdiff_f32", "gs_clamp_finite_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
+    "gs_comm_unique_id", "gs_comm_create_rccl", "gs_comm_create_callback", "gs_comm_create_null", "gs_comm_destroy", "gs_comm_rank",
+    "gs_comm_world", "gs_comm_allreduce", "gs_comm_set_timing", "gs_comm_read_timing", "gs_gcond_outer_step_sharded",
+    "gs_gcond_outer_step_sharded_ex", "gs_sample_set_cand_cap", "gs_gcond_set_h1_rows",
 ]
+
+# gs_allreduce_fn of include/gslim.h: int fn(void* user, void* buf, long count, int dtype, gs_stream_t stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_long, C.c_int, vp)
 
 
 def lib():
@@ -164,6 +170,21 @@ def lib():
     L.gs_edge_scatter_sym_f32.argtypes = [vp, vp, vp, l, i, vp, vp, vp]
     L.gs_edge_score_bwd_f32.argtypes = [vp, vp, vp, vp, vp, l, i, i, vp, vp, l, vp]
     L.gs_segment_sum_rows_f32.argtypes = [vp, l, vp, vp, i, i, vp, l, vp]
+    L.gs_comm_unique_id.argtypes = [vp]
+    L.gs_comm_create_rccl.argtypes = [vp, i, i, C.POINTER(vp)]
+    L.gs_comm_create_callback.argtypes = [ALLREDUCE_FN, vp, i, i, C.POINTER(vp)]
+    L.gs_comm_create_null.argtypes = [i, i, C.POINTER(vp)]
+    L.gs_comm_destroy.restype = None
+    L.gs_comm_destroy.argtypes = [vp]
+    L.gs_comm_rank.argtypes = [vp]
+    L.gs_comm_world.argtypes = [vp]
+    L.gs_comm_allreduce.argtypes = [vp, vp, l, i, i, vp]
+    L.gs_comm_set_timing.argtypes = [vp, i]
+    L.gs_comm_read_timing.argtypes = [vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_double)]
+    L.gs_gcond_outer_step_sharded.argtypes = [vp, i, vp, vp]
+    L.gs_gcond_outer_step_sharded_ex.argtypes = [vp, i, i, i, i, vp, vp]
+    L.gs_sample_set_cand_cap.argtypes = [i]
+    L.gs_gcond_set_h1_rows.argtypes = [i]
     _lib = L
     return L
 

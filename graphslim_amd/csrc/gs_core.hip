@@ -280,6 +280,8 @@ extern "C" int gs_dense_gcn_norm_bwd(const float* adj, const float* r, const flo
                                      gs_stream_t stream) {
   if (n <= 0) return GS_OK;
   if (!adj || !r || !d_adj_norm || !d_adj) GS_FAIL(GS_ERR_ARG, "gs_dense_gcn_norm_bwd: null pointer");
+  if (n > 2048 && d_adj == d_adj_norm)
+    GS_FAIL(GS_ERR_ARG, "gs_dense_gcn_norm_bwd: d_adj must not alias d_adj_norm for n > 2048 (d_adj stages the column partials)");
   hipStream_t s = (hipStream_t)stream;
   // d deg is staged in the first n floats of d_adj's last row region?  no: use d_adj itself as scratch is unsafe;
   // the [n] vector lives at the tail of r (caller allocates r with 2n floats: r[0..n) = deg^-1/2, r[n..2n) scratch).

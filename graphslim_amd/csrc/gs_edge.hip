@@ -191,6 +191,7 @@ bool gs_edge_eligible(const gs_gemm_desc& p) {
   if (!g_edge_enabled || !p.bgen_mask || !p.bgen_idx || !p.bgen_w || !p.gatherA_k) return false;
   if (p.N != 256 || p.sAm != 1 || p.sBn != 1 || p.sBk != 256 || p.ldc != 256 || p.bgen_ldm < 256) return false;
   if ((p.M & 3) || (p.sAk & 3) || (p.bgen_ldm & 3) || p.kchunk <= 0 || (p.kchunk % EG_BK) || !p.Kb) return false;
+  if (p.bgen_div < 1 || (p.sBb1 & 3)) return false;            // the kernel divides by f2 and reads Y rows with 16-byte loads
   if (p.gatherA_k != p.bgen_idx) return false;                 // one source id per edge feeds both the X row and the mask row
   if (p.alpha != 1.f || p.beta != 0.f || p.bias || p.relu || p.mask || p.colstat || p.offA || p.offB || p.offC || p.Mb) return false;
   if (p.gatherA_m || p.gatherB_k || p.sAb1 != 0 || p.sAb2 != 0 || p.sBb2 != 0) return false;

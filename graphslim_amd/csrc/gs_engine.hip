@@ -18,6 +18,10 @@ int gs_panel_marginals(const float*, long, const float*, long, const float*, lon
 int gs_panel_forward_a1(const gs_panel_a1*, int, int, const float*, long, const float*, float*, long, int, int, float*, int, void*,
                         unsigned long long*, hipStream_t);
 int gs_panel_tiles(int);
+int gs_panel_rows(const float*, long, const float*, long, const float*, int, float*, long, int, int, const int*, const int*, int, long, int,
+                  void*, hipStream_t);
+extern "C" int gs_comm_allreduce(gs_comm*, void*, long, int, int, gs_stream_t);
+extern "C" int gs_comm_world(const gs_comm*);
 
 namespace {
 
@@ -61,6 +65,8 @@ struct gs_gcond {
   // real side
   gs_blocks blk;
   int *marker, *kcount;
+  int *h1_flag, *h1_list, *h1_count;   // rows of H1full this rank's sampled blocks gather (sharded ranks: only those are computed)
+  int h1_rows_max;
   float *H1full, *P0, *rs0, *Sr, *rsr, *Zr, *gw_real, *Tm, *Y1, *Bmat, *slabs_r, *colpart, *colpart_r;
   // synthetic side
   float *adj_raw, *adj_norm, *rnorm, *Q, *rsq, *H1s, *Ss, *Zs, *Ps, *Gs, *gw_syn, *stats, *ab, *loss_c, *D, *Ug, *Vs, *dSs,
@@ -220,6 +226,11 @@ static size_t carve(gs_gcond* e, void* base) {
     e->colpart_r = w.take<float>(C * nch_r * (h > 0 ? h : 1));      // the real-side branch may run on its own stream
   }
   e->H1full = e->T == 2 ? w.take<float>(N * h) : nullptr;
+  if (e->T == 2 && !e->gcn) {
+    e->h1_flag = w.take<int>(N); e->h1_list = w.take<int>(N); e->h1_count = w.take<int>(1);
+  } else {
+    e->h1_flag = e->h1_list = e->h1_count = nullptr;
+  }
   e->P0 = w.take<float>(C * cap1 * F); e->rs0 = w.take<float>(C * cap1);
   e->Sr = w.take<float>(C * bcap * F); e->rsr = w.take<float>(C * bcap);
   e->Zr = w.take<float>(C * bcap * C); e->gw_real = w.take<float>(C * P);
@@ -251,7 +262,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->sumU = w.take<float>(Ph); e->sumV = w.take<float>(Ph);
   e->A1 = w.take<float>(n2 * Ph); e->E2 = w.take<float>(n2 * Ph); e->e3 = w.take<float>(n2); e->de3 = w.take<float>(n2);
   e->dE2 = w.take<float>(n2 * Ph); e->dY1 = w.take<float>(n2 * Ph);
-  e->ar_marg = w.take<float>(2 * n * Ph);     // [rowsum_c | colsum_r] contiguous (one all-reduce)
+  e->ar_marg = w.take<float>(2 * n * Ph + Ph * Ph + Ph);     // [rowsum_c | colsum_r | dW1 | db1] contiguous (one all-reduce; the tail in PGE epochs)
   e->rowsum_c = e->ar_marg; e->colsum_r = e->ar_marg ? e->ar_marg + n * Ph : nullptr; e->dU = w.take<float>(n * Ph); e->W1T = w.take<float>(Ph * Ph); e->W1mT = w.take<float>(d * h);
   e->bsplit_main = w.take<float>(Ph * Ph * 3 / 2 + 16);             // pre-split B images: 4 B (modes 1, 2) or 6 B (mode 3) per element
   e->bsplit_aux = w.take<float>((h > 0 ? h : 1) * d * 3 / 2 + 16);
@@ -635,6 +646,37 @@ static void launch_ell(const int* col, const float* val, const int* nrows, int c
                        src, ld_src, rs_in, F, out, rs_out, C);
 }
 
+// ---- the rows of H1 = relu(X W1 + b1) a rank needs: the hop-2 sources of ITS classes' blocks ---------------------------------
+// flag[v] = 1 for every source id of a real edge slot (val != 0; padding slots carry (0, 0.f)) of a live frontier row
+__global__ __launch_bounds__(256) void gs_h1_mark_kernel(const int* __restrict__ col0, const float* __restrict__ val0,
+                                                         const int* __restrict__ n1, int cap1, int f2, int C, int* __restrict__ flag) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)C * cap1 * f2) return;
+  const int c = (int)(e / ((long)cap1 * f2)), l = (int)((e / f2) % cap1);
+  if (l < n1[c] && val0[e] != 0.f) flag[col0[e]] = 1;
+}
+
+// list = the flagged ids (wave-level compaction, one atomic per wave: the order is arbitrary, the values computed from the list do
+// not depend on it), count = how many
+__global__ __launch_bounds__(256) void gs_h1_compact_kernel(const int* __restrict__ flag, int N, int* __restrict__ list,
+                                                            int* __restrict__ count) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = v < N && flag[v] != 0;
+  const unsigned long long m = __ballot(on);
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
+  base = __shfl(base, 0, 64);
+  if (on) list[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+}
+
+static int g_h1_rows = 1;
+// measurement knob: 1 (default) = a sharded rank computes only the H1 rows its blocks gather; 0 = every rank computes all N rows
+extern "C" int gs_gcond_set_h1_rows(int on) {
+  g_h1_rows = on != 0;
+  return GS_OK;
+}
+
 extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   if (!e->have_blocks) GS_FAIL(GS_ERR_STATE, "gs_gcond: no sampled blocks yet");
@@ -685,11 +727,28 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     // (W1 transposed first so that both operands are k-contiguous — see the dY1 product)
     hipLaunchKernelGGL(gs_transpose_small_kernel, dim3(gs_cdiv(h, 32), gs_cdiv(d, 32)), dim3(32, 8), 0, s, th + e->oW1, d, h, e->W1mT);
     GS_LAUNCH_CHECK();
-    gs_gemm_desc g = mk(e->io.X, e->ldx, 1, e->W1mT, 1, d, e->H1full, h, e->N, h, d);
-    g.bias = th + e->ob1;
-    g.relu = 1;
-    g.prec = e->operand_mode; g.scratch = e->bsplit_aux;
-    GS_TRY(gs_gemm_f32(&g, stream));
+    // Unsharded, the 40 classes' blocks touch (nearly) every node: all N rows in one product.  A sharded rank's few classes
+    // gather fewer slots than there are nodes: their distinct sources are listed (mark + compact) and only those rows of H1full
+    // are produced — same arithmetic per row, so every value downstream is bitwise the full product's.
+    const long slots = (long)Cl * cap1 * f2;
+    int rows_rc = GS_ERR_UNSUPPORTED;
+    if (g_h1_rows && !e->S_full && e->h1_flag && slots < (long)e->N) {
+      GS_HIP(hipMemsetAsync(e->h1_flag, 0, sizeof(int) * (size_t)e->N, s));
+      GS_HIP(hipMemsetAsync(e->h1_count, 0, sizeof(int), s));
+      hipLaunchKernelGGL(gs_h1_mark_kernel, dim3(gs_cdiv(slots, 256)), dim3(256), 0, s, b.col0, b.val0, b.n1, cap1, f2, Cl, e->h1_flag);
+      hipLaunchKernelGGL(gs_h1_compact_kernel, dim3(gs_cdiv(e->N, 256)), dim3(256), 0, s, e->h1_flag, e->N, e->h1_list, e->h1_count);
+      GS_LAUNCH_CHECK();
+      rows_rc = gs_panel_rows(e->io.X, e->ldx, e->W1mT, d, th + e->ob1, 1, e->H1full, h, h, d, e->h1_list, e->h1_count, (int)slots,
+                              (long)e->N, e->operand_mode, e->bsplit_aux, s);
+      if (rows_rc != GS_OK && rows_rc != GS_ERR_UNSUPPORTED) return rows_rc;
+    }
+    if (rows_rc != GS_OK) {
+      gs_gemm_desc g = mk(e->io.X, e->ldx, 1, e->W1mT, 1, d, e->H1full, h, e->N, h, d);
+      g.bias = th + e->ob1;
+      g.relu = 1;
+      g.prec = e->operand_mode; g.scratch = e->bsplit_aux;
+      GS_TRY(gs_gemm_f32(&g, stream));
+    }
     src = e->H1full;
     ld_src = h;
   }
@@ -1666,7 +1725,7 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
       GS_TRY(gs_gemm_group_f32(g2, 2, stream));
     }
     if (e->with_bn) {      // gradients of the folded model -> gradients of [W1, b1, W2, b2, bn.weight, bn.bias]
-      hipLaunchKernelGGL(gs_bn_unfold_grads_kernel, dim3(gs_cdiv(h, 32)), dim3(256), 0, s, e->g_model, th_true, e->dH1m, e->H1s, n, d, h,
+      hipLaunchKernelGGL(gs_bn_unfold_grads_kernel, dim3(gs_cdiv(h, 32)), dim3(256), 0, s, e->g_model, th_true, e->dH1m, X, (long)d, n, d, h,
                          e->oW1, e->ob1, e->og, e->obeta);
       GS_LAUNCH_CHECK();
     }
@@ -1780,28 +1839,65 @@ extern "C" int gs_gcond_stage_real_async(gs_gcond* e, gs_stream_t stream) {
   return GS_OK;
 }
 
+// ---- exchanges of the sharded iteration (tags: gs_comm_read_timing) -------------------------------------------------
+static inline int xchg(gs_comm* comm, void* buf, long count, int f64, int tag, gs_stream_t stream) {
+  return comm ? gs_comm_allreduce(comm, buf, count, f64, tag, stream) : GS_OK;
+}
+
+// PGE forward with the two exchanges between its parts when `comm` is given (BN-2 column sums, pair scores)
+static int pge_forward_x(gs_gcond* e, int inference, gs_comm* comm, gs_stream_t stream) {
+  if (!comm) return gs_gcond_stage_pge_forward(e, inference, stream);
+  GS_TRY(gs_gcond_stage_pge_forward_part(e, inference, 1, stream));
+  GS_TRY(xchg(comm, e->sums, 2L * e->Ph, 1, 0, stream));
+  GS_TRY(gs_gcond_stage_pge_forward_part(e, inference, 2, stream));
+  GS_TRY(xchg(comm, e->e3, (long)e->n * e->n, 0, 1, stream));
+  return gs_gcond_stage_pge_forward_part(e, inference, 3, stream);
+}
+
+// PGE backward with its two exchanges (BN-2 backward sums; BN-1 marginals — and dW1 | db1 behind them in ONE buffer when the PGE
+// is stepped: the weight-gradient partials are copied behind the marginals, exchanged with them and copied back)
+static int pge_backward_x(gs_gcond* e, int need_param_grads, int need_feat_grad, gs_comm* comm, gs_stream_t stream) {
+  if (!comm) return gs_gcond_stage_pge_backward(e, need_param_grads, need_feat_grad, stream);
+  hipStream_t s = (hipStream_t)stream;
+  const long Ph = e->Ph, nm = 2L * e->n * Ph, nw = Ph * Ph + Ph;
+  GS_TRY(gs_gcond_stage_pge_backward_part(e, need_param_grads, need_feat_grad, 1, stream));
+  GS_TRY(xchg(comm, e->sums, 3L * Ph, 1, 3, stream));
+  GS_TRY(gs_gcond_stage_pge_backward_part(e, need_param_grads, need_feat_grad, 2, stream));
+  const bool w1 = need_param_grads && gs_comm_world(comm) > 1;
+  if (w1) GS_HIP(hipMemcpyAsync(e->ar_marg + nm, e->d_pge + e->pW1, sizeof(float) * nw, hipMemcpyDeviceToDevice, s));
+  GS_TRY(xchg(comm, e->ar_marg, nm + (w1 ? nw : 0), 0, 4, stream));
+  if (w1) GS_HIP(hipMemcpyAsync(e->d_pge + e->pW1, e->ar_marg + nm, sizeof(float) * nw, hipMemcpyDeviceToDevice, s));
+  return gs_gcond_stage_pge_backward_part(e, need_param_grads, need_feat_grad, 3, stream);
+}
+
 // One outer iteration with the update rule chosen by the caller (the sibling methods share train_class and differ only here):
 //   GCond    (gcond.py:47-72)   : step_pge = epoch%50<10, step_feat = !step_pge, inference + inner steps
 //   DosCond  (doscond.py:40-50) : both optimisers stepped, no inference, no inner steps
 //   GCondX   (gcondx.py:44-66)  : identity structure, feat stepped unless ol%5<1, inner steps on A^ = I
 //   DosCondX (doscondx.py:42-49): identity structure, feat stepped, nothing else
-extern "C" int gs_gcond_outer_step_ex(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner,
-                                      gs_stream_t stream) {
+// comm != NULL: this rank's share of a sharded iteration (gs_gcond_set_shard), the all-reduce(sum) exchanges issued here on
+// `stream` between the parts — the whole iteration is this ONE host call per rank.
+static int outer_step_impl(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_comm* comm,
+                           gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
-  if (sharded_c(e) || sharded_r(e))
-    GS_FAIL(GS_ERR_STATE, "gs_gcond_outer_step: a sharded engine is driven stage by stage with all-reduces in between (graphslim_amd/parallel.py)");
+  if (!comm && (sharded_c(e) || sharded_r(e)))
+    GS_FAIL(GS_ERR_STATE, "gs_gcond_outer_step: a sharded engine needs a communicator (gs_gcond_outer_step_sharded) or is driven stage "
+                          "by stage with all-reduces in between");
+  if (comm && gs_comm_world(comm) > 1 && e->pge_chunks > 1)
+    GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond_outer_step_sharded: the chunked PGE (pge_chunks > 1) cannot be sharded over pair rows");
   if (e->identity) { step_pge = 0; run_inference = 0; }
   GS_TRY(gs_gcond_stage_real_async(e, stream));
   if (!e->identity) {
     if (e->reuse_fwd && e->fwd_cached)
       GS_TRY(adopt_cached_forward(e, stream));
     else
-      GS_TRY(gs_gcond_stage_pge_forward(e, 0, stream));
+      GS_TRY(pge_forward_x(e, 0, comm, stream));
   }
   GS_TRY(gs_gcond_stage_syn_match(e, stream));
+  GS_TRY(xchg(comm, e->ar_syn, (long)e->n * e->d + (long)e->n * e->n + e->C, 0, 2, stream));
   GS_TRY(gs_gcond_stage_syn_finish(e, stream));
   // only the gradient of a group that is stepped is consumed (zero_grad() discards the rest unread, gcond.py:54-61)
-  if (!e->identity && (step_pge || step_feat)) GS_TRY(gs_gcond_stage_pge_backward(e, step_pge, step_feat, stream));
+  if (!e->identity && (step_pge || step_feat)) GS_TRY(pge_backward_x(e, step_pge, step_feat, comm, stream));
   if (step_pge)
     GS_TRY(gs_adam_step_f32(e->io.pge_params, e->d_pge, e->m_pge, e->v_pge, e->Ppge, e->cfg.lr_adj, 0.9f, 0.999f, 1e-8f, 0.f,
                             ++e->step_pge, stream));
@@ -1809,7 +1905,7 @@ extern "C" int gs_gcond_outer_step_ex(gs_gcond* e, int step_pge, int step_feat, 
     GS_TRY(gs_adam_step_f32(e->io.feat_syn, e->d_feat, e->m_feat, e->v_feat, (long)e->n * e->d, e->cfg.lr_feat, 0.9f, 0.999f,
                             1e-8f, 0.f, ++e->step_feat, stream));
   if (step_pge || step_feat) e->fwd_cached = false;
-  if (run_inference) GS_TRY(gs_gcond_stage_pge_forward(e, 1, stream));
+  if (run_inference) GS_TRY(pge_forward_x(e, 1, comm, stream));
   if (run_inner) {
     if (!e->identity && !run_inference) GS_FAIL(GS_ERR_ARG, "gs_gcond_outer_step_ex: inner steps need the inference pass");
     GS_TRY(gs_gcond_stage_inner_steps(e, stream));
@@ -1817,9 +1913,25 @@ extern "C" int gs_gcond_outer_step_ex(gs_gcond* e, int step_pge, int step_feat, 
   return GS_OK;
 }
 
+extern "C" int gs_gcond_outer_step_ex(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner,
+                                      gs_stream_t stream) {
+  return outer_step_impl(e, step_pge, step_feat, run_inference, run_inner, nullptr, stream);
+}
+
 extern "C" int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream) {
   const int pge_epoch = (epoch % 50 < 10);     // gcond.py:58-61
-  return gs_gcond_outer_step_ex(e, pge_epoch, !pge_epoch, 1, 1, stream);
+  return outer_step_impl(e, pge_epoch, !pge_epoch, 1, 1, nullptr, stream);
+}
+
+extern "C" int gs_gcond_outer_step_sharded_ex(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner,
+                                              gs_comm* comm, gs_stream_t stream) {
+  if (!comm) GS_FAIL(GS_ERR_ARG, "gs_gcond_outer_step_sharded: null communicator");
+  return outer_step_impl(e, step_pge, step_feat, run_inference, run_inner, comm, stream);
+}
+
+extern "C" int gs_gcond_outer_step_sharded(gs_gcond* e, int epoch, gs_comm* comm, gs_stream_t stream) {
+  const int pge_epoch = (epoch % 50 < 10);
+  return gs_gcond_outer_step_sharded_ex(e, pge_epoch, !pge_epoch, 1, 1, comm, stream);
 }
 
 // In-situ timing of the dominant kernel: while on, HIP events are recorded on the launch stream around every PGE layer-2

@@ -411,19 +411,28 @@ __global__ void gs_bn_fold_kernel(const float* __restrict__ theta, int d, int h,
 
 // inner-step gradients of the folded model -> gradients of the true parameters (in place on g; g has room for bn.weight / bn.bias):
 //   gW1[:, j] = gW1'[:, j] s_j ; gb1_j = gb1'_j s_j ; g bn.bias_j = gb1'_j ;
-//   g bn.weight_j = sum_i dpre'_ij pre_ij / sqrt(1 + eps) = sum_i dH1_ij (H1_ij - beta_j) / bn.weight_j
-// (dH1 is already masked by the ReLU, so H1 = pre' wherever dH1 != 0).  One block per 32 hidden columns.
+//   g bn.weight_j = sum_i dpre'_ij pre_ij / sqrt(1 + eps),  pre = X W1 + b1 with the TRUE W1, b1
+// (dH1 = dpre' is already masked by the ReLU).  pre is re-formed from X and theta: Adam trains bn.weight, so the shortcut
+// (H1 - beta) / bn.weight of the first build divides by a parameter that may pass through zero.  One block per 32 hidden columns.
 __global__ __launch_bounds__(256) void gs_bn_unfold_grads_kernel(float* __restrict__ g, const float* __restrict__ theta,
-                                                                 const float* __restrict__ dH1, const float* __restrict__ H1, int n,
-                                                                 int d, int h, long oW1, long ob1, long og, long obeta) {
+                                                                 const float* __restrict__ dH1, const float* __restrict__ X, long ldx,
+                                                                 int n, int d, int h, long oW1, long ob1, long og, long obeta) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + tx;
   const float rs = 1.f / sqrtf(1.f + 1e-5f);
   __shared__ double sh[8][32];
   double acc = 0.0;
-  const float gam = j < h ? theta[og + j] : 1.f, bet = j < h ? theta[obeta + j] : 0.f;
-  if (j < h)
-    for (int i = ty; i < n; i += 8) acc += (double)dH1[(long)i * h + j] * (double)(H1[(long)i * h + j] - bet);
+  const float gam = j < h ? theta[og + j] : 1.f;
+  if (j < h) {
+    const float b1 = theta[ob1 + j];
+    for (int i = ty; i < n; i += 8) {
+      const float dh = dH1[(long)i * h + j];
+      if (dh == 0.f) continue;
+      float pre = b1;
+      for (int k = 0; k < d; ++k) pre = fmaf(X[(long)i * ldx + k], theta[oW1 + (long)k * h + j], pre);
+      acc += (double)dh * (double)pre;
+    }
+  }
   sh[ty][tx] = acc;
   __syncthreads();
   if (j >= h) return;
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(256) void gs_bn_unfold_grads_kernel(float* __restri
     for (int q = 0; q < 8; ++q) t += sh[q][tx];
     const float gb = g[ob1 + j];
     g[obeta + j] = gb;
-    g[og + j] = (float)(t / (double)gam);
+    g[og + j] = (float)(t * (double)rs);
     g[ob1 + j] = gb * sj;
   }
 }

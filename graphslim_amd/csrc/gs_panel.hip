@@ -54,6 +54,9 @@ struct gs_panel_args {
   // [A1 > 0] mask of the fused-marginals epilogue is recomputed from them (mask is not read).
   const float* a1_U; const float* a1_V; long a1_ld;     // U [n][ld], V already offset to this rank's first pair row r
   const float* a1_c;                 // [Ph][8]: per column {b0, mu1, is1, g1, be1, 0, 0, 0}
+  // row-list form (gs_panel_rows_kernel): row i of the product reads A[rowidx[i]] and writes C[rowidx[i]]; the row count is read
+  // on the device (*m_dev, <= the M the grid was sized for) — the rows of H1 = relu(X W1 + b1) a rank's sampled blocks gather
+  const int* rowidx; const int* m_dev;
   unsigned long long* span;          // optional [2]: device-side launch span — min over workgroups of the start tick, max of the
                                      // end tick (s_memrealtime, 100 MHz); see gs_gcond_probe
   int krep, triage;                  // measurement hooks (gs_panel_debug): K loop repeated krep times; bit 0: no stores;
@@ -66,20 +69,21 @@ struct gs_panel_args {
 // issued before it — a full write round trip per tile (17-37 us of the 70 us the first build of this kernel spent outside its
 // K loop, tools/trace_panel.py).  So the bias row is parked in LDS before the K loop (LDS reads count on lgkmcnt, not vmcnt) and
 // the code is branch-free per (HAS_MASK, FULL) instantiation.
-template <int NTW, bool HAS_MASK, bool FULL, int BS = 1>
+template <int NTW, bool HAS_MASK, bool FULL, int BS = 1, bool ROWS = false>
 __device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32x16 (&acc)[NTW], const float* sbias, int m0,
                                                int row_in_tile, int col0, float (&cs1)[NTW], float (&cs2)[NTW]) {
   const float floor_ = p.relu ? 0.f : -__builtin_inff();
   // Addresses = a tile-uniform base (scalar registers) + a 32-bit per-lane offset + an immediate per N tile: one offset
   // register per accumulator row instead of a 64-bit address pair per store (the pair form needed > 256 registers and
   // spilled; a kernel that needs scratch memory also makes the runtime manage scratch per queue on the launch path).
-  float* __restrict__ Cb = p.C + (long)m0 * p.ldc;
+  float* __restrict__ Cb = ROWS ? p.C : p.C + (long)m0 * p.ldc;
   const float* __restrict__ Mb = HAS_MASK ? p.mask + (long)m0 * p.ldmask : nullptr;
   unsigned coff[16], moff[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const unsigned rt = (unsigned)(row_in_tile + (r & 3) + 8 * (r >> 2));      // row inside the tile
-    coff[r] = rt * (unsigned)p.ldc + (unsigned)col0;
+    if constexpr (ROWS) coff[r] = (unsigned)p.rowidx[min(m0 + (int)rt, p.M - 1)] * (unsigned)p.ldc + (unsigned)col0;
+    else coff[r] = rt * (unsigned)p.ldc + (unsigned)col0;
     if (HAS_MASK) moff[r] = (FULL ? rt : min(rt, (unsigned)(p.M - 1 - m0))) * (unsigned)p.ldmask + (unsigned)col0;
   }
   // (mask variant: the 16 mask values of a tile are requested right before use — a two-tile ping-pong needs 32 more
@@ -245,7 +249,7 @@ __device__ __forceinline__ void panel_transform_a(const gs_panel_args& p, f32x4 
 // launch runs in these: 206 116 rows are 1 611 tiles of 128 rows on 512 workgroup slots = 3.15 rounds, and the 75 tiles of the
 // fourth round kept 75 CUs busy for a whole solo tile (43 us of 258) while 181 CUs idled; as 300 tiles of a quarter of the
 // work they take one short round on every CU.  Same arithmetic per output element either way (same k order).
-template <int MODE, int NT, int WN, bool MARG = false, bool AGEN = false, bool MGEN = false, bool FGEN = false>
+template <int MODE, int NT, int WN, bool MARG = false, bool AGEN = false, bool MGEN = false, bool FGEN = false, bool RIDX = false>
 __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, int m0, int stat_row) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128, NTW = NT / WN, ROWS = 128 / WN;
   static_assert(!MARG || WN == 1, "the fused-marginals form uses 128-row tiles");
@@ -267,7 +271,7 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
     row = min(16 * rb + (i >> 3), p.mg_nr - 1) * p.mg_n + min(8 * cb + (i & 7), p.mg_n - 1);
   }
   const int j0 = WN == 1 ? 0 : wave * NTW;            // first N tile of this wave
-  const float* __restrict__ arow = p.A + (long)min(row, p.M - 1) * p.lda + 16 * h;
+  const float* __restrict__ arow = p.A + (long)(RIDX ? p.rowidx[min(row, p.M - 1)] : min(row, p.M - 1)) * p.lda + 16 * h;
   int rsel = 0;                                        // FGEN: which of the tile's two V rows this lane's pair row uses
   if constexpr (FGEN) {     // pair row (r, c) = (row / n, row % n): the lane streams U[c]; V[r] (<= 2 distinct r per tile) sits in LDS
     const int rr = min(row, p.M - 1), r = rr / p.mg_n;
@@ -504,7 +508,10 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   const int col0 = 32 * j0 + li;
   const bool full = m0 + ROWS <= p.M;
   float cs1[NTW], cs2[NTW];
-  if (p.mask) {
+  if constexpr (RIDX) {
+    if (full) panel_epilogue<NTW, false, true, BS, true>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+    else panel_epilogue<NTW, false, false, BS, true>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+  } else if (p.mask) {
     if (full) panel_epilogue<NTW, true, true, BS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
     else panel_epilogue<NTW, true, false, BS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
   } else {
@@ -554,6 +561,19 @@ __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) 
   const int b = blockIdx.x;
   if (b < p.n_full) panel_tile<MODE, NT, 1>(p, smem, b * PN_BM, b);
   else panel_tile<MODE, NT, 4>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
+}
+
+// row-list form: C[rowidx[i]] = A[rowidx[i]] B^T (+ bias)(relu) for i < *m_dev; the grid is sized for the largest possible count and
+// the tiles beyond the device-side count leave at once (128-row tiles throughout: the count is not known when the grid is sized)
+template <int MODE, int NT>
+__global__ __launch_bounds__(256, 2) void gs_panel_rows_kernel(gs_panel_args pin) {
+  constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;
+  __shared__ __attribute__((aligned(16))) char smem[MODE == 3 ? 3 * PN_N * 96 + 8192 : 2 * PN_STAGE + PN_N * 4];
+  gs_panel_args p = pin;
+  p.M = min(*pin.m_dev, pin.M);
+  const int m0 = blockIdx.x * PN_BM;
+  if (m0 >= p.M) return;
+  panel_tile<MODE, NT, 1, false, false, false, false, true>(p, smem, m0, blockIdx.x);
 }
 
 template <int MODE, int NT, bool AGEN, bool MGEN>
@@ -704,6 +724,34 @@ int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s) {
   a.trace = (g_panel_triage & 2) ? (unsigned long long*)d.scratch : nullptr;   // (trace runs use prec = 0: scratch is free)
   if (d.N == 256) panel_dispatch<8>(d, a, s);
   else panel_dispatch<4>(d, a, s);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// engine-internal: C[rowidx[i]][N] = relu?(A[rowidx[i]][K] W^T + bias) for i < *m_dev (device count, at most m_max): the row-list
+// form of the plain product.  GS_ERR_UNSUPPORTED when the shape is not covered (the caller then computes every row).
+int gs_panel_rows(const float* A, long lda, const float* W, long ldw, const float* bias, int relu, float* Cout, long ldc, int N, int K,
+                  const int* rowidx, const int* m_dev, int m_max, long rows_total, int prec, void* scratch, hipStream_t s) {
+  if (!g_panel_enabled || !rowidx || !m_dev || m_max < 1) return GS_ERR_UNSUPPORTED;
+  if ((N != 256 && N != 128) || K < 32 || (K & 31) || (lda & 3) || (ldw & 3) || prec < 0 || prec > 3 || (prec != 0 && !scratch)) return GS_ERR_UNSUPPORTED;
+  if ((double)rows_total * (double)ldc >= 4294967296.0 || (((uintptr_t)A | (uintptr_t)W) & 15)) return GS_ERR_UNSUPPORTED;
+  gs_panel_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.C = Cout; a.ldc = ldc; a.M = m_max; a.K = K; a.bias = bias; a.relu = relu; a.krep = 1;
+  a.rowidx = rowidx; a.m_dev = m_dev;
+  a.n_full = gs_cdiv(m_max, PN_BM);
+  const dim3 grid(a.n_full), block(256);
+  a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);
+#define GS_ROWS_LAUNCH(MODE_)                                                                 \
+  do {                                                                                        \
+    if (N == 256) hipLaunchKernelGGL((gs_panel_rows_kernel<MODE_, 8>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((gs_panel_rows_kernel<MODE_, 4>), grid, block, 0, s, a);          \
+  } while (0)
+  if (prec == 0) GS_ROWS_LAUNCH(0);
+  else if (prec == 1) GS_ROWS_LAUNCH(1);
+  else if (prec == 2) GS_ROWS_LAUNCH(2);
+  else GS_ROWS_LAUNCH(3);
+#undef GS_ROWS_LAUNCH
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

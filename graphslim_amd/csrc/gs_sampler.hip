@@ -61,13 +61,13 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
                                                              const int* __restrict__ cls_ptr,
                                                              const int* __restrict__ cls_nodes, int* marker,
                                                              gs_blocks blk, uint64_t seed, uint32_t step, int class_key0,
-                                                             int seeds_only) {
+                                                             int seeds_only, int cand_cap) {
   const int c = blockIdx.x, tid = threadIdx.x;
   const int ckey = class_key0 + c;   // RNG key = global class id (a class shard draws what the full run draws)
   const int bcap = blk.bcap, f1 = blk.f1, cap1 = blk.cap1;
   const int* pool = cls_nodes + cls_ptr[c];
   const int npool = cls_ptr[c + 1] - cls_ptr[c];
-  const int B = min(bcap, npool);
+  int B = min(bcap, npool);
   int* mk = marker + (long)c * n_nodes;
 
   __shared__ int s_g[GS_MAX_BCAP * GS_MAX_F];          // global id per hop-1 edge slot (-1 = padding)
@@ -86,37 +86,58 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
     // are the batch — a uniform subset because the keys are i.i.d. and ties are broken by the index.  Selection without a
     // sort: histogram of the top 12 key bits, the bin T in which the B-th smallest falls, every index below T, and the
     // (need) smallest of bin T by rank among the (few) members of that bin.  Seeds keep ascending pool order.
-    int* hist = s_g;                               // 4096 bins (s_g / s_sel are not in use yet)
-    int* cand = s_sel;                             // members of bin T: [2 m] = (key, index) pairs, m <= 2048
-    for (int i = tid; i < 4096; i += 256) hist[i] = 0;
-    __syncthreads();
+    int* hist = s_g;                               // 4096 bins (s_g / s_sel / s_cnt are not in use yet)
+    int* cand = s_sel;                             // members of the crossing bin: [2 m] = (key, index) pairs, m <= cand_cap <= 2048
+    int* take = s_cnt;                             // take[a] = candidate a is among the `need` smallest (its own array: the rank pass
+                                                   // only READS cand, so no wave can see a half-updated candidate list)
     const int per = (npool + 255) / 256, i_lo = min(tid * per, npool), i_hi = min(i_lo + per, npool);
-    for (int i = i_lo; i < i_hi; ++i) atomicAdd(&hist[gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i) >> 20], 1);
-    __syncthreads();
-    int hsum = 0;
-    for (int q = 0; q < 16; ++q) hsum += hist[tid * 16 + q];
-    int htot = 0;
-    int hbase = block_excl_scan_256(hsum, s_tmp, &htot);          // elements in the bins in front of this thread's 16
-    if (hbase < B && hbase + hsum >= B) {                         // the crossing lies in this thread's bins (exactly one thread)
-      int acc = hbase;
-      for (int q = 0; q < 16; ++q) {
-        const int hq = hist[tid * 16 + q];
-        if (acc + hq >= B) { s_hash[0] = tid * 16 + q; s_hash[1] = acc; s_hash[2] = 0; break; }
-        acc += hq;
+    // level 0 bins the top 12 key bits; if the crossing bin holds more than cand_cap members (pools beyond ~ 4096 cand_cap), level 1
+    // bins the next 12 bits of that bin's members, so that the ranked set stays small.  kmask / kpref select the members of the
+    // bins fixed so far; `below` counts the indices already known to be taken (keys in front of the crossing bin).
+    uint32_t kmask = 0u, kpref = 0u;
+    int below = 0, shift = 20, mcount = 0;
+    for (int level = 0; level < 2; ++level) {
+      for (int i = tid; i < 4096; i += 256) hist[i] = 0;
+      __syncthreads();
+      for (int i = i_lo; i < i_hi; ++i) {
+        const uint32_t key = gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i);
+        if ((key & kmask) == kpref) atomicAdd(&hist[(key >> shift) & 4095u], 1);
       }
+      __syncthreads();
+      int hsum = 0;
+      for (int q = 0; q < 16; ++q) hsum += hist[tid * 16 + q];
+      int htot = 0;
+      const int hbase = below + block_excl_scan_256(hsum, s_tmp, &htot);   // indices in front of this thread's 16 bins
+      if (hbase < B && hbase + hsum >= B) {                                  // the crossing lies in this thread's bins (exactly one thread)
+        int acc = hbase;
+        for (int q = 0; q < 16; ++q) {
+          const int hq = hist[tid * 16 + q];
+          if (acc + hq >= B) { s_hash[0] = tid * 16 + q; s_hash[1] = acc; s_hash[2] = hq; break; }
+          acc += hq;
+        }
+      }
+      __syncthreads();
+      kmask |= 4095u << shift;
+      kpref |= (uint32_t)s_hash[0] << shift;
+      below = s_hash[1];
+      mcount = s_hash[2];
+      __syncthreads();
+      if (mcount <= cand_cap) break;
+      shift -= 12;
     }
+    const int need = B - below;
+    if (tid == 0) s_hash[3] = 0;
     __syncthreads();
-    const int Tbin = s_hash[0], below = s_hash[1], need = B - below;
     for (int i = i_lo; i < i_hi; ++i) {
       const uint32_t key = gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i);
-      if ((int)(key >> 20) == Tbin) {
-        const int slot = atomicAdd(&s_hash[2], 1);
+      if ((key & kmask) == kpref) {
+        const int slot = atomicAdd(&s_hash[3], 1);
         if (slot < 2048) { cand[2 * slot] = (int)key; cand[2 * slot + 1] = i; }
       }
     }
     __syncthreads();
-    const int m = min(s_hash[2], 2048);
-    for (int a = tid; a < m; a += 256) {            // rank of candidate a among the members of bin T (m is ~ npool / 4096)
+    const int m = min(s_hash[3], 2048);             // (> 2048 only for pools beyond 2^35 entries: the batch then comes out short: B below)
+    for (int a = tid; a < m; a += 256) {            // rank of candidate a among the members of the crossing bin
       const uint32_t ka = (uint32_t)cand[2 * a];
       const int ia = cand[2 * a + 1];
       int rank = 0;
@@ -124,29 +145,32 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
         const uint32_t kq = (uint32_t)cand[2 * q];
         rank += (kq < ka) || (kq == ka && cand[2 * q + 1] < ia);
       }
-      if (rank >= need) cand[2 * a + 1] = -1;       // not taken
+      take[a] = rank < need;
     }
     __syncthreads();
-    int mine = 0;
+    int mine = 0, taken_total = 0;
     for (int pass = 0; pass < 2; ++pass) {          // count, then write in ascending pool order
       int base = 0;
       if (pass == 1) {
-        int tot = 0;
-        base = block_excl_scan_256(mine, s_tmp, &tot);
+        base = block_excl_scan_256(mine, s_tmp, &taken_total);
         mine = 0;
       }
       for (int i = i_lo; i < i_hi; ++i) {
-        const int bin = (int)(gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i) >> 20);
-        bool take = bin < Tbin;
-        if (bin == Tbin)
-          for (int q = 0; q < m; ++q) take |= (cand[2 * q + 1] == i);
-        if (take) {
+        const uint32_t key = gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i);
+        bool tk = false;
+        if ((key & kmask) == kpref) {
+          for (int q = 0; q < m; ++q) tk |= (cand[2 * q + 1] == i) && take[q];
+        } else {
+          tk = (key & kmask) < kpref;               // in front of the crossing bin (top 12 or 24 key bits compared as a number)
+        }
+        if (tk) {
           if (pass == 1 && base + mine < B) s_seed[base + mine] = i;
           ++mine;
         }
       }
     }
     __syncthreads();
+    B = min(B, taken_total);                        // == B by construction (exact ranks); never read seed slots that were not written
     if (tid < B) s_seed[tid] = pool[s_seed[tid]];
   }
   __syncthreads();
@@ -276,6 +300,15 @@ __global__ __launch_bounds__(256) void gs_sample_hop2_kernel(const int* __restri
   }
 }
 
+// members of the crossing key bin that are ranked directly (<= 2048: the LDS candidate list); larger bins get a second 12-bit
+// level.  Test hook: a small value forces the two-level path on ordinary pools (same seeds either way: the selection is exact).
+static int g_cand_cap = 2048;
+extern "C" int gs_sample_set_cand_cap(int cap) {
+  if (cap < 1 || cap > 2048) GS_FAIL(GS_ERR_ARG, "gs_sample_set_cand_cap: cap must be in [1, 2048]");
+  g_cand_cap = cap;
+  return GS_OK;
+}
+
 int gs_sample_blocks_ex(const int* rowptr, const int* col, const float* val, int n_nodes, const int* cls_ptr,
                         const int* cls_nodes, int* marker, const gs_blocks* out, uint64_t seed, uint32_t step, int class_key0,
                         gs_stream_t stream, int seeds_only) {
@@ -288,7 +321,7 @@ int gs_sample_blocks_ex(const int* rowptr, const int* col, const float* val, int
   if (b.C < 1) return GS_OK;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gs_sample_hop1_kernel, dim3(b.C), dim3(256), 0, s, rowptr, col, val, n_nodes, cls_ptr, cls_nodes,
-                     marker, b, seed, step, class_key0, seeds_only);
+                     marker, b, seed, step, class_key0, seeds_only, g_cand_cap);
   if (seeds_only) {
     GS_LAUNCH_CHECK();
     return GS_OK;

@@ -407,6 +407,15 @@ class GCondEngine:
     def outer_step_ex(self, step_pge, step_feat, run_inference, run_inner):
         check(self.L.gs_gcond_outer_step_ex(self.h, int(step_pge), int(step_feat), int(run_inference), int(run_inner), self._s()))
 
+    def outer_step_sharded(self, epoch, comm):
+        """This rank's share of a sharded outer iteration, exchanges included: ONE library call (gs_gcond_outer_step_sharded).
+        comm: graphslim_amd.parallel.Comm."""
+        check(self.L.gs_gcond_outer_step_sharded(self.h, epoch, comm.h, self._s()))
+
+    def outer_step_sharded_ex(self, step_pge, step_feat, run_inference, run_inner, comm):
+        check(self.L.gs_gcond_outer_step_sharded_ex(self.h, int(step_pge), int(step_feat), int(run_inference), int(run_inner), comm.h,
+                                                    self._s()))
+
     def set_identity_structure(self, on=True):
         check(self.L.gs_gcond_set_identity_structure(self.h, int(on), self._s()))
 

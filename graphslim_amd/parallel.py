@@ -1,4 +1,6 @@
-"""Multi-GPU GCond: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+"""Multi-GPU GCond: one process per GPU; the exchanges are issued INSIDE libgslim_hip.so (gs_comm: RCCL over xGMI), one
+library call per rank and outer iteration (gs_gcond_outer_step_sharded).  torch.distributed only bootstraps (rendezvous,
+broadcast of the RCCL unique id) and carries the test transports (gloo).
 
 What shards: inside one outer iteration theta, X~ and A^ are fixed, so the C class terms of
 train_class (gcond_base.py:210-239) are independent summands — classes are partitioned over ranks (sampler, real-side
@@ -10,8 +12,13 @@ and runs the (tiny) inner SGC steps replicated, so the replicas never drift.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+
 import numpy as np
 import torch
+
+from ._lib import ALLREDUCE_FN, check, lib, ptr, stream
 
 
 def split_even(n, world):
@@ -75,13 +82,121 @@ class Collective:
         return out
 
 
+class Comm:
+    """gs_comm handle (include/gslim.h): the all-reduce(sum) transport the library itself calls between the parts of a sharded
+    iteration.  null() — no exchange (world 1, timing-only virtual ranks); rccl() — ncclAllReduce on a communicator the library
+    creates (the unique id travels over torch.distributed); callback() — a Python function performs the exchange (gloo between
+    processes sharing one GPU, in-process virtual ranks)."""
+
+    TAGS = ("bn2_sums", "pair_scores", "dfeat_dadj_loss", "bn2_bwd_sums", "marginals_dw1", "tag5", "tag6", "other")
+
+    def __init__(self, h, kind, keep=None):
+        self.h, self.kind, self._keep = h, kind, keep
+
+    @classmethod
+    def null(cls, rank=0, world=1):
+        h = C.c_void_p()
+        check(lib().gs_comm_create_null(rank, world, C.byref(h)))
+        return cls(h, "null")
+
+    @classmethod
+    def rccl(cls, dist, group=None):
+        """One RCCL communicator over the ranks of `group`; the current CUDA device is this rank's GPU."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            check(lib().gs_comm_unique_id(buf))
+        box = [buf.raw if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        idb = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        check(lib().gs_comm_create_rccl(idb, rank, world, C.byref(h)))
+        return cls(h, "rccl")
+
+    @classmethod
+    def rccl_world1(cls):
+        """A one-rank RCCL communicator (the 1-GPU test leg of the RCCL binding)."""
+        buf = C.create_string_buffer(128)
+        check(lib().gs_comm_unique_id(buf))
+        h = C.c_void_p()
+        check(lib().gs_comm_create_rccl(buf, 0, 1, C.byref(h)))
+        return cls(h, "rccl")
+
+    @classmethod
+    def callback(cls, fn, rank, world, host=False):
+        """fn(tensor) all-reduces the given zero-copy view of the engine buffer in place (any exception fails the library call).
+        host: the buffers are host memory (the CPU tests of the transport itself)."""
+
+        def _cb(user, buf, count, dtype, stream):
+            try:
+                if host:
+                    arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double if dtype else C.c_float)), shape=(count,))
+                    fn(torch.from_numpy(arr))
+                else:
+                    from .engine import device_view
+                    dev = torch.device("cuda", torch.cuda.current_device())
+                    fn(device_view(buf, count, torch.float64 if dtype else torch.float32, dev))
+                return 0
+            except Exception:      # noqa: BLE001 — must not propagate through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        cb = ALLREDUCE_FN(_cb)
+        h = C.c_void_p()
+        check(lib().gs_comm_create_callback(cb, None, rank, world, C.byref(h)))
+        return cls(h, "callback", keep=(cb, fn))
+
+    @classmethod
+    def from_dist(cls, dist=None, group=None):
+        """The transport that fits the process group: none -> null, nccl -> RCCL inside the library, anything else (gloo) ->
+        callback onto dist.all_reduce."""
+        if dist is None or dist.get_world_size(group) == 1:
+            return cls.null()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if dist.get_backend(group) == "nccl" and os.environ.get("GS_COMM", "rccl") == "rccl":
+            return cls.rccl(dist, group)
+        return cls.callback(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group), rank, world)
+
+    def allreduce(self, t, tag=7):
+        check(lib().gs_comm_allreduce(self.h, ptr(t), t.numel(), 1 if t.dtype == torch.float64 else 0, tag, stream()))
+
+    @property
+    def world(self):
+        return lib().gs_comm_world(self.h)
+
+    def set_timing(self, on):
+        check(lib().gs_comm_set_timing(self.h, int(on)))
+
+    def timing_report(self):
+        """{exchange point: {"calls", "bytes" (per call), "avg_us"}} since set_timing(True) (synchronises the recorded events)."""
+        calls, nbytes, us = (C.c_long * 8)(), (C.c_long * 8)(), (C.c_double * 8)()
+        check(lib().gs_comm_read_timing(self.h, calls, nbytes, us))
+        return {self.TAGS[t]: {"calls": calls[t], "bytes": nbytes[t] // max(calls[t], 1), "avg_us": round(us[t] / max(calls[t], 1), 2)}
+                for t in range(8) if calls[t]}
+
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            try:
+                lib().gs_comm_destroy(h)
+            except Exception:      # noqa: BLE001 — interpreter shutdown
+                pass
+            self.h = None
+
+
 class ShardedGCond:
-    """Drives one rank's engine through a sharded outer iteration (same order as gs_gcond_outer_step)."""
+    """One rank's engine of a sharded run.  outer_step = ONE library call (gs_gcond_outer_step_sharded: the stage sequence of
+    gs_gcond_outer_step with the all-reduces issued by the library through `comm`); `phases` / `outer_step_py` keep the same
+    iteration as a host-side phase list over a torch.distributed Collective (the first form; tests compare the two)."""
 
-    parallelism = "class-parallel + PGE pair-row sharding, all-reduce(sum)"
+    parallelism = "class-parallel + PGE pair-row sharding, all-reduce(sum) issued inside the library (gs_comm)"
 
-    def __init__(self, engine, rank, world, pool_sizes, collective: Collective):
-        self.eng, self.rank, self.world, self.col = engine, rank, world, collective
+    def __init__(self, engine, rank, world, pool_sizes, collective: Collective = None, comm: Comm = None):
+        self.eng, self.rank, self.world = engine, rank, world
+        self.col = collective if collective is not None else Collective(None)
+        self._comm = comm          # built on first use: the transport that fits the Collective's process group
+        self.driver = os.environ.get("GS_SHARDED_DRIVER", "library")      # "python": the host-side phase list (first form)
         s = engine.shapes
         self.class_ranges = split_classes([min(s.bcap, int(p)) for p in pool_sizes], world)
         self.row_ranges = split_even(s.n_syn, world)
@@ -116,11 +231,56 @@ class ShardedGCond:
         ph += fwd(True) + [(e.inner_steps, None)]
         return ph
 
-    def outer_step(self, epoch):
+    def outer_step_py(self, epoch):
         for fn, buf in self.phases(epoch):
             fn()
             if buf is not None:
                 self.col.allreduce(self.v[buf], buf)
+
+    @property
+    def comm(self):
+        if self._comm is None:
+            self._comm = Comm.from_dist(self.col.dist, self.col.group)
+        return self._comm
+
+    def outer_step(self, epoch):
+        if self.driver == "python":
+            return self.outer_step_py(epoch)
+        self.eng.outer_step_sharded(epoch, self.comm)
+
+    def verify_transport(self):
+        """Before the first iteration of a multi-rank job: all-reduce a known vector through the library's transport and through
+        torch.distributed and compare.  A transport that cannot be created or disagrees (an RCCL build this library's binding does
+        not fit) switches this rank — and, through the agreement all-reduce, every rank — to the host-side phase list over
+        torch.distributed, loudly."""
+        import sys
+        dist, group = self.col.dist, self.col.group
+        if dist is None or dist.get_world_size(group) == 1:
+            return True
+        dev = self.eng.dev
+        ok = 1.0
+        try:
+            t = torch.arange(4096, device=dev, dtype=torch.float32) * float(self.rank + 1)
+            d = torch.arange(64, device=dev, dtype=torch.float64) * float(self.rank + 1)
+            rt, rd = t.clone(), d.clone()
+            self.comm.allreduce(t, 7)
+            self.comm.allreduce(d, 7)
+            dist.all_reduce(rt, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(rd, op=dist.ReduceOp.SUM, group=group)
+            torch.cuda.synchronize(dev)
+            if not (torch.equal(t, rt) and torch.equal(d, rd)):
+                ok = 0.0
+        except Exception as e:      # noqa: BLE001
+            print(f"graphslim_amd.parallel: rank {self.rank}: library transport failed ({e!r})", file=sys.stderr, flush=True)
+            ok = 0.0
+        flag = torch.tensor([ok], device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if float(flag) < 1.0:
+            print(f"graphslim_amd.parallel: rank {self.rank}: falling back to the host-side phase list over torch.distributed",
+                  file=sys.stderr, flush=True)
+            self.driver = "python"
+            return False
+        return True
 
 
 class RowShard:
@@ -218,6 +378,8 @@ def active_dist():
 def make_engine(p, dev, rank, world):
     """bench.py entry: this rank's sharded engine over torch.distributed (process group already initialised)."""
     import torch.distributed as dist
-    import bench
-    eng = bench.make_engine(p, dev)
-    return ShardedGCond(eng, rank, world, [len(q) for q in p["pools"]], Collective(dist))
+    from .workloads import make_engine as _make
+    eng = _make(p, dev)
+    sh = ShardedGCond(eng, rank, world, [len(q) for q in p["pools"]], Collective(dist))
+    sh.verify_transport()
+    return sh

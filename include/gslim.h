@@ -171,7 +171,8 @@ int gs_sample_blocks(const int* rowptr, const int* col, const float* val, int n_
  * dense_gcn_norm forward / backward (graphslim/utils.py:429-439 and its autograd).
  * fwd: A^ = D^-1/2 (adj + I) D^-1/2 with row-sum degrees; r_out has 2n floats: [0,n) keeps deg^-1/2,
  *      [n,2n) is scratch for the backward pass.
- * bwd: d adj from d A^.
+ * bwd: d adj from d A^.  d_adj must NOT alias d_adj_norm when n > 2048 (the large-n path stages column partials in
+ *      d_adj before it is written; GS_ERR_ARG otherwise); in-place use is fine for n <= 2048.
  * ------------------------------------------------------------------------------------------- */
 int gs_dense_gcn_norm_fwd(const float* adj, int n, float* adj_norm, float* r_out, gs_stream_t stream);
 int gs_dense_gcn_norm_bwd(const float* adj, const float* r, const float* d_adj_norm, int n, float* d_adj,
@@ -432,6 +433,42 @@ int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int part, gs_str
 int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grads, int need_feat_grad, int part, gs_stream_t stream);
 int gs_gcond_stage_syn_finish(gs_gcond* e, gs_stream_t stream);       /* books the (all-reduced) loss_c into the accumulator */
 int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream);      /* the SGC steps of gs_gcond_stage_inner, without PGE.inference */
+
+/* ---- the exchange itself, inside the library -----------------------------------------------------------------------
+ * gs_comm: all-reduce(sum) between the ranks of a sharded run, issued by the library on the engine's stream.  Transports:
+ *   rccl      ncclAllReduce (RCCL over xGMI; bound with dlopen, the library has no link-time dependency on it).  Rank 0 calls
+ *             gs_comm_unique_id and hands the 128 bytes to every rank (host side: any broadcast, e.g. torch.distributed);
+ *             every rank then calls gs_comm_create_rccl with its device current.
+ *   callback  `fn(user, buf, count, dtype, stream)` performs the exchange (dtype 0 = fp32, 1 = fp64; returns 0 on success):
+ *             tests over gloo between processes that share one GPU, in-process virtual ranks.
+ *   null      no exchange (world 1; timing-only virtual ranks).
+ * gs_gcond_outer_step_sharded = gs_gcond_outer_step for this rank's share (gs_gcond_set_shard), with the exchanges of the
+ * part-wise protocol above issued in between: ONE host call per rank and outer iteration; `_ex` takes the update rule of
+ * gs_gcond_outer_step_ex.  Exchange points (`tag` of gs_comm_allreduce / index of gs_comm_read_timing's arrays [8]):
+ * 0 BN-2 sums, 1 pair scores, 2 [dX~ | d adj | loss_c], 3 BN-2 backward sums, 4 marginals (+ dW1 | db1), 7 other. */
+typedef struct gs_comm gs_comm;
+typedef int (*gs_allreduce_fn)(void* user, void* buf, long count, int dtype, gs_stream_t stream);
+int gs_comm_unique_id(void* id128);                                   /* host: 128 bytes out */
+int gs_comm_create_rccl(const void* id128, int rank, int world, gs_comm** out);
+int gs_comm_create_callback(gs_allreduce_fn fn, void* user, int rank, int world, gs_comm** out);
+int gs_comm_create_null(int rank, int world, gs_comm** out);
+void gs_comm_destroy(gs_comm* c);
+int gs_comm_rank(const gs_comm* c);
+int gs_comm_world(const gs_comm* c);
+int gs_comm_allreduce(gs_comm* c, void* buf, long count, int dtype, int tag, gs_stream_t stream);
+int gs_comm_set_timing(gs_comm* c, int on);                           /* event pairs around every exchange from now on */
+int gs_comm_read_timing(gs_comm* c, long* calls, long* bytes, double* total_us);   /* host arrays [8]; synchronises */
+int gs_gcond_outer_step_sharded(gs_gcond* e, int epoch, gs_comm* comm, gs_stream_t stream);
+int gs_gcond_outer_step_sharded_ex(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_comm* comm,
+                                   gs_stream_t stream);
+
+/* Measurement knob: 1 (default) = a sharded rank computes only the rows of H1 = relu(X W1 + b1) (models/sgc.py:38-43) that the
+ * sampled blocks of ITS classes gather (marked and compacted on the device); 0 = every rank computes all N rows.  Same values. */
+int gs_gcond_set_h1_rows(int on);
+
+/* Test hook of the sampler's seed selection (gs_sample_blocks): members of the crossing key bin that are ranked directly
+ * (1 .. 2048, default 2048); a small value forces the second histogram level on ordinary pools.  Same seeds either way. */
+int gs_sample_set_cand_cap(int cap);
 
 /* Named views into engine-owned scratch for the parity tests (device pointer + element count):
  * "gw_real" [C][|theta|], "gw_syn" [C][|theta|], "loss" [1], "d_feat" [n'][d] (total gradient wrt X~),

@@ -52,3 +52,55 @@ def sbm_graph(n, nclass, d, avg_deg, seed, homophily=0.8):
     mu = rng.normal(size=(nclass, d))
     x = (mu[y] + rng.normal(size=(n, d))).astype(np.float32)
     return a, x, y.astype(np.int64)
+
+
+class VirtualWorld:
+    """`world` ranks as threads of ONE process sharing one GPU, each driving its own engine through the library's sharded entry
+    point (gs_gcond_outer_step_sharded): the callback transport of gs_comm sums the ranks' buffers in place (ctypes releases the GIL
+    inside the library call; the callback re-enters Python on the calling thread).  All threads use the legacy default stream."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world, timeout=120)
+        self.slots = [None] * world
+        self.calls = 0
+
+    def comm(self, rank):
+        from graphslim_amd.parallel import Comm
+
+        def fn(t):
+            self.slots[rank] = t
+            self.barrier.wait()
+            if rank == 0:
+                torch.cuda.synchronize()
+                total = torch.stack(self.slots).sum(0)
+                for s in self.slots:
+                    s.copy_(total)
+                torch.cuda.synchronize()
+                self.calls += 1
+            self.barrier.wait()
+
+        return Comm.callback(fn, rank, self.world)
+
+    def run(self, fns):
+        """fns[r]() on thread r; re-raises the first exception (and breaks the barrier so the others do not wait forever)."""
+        import threading
+        errs = []
+
+        def wrap(r):
+            try:
+                torch.cuda.set_device(0)
+                fns[r]()
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+                self.barrier.abort()
+
+        ts = [threading.Thread(target=wrap, args=(r,)) for r in range(self.world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        torch.cuda.synchronize()
+        if errs:
+            raise errs[0]

@@ -306,12 +306,24 @@ def test_error_paths():
 
 
 class _LockStep:
-    """world sharded engines on ONE GPU driven phase by phase; the all-reduce is emulated by summing the buffers."""
+    """world sharded engines on ONE GPU.  driver "c": every rank on its own thread calls the library's ONE-call sharded iteration
+    (gs_gcond_outer_step_sharded) and the library issues the exchanges through the callback transport (helpers.VirtualWorld sums
+    the ranks' buffers); driver "py": the host-side phase list, the all-reduce emulated by summing the buffers between phases."""
 
-    def __init__(self, shs):
-        self.shs = shs
+    def __init__(self, shs, driver="c"):
+        self.shs, self.driver = shs, driver
+        if driver == "c":
+            from helpers import VirtualWorld
+            self.vw = VirtualWorld(len(shs))
+            for r, sh in enumerate(shs):
+                sh._comm = self.vw.comm(r)
 
     def outer_step(self, epoch):
+        if self.driver == "c":
+            before = self.vw.calls
+            self.vw.run([(lambda sh=sh: sh.outer_step(epoch)) for sh in self.shs])
+            assert self.vw.calls - before >= 5          # the library really exchanged (5 - 7 joins per iteration)
+            return
         phases = [sh.phases(epoch) for sh in self.shs]
         for i in range(len(phases[0])):
             for ph in phases:
@@ -324,8 +336,9 @@ class _LockStep:
                     v.copy_(total)
 
 
+@pytest.mark.parametrize("driver", ["c", "py"])
 @pytest.mark.parametrize("t,world", [(1, 2), (2, 2), (2, 3), (2, 8)])
-def test_sharded_engines_reproduce_the_single_gpu_run(t, world):
+def test_sharded_engines_reproduce_the_single_gpu_run(t, world, driver):
     """class-parallel + PGE pair-row sharding with all-reduce(sum) == the unsharded iteration
     (same sampled blocks because the sampler keys its RNG by the global class id)."""
     from graphslim_amd.parallel import Collective, ShardedGCond
@@ -342,7 +355,7 @@ def test_sharded_engines_reproduce_the_single_gpu_run(t, world):
     ref = build()
     engs = [build() for _ in range(world)]
     shs = [ShardedGCond(e, r, world, [len(q) for q in p["pools"]], Collective(None)) for r, e in enumerate(engs)]
-    lock = _LockStep(shs)
+    lock = _LockStep(shs, driver)
     for epoch in (0, 10):
         ref.set_model(p["theta"])
         for e in engs:
@@ -370,6 +383,91 @@ def test_sharded_engines_reproduce_the_single_gpu_run(t, world):
         assert torch.equal(e.model_params, engs[0].model_params)
 
 
+def test_h1_rows_of_a_class_shard_are_the_full_product():
+    """A sharded rank computes only the rows of H1 = relu(X W1 + b1) its classes' blocks gather (device-side mark + compact, row-list
+    form of the row-panel product): the real-side gradients of the shard must be BITWISE those computed from the full product, in
+    every operand mode, and the listed rows of H1full bitwise the full product's rows."""
+    import bench
+    from graphslim_amd import _lib
+    from graphslim_amd.host import init_sgc_params
+    p = bench.build_problem("ogbn-arxiv", seed=1, scale=0.25)
+    eng = bench.make_engine(p, DEV)
+    bench.init_state(p, eng)
+    torch.manual_seed(3)
+    eng.set_model(init_sgc_params(p["data"].feat_full.shape[1], p["hidden"], p["data"].nclass, p["T"]))
+    C, N = p["data"].nclass, p["data"].bench_n
+    L = _lib.lib()
+    c_lo, c_hi = 7, 10
+    assert (c_hi - c_lo) * 256 * 11 * 5 < N          # the row-list form is the one that runs
+    eng.set_shard(c_lo, c_hi, 0, len(p["labels_syn"]))
+    eng.stage_sample()
+    try:
+        for mode in ("f32", "bf16x6", "bf16x3"):
+            eng.set_operand_mode(mode)
+            _lib.check(L.gs_gcond_set_h1_rows(0))
+            eng.view("H1full").zero_()
+            eng.stage_real_grads()
+            full_h1 = eng.view("H1full").clone().reshape(N, -1)
+            full_gw = eng.view("gw_real").clone().reshape(C, -1)[c_lo:c_hi]
+            _lib.check(L.gs_gcond_set_h1_rows(1))
+            eng.view("H1full").fill_(float("nan"))
+            eng.stage_real_grads()
+            torch.cuda.synchronize()
+            h1 = eng.view("H1full").reshape(N, -1)
+            rows = ~torch.isnan(h1[:, 0])
+            assert 0 < int(rows.sum()) < N
+            assert torch.equal(h1[rows], full_h1[rows]), mode
+            assert torch.equal(eng.view("gw_real").reshape(C, -1)[c_lo:c_hi], full_gw), mode
+            blk = eng.get_blocks()
+            need = torch.zeros(N, dtype=torch.bool, device=DEV)
+            for c in range(c_lo, c_hi):
+                n1 = int(blk.n1[c])
+                m = blk.val0[c, :n1] != 0
+                need[blk.col0[c, :n1][m].long()] = True
+            assert torch.equal(need, rows)               # exactly the gathered sources, nothing else
+    finally:
+        _lib.check(L.gs_gcond_set_h1_rows(1))
+        eng.set_operand_mode("f32")
+
+
+def test_library_rccl_binding_world1():
+    """gs_comm's RCCL transport (dlopen of librccl, ncclCommInitRank, ncclAllReduce on the engine's stream) with ONE rank — all a
+    1-GPU box can run of it: a whole sharded outer iteration through gs_gcond_outer_step_sharded reproduces gs_gcond_outer_step
+    bitwise (world 1: every all-reduce is the identity, but each one goes through ncclAllReduce on fp32 and fp64 engine buffers),
+    and the bookkeeping reports the joins."""
+    from graphslim_amd.parallel import Comm, ShardedGCond
+    p = _problem(2, seed=3)
+
+    def build():
+        eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 2, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
+                          p["f2"], bcap=p["bcap"], inner=1, csr=p["csr"], pools=p["pools"], external=False, seed=5)
+        eng.set_feat(p["xs"])
+        eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
+        eng.set_model(p["theta"])
+        return eng
+
+    ref, eng = build(), build()
+    comm = Comm.rccl_world1()
+    assert comm.world == 1
+    v = torch.arange(1000, device=DEV, dtype=torch.float32)
+    comm.allreduce(v)
+    w = torch.arange(77, device=DEV, dtype=torch.float64)
+    comm.allreduce(w)
+    torch.cuda.synchronize()
+    assert torch.equal(v, torch.arange(1000, device=DEV, dtype=torch.float32)) and torch.equal(w, torch.arange(77, device=DEV, dtype=torch.float64))
+    sh = ShardedGCond(eng, 0, 1, [len(q) for q in p["pools"]], comm=comm)
+    comm.set_timing(True)
+    for epoch in (0, 10):
+        ref.outer_step(epoch)
+        sh.outer_step(epoch)
+    torch.cuda.synchronize()
+    rep = comm.timing_report()
+    assert rep["bn2_sums"]["calls"] == 4 and rep["pair_scores"]["calls"] == 4 and rep["dfeat_dadj_loss"]["calls"] == 2, rep
+    assert rep["marginals_dw1"]["calls"] == 2 and rep["bn2_bwd_sums"]["calls"] == 2, rep
+    assert torch.equal(eng.feat_syn, ref.feat_syn) and torch.equal(eng.pge_params, ref.pge_params)
+    assert torch.equal(eng.model_params, ref.model_params) and torch.equal(eng.adj_syn, ref.adj_syn)
+
+
 def test_rccl_allreduce_on_engine_views_world1():
     """The collectives of graphslim_amd/parallel.py run on zero-copy views of library-owned buffers (fp32 and fp64):
     check that RCCL accepts them (single-rank group on this box; multi-rank equivalence is covered by the lock-step test)."""
@@ -387,7 +485,7 @@ def test_rccl_allreduce_on_engine_views_world1():
         eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
         eng.set_model(p["theta"])
         sh = ShardedGCond(eng, 0, 1, [len(q) for q in p["pools"]], Collective(dist))
-        sh.outer_step(0)
+        sh.outer_step_py(0)
         for name, v in sh.v.items():
             before = v.clone()
             dist.all_reduce(v)                      # world 1: identity, but exercises RCCL on the view

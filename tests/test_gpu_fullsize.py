@@ -147,8 +147,8 @@ def test_planetoid_r0005_full_size(name):
     check(run_config(name, 0))
 
 
-@pytest.mark.parametrize("world,mode", [(2, "f32"), (3, "f32"), (8, "f32"), (2, "bf16x3")])
-def test_sharded_ranks_reproduce_the_single_gpu_run_at_panel_shapes(world, mode):
+@pytest.mark.parametrize("world,mode,driver", [(2, "f32", "c"), (3, "f32", "c"), (8, "f32", "c"), (2, "bf16x3", "c"), (3, "f32", "py")])
+def test_sharded_ranks_reproduce_the_single_gpu_run_at_panel_shapes(world, mode, driver):
     """Class-parallel + pair-row sharding at a shape where the round-2 PGE forms are the ones that run
     (n' >= 128: A1 generated in the forward product, marginals fused with the regenerated mask, dE2 generated in feature epochs)
     with r_lo > 0 and ragged row ranges: `world` virtual ranks in lock step on one GPU (exchanges = sums of the ranks' buffers)
@@ -173,7 +173,7 @@ def test_sharded_ranks_reproduce_the_single_gpu_run_at_panel_shapes(world, mode)
     ref = build()
     engs = [build() for _ in range(world)]
     shs = [ShardedGCond(e, r, world, [len(q) for q in p["pools"]], Collective(None)) for r, e in enumerate(engs)]
-    lock = _LockStep(shs)
+    lock = _LockStep(shs, driver)
     ph, d = p["ph"], p["data"].feat_full.shape[1]
     keep = np.ones(ref.pge_params.numel(), dtype=bool)       # the two biases in front of a batch-statistics BatchNorm: zero true gradient
     keep[ph * 2 * d: ph * 2 * d + ph] = False

@@ -276,6 +276,113 @@ def test_sampler_properties(E):
     assert abs(freq.mean() - p) < 1e-9 and freq.std() < 3.5 * np.sqrt(p * (1 - p) / T_)
 
 
+def test_sampler_neighbour_subsets_are_uniform(E):
+    """loader.py:216-223 / torch_sparse sample_adj semantics at the level the reference defines them (distributional):
+    the <= f neighbours kept for a row are a UNIFORM f-subset of its neighbours — every neighbour is kept with probability f / deg
+    (chi-square over the neighbours of each row) and every PAIR of neighbours jointly with f (f - 1) / (deg (deg - 1)) (the
+    signature of sampling without replacement, as opposed to independent draws) — for the hop-1 draw of the seeds and for the
+    hop-2 draw of the same rows (another fan-out, another RNG stream)."""
+    n, C = 1200, 2
+    a, x, y = sbm_graph(n, C, 4, 30, seed=11)
+    rp, col, val = O.normalize_adj_sparse(a)
+    deg = np.diff(rp)
+    rng = np.random.default_rng(0)
+    cand = np.where(deg >= 24)[0]
+    pools = [np.sort(rng.permutation(cand)[:12]), np.sort(rng.permutation(n)[:400])]      # class 0: 12 fixed seeds (pool < bcap)
+    cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
+    cls_nodes = np.concatenate(pools)
+    i32 = lambda v: torch.as_tensor(np.asarray(v), dtype=torch.int32, device=DEV)
+    bcap, f1, f2 = 16, 10, 5
+    blocks = E.BlockSet(C, bcap, f1, f2, DEV)
+    marker = torch.full((C * n,), 0x7fffffff, dtype=torch.int32, device=DEV)
+    args = (i32(rp), i32(col), torch.as_tensor(val, device=DEV), n, i32(cls_ptr), i32(cls_nodes), marker, blocks)
+    T_ = 1500
+    seeds = pools[0]
+    nbr = {int(v): col[rp[v]:rp[v + 1]] for v in seeds}
+    pos = {int(v): {int(u): i for i, u in enumerate(nbr[int(v)])} for v in seeds}
+    cnt1 = {int(v): np.zeros(len(nbr[int(v)])) for v in seeds}
+    cnt2 = {int(v): np.zeros(len(nbr[int(v)])) for v in seeds}
+    pair1 = {int(v): 0 for v in seeds}
+    pair2 = {int(v): 0 for v in seeds}
+    for t in range(T_):
+        E.sample_blocks(*args, 4242, t)
+        nid = blocks.nid1[0].cpu().numpy()
+        c1, v1 = blocks.col1[0].cpu().numpy(), blocks.val1[0].cpu().numpy()
+        c0, v0 = blocks.col0[0].cpu().numpy(), blocks.val0[0].cpu().numpy()
+        assert int(blocks.n_seed[0]) == len(seeds) and np.array_equal(nid[:len(seeds)], seeds)      # pool <= bcap: all of it, in order
+        for b, v in enumerate(seeds):
+            v = int(v)
+            got1 = [pos[v][int(u)] for u in nid[c1[b][v1[b] != 0]]]
+            got2 = [pos[v][int(u)] for u in c0[b][v0[b] != 0]]
+            assert len(got1) == f1 and len(set(got1)) == f1 and len(got2) == f2 and len(set(got2)) == f2
+            cnt1[v][got1] += 1
+            cnt2[v][got2] += 1
+            pair1[v] += (0 in got1) and (1 in got1)
+            pair2[v] += (0 in got2) and (1 in got2)
+    for cnt, pair, f in ((cnt1, pair1, f1), (cnt2, pair2, f2)):
+        chi_tot, dof, pair_obs, pair_exp = 0.0, 0, 0.0, 0.0
+        for v in cnt:
+            D = len(cnt[v])
+            pr = f / D
+            chi = float((((cnt[v] - T_ * pr) ** 2) / (T_ * pr * (1 - pr))).sum())
+            assert chi < D + 5 * np.sqrt(2 * D), (v, D, chi)           # per row: E[chi] = D (the indicators are negatively correlated)
+            chi_tot += chi
+            dof += D
+            pair_obs += pair[v]
+            pair_exp += T_ * f * (f - 1) / (D * (D - 1))
+        assert abs(chi_tot - dof) < 5 * np.sqrt(2 * dof), (chi_tot, dof)
+        # joint inclusion of two fixed neighbours: without replacement f(f-1)/(D(D-1)); independent draws would give (f/D)^2 (larger)
+        assert abs(pair_obs - pair_exp) < 5 * np.sqrt(pair_exp), (pair_obs, pair_exp)
+
+
+def test_sampler_seed_selection_two_level_path_and_ties(E):
+    """the parallel seed selection must deliver exactly bcap distinct seeds whatever the key distribution.  The second
+    histogram level (pools so large that the crossing key bin overflows the ranked candidate list) is forced on an ordinary pool
+    through the test hook gs_sample_set_cand_cap: the blocks must be bitwise those of the one-level path (the selection is exact
+    either way), every batch complete and duplicate-free."""
+    from graphslim_amd import _lib
+    n, C = 40000, 3
+    rng = np.random.default_rng(5)
+    m = 4 * n
+    src, dst = rng.integers(0, n, m), rng.integers(0, n, m)
+    keep = src != dst
+    a = sp.coo_matrix((np.ones(keep.sum()), (src[keep], dst[keep])), shape=(n, n)).tocsr()
+    a = ((a + a.T) > 0).astype(np.int64).tocsr()
+    rp, col, val = O.normalize_adj_sparse(a)
+    perm = rng.permutation(n)
+    pools = [np.sort(perm[:30000]), np.sort(perm[30000:30300]), np.sort(perm[30300:30310])]
+    cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
+    cls_nodes = np.concatenate(pools)
+    i32 = lambda v: torch.as_tensor(np.asarray(v), dtype=torch.int32, device=DEV)
+    bcap, f1, f2 = 256, 4, 3
+    marker = torch.full((C * n,), 0x7fffffff, dtype=torch.int32, device=DEV)
+    L = _lib.lib()
+    out = {}
+    try:
+        for cap in (2048, 3, 1):
+            _lib.check(L.gs_sample_set_cand_cap(cap))
+            blocks = E.BlockSet(C, bcap, f1, f2, DEV)
+            res = []
+            for step in range(6):
+                E.sample_blocks(i32(rp), i32(col), torch.as_tensor(val, device=DEV), n, i32(cls_ptr), i32(cls_nodes), marker, blocks, 77, step)
+                torch.cuda.synchronize()
+                res.append({f: getattr(blocks, f).cpu().numpy().copy() for f in blocks.FIELDS})
+            out[cap] = res
+    finally:
+        _lib.check(L.gs_sample_set_cand_cap(2048))
+    assert L.gs_sample_set_cand_cap(0) == -1 and L.gs_sample_set_cand_cap(4096) == -1
+    for step in range(6):
+        r = out[2048][step]
+        for c in range(C):
+            B = int(r["n_seed"][c])
+            assert B == min(bcap, len(pools[c]))
+            sd = r["nid1"][c, :B]
+            assert len(set(sd.tolist())) == B and set(sd.tolist()) <= set(pools[c].tolist())
+        for cap in (3, 1):
+            for f in r:
+                assert np.array_equal(out[cap][step][f], r[f]), (cap, step, f)
+
+
 def test_spmm_csr_ragged_rows_and_nonfinite_row0(E):
     """Rows of very different length inside one wave (sub-wave row groups), F not a multiple of the lane tile, and a
     non-finite X[0] that no row references: padding slots must not leak 0*inf."""

@@ -83,9 +83,9 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng = FakeEngine(rank)
     sh = ShardedGCond(eng, rank, world, [500, 30, 300, 256, 10], Collective(dist))
-    sh.outer_step(0)      # PGE epoch: ar_w1 exchanged
+    sh.outer_step_py(0)      # PGE epoch: ar_w1 exchanged
     a = {k: v.clone() for k, v in eng.bufs.items()}
-    sh.outer_step(10)     # feature epoch: ar_w1 untouched by the collective
+    sh.outer_step_py(10)     # feature epoch: ar_w1 untouched by the collective
     q.put((rank, eng.shard, eng.calls, {k: v.tolist() for k, v in a.items()}, eng.bufs["ar_w1"].tolist()))
     dist.barrier()
     dist.destroy_process_group()
@@ -118,6 +118,66 @@ def test_sharded_driver_over_gloo_world2():
     assert bufs0["ar_bn2"][0] == 9.0 and bufs0["e3"][0] == 9.0
     # feature epoch: ar_w1 is filled locally but NOT reduced (3 + own contribution only)
     assert w0 == [4.0] * 6 and w1 == [5.0] * 6
+
+
+def _comm_worker(rank, world, port, q):
+    """The library's own exchange entry point (gs_comm_allreduce, callback transport) between two real processes over gloo, on
+    host buffers: what gs_gcond_outer_step_sharded calls between the parts of an iteration, minus the GPU."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import torch.distributed as dist
+    from graphslim_amd import _lib
+    from graphslim_amd.parallel import Comm
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = Comm.callback(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), rank, world, host=True)
+    L = _lib.lib()
+    a = np.full(1000, rank + 1.0, dtype=np.float32)
+    b = np.arange(6, dtype=np.float64) * (rank + 1)
+    _lib.check(L.gs_comm_allreduce(comm.h, a.ctypes.data_as(C.c_void_p), a.size, 0, 2, None))
+    _lib.check(L.gs_comm_allreduce(comm.h, b.ctypes.data_as(C.c_void_p), b.size, 1, 0, None))
+    _lib.check(L.gs_comm_allreduce(comm.h, b.ctypes.data_as(C.c_void_p), 0, 1, 0, None))         # empty buffers are legal
+    calls, nbytes, us = (C.c_long * 8)(), (C.c_long * 8)(), (C.c_double * 8)()
+    _lib.check(L.gs_comm_read_timing(comm.h, calls, nbytes, us))
+    bad = L.gs_comm_allreduce(comm.h, None, 5, 0, 0, None)
+    q.put((rank, a.tolist()[:3], b.tolist(), list(calls), list(nbytes), bad, comm.world, L.gs_comm_rank(comm.h)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_library_exchange_entry_point_over_gloo_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, a, b, calls, nbytes, bad, world, crank in res:
+        assert a == [3.0, 3.0, 3.0] and b == [0.0, 3.0, 6.0, 9.0, 12.0, 15.0]      # sums over the two ranks, fp32 and fp64
+        assert calls[2] == 1 and calls[0] == 2 and nbytes[2] == 4000 and nbytes[0] == 48
+        assert bad == -1 and world == 2 and crank == rank                           # GS_ERR_ARG for a null buffer
+
+
+def test_null_transport_and_argument_checks():
+    import ctypes as C
+    from graphslim_amd import _lib
+    from graphslim_amd.parallel import Comm
+    L = _lib.lib()
+    c = Comm.null(3, 8)
+    assert c.world == 8 and L.gs_comm_rank(c.h) == 3
+    x = np.ones(4, dtype=np.float32)
+    _lib.check(L.gs_comm_allreduce(c.h, x.ctypes.data_as(C.c_void_p), 4, 0, 1, None))          # no exchange: values untouched
+    assert x.tolist() == [1.0] * 4
+    h = C.c_void_p()
+    assert L.gs_comm_create_null(8, 8, C.byref(h)) == -1 and b"gs_comm_create_null" in L.gs_last_error()
+    assert L.gs_gcond_outer_step_sharded(None, 0, c.h, None) == -1
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -9,14 +9,14 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import bench  # noqa: E402
-from graphslim_amd.parallel import Collective, ShardedGCond  # noqa: E402
+from graphslim_amd.parallel import Comm, ShardedGCond  # noqa: E402
 
 world, rank = int(sys.argv[1]), int(sys.argv[2])
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 p = bench.build_problem("ogbn-arxiv", seed=1)
 eng = bench.make_engine(p, "cuda:0")
 bench.init_state(p, eng)
-sh = ShardedGCond(eng, rank, world, [len(q) for q in p["pools"]], Collective(None)) if world > 0 else eng
+sh = ShardedGCond(eng, rank, world, [len(q) for q in p["pools"]], comm=Comm.null(rank, world)) if world > 0 else eng
 bench.run_steps(p, sh, 5, 5)
 torch.cuda.synchronize()
 t0 = time.perf_counter()

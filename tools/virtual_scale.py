@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Compute-only estimate of multi-GPU scaling on ONE GPU: for world in (1, 2, 4, 8) every virtual rank's sharded outer
-iteration (graphslim_amd/parallel.py phases, all-reduce replaced by a no-op) is timed in turn; max over ranks is the
+iteration (gs_gcond_outer_step_sharded: ONE library call per iteration, null transport = exchanges are no-ops) is timed in turn; max over ranks is the
 per-step time the slowest rank would need, without RCCL latency.  Partial sums are not exchanged, so the values are
 meaningless — only the timing is used (no data-dependent control flow in the engine)."""
 import os
@@ -10,7 +10,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import bench  # noqa: E402
-from graphslim_amd.parallel import Collective, ShardedGCond  # noqa: E402
+from graphslim_amd.parallel import Comm, ShardedGCond  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "ogbn-arxiv"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -37,7 +37,7 @@ print(f"fused single-GPU outer step: {base:.3f} ms (host issue {host_ms:.3f} ms)
 for world in (1, 2, 4, 8):
     ts, hs = [], []
     for r in range(world):
-        sh = ShardedGCond(eng, r, world, pools, Collective(None))
+        sh = ShardedGCond(eng, r, world, pools, comm=Comm.null(r, world))      # the library's one-call sharded iteration, exchanges = no-ops
         bench.init_state(p, eng)
         ts.append(timed(sh))
         hs.append(round(host_ms, 3))
