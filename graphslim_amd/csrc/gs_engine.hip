@@ -18,6 +18,13 @@ int gs_panel_marginals(const float*, long, const float*, long, const float*, lon
 int gs_panel_forward_a1(const gs_panel_a1*, int, int, const float*, long, const float*, float*, long, int, int, float*, int, void*,
                         unsigned long long*, hipStream_t);
 int gs_panel_tiles(int);
+struct gs_zg_args {
+  const float* A; long sAm, sAk; const float* B; long sBk, sBn; int n, K, C; const float* rs; const float* bias;
+  const int* labels; const int* syn_lo; const int* syn_hi; int divide_by_n; float* P; float* G;
+};
+struct gs_adam_ep { float* theta; float* m; float* v; const float* gbase; float step_size, inv_sqrt_bc2, b1, b2, eps; };
+int gs_chain_zg(const gs_zg_args*, hipStream_t);
+int gs_chain_group(const gs_gemm_desc*, int, const gs_adam_ep*, hipStream_t);
 int gs_panel_rows(const float*, long, const float*, long, const float*, int, float*, long, int, int, const int*, const int*, int, long, int,
                   void*, hipStream_t);
 extern "C" int gs_comm_allreduce(gs_comm*, void*, long, int, int, gs_stream_t);
@@ -572,6 +579,7 @@ extern "C" int gs_gcond_set_shard(gs_gcond* e, int c_lo, int c_hi, int r_lo, int
 static inline bool sharded_c(const gs_gcond* e) { return e->c_lo != 0 || e->c_hi != e->C; }
 static inline bool sharded_r(const gs_gcond* e) { return e->r_lo != 0 || e->r_hi != e->n; }
 
+static int g_fused_chains = 1;      // gs_gcond_set_fused_chains
 static int g_defer_last_stage = 1;
 // measurement knob: 1 (default) = the last stage of the BN-2 / layer-3 statistics reductions is folded into its consumer
 // launch (unsharded engines); 0 = separate launch.  Same bits either way.
@@ -656,18 +664,56 @@ __global__ __launch_bounds__(256) void gs_h1_mark_kernel(const int* __restrict__
   if (l < n1[c] && val0[e] != 0.f) flag[col0[e]] = 1;
 }
 
-// list = the flagged ids (wave-level compaction, one atomic per wave: the order is arbitrary, the values computed from the list do
-// not depend on it), count = how many
+// list = the flagged ids, count = how many.  One block compacts 2 048 flags (8 per thread, block-wide exclusive scan) and takes
+// its output range with ONE atomic (a wave-per-atomic form spent 32 us on 2 646 serialised atomics): the order of the list is
+// arbitrary across blocks, the values computed from it do not depend on it.
 __global__ __launch_bounds__(256) void gs_h1_compact_kernel(const int* __restrict__ flag, int N, int* __restrict__ list,
                                                             int* __restrict__ count) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool on = v < N && flag[v] != 0;
-  const unsigned long long m = __ballot(on);
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
-  base = __shfl(base, 0, 64);
-  if (on) list[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+  __shared__ int s_w[4];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int v0 = (blockIdx.x * 256 + tid) * 8;
+  int f[8], mine = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { f[q] = (v0 + q < N) && flag[v0 + q] != 0; mine += f[q]; }
+  int x = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+  if (lane == 63) s_w[w] = x;
+  __syncthreads();
+  if (tid == 0) {
+    const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    s_base = tot ? atomicAdd(count, tot) : 0;
+  }
+  __syncthreads();
+  int pos = s_base + x - mine;
+  for (int i = 0; i < w; ++i) pos += s_w[i];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) if (f[q]) list[pos++] = v0 + q;
+}
+
+// sum of n floats in two stages (fp64 partials of 128 blocks, then one wave): the one-block form took 53 us at n = n'^2 = 206 116
+__global__ __launch_bounds__(256) void gs_sum_stage1_kernel(const float* __restrict__ x, long n, double* __restrict__ part) {
+  double s = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i];
+  s = gs_wave_sum_d(s);
+  __shared__ double sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(64) void gs_sum_stage2_kernel(const double* __restrict__ part, int np, float* __restrict__ out) {
+  double s = 0;
+  for (int i = threadIdx.x; i < np; i += 64) s += part[i];
+  s = gs_wave_sum_d(s);
+  if (threadIdx.x == 0) out[0] = (float)s;
+}
+static int sum_f32(gs_gcond* e, const float* x, long n, float* out, hipStream_t s) {
+  double* part = reinterpret_cast<double*>(e->colpart);      // (free here: its users ran earlier on this stream)
+  hipLaunchKernelGGL(gs_sum_stage1_kernel, dim3(128), dim3(256), 0, s, x, n, part);
+  hipLaunchKernelGGL(gs_sum_stage2_kernel, dim3(1), dim3(64), 0, s, (const double*)part, 128, out);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
 }
 
 static int g_h1_rows = 1;
@@ -736,7 +782,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       GS_HIP(hipMemsetAsync(e->h1_flag, 0, sizeof(int) * (size_t)e->N, s));
       GS_HIP(hipMemsetAsync(e->h1_count, 0, sizeof(int), s));
       hipLaunchKernelGGL(gs_h1_mark_kernel, dim3(gs_cdiv(slots, 256)), dim3(256), 0, s, b.col0, b.val0, b.n1, cap1, f2, Cl, e->h1_flag);
-      hipLaunchKernelGGL(gs_h1_compact_kernel, dim3(gs_cdiv(e->N, 256)), dim3(256), 0, s, e->h1_flag, e->N, e->h1_list, e->h1_count);
+      hipLaunchKernelGGL(gs_h1_compact_kernel, dim3(gs_cdiv(e->N, 2048)), dim3(256), 0, s, e->h1_flag, e->N, e->h1_list, e->h1_count);
       GS_LAUNCH_CHECK();
       rows_rc = gs_panel_rows(e->io.X, e->ldx, e->W1mT, d, th + e->ob1, 1, e->H1full, h, h, d, e->h1_list, e->h1_count, (int)slots,
                               (long)e->N, e->operand_mode, e->bsplit_aux, s);
@@ -798,10 +844,26 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       hipLaunchKernelGGL(gs_make_bmat_kernel, dim3(gs_cdiv((long)Cl * cap1 * f2, 4)), dim3(256), 0, s, b.col0, b.val0, b.n1, cap1,
                          f2, e->H1full, (long)h, Y1, h, Bmat, kcount, Cl);
     GS_LAUNCH_CHECK();
+    // K slabs: the engine's choice fills the chip with ALL classes (derive()); a class shard has fewer classes, so its slabs are
+    // shortened until the launch again has ~512 workgroups (one workgroup = one class x slab x 128-feature tile is bound by ONE
+    // compute unit's matrix rate: 5 classes in 1 024-edge slabs ran 194 us on 70 workgroups), within the slab scratch's size
+    int kchunk = e->kchunk_r, nsplit = e->nsplit_r;
+    if (Cl < C) {
+      const long budget = (long)C * e->nsplit_r / Cl;                          // slabs per class that fit slabs_r
+      long want = gs_cdiv(512, (long)Cl * gs_cdiv(d, 128));
+      want = want > budget ? budget : want;
+      if (want > nsplit) {
+        long kc = gs_cdiv(K, want);
+        kc = ((kc + 15) / 16) * 16;
+        kchunk = (int)(kc < 64 ? 64 : kc);
+        nsplit = gs_cdiv(K, kchunk);
+        if ((long)nsplit > budget) { kchunk = e->kchunk_r; nsplit = e->nsplit_r; }
+      }
+    }
     gs_gemm_desc gwd = mk(e->io.X, 1, e->ldx, Bmat, h, 1, e->slabs_r, h, d, h, (int)K);
     gwd.gatherA_k = b.col0; gwd.sGb1 = K;
-    gwd.nb1 = Cl; gwd.nb2 = e->nsplit_r; gwd.kchunk = e->kchunk_r; gwd.Kb = kcount;
-    gwd.sBb1 = K * h; gwd.sCb1 = (long)e->nsplit_r * d * h; gwd.sCb2 = (long)d * h;
+    gwd.nb1 = Cl; gwd.nb2 = nsplit; gwd.kchunk = kchunk; gwd.Kb = kcount;
+    gwd.sBb1 = K * h; gwd.sCb1 = (long)nsplit * d * h; gwd.sCb2 = (long)d * h;
     if (fused) {   // B(k, :) = val0[k] * [H1full[col0[k]] > 0] * Y1[k / f2]
       gwd.B = Y1; gwd.sBb1 = (long)cap1 * h;
       gwd.bgen_mask = e->H1full; gwd.bgen_ldm = h; gwd.bgen_idx = b.col0; gwd.bgen_w = b.val0; gwd.bgen_div = f2;
@@ -809,9 +871,9 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     }
     GS_TRY(gs_gemm_f32(&gwd, stream));
     if (((long)d * h) % 4 == 0 && P % 4 == 0 && e->oW1 % 4 == 0)   // 16-byte form that skips the slabs beyond each class's edge count
-      GS_TRY(gs_reduce_slabs_active(gw + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, Cl, kcount, e->kchunk_r, stream));
+      GS_TRY(gs_reduce_slabs_active(gw + e->oW1, P, e->slabs_r, (long)d * h, nsplit, (long)d * h, Cl, kcount, kchunk, stream));
     else
-      GS_TRY(gs_reduce_slabs_batched_f32(gw + e->oW1, P, e->slabs_r, (long)d * h, e->nsplit_r, (long)d * h, Cl, 0.f, stream));
+      GS_TRY(gs_reduce_slabs_batched_f32(gw + e->oW1, P, e->slabs_r, (long)d * h, nsplit, (long)d * h, Cl, 0.f, stream));
     if (!fused) GS_TRY(colsum_batched(e, Bmat, K * h, (int)K, kcount, h, Cl, gw + e->ob1, P, stream, e->colpart_r));
   }
   return GS_OK;
@@ -895,7 +957,7 @@ static int pge_backward_chunked(gs_gcond* e, int need_param_grads, gs_stream_t s
     GS_TRY(gs_reduce_slabs_f32(g + e->pw2, e->chunk_bwd, Ph, nc, 5L * Ph, 0.f, stream));
     GS_TRY(gs_reduce_slabs_f32(g + e->pbe2, e->chunk_bwd + Ph, Ph, nc, 5L * Ph, 0.f, stream));
     GS_TRY(gs_reduce_slabs_f32(g + e->pg2, e->chunk_bwd + 2 * Ph, Ph, nc, 5L * Ph, 0.f, stream));
-    hipLaunchKernelGGL(gs_sum_kernel, dim3(1), dim3(1024), 0, s, e->de3, n2, g + e->pb2);
+    GS_TRY(sum_f32(e, e->de3, n2, g + e->pb2, s));
     const int nblk = gs_cdiv(n2, e->rows_per_block);
     const int nsplit = gs_cdiv(n2, e->kchunk_w);
     gs_gemm_desc w = mk(e->dE2, 1, Ph, e->A1, Ph, 1, e->slabs_w, Ph, Ph, Ph, (int)n2);
@@ -1307,11 +1369,22 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       gs_gemm_desc g = mk(e->Q, n, 1, Hin, F, 1, e->Ss, F, n, F, n);
       GS_TRY(gs_gemm_f32(&g, stream));
     }
-    gs_gemm_desc z = mk(e->Ss, F, 1, Wl, C, 1, e->Zs, C, n, C, F);
-    GS_TRY(gs_gemm_f32(&z, stream));
-    hipLaunchKernelGGL(gs_syn_softmax_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Zs, e->rsq, bl, e->io.labels_syn,
-                       e->io.syn_lo, e->io.syn_hi, n, C, e->Ps, e->Gs, 0);
-    GS_LAUNCH_CHECK();
+    int zrc = GS_ERR_UNSUPPORTED;
+    if (g_fused_chains) {      // logits, softmax and NLL gradient in one launch (gs_chain.hip): Z never reaches memory
+      gs_zg_args zg;
+      zg.A = e->Ss; zg.sAm = F; zg.sAk = 1; zg.B = Wl; zg.sBk = C; zg.sBn = 1; zg.n = n; zg.K = F; zg.C = C;
+      zg.rs = e->rsq; zg.bias = bl; zg.labels = e->io.labels_syn; zg.syn_lo = e->io.syn_lo; zg.syn_hi = e->io.syn_hi;
+      zg.divide_by_n = 0; zg.P = e->Ps; zg.G = e->Gs;
+      zrc = gs_chain_zg(&zg, s);
+      if (zrc != GS_OK && zrc != GS_ERR_UNSUPPORTED) return zrc;
+    }
+    if (zrc != GS_OK) {
+      gs_gemm_desc z = mk(e->Ss, F, 1, Wl, C, 1, e->Zs, C, n, C, F);
+      GS_TRY(gs_gemm_f32(&z, stream));
+      hipLaunchKernelGGL(gs_syn_softmax_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Zs, e->rsq, bl, e->io.labels_syn,
+                         e->io.syn_lo, e->io.syn_hi, n, C, e->Ps, e->Gs, 0);
+      GS_LAUNCH_CHECK();
+    }
   }
   if (part) {   // rows / classes of other ranks contribute zero from this rank
     GS_HIP(hipMemsetAsync(e->loss_c, 0, sizeof(float) * C, s));
@@ -1496,7 +1569,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
                        e->W1T);
     if (sharded_r(e)) GS_HIP(hipMemsetAsync(e->ar_marg, 0, sizeof(float) * 2 * (long)n * Ph, s));
     if (need_param_grads) {
-      hipLaunchKernelGGL(gs_sum_kernel, dim3(1), dim3(1024), 0, s, e->de3, n2, g + e->pb2);   // db2 = sum de3 (replicated)
+      GS_TRY(sum_f32(e, e->de3, n2, g + e->pb2, s));   // db2 = sum de3 (replicated)
       if (rows == 0) GS_HIP(hipMemsetAsync(g + e->pW1, 0, sizeof(float) * ((long)Ph * Ph + Ph), s));
     }
     GS_LAUNCH_CHECK();
@@ -1633,11 +1706,87 @@ extern "C" int gs_gcond_stage_update(gs_gcond* e, int epoch, gs_stream_t stream)
 // ================================================================================================
 // stage: inner_loop SGC steps on (X~, A^) after PGE.inference  (gcond.py:63-72).  Replicated on every rank.
 // ================================================================================================
+// measurement / test knob: 1 (default) = the fused launch chains of gs_chain.hip (inner SGC steps: logits + softmax + NLL gradient in
+// one launch, products re-associated through the C-wide operand, Adam in the gradient products' epilogue; synthetic match: logits +
+// softmax in one launch); 0 = one launch per product / element-wise pass (the first form)
+extern "C" int gs_gcond_set_fused_chains(int on) {
+  g_fused_chains = on != 0;
+  return GS_OK;
+}
+
+static gs_adam_ep model_adam(gs_gcond* e) {
+  const int step = ++e->step_model;
+  const double bc1 = 1.0 - pow(0.9, step), bc2 = 1.0 - pow(0.999, step);
+  gs_adam_ep ep;
+  ep.theta = e->io.model_params; ep.m = e->m_model; ep.v = e->v_model; ep.gbase = e->g_model;
+  ep.step_size = (float)((double)e->cfg.lr_model / bc1); ep.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  ep.b1 = 0.9f; ep.b2 = 0.999f; ep.eps = 1e-8f;
+  return ep;
+}
+
+// The inner SGC steps as fused launches (gs_chain.hip; algebra in its header).  SGC without BatchNorm / block structure, C <= 64.
+static int inner_steps_fused(gs_gcond* e, gs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int C = e->C, n = e->n, d = e->d, h = e->h, F = e->F;
+  const float* X = e->io.feat_syn;
+  const float* th = e->io.model_params;
+  const float* A = e->adj_norm_in;
+  float* g = e->g_model;
+  {
+    gs_gemm_desc q = mk(A, n, 1, A, n, 1, e->Qin, n, n, n, n);
+    GS_TRY(gs_gemm_f32(&q, stream));
+    hipLaunchKernelGGL(gs_rowsum_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Qin, n, n, e->rsq_in);
+    GS_LAUNCH_CHECK();
+    if (e->T == 1) {   // S = Q X does not depend on theta: once per outer iteration
+      gs_gemm_desc sg = mk(e->Qin, n, 1, X, d, 1, e->S_in, d, n, d, n);
+      GS_TRY(gs_gemm_f32(&sg, stream));
+    }
+  }
+  gs_zg_args zg;
+  zg.n = n; zg.C = C; zg.rs = e->rsq_in; zg.bias = th + e->obl; zg.labels = e->io.labels_syn; zg.syn_lo = e->io.syn_lo;
+  zg.syn_hi = e->io.syn_hi; zg.divide_by_n = 1; zg.P = nullptr; zg.G = e->Gs;
+  for (int it = 0; it < e->cfg.inner_loop; ++it) {
+    if (e->T == 1) {
+      zg.A = e->S_in; zg.sAm = d; zg.sAk = 1; zg.B = th + e->oWl; zg.sBk = C; zg.sBn = 1; zg.K = d;
+      GS_TRY(gs_chain_zg(&zg, s));                                                       // Z = S Wl + rs (x) bl ; G
+      gs_gemm_desc g2[2];
+      g2[0] = mk(e->S_in, 1, F, e->Gs, C, 1, g + e->oWl, C, F, C, n);                    // gWl = S^T G
+      g2[1] = mk(e->rsq_in, 0, 1, e->Gs, C, 1, g + e->obl, C, 1, C, n);                  // gbl = rs^T G
+      const gs_adam_ep ep = model_adam(e);
+      GS_TRY(gs_chain_group(g2, 2, &ep, s));                                             // (+ Adam on Wl, bl)
+      continue;
+    }
+    float* Tm = e->Zs;      // [n x C] T = H1 Wl
+    float* R = e->Ug;       // [n x C] R = Q^T G   (the matching stage's Ug: free here)
+    gs_gemm_desc a = mk(X, d, 1, th + e->oW1, h, 1, e->H1s, h, n, h, d);
+    a.bias = th + e->ob1; a.relu = 1;
+    GS_TRY(gs_gemm_f32(&a, stream));                                                     // H1 = relu(X W1 + b1)
+    gs_gemm_desc t = mk(e->H1s, h, 1, th + e->oWl, C, 1, Tm, C, n, C, h);
+    GS_TRY(gs_gemm_f32(&t, stream));                                                     // T = H1 Wl
+    zg.A = e->Qin; zg.sAm = n; zg.sAk = 1; zg.B = Tm; zg.sBk = C; zg.sBn = 1; zg.K = n;
+    GS_TRY(gs_chain_zg(&zg, s));                                                         // Z = Q T + rs (x) bl ; G
+    gs_gemm_desc r = mk(e->Qin, 1, n, e->Gs, C, 1, R, C, n, C, n);
+    GS_TRY(gs_gemm_f32(&r, stream));                                                     // R = Q^T G
+    gs_gemm_desc dh = mk(R, C, 1, th + e->oWl, 1, C, e->dH1m, h, n, h, C);
+    dh.mask = e->H1s; dh.ldmask = h;
+    GS_TRY(gs_gemm_f32(&dh, stream));                                                    // dH1 = (R Wl^T) * [H1 > 0]
+    gs_gemm_desc g4[4];
+    g4[0] = mk(X, 1, d, e->dH1m, h, 1, g + e->oW1, h, d, h, n);                          // gW1 = X^T dH1
+    g4[1] = mk(e->ones, 0, 1, e->dH1m, h, 1, g + e->ob1, h, 1, h, n);                    // gb1 = 1^T dH1
+    g4[2] = mk(e->H1s, 1, h, R, C, 1, g + e->oWl, C, h, C, n);                           // gWl = H1^T R
+    g4[3] = mk(e->rsq_in, 0, 1, e->Gs, C, 1, g + e->obl, C, 1, C, n);                    // gbl = rs^T G
+    const gs_adam_ep ep = model_adam(e);
+    GS_TRY(gs_chain_group(g4, 4, &ep, s));                                               // (+ Adam on theta)
+  }
+  return GS_OK;
+}
+
 extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   hipStream_t s = (hipStream_t)stream;
   const int C = e->C, n = e->n, d = e->d, h = e->h, F = e->F;
   if (e->cfg.inner_loop == 0) return GS_OK;
+  if (g_fused_chains && !e->gcn && !e->with_bn && !e->blk_pos && C <= 64) return inner_steps_fused(e, stream);
   const float* X = e->io.feat_syn;
   float* th_true = e->io.model_params;                 // Adam steps these ...
   const float* th = model_th(e);                       // ... the products read these (the BatchNorm-folded image under with_bn)

@@ -466,6 +466,12 @@ int gs_gcond_outer_step_sharded_ex(gs_gcond* e, int step_pge, int step_feat, int
  * sampled blocks of ITS classes gather (marked and compacted on the device); 0 = every rank computes all N rows.  Same values. */
 int gs_gcond_set_h1_rows(int on);
 
+/* Measurement / test knob: 1 (default) = the latency-bound chains run as fused launches (csrc/gs_chain.hip: the inner SGC steps of
+ * gcond.py:63-72 with logits + softmax + NLL gradient in one launch, the two n' x n' x h products re-associated into n' x n' x C
+ * ones, Adam in the epilogue of the gradient products; the synthetic match's logits + softmax in one launch); 0 = one launch per
+ * product (first form).  Same values up to fp32 re-association. */
+int gs_gcond_set_fused_chains(int on);
+
 /* Test hook of the sampler's seed selection (gs_sample_blocks): members of the crossing key bin that are ranked directly
  * (1 .. 2048, default 2048); a small value forces the second histogram level on ordinary pools.  Same seeds either way. */
 int gs_sample_set_cand_cap(int cap);

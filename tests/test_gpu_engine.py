@@ -430,6 +430,52 @@ def test_h1_rows_of_a_class_shard_are_the_full_product():
         eng.set_operand_mode("f32")
 
 
+@pytest.mark.parametrize("workload,scale", [("ogbn-arxiv", 0.25), ("cora", 1.0), ("reddit", 0.2)])
+def test_fused_chains_against_the_launch_per_product_form(workload, scale):
+    """csrc/gs_chain.hip against the first form (gs_gcond_set_fused_chains 0 / 1) from identical state: the synthetic match (logits +
+    softmax + NLL gradient in one launch: same K partition and summation order, so loss and gradients must be BITWISE equal) and
+    PGE.inference + the inner SGC steps (T = 2: products re-associated through the C-wide operand -> fp32 re-association level;
+    T = 1: same sums -> theta within one ulp-level step of Adam)."""
+    import bench
+    from graphslim_amd import _lib
+    from graphslim_amd.host import init_sgc_params
+    L = _lib.lib()
+    p = bench.build_problem(workload, seed=1, scale=scale)
+    d = p["data"].feat_full.shape[1]
+    torch.manual_seed(11)
+    theta = init_sgc_params(d, p["hidden"], p["data"].nclass, p["T"])
+
+    def run(fused):
+        _lib.check(L.gs_gcond_set_fused_chains(fused))
+        eng = bench.make_engine(p, DEV)
+        bench.init_state(p, eng)
+        eng.set_model(theta)
+        eng.stage_sample()
+        eng.stage_real_grads()
+        eng.stage_pge_forward(False)
+        eng.stage_syn_match()
+        eng.syn_finish()
+        out = {"loss": eng.buffer("loss").clone(), "d_feat": eng.buffer("d_feat").clone(), "d_adj": eng.buffer("d_adj").clone(),
+               "Ps": eng.buffer("Ps").clone()}
+        eng.stage_inner()
+        torch.cuda.synchronize()
+        out["theta"] = eng.model_params.cpu().clone()
+        out["g_model"] = eng.buffer("g_model").clone()
+        return out
+
+    try:
+        a, b = run(0), run(1)
+    finally:
+        _lib.check(L.gs_gcond_set_fused_chains(1))
+    for k in ("loss", "Ps", "d_feat", "d_adj"):
+        assert torch.equal(a[k], b[k]), k
+    gmax = float(a["g_model"].abs().max())
+    assert float((a["g_model"] - b["g_model"]).abs().max()) <= 2e-5 * gmax      # the LAST step's gradient (after inner_loop - 1 updates)
+    # Adam's first steps move every entry by ~lr: compare on that scale
+    assert float((a["theta"] - b["theta"]).abs().max()) <= 0.02 * 0.01 * p["inner"], float((a["theta"] - b["theta"]).abs().max())
+    assert float((a["theta"] - b["theta"]).abs().mean()) <= 1e-6
+
+
 def test_library_rccl_binding_world1():
     """gs_comm's RCCL transport (dlopen of librccl, ncclCommInitRank, ncclAllReduce on the engine's stream) with ONE rank — all a
     1-GPU box can run of it: a whole sharded outer iteration through gs_gcond_outer_step_sharded reproduces gs_gcond_outer_step

@@ -14,6 +14,10 @@ from graphslim_amd.parallel import Comm, ShardedGCond  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "ogbn-arxiv"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+worlds = [int(w) for w in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8]
+if os.environ.get("GS_H1_ROWS") is not None:      # A/B of the row-list H1 product of a class shard
+    from graphslim_amd import _lib
+    _lib.lib().gs_gcond_set_h1_rows(int(os.environ["GS_H1_ROWS"]))
 p = bench.build_problem(wl, seed=1)
 dev = "cuda:0"
 eng = bench.make_engine(p, dev)
@@ -34,7 +38,7 @@ def timed(e):
 
 base = timed(eng)
 print(f"fused single-GPU outer step: {base:.3f} ms (host issue {host_ms:.3f} ms)")
-for world in (1, 2, 4, 8):
+for world in worlds:
     ts, hs = [], []
     for r in range(world):
         sh = ShardedGCond(eng, r, world, pools, comm=Comm.null(r, world))      # the library's one-call sharded iteration, exchanges = no-ops
