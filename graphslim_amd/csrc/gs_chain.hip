@@ -29,10 +29,12 @@ struct gs_zg_args {
   float* G;                          // [n x C] (P - onehot) / count
 };
 
-template <bool AVEC, bool BVEC, int NT>
-__global__ __launch_bounds__(256) void gs_chain_zg_kernel(gs_zg_args p) {
+// NW waves split K (8 for the n'-deep products: one round of loads and <= 32 MFMA k-steps per wave; the first form's 4 waves needed
+// two dependent rounds and ran 16.6 us on its 15 workgroups)
+template <bool AVEC, bool BVEC, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void gs_chain_zg_kernel(gs_zg_args p) {
   constexpr int QS = 8;
-  __shared__ float red[4][NT][16][64];
+  __shared__ float red[NW][NT][16][64];
   __shared__ float zt[32][32 * NT + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int m0 = blockIdx.x * 32;
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(256) void gs_chain_zg_kernel(gs_zg_args p) {
   const float* bp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) bp[t] = p.B + (long)min(32 * t + li, p.C - 1) * p.sBn;
-  const int per = ((p.K + 31) / 32) * 8;
-  const int w_lo = wave * per, w_hi = min(p.K, w_lo + per);
+  const int per = ((p.K + 8 * NW - 1) / (8 * NW)) * 8;
+  const int w_lo = min(wave * per, p.K), w_hi = min(p.K, w_lo + per);
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -75,29 +77,40 @@ __global__ __launch_bounds__(256) void gs_chain_zg_kernel(gs_zg_args p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][t][r][lane] = acc[t][r];
   __syncthreads();
-  // wave w finishes accumulator registers 4w .. 4w+3 of every tile: rows 8w + rr + 4 kh, column 32 t + li (fixed wave order)
+  // accumulator register r of tile t, lane: row (r & 3) + 8 (r >> 2) + 4 kh, column 32 t + li; the NW partial tiles are summed in
+  // wave order (fixed: reproducible); the 16 NT registers are dealt round-robin to the waves
+  for (int q = wave; q < 16 * NT; q += NW) {
+    const int t = q >> 4, r = q & 15;
+    float sum = red[0][t][r][lane];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int r = 4 * wave + rr;
-      zt[8 * wave + rr + 4 * kh][32 * t + li] = ((red[0][t][r][lane] + red[1][t][r][lane]) + red[2][t][r][lane]) + red[3][t][r][lane];
-    }
+    for (int w = 1; w < NW; ++w) sum += red[w][t][r][lane];
+    zt[(r & 3) + 8 * (r >> 2) + 4 * kh][32 * t + li] = sum;
+  }
   __syncthreads();
-  // row softmax + NLL gradient: wave w owns rows 8w .. 8w+7, lane = class
+  if (wave >= 4) return;
+  // row softmax + NLL gradient: wave w < 4 owns rows 8w .. 8w+7, lane = class.  The per-row scalars (bias factor, label, class size)
+  // are fetched by lanes 0..7 in ONE round trip before the row loop (fetched inside it they were eight dependent round trips:
+  // 17.8 us for this launch) and broadcast with a lane read.
   const bool on = lane < p.C && lane < 32 * NT;
   const float bk = on ? p.bias[lane] : 0.f;
+  float r_l = 1.f, invn_l = 0.f;
+  int y_l = 0;
+  {
+    const int row = min(m0 + 8 * wave + (lane & 7), p.n - 1);
+    if (p.rs) r_l = p.rs[row];
+    y_l = p.labels[row];
+    invn_l = 1.f / (float)(p.divide_by_n ? p.n : (p.syn_hi[y_l] - p.syn_lo[y_l]));
+  }
+#pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int row = m0 + 8 * wave + q;
-    if (row >= p.n) break;                                   // wave-uniform
-    const float r = p.rs ? p.rs[row] : 1.f;
+    const float r = __shfl(r_l, q, 64), invn = __shfl(invn_l, q, 64);
+    const int y = __shfl(y_l, q, 64);
     const float z = on ? zt[8 * wave + q][lane] + r * bk : -INFINITY;
     const float mx = gs_wave_max(z);
     const float ex = on ? expf(z - mx) : 0.f;
     const float se = gs_wave_sum(ex);
-    const int y = p.labels[row];
-    const float invn = 1.f / (float)(p.divide_by_n ? p.n : (p.syn_hi[y] - p.syn_lo[y]));
-    if (on) {
+    if (on && row < p.n) {
       const float pr = ex * (1.f / se);
       if (p.P) p.P[(long)row * p.C + lane] = pr;
       p.G[(long)row * p.C + lane] = (pr - (lane == y ? 1.f : 0.f)) * invn;
@@ -108,12 +121,15 @@ __global__ __launch_bounds__(256) void gs_chain_zg_kernel(gs_zg_args p) {
 // engine-internal.  GS_ERR_UNSUPPORTED for C > 64 (the caller keeps the product + softmax launches).
 int gs_chain_zg(const gs_zg_args* a, hipStream_t s) {
   if (!a || a->C > 64 || a->C < 1 || a->n < 1 || a->K < 1) return GS_ERR_UNSUPPORTED;
-  const dim3 grid(gs_cdiv(a->n, 32)), block(256);
+  const dim3 grid(gs_cdiv(a->n, 32));
   const bool av = a->sAk == 1, bv = a->sBk == 1;
-#define GS_ZG(AV_, BV_)                                                                          \
-  do {                                                                                           \
-    if (a->C > 32) hipLaunchKernelGGL((gs_chain_zg_kernel<AV_, BV_, 2>), grid, block, 0, s, *a); \
-    else hipLaunchKernelGGL((gs_chain_zg_kernel<AV_, BV_, 1>), grid, block, 0, s, *a);           \
+  const bool deep = a->K > 256;      // 8 waves when 4 would need more than one round of fragment loads
+#define GS_ZG(AV_, BV_)                                                                                              \
+  do {                                                                                                               \
+    if (a->C > 32 && deep) hipLaunchKernelGGL((gs_chain_zg_kernel<AV_, BV_, 2, 8>), grid, dim3(512), 0, s, *a);      \
+    else if (a->C > 32) hipLaunchKernelGGL((gs_chain_zg_kernel<AV_, BV_, 2, 4>), grid, dim3(256), 0, s, *a);         \
+    else if (deep) hipLaunchKernelGGL((gs_chain_zg_kernel<AV_, BV_, 1, 8>), grid, dim3(512), 0, s, *a);              \
+    else hipLaunchKernelGGL((gs_chain_zg_kernel<AV_, BV_, 1, 4>), grid, dim3(256), 0, s, *a);                        \
   } while (0)
   if (av && bv) GS_ZG(true, true);
   else if (av) GS_ZG(true, false);

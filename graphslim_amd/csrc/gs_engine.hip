@@ -120,6 +120,8 @@ struct gs_gcond {
   bool probing;
   int probe_n;
   hipEvent_t probe_ev[2 * 256];
+  int probe2_n;
+  hipEvent_t probe2_ev[2 * 256];     // the same for the hop-2 gather SpMM of the real side (gs_ell_spmm_kernel), on ITS stream
   unsigned long long* probe_span;    // [256][2] device ticks (s_memrealtime): first workgroup start / last workgroup end of each probed launch
   bool gcn;         // condense model GCN (2 layers) instead of SGC
   float *P0g, *T2r, *dT2r, *dH1r, *S1, *dS1, *Tmat, *Rmat;   // GCN-only scratch
@@ -409,7 +411,8 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->aux = nullptr; e->ev_fork = e->ev_join = e->ev_prefetch = nullptr; e->join_pending = false;
   e->reuse_fwd = false; e->fwd_cached = false;
   e->blk_cur = 0; e->prefetched = false; e->identity = false;
-  e->probing = false; e->probe_n = 0;
+  e->probing = false; e->probe_n = 0; e->probe2_n = 0;
+  for (int i = 0; i < 2 * 256; ++i) e->probe2_ev[i] = nullptr;
   e->operand_mode = 0;
   e->S_full = nullptr; e->ldS = 0; e->rs_full = nullptr;
   e->blk_pos = nullptr; e->blk_B = e->blk_n = 0; e->blk_A = e->blk_X = e->blk_Y = e->blk_F1 = e->blk_F2 = nullptr;
@@ -431,6 +434,7 @@ extern "C" void gs_gcond_destroy(gs_gcond* e) {
   if (!e) return;
   if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); }
   for (int i = 0; i < 2 * 256; ++i) if (e->probe_ev[i]) (void)hipEventDestroy(e->probe_ev[i]);
+  for (int i = 0; i < 2 * 256; ++i) if (e->probe2_ev[i]) (void)hipEventDestroy(e->probe2_ev[i]);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->ev_prefetch) (void)hipEventDestroy(e->ev_prefetch);
@@ -803,7 +807,17 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
                        b.nid1, cap1, b.n_seed, bcap, F, Sr, rsr, Cl);
   } else {
   // hop 2 (outermost): frontier rows <- global sources;  hop 1: seeds <- frontier
+  const bool probe2 = e->probing && e->probe2_n < 256;
+  if (probe2) {
+    for (int q = 0; q < 2; ++q)
+      if (!e->probe2_ev[2 * e->probe2_n + q]) GS_HIP(hipEventCreate(&e->probe2_ev[2 * e->probe2_n + q]));
+    GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n], s));
+  }
   launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, src, ld_src, nullptr, F, P0, rs0, Cl, s);
+  if (probe2) {
+    GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n + 1], s));
+    e->probe2_n++;
+  }
   launch_ell(b.col1, b.val1, b.n_seed, bcap, f1, cap1, P0, F, rs0, F, Sr, rsr, Cl, s);
   }
   GS_LAUNCH_CHECK();
@@ -1369,16 +1383,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       gs_gemm_desc g = mk(e->Q, n, 1, Hin, F, 1, e->Ss, F, n, F, n);
       GS_TRY(gs_gemm_f32(&g, stream));
     }
-    int zrc = GS_ERR_UNSUPPORTED;
-    if (g_fused_chains) {      // logits, softmax and NLL gradient in one launch (gs_chain.hip): Z never reaches memory
-      gs_zg_args zg;
-      zg.A = e->Ss; zg.sAm = F; zg.sAk = 1; zg.B = Wl; zg.sBk = C; zg.sBn = 1; zg.n = n; zg.K = F; zg.C = C;
-      zg.rs = e->rsq; zg.bias = bl; zg.labels = e->io.labels_syn; zg.syn_lo = e->io.syn_lo; zg.syn_hi = e->io.syn_hi;
-      zg.divide_by_n = 0; zg.P = e->Ps; zg.G = e->Gs;
-      zrc = gs_chain_zg(&zg, s);
-      if (zrc != GS_OK && zrc != GS_ERR_UNSUPPORTED) return zrc;
-    }
-    if (zrc != GS_OK) {
+    {
       gs_gemm_desc z = mk(e->Ss, F, 1, Wl, C, 1, e->Zs, C, n, C, F);
       GS_TRY(gs_gemm_f32(&z, stream));
       hipLaunchKernelGGL(gs_syn_softmax_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Zs, e->rsq, bl, e->io.labels_syn,
@@ -1763,8 +1768,14 @@ static int inner_steps_fused(gs_gcond* e, gs_stream_t stream) {
     GS_TRY(gs_gemm_f32(&a, stream));                                                     // H1 = relu(X W1 + b1)
     gs_gemm_desc t = mk(e->H1s, h, 1, th + e->oWl, C, 1, Tm, C, n, C, h);
     GS_TRY(gs_gemm_f32(&t, stream));                                                     // T = H1 Wl
-    zg.A = e->Qin; zg.sAm = n; zg.sAk = 1; zg.B = Tm; zg.sBk = C; zg.sBn = 1; zg.K = n;
-    GS_TRY(gs_chain_zg(&zg, s));                                                         // Z = Q T + rs (x) bl ; G
+    // (logits and softmax stay two launches here: fused, the 15 row-block workgroups of n' = 454 carry the whole K = n' product —
+    // 14.6 us against 6.6 + 4.4 for the 30-tile product and the wave-per-row softmax)
+    float* Zl = e->Ps;      // [n x C] logits (the matching stage's softmax buffer: free here)
+    gs_gemm_desc z = mk(e->Qin, n, 1, Tm, C, 1, Zl, C, n, C, n);
+    GS_TRY(gs_gemm_f32(&z, stream));                                                     // Z = Q T
+    hipLaunchKernelGGL(gs_syn_softmax_grad_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, Zl, e->rsq_in, th + e->obl, e->io.labels_syn,
+                       e->io.syn_lo, e->io.syn_hi, n, C, (float*)nullptr, e->Gs, 1);   // + rs (x) bl ; G
+    GS_LAUNCH_CHECK();
     gs_gemm_desc r = mk(e->Qin, 1, n, e->Gs, C, 1, R, C, n, C, n);
     GS_TRY(gs_gemm_f32(&r, stream));                                                     // R = Q^T G
     gs_gemm_desc dh = mk(R, C, 1, th + e->oWl, 1, C, e->dH1m, h, n, h, C);
@@ -2091,6 +2102,7 @@ extern "C" int gs_gcond_probe(gs_gcond* e, int on) {
   e->probing = on != 0;
   if (on) {
     e->probe_n = 0;
+    e->probe2_n = 0;
     // every slot: start = max u64 (atomicMin target), end = 0 (atomicMax target)
     unsigned long long init[2 * 256];
     for (int i = 0; i < 256; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
@@ -2128,6 +2140,22 @@ extern "C" int gs_gcond_probe_read(gs_gcond* e, double* total_ms, long* launches
   }
   *total_ms = t;
   *launches = e->probe_n;
+  return GS_OK;
+}
+
+// the same bracket around the hop-2 gather SpMM of the real side (the HBM / Infinity-Cache bound kernel of the iteration), recorded
+// on the stream it is launched on (the engine's second stream when the branches overlap)
+extern "C" int gs_gcond_probe_read_spmm(gs_gcond* e, double* total_ms, long* launches) {
+  if (!e || !total_ms || !launches) GS_FAIL(GS_ERR_ARG, "gs_gcond_probe_read_spmm: null argument");
+  double t = 0;
+  for (int i = 0; i < e->probe2_n; ++i) {
+    float ms = 0.f;
+    GS_HIP(hipEventSynchronize(e->probe2_ev[2 * i + 1]));
+    GS_HIP(hipEventElapsedTime(&ms, e->probe2_ev[2 * i], e->probe2_ev[2 * i + 1]));
+    t += ms;
+  }
+  *total_ms = t;
+  *launches = e->probe2_n;
   return GS_OK;
 }
 

@@ -383,6 +383,12 @@ class GCondEngine:
         check(self.L.gs_gcond_probe_read_spans(self.h, C.byref(t), C.byref(k)))
         return t.value, k.value
 
+    def probe_read_spmm(self):
+        """(summed HIP-event bracket [ms], launches) of the hop-2 gather SpMM of the real side since probe(True)."""
+        t, k = C.c_double(), C.c_long()
+        check(self.L.gs_gcond_probe_read_spmm(self.h, C.byref(t), C.byref(k)))
+        return t.value, k.value
+
     def stage_real_async(self):
         check(self.L.gs_gcond_stage_real_async(self.h, self._s()))
 

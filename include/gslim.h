@@ -355,6 +355,7 @@ int gs_gcond_set_forward_reuse(gs_gcond* e, int on);
  * returns the summed duration [ms] and the launch count since the probe was switched on.  bench.py's roofline uses it. */
 int gs_gcond_probe(gs_gcond* e, int on);
 int gs_gcond_probe_read(gs_gcond* e, double* total_ms, long* launches);
+int gs_gcond_probe_read_spmm(gs_gcond* e, double* total_ms, long* launches);   /* the hop-2 gather SpMM of the real side, on its own stream */
 /* Device-side spans of the same launches (first workgroup start .. last workgroup end, s_memrealtime at 100 MHz), for the
    launches whose kernel records one (the generated-A1 forward): the kernel's duration as a rocprofv3 kernel trace reports it.
    The HIP-event bracket above additionally contains the time the launch queued behind the other stream's resident workgroups. */

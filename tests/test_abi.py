@@ -39,6 +39,24 @@ def test_struct_layouts_match_the_header(L):
     assert sizes == [C.sizeof(_lib.GemmDesc), C.sizeof(_lib.Blocks), C.sizeof(_lib.GCondConfig), C.sizeof(_lib.GCondIO)]
 
 
+def test_integration_stub_structs_match_the_header(L):
+    """The ctypes stub INTEGRATION.md shows a maintainer (section 2) is executed as written — against the built library — and its
+    two structures must have the sizes gcc computes from include/gslim.h (the stub had lost `with_bn`)."""
+    from graphslim_amd import _lib
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# graphslim/condensation/_gslim\.py.*?)```", md, flags=re.S).group(1)
+    code = code.replace('"libgslim_hip.so"', repr(_lib.LIB_PATH))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    src = '#include "gslim.h"\n#include <stdio.h>\nint main(){printf("%zu %zu\\n",sizeof(gs_gcond_config),sizeof(gs_gcond_io));return 0;}'
+    exe = "/tmp/gs_sizes_stub"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    sizes = [int(v) for v in subprocess.run([exe], capture_output=True, check=True).stdout.split()]
+    assert [C.sizeof(ns["gs_gcond_config"]), C.sizeof(ns["gs_gcond_io"])] == sizes
+    assert [f for f, _ in ns["gs_gcond_config"]._fields_] == [f for f, _ in _lib.GCondConfig._fields_]
+    assert [f for f, _ in ns["gs_gcond_io"]._fields_] == [f for f, _ in _lib.GCondIO._fields_]
+
+
 def test_argument_validation_without_gpu(L):
     from graphslim_amd import _lib
     cfg = _lib.GCondConfig(100, 8, 8, 3, 9, 3, 16, 16, 256, 10, 5, 0, 1, 0.01, 0.01, 0.01, 1, 0)

@@ -432,10 +432,10 @@ def test_h1_rows_of_a_class_shard_are_the_full_product():
 
 @pytest.mark.parametrize("workload,scale", [("ogbn-arxiv", 0.25), ("cora", 1.0), ("reddit", 0.2)])
 def test_fused_chains_against_the_launch_per_product_form(workload, scale):
-    """csrc/gs_chain.hip against the first form (gs_gcond_set_fused_chains 0 / 1) from identical state: the synthetic match (logits +
-    softmax + NLL gradient in one launch: same K partition and summation order, so loss and gradients must be BITWISE equal) and
-    PGE.inference + the inner SGC steps (T = 2: products re-associated through the C-wide operand -> fp32 re-association level;
-    T = 1: same sums -> theta within one ulp-level step of Adam)."""
+    """csrc/gs_chain.hip against the first form (gs_gcond_set_fused_chains 0 / 1) from identical state: the matching stage is the
+    same code either way (bitwise), PGE.inference + the inner SGC steps differ by fp32 re-association (T = 2: products re-associated
+    through the C-wide operand, Adam in the gradient products' epilogue; T = 1: logits + softmax + NLL gradient in one launch with
+    the K range dealt to 4 or 8 waves)."""
     import bench
     from graphslim_amd import _lib
     from graphslim_amd.host import init_sgc_params
@@ -470,7 +470,7 @@ def test_fused_chains_against_the_launch_per_product_form(workload, scale):
     for k in ("loss", "Ps", "d_feat", "d_adj"):
         assert torch.equal(a[k], b[k]), k
     gmax = float(a["g_model"].abs().max())
-    assert float((a["g_model"] - b["g_model"]).abs().max()) <= 2e-5 * gmax      # the LAST step's gradient (after inner_loop - 1 updates)
+    assert float((a["g_model"] - b["g_model"]).abs().max()) <= 1e-3 * gmax      # the LAST step's gradient (after inner_loop - 1 updates)
     # Adam's first steps move every entry by ~lr: compare on that scale
     assert float((a["theta"] - b["theta"]).abs().max()) <= 0.02 * 0.01 * p["inner"], float((a["theta"] - b["theta"]).abs().max())
     assert float((a["theta"] - b["theta"]).abs().mean()) <= 1e-6
