@@ -120,7 +120,19 @@ def roofline_hbm(eng, spmm_ms, spmm_launches):
         if rec:
             traffic, src = int(rec["hbm_bytes_per_launch"]), "profiles/r03/pmc_bench_hbm_per_kernel.json (average over the hop-2 and hop-1 launches)"
     ach = alg / sec / 1e9
+    # the same launch with nothing else on the chip (the real-side stage run back to back on one stream: its kernels are in order)
+    base.set_overlap(0)
+    base.probe(True)
+    for _ in range(10):
+        base.stage_real_grads()
+    torch.cuda.synchronize()
+    iso_ms, iso_k = base.probe_read_spmm()
+    base.probe(False)
+    base.set_overlap(1)
+    iso = iso_ms / 1e3 / max(iso_k, 1)
     return {"bound": "hbm", "kernel": "gs_ell_spmm_kernel<4> (hop-2 gather SpMM of the real side, width %d)" % F,
+            "isolated_launch_us": round(iso * 1e6, 2), "isolated_achieved": round(alg / iso / 1e9, 1),
+            "isolated_gather_rate_GBps": round((4.0 * F * nnz + 4.0 * F * rows + 8.0 * nnz) / iso / 1e9, 1),
             "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
             "traffic_source": src, "avg_launch_us": round(sec * 1e6, 2), "launches_timed": int(spmm_launches),
             "algorithmic_bytes_per_launch": alg, "rows": rows, "nnz": nnz, "distinct_source_rows": distinct,
@@ -150,9 +162,11 @@ def eval_accuracy(p, eng, epochs, runs=3, eval_epochs=300):
     torch.cuda.synchronize()
     t_reduce = time.perf_counter() - t0
     base.set_forward_reuse(False)
-    args = cli(["-D", "ogbn-arxiv" if p["name"] == "ogbn-arxiv" else p["name"].split("-")[0], "-M", "gcond", "-R", str(p["rate"]), "-G", "0",
-                "--eval_epochs", str(eval_epochs), "--run_eval", str(runs), "--save_path", tempfile.mkdtemp(prefix="gs_bench_")],
-               standalone_mode=False)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # (cli prints its argument table: stdout carries the ONE JSON line only)
+        args = cli(["-D", "ogbn-arxiv" if p["name"] == "ogbn-arxiv" else p["name"].split("-")[0], "-M", "gcond", "-R", str(p["rate"]),
+                    "-G", "0", "--eval_epochs", str(eval_epochs), "--run_eval", str(runs), "--save_path",
+                    tempfile.mkdtemp(prefix="gs_bench_")], standalone_mode=False)
     data = p["data"]
     dev = base.dev
     data.feat_syn = base.feat_syn.clone()
@@ -161,11 +175,12 @@ def eval_accuracy(p, eng, epochs, runs=3, eval_epochs=300):
     setting = "ind" if p["name"].startswith(("reddit", "flickr")) else "trans"
     accs = []
     t1 = time.perf_counter()
-    for i in range(runs):
-        seed_everything(args.seed + i)
-        m = GCN(data.feat_full.shape[1], args.hidden, data.nclass, evaluation_args(args), mode="eval")
-        m.fit_with_val(data, train_iters=eval_epochs, normadj=True, setting=setting, reduced=True)
-        accs.append(float(m.test(data, setting=setting)))
+    with contextlib.redirect_stdout(sys.stderr):
+        for i in range(runs):
+            seed_everything(args.seed + i)
+            m = GCN(data.feat_full.shape[1], args.hidden, data.nclass, evaluation_args(args), mode="eval")
+            m.fit_with_val(data, train_iters=eval_epochs, normadj=True, setting=setting, reduced=True)
+            accs.append(float(m.test(data, setting=setting)))
     return {"eval_acc_mean": round(float(np.mean(accs)), 5), "eval_acc_std": round(float(np.std(accs)), 5), "runs": runs,
             "eval_epochs": eval_epochs, "condensation_epochs": epochs, "outer_iterations": epochs * p["outer"],
             "condensation_s": round(t_reduce, 2), "evaluation_s": round(time.perf_counter() - t1, 2),

@@ -57,6 +57,15 @@ class SGDDLoop:
             return 0.0
         v = float(self.reg.acc)
         self.reg.acc.zero_()
+        bad_eig, clamped = self.reg.read_health()
+        if (bad_eig or clamped) and not getattr(self, "_warned", False):
+            self._warned = True
+            import warnings
+            warnings.warn(f"graphslim_amd SGDD: the optimal-transport regulariser left the fp32 range of upstream's formula "
+                          f"({bad_eig} eigen-decomposition(s) not converged, {clamped} entries replaced by the range guard since the last "
+                          f"epoch): with a rank-deficient adjacency corner the pseudo-inverse holds rounding-level reciprocals "
+                          f"(ignr.py:13-27) — upstream's own run turns NaN here; consider opt_scale = 0 or a smaller mx_size")
+        self.health = (bad_eig, clamped)
         return v
 
 
@@ -85,8 +94,8 @@ class SGDD(GCondBase):
         self.adj_syn = None
         print("adj_syn:", (n, n), "feat_syn:", self.feat_syn.shape)
 
-    @verbose_time_memory
-    def reduce(self, data, verbose=True):
+    def prepare(self, data):
+        """Everything of reduce() in front of its loop (sgdd.py:30-54): engine, IGNR, regulariser.  Returns (engine, loop)."""
         args = self.args
         if args.condense_model != "SGC":
             raise NotImplementedError("graphslim_amd: SGDD is built for condense_model SGC (every configs/sgdd/*.json)")
@@ -116,9 +125,16 @@ class SGDD(GCondBase):
         loop = self.loop = SGDDLoop(eng, self.ignr_init, pinv_corner(data.adj_mx), args.ep_ratio, args.opt_scale, args.lr_feat,
                                     args.lr_adj)
         self.feat_syn = eng.feat_syn
+        init_sgc_params(d, args.hidden, nclass, args.ntrans)                              # model constructor draw (:54)
+        return eng, loop
+
+    @verbose_time_memory
+    def reduce(self, data, verbose=True):
+        args = self.args
+        eng, loop = self.prepare(data)
+        nclass, d = data.nclass, self.d
         outer_loop, inner_loop = self.get_loops(args)
         loss_avg, best_val = 0, 0
-        init_sgc_params(d, args.hidden, nclass, args.ntrans)                              # model constructor draw (:54)
         labels_t = torch.from_numpy(np.asarray(data.labels_syn)).to(self.device)
         for it in trange(args.epochs):
             eng.set_model(init_sgc_params(d, args.hidden, nclass, args.ntrans))           # :58-60 initialize() + a fresh Adam

@@ -410,6 +410,7 @@ class TransportRegulariser:
         self.dmu = f(n + 1)
         self.value = f(1)
         self.acc = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.bad = torch.zeros(2, dtype=torch.int64, device=self.dev)      # [non-converged decompositions, entries the range guard touched]
         self.eig = _SymEig.get()
 
     def forward_backward(self, adj, P, scale, d_adj, dP):
@@ -421,6 +422,7 @@ class TransportRegulariser:
         # adj = Q diag(lam) Q^T
         self.Qr.copy_(adj)
         self.eig.eigh(self.Qr, self.lam, self.work, self.info)
+        self.bad[0] += (self.info[0] != 0)           # rocSOLVER's `info`: off-diagonals that did not converge (device-side, no sync)
         check(L.gs_ot_spectrum_f32(ptr(self.lam), n, self.SV_EPS, ptr(self.spec), s))
         g, gp, hp, tr = self.spec[:n], self.spec[n:2 * n], self.spec[2 * n:3 * n], self.spec[3 * n:]
         # R = Ly_inv_rt = Q diag(g) Q^T = Qr^T diag(g) Qr:  T = diag(g) Qr (rows scaled) -> via columns of Qr^T ... rows: scale_cols on Qr^T
@@ -431,9 +433,12 @@ class TransportRegulariser:
         gemm(self.T1, self.T2, self.M, n, n, mx, (1, n), (n, 1), n)                                      # M = T1^T T2
         self.Wr.copy_(self.M)
         # fp32 overflow guard: with a rank-deficient corner (Lx_inv entries up to 1e14 measured) and a near-singular structure the
-        # product can exceed the fp32 range; upstream's eigh would then see inf / NaN and the whole job turns NaN
+        # product can exceed the fp32 range; upstream's eigh would then see inf / NaN and the whole job turns NaN.  The guard is
+        # counted (self.bad[1]) and reported by the host loop: a run it touched has left the range where upstream's formula is defined.
+        self.bad[1] += ((~torch.isfinite(self.Wr)) | (self.Wr.abs() > 1e15)).sum()
         check(L.gs_clamp_finite_f32(ptr(self.Wr), n * n, 1e15, s))       # (the decomposition squares and sums the entries)
         self.eig.eigh(self.Wr, self.mu, self.work, self.info)
+        self.bad[0] += (self.info[0] != 0)
         check(L.gs_ot_value_f32(ptr(self.mu), ptr(tr), n, float(scale), ptr(self.dmu), ptr(self.value), ptr(self.acc), s))
         if scale <= 0:
             return self.value
@@ -451,11 +456,19 @@ class TransportRegulariser:
         # d adj += Q K' Q^T = Qr^T K' Qr
         gemm(self.Qr, self.M, self.T, n, n, n, (1, n), (n, 1), n)                                        # T = Qr^T K'
         gemm(self.T, self.Qr, self.M, n, n, n, (n, 1), (n, 1), n)                                        # M = T Qr = the term's d / d adj
+        self.bad[1] += ((~torch.isfinite(self.M)) | (self.M.abs() > 1e30)).sum() + ((~torch.isfinite(dP)) | (dP.abs() > 1e30)).sum()
         check(L.gs_clamp_finite_f32(ptr(self.M), n * n, 1e30, s))
         check(L.gs_clamp_finite_f32(ptr(dP), dP.numel(), 1e30, s))
         if d_adj is not None:
             self.add_to(d_adj)
         return self.value
+
+    def read_health(self):
+        """(eigen-decompositions rocSOLVER reported as not converged, entries the fp32 range guard replaced) since the last call —
+        one host sync; the host loop reads it once per epoch and warns."""
+        v = [int(x) for x in self.bad.tolist()]
+        self.bad.zero_()
+        return v[0], v[1]
 
     def add_to(self, d_adj):
         """d_adj += the term's gradient wrt the structure (left in self.M by forward_backward): one slab, beta = 1."""

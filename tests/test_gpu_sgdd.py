@@ -202,6 +202,84 @@ def test_replay_of_the_reference_sgdd_run(golden_dir, tag):
         assert (drv > 3e-2).mean() <= 0.03 and drv.max() <= 0.2, (key, (drv > 3e-2).mean(), drv.max())
 
 
+def _full_size_sgdd(dataset, rate, tmp_path):
+    """SGDD at a product configuration (configs/sgdd/<dataset>.json) on the dataset-shaped synthetic graph: the product's own setup
+    (SGDD.prepare: engine with the HIP sampler, IGNR, regulariser with the pseudo-inverse of the real corner) and the oracle's state
+    from the same initial values."""
+    import graphslim  # noqa: F401
+    from graphslim.config import cli
+    from graphslim.condensation import SGDD
+    from graphslim.dataset import get_dataset
+    from graphslim_amd import host as H
+    args = cli(["-D", dataset, "-M", "sgdd", "-R", str(rate), "-G", "0", "--save_path", str(tmp_path)], standalone_mode=False)
+    graph = get_dataset(args.dataset, args)
+    H.seed_everything(args.seed)
+    agent = SGDD(setting=args.setting, data=graph, args=args)
+    eng, loop = agent.prepare(graph)
+    Lx = loop.reg.Lx_inv.cpu()
+    st = S.SGDDState(eng.feat_syn.cpu().clone(), {k: v.cpu().clone() for k, v in agent.ignr_init.items()},
+                     torch.from_numpy(np.asarray(graph.labels_syn)).long(), agent.num_class_dict if hasattr(agent, "num_class_dict") else graph.num_class_dict,
+                     graph.nclass, Lx, args.lr_feat, args.lr_adj, args.lr, args.ep_ratio, args.opt_scale)
+    return args, graph, agent, eng, loop, st
+
+
+@pytest.mark.parametrize("dataset,rate", [("cora", 0.5), ("ogbn-arxiv", 0.005)])
+def test_full_size_iterations_against_the_oracle(tmp_path, dataset, rate):
+    """VERDICT r02 "next" 3: SGDD at the sizes that matter (cora r = 0.5: n' = 70, corner 200; ogbn-arxiv r = 0.5 %: n' = 454, 206 k
+    pairs, corner 1 000) against oracle/sgdd_oracle.py — the literal restatement of sgdd.py:64-95 / ignr.py:184-209 with torch.svd and
+    torch.linalg.eigh in fp32 — on the blocks the HIP sampler drew.  First iteration (identical state): matching loss 1e-4, regulariser
+    value 1e-3, the regulariser's own structure gradient against fp64 autograd of upstream's formula.  Then both sides run the same
+    structure-epoch schedule and the test answers the question the r02 whole job left open (40 % accuracy with the shipped
+    opt_scale): does upstream's formula, evaluated by the oracle from the same state on the same blocks, saturate the structure the
+    same way?  It must: mean and extremes of the learned structure stay together, and the regulariser values stay within 2 %."""
+    import bench
+    from graphslim_amd import host as H
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    args, graph, agent, eng, loop, st = _full_size_sgdd(dataset, rate, tmp_path)
+    d, nclass = graph.feat_full.shape[1], graph.nclass
+    X, Y = graph.feat_full, graph.labels_full
+    iters = 6
+    theta = H.init_sgc_params(d, args.hidden, nclass, args.ntrans)
+    eng.set_model(theta)
+    st.new_epoch([t.clone() for t in theta])
+    rows = []
+    for k in range(iters):
+        adj0 = loop.gen.forward(eng.feat_syn, train=False).clone() if k == 0 else None      # (eval-mode pass: no running-statistics update)
+        loop.step(0)                                                                        # a structure epoch (it % 50 < 10)
+        batches = bench.blocks_to_batches(eng.get_blocks())
+        ml, reg, _, g_p, adj_in = st.outer_iteration(0, batches, X, Y, args.inner_loop)
+        torch.cuda.synchronize()
+        a_e, a_o = loop.adj_inner.cpu(), adj_in
+        rows.append(dict(ml_e=float(eng.buffer("loss")[0]), ml_o=float(ml), reg_e=float(loop.reg.value), reg_o=float(reg),
+                         mean_e=float(a_e.mean()), mean_o=float(a_o.mean()), max_e=float(a_e.max()), max_o=float(a_o.max()),
+                         dadj=float((a_e - a_o).abs().max())))
+        if k == 0:
+            # the regulariser's structure gradient (left in reg.M) against fp64 autograd of upstream's formula at the same structure
+            adj64 = S.ignr_structure(eng.feat_syn.cpu().double(), {q: v.double() for q, v in agent.ignr_init.items()},
+                                     {q: [v[0].double(), v[1].double()] for q, v in S.new_running().items()}, args.ep_ratio, True)
+            a64 = adj64.detach().clone().requires_grad_(True)
+            val64 = S.opt_loss(a64, agent.ignr_init["P"].double(), loop.reg.Lx_inv.cpu().double())
+            g64 = torch.autograd.grad(args.opt_scale * val64, a64)[0]
+            g64 = 0.5 * (g64 + g64.t())                                   # (the structure is symmetric: both triangles carry the gradient)
+            rows[0]["val64"] = float(val64)
+            rows[0]["gadj_rel"] = float((loop.reg.M.cpu().double() - g64).abs().max() / (g64.abs().max() + 1e-300))
+    for r in rows:
+        print({k: (f"{v:.6g}" if isinstance(v, float) else v) for k, v in r.items()})
+    bad_eig, clamped = loop.reg.read_health()
+    print(f"sgdd full size [{dataset}]: n' = {eng.shapes.n_syn}, corner {agent.mx}, rocSOLVER non-converged {bad_eig}, range-guard entries {clamped}")
+    r0 = rows[0]
+    assert abs(r0["ml_e"] - r0["ml_o"]) <= 1e-4 * abs(r0["ml_o"]), r0
+    assert abs(r0["reg_e"] - r0["reg_o"]) <= 1e-3 * abs(r0["reg_o"]), r0
+    assert abs(r0["reg_e"] - r0["val64"]) <= 1e-3 * abs(r0["val64"]), r0
+    assert bad_eig == 0
+    if dataset == "cora":      # (at the arxiv corner the fp64 gradient itself is dominated by rounding-level reciprocals: reported only)
+        assert r0["gadj_rel"] <= 5e-2, r0
+    for r in rows:
+        assert abs(r["ml_e"] - r["ml_o"]) <= 5e-3 * abs(r["ml_o"]), r
+        assert abs(r["reg_e"] - r["reg_o"]) <= 2e-2 * abs(r["reg_o"]), r
+        assert abs(r["mean_e"] - r["mean_o"]) <= 2e-2 and abs(r["max_e"] - r["max_o"]) <= 5e-2, r
+
+
 def test_sgdd_reduce_api(tmp_path):
     """`-M sgdd` end to end through the reference's entry points with the shipped configs/sgdd/cora.json (opt_scale 1e-11, ep_ratio
     0.5, mx_size 200): cli -> get_dataset -> SGDD(...).reduce (checkpoints incl. intermediate evaluation) -> Evaluator.evaluate."""
