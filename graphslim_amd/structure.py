@@ -432,12 +432,17 @@ class TransportRegulariser:
         gemm(self.Lx_inv, self.T1, self.T2, mx, n, mx, (mx, 1), (n, 1), n)                               # T2 = Lx_inv T1
         gemm(self.T1, self.T2, self.M, n, n, mx, (1, n), (n, 1), n)                                      # M = T1^T T2
         self.Wr.copy_(self.M)
-        # fp32 overflow guard: with a rank-deficient corner (Lx_inv entries up to 1e14 measured) and a near-singular structure the
-        # product can exceed the fp32 range; upstream's eigh would then see inf / NaN and the whole job turns NaN.  The guard is
-        # counted (self.bad[1]) and reported by the host loop: a run it touched has left the range where upstream's formula is defined.
-        self.bad[1] += ((~torch.isfinite(self.Wr)) | (self.Wr.abs() > 1e15)).sum()
-        check(L.gs_clamp_finite_f32(ptr(self.Wr), n * n, 1e15, s))       # (the decomposition squares and sums the entries)
+        # With a rank-deficient corner (Lx_inv entries up to 1e14 measured) M's entries reach 1e15 .. 1e20: inside the fp32 range, but
+        # rocSOLVER's tridiagonalisation squares and sums them.  LAPACK's ssyev (behind upstream's CPU eigh) rescales such a matrix
+        # before reducing it; the same here, exactly: M / s with s the power of two below max |M|, mu = s mu'.  (Round 2 clamped the
+        # entries at 1e15 instead, which changed the value where upstream's is still finite.)  Only NON-FINITE entries — a product
+        # that really left the range, where upstream's run turns NaN — are replaced, and counted (self.bad[1]).
+        self.bad[1] += (~torch.isfinite(self.Wr)).sum()
+        check(L.gs_clamp_finite_f32(ptr(self.Wr), n * n, 3.0e38, s))
+        sc = torch.exp2(torch.floor(torch.log2(self.Wr.abs().max().clamp_min(1e-30))))
+        self.Wr.div_(sc)
         self.eig.eigh(self.Wr, self.mu, self.work, self.info)
+        self.mu.mul_(sc)
         self.bad[0] += (self.info[0] != 0)
         check(L.gs_ot_value_f32(ptr(self.mu), ptr(tr), n, float(scale), ptr(self.dmu), ptr(self.value), ptr(self.acc), s))
         if scale <= 0:
