@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 from graphslim_amd.workloads import (WORKLOADS, blocks_to_batches, build_problem, init_state, make_engine, new_model,  # noqa: E402,F401
                                       run_steps)
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "pmc_panel_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "pmc_panel_summary.json")
 
 
 def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20, span=None):
@@ -70,12 +70,21 @@ def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20, span=None):
     if (n, ph) == (454, 256) and os.path.exists(PMC_SUMMARY):
         rec = json.load(open(PMC_SUMMARY)).get(kname)
         if rec:
-            traffic, src = int(rec["hbm_bytes_per_launch"]), "profiles/r02/pmc_panel_summary.json"
+            traffic, src = int(rec["hbm_bytes_per_launch"]), "profiles/r03/pmc_panel_summary.json"
     # algorithmic bytes: E2 written once; U, V (n' x Ph each) and the weight block read once — A1 is formed in registers
     alg_bytes = rows * ph * 4.0 + (2 * n * ph + ph * ph + ph) * 4.0
+    extra = {}
     if mode == "f32":
         peak, bound, unit = 157.3, "mfma", "TFLOP/s"     # fp32 matrix peak (MI355X_MICROARCH.md chip table)
         ach = flops / sec / 1e12
+    elif mode == "bf16x6":
+        # the exact split executes SIX bf16 products per fp32 product: that is the algorithm's work on the bf16 pipe (dense peak
+        # 2 500 TFLOP/s, MI355X_MICROARCH.md); the fp32-equivalent rate is reported beside it
+        peak, bound, unit = 2500.0, "mfma", "TFLOP/s"
+        ach = 6.0 * flops / sec / 1e12
+        extra = {"executed_flops_per_launch": 6.0 * flops, "fp32_equivalent_tflops": round(flops / sec / 1e12, 2),
+                 "fp32_equivalent_over_fp32_matrix_peak": round(flops / sec / 1e12 / 157.3, 4),
+                 "hbm_GBps_of_algorithmic_bytes": round(alg_bytes / sec / 1e9, 1)}
     else:
         # the split / bf16 modes need 3/16 or 1/16 of the fp32 pipe time: the launch is bounded by its E2 write stream
         peak, bound, unit = 8000.0, "hbm", "GB/s"
@@ -88,7 +97,7 @@ def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20, span=None):
             "event_bracket_us": round(bracket * 1e6, 2), "launches_timed": int(insitu_launches),
             "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
             "isolated_launch_us": round(iso * 1e6, 2),
-            "isolated_span_us": round(iso_span_ms / max(iso_span_k, 1) * 1e3, 2) if iso_span_k else None}
+            "isolated_span_us": round(iso_span_ms / max(iso_span_k, 1) * 1e3, 2) if iso_span_k else None, **extra}
 
 
 PMC_HBM = os.path.join(ROOT, "profiles", "r03", "pmc_bench_hbm_per_kernel.json")
@@ -268,8 +277,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink N for smoke runs (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of extra back-to-back iterations for the `sustained` field (0 = off)")
-    ap.add_argument("--operand-mode", default="f32", choices=["f32", "bf16x6", "bf16x3", "bf16"],
-                    help="operand precision of the row-panel products for the HEADLINE run (default: exact fp32)")
+    ap.add_argument("--operand-mode", default=None, choices=["f32", "bf16x6", "bf16x3", "bf16"],
+                    help="operand form of the five large contractions for the HEADLINE run (default: the engine's default, the exact "
+                         "three-way bf16 split bf16x6 — fp32-level error; f32 = the fp32 matrix pipe)")
     ap.add_argument("--full-neighbour", action="store_true",
                     help="SGC ntrans = 1 workloads (cora, reddit): exact 2-hop full neighbourhoods (SURVEY 8e mode F) — S_full = A^ A^ X "
                          "by row-sharded SpMM once before the timed region, seed-row gathers per iteration; not the headline")
@@ -279,6 +289,9 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_child:
         return cpu_baseline_child(args.cpu_baseline_child)
+    from graphslim_amd.engine import DEFAULT_OPERAND_MODE
+    if args.operand_mode is None:
+        args.operand_mode = DEFAULT_OPERAND_MODE
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -383,7 +396,7 @@ def main():
     # opt-in operand precisions of the row-panel / edge products (VERDICT r01 row *J): same steps, same cadence, tagged dtype.
     # NOT the headline: `value` is measured in args.operand_mode (default exact fp32 = the reference's precision).
     modes = {}
-    for m in ("bf16x6", "bf16x3", "bf16"):
+    for m in ("f32", "bf16x6", "bf16x3", "bf16"):
         if m == args.operand_mode or world > 1:
             continue
         base.set_operand_mode(m)
@@ -395,7 +408,8 @@ def main():
         dm = time.perf_counter() - tm
         ls, kk = eng.read_loss()
         modes[m] = {"value": round(args.steps / dm, 3), "unit": "outer-iters/s", "ms_per_step": round(1e3 * dm / args.steps, 3),
-                    "dtype": {"bf16x6": "f32 operands split EXACTLY into three bf16 parts (8 + 8 + 8 bits), 6 bf16 MFMA products "
+                    "dtype": {"f32": "f32 operands on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), f32 accumulate",
+                              "bf16x6": "f32 operands split EXACTLY into three bf16 parts (8 + 8 + 8 bits), 6 bf16 MFMA products "
                                         "(the 3 dropped cross terms <= 2^-23 of a product), f32 accumulate: fp32-level error",
                               "bf16x3": "split-bf16 x3 operands (hi*hi + hi*lo + lo*hi), f32 accumulate",
                               "bf16": "bf16 operands, f32 accumulate"}[m],
@@ -423,7 +437,10 @@ def main():
             "metric": "GCond outer-loop iters/sec", "value": round(units / dt, 3), "unit": "outer-iters/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if args.operand_mode == "f32" else f"f32 with {args.operand_mode} MFMA operands", "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x6": "f32 (storage, accumulation, every element-wise pass); the five large contractions take their "
+                                              "f32 operands as EXACT three-way bf16 splits (8 + 8 + 8 bits, six bf16 MFMA products): fp32-level error",
+                      "bf16x3": "f32 with two-way split bf16 MFMA operands (2^-16 operand representation)",
+                      "bf16": "f32 with bf16 MFMA operands"}[args.operand_mode], "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped synthetic graph, GCond r={p['rate']}, SGC T={p['T']} h={p['hidden']}, "
                                    f"PGE h={p['ph']}, n'={len(p['labels_syn'])}, seeds/class 256, fan-out {list(p['fan'])}, "
                                    f"inner_loop {p['inner']}, GPU sampler", "N": int(p['data'].bench_n),

@@ -5,6 +5,7 @@ torch is used only to own device memory and the stream; all arithmetic happens i
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -14,6 +15,12 @@ from . import _lib
 from ._lib import Blocks, GCondConfig, GCondIO, GemmDesc, check, ptr, stream
 
 METRICS = {"ours": 0, "mse": 1, "cos": 2}
+
+# Operand form of the five large contractions.  The host mirror's default is the EXACT three-way bf16 split
+# ("bf16x6": every fp32 operand = h + m + l with 8 + 8 + 8 significant bits, six bf16 MFMA products, fp32 accumulation — fp32-level
+# error, measured <= the fp32 MFMA's own against fp64, every parity gate of the fp32 path incl. the headline-shape accuracy gate);
+# "f32" selects the fp32 matrix pipe (1/16 of the bf16 rate).  The C library's own default stays 0 = fp32.
+DEFAULT_OPERAND_MODE = os.environ.get("GS_OPERAND_MODE", "bf16x6")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -290,6 +297,7 @@ class GCondEngine:
             check(L.gs_gcond_create(C.byref(cfg), C.byref(io), stream(), C.byref(h)))
         self.h = h
         self.L = L
+        self.set_operand_mode(DEFAULT_OPERAND_MODE)
 
     def _s(self):
         """torch's current stream — which must belong to this engine's device (an engine built for cuda:1 must
@@ -446,9 +454,10 @@ class GCondEngine:
     OPERAND_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x6": 3}
 
     def set_operand_mode(self, mode):
-        """Operand form of the row-panel products (gs_gcond_set_operand_mode): 'f32' (default, fp32 MFMA), 'bf16x6' (exact
+        """Operand form of the row-panel products (gs_gcond_set_operand_mode): 'f32' (fp32 MFMA), 'bf16x6' (DEFAULT_OPERAND_MODE: exact
         three-way bf16 split, 6 bf16 MFMAs, fp32 accumulate: fp32-level error), 'bf16x3' (two-way split, 3 MFMAs), 'bf16'."""
         check(self.L.gs_gcond_set_operand_mode(self.h, self.OPERAND_MODES.get(mode, mode)))
+        self.operand_mode = mode
 
     def set_full_neighbour(self, S_full=None, rs_full=None):
         """Full-neighbour mode for SGC with ntrans = 1 (gs_gcond_set_full_neighbour): S_full [N, ld >= d] = A^ A^ X and
