@@ -20,7 +20,7 @@ for spec in sys.argv[1:]:
     args = cli(["-D", ds, "-M", method, "-R", rate, "-G", "0", "--save_path", tempfile.mkdtemp(prefix="gs_full_")], standalone_mode=False)
     if "full" in opt:
         args.neighbour_mode = "full"
-    for m in ("bf16x6", "bf16x3", "bf16"):
+    for m in ("f32", "bf16x6", "bf16x3", "bf16"):
         if m in opt:
             args.operand_mode = m
     for o in opt:
@@ -39,7 +39,7 @@ for spec in sys.argv[1:]:
     wmean, wstd = Evaluator(args).evaluate(graph, model_type="GCN", verbose=False, reduced=False)   # whole-dataset baseline
     args.run_eval = keep
     t5 = time.time()
-    print(f"FULL {method} seed={args.seed} {ds}{' [full-neighbour mode]' if 'full' in opt else ''}{' [operand mode ' + args.operand_mode + ']' if getattr(args, 'operand_mode', 'f32') != 'f32' else ''} r={rate} setting={args.setting} N={graph.num_nodes} n'={agent.nnodes_syn} epochs={args.epochs} outer={args.outer_loop} "
+    print(f"FULL {method} seed={args.seed} {ds}{' [full-neighbour mode]' if 'full' in opt else ''}{' [operand mode ' + (getattr(args, 'operand_mode', None) or 'default bf16x6') + ']'} r={rate} setting={args.setting} N={graph.num_nodes} n'={agent.nnodes_syn} epochs={args.epochs} outer={args.outer_loop} "
           f"inner={args.inner_loop}: data {t1 - t0:.1f}s  reduce {t2 - t1:.1f}s ({args.epochs * args.outer_loop} outer iterations, "
           f"{(args.epochs * args.outer_loop) / (t2 - t1):.0f} it/s incl. checkpoints)  final eval ({args.run_eval} runs x {args.eval_epochs} epochs) "
           f"{t3 - t2:.1f}s  acc {100 * mean:.2f} +/- {100 * std:.2f}  | GCN trained on the ORIGINAL graph (3 runs, {t5 - t4:.1f}s): "

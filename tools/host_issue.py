@@ -8,8 +8,13 @@ p = bench.build_problem("ogbn-arxiv", seed=1)
 eng = bench.make_engine(p, "cuda:0")
 bench.init_state(p, eng)
 bench.new_model(p, eng)
-for mode in ("f32", "bf16x3"):
-    eng.set_operand_mode(mode)
+from graphslim_amd.parallel import Comm, ShardedGCond
+for mode in ("bf16x6", "f32", "sharded-8 (rank 3 of 8, one library call per iteration)"):
+    if mode.startswith("sharded"):
+        eng.set_operand_mode("bf16x6")
+        eng = ShardedGCond(eng, 3, 8, [len(q) for q in p["pools"]], comm=Comm.null(3, 8))
+    else:
+        eng.set_operand_mode(mode)
     for _ in range(10):
         eng.outer_step(10)
     torch.cuda.synchronize()

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "ogbn-arxiv"
-mode = sys.argv[2] if len(sys.argv) > 2 else "f32"
+mode = sys.argv[2] if len(sys.argv) > 2 else None      # None: the engine default (bf16x6)
 if os.environ.get("GS_SMALL"):      # routing sweep: "max_tiles,max_gflop" of the latency-oriented 32x32 kernel
     import ctypes as C
     from graphslim_amd import _lib
@@ -20,7 +20,9 @@ if os.environ.get("GS_SMALL"):      # routing sweep: "max_tiles,max_gflop" of th
     _lib.lib().gs_gemm_set_small(C.c_long(int(t)), C.c_double(float(g)))
 p = bench.build_problem(name, seed=1)
 eng = bench.make_engine(p, "cuda:0")
-eng.set_operand_mode(mode)
+if mode:
+    eng.set_operand_mode(mode)
+print(f"workload {name}, operand mode {eng.operand_mode}")
 bench.init_state(p, eng)
 bench.new_model(p, eng)
 for _ in range(3):
@@ -43,20 +45,20 @@ stages = [
     ("sample (next blocks)", eng.stage_sample),
     ("real-side gradients", eng.stage_real_grads),
     ("PGE forward (training)", lambda: eng.stage_pge_forward(False)),
-    ("synthetic match forward", eng.stage_syn_match),
-    ("distance + second-order backward", eng.syn_finish),
+    ("synthetic match (fwd + class terms + 2nd-order bwd)", eng.stage_syn_match),
+    ("loss bookkeeping", eng.syn_finish),
     ("PGE backward (feature epoch)", lambda: eng.stage_pge_backward(False, True)),
     ("PGE backward (PGE epoch)", lambda: eng.stage_pge_backward(True, True)),
     ("Adam (feature epoch)", lambda: eng.stage_update(10)),
     ("PGE forward (inference)", lambda: eng.stage_pge_forward(True)),
-    ("inner SGC steps", eng.stage_inner),
+    ("inner SGC steps", eng.inner_steps),
 ]
 tot = 0.0
 for label, fn in stages:
     us = timed(fn)
     if "PGE epoch" not in label and "sample" not in label:
         tot += us
-    print(f"{label:36s} {us:8.1f} us")
+    print(f"{label:52s} {us:8.1f} us")
 print(f"sum of the feature-epoch stages (no overlap, sampling excluded): {tot:.1f} us")
 it = timed(lambda: eng.outer_step(10), 40)
 print(f"outer_step (feature epoch, two streams + prefetched sampling): {it:.1f} us")
