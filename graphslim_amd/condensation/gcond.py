@@ -38,10 +38,16 @@ class _GradMatch(GCondBase):
         if args.nlayers != 2:
             raise NotImplementedError("graphslim_amd: nlayers (propagations) must be 2")
         with_bn = bool(getattr(args, "with_bn", False))
+        if with_bn and args.condense_model == "GCN":
+            # no reference behaviour to match: in train_class the synthetic forward hands the DENSE adj_syn to GraphConvolution.forward,
+            # which returns [1, n', hidden] (layers.py:41-47), and BatchNorm1d(hidden) raises — golden G22 records upstream's outcome
+            raise NotImplementedError("graphslim_amd: with_bn with condense_model = 'GCN' has no reference behaviour to match — upstream's "
+                                      "train_class raises RuntimeError ('running_mean should contain n' elements not hidden', "
+                                      "models/base.py:65 on the 3-D output of layers.py:41-47); with_bn is built for SGC")
         if with_bn and not (args.condense_model == "SGC" and args.ntrans == 2 and args.dis_metric == "ours"):
             # models/sgc.py:27-33 puts BatchNorm layers between transforms only (ntrans >= 2); built for the shipped depth.  Their
             # weight / bias are 1-D parameters: distance 0 under 'ours' (utils.py:98-101), but part of the mse / cos distances,
-            # whose second-order terms are not built.  GCN + with_bn (models/gcn.py:14-22) is not built either.
+            # whose second-order terms are not built.
             raise NotImplementedError("graphslim_amd: with_bn is built for condense_model SGC with ntrans = 2 and dis_metric 'ours'")
         if float(getattr(args, "dropout", 0.0) or 0.0) != 0.0:
             # models/sgc.py:38-43 and models/base.py:51-78 apply F.dropout(training=True) inside train_class and the inner

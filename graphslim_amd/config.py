@@ -53,7 +53,12 @@ def setting_config(args):
     if args.dataset in ["flickr", "reddit", "amazon", "yelp"]:
         args.setting = "ind"
     if args.dataset in ["yelp", "amazon"]:
-        raise NotImplementedError("graphslim_amd: multi-label datasets (f1 metric) are outside the built path")
+        # upstream cannot condense them with the gradient-matching family either: GCondBase.__init__ -> generate_labels_syn counts
+        # data.labels_train.tolist() with collections.Counter, and a row of the multi-hot label matrix is a list —
+        # TypeError("unhashable type: 'list'"), golden G21 (tests/golden/make_golden.py::g21, tests/test_host.py)
+        raise NotImplementedError("graphslim_amd: multi-label datasets (yelp, amazon: f1 metric, sigmoid output) have no reference "
+                                  "behaviour to match on this path — upstream's GCondBase.__init__ raises TypeError(\"unhashable type: "
+                                  "'list'\") in generate_labels_syn (gcond_base.py:93)")
     args.metric = accuracy
     args.run_inter_eval = 3
     args.eval_interval = args.epochs // 10

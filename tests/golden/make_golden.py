@@ -398,12 +398,12 @@ def g6():
 # ---------------------------------------------------------------- G7 train_class ---------------
 
 
-def run_train_class(tag, n, nclass, d, hidden, T, rate, dataset, out, kind="SGC", dis_metric="ours", sizes=(4, 3)):
+def run_train_class(tag, n, nclass, d, hidden, T, rate, dataset, out, kind="SGC", dis_metric="ours", sizes=(4, 3), with_bn=False):
     a, x, y = make_graph(n, nclass, d, 5, seed=41)
     per = [max(6, n // (4 * nclass)) + 2 * c for c in range(nclass)]
     data = FakeData(a, x, y, nclass, per, 10, 10, seed=2, sizes=sizes)
     args = args_obj(ntrans=T, hidden=hidden, reduction_rate=rate, dataset=dataset, condense_model=kind,
-                    dis_metric=dis_metric)
+                    dis_metric=dis_metric, with_bn=with_bn)
     torch.manual_seed(61)
     np.random.seed(61)
     agent = GCondBase("trans", data, args)
@@ -419,6 +419,8 @@ def run_train_class(tag, n, nclass, d, hidden, T, rate, dataset, out, kind="SGC"
     adj_syn = agent.pge(agent.feat_syn)
     agent.adj_syn = RU.normalize_adj_tensor(adj_syn, sparse=False)
     calls0 = data.calls
+    if with_bn:
+        agent.check_bn(model)                      # gcond.py:50
     loss = agent.train_class(model, adj, features, labels, labels_syn, args)
     agent.optimizer_feat.zero_grad()
     agent.optimizer_pge.zero_grad()
@@ -820,6 +822,8 @@ def g16():
     model = agent.check_bn(model)
     assert not model.bns[0].training
     calls0 = data.calls
+    if with_bn:
+        agent.check_bn(model)                      # gcond.py:50
     loss = agent.train_class(model, adj, features, labels, labels_syn, args)
     agent.optimizer_feat.zero_grad()
     agent.optimizer_pge.zero_grad()
@@ -1021,8 +1025,45 @@ def g20():
     save("g20_sgdd", **out)
 
 
+def g21():
+    """What the reference's gradient-matching family does with a MULTI-LABEL dataset (configs/gcond/{yelp,amazon}.json, config.py
+    setting_config: metric f1, multi_label): GCondBase.__init__ calls generate_labels_syn (gcond_base.py:93-115), which counts
+    `data.labels_train.tolist()` with collections.Counter — for the [n_train, n_labels] multi-hot label matrix of the GraphSAINT
+    yelp / amazon files (dataset/loader.py class_map of lists) every row is a list.  The fixture records the outcome (exception type
+    and message) so that the scope fence in graphslim_amd/config.py is pinned to the reference's behaviour."""
+    rng = np.random.default_rng(3)
+    y = (rng.random((60, 5)) < 0.3).astype(np.int64)          # multi-hot labels, as convertor / loader build them for yelp / amazon
+    me = types.SimpleNamespace(args=types.SimpleNamespace(reduction_rate=0.1, verbose=False), data=types.SimpleNamespace())
+    data = types.SimpleNamespace(labels_train=torch.from_numpy(y))
+    try:
+        ls = GCondBase.generate_labels_syn(me, data)
+        outcome = ("ok", repr(np.asarray(ls).shape))
+    except Exception as e:      # noqa: BLE001 — the fixture IS the exception
+        outcome = (type(e).__name__, str(e))
+    save("g21_multi_label_labels_syn", type=np.array(outcome[0]), message=np.array(outcome[1]), labels_shape=np.array(y.shape))
+    print("g21:", outcome)
+
+
+def g22():
+    """What the reference does with with_bn when the condensation model is GCN (gcond_base.py:261-285 check_bn, models/gcn.py:14-22,
+    models/base.py:51-70): in train_class the SYNTHETIC forward hands the dense adj_syn to GraphConvolution.forward, which returns a
+    3-D [1, n', hidden] tensor for a dense adjacency (layers.py:41-47) — the same shape that breaks the evaluation GCN in G17 — and
+    BatchNorm1d(hidden) sees n' channels.  The fixture records the outcome, so that the fence in graphslim_amd/condensation/gcond.py
+    (with_bn is built for SGC only) is pinned to the reference's behaviour."""
+    outcome = {}
+    for tag, T in (("gcn", 2),):
+        out = {}
+        try:
+            run_train_class(tag, 80, 4, 6, 12, T, 0.4, "ogbn-arxiv", out, kind="GCN", with_bn=True)
+            outcome[tag] = ("ok", repr(float(out[f"{tag}_loss"])))
+        except Exception as e:      # noqa: BLE001 — the fixture IS the exception
+            outcome[tag] = (type(e).__name__, str(e))
+    save("g22_gcn_with_bn_train_class", **{f"{k}_{q}": np.array(v[i]) for k, v in outcome.items() for i, q in enumerate(("type", "message"))})
+    print("g22:", outcome)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16",
-                             "g17", "g18", "g19", "g20"]
+                             "g17", "g18", "g19", "g20", "g21", "g22"]
     for w in which:
         globals()[w]()

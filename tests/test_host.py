@@ -287,6 +287,33 @@ def test_g15_appnp_condense_model_is_fenced_like_the_reference_fails(golden_dir)
         agent.reduce(None, verbose=False)
 
 
+def test_g21_multi_label_is_fenced_like_the_reference_fails(golden_dir):
+    """configs/gcond/{yelp,amazon}.json exist upstream, but the gradient-matching family cannot start on a multi-label dataset:
+    golden G21 is the outcome of the reference's generate_labels_syn on a multi-hot label matrix (TypeError from collections.Counter
+    on list rows, gcond_base.py:93).  The package refuses the datasets at configuration time and says why."""
+    from helpers import load_golden
+    from graphslim_amd import config
+    g = load_golden(golden_dir, "g21_multi_label_labels_syn")
+    assert str(g["type"]) == "TypeError" and "unhashable type: 'list'" in str(g["message"])
+    for ds in ("yelp", "amazon"):
+        args = type("A", (), {"dataset": ds, "reduction_rate": -1, "epochs": 100})()
+        with pytest.raises(NotImplementedError, match="TypeError"):
+            config.setting_config(args)
+
+
+def test_g22_gcn_condense_model_with_bn_is_fenced_like_the_reference_fails(golden_dir):
+    """with_bn + condense_model GCN: golden G22 is the outcome of the reference's check_bn + train_class (RuntimeError from
+    BatchNorm1d on the 3-D activations GraphConvolution returns for the dense synthetic adjacency) — no behaviour to match."""
+    from helpers import load_golden
+    from graphslim_amd.condensation.gcond import GCond
+    g = load_golden(golden_dir, "g22_gcn_with_bn_train_class")
+    assert str(g["gcn_type"]) == "RuntimeError" and "running_mean should contain" in str(g["gcn_message"])
+    agent = GCond.__new__(GCond)
+    agent.args = type("A", (), {"condense_model": "GCN", "verbose": False, "nlayers": 2, "ntrans": 2, "with_bn": True, "dis_metric": "ours"})()
+    with pytest.raises(NotImplementedError, match="RuntimeError"):
+        agent.reduce(None, verbose=False)
+
+
 def test_g17_evaluation_gcn_with_bn_is_fenced_like_the_reference_fails(golden_dir):
     """with_bn reaches the evaluation model through the shared args (eval_agent.py, gcond_base.py:287-340), but upstream's GCN
     cannot run it on a condensed graph: golden G17 is the outcome of the reference's fit_with_val(reduced=True) — a RuntimeError
