@@ -283,7 +283,7 @@ def main():
     ap.add_argument("--full-neighbour", action="store_true",
                     help="SGC ntrans = 1 workloads (cora, reddit): exact 2-hop full neighbourhoods (SURVEY 8e mode F) — S_full = A^ A^ X "
                          "by row-sharded SpMM once before the timed region, seed-row gathers per iteration; not the headline")
-    ap.add_argument("--eval-epochs", type=int, default=100,
+    ap.add_argument("--eval-epochs", type=int, default=200,
                     help="condensation epochs of the bounded job behind `eval_acc` (0 = off; the reference schedule is 600)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()

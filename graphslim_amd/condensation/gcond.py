@@ -49,11 +49,13 @@ class _GradMatch(GCondBase):
             # weight / bias are 1-D parameters: distance 0 under 'ours' (utils.py:98-101), but part of the mse / cos distances,
             # whose second-order terms are not built.
             raise NotImplementedError("graphslim_amd: with_bn is built for condense_model SGC with ntrans = 2 and dis_metric 'ours'")
-        if float(getattr(args, "dropout", 0.0) or 0.0) != 0.0:
-            # models/sgc.py:38-43 and models/base.py:51-78 apply F.dropout(training=True) inside train_class and the inner
-            # loop; the engine has no dropout stage, so a non-zero value must not be silently ignored
-            raise NotImplementedError("graphslim_amd: dropout != 0 in the condensation model is not built (the reference's "
-                                      "GCond configs all use dropout = 0, configs/gcond/*.json)")
+        if float(getattr(args, "dropout", 0.0) or 0.0) != 0.0 and not (args.condense_model == "SGC" and args.ntrans == 1):
+            # models/sgc.py:38-43 and models/base.py:51-78 apply F.dropout(training=True) after every transform BUT THE LAST, inside
+            # train_class and the inner loop.  With SGC and one transform there is no such layer: the value is accepted and — exactly as
+            # upstream — has no effect.  With a hidden layer the engine has no dropout stage, so a non-zero value must not be silently
+            # ignored; every configs/{gcond,doscond,gcondx,doscondx,msgc,sgdd}/*.json uses dropout = 0.
+            raise NotImplementedError("graphslim_amd: dropout != 0 in a condensation model with a hidden layer (SGC ntrans = 2, GCN) is "
+                                      "not built (the reference's gradient-matching configs all use dropout = 0)")
         labels_syn = np.asarray(data.labels_syn)
         if args.setting == "trans":
             features, adj = data.feat_full, data.adj_full

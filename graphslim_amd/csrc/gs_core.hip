@@ -14,7 +14,7 @@ void gs_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gs_last_error(void) { return g_err; }
-extern "C" int gs_version(void) { return 200; }   // 100 * round + revision: round 2 added the panel / edge kernels, operand modes, the structure generators
+extern "C" int gs_version(void) { return 300; }   // 100 * round + revision: round 3 added gs_comm / the sharded one-call iteration, the fused chains, row-list H1
 
 // ------------------------------------------------------------------------------------------------
 // CSR SpMM:  Y[i,:] = sum_e val[e] * X[col[e],:]

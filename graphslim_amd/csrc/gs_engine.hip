@@ -62,7 +62,7 @@ gs_gemm_desc mk(const float* A, long sAm, long sAk, const float* B, long sBk, lo
 struct gs_gcond {
   gs_gcond_config cfg;
   gs_gcond_io io;
-  int N, d, ldx, C, n, T, h, Ph, bcap, f1, f2, cap1, F;
+  int N, d, ldx, C, n, T, h, Ph, bcap, f1, f2, cap1, F, Fp;     // Fp = F rounded up to 4: row stride of the real side's P0 / Sr
   long P, Ppge;
   long oW1, ob1, oWl, obl;                                   // model parameter offsets
   long pW0, pb0, pW1, pb1, pw2, pb2, pg1, pbe1, pg2, pbe2;   // PGE parameter offsets
@@ -155,6 +155,7 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   e->pge_chunks = c.pge_chunks > 1 ? c.pge_chunks : 1;
   if (e->gcn) e->T = 2;                       // GCN: two GraphConvolution layers, same parameter layout as SGC T = 2
   e->F = (e->T == 1) ? c.d : c.hidden;
+  e->Fp = (e->F + 3) & ~3;
   gs_pdesc& pd = e->pd;
   memset(&pd, 0, sizeof(pd));
   if (e->T == 1) {
@@ -240,8 +241,8 @@ static size_t carve(gs_gcond* e, void* base) {
   } else {
     e->h1_flag = e->h1_list = e->h1_count = nullptr;
   }
-  e->P0 = w.take<float>(C * cap1 * F); e->rs0 = w.take<float>(C * cap1);
-  e->Sr = w.take<float>(C * bcap * F); e->rsr = w.take<float>(C * bcap);
+  e->P0 = w.take<float>(C * cap1 * e->Fp); e->rs0 = w.take<float>(C * cap1);
+  e->Sr = w.take<float>(C * bcap * e->Fp); e->rsr = w.take<float>(C * bcap);
   e->Zr = w.take<float>(C * bcap * C); e->gw_real = w.take<float>(C * P);
   if (e->T == 2) {
     e->Tm = w.take<float>(C * bcap * h); e->Y1 = w.take<float>(C * cap1 * h);
@@ -645,17 +646,18 @@ extern "C" int gs_gcond_stage_sample(gs_gcond* e, gs_stream_t stream) {
 // stage: real-side per-class gradients gw_real[c] (gcond_base.py:212-224), propagate-first form
 // ================================================================================================
 static void launch_ell(const int* col, const float* val, const int* nrows, int cap_rows, int f, long col_base_stride,
-                       const float* src, long ld_src, const float* rs_in, int F, float* out, float* rs_out, int C,
+                       const float* src, long ld_src, const float* rs_in, int F, float* out, long ld_out, float* rs_out, int C,
                        hipStream_t s) {
   long waves = (long)C * cap_rows;
   int blocks = gs_cdiv(waves, 4);
-  bool vec = (F % 4 == 0) && (ld_src % 4 == 0) && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
+  const int F4 = (F + 3) & ~3;
+  bool vec = (ld_src % 4 == 0) && (ld_out % 4 == 0) && ld_src >= F4 && ld_out >= F4 && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
   if (vec)
     hipLaunchKernelGGL((gs_ell_spmm_kernel<4>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
-                       src, ld_src, rs_in, F, out, rs_out, C);
+                       src, ld_src, rs_in, F, out, ld_out, rs_out, C);
   else
     hipLaunchKernelGGL((gs_ell_spmm_kernel<1>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
-                       src, ld_src, rs_in, F, out, rs_out, C);
+                       src, ld_src, rs_in, F, out, ld_out, rs_out, C);
 }
 
 // ---- the rows of H1 = relu(X W1 + b1) a rank needs: the hop-2 sources of ITS classes' blocks ---------------------------------
@@ -736,22 +738,23 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   const long P = e->P, c0 = e->c_lo;
   const gs_blocks b = blocks_view(e);
   // class-major scratch of this rank's classes
-  float* P0 = e->P0 + c0 * cap1 * F; float* rs0 = e->rs0 + c0 * cap1;
-  float* Sr = e->Sr + c0 * bcap * F; float* rsr = e->rsr + c0 * bcap;
+  const long Fp = e->Fp;
+  float* P0 = e->P0 + c0 * cap1 * Fp; float* rs0 = e->rs0 + c0 * cap1;
+  float* Sr = e->Sr + c0 * bcap * Fp; float* rsr = e->rsr + c0 * bcap;
   float* Zr = e->Zr + c0 * bcap * C; float* gw = e->gw_real + c0 * P;
   const float* th = model_th(e);
   if (e->gcn) {
     // GCN (layers.py:36-51), propagate-first: P0 = A0 X_g ; H1 = relu(P0 W1 + b1) ; Z = A1 (H1 W2) + b2
     float* P0g = e->P0g + c0 * cap1 * d; float* H1r = e->Y1 + c0 * cap1 * h; float* T2r = e->T2r + c0 * cap1 * C;
     float* dT2 = e->dT2r + c0 * cap1 * C; float* dH1 = e->dH1r + c0 * cap1 * h;
-    launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, e->io.X, e->ldx, nullptr, d, P0g, nullptr, Cl, s);
+    launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, e->io.X, e->ldx, nullptr, d, P0g, d, nullptr, Cl, s);
     GS_LAUNCH_CHECK();
     gs_gemm_desc g1 = mk(P0g, d, 1, th + e->oW1, h, 1, H1r, h, Cl * cap1, h, d);
     g1.bias = th + e->ob1; g1.relu = 1;
     GS_TRY(gs_gemm_f32(&g1, stream));
     gs_gemm_desc g2 = mk(H1r, h, 1, th + e->oWl, C, 1, T2r, C, Cl * cap1, C, h);
     GS_TRY(gs_gemm_f32(&g2, stream));
-    launch_ell(b.col1, b.val1, b.n_seed, bcap, f1, cap1, T2r, C, nullptr, C, Zr, nullptr, Cl, s);
+    launch_ell(b.col1, b.val1, b.n_seed, bcap, f1, cap1, T2r, C, nullptr, C, Zr, C, nullptr, Cl, s);
     hipLaunchKernelGGL(gs_real_softmax_grad_kernel, dim3(gs_cdiv((long)Cl * bcap, 4)), dim3(256), 0, s, Zr, e->ones, th + e->obl,
                        b.n_seed, bcap, C, (int)c0, Cl);                      // Z + 1 * b2 ; G in place
     GS_LAUNCH_CHECK();
@@ -804,7 +807,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   }
   if (e->S_full) {      // full-neighbour mode: S_c = S_full[seeds of class c], rs_c = rs_full[seeds]
     hipLaunchKernelGGL(gs_gather_seed_rows_kernel, dim3(gs_cdiv((long)Cl * bcap, 4)), dim3(256), 0, s, e->S_full, e->ldS, e->rs_full,
-                       b.nid1, cap1, b.n_seed, bcap, F, Sr, rsr, Cl);
+                       b.nid1, cap1, b.n_seed, bcap, F, Sr, Fp, rsr, Cl);
   } else {
   // hop 2 (outermost): frontier rows <- global sources;  hop 1: seeds <- frontier
   const bool probe2 = e->probing && e->probe2_n < 256;
@@ -813,16 +816,16 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       if (!e->probe2_ev[2 * e->probe2_n + q]) GS_HIP(hipEventCreate(&e->probe2_ev[2 * e->probe2_n + q]));
     GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n], s));
   }
-  launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, src, ld_src, nullptr, F, P0, rs0, Cl, s);
+  launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, src, ld_src, nullptr, F, P0, Fp, rs0, Cl, s);
   if (probe2) {
     GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n + 1], s));
     e->probe2_n++;
   }
-  launch_ell(b.col1, b.val1, b.n_seed, bcap, f1, cap1, P0, F, rs0, F, Sr, rsr, Cl, s);
+  launch_ell(b.col1, b.val1, b.n_seed, bcap, f1, cap1, P0, Fp, rs0, F, Sr, Fp, rsr, Cl, s);
   }
   GS_LAUNCH_CHECK();
   {  // Z = S Wl  (all classes at once), then G in place
-    gs_gemm_desc g = mk(Sr, F, 1, th + e->oWl, C, 1, Zr, C, Cl * bcap, C, F);
+    gs_gemm_desc g = mk(Sr, Fp, 1, th + e->oWl, C, 1, Zr, C, Cl * bcap, C, F);
     GS_TRY(gs_gemm_f32(&g, stream));
     hipLaunchKernelGGL(gs_real_softmax_grad_kernel, dim3(gs_cdiv((long)Cl * bcap, 4)), dim3(256), 0, s, Zr, rsr, th + e->obl,
                        b.n_seed, bcap, C, (int)c0, Cl);
@@ -832,8 +835,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
      // (Tm below has a 160x larger tile grid: grouping it in as well fills the launch with empty workgroups — measured
      // 341 instead of 360 outer-iters/s)
     gs_gemm_desc g2[2];
-    g2[0] = mk(Sr, 1, F, Zr, C, 1, gw + e->oWl, C, F, C, bcap);
-    g2[0].nb1 = Cl; g2[0].sAb1 = (long)bcap * F; g2[0].sBb1 = (long)bcap * C; g2[0].sCb1 = P;
+    g2[0] = mk(Sr, 1, Fp, Zr, C, 1, gw + e->oWl, C, F, C, bcap);
+    g2[0].nb1 = Cl; g2[0].sAb1 = (long)bcap * Fp; g2[0].sBb1 = (long)bcap * C; g2[0].sCb1 = P;
     g2[1] = mk(rsr, 0, 1, Zr, C, 1, gw + e->obl, C, 1, C, bcap);
     g2[1].nb1 = Cl; g2[1].sAb1 = bcap; g2[1].sBb1 = (long)bcap * C; g2[1].sCb1 = P;
     GS_TRY(gs_gemm_group_f32(g2, 2, stream));
@@ -2178,7 +2181,7 @@ extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* 
       {"loss_c", e->loss_c, C},            {"d_feat", e->d_feat, n * e->d},     {"d_adj_norm", e->dAn, n * n},
       {"d_adj", e->d_adj, n * n},          {"d_pge", e->d_pge, e->Ppge},        {"adj_norm", e->adj_norm, n * n},
       {"adj_raw", e->adj_raw, n * n},      {"adj_norm_inner", e->adj_norm_in, n * n}, {"D", e->D, C * e->P},
-      {"g_model", e->g_model, e->P},       {"Sr", e->Sr, C * e->bcap * e->F},   {"rsr", e->rsr, C * e->bcap},
+      {"g_model", e->g_model, e->P},       {"Sr", e->Sr, C * e->bcap * e->Fp},   {"rsr", e->rsr, C * e->bcap},
       {"Q", e->Q, n * n},                  {"Ss", e->Ss, n * e->F},             {"Ps", e->Ps, n * C},
       {"dQ", e->dQ, n * n},                {"e3", e->e3, n * n},                {"H1full", e->H1full, e->H1full ? (long)e->N * e->h : 0},
       // all-reduce(sum) buffers of the sharded engine.  ar_bn2 / ar_l3 are fp64 (count in doubles), the rest fp32.

@@ -15,16 +15,18 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
                                                           const int* __restrict__ nrows, int cap_rows, int f,
                                                           long col_base_stride, const float* __restrict__ src, long ld_src,
                                                           const float* __restrict__ rs_in, int F, float* __restrict__ out,
-                                                          float* __restrict__ rs_out, int nclass) {
+                                                          long ld_out, float* __restrict__ rs_out, int nclass) {
+  // (VEC = 4 needs ld_src, ld_out multiples of 4 that cover F rounded up to 4 — the engine pads its row strides, so that widths
+  // like 602 (reddit) or 1 433 (cora) take the 16-byte path too: the columns [F, round4(F)) carry zeros from X's padding)
   const int lane = threadIdx.x & 63;
   const long grow = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // (c, row)
   if (grow >= (long)nclass * cap_rows) return;
   const int c = (int)(grow / cap_rows), row = (int)(grow - (long)c * cap_rows);
-  float* o = out + grow * F;
+  float* o = out + grow * ld_out;
   if (row >= nrows[c]) {
     for (int c0 = lane * VEC; c0 < F; c0 += 64 * VEC)
       for (int q = 0; q < VEC; ++q)
-        if (c0 + q < F) o[c0 + q] = 0.f;
+        if (c0 + q < (VEC == 4 ? (int)ld_out : F)) o[c0 + q] = 0.f;
     if (lane == 0 && rs_out) rs_out[grow] = 0.f;
     return;
   }
@@ -453,12 +455,12 @@ __global__ __launch_bounds__(256) void gs_bn_unfold_grads_kernel(float* __restri
 __global__ __launch_bounds__(256) void gs_gather_seed_rows_kernel(const float* __restrict__ S_full, long ldS,
                                                                   const float* __restrict__ rs_full, const int* __restrict__ nid,
                                                                   int cap1, const int* __restrict__ n_seed, int bcap, int F,
-                                                                  float* __restrict__ Sr, float* __restrict__ rsr, int C) {
+                                                                  float* __restrict__ Sr, long ldSr, float* __restrict__ rsr, int C) {
   const int lane = threadIdx.x & 63;
   const long w = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (w >= (long)C * bcap) return;
   const int c = (int)(w / bcap), b = (int)(w - (long)c * bcap);
-  float* out = Sr + w * F;
+  float* out = Sr + w * ldSr;
   if (b >= n_seed[c]) {
     for (int k = lane; k < F; k += 64) out[k] = 0.f;
     if (lane == 0) rsr[w] = 0.f;

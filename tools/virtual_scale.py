@@ -36,14 +36,23 @@ def timed(e):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-base = timed(eng)
+def timed3(e):
+    """median of three measurements (one in three 40-step windows on this pool's boxes runs at about half speed, whichever rank it
+    hits — host issue rises with it: a box-level disturbance, not a property of a rank)"""
+    global host_ms
+    r = sorted((timed(e), host_ms) for _ in range(3))
+    host_ms = r[1][1]
+    return r[1][0]
+
+
+base = timed3(eng)
 print(f"fused single-GPU outer step: {base:.3f} ms (host issue {host_ms:.3f} ms)")
 for world in worlds:
     ts, hs = [], []
     for r in range(world):
         sh = ShardedGCond(eng, r, world, pools, comm=Comm.null(r, world))      # the library's one-call sharded iteration, exchanges = no-ops
         bench.init_state(p, eng)
-        ts.append(timed(sh))
+        ts.append(timed3(sh))
         hs.append(round(host_ms, 3))
     print(f"world {world}: per-rank ms {[round(t, 3) for t in ts]}  max {max(ts):.3f}  compute-only speed-up {base / max(ts):.2f}x  host issue ms {hs}", flush=True)
 eng.set_shard(0, p["data"].nclass, 0, len(p["labels_syn"]))
