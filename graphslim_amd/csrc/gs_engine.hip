@@ -1967,8 +1967,20 @@ extern "C" int gs_gcond_set_structure(gs_gcond* e, const float* adj, int inferen
 
 // Sampling + real-side class gradients of this rank's classes, forked onto the engine's second stream when overlap is on
 // (the join is taken by the first stage that reads gw_real); also samples the NEXT iteration's blocks behind them.
+// ---- exchanges of the sharded iteration (tags: gs_comm_read_timing) -------------------------------------------------
+static inline int xchg(gs_comm* comm, void* buf, long count, int f64, int tag, gs_stream_t stream) {
+  return comm ? gs_comm_allreduce(comm, buf, count, f64, tag, stream) : GS_OK;
+}
+
+static int real_async(gs_gcond* e, gs_stream_t stream, bool fork_recorded);
 extern "C" int gs_gcond_stage_real_async(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  return real_async(e, stream, false);
+}
+
+// fork_recorded: the caller has already recorded ev_fork on `stream` (and enqueued independent work behind it: the outer step
+// issues the first part of the PGE forward BEFORE this branch's ~20 launches, see outer_step_impl)
+static int real_async(gs_gcond* e, gs_stream_t stream, bool fork_recorded) {
   if (e->overlap && e->overlap_sampling_only) {
     // level 2: the real-side gradients stay on the caller's stream; the second stream only samples the NEXT iteration's blocks
     // (into the other block buffer) while they run
@@ -1984,7 +1996,7 @@ extern "C" int gs_gcond_stage_real_async(gs_gcond* e, gs_stream_t stream) {
     GS_TRY(gs_gcond_stage_real_grads(e, stream));
   } else if (e->overlap) {
     hipStream_t s = (hipStream_t)stream;
-    GS_HIP(hipEventRecord(e->ev_fork, s));
+    if (!fork_recorded) GS_HIP(hipEventRecord(e->ev_fork, s));
     GS_HIP(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
     GS_TRY(gs_gcond_stage_sample(e, (gs_stream_t)e->aux));
     GS_TRY(gs_gcond_stage_real_grads(e, (gs_stream_t)e->aux));
@@ -2002,10 +2014,6 @@ extern "C" int gs_gcond_stage_real_async(gs_gcond* e, gs_stream_t stream) {
   return GS_OK;
 }
 
-// ---- exchanges of the sharded iteration (tags: gs_comm_read_timing) -------------------------------------------------
-static inline int xchg(gs_comm* comm, void* buf, long count, int f64, int tag, gs_stream_t stream) {
-  return comm ? gs_comm_allreduce(comm, buf, count, f64, tag, stream) : GS_OK;
-}
 
 // PGE forward with the two exchanges between its parts when `comm` is given (BN-2 column sums, pair scores)
 static int pge_forward_x(gs_gcond* e, int inference, gs_comm* comm, gs_stream_t stream) {
@@ -2049,12 +2057,28 @@ static int outer_step_impl(gs_gcond* e, int step_pge, int step_feat, int run_inf
   if (comm && gs_comm_world(comm) > 1 && e->pge_chunks > 1)
     GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond_outer_step_sharded: the chunked PGE (pge_chunks > 1) cannot be sharded over pair rows");
   if (e->identity) { step_pge = 0; run_inference = 0; }
-  GS_TRY(gs_gcond_stage_real_async(e, stream));
-  if (!e->identity) {
-    if (e->reuse_fwd && e->fwd_cached)
-      GS_TRY(adopt_cached_forward(e, stream));
-    else
-      GS_TRY(pge_forward_x(e, 0, comm, stream));
+  const bool recompute_fwd = !e->identity && !(e->reuse_fwd && e->fwd_cached);
+  if (recompute_fwd && e->overlap && !e->overlap_sampling_only) {
+    // Issue order: the two branches are independent, and the host needs ~3 us per launch.  A class shard's real-side branch is
+    // ~20 short launches: enqueued first (round-3 trace of rank 2 of 8) they left the main queue EMPTY for 195 us while the host
+    // was still feeding the second stream.  So the fork point is recorded, the first part of the PGE forward (its long product)
+    // goes to the main queue, THEN the real-side branch to the second stream, then the rest of the forward.
+    hipStream_t s = (hipStream_t)stream;
+    GS_HIP(hipEventRecord(e->ev_fork, s));
+    GS_TRY(gs_gcond_stage_pge_forward_part(e, 0, 1, stream));
+    GS_TRY(xchg(comm, e->sums, 2L * e->Ph, 1, 0, stream));
+    GS_TRY(real_async(e, stream, true));
+    GS_TRY(gs_gcond_stage_pge_forward_part(e, 0, 2, stream));
+    GS_TRY(xchg(comm, e->e3, (long)e->n * e->n, 0, 1, stream));
+    GS_TRY(gs_gcond_stage_pge_forward_part(e, 0, 3, stream));
+  } else {
+    GS_TRY(gs_gcond_stage_real_async(e, stream));
+    if (!e->identity) {
+      if (!recompute_fwd)
+        GS_TRY(adopt_cached_forward(e, stream));
+      else
+        GS_TRY(pge_forward_x(e, 0, comm, stream));
+    }
   }
   GS_TRY(gs_gcond_stage_syn_match(e, stream));
   GS_TRY(xchg(comm, e->ar_syn, (long)e->n * e->d + (long)e->n * e->n + e->C, 0, 2, stream));
