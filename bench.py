@@ -285,6 +285,7 @@ def main():
                          "by row-sharded SpMM once before the timed region, seed-row gathers per iteration; not the headline")
     ap.add_argument("--eval-epochs", type=int, default=200,
                     help="condensation epochs of the bounded job behind `eval_acc` (0 = off; the reference schedule is 600)")
+    ap.add_argument("--no-modes", action="store_true", help="skip the tagged runs in the other operand modes (profiling: one mode per trace)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -397,7 +398,7 @@ def main():
     # NOT the headline: `value` is measured in args.operand_mode (default exact fp32 = the reference's precision).
     modes = {}
     for m in ("f32", "bf16x6", "bf16x3", "bf16"):
-        if m == args.operand_mode or world > 1:
+        if m == args.operand_mode or world > 1 or args.no_modes:
             continue
         base.set_operand_mode(m)
         run_steps(p, eng, args.warmup, max(args.warmup, 1))

@@ -202,43 +202,50 @@ __device__ __forceinline__ void panel_epilogue_marg(const gs_panel_args& p, cons
 
 // In-place transform of a lane's 16 A elements (k = 32 kb + 16 h + t) for the generated-operand forms.
 //   AGEN: a holds E2[row][k] -> dE2 = g2 is2 (dy2 - dbe2 / N - xh2 dg2 / N), xh2 = (E2 - mu2) is2, dy2 = de3 w2 [g2 xh2 + be2 > 0]
-//         (gs_pge_bn2_bwd_v4_kernel, same arithmetic, constants folded into the [K][8] table gc)
+//         (gs_pge_bn2_bwd_v4_kernel, same arithmetic, constants folded into the table)
 //   FGEN: a holds U[c][k]   -> A1[(r, c)][k] = relu(g1 ((U[c][k] + V[r][k] + b0 - mu1) is1) + be1)   (gs_pge_make_a1_v5_kernel,
-//         same arithmetic; V rows in LDS at vs, constants table gc)
+//         same arithmetic; the tile's two V rows in table slots 5 / 6 (mode 3) or in LDS at vs)
+// The per-column constants sit in LDS as a STRUCTURE OF ARRAYS tab[slot][GS_TAB_K] (slot = the position inside the [K][8] rows the
+// producers write): one 16-byte LDS read delivers a constant for 4 consecutive k, so the 16 k of a lane need 4 rounds of 6-7 reads
+// issued together.  The first form read one [8]-row per k — 32 dependent LDS round trips per 32-k block, each waited for with
+// lgkmcnt(0), in front of the block's MFMAs (round-3 ISA reading; the product ran at 3x its MFMA floor).  Same values: same
+// operations in the same order per element.
+#define GS_TAB_K 256
 template <bool AGEN, bool FGEN, bool VTAB = false>
-__device__ __forceinline__ void panel_transform_a(const gs_panel_args& p, f32x4 (&a)[4], const f32x4* __restrict__ gc,
+__device__ __forceinline__ void panel_transform_a(const gs_panel_args& p, f32x4 (&a)[4], const float* __restrict__ tab,
                                                   const float* __restrict__ vs, float gen_d, int rsel, int kb, int h) {
+  const int k0 = 32 * kb + 16 * h;
   if constexpr (AGEN) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int k = 32 * kb + 16 * h + t;
-      const f32x4 c0 = gc[2 * k], c1 = gc[2 * k + 1];
-      const float xh = fmaf(a[t >> 2][t & 3], c0[0], c0[1]);
-      const float y = fmaf(c0[2], xh, c0[3]);
-      const float sel = y > 0.f ? gen_d * c1[0] : 0.f;
-      a[t >> 2][t & 3] = fmaf(-xh, c1[2], sel - c1[1]);
-    }
-  }
-  if constexpr (FGEN && VTAB) {       // mode 3: the two V rows of the tile ride in slots 5 / 6 of the constants table
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int k = 32 * kb + 16 * h + t;
-      const f32x4 c0 = gc[2 * k], c1 = gc[2 * k + 1];
-      const float x = ((a[t >> 2][t & 3] + (rsel ? c1[2] : c1[1])) + c0[0]) - c0[1];
-      a[t >> 2][t & 3] = fmaxf(fmaf(c0[3], x * c0[2], c1[0]), 0.f);
-    }
-  }
-  if constexpr (FGEN && !VTAB) {
-    const float* __restrict__ vk = vs + rsel * p.K + 32 * kb + 16 * h;
-#pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
-      const f32x4 vv = *reinterpret_cast<const f32x4*>(vk + 4 * t4);
+      const float* q = tab + k0 + 4 * t4;
+      const f32x4 is2 = *reinterpret_cast<const f32x4*>(q), nm = *reinterpret_cast<const f32x4*>(q + GS_TAB_K),
+                  g2 = *reinterpret_cast<const f32x4*>(q + 2 * GS_TAB_K), be2 = *reinterpret_cast<const f32x4*>(q + 3 * GS_TAB_K),
+                  c4 = *reinterpret_cast<const f32x4*>(q + 4 * GS_TAB_K), c5 = *reinterpret_cast<const f32x4*>(q + 5 * GS_TAB_K),
+                  c6 = *reinterpret_cast<const f32x4*>(q + 6 * GS_TAB_K);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int k = 32 * kb + 16 * h + 4 * t4 + t;
-        const f32x4 c0 = gc[2 * k], c1 = gc[2 * k + 1];
-        const float x = ((a[t4][t] + vv[t]) + c0[0]) - c0[1];
-        a[t4][t] = fmaxf(fmaf(c0[3], x * c0[2], c1[0]), 0.f);
+        const float xh = fmaf(a[t4][t], is2[t], nm[t]);
+        const float y = fmaf(g2[t], xh, be2[t]);
+        const float sel = y > 0.f ? gen_d * c4[t] : 0.f;
+        a[t4][t] = fmaf(-xh, c6[t], sel - c5[t]);
+      }
+    }
+  }
+  if constexpr (FGEN) {
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const float* q = tab + k0 + 4 * t4;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(q), mu1 = *reinterpret_cast<const f32x4*>(q + GS_TAB_K),
+                  is1 = *reinterpret_cast<const f32x4*>(q + 2 * GS_TAB_K), g1 = *reinterpret_cast<const f32x4*>(q + 3 * GS_TAB_K),
+                  be1 = *reinterpret_cast<const f32x4*>(q + 4 * GS_TAB_K);
+      f32x4 vv;
+      if constexpr (VTAB) vv = *reinterpret_cast<const f32x4*>(q + (5 + rsel) * GS_TAB_K);      // the tile's two V rows: slots 5 / 6
+      else vv = *reinterpret_cast<const f32x4*>(vs + rsel * p.K + k0 + 4 * t4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float x = ((a[t4][t] + vv[t]) + b0[t]) - mu1[t];
+        a[t4][t] = fmaxf(fmaf(g1[t], x * is1[t], be1[t]), 0.f);
       }
     }
   }
@@ -260,8 +267,8 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   //      mode 3     [3 B sub-stages of N x 96 B][ONE table of 256 x 8 floats: generated-operand constants in slots 0-4 (0-6),
   //                  the tile's two V rows in slots 5 / 6 (FGEN), the bias in slot 7] — 72 + 8 = 80 KB at N = 256: exactly two
   //                  workgroups per CU with a prefetch distance of two sub-stages
-  constexpr int S3 = PN_N * 96, OFF_X = MODE == 3 ? 3 * S3 : 2 * PN_STAGE, BS = MODE == 3 ? 8 : 1;
-  float* sbias = reinterpret_cast<float*>(smem + OFF_X) + (MODE == 3 ? 7 : 0);
+  constexpr int S3 = PN_N * 96, OFF_X = MODE == 3 ? 3 * S3 : 2 * PN_STAGE, BS = 1;
+  float* sbias = reinterpret_cast<float*>(smem + OFF_X) + (MODE == 3 ? 7 * GS_TAB_K : 0);      // (mode 3: slot 7 of the table)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
@@ -317,39 +324,43 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   }
   // AGEN: the per-column constants of the operand transform sit behind the bias row ([K <= 256][8] floats), this lane's
   // pair row has ONE upstream scalar (de3 of the pair)
-  const f32x4* __restrict__ gc = reinterpret_cast<const f32x4*>(smem + OFF_X + (MODE == 3 ? 0 : PN_N * 4));
+  const float* __restrict__ gc = reinterpret_cast<const float*>(smem + OFF_X + (MODE == 3 ? 0 : PN_N * 4));      // tab[8][GS_TAB_K]
   float gen_d = 0.f;
   if constexpr (AGEN) gen_d = p.gen_d[min(row, p.M - 1)];
-  if constexpr (MODE == 3) {
-    // one pass writes the whole table: thread i owns half-row i (row k = i >> 1): no two threads touch the same 16 bytes
-    f32x4* gw = reinterpret_cast<f32x4*>(smem + OFF_X);
-    const float* __restrict__ tab = AGEN ? p.gen_c : (FGEN ? p.a1_c : nullptr);
+  // The [K][8] constants rows of the producers are transposed into the structure-of-arrays image tab[slot][GS_TAB_K] (see
+  // panel_transform_a): thread i owns half-row i of the source (row k = i >> 1, slots 4 (i & 1) .. + 3): every float of the image
+  // is written by exactly one thread.  Mode 3 also parks the tile's two V rows (slots 5, 6; FGEN) and the bias (slot 7) there.
+  {
+    float* tw = const_cast<float*>(gc);
+    const float* __restrict__ src = AGEN ? p.gen_c : (FGEN ? p.a1_c : nullptr);
     const int r0 = FGEN ? m0 / p.mg_n : 0;
-    for (int i = tid; i < 512; i += 256) {
-      const int k = i >> 1;
-      f32x4 t = {0.f, 0.f, 0.f, 0.f};
-      if ((AGEN || FGEN) && k < p.K) t = reinterpret_cast<const f32x4*>(tab)[i];
-      if (i & 1) {
-        if constexpr (FGEN) {
-          if (k < p.K) {
-            t[1] = p.a1_V[(long)min(r0, p.mg_nr - 1) * p.a1_ld + k];
-            t[2] = p.a1_V[(long)min(r0 + 1, p.mg_nr - 1) * p.a1_ld + k];
+    if constexpr (AGEN || FGEN || MODE == 3) {
+      for (int i = tid; i < 2 * GS_TAB_K; i += 256) {
+        const int k = i >> 1, hf = i & 1;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (AGEN || FGEN) {
+          if (k < p.K) t = reinterpret_cast<const f32x4*>(src)[i];
+        }
+        if constexpr (MODE == 3) {
+          if (hf) {
+            if constexpr (FGEN) {
+              if (k < p.K) {
+                t[1] = p.a1_V[(long)min(r0, p.mg_nr - 1) * p.a1_ld + k];
+                t[2] = p.a1_V[(long)min(r0 + 1, p.mg_nr - 1) * p.a1_ld + k];
+              }
+            }
+            if constexpr (!MARG) t[3] = (p.bias && k < PN_N) ? p.bias[k] : 0.f;
           }
         }
-        if constexpr (!MARG) t[3] = (p.bias && k < PN_N) ? p.bias[k] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tw[(4 * hf + q) * GS_TAB_K + k] = t[q];
       }
-      gw[i] = t;
     }
-  } else if constexpr (AGEN) {
-    f32x4* gw = reinterpret_cast<f32x4*>(smem + 2 * PN_STAGE + PN_N * 4);
-    for (int i = tid; i < 2 * p.K; i += 256) gw[i] = reinterpret_cast<const f32x4*>(p.gen_c)[i];
   }
 
-  // FGEN: [K][8] layer-1 constants behind the bias row, then the V rows of the tile's (at most two) r
+  // FGEN (modes 0-2): the V rows of the tile's (at most two) r behind the table
   const float* __restrict__ vs = reinterpret_cast<const float*>(smem + 2 * PN_STAGE + PN_N * 4 + 256 * 32);
   if constexpr (FGEN && MODE != 3) {
-    f32x4* gw = reinterpret_cast<f32x4*>(smem + 2 * PN_STAGE + PN_N * 4);
-    for (int i = tid; i < 2 * p.K; i += 256) gw[i] = reinterpret_cast<const f32x4*>(p.a1_c)[i];
     f32x4* vw = reinterpret_cast<f32x4*>(smem + 2 * PN_STAGE + PN_N * 4 + 256 * 32);
     const int kq = p.K >> 2, r0 = m0 / p.mg_n;
     for (int i = tid; i < 2 * kq; i += 256) {
