@@ -398,6 +398,7 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
     //   end of a u == 1 step: the A fragments (issued one step ago) have landed when at most 2 PW3 newer loads are outstanding
     // (0 once nothing newer has been issued: the last step).
     constexpr int PW3c = 3 * NT / 4;
+    bf16x8 ah, am, al;
     const int nsb = 2 * nkb, nsb_run = nsb * p.krep;
     load_a(0, a_cur);
     stage_b3(0, 0);
@@ -405,19 +406,21 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
     int slot = 0;
     for (int ss = 0; ss < nsb_run; ++ss) {
       const int sb = ss % nsb, u = sb & 1, kb = sb >> 1;
+      if (p.triage & 4) {      // measurement only (tools/triage_panel3.py): no waits, no barrier — results are garbage
+      } else
       if (ss + 1 >= nsb_run) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (u == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW3c + 4) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW3c) : "memory");
       // (a bare barrier: __syncthreads() carries a workgroup-scope release fence, which the compiler lowers to vmcnt(0) and
       // would drain the two prefetched sub-stages at every step; LDS visibility of the direct-to-LDS loads is what the vmcnt
       // above waits for, this wave's own LDS reads of the stage about to be overwritten are done once lgkmcnt is 0)
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (u == 0) {
+      if (!(p.triage & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (u == 0 && !(p.triage & 8)) {
         if (ss + 2 < nsb_run) load_a(((sb + 2) % nsb) >> 1, a_nxt);
       }
-      if (ss + 2 < nsb_run) stage_b3((sb + 2) % nsb, slot == 0 ? 2 : slot - 1);      // slot of ss + 2 = (slot + 2) % 3
+      if (ss + 2 < nsb_run && !(p.triage & 8)) stage_b3((sb + 2) % nsb, slot == 0 ? 2 : slot - 1);      // slot of ss + 2 = (slot + 2) % 3
       if (u == 0) panel_transform_a<AGEN, FGEN, true>(p, a_cur, gc, vs, gen_d, rsel, kb, h);
-      bf16x8 ah, am, al;
+      if (!(p.triage & 16) || ss == 0)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float x = u == 0 ? a_cur[e >> 2][e & 3] : a_cur[2 + (e >> 2)][e & 3];
@@ -445,6 +448,18 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+      }
+      // Issue order for the scheduler, tile after tile: [2 MFMAs of tile j][3 LDS reads of tile j + 1][4 MFMAs of tile j] — the
+      // reads of the NEXT tile get 128 cycles of this tile's MFMAs before the lgkmcnt(0) in front of the next tile's first MFMA
+      // (the waitcnt pass always waits for ALL outstanding LDS reads here, so the reads must not be the last thing issued before
+      // it).  Left to itself the scheduler grouped the tiles in pairs and put every read right in front of its first use: three
+      // exposed LDS latencies per 12 MFMAs (round-3 ISA reading).
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (j + 1 < NTW) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       }
       if (u == 1) {
         if (ss + 1 < nsb_run) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW3c) : "memory");
