@@ -418,7 +418,7 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
       if (u == 0 && !(p.triage & 8)) {
         if (ss + 2 < nsb_run) load_a(((sb + 2) % nsb) >> 1, a_nxt);
       }
-      if (ss + 2 < nsb_run && !(p.triage & 8)) stage_b3((sb + 2) % nsb, slot == 0 ? 2 : slot - 1);      // slot of ss + 2 = (slot + 2) % 3
+      if (ss + 2 < nsb_run && !(p.triage & 32)) stage_b3((sb + 2) % nsb, slot == 0 ? 2 : slot - 1);      // slot of ss + 2 = (slot + 2) % 3
       if (u == 0) panel_transform_a<AGEN, FGEN, true>(p, a_cur, gc, vs, gen_d, rsel, kb, h);
       if (!(p.triage & 16) || ss == 0)
 #pragma unroll

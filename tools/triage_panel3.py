@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the exact-split row-panel loop spends its time: the K loop repeated in-kernel (slope = one pass) with phases compiled in
-but switched off at run time (gs_panel_debug triage bits; results are garbage in those runs): 4 = no waits / barrier, 8 = no global
-loads inside the loop (A rows, B staging), 16 = operand split only in the first step, 1 = no stores."""
+but switched off at run time (gs_panel_debug triage bits; results are garbage in those runs): 4 = no waits / barrier, 8 = no A-row loads inside
+the loop, 32 = no B staging inside the loop, 16 = operand split only in the first step, 1 = no stores."""
 import ctypes as C
 import os
 import sys
@@ -32,7 +32,7 @@ a = torch.randn(M, K, device=dev)
 w = torch.randn(256, K, device=dev) / 16
 out = torch.empty(M, 256, device=dev)
 scratch = torch.empty(256 * K * 3 // 2 + 16, device=dev)
-for tri in (0, 1, 4, 8, 16, 24, 28, 29):
+for tri in (0, 1, 4, 8, 32, 40, 16, 60, 61):
     ts = []
     for R in (1, 2, 3):
         L.gs_panel_debug(R, tri)
