@@ -820,7 +820,7 @@ int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, lo
   if ((((uintptr_t)a1->U | (uintptr_t)a1->V | (uintptr_t)W) & 15)) return GS_ERR_UNSUPPORTED;
   gs_panel_args a;
   memset(&a, 0, sizeof(a));
-  a.M = nr * n; a.K = K; a.C = C; a.ldc = ldc; a.bias = bias; a.colstat = colstat; a.krep = 1;
+  a.M = nr * n; a.K = K; a.C = C; a.ldc = ldc; a.bias = bias; a.colstat = colstat; a.krep = g_panel_krep; a.triage = g_panel_triage & ~2;
   a.mg_n = n; a.mg_nr = nr;
   a.a1_U = a1->U; a.a1_V = a1->V; a.a1_ld = a1->ld; a.a1_c = a1->table;
   a.A = a1->U; a.lda = a1->ld;

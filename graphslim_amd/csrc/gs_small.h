@@ -75,6 +75,33 @@ __device__ __forceinline__ void gs_small_tile(const gs_gemm_desc& p, int bx, int
   const int per = ((k_hi - k_lo + 31) / 32) * 8;
   const int w_lo = k_lo + wave * per, w_hi = min(k_hi, w_lo + per);
 
+  // epilogue operands (bias, ReLU-derivative mask, beta * C) do not depend on the product: they are requested BEFORE the K loop, so
+  // that their round trip overlaps the fragment loads instead of following the LDS reduction (one dependent memory round trip less
+  // per launch of a latency-bound chain)
+  const int col = n0 + li, colc = min(col, p.N - 1);
+  float bv = 0.f;
+  if (p.bias) bv = p.bias[(long)b1 * p.sbias_b1 + colc];
+  const bool has_mask = p.mask != nullptr, has_beta = p.beta != 0.f;
+  float mk[4], cv[4];
+  const int rbase = m0 + 8 * wave + 4 * kh;
+  if (has_mask) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) mk[rr] = p.mask[(long)min(rbase + rr, M - 1) * p.ldmask + colc];
+  }
+  if (has_beta) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) cv[rr] = C[(long)min(rbase + rr, M - 1) * p.ldc + colc];
+  }
+
+  float adm[4], adv[4], adp[4];      // (fused Adam: this lane's moments and parameters, requested ahead as well)
+  if constexpr (ADAM) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const long i = (C + (long)min(rbase + rr, M - 1) * p.ldc + colc) - ep->gbase;
+      adm[rr] = ep->m[i]; adv[rr] = ep->v[i]; adp[rr] = ep->theta[i];
+    }
+  }
+
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -101,20 +128,6 @@ __device__ __forceinline__ void gs_small_tile(const gs_gemm_desc& p, int bx, int
   for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();
   // wave w finishes accumulator registers r = 4w .. 4w+3: rows m0 + 8w + {0..3} + 4*(lane>>5), column n0 + (lane&31)
-  const int col = n0 + li, colc = min(col, p.N - 1);
-  float bv = 0.f;
-  if (p.bias) bv = p.bias[(long)b1 * p.sbias_b1 + colc];
-  const bool has_mask = p.mask != nullptr, has_beta = p.beta != 0.f;
-  float mk[4], cv[4];
-  const int rbase = m0 + 8 * wave + 4 * kh;
-  if (has_mask) {
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) mk[rr] = p.mask[(long)min(rbase + rr, M - 1) * p.ldmask + colc];
-  }
-  if (has_beta) {
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) cv[rr] = C[(long)min(rbase + rr, M - 1) * p.ldc + colc];
-  }
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int r = 4 * wave + rr;
@@ -128,8 +141,8 @@ __device__ __forceinline__ void gs_small_tile(const gs_gemm_desc& p, int bx, int
       C[(long)row * p.ldc + col] = v;
       if constexpr (ADAM) {
         const long i = (C + (long)row * p.ldc + col) - ep->gbase;
-        float mi = ep->m[i], vi = ep->v[i];
-        const float pi = ep->theta[i];
+        float mi = adm[rr], vi = adv[rr];
+        const float pi = adp[rr];
         mi = mi + (1.f - ep->b1) * (v - mi);
         vi = ep->b2 * vi + (1.f - ep->b2) * v * v;
         const float denom = sqrtf(vi) * ep->inv_sqrt_bc2 + ep->eps;

@@ -151,7 +151,7 @@ def test_one_outer_iteration_against_the_oracle(golden_dir, tag, epoch):
     loop.step(epoch)
     ml, reg, g_x, g_p, adj_in = st.outer_iteration(epoch, batches, torch.from_numpy(s["x"]), torch.from_numpy(s["y"]).long(), inner)
     assert abs(float(eng.buffer("loss")[0]) - float(ml)) <= 1e-4 * abs(float(ml))
-    assert abs(float(loop.reg.value) - float(reg)) <= 5e-3 * abs(float(reg)), (float(loop.reg.value), float(reg))
+    assert abs(float(loop.reg.value) - float(reg)) <= 1e-3 * abs(float(reg)), (float(loop.reg.value), float(reg))
     got = {k: v.cpu() for k, v in loop.gen.views(loop.gen.grad).items()}
     # the transport plan's gradient is the regulariser's alone; fp32 autograd through torch.svd's backward (1 / (s_i^2 - s_j^2) terms)
     # is not a usable reference for it: compare with fp64 autograd of the same formula at the same structure

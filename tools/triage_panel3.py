@@ -40,3 +40,21 @@ for tri in (0, 1, 4, 8, 32, 40, 16, 60, 61):
         ts.append(min(timed(lambda: _lib.check(L.gs_gemm_f32(C.byref(d), _lib.stream()))) for _ in range(3)))
     L.gs_panel_debug(1, 0)
     print(f"prec=3 triage={tri:2d}: R=1,2,3 -> {ts[0]:.1f} {ts[1]:.1f} {ts[2]:.1f} us; per pass {ts[2] - ts[1]:.1f} us, overhead {ts[0] - (ts[2] - ts[1]):.1f} us")
+
+# the same on the product the bench's roofline names: the PGE forward with the generated A1 operand (A streams from the L2-resident
+# U, V instead of HBM), through an ogbn-arxiv-shaped engine
+del a, out
+import bench  # noqa: E402
+p = bench.build_problem("ogbn-arxiv", seed=1)
+eng = bench.make_engine(p, dev)
+bench.init_state(p, eng)
+bench.new_model(p, eng)
+eng.outer_step(10)
+torch.cuda.synchronize()
+for tri in (0, 1, 8, 32, 40, 16, 60):
+    ts = []
+    for R in (1, 2, 3):
+        L.gs_panel_debug(R, tri)
+        ts.append(min(timed(lambda: eng.pge_forward_part(False, 1)) for _ in range(3)))
+    L.gs_panel_debug(1, 0)
+    print(f"fwdgen prec=3 triage={tri:2d}: R=1,2,3 -> {ts[0]:.1f} {ts[1]:.1f} {ts[2]:.1f} us; per pass {(ts[2] - ts[0]) / 2:.1f} us, rest of part 1 {ts[0] - (ts[2] - ts[0]) / 2:.1f} us")
