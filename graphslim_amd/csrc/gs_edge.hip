@@ -25,19 +25,32 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define EG_LDA 132
 #define EG_LDB 260
 #define EG_STAGE (EG_BK * (EG_LDA + EG_LDB))   // floats per stage
+// MODE 4 = MODE 3's arithmetic with the B operand split ONCE, when it is written to LDS (round 3): the stage holds A as fp32
+// [16][132] and B as three bf16 planes (h, m, l) of [16 k][288] (row stride 576 B = 144 dwords = 16 mod 64: the hardware-transposed
+// fragment reads of all 32 lanes of a half hit 64 distinct banks).  A B fragment = 2 x ds_read_b64_tr_b16 per plane (4 consecutive k of
+// the lane's column each) instead of 8 ds_read_b32 + 8 three-way splits per tile and wave: the split of a B element is done once by
+// the thread that generates it, not by each of the four waves that read it (the first form of mode 3 was VALU-bound: ~1 500 VALU
+// cycles beside 1 536 MFMA cycles per 16-edge step).
+#define EG4_LDB 288                                    // bf16 elements per k row of a plane
+#define EG4_PLANE (EG_BK * EG4_LDB * 2)                // bytes
+#define EG4_STAGE (EG_BK * EG_LDA * 4 + 3 * EG4_PLANE) // bytes per stage
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct gs_edge_args {
   const float* X; long ldx; int d;
   const int* col; const float* w; long sK;       // [class][sK] source node ids / edge weights
   const float* H1; long ldm;                     // mask rows: H1[src][n] > 0
+  const unsigned* bits; long ldbits;             // BITS: the same predicate as sign bits, 8 words per source row (32 B instead of 1 KiB)
   const float* Y; long sYc; int f2;              // Y1 rows: Y[class * sYc + (k / f2) * 256 + n]
   const int* kcount; int kchunk;
   float* out; long sOc, sOs;                     // slabs: out[class * sOc + slab * sOs + m * 256 + n]
 };
 
-template <int MODE>
+template <int MODE, bool BITS = false>
 __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * EG_STAGE];
+  constexpr int STAGE_F = MODE == 4 ? EG4_STAGE / 4 : EG_STAGE;      // floats per stage
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_F];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
@@ -58,7 +71,9 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
     const float* __restrict__ Y = p.Y + (long)c * p.sYc;
     const int row = tid >> 4, quad = tid & 15;
     const bool m_ok0 = m0 + 4 * quad < p.d, m_ok1 = m0 + 64 + 4 * quad < p.d;      // d % 4 == 0 (checked by the launcher)
-    f32x4 ra[2], rm[4], ry[4];
+    f32x4 ra[2], rm[BITS ? 1 : 4], ry[4];
+    unsigned mw[BITS ? 4 : 1];                       // BITS: word 2 i + (quad >> 3) of the source row holds columns 4 quad + 64 i .. + 3
+    const int bo = (4 * quad) & 31;
     float rw;
     auto load_raw = [&](int k0) {
       const int k = k0 + row;
@@ -68,25 +83,53 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
       const float* xr = p.X + (long)src * p.ldx + m0 + 4 * quad;
       ra[0] = m_ok0 ? *reinterpret_cast<const f32x4*>(xr) : f32x4{0.f, 0.f, 0.f, 0.f};
       ra[1] = m_ok1 ? *reinterpret_cast<const f32x4*>(xr + 64) : f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* mr = p.H1 + (long)src * p.ldm + 4 * quad;
       const float* yr = Y + (long)(kk / p.f2) * 256 + 4 * quad;
+      if constexpr (BITS) {
+        const unsigned* br = p.bits + (long)src * p.ldbits + (quad >> 3);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rm[i] = *reinterpret_cast<const f32x4*>(mr + 64 * i);
-        ry[i] = *reinterpret_cast<const f32x4*>(yr + 64 * i);
+        for (int i = 0; i < 4; ++i) mw[i] = br[2 * i];
+      } else {
+        const float* mr = p.H1 + (long)src * p.ldm + 4 * quad;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rm[i] = *reinterpret_cast<const f32x4*>(mr + 64 * i);
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ry[i] = *reinterpret_cast<const f32x4*>(yr + 64 * i);
+    };
+    auto on = [&](int i, int e) -> bool {
+      if constexpr (BITS) return (mw[i] >> (bo + e)) & 1u;
+      else return rm[i][e] > 0.f;
     };
     auto write_stage = [&](int st) {
-      float* as = smem + st * EG_STAGE + row * EG_LDA + 4 * quad;
-      float* bs = smem + st * EG_STAGE + EG_BK * EG_LDA + row * EG_LDB + 4 * quad;
+      float* as = smem + st * STAGE_F + row * EG_LDA + 4 * quad;
       *reinterpret_cast<f32x4*>(as) = ra[0];
       *reinterpret_cast<f32x4*>(as + 64) = ra[1];
+      if constexpr (MODE == 4) {
+        char* bp = reinterpret_cast<char*>(smem + st * STAGE_F) + EG_BK * EG_LDA * 4 + row * (EG4_LDB * 2) + 8 * quad;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 b;
+        for (int i = 0; i < 4; ++i) {
+          bf16x4 bh, bm, bl;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b[e] = rm[i][e] > 0.f ? rw * ry[i][e] : 0.f;
-        *reinterpret_cast<f32x4*>(bs + 64 * i) = b;
+          for (int e = 0; e < 4; ++e) {
+            const float x = on(i, e) ? rw * ry[i][e] : 0.f;
+            const __bf16 hb = (__bf16)x;
+            const float r1 = x - (float)hb;
+            const __bf16 mb = (__bf16)r1;
+            bh[e] = hb; bm[e] = mb; bl[e] = (__bf16)(r1 - (float)mb);
+          }
+          *reinterpret_cast<bf16x4*>(bp + 128 * i) = bh;                       // columns 4 quad + 64 i .. + 3 of row k
+          *reinterpret_cast<bf16x4*>(bp + EG4_PLANE + 128 * i) = bm;
+          *reinterpret_cast<bf16x4*>(bp + 2 * EG4_PLANE + 128 * i) = bl;
+        }
+      } else {
+        float* bs = smem + st * STAGE_F + EG_BK * EG_LDA + row * EG_LDB + 4 * quad;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 b;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[e] = on(i, e) ? rw * ry[i][e] : 0.f;
+          *reinterpret_cast<f32x4*>(bs + 64 * i) = b;
+        }
       }
     };
     load_raw(k_lo);
@@ -96,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
     for (int k0 = k_lo; k0 < k_hi; k0 += EG_BK) {
       const bool more = k0 + EG_BK < k_hi;
       if (more) load_raw(k0 + EG_BK);                 // in flight under the MFMAs below
-      const float* __restrict__ as = smem + st * EG_STAGE + 32 * wave + li;
-      const float* __restrict__ bs = smem + st * EG_STAGE + EG_BK * EG_LDA + col_n;
+      const float* __restrict__ as = smem + st * STAGE_F + 32 * wave + li;
+      const float* __restrict__ bs = smem + st * STAGE_F + EG_BK * EG_LDA + col_n;
       if constexpr (MODE == 0) {
         float a[8];
 #pragma unroll
@@ -109,6 +152,41 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
           for (int t = 0; t < 8; ++t) b[t] = bs[(2 * t + h) * EG_LDB + 32 * j];
 #pragma unroll
           for (int t = 0; t < 8; ++t) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc[j], 0, 0, 0);
+        }
+      } else if constexpr (MODE == 4) {
+        bf16x8 ah, am, al;                                                     // A: this wave's own 32 feature rows, split here
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float x = as[(8 * h + t) * EG_LDA];
+          const __bf16 hb = (__bf16)x;
+          const float r1 = x - (float)hb;
+          const __bf16 mb = (__bf16)r1;
+          ah[t] = hb; am[t] = mb; al[t] = (__bf16)(r1 - (float)mb);
+        }
+        // B fragment of tile j: k = 8 h .. 8 h + 7 of column 32 j + li = two transposed reads per plane: lane 16 g + 4 q + p supplies the
+        // address of (row 8 h + 4 s + q, columns 32 j + 16 (g & 1) + 4 p ..) and receives rows 8 h + 4 s .. + 3 of column 32 j + li
+        // (tools/micro/tr16_probe.hip prints the mapping).  EXEC is all ones here (block-uniform control flow).
+        const int g1 = (lane >> 4) & 1, q4 = (lane >> 2) & 3, p4 = lane & 3;
+        const char* bq = reinterpret_cast<const char*>(smem + st * STAGE_F) + EG_BK * EG_LDA * 4 + (8 * h + q4) * (EG4_LDB * 2) +
+                         (16 * g1 + 4 * p4) * 2;
+        auto frag = [&](int j, int P) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(bq + P * EG4_PLANE + 64 * j));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(bq + P * EG4_PLANE + 64 * j + 4 * (EG4_LDB * 2)));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          return __builtin_bit_cast(bf16x8, v);
+        };
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bf16x8 bh = frag(j, 0), bm = frag(j, 1), bl = frag(j, 2);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);     // small terms first (same order as mode 3)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
         }
       } else if constexpr (MODE == 3) {
         bf16x8 ah, am, al;                                                     // x = h + m + l exactly (8 + 8 + 8 bits)
@@ -180,9 +258,12 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
     }
 }
 
-static int g_edge_enabled = 1;
+static int g_edge_enabled = 1, g_edge_split_at_write = 1;
+// 0 = general tiled kernel; 1 (default) = the dedicated edge kernel, exact split done once at LDS-write time + transposed fragment
+// reads (round 3); 2 = the dedicated kernel with the split at fragment-read time (round 2's form of mode 3).  Same bits either way.
 extern "C" int gs_gemm_set_edge_kernel(int enable) {
   g_edge_enabled = enable != 0;
+  g_edge_split_at_write = enable != 2;
   return GS_OK;
 }
 
@@ -204,14 +285,23 @@ int gs_edge_launch(const gs_gemm_desc& d, hipStream_t s) {
   a.X = d.A; a.ldx = d.sAk; a.d = d.M;
   a.col = d.bgen_idx; a.w = d.bgen_w; a.sK = d.sGb1;
   a.H1 = d.bgen_mask; a.ldm = d.bgen_ldm;
+  a.bits = d.bgen_bits; a.ldbits = d.bgen_ldbits;
   a.Y = d.B; a.sYc = d.sBb1; a.f2 = d.bgen_div;
   a.kcount = d.Kb; a.kchunk = d.kchunk;
   a.out = d.C; a.sOc = d.sCb1; a.sOs = d.sCb2;
   const dim3 grid(d.nb2, d.nb1, gs_cdiv(d.M, 128)), block(256);
-  if (d.prec == 0) hipLaunchKernelGGL((gs_edge_gemm_kernel<0>), grid, block, 0, s, a);
-  else if (d.prec == 1) hipLaunchKernelGGL((gs_edge_gemm_kernel<1>), grid, block, 0, s, a);
-  else if (d.prec == 2) hipLaunchKernelGGL((gs_edge_gemm_kernel<2>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((gs_edge_gemm_kernel<3>), grid, block, 0, s, a);
+  const bool bits = d.bgen_bits != nullptr && d.bgen_ldbits >= 8;
+#define GS_EDGE_LAUNCH(MODE_)                                                                    \
+  do {                                                                                           \
+    if (bits) hipLaunchKernelGGL((gs_edge_gemm_kernel<MODE_, true>), grid, block, 0, s, a);      \
+    else hipLaunchKernelGGL((gs_edge_gemm_kernel<MODE_, false>), grid, block, 0, s, a);          \
+  } while (0)
+  if (d.prec == 0) GS_EDGE_LAUNCH(0);
+  else if (d.prec == 1) GS_EDGE_LAUNCH(1);
+  else if (d.prec == 2) GS_EDGE_LAUNCH(2);
+  else if (g_edge_split_at_write) GS_EDGE_LAUNCH(4);
+  else GS_EDGE_LAUNCH(3);
+#undef GS_EDGE_LAUNCH
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

@@ -26,7 +26,7 @@ struct gs_adam_ep { float* theta; float* m; float* v; const float* gbase; float 
 int gs_chain_zg(const gs_zg_args*, hipStream_t);
 int gs_chain_group(const gs_gemm_desc*, int, const gs_adam_ep*, hipStream_t);
 int gs_panel_rows(const float*, long, const float*, long, const float*, int, float*, long, int, int, const int*, const int*, int, long, int,
-                  void*, hipStream_t);
+                  void*, unsigned*, long, hipStream_t);
 extern "C" int gs_comm_allreduce(gs_comm*, void*, long, int, int, gs_stream_t);
 extern "C" int gs_comm_world(const gs_comm*);
 
@@ -73,6 +73,7 @@ struct gs_gcond {
   gs_blocks blk;
   int *marker, *kcount;
   int *h1_flag, *h1_list, *h1_count;   // rows of H1full this rank's sampled blocks gather (sharded ranks: only those are computed)
+  unsigned* H1bits;                    // [N][h / 32] sign bits of H1full, written by its product's epilogue: the edge product's mask
   int h1_rows_max;
   float *H1full, *P0, *rs0, *Sr, *rsr, *Zr, *gw_real, *Tm, *Y1, *Bmat, *slabs_r, *colpart, *colpart_r;
   // synthetic side
@@ -236,6 +237,7 @@ static size_t carve(gs_gcond* e, void* base) {
     e->colpart_r = w.take<float>(C * nch_r * (h > 0 ? h : 1));      // the real-side branch may run on its own stream
   }
   e->H1full = e->T == 2 ? w.take<float>(N * h) : nullptr;
+  e->H1bits = (e->T == 2 && !e->gcn && h == 256) ? w.take<unsigned>(N * (h / 32)) : nullptr;
   if (e->T == 2 && !e->gcn) {
     e->h1_flag = w.take<int>(N); e->h1_list = w.take<int>(N); e->h1_count = w.take<int>(1);
   } else {
@@ -661,13 +663,14 @@ static void launch_ell(const int* col, const float* val, const int* nrows, int c
 }
 
 // ---- the rows of H1 = relu(X W1 + b1) a rank needs: the hop-2 sources of ITS classes' blocks ---------------------------------
-// flag[v] = 1 for every source id of a real edge slot (val != 0; padding slots carry (0, 0.f)) of a live frontier row
+// flag[v] = 1 for every source id an edge slot of a live frontier row names.  Padding slots carry (0, 0.f) and the gather still
+// multiplies row 0 by their zero weight: row 0 is listed with them, or a never-written (non-finite) row 0 would turn 0 * x into NaN
 __global__ __launch_bounds__(256) void gs_h1_mark_kernel(const int* __restrict__ col0, const float* __restrict__ val0,
                                                          const int* __restrict__ n1, int cap1, int f2, int C, int* __restrict__ flag) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)C * cap1 * f2) return;
   const int c = (int)(e / ((long)cap1 * f2)), l = (int)((e / f2) % cap1);
-  if (l < n1[c] && val0[e] != 0.f) flag[col0[e]] = 1;
+  if (l < n1[c]) flag[col0[e]] = 1;
 }
 
 // list = the flagged ids, count = how many.  One block compacts 2 048 flags (8 per thread, block-wide exclusive scan) and takes
@@ -719,6 +722,16 @@ static int sum_f32(gs_gcond* e, const float* x, long n, float* out, hipStream_t 
   hipLaunchKernelGGL(gs_sum_stage1_kernel, dim3(128), dim3(256), 0, s, x, n, part);
   hipLaunchKernelGGL(gs_sum_stage2_kernel, dim3(1), dim3(64), 0, s, (const double*)part, 128, out);
   GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+static int g_h1_bits = 0;
+// measurement / test knob: 1 = H1's product also writes its sign bits and the edge product reads its ReLU mask from them (32 B
+// instead of 1 KiB per sampled edge); 0 (default) = the mask is read from the fp32 rows of H1full.  Same predicate, same bits out.
+// Measured at the headline shape (round 3): the real side is 10-17 us SLOWER with the bits (the 128 ballots + 4-byte scattered
+// stores per wave in H1's epilogue cost more than the mask rows, which the hop-2 gather has just pulled into L2, save).
+extern "C" int gs_gcond_set_h1_bits(int on) {
+  g_h1_bits = on != 0;
   return GS_OK;
 }
 
@@ -776,6 +789,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   }
   const float* src = e->io.X;
   long ld_src = e->ldx;
+  bool use_bits = false;
   if (e->T == 2) {   // H1full = relu(X W1 + b1) for every node once: theta is shared by all classes
     // (W1 transposed first so that both operands are k-contiguous — see the dY1 product)
     hipLaunchKernelGGL(gs_transpose_small_kernel, dim3(gs_cdiv(h, 32), gs_cdiv(d, 32)), dim3(32, 8), 0, s, th + e->oW1, d, h, e->W1mT);
@@ -785,6 +799,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     // are produced — same arithmetic per row, so every value downstream is bitwise the full product's.
     const long slots = (long)Cl * cap1 * f2;
     int rows_rc = GS_ERR_UNSUPPORTED;
+    // (the sign bits are an output of the row-panel kernel: asked for only where the product takes that route)
+    const bool want_bits = g_h1_bits && e->H1bits && e->cfg.dis_metric == 0;
     if (g_h1_rows && !e->S_full && e->h1_flag && slots < (long)e->N) {
       GS_HIP(hipMemsetAsync(e->h1_flag, 0, sizeof(int) * (size_t)e->N, s));
       GS_HIP(hipMemsetAsync(e->h1_count, 0, sizeof(int), s));
@@ -792,14 +808,17 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       hipLaunchKernelGGL(gs_h1_compact_kernel, dim3(gs_cdiv(e->N, 2048)), dim3(256), 0, s, e->h1_flag, e->N, e->h1_list, e->h1_count);
       GS_LAUNCH_CHECK();
       rows_rc = gs_panel_rows(e->io.X, e->ldx, e->W1mT, d, th + e->ob1, 1, e->H1full, h, h, d, e->h1_list, e->h1_count, (int)slots,
-                              (long)e->N, e->operand_mode, e->bsplit_aux, s);
+                              (long)e->N, e->operand_mode, e->bsplit_aux, want_bits ? e->H1bits : nullptr, h / 32, s);
       if (rows_rc != GS_OK && rows_rc != GS_ERR_UNSUPPORTED) return rows_rc;
+      use_bits = rows_rc == GS_OK && want_bits;
     }
     if (rows_rc != GS_OK) {
       gs_gemm_desc g = mk(e->io.X, e->ldx, 1, e->W1mT, 1, d, e->H1full, h, e->N, h, d);
       g.bias = th + e->ob1;
       g.relu = 1;
       g.prec = e->operand_mode; g.scratch = e->bsplit_aux;
+      use_bits = want_bits && gs_gemm_route(&g) == 5;       // 5 = the row-panel kernel
+      if (use_bits) { g.signbits = e->H1bits; g.ld_signbits = h / 32; }
       GS_TRY(gs_gemm_f32(&g, stream));
     }
     src = e->H1full;
@@ -884,6 +903,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     if (fused) {   // B(k, :) = val0[k] * [H1full[col0[k]] > 0] * Y1[k / f2]
       gwd.B = Y1; gwd.sBb1 = (long)cap1 * h;
       gwd.bgen_mask = e->H1full; gwd.bgen_ldm = h; gwd.bgen_idx = b.col0; gwd.bgen_w = b.val0; gwd.bgen_div = f2;
+      if (use_bits) { gwd.bgen_bits = e->H1bits; gwd.bgen_ldbits = h / 32; }
       gwd.prec = e->operand_mode;      // honoured by the dedicated edge kernel (gs_edge.hip); the tiled fallback is fp32
     }
     GS_TRY(gs_gemm_f32(&gwd, stream));
@@ -2211,7 +2231,7 @@ extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* 
       // all-reduce(sum) buffers of the sharded engine.  ar_bn2 / ar_l3 are fp64 (count in doubles), the rest fp32.
       {"ar_bn2", e->sums, 2 * Ph},         {"ar_l3", e->sums, 3 * Ph},          {"ar_syn", e->ar_syn, n * e->d + n * n + C},
       {"ar_marg", e->ar_marg, 2 * n * Ph}, {"ar_w1", e->d_pge + e->pW1, Ph * Ph + Ph},
-      {"ar_gw_real", e->gw_real, C * e->P},
+      {"ar_gw_real", e->gw_real, C * e->P},  {"H1bits", e->H1bits, e->H1bits ? (long)e->N * (e->h / 32) : 0},
   };
   for (auto& t : tab)
     if (!strcmp(t.k, name)) {

@@ -667,6 +667,7 @@ extern "C" int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream) {
   if ((long)nbatch > 65535) GS_FAIL(GS_ERR_ARG, "gs_gemm_f32: too many batches (%d)", nbatch);
   hipStream_t s = (hipStream_t)stream;
   if (gs_panel_eligible(p)) return gs_panel_launch(p, s);
+  if (p.signbits) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gemm_f32: signbits is an output of the row-panel kernel only (N 128 / 256, k-contiguous operands, unbatched)");
   if (gs_edge_eligible(p)) return gs_edge_launch(p, s);
   if (small_route(p, nbatch)) return launch_small(p, nbatch, s);
   // tile choice: fill the 256 CUs; narrow outputs get the tall/flat tiles

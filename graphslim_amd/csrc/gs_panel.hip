@@ -57,6 +57,7 @@ struct gs_panel_args {
   // row-list form (gs_panel_rows_kernel): row i of the product reads A[rowidx[i]] and writes C[rowidx[i]]; the row count is read
   // on the device (*m_dev, <= the M the grid was sized for) — the rows of H1 = relu(X W1 + b1) a rank's sampled blocks gather
   const int* rowidx; const int* m_dev;
+  unsigned* bits; long ldbits;       // optional sign bits of the written C: bit (n & 31) of bits[row * ldbits + (n >> 5)] = [C(row, n) > 0]
   unsigned long long* span;          // optional [2]: device-side launch span — min over workgroups of the start tick, max of the
                                      // end tick (s_memrealtime, 100 MHz); see gs_gcond_probe
   int krep, triage;                  // measurement hooks (gs_panel_debug): K loop repeated krep times; bit 0: no stores;
@@ -110,6 +111,17 @@ __device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32
         Cb[coff[r] + 32u * j] = v[r];
         s1 += v[r];
         s2 = fmaf(v[r], v[r], s2);
+      }
+    }
+    if (p.bits) {      // (tile-uniform) sign bits: one ballot per accumulator register = 32 columns of two rows (the two half-waves)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned long long m = __ballot(v[r] > 0.f);
+        const int rt = m0 + row_in_tile + (r & 3) + 8 * (r >> 2);
+        if ((threadIdx.x & 31) == 0 && (FULL || rt < p.M)) {
+          const long grow = ROWS ? (long)p.rowidx[rt] : (long)rt;
+          p.bits[grow * p.ldbits + ((col0 + 32 * j) >> 5)] = (threadIdx.x & 32) ? (unsigned)(m >> 32) : (unsigned)m;
+        }
       }
     }
     cs1[j] = s1;
@@ -746,6 +758,7 @@ int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s) {
   a.C = d.C; a.ldc = d.ldc;
   a.M = d.M; a.K = d.K;
   a.bias = d.bias; a.relu = d.relu; a.mask = d.mask; a.ldmask = d.ldmask; a.colstat = d.colstat;
+  a.bits = d.signbits; a.ldbits = d.ld_signbits;
   a.krep = g_panel_krep; a.triage = g_panel_triage;
   a.trace = (g_panel_triage & 2) ? (unsigned long long*)d.scratch : nullptr;   // (trace runs use prec = 0: scratch is free)
   if (d.N == 256) panel_dispatch<8>(d, a, s);
@@ -757,7 +770,8 @@ int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s) {
 // engine-internal: C[rowidx[i]][N] = relu?(A[rowidx[i]][K] W^T + bias) for i < *m_dev (device count, at most m_max): the row-list
 // form of the plain product.  GS_ERR_UNSUPPORTED when the shape is not covered (the caller then computes every row).
 int gs_panel_rows(const float* A, long lda, const float* W, long ldw, const float* bias, int relu, float* Cout, long ldc, int N, int K,
-                  const int* rowidx, const int* m_dev, int m_max, long rows_total, int prec, void* scratch, hipStream_t s) {
+                  const int* rowidx, const int* m_dev, int m_max, long rows_total, int prec, void* scratch, unsigned* bits, long ldbits,
+                  hipStream_t s) {
   if (!g_panel_enabled || !rowidx || !m_dev || m_max < 1) return GS_ERR_UNSUPPORTED;
   if ((N != 256 && N != 128) || K < 32 || (K & 31) || (lda & 3) || (ldw & 3) || prec < 0 || prec > 3 || (prec != 0 && !scratch)) return GS_ERR_UNSUPPORTED;
   if ((double)rows_total * (double)ldc >= 4294967296.0 || (((uintptr_t)A | (uintptr_t)W) & 15)) return GS_ERR_UNSUPPORTED;
@@ -765,6 +779,7 @@ int gs_panel_rows(const float* A, long lda, const float* W, long ldw, const floa
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.C = Cout; a.ldc = ldc; a.M = m_max; a.K = K; a.bias = bias; a.relu = relu; a.krep = 1;
   a.rowidx = rowidx; a.m_dev = m_dev;
+  a.bits = bits; a.ldbits = ldbits;
   a.n_full = gs_cdiv(m_max, PN_BM);
   const dim3 grid(a.n_full), block(256);
   a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);

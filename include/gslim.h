@@ -83,6 +83,15 @@ typedef struct gs_gemm_desc {
      prec != 0 needs `scratch`: N * K * 4 bytes (modes 1, 2) or N * K * 6 bytes (mode 3) of device memory for the pre-split B. */
   int prec;
   void* scratch;
+  /* sign bits (round 3; both optional, row-panel / edge kernels only).  signbits: the product also writes, per output row m,
+     N / 32 words whose bit (n & 31) of word (n >> 5) is [C(m, n) > 0] — GS_ERR_UNSUPPORTED unless the product runs on the
+     row-panel kernel.  bgen_bits: the generated B operand reads its mask from such words (row bgen_idx[k], stride bgen_ldbits
+     words) instead of the fp32 rows of bgen_mask (32 B instead of 1 KiB per edge at N = 256); bgen_mask must still be given
+     (the tiled fallback reads it). */
+  unsigned* signbits;
+  long ld_signbits;
+  const unsigned* bgen_bits;
+  long bgen_ldbits;
 } gs_gemm_desc;
 
 /* K-tile depth (16 or 32) of the small tiles and of the 128x128 tile (0 = by operand mode); a measurement knob (defaults 32 / 0). */
@@ -93,7 +102,9 @@ int gs_gemm_set_tuning(int bk_small, int bk_big);
 int gs_gemm_set_small(long max_tiles, double max_gflop);
 /* route eligible products to the row-panel kernel (default 1); 0 sends them to the 128x128 tile (A/B measurements) */
 int gs_gemm_set_panel(int enable);
-/* route the real-side edge product (generated B, gathered K, N == 256) to its dedicated kernel (default 1); 0 = 128x128 tile */
+/* route the real-side edge product (generated B, gathered K, N == 256) to its dedicated kernel (default 1: exact split done once at
+   LDS-write time, hardware-transposed fragment reads); 2 = the same kernel with the split at fragment-read time (round 2's form,
+   bitwise the same result); 0 = 128x128 tile */
 int gs_gemm_set_edge_kernel(int enable);
 /* the row-panel kernel finishes the last partial round of a launch in 32-row tiles (default 1); 0 = 128-row tiles throughout */
 int gs_gemm_set_panel_narrow_tail(int on);
@@ -472,6 +483,11 @@ int gs_gcond_set_h1_rows(int on);
  * ones, Adam in the epilogue of the gradient products; the synthetic match's logits + softmax in one launch); 0 = one launch per
  * product (first form).  Same values up to fp32 re-association. */
 int gs_gcond_set_fused_chains(int on);
+
+/* Measurement / test knob: 1 = the product H1 = relu(X W1 + b1) also writes its sign bits (gs_gemm_desc.signbits) and the
+ * real-side edge product reads its ReLU mask from them (gs_gemm_desc.bgen_bits: 32 B instead of 1 KiB per sampled edge); 0 (default:
+ * measured faster, the mask rows are L2-resident) = the mask comes from the fp32 rows.  Same predicate: bitwise the same gradients. */
+int gs_gcond_set_h1_bits(int on);
 
 /* Test hook of the sampler's seed selection (gs_sample_blocks): members of the crossing key bin that are ranked directly
  * (1 .. 2048, default 2048); a small value forces the second histogram level on ordinary pools.  Same seeds either way. */

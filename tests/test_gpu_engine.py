@@ -422,8 +422,7 @@ def test_h1_rows_of_a_class_shard_are_the_full_product():
             need = torch.zeros(N, dtype=torch.bool, device=DEV)
             for c in range(c_lo, c_hi):
                 n1 = int(blk.n1[c])
-                m = blk.val0[c, :n1] != 0
-                need[blk.col0[c, :n1][m].long()] = True
+                need[blk.col0[c, :n1].reshape(-1).long()] = True      # (padding slots name row 0 with weight 0: listed too)
             assert torch.equal(need, rows)               # exactly the gathered sources, nothing else
     finally:
         _lib.check(L.gs_gcond_set_h1_rows(1))
@@ -474,6 +473,78 @@ def test_fused_chains_against_the_launch_per_product_form(workload, scale):
     # Adam's first steps move every entry by ~lr: compare on that scale
     assert float((a["theta"] - b["theta"]).abs().max()) <= 0.02 * 0.01 * p["inner"], float((a["theta"] - b["theta"]).abs().max())
     assert float((a["theta"] - b["theta"]).abs().mean()) <= 1e-6
+
+
+def test_edge_product_split_at_lds_write_is_bitwise_the_read_time_split():
+    """Round 3's form of the exact-split edge product (B split once when it is written to LDS as three bf16 planes, fragments by the
+    hardware-transposed ds_read_b64_tr_b16) against round 2's (fp32 in LDS, every wave splits what it reads): same h / m / l per
+    element, same MFMA order -> the real-side gradients must be BITWISE equal, at the headline shape and on a ragged one."""
+    import bench
+    from graphslim_amd import _lib
+    from graphslim_amd.host import init_sgc_params
+    L = _lib.lib()
+    for scale in (1.0, 0.13):
+        p = bench.build_problem("ogbn-arxiv", seed=1, scale=scale)
+        eng = bench.make_engine(p, DEV)
+        eng.set_operand_mode("bf16x6")
+        bench.init_state(p, eng)
+        torch.manual_seed(5)
+        eng.set_model(init_sgc_params(p["data"].feat_full.shape[1], p["hidden"], p["data"].nclass, p["T"]))
+        eng.stage_sample()
+        try:
+            _lib.check(L.gs_gemm_set_edge_kernel(2))
+            eng.stage_real_grads()
+            a = eng.view("gw_real").clone()
+            _lib.check(L.gs_gemm_set_edge_kernel(1))
+            eng.view("gw_real").zero_()
+            eng.stage_real_grads()
+            torch.cuda.synchronize()
+            b = eng.view("gw_real")
+            assert float(a.abs().max()) > 0
+            assert torch.equal(a, b), float((a - b).abs().max())
+        finally:
+            _lib.check(L.gs_gemm_set_edge_kernel(1))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "bf16x3"])
+def test_sign_bit_mask_of_h1_gives_bitwise_the_same_real_side_gradients(mode):
+    """The product H1 = relu(X W1 + b1) writes its sign bits in the epilogue (one ballot per accumulator register) and the edge
+    product reads the ReLU mask from them (32 B instead of 1 KiB per sampled edge): the bit image must be exactly [H1full > 0] on
+    every row the product wrote — the full product and the row-list product of a class shard — and the real-side gradients bitwise
+    those of the fp32-mask path."""
+    import bench
+    from graphslim_amd import _lib
+    from graphslim_amd.host import init_sgc_params
+    L = _lib.lib()
+    p = bench.build_problem("ogbn-arxiv", seed=1, scale=0.25)
+    N, C = p["data"].bench_n, p["data"].nclass
+    eng = bench.make_engine(p, DEV)
+    eng.set_operand_mode(mode)
+    bench.init_state(p, eng)
+    torch.manual_seed(9)
+    eng.set_model(init_sgc_params(p["data"].feat_full.shape[1], p["hidden"], C, p["T"]))
+    try:
+        for c_lo, c_hi in ((0, C), (7, 10)):
+            eng.set_shard(c_lo, c_hi, 0, len(p["labels_syn"]))
+            eng.stage_sample()
+            _lib.check(L.gs_gcond_set_h1_bits(0))
+            eng.stage_real_grads()
+            ref = eng.view("gw_real").clone().reshape(C, -1)[c_lo:c_hi]
+            _lib.check(L.gs_gcond_set_h1_bits(1))
+            eng.view("H1bits", torch.int32).zero_()
+            eng.view("H1full").fill_(float("nan"))
+            eng.stage_real_grads()
+            torch.cuda.synchronize()
+            got = eng.view("gw_real").reshape(C, -1)[c_lo:c_hi]
+            assert float(ref.abs().max()) > 0 and torch.equal(got, ref), (mode, c_lo, c_hi)
+            h1 = eng.view("H1full").reshape(N, -1)
+            rows = ~torch.isnan(h1[:, 0])
+            assert (int(rows.sum()) == N) == (c_hi - c_lo == C)
+            words = eng.view("H1bits", torch.int32).reshape(N, -1)[rows].long() & 0xFFFFFFFF
+            bits = ((words[:, :, None] >> torch.arange(32, device=DEV)) & 1).reshape(int(rows.sum()), -1).bool()
+            assert torch.equal(bits, h1[rows] > 0), (mode, c_lo, c_hi)
+    finally:
+        _lib.check(L.gs_gcond_set_h1_bits(0))
 
 
 def test_library_rccl_binding_world1():
