@@ -69,7 +69,7 @@ SYMBOLS = [
     "gs_scale_cols_f32", "gs_ot_divdiff_f32", "gs_clamp_finite_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
     "gs_comm_unique_id", "gs_comm_create_rccl", "gs_comm_create_callback", "gs_comm_create_null", "gs_comm_destroy", "gs_comm_rank",
     "gs_comm_world", "gs_comm_allreduce", "gs_comm_set_timing", "gs_comm_read_timing", "gs_gcond_outer_step_sharded",
-    "gs_gcond_outer_step_sharded_ex", "gs_sample_set_cand_cap", "gs_gcond_set_h1_rows", "gs_gcond_set_fused_chains", "gs_gcond_set_h1_bits",
+    "gs_gcond_outer_step_sharded_ex", "gs_sample_set_cand_cap", "gs_gcond_set_h1_rows", "gs_gcond_set_fused_chains", "gs_gcond_set_h1_bits", "gs_gcond_set_aux_priority", "gs_gcond_set_dw1_generated",
 ]
 
 # gs_allreduce_fn of include/gslim.h: int fn(void* user, void* buf, long count, int dtype, gs_stream_t stream)
@@ -189,6 +189,8 @@ def lib():
     L.gs_gcond_set_h1_rows.argtypes = [i]
     L.gs_gcond_set_fused_chains.argtypes = [i]
     L.gs_gcond_set_h1_bits.argtypes = [i]
+    L.gs_gcond_set_aux_priority.argtypes = [i]
+    L.gs_gcond_set_dw1_generated.argtypes = [i]
     _lib = L
     return L
 

@@ -47,6 +47,116 @@ struct gs_edge_args {
   float* out; long sOc, sOs;                     // slabs: out[class * sOc + slab * sOs + m * 256 + n]
 };
 
+// One K step (16 rows of both LDS images of `stage`) of a workgroup's 128 x 256 tile: wave w owns rows [32 w, 32 w + 32) x 256 columns,
+// 8 MFMA tiles.  Shared by the edge product and the PGE dW1 product below (same stage layout, same arithmetic).
+template <int MODE>
+__device__ __forceinline__ void eg_mfma_step(const float* __restrict__ stage, f32x16 (&acc)[8], int wave, int lane) {
+  const int li = lane & 31, h = lane >> 5, col_n = li;
+  const float* __restrict__ as = stage + 32 * wave + li;
+  const float* __restrict__ bs = stage + EG_BK * EG_LDA + col_n;
+  if constexpr (MODE == 0) {
+    float a[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a[t] = as[(2 * t + h) * EG_LDA];          // MFMA t consumes k = 2 t + (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float b[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) b[t] = bs[(2 * t + h) * EG_LDB + 32 * j];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc[j], 0, 0, 0);
+    }
+  } else if constexpr (MODE == 4) {
+    bf16x8 ah, am, al;                                                     // A: this wave's own 32 feature rows, split here
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float x = as[(8 * h + t) * EG_LDA];
+      const __bf16 hb = (__bf16)x;
+      const float r1 = x - (float)hb;
+      const __bf16 mb = (__bf16)r1;
+      ah[t] = hb; am[t] = mb; al[t] = (__bf16)(r1 - (float)mb);
+    }
+    // B fragment of tile j: k = 8 h .. 8 h + 7 of column 32 j + li = two transposed reads per plane: lane 16 g + 4 q + p supplies the
+    // address of (row 8 h + 4 s + q, columns 32 j + 16 (g & 1) + 4 p ..) and receives rows 8 h + 4 s .. + 3 of column 32 j + li
+    // (tools/micro/tr16_probe.hip prints the mapping).  EXEC is all ones here (block-uniform control flow).
+    const int g1 = (lane >> 4) & 1, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    const char* bq = reinterpret_cast<const char*>(stage) + EG_BK * EG_LDA * 4 + (8 * h + q4) * (EG4_LDB * 2) +
+                     (16 * g1 + 4 * p4) * 2;
+    auto frag = [&](int j, int P) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(bq + P * EG4_PLANE + 64 * j));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(bq + P * EG4_PLANE + 64 * j + 4 * (EG4_LDB * 2)));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bf16x8 bh = frag(j, 0), bm = frag(j, 1), bl = frag(j, 2);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);     // small terms first (same order as mode 3)
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+    }
+  } else if constexpr (MODE == 3) {
+    bf16x8 ah, am, al;                                                     // x = h + m + l exactly (8 + 8 + 8 bits)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float x = as[(8 * h + t) * EG_LDA];
+      const __bf16 hb = (__bf16)x;
+      const float r1 = x - (float)hb;
+      const __bf16 mb = (__bf16)r1;
+      ah[t] = hb; am[t] = mb; al[t] = (__bf16)(r1 - (float)mb);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bf16x8 bh, bm, bl;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float x = bs[(8 * h + t) * EG_LDB + 32 * j];
+        const __bf16 hb = (__bf16)x;
+        const float r1 = x - (float)hb;
+        const __bf16 mb = (__bf16)r1;
+        bh[t] = hb; bm[t] = mb; bl[t] = (__bf16)(r1 - (float)mb);
+      }
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);     // small terms first
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+    }
+  } else {
+    bf16x8 ah, al;                                                         // lane half h supplies k = 8 h .. 8 h + 7
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float x = as[(8 * h + t) * EG_LDA];
+      const __bf16 hb = (__bf16)x;
+      ah[t] = hb;
+      if constexpr (MODE == 1) al[t] = (__bf16)(x - (float)hb);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bf16x8 bh, bl;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float x = bs[(8 * h + t) * EG_LDB + 32 * j];
+        const __bf16 hb = (__bf16)x;
+        bh[t] = hb;
+        if constexpr (MODE == 1) bl[t] = (__bf16)(x - (float)hb);
+      }
+      if constexpr (MODE == 1) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+      }
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+    }
+  }
+}
+
 template <int MODE, bool BITS = false>
 __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
   constexpr int STAGE_F = MODE == 4 ? EG4_STAGE / 4 : EG_STAGE;      // floats per stage
@@ -58,7 +168,6 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
   const int kc = p.kcount[c];
   const int k_lo = slab * p.kchunk, k_hi = min(kc, k_lo + p.kchunk);
   float* __restrict__ out = p.out + (long)c * p.sOc + (long)slab * p.sOs;
-  const int col_n = li;     // this lane's column inside a 32-wide N tile
   f32x16 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -139,109 +248,7 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
     for (int k0 = k_lo; k0 < k_hi; k0 += EG_BK) {
       const bool more = k0 + EG_BK < k_hi;
       if (more) load_raw(k0 + EG_BK);                 // in flight under the MFMAs below
-      const float* __restrict__ as = smem + st * STAGE_F + 32 * wave + li;
-      const float* __restrict__ bs = smem + st * STAGE_F + EG_BK * EG_LDA + col_n;
-      if constexpr (MODE == 0) {
-        float a[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) a[t] = as[(2 * t + h) * EG_LDA];          // MFMA t consumes k = 2 t + (lane >> 5)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float b[8];
-#pragma unroll
-          for (int t = 0; t < 8; ++t) b[t] = bs[(2 * t + h) * EG_LDB + 32 * j];
-#pragma unroll
-          for (int t = 0; t < 8; ++t) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc[j], 0, 0, 0);
-        }
-      } else if constexpr (MODE == 4) {
-        bf16x8 ah, am, al;                                                     // A: this wave's own 32 feature rows, split here
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float x = as[(8 * h + t) * EG_LDA];
-          const __bf16 hb = (__bf16)x;
-          const float r1 = x - (float)hb;
-          const __bf16 mb = (__bf16)r1;
-          ah[t] = hb; am[t] = mb; al[t] = (__bf16)(r1 - (float)mb);
-        }
-        // B fragment of tile j: k = 8 h .. 8 h + 7 of column 32 j + li = two transposed reads per plane: lane 16 g + 4 q + p supplies the
-        // address of (row 8 h + 4 s + q, columns 32 j + 16 (g & 1) + 4 p ..) and receives rows 8 h + 4 s .. + 3 of column 32 j + li
-        // (tools/micro/tr16_probe.hip prints the mapping).  EXEC is all ones here (block-uniform control flow).
-        const int g1 = (lane >> 4) & 1, q4 = (lane >> 2) & 3, p4 = lane & 3;
-        const char* bq = reinterpret_cast<const char*>(smem + st * STAGE_F) + EG_BK * EG_LDA * 4 + (8 * h + q4) * (EG4_LDB * 2) +
-                         (16 * g1 + 4 * p4) * 2;
-        auto frag = [&](int j, int P) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(bq + P * EG4_PLANE + 64 * j));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(bq + P * EG4_PLANE + 64 * j + 4 * (EG4_LDB * 2)));
-          typedef short s16x8 __attribute__((ext_vector_type(8)));
-          const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          return __builtin_bit_cast(bf16x8, v);
-        };
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bf16x8 bh = frag(j, 0), bm = frag(j, 1), bl = frag(j, 2);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);     // small terms first (same order as mode 3)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
-        }
-      } else if constexpr (MODE == 3) {
-        bf16x8 ah, am, al;                                                     // x = h + m + l exactly (8 + 8 + 8 bits)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float x = as[(8 * h + t) * EG_LDA];
-          const __bf16 hb = (__bf16)x;
-          const float r1 = x - (float)hb;
-          const __bf16 mb = (__bf16)r1;
-          ah[t] = hb; am[t] = mb; al[t] = (__bf16)(r1 - (float)mb);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          bf16x8 bh, bm, bl;
-#pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            const float x = bs[(8 * h + t) * EG_LDB + 32 * j];
-            const __bf16 hb = (__bf16)x;
-            const float r1 = x - (float)hb;
-            const __bf16 mb = (__bf16)r1;
-            bh[t] = hb; bm[t] = mb; bl[t] = (__bf16)(r1 - (float)mb);
-          }
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);     // small terms first
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
-        }
-      } else {
-        bf16x8 ah, al;                                                         // lane half h supplies k = 8 h .. 8 h + 7
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float x = as[(8 * h + t) * EG_LDA];
-          const __bf16 hb = (__bf16)x;
-          ah[t] = hb;
-          if constexpr (MODE == 1) al[t] = (__bf16)(x - (float)hb);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          bf16x8 bh, bl;
-#pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            const float x = bs[(8 * h + t) * EG_LDB + 32 * j];
-            const __bf16 hb = (__bf16)x;
-            bh[t] = hb;
-            if constexpr (MODE == 1) bl[t] = (__bf16)(x - (float)hb);
-          }
-          if constexpr (MODE == 1) {
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-          }
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
-        }
-      }
+      eg_mfma_step<MODE>(smem + st * STAGE_F, acc, wave, lane);
       if (more) write_stage(st ^ 1);
       __syncthreads();
       st ^= 1;
@@ -303,5 +310,197 @@ int gs_edge_launch(const gs_gemm_desc& d, hipStream_t s) {
   else GS_EDGE_LAUNCH(3);
 #undef GS_EDGE_LAUNCH
   GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// ---- PGE epochs: dW1 | db1 on GENERATED operands (parametrized_adj.py:57-64, the backward of layer 2) -----------------------------
+//
+//     dW1[o][j] = sum over pair rows p = (r, c) of  dE2[p][o] * A1[p][j],        db1[o] = sum_p dE2[p][o]
+//
+// K = n'^2 pair rows (206 116 at ogbn-arxiv), M = N = 256: 27 GFLOP — the same shape as the edge product above (a K-long sum of
+// outer products of two generated 128- / 256-wide rows), so it runs on the same stage layout and MFMA step.  Neither operand
+// exists in memory:
+//   * dE2[p][o] is formed from E2[p][o] (the only HBM stream, read once per 128-column half) with the SAME arithmetic and the same
+//     constants table as the fused-marginals product (gs_panel.hip, panel_transform_a<AGEN>), so both kernels see the same dE2;
+//   * A1[(r, c)][j] = max(Us[c][j] + Vs[r][j], 0) with the BatchNorm-1 affine folded into the two n' x 256 terms
+//     (gs_pge_scale_uv_kernel below: Us = s U + t, Vs = s V, s = g1 is1, t = s (b0 - mu1) + be1) — L2-resident, no constants.
+// A K step = 16 consecutive c of ONE r (the last step of an r is masked: n' = 454 -> 29 steps, 2 % idle rows), so r and the first c
+// are wave-uniform and the Vs row is read once per step.  Workgroup = (K slab, 128-column half of dE2); the slabs carry
+// [256][256] of dW1 followed by [256] of db1 and are reduced in a fixed order by gs_reduce_slabs_f32.
+// Round 2 materialised dE2 (211 MB written + read three times) and A1 (211 MB) for a general tiled product that fetched both
+// twice (895 MB per launch).
+struct gs_dw1_args {
+  const float* E2; long lde;          // this rank's pair rows: row (r - r_lo) n' + c
+  const float* de3;                   // [rows] gradient of the layer-3 output of the same rows
+  const float* tab;                   // [256][8] rows of gs_panel_gen_row
+  const float* Us; const float* Vs;   // [n'][256]; Vs already offset to this rank's first r
+  int n, spr, stages, q;              // n', steps per r = ceil(n' / 16), nr * spr, steps per slab
+  float* out; long sOs;               // slabs: out[slab * sOs + m * 256 + j], db1 at out[slab * sOs + 65536 + m]
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gs_dw1_gen_kernel(gs_dw1_args p) {
+  constexpr int STAGE_F = MODE == 4 ? EG4_STAGE / 4 : EG_STAGE;      // floats per stage
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_F];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  const int slab = blockIdx.x, m0 = blockIdx.z * 128;
+  const int s_lo = slab * p.q, s_hi = min(p.stages, s_lo + p.q);
+  float* __restrict__ out = p.out + (long)slab * p.sOs;
+  f32x16 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // generation: A side (dE2 half): thread = 4 columns m0 + 4 cgA .. of rows 2 rpA, 2 rpA + 1 of the step (a half-wave reads 512
+  // contiguous bytes of an E2 row); B side (A1): thread = 4 columns 4 lane .. of rows 4 wave .. + 3 (a wave reads a whole Us row)
+  const int cgA = tid & 31, rpA = tid >> 5;
+  f32x4 dsum = {0.f, 0.f, 0.f, 0.f};
+  if (s_lo < s_hi) {      // (block-uniform)
+    f32x4 k_is2, k_nm, k_g2, k_be2, k_c4, k_c5, k_c6;
+    {
+      const float* t = p.tab + (long)(m0 + 4 * cgA) * 8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(t + 8 * e), hi = *reinterpret_cast<const f32x4*>(t + 8 * e + 4);
+        k_is2[e] = lo[0]; k_nm[e] = lo[1]; k_g2[e] = lo[2]; k_be2[e] = lo[3];
+        k_c4[e] = hi[0]; k_c5[e] = hi[1]; k_c6[e] = hi[2];
+      }
+    }
+    // every row of step s + 1 is requested one MFMA block ahead (a second E2 register set with two blocks of lead measured the same:
+    // the loop is not waiting for memory)
+    int r = s_lo / p.spr, c0 = 16 * (s_lo - r * p.spr), nvalid = 0;
+    f32x4 ra[2], ru[4], rv;
+    float rd[2];
+    auto load_raw = [&](int r_, int c0_) {
+      nvalid = p.n - c0_;
+      const long row0 = (long)r_ * p.n;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const long row = row0 + min(c0_ + 2 * rpA + i, p.n - 1);
+        ra[i] = *reinterpret_cast<const f32x4*>(p.E2 + row * p.lde + m0 + 4 * cgA);
+        rd[i] = p.de3[row];
+      }
+      rv = *reinterpret_cast<const f32x4*>(p.Vs + (long)r_ * 256 + 4 * lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        ru[i] = *reinterpret_cast<const f32x4*>(p.Us + (long)min(c0_ + 4 * wave + i, p.n - 1) * 256 + 4 * lane);
+    };
+    auto write_stage = [&](int st) {
+      float* base = smem + st * STAGE_F;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 2 * rpA + i;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = fmaf(ra[i][e], k_is2[e], k_nm[e]);
+          const float y = fmaf(k_g2[e], xh, k_be2[e]);
+          const float sel = y > 0.f ? rd[i] * k_c4[e] : 0.f;
+          const float val = fmaf(-xh, k_c6[e], sel - k_c5[e]);
+          v[e] = row < nvalid ? val : 0.f;
+          dsum[e] += v[e];
+        }
+        *reinterpret_cast<f32x4*>(base + row * EG_LDA + 4 * cgA) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 4 * wave + i;
+        f32x4 b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = fmaxf(ru[i][e] + rv[e], 0.f);
+        if constexpr (MODE == 4) {
+          char* bp = reinterpret_cast<char*>(base) + EG_BK * EG_LDA * 4 + row * (EG4_LDB * 2) + 8 * lane;
+          bf16x4 bh, bm, bl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = b[e];
+            const __bf16 hb = (__bf16)x;
+            const float r1 = x - (float)hb;
+            const __bf16 mb = (__bf16)r1;
+            bh[e] = hb; bm[e] = mb; bl[e] = (__bf16)(r1 - (float)mb);
+          }
+          *reinterpret_cast<bf16x4*>(bp) = bh;
+          *reinterpret_cast<bf16x4*>(bp + EG4_PLANE) = bm;
+          *reinterpret_cast<bf16x4*>(bp + 2 * EG4_PLANE) = bl;
+        } else {
+          *reinterpret_cast<f32x4*>(base + EG_BK * EG_LDA + row * EG_LDB + 4 * lane) = b;
+        }
+      }
+    };
+    load_raw(r, c0);
+    write_stage(0);
+    __syncthreads();
+    int st = 0;
+    for (int sidx = s_lo; sidx < s_hi; ++sidx) {
+      const bool more = sidx + 1 < s_hi;
+      if (more) {
+        c0 += 16;
+        if (c0 >= 16 * p.spr) { c0 = 0; ++r; }
+        load_raw(r, c0);
+      }
+      eg_mfma_step<MODE>(smem + st * STAGE_F, acc, wave, lane);
+      if (more) write_stage(st ^ 1);
+      __syncthreads();
+      st ^= 1;
+    }
+  }
+  const int rbase = m0 + 32 * wave + 4 * h;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(long)(rbase + (r & 3) + 8 * (r >> 2)) * 256 + 32 * j + li] = acc[j][r];
+  // db1: the 8 row pairs' column sums, fixed order (the stages are free: the loop ended on a barrier)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) smem[rpA * 128 + 4 * cgA + e] = dsum[e];
+  __syncthreads();
+  if (tid < 128) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += smem[g * 128 + tid];
+    out[65536 + m0 + tid] = t;
+  }
+}
+
+// Us = s U + t, Vs = s V per column (s = g1 is1, t = s (b0 - mu1) + be1 from the [Ph][8] rows {b0, mu1, is1, g1, be1, ...} the
+// BatchNorm-1 statistics kernel leaves): relu(Us[c] + Vs[r]) = the layer-1 activation of pair (r, c) up to fp32 rounding
+__global__ void gs_pge_scale_uv_kernel(const float* __restrict__ U, const float* __restrict__ V, const float* __restrict__ tab,
+                                       long total, int Ph, float* __restrict__ Us, float* __restrict__ Vs) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float* t = tab + (i % Ph) * 8;
+  const float sc = t[3] * t[2];
+  Us[i] = fmaf(sc, U[i], fmaf(sc, t[0] - t[1], t[4]));
+  Vs[i] = sc * V[i];
+}
+
+// engine-internal (gs_engine.hip): slabs must hold nsplit * (65536 + 256) floats, uv 2 n' 256 floats; *nsplit_out = slabs written.
+// GS_ERR_UNSUPPORTED when the shape is not covered (the caller then materialises both operands).
+int gs_dw1_generated(const float* E2, const float* de3, const float* gen_tab, const float* U, const float* V, const float* a1_tab,
+                     int n, int r_lo, int nr, int Ph, int prec, float* uv, float* slabs, long slabs_cap, int* nsplit_out,
+                     hipStream_t s) {
+  if (!g_edge_enabled || Ph != 256 || n < 16 || nr < 1 || prec < 0 || prec > 3) return GS_ERR_UNSUPPORTED;
+  if (((uintptr_t)E2 | (uintptr_t)uv | (uintptr_t)gen_tab) & 15) return GS_ERR_UNSUPPORTED;
+  gs_dw1_args a;
+  a.E2 = E2; a.lde = Ph; a.de3 = de3; a.tab = gen_tab;
+  a.Us = uv; a.Vs = uv + (long)n * Ph + (long)r_lo * Ph;
+  a.n = n; a.spr = gs_cdiv(n, EG_BK); a.stages = nr * a.spr;
+  // 512 workgroup slots (2 per CU) = 256 slabs x 2 halves; short sums (a rank's shard): at least 16 steps per slab
+  int nsplit = a.stages >= 256 * 16 ? 256 : gs_cdiv(a.stages, 16);
+  a.q = gs_cdiv(a.stages, nsplit);
+  nsplit = gs_cdiv(a.stages, a.q);
+  a.sOs = 65536 + 256;
+  if ((long)nsplit * a.sOs > slabs_cap) return GS_ERR_UNSUPPORTED;
+  a.out = slabs;
+  const long total = (long)n * Ph;
+  hipLaunchKernelGGL(gs_pge_scale_uv_kernel, dim3(gs_cdiv(total, 256)), dim3(256), 0, s, U, V, a1_tab, total, Ph, uv, uv + total);
+  const dim3 grid(nsplit, 1, 2), block(256);
+  if (prec == 0) hipLaunchKernelGGL((gs_dw1_gen_kernel<0>), grid, block, 0, s, a);
+  else if (prec == 1) hipLaunchKernelGGL((gs_dw1_gen_kernel<1>), grid, block, 0, s, a);
+  else if (prec == 2) hipLaunchKernelGGL((gs_dw1_gen_kernel<2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gs_dw1_gen_kernel<4>), grid, block, 0, s, a);
+  GS_LAUNCH_CHECK();
+  *nsplit_out = nsplit;
   return GS_OK;
 }

@@ -15,6 +15,8 @@ struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3;
 struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; };
 int gs_panel_marginals(const float*, long, const float*, long, const float*, long, int, int, int, int, float*, float*, int, void*,
                        const gs_panel_gen*, const gs_panel_a1*, hipStream_t);
+int gs_dw1_generated(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*,
+                     float*, long, int*, hipStream_t);
 int gs_panel_forward_a1(const gs_panel_a1*, int, int, const float*, long, const float*, float*, long, int, int, float*, int, void*,
                         unsigned long long*, hipStream_t);
 int gs_panel_tiles(int);
@@ -339,6 +341,20 @@ extern "C" int gs_gcond_workspace_bytes(const gs_gcond_config* cfg, size_t* byte
   return GS_OK;
 }
 
+static int g_dw1_generated = 1;
+// measurement / test knob: 1 (default) = PGE epochs run the backward of layer 2 on generated operands (marginals as in feature epochs,
+// dW1 | db1 by gs_dw1_gen_kernel); 0 = dE2 and A1 are materialised for a general tiled product (round 2's form)
+extern "C" int gs_gcond_set_dw1_generated(int on) {
+  g_dw1_generated = on != 0;
+  return GS_OK;
+}
+
+static int g_aux_priority = -1;
+extern "C" int gs_gcond_set_aux_priority(int level) {
+  g_aux_priority = level;
+  return GS_OK;
+}
+
 extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io, gs_stream_t stream, gs_gcond** out) {
   GS_TRY(check_cfg(cfg));
   if (!io || !out) GS_FAIL(GS_ERR_ARG, "gs_gcond_create: null argument");
@@ -424,7 +440,8 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   // priority so that its latency-bound kernels are not queued behind the PGE forward's big GEMM
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  e->overlap = (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, prio_hi) == hipSuccess) &&
+  const int prio = g_aux_priority < 0 ? prio_hi : (g_aux_priority > 0 ? prio_lo : 0);
+  e->overlap = (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, prio) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming) == hipSuccess);
@@ -1590,7 +1607,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
   if (part == 2) {
     // one launch: the layer-3 statistics as floats (dw2, dbe2, dg2), the constants table of the generated dE2 operand where
     // that form applies (feature epochs), and W1^T
-    const bool want_gen = !need_param_grads && Ph <= 256 && rows > 0;
+    const bool want_gen = (!need_param_grads || g_dw1_generated) && Ph <= 256 && rows > 0;
     hipLaunchKernelGGL(gs_pge_bwd_prep_kernel, dim3(gs_cdiv(Ph, 32), gs_cdiv(Ph, 32)), dim3(32, 8), 0, s,
                        e->l3_slices > 1 ? e->sums2 : e->sums, e->l3_slices, Ph, g + e->pw2, g + e->pbe2, g + e->pg2, e->mu2, e->is2,
                        pp + e->pg2, pp + e->pbe2, pp + e->pw2, 1.f / (float)n2, want_gen ? e->gen_tab : (float*)nullptr, pp + e->pW1,
@@ -1622,7 +1639,22 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
           return rc;
         }
       }
-      if (fused_done) return GS_OK;
+      if (fused_done && need_param_grads) {
+        // PGE epochs: dW1 = dE2^T A1 and db1 = colsum(dE2) from the same generated operands (gs_edge.hip) — the dE2 buffer is
+        // free (nothing materialised): it holds the folded layer-1 terms and the slabs
+        float* uv = e->dE2;
+        float* slabs = e->dE2 + 2L * n * Ph;
+        int nsplit = 0;
+        const int rc = gs_dw1_generated(e->E2, de3l, e->gen_tab, e->U, e->V, e->a1_tab, n, e->r_lo, nr, Ph, e->operand_mode, uv, slabs,
+                                        n2 * Ph - 2L * n * Ph, &nsplit, s);
+        if (rc == GS_OK) {
+          GS_TRY(gs_reduce_slabs_f32(g + e->pW1, slabs, (long)Ph * Ph + Ph, nsplit, 65536 + 256, 0.f, stream));   // dW1 | db1
+          return GS_OK;
+        }
+        if (rc != GS_ERR_UNSUPPORTED) return rc;
+      } else if (fused_done) {
+        return GS_OK;
+      }
       hipLaunchKernelGGL(gs_pge_bn2_bwd_v4_kernel, dim3(gs_cdiv(gs_cdiv(rows, 8) * (long)(Ph / 4), 256)), dim3(256), 0, s, e->E2, de3l, e->mu2,
                          e->is2, pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, rows, n2, Ph, e->dE2);
       GS_LAUNCH_CHECK();
@@ -1640,7 +1672,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
                            (float*)nullptr, (float*)nullptr);
         GS_LAUNCH_CHECK();
       }
-      {  // dY1 = (dE2 W1) * [A1 > 0] is needed only through its two marginals (W1^T from the prep launch above: both
+      if (!fused_done) {  // dY1 = (dE2 W1) * [A1 > 0] is needed only through its two marginals (W1^T from the prep launch above: both
          // operands k-contiguous).  Preferred route: the row-panel kernel's fused-marginals form (pair-patch tiles,
          // gs_panel.hip) — dY1 is never materialised, its buffer holds the partial sums instead.
         const int nrb = gs_cdiv(nr, 16), ncb = gs_cdiv(n, 8);

@@ -489,6 +489,14 @@ int gs_gcond_set_fused_chains(int on);
  * measured faster, the mask rows are L2-resident) = the mask comes from the fp32 rows.  Same predicate: bitwise the same gradients. */
 int gs_gcond_set_h1_bits(int on);
 
+/* Measurement / test knob: 1 (default) = PGE epochs compute dW1 | db1 of the structure generator's second layer from generated
+ * operands (dE2 from E2, the layer-1 activations from U, V: nothing materialised); 0 = round 2's form (both operands written to
+ * memory for a general tiled product).  Same values up to fp32 rounding of the folded BatchNorm-1 affine. */
+int gs_gcond_set_dw1_generated(int on);
+
+/* Priority of the second (real-side) stream of engines created AFTER the call: -1 = highest (default), 0 = normal, 1 = lowest. */
+int gs_gcond_set_aux_priority(int level);
+
 /* Test hook of the sampler's seed selection (gs_sample_blocks): members of the crossing key bin that are ranked directly
  * (1 .. 2048, default 2048); a small value forces the second histogram level on ordinary pools.  Same seeds either way. */
 int gs_sample_set_cand_cap(int cap);

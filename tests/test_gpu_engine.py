@@ -547,6 +547,52 @@ def test_sign_bit_mask_of_h1_gives_bitwise_the_same_real_side_gradients(mode):
         _lib.check(L.gs_gcond_set_h1_bits(0))
 
 
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16x6", 2e-5), ("bf16x3", 1e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("scale", [1.0, 0.13])
+def test_pge_epoch_backward_on_generated_operands(mode, tol, scale):
+    """PGE epochs (gcond.py:58-59; parametrized_adj.py:57-64 backward): dW1 = dE2^T A1 and db1 = colsum(dE2) from operands generated
+    in the kernel (dE2 from E2, the layer-1 activations from U, V with the BatchNorm-1 affine folded in; gs_dw1_gen_kernel) against
+    round 2's form, which writes both operands to memory and multiplies them on the fp32 matrix pipe: every PGE parameter gradient
+    within the operand mode's tolerance of that reference (relative to the largest entry of its tensor), at the headline shape
+    (n' = 454: 29 K steps per pair row, the last one masked) and on a small ragged one."""
+    import bench
+    from graphslim_amd import _lib
+    from graphslim_amd.host import init_sgc_params
+    L = _lib.lib()
+    p = bench.build_problem("ogbn-arxiv", seed=1, scale=scale)
+    eng = bench.make_engine(p, DEV)
+    eng.set_operand_mode(mode)
+    bench.init_state(p, eng)
+    torch.manual_seed(4)
+    eng.set_model(init_sgc_params(p["data"].feat_full.shape[1], p["hidden"], p["data"].nclass, p["T"]))
+    eng.stage_sample()
+    eng.stage_real_grads()
+    eng.stage_pge_forward(False)
+    eng.stage_syn_match()
+    eng.syn_finish()
+    shapes = eng.pge_shapes()
+    out = {}
+    try:
+        for gen in (0, 1):
+            _lib.check(L.gs_gcond_set_dw1_generated(gen))
+            eng.view("d_pge").fill_(float("nan"))
+            eng.stage_pge_backward(True, False)
+            torch.cuda.synchronize()
+            out[gen] = eng.view("d_pge").clone()
+    finally:
+        _lib.check(L.gs_gcond_set_dw1_generated(1))
+    assert not torch.isnan(out[1]).any()
+    floor = 1e-6 * float(out[0].abs().max())
+    off = 0
+    for shp in shapes:
+        k = int(np.prod(shp))
+        a, b = out[0][off:off + k], out[1][off:off + k]
+        off += k
+        # (b0 and b1 feed a BatchNorm: their gradients are analytically zero, both forms leave rounding noise ~1e-9 there)
+        assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + floor, (shp, float((a - b).abs().max()), float(a.abs().max()))
+    assert off == out[0].numel()
+
+
 def test_library_rccl_binding_world1():
     """gs_comm's RCCL transport (dlopen of librccl, ncclCommInitRank, ncclAllReduce on the engine's stream) with ONE rank — all a
     1-GPU box can run of it: a whole sharded outer iteration through gs_gcond_outer_step_sharded reproduces gs_gcond_outer_step
