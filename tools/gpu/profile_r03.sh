@@ -17,7 +17,10 @@ rm -rf $O/kt
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_bench_$c -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain-s 0 --eval-epochs 0 --no-modes > /dev/null 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_panel_$c -- python3 tools/probe_panel.py > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_dw1_$c -- python3 tools/probe_dw1.py > /dev/null 2>&1
 done
+python3 tools/make_pmc_summary.py $O/pmc_dw1_FETCH_SIZE $O/pmc_dw1_WRITE_SIZE $O/pmc_pge_epoch_backward_hbm_per_kernel.json > /dev/null
+tools/gpu/prof_kernels.sh "dw1|scale_uv|reduce_slabs_v4|marg|bn2_bwd|make_a1|gemm_f32_kernel" tools/probe_dw1.py > $O/pge_epoch_backward_kernels.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_panel_sq -- python3 tools/probe_panel.py > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_panel_grbm -- python3 tools/probe_panel.py > /dev/null 2>&1
 python3 tools/make_pmc_summary.py $O/pmc_panel_FETCH_SIZE $O/pmc_panel_WRITE_SIZE $O/pmc_panel_summary.json > /dev/null
