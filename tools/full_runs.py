@@ -14,6 +14,11 @@ from graphslim.dataset import get_dataset
 from graphslim.evaluation.eval_agent import Evaluator
 from graphslim_amd.host import seed_everything
 
+for env, fn in (("GS_DW1_GEN", "gs_gcond_set_dw1_generated"), ("GS_EDGE_KERNEL", "gs_gemm_set_edge_kernel")):      # A/B knobs of the library
+    if os.environ.get(env):
+        from graphslim_amd import _lib
+        getattr(_lib.lib(), fn)(int(os.environ[env]))
+        print(f"{fn}({os.environ[env]})", flush=True)
 for spec in sys.argv[1:]:
     ds, rate, *opt = spec.split(":")
     method = "msgc" if "msgc" in opt else ("sgdd" if "sgdd" in opt else "gcond")
