@@ -1166,14 +1166,13 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
   }
   if (part != 3) GS_FAIL(GS_ERR_ARG, "gs_gcond_stage_pge_forward_part: part must be 1, 2 or 3");
   float* adj = inference ? e->io.adj_syn : e->adj_raw;
-  hipLaunchKernelGGL(gs_pge_adj_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, e->e3, n, adj);
+  float* rn = inference ? e->rnorm_in : e->rnorm;
+  // structure + degrees in one launch, then the scaling pass of dense_gcn_norm (gs_dense_gcn_norm_fwd's two launches, bitwise)
+  hipLaunchKernelGGL(gs_pge_adj_deg_kernel, dim3(n), dim3(256), 0, s, e->e3, n, adj, rn);
+  hipLaunchKernelGGL(gs_pge_norm_scale_kernel, dim3(gs_cdiv(n2, 256)), dim3(256), 0, s, adj, rn, n, inference ? e->adj_norm_in : e->adj_norm);
   GS_LAUNCH_CHECK();
-  if (inference) {
-    GS_TRY(gs_dense_gcn_norm_fwd(adj, n, e->adj_norm_in, e->rnorm_in, stream));
-    e->fwd_cached = true;     // U, V, A1, E2, BN statistics and e3 of the current (X~, theta_PGE) are in place
-    return GS_OK;
-  }
-  return gs_dense_gcn_norm_fwd(adj, n, e->adj_norm, e->rnorm, stream);
+  if (inference) e->fwd_cached = true;     // U, V, A1, E2, BN statistics and e3 of the current (X~, theta_PGE) are in place
+  return GS_OK;
 }
 
 // adopt the last inference forward as this iteration's training forward (three small device copies)

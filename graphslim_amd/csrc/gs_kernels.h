@@ -806,6 +806,39 @@ __global__ void gs_pge_adj_kernel(const float* __restrict__ e3, int n, float* __
   adj[idx] = (r == c) ? 0.f : 1.f / (1.f + expf(-x));
 }
 
+// gs_pge_adj_kernel + the degree pass of dense_gcn_norm (gs_norm_deg_kernel, gs_core.hip) in one launch: block i writes row i of
+// the structure and r[i] = (1 + sum_j adj[i][j])^-1/2 — the same per-thread strided partial sums, wave sums and 4-term total as the
+// separate degree kernel, so r is bitwise the two-launch value (one dependent launch less on both PGE passes)
+__global__ __launch_bounds__(256) void gs_pge_adj_deg_kernel(const float* __restrict__ e3, int n, float* __restrict__ adj,
+                                                             float* __restrict__ r) {
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float x = 0.5f * (e3[(long)i * n + j] + e3[(long)j * n + i]);
+    const float a = (i == j) ? 0.f : 1.f / (1.f + expf(-x));
+    adj[(long)i * n + j] = a;
+    s += a;
+  }
+  __shared__ float red[4];
+  s = gs_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float deg = red[0] + red[1] + red[2] + red[3] + 1.0f;
+    const float ri = powf(deg, -0.5f);
+    r[i] = isinf(ri) ? 0.f : ri;
+  }
+}
+
+// A^ = diag(r) (adj + I) diag(r): the scaling pass of dense_gcn_norm (gs_norm_scale_kernel of gs_core.hip, same arithmetic)
+__global__ void gs_pge_norm_scale_kernel(const float* __restrict__ adj, const float* __restrict__ r, int n, float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * n) return;
+  const int i = (int)(idx / n), j = (int)(idx - (long)i * n);
+  const float m = adj[idx] + (i == j ? 1.f : 0.f);
+  out[idx] = r[i] * m * r[j];
+}
+
 // de3[r,c] = (g(r,c) + g(c,r)) / 2,  g = d_adj * a (1 - a) off the diagonal, 0 on it
 __global__ void gs_pge_adj_bwd_kernel(const float* __restrict__ d_adj, const float* __restrict__ adj, int n,
                                       float* __restrict__ de3) {

@@ -104,10 +104,17 @@ class Comm:
         """One RCCL communicator over the ranks of `group`; the current CUDA device is this rank's GPU."""
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         buf = C.create_string_buffer(128)
+        payload = None
         if rank == 0:
-            check(lib().gs_comm_unique_id(buf))
-        box = [buf.raw if rank == 0 else None]
+            try:      # a failure here (librccl not loadable) must still reach the broadcast: the other ranks are waiting in it
+                check(lib().gs_comm_unique_id(buf))
+                payload = buf.raw
+            except Exception as e:      # noqa: BLE001
+                payload = repr(e)
+        box = [payload]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if not isinstance(box[0], bytes):
+            raise RuntimeError(f"graphslim_amd: rank 0 could not create an RCCL unique id ({box[0]})")
         idb = C.create_string_buffer(box[0], 128)
         h = C.c_void_p()
         check(lib().gs_comm_create_rccl(idb, rank, world, C.byref(h)))
