@@ -128,7 +128,31 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
     const int need = B - below;
     if (tid == 0) s_hash[3] = 0;
     __syncthreads();
-    for (int i = i_lo; i < i_hi; ++i) {
+    // Each thread's slice of the pool is at most 128 indices for pools up to 32 768 (every BASELINE configuration): the class of each
+    // index — in front of the crossing bin / inside it — is then kept as two 128-bit masks in registers, so that the count and write
+    // passes below do not hash the pool again (the first form evaluated the 64-bit hash four times per index: 43 us of the 91 us the
+    // 18 000-node class of the ogbn-arxiv shape took, round-3 phase stamps).  Larger slices recompute.
+    const bool use_mask = per <= 128;
+    uint32_t m_below[4] = {0u, 0u, 0u, 0u}, m_in[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      uint32_t bb = 0u, bi = 0u;
+      for (int bit = 0; bit < 32; ++bit) {
+        const int i = i_lo + 32 * w + bit;
+        if (i >= i_hi) break;
+        const uint32_t key = gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i);
+        if ((key & kmask) == kpref) {
+          const int slot = atomicAdd(&s_hash[3], 1);
+          if (slot < 2048) { cand[2 * slot] = (int)key; cand[2 * slot + 1] = i; }
+          bi |= 1u << bit;
+        } else if ((key & kmask) < kpref) {
+          bb |= 1u << bit;
+        }
+      }
+      m_below[w] = bb;
+      m_in[w] = bi;
+    }
+    for (int i = i_lo + 128; i < i_hi; ++i) {      // (slices beyond 128 indices: candidates only, classes recomputed below)
       const uint32_t key = gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i);
       if ((key & kmask) == kpref) {
         const int slot = atomicAdd(&s_hash[3], 1);
@@ -148,6 +172,11 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
       take[a] = rank < need;
     }
     __syncthreads();
+    auto taken_in_bin = [&](int i) {
+      bool tk = false;
+      for (int q = 0; q < m; ++q) tk |= (cand[2 * q + 1] == i) && take[q];
+      return tk;
+    };
     int mine = 0, taken_total = 0;
     for (int pass = 0; pass < 2; ++pass) {          // count, then write in ascending pool order
       int base = 0;
@@ -155,17 +184,30 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
         base = block_excl_scan_256(mine, s_tmp, &taken_total);
         mine = 0;
       }
-      for (int i = i_lo; i < i_hi; ++i) {
-        const uint32_t key = gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i);
-        bool tk = false;
-        if ((key & kmask) == kpref) {
-          for (int q = 0; q < m; ++q) tk |= (cand[2 * q + 1] == i) && take[q];
-        } else {
-          tk = (key & kmask) < kpref;               // in front of the crossing bin (top 12 or 24 key bits compared as a number)
+      if (use_mask) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          uint32_t in_w = m_in[w], tk_w = m_below[w];
+          while (in_w) {                            // members of the crossing bin (few): look their decision up
+            const int bit = __builtin_ctz(in_w);
+            in_w &= in_w - 1u;
+            if (taken_in_bin(i_lo + 32 * w + bit)) tk_w |= 1u << bit;
+          }
+          while (tk_w) {                            // ascending bit order = ascending pool order
+            const int bit = __builtin_ctz(tk_w);
+            tk_w &= tk_w - 1u;
+            if (pass == 1 && base + mine < B) s_seed[base + mine] = i_lo + 32 * w + bit;
+            ++mine;
+          }
         }
-        if (tk) {
-          if (pass == 1 && base + mine < B) s_seed[base + mine] = i;
-          ++mine;
+      } else {
+        for (int i = i_lo; i < i_hi; ++i) {
+          const uint32_t key = gs_rand_u32(seed ^ 0x5eedull, step, (uint32_t)ckey, (uint32_t)i);
+          const bool tk = ((key & kmask) == kpref) ? taken_in_bin(i) : (key & kmask) < kpref;   // top 12 or 24 key bits compared as a number
+          if (tk) {
+            if (pass == 1 && base + mine < B) s_seed[base + mine] = i;
+            ++mine;
+          }
         }
       }
     }
@@ -251,21 +293,26 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
     off += cnt;
   }
   __syncthreads();
+  // The lists are filled and sorted in LDS (s_sel: Floyd's scratch is no longer needed) and written out once, coalesced.  The first
+  // form filled and insertion-sorted them in global memory: a dependent ~1 us round trip per move, 8 - 80 us per class depending on
+  // its longest list (round-3 phase stamps), the longest part of the kernel for small pools whose seeds share neighbours.
+  int* ledge = s_sel;
   for (int j = 0; j < k; ++j) {
     int lid = s_g[tid * GS_MAX_F + j];
     int pos = atomicAdd(&s_cnt[lid], 1);
-    tedge[pos] = tid * f1 + j;
+    ledge[pos] = tid * f1 + j;
   }
   __syncthreads();
-  __threadfence_block();
   for (int l = tid; l < n1; l += 256) {   // ascending edge-slot order -> deterministic summation order
-    int a = tptr[l], b = (l + 1 <= cap1) ? s_cnt[l] : a;   // s_cnt[l] == end of list l after the fill
+    const int a = l ? s_cnt[l - 1] : 0, b = s_cnt[l];      // after the fill the cursor of list l stands at its end = the start of list l + 1
     for (int i = a + 1; i < b; ++i) {
-      int x = tedge[i], q = i - 1;
-      while (q >= a && tedge[q] > x) { tedge[q + 1] = tedge[q]; --q; }
-      tedge[q + 1] = x;
+      int x = ledge[i], q = i - 1;
+      while (q >= a && ledge[q] > x) { ledge[q + 1] = ledge[q]; --q; }
+      ledge[q + 1] = x;
     }
   }
+  __syncthreads();
+  for (int i = tid; i < tot; i += 256) tedge[i] = ledge[i];
   if (tid == 0) {
     blk.n_seed[c] = B;
     blk.n1[c] = n1;
