@@ -70,7 +70,7 @@ struct gs_panel_args {
 // issued before it — a full write round trip per tile (17-37 us of the 70 us the first build of this kernel spent outside its
 // K loop, tools/trace_panel.py).  So the bias row is parked in LDS before the K loop (LDS reads count on lgkmcnt, not vmcnt) and
 // the code is branch-free per (HAS_MASK, FULL) instantiation.
-template <int NTW, bool HAS_MASK, bool FULL, int BS = 1, bool ROWS = false>
+template <int NTW, bool HAS_MASK, bool FULL, int BS = 1, bool ROWS = false, bool BITS = false>
 __device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32x16 (&acc)[NTW], const float* sbias, int m0,
                                                int row_in_tile, int col0, float (&cs1)[NTW], float (&cs2)[NTW]) {
   const float floor_ = p.relu ? 0.f : -__builtin_inff();
@@ -113,7 +113,9 @@ __device__ __forceinline__ void panel_epilogue(const gs_panel_args& p, const f32
         s2 = fmaf(v[r], v[r], s2);
       }
     }
-    if (p.bits) {      // (tile-uniform) sign bits: one ballot per accumulator register = 32 columns of two rows (the two half-waves)
+    // (BITS is a compile-time form of its own: as a run-time test this block put a branch between the stores of two tiles and the
+    // plain products' epilogues got 10 us slower and 9 % dirtier in WRITE_SIZE / FETCH_SIZE — round-3 PMC diff)
+    if constexpr (BITS) {      // sign bits: one ballot per accumulator register = 32 columns of two rows (the two half-waves)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned long long m = __ballot(v[r] > 0.f);
@@ -268,7 +270,8 @@ __device__ __forceinline__ void panel_transform_a(const gs_panel_args& p, f32x4 
 // launch runs in these: 206 116 rows are 1 611 tiles of 128 rows on 512 workgroup slots = 3.15 rounds, and the 75 tiles of the
 // fourth round kept 75 CUs busy for a whole solo tile (43 us of 258) while 181 CUs idled; as 300 tiles of a quarter of the
 // work they take one short round on every CU.  Same arithmetic per output element either way (same k order).
-template <int MODE, int NT, int WN, bool MARG = false, bool AGEN = false, bool MGEN = false, bool FGEN = false, bool RIDX = false>
+template <int MODE, int NT, int WN, bool MARG = false, bool AGEN = false, bool MGEN = false, bool FGEN = false, bool RIDX = false,
+          bool BITS = false>
 __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, int m0, int stat_row) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128, NTW = NT / WN, ROWS = 128 / WN;
   static_assert(!MARG || WN == 1, "the fused-marginals form uses 128-row tiles");
@@ -547,14 +550,14 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   const bool full = m0 + ROWS <= p.M;
   float cs1[NTW], cs2[NTW];
   if constexpr (RIDX) {
-    if (full) panel_epilogue<NTW, false, true, BS, true>(p, acc, sbias, m0, rit, col0, cs1, cs2);
-    else panel_epilogue<NTW, false, false, BS, true>(p, acc, sbias, m0, rit, col0, cs1, cs2);
-  } else if (p.mask) {
+    if (full) panel_epilogue<NTW, false, true, BS, true, BITS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+    else panel_epilogue<NTW, false, false, BS, true, BITS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+  } else if (!BITS && p.mask) {
     if (full) panel_epilogue<NTW, true, true, BS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
     else panel_epilogue<NTW, true, false, BS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
   } else {
-    if (full) panel_epilogue<NTW, false, true, BS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
-    else panel_epilogue<NTW, false, false, BS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+    if (full) panel_epilogue<NTW, false, true, BS, false, BITS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
+    else panel_epilogue<NTW, false, false, BS, false, BITS>(p, acc, sbias, m0, rit, col0, cs1, cs2);
   }
   if (has_stat) {
     // per-tile column sums / sums of squares of the written rows: colstat[(stat_row * 2 + q) * N + col]
@@ -590,20 +593,20 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
   }
 }
 
-template <int MODE, int NT>     // NT = output columns / 32: 8 (N = 256) or 4 (N = 128, the Planetoid PGE width)
+template <int MODE, int NT, bool BITS = false>     // NT = output columns / 32: 8 (N = 256) or 4 (N = 128, the Planetoid PGE width)
 __global__ __launch_bounds__(256, 2) void gs_panel_gemm_kernel(gs_panel_args p) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;   // bytes of one K block of B in LDS: N rows x 128 B
   // (ONE __shared__ object: a second one beside a direct-to-LDS staging array can make hipcc drain vmcnt before every
   // ds_read, cdna_hip_programming.md section 5 "three .s-level traps" (a)) — the bias row lives behind the two B stages
   __shared__ __attribute__((aligned(16))) char smem[MODE == 3 ? 3 * PN_N * 96 + 8192 : 2 * PN_STAGE + PN_N * 4];
   const int b = blockIdx.x;
-  if (b < p.n_full) panel_tile<MODE, NT, 1>(p, smem, b * PN_BM, b);
-  else panel_tile<MODE, NT, 4>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
+  if (b < p.n_full) panel_tile<MODE, NT, 1, false, false, false, false, false, BITS>(p, smem, b * PN_BM, b);
+  else panel_tile<MODE, NT, 4, false, false, false, false, false, BITS>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
 }
 
 // row-list form: C[rowidx[i]] = A[rowidx[i]] B^T (+ bias)(relu) for i < *m_dev; the grid is sized for the largest possible count and
 // the tiles beyond the device-side count leave at once (128-row tiles throughout: the count is not known when the grid is sized)
-template <int MODE, int NT>
+template <int MODE, int NT, bool BITS = false>
 __global__ __launch_bounds__(256, 2) void gs_panel_rows_kernel(gs_panel_args pin) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;
   __shared__ __attribute__((aligned(16))) char smem[MODE == 3 ? 3 * PN_N * 96 + 8192 : 2 * PN_STAGE + PN_N * 4];
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void gs_panel_rows_kernel(gs_panel_args pin
   p.M = min(*pin.m_dev, pin.M);
   const int m0 = blockIdx.x * PN_BM;
   if (m0 >= p.M) return;
-  panel_tile<MODE, NT, 1, false, false, false, false, true>(p, smem, m0, blockIdx.x);
+  panel_tile<MODE, NT, 1, false, false, false, false, true, BITS>(p, smem, m0, blockIdx.x);
 }
 
 template <int MODE, int NT, bool AGEN, bool MGEN>
@@ -745,6 +748,15 @@ static void panel_dispatch(const gs_gemm_desc& d, gs_panel_args& a, hipStream_t 
   a.n_full = nf;
   const dim3 grid(nf + nn), block(256);
   a.ldb_bytes = panel_prepare_b(d.B, d.sBn, d.N, d.K, d.prec, d.scratch, s, &a.B);
+  if constexpr (NT == 8) {
+    if (a.bits) {      // the sign-bit epilogue is a form of its own (N = 256, no mask: gs_panel_launch checks)
+      if (d.prec == 0) hipLaunchKernelGGL((gs_panel_gemm_kernel<0, NT, true>), grid, block, 0, s, a);
+      else if (d.prec == 1) hipLaunchKernelGGL((gs_panel_gemm_kernel<1, NT, true>), grid, block, 0, s, a);
+      else if (d.prec == 2) hipLaunchKernelGGL((gs_panel_gemm_kernel<2, NT, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((gs_panel_gemm_kernel<3, NT, true>), grid, block, 0, s, a);
+      return;
+    }
+  }
   if (d.prec == 0) hipLaunchKernelGGL((gs_panel_gemm_kernel<0, NT>), grid, block, 0, s, a);
   else if (d.prec == 1) hipLaunchKernelGGL((gs_panel_gemm_kernel<1, NT>), grid, block, 0, s, a);
   else if (d.prec == 2) hipLaunchKernelGGL((gs_panel_gemm_kernel<2, NT>), grid, block, 0, s, a);
@@ -758,6 +770,7 @@ int gs_panel_launch(const gs_gemm_desc& d, hipStream_t s) {
   a.C = d.C; a.ldc = d.ldc;
   a.M = d.M; a.K = d.K;
   a.bias = d.bias; a.relu = d.relu; a.mask = d.mask; a.ldmask = d.ldmask; a.colstat = d.colstat;
+  if (d.signbits && (d.N != 256 || d.mask)) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gemm_f32: signbits needs N = 256 and no mask");
   a.bits = d.signbits; a.ldbits = d.ld_signbits;
   a.krep = g_panel_krep; a.triage = g_panel_triage;
   a.trace = (g_panel_triage & 2) ? (unsigned long long*)d.scratch : nullptr;   // (trace runs use prec = 0: scratch is free)
@@ -783,10 +796,12 @@ int gs_panel_rows(const float* A, long lda, const float* W, long ldw, const floa
   a.n_full = gs_cdiv(m_max, PN_BM);
   const dim3 grid(a.n_full), block(256);
   a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);
-#define GS_ROWS_LAUNCH(MODE_)                                                                 \
-  do {                                                                                        \
-    if (N == 256) hipLaunchKernelGGL((gs_panel_rows_kernel<MODE_, 8>), grid, block, 0, s, a); \
-    else hipLaunchKernelGGL((gs_panel_rows_kernel<MODE_, 4>), grid, block, 0, s, a);          \
+  if (bits && N != 256) return GS_ERR_UNSUPPORTED;
+#define GS_ROWS_LAUNCH(MODE_)                                                                                  \
+  do {                                                                                                         \
+    if (N == 256 && bits) hipLaunchKernelGGL((gs_panel_rows_kernel<MODE_, 8, true>), grid, block, 0, s, a);    \
+    else if (N == 256) hipLaunchKernelGGL((gs_panel_rows_kernel<MODE_, 8>), grid, block, 0, s, a);             \
+    else hipLaunchKernelGGL((gs_panel_rows_kernel<MODE_, 4>), grid, block, 0, s, a);                           \
   } while (0)
   if (prec == 0) GS_ROWS_LAUNCH(0);
   else if (prec == 1) GS_ROWS_LAUNCH(1);
