@@ -50,6 +50,9 @@ class GCondIO(C.Structure):
                 ("model_params", vp), ("adj_syn", vp), ("workspace", vp), ("workspace_bytes", C.c_size_t)]
 
 
+# measurement knobs / debug hooks declared in include/gslim_internal.h (not product ABI)
+INTERNAL_SYMBOLS = ["gs_gemm_set_panel_tall", "gs_panel_tall_debug"]
+
 _lib = None
 
 # every symbol include/gslim.h declares (tests/test_abi.py checks the list against the header)
@@ -103,6 +106,8 @@ def lib():
     L.gs_gemm_set_panel_marg.argtypes = [i]
     L.gs_gemm_set_panel_a1gen.argtypes = [i]
     L.gs_panel_debug.argtypes = [i, i]
+    L.gs_gemm_set_panel_tall.argtypes = [i]
+    L.gs_panel_tall_debug.argtypes = [i, i, i]
     L.gs_reduce_slabs_f32.argtypes = [vp, vp, l, i, l, f, vp]
     L.gs_reduce_slabs_batched_f32.argtypes = [vp, l, vp, l, i, l, i, f, vp]
     L.gs_spmm_csr_f32.argtypes = [vp, vp, vp, i, vp, l, i, vp, l, vp]

@@ -17,7 +17,7 @@ int gs_panel_marginals(const float*, long, const float*, long, const float*, lon
                        const gs_panel_gen*, const gs_panel_a1*, hipStream_t);
 int gs_dw1_generated(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*,
                      float*, long, int*, hipStream_t);
-int gs_panel_forward_a1(const gs_panel_a1*, int, int, const float*, long, const float*, float*, long, int, int, float*, int, void*,
+int gs_panel_forward_a1(const gs_panel_a1*, int, int, const float*, long, const float*, float*, long, int, int, float*, int*, int, void*,
                         unsigned long long*, hipStream_t);
 int gs_panel_tiles(int);
 struct gs_zg_args {
@@ -1116,10 +1116,10 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       e->a1_valid = false;
       int tiles = 0;
       if (probe) GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s));
-      const int rc = gs_panel_forward_a1(&a1, n, nr, pp + e->pW1, Ph, pp + e->pb1, e->E2, Ph, Ph, Ph, e->statp, e->operand_mode,
+      const int rc = gs_panel_forward_a1(&a1, n, nr, pp + e->pW1, Ph, pp + e->pb1, e->E2, Ph, Ph, Ph, e->statp, &tiles, e->operand_mode,
                                          e->bsplit_main, probe ? e->probe_span + 2 * e->probe_n : nullptr, s);
       if (rc == GS_OK) {
-        tiles = gs_panel_tiles((int)rows);
+        // (tiles = the number of [2][Ph] partial-sum slabs the kernel wrote: one per 128-row tile, or one per workgroup — gs_panel2.hip)
       } else if (rc != GS_ERR_UNSUPPORTED) {
         return rc;
       } else {
@@ -2263,6 +2263,8 @@ extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* 
       {"ar_bn2", e->sums, 2 * Ph},         {"ar_l3", e->sums, 3 * Ph},          {"ar_syn", e->ar_syn, n * e->d + n * n + C},
       {"ar_marg", e->ar_marg, 2 * n * Ph}, {"ar_w1", e->d_pge + e->pW1, Ph * Ph + Ph},
       {"ar_gw_real", e->gw_real, C * e->P},  {"H1bits", e->H1bits, e->H1bits ? (long)e->N * (e->h / 32) : 0},
+      // PGE layer-2 pre-activations of this rank's pair rows and the BatchNorm-2 batch statistics (kernel A/B tests)
+      {"E2", e->E2, (long)(e->r_hi - e->r_lo) * n * Ph}, {"mu2", e->mu2, Ph}, {"is2", e->is2, Ph},
   };
   for (auto& t : tab)
     if (!strcmp(t.k, name)) {

@@ -686,6 +686,15 @@ static long panel_prepare_b(const float* W, long ldw, int N, int K, int prec, vo
   return (long)K * 4;
 }
 
+// the tall (256-row, persistent) form of the exact-split products at N = 256: gs_panel2.hip
+int gs_tall_plain(const float* A, long lda, const void* Bimg, long ldb_bytes, const float* bias, int relu, float* C, long ldc, long c_rows,
+                  int M, int K, const int* rowidx, const int* m_dev, long a_rows, hipStream_t s);
+int gs_tall_forward_a1(const float* U, const float* V, long ld, const float* table, int n, int nr, const void* Bimg, long ldb_bytes,
+                       const float* bias, float* C, long ldc, int K, float* colstat, int* stat_slabs, unsigned long long* span,
+                       hipStream_t s);
+int gs_tall_marginals(const float* E2, const void* Bimg, long ldb_bytes, const float* gen_table, const float* de3, const float* U,
+                      const float* V, long ld, const float* a1_table, int n, int nr, int K, float* partU, float* partV, hipStream_t s);
+
 static int g_panel_krep = 1, g_panel_triage = 0;
 extern "C" int gs_panel_debug(int krep, int triage) {      // measurement hook (tools/ab_panel.py), not part of the product ABI
   g_panel_krep = krep < 1 ? 1 : krep;
@@ -749,6 +758,9 @@ static void panel_dispatch(const gs_gemm_desc& d, gs_panel_args& a, hipStream_t 
   const dim3 grid(nf + nn), block(256);
   a.ldb_bytes = panel_prepare_b(d.B, d.sBn, d.N, d.K, d.prec, d.scratch, s, &a.B);
   if constexpr (NT == 8) {
+    if (d.prec == 3 && !a.bits && !a.mask && !a.colstat && g_panel_krep == 1 && !g_panel_triage &&
+        gs_tall_plain(a.A, a.lda, a.B, a.ldb_bytes, a.bias, a.relu, a.C, a.ldc, a.M, a.M, a.K, nullptr, nullptr, a.M, s) == GS_OK)
+      return;
     if (a.bits) {      // the sign-bit epilogue is a form of its own (N = 256, no mask: gs_panel_launch checks)
       if (d.prec == 0) hipLaunchKernelGGL((gs_panel_gemm_kernel<0, NT, true>), grid, block, 0, s, a);
       else if (d.prec == 1) hipLaunchKernelGGL((gs_panel_gemm_kernel<1, NT, true>), grid, block, 0, s, a);
@@ -797,6 +809,9 @@ int gs_panel_rows(const float* A, long lda, const float* W, long ldw, const floa
   const dim3 grid(a.n_full), block(256);
   a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);
   if (bits && N != 256) return GS_ERR_UNSUPPORTED;
+  if (prec == 3 && N == 256 && !bits &&
+      gs_tall_plain(A, lda, a.B, a.ldb_bytes, bias, relu, Cout, ldc, rows_total, m_max, K, rowidx, m_dev, rows_total, s) == GS_OK)
+    return GS_OK;
 #define GS_ROWS_LAUNCH(MODE_)                                                                                  \
   do {                                                                                                         \
     if (N == 256 && bits) hipLaunchKernelGGL((gs_panel_rows_kernel<MODE_, 8, true>), grid, block, 0, s, a);    \
@@ -843,7 +858,7 @@ extern "C" int gs_gemm_set_panel_a1gen(int on) {
 // gs_gemm_desc.colstat ([gs_panel_tiles(nr * n)][2][N]).  GS_ERR_UNSUPPORTED when the shape is not covered (the caller then
 // materialises A1 and takes the plain product).
 int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, long ldw, const float* bias, float* C, long ldc, int N,
-                        int K, float* colstat, int prec, void* scratch, unsigned long long* span, hipStream_t s) {
+                        int K, float* colstat, int* stat_slabs, int prec, void* scratch, unsigned long long* span, hipStream_t s) {
   if (!g_panel_a1gen || !g_panel_enabled || !a1 || !a1->table || n < 128 || nr < 1) return GS_ERR_UNSUPPORTED;   // (<= 2 r per tile)
   if ((N != 256 && N != 128) || K < 32 || K > 256 || (K & 31) || (ldw & 3) || (a1->ld & 3)) return GS_ERR_UNSUPPORTED;
   if ((double)nr * n * (double)ldc >= 4294967296.0 || (prec != 0 && !scratch) || prec < 0 || prec > 3) return GS_ERR_UNSUPPORTED;
@@ -860,6 +875,10 @@ int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, lo
   a.n_full = nf;
   const dim3 grid(nf + nn), block(256);
   a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);
+  if (stat_slabs) *stat_slabs = nf + nn;
+  if (prec == 3 && N == 256 && g_panel_krep == 1 && !a.triage &&
+      gs_tall_forward_a1(a1->U, a1->V, a1->ld, a1->table, n, nr, a.B, a.ldb_bytes, bias, C, ldc, K, colstat, stat_slabs, span, s) == GS_OK)
+    return GS_OK;
 #define GS_FWD_LAUNCH(MODE_)                                                                    \
   do {                                                                                          \
     if (N == 256) hipLaunchKernelGGL((gs_panel_fwdgen_kernel<MODE_, 8>), grid, block, 0, s, a); \
@@ -903,6 +922,9 @@ int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, con
   }
   const dim3 grid((unsigned)(gs_cdiv(nr, 16) * a.mg_ncb)), block(256);
   a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);
+  if (prec == 3 && N == 256 && gen && a1 && lda == K &&
+      gs_tall_marginals(dE2, a.B, a.ldb_bytes, a.gen_c, a.gen_d, a1->U, a1->V, a1->ld, a1->table, n, nr, K, partU, partV, s) == GS_OK)
+    return GS_OK;
 #define GS_MARG_LAUNCH(MODE_)                                                                                        \
   do {                                                                                                               \
     if (N == 256 && gen && a1) hipLaunchKernelGGL((gs_panel_marg_kernel<MODE_, 8, (MODE_ == 0 || MODE_ == 3), true>), grid, block, 0, s, a); \

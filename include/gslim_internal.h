@@ -1,0 +1,19 @@
+/* Measurement knobs and debug hooks of libgslim_hip.so — NOT part of the product ABI (include/gslim.h).  They are process-global,
+   not thread-safe, and exist for the A/B tools under tools/ and the bitwise form-against-form tests; a product build may drop them. */
+#ifndef GSLIM_INTERNAL_H
+#define GSLIM_INTERNAL_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* exact-split products at N = 256 on the persistent 256-row kernel of csrc/gs_panel2.hip (default 1); 0 = the 128-row kernels of
+   csrc/gs_panel.hip everywhere (bitwise the same products; BN-2 partial sums grouped per tile instead of per workgroup) */
+int gs_gemm_set_panel_tall(int on);
+/* csrc/gs_panel2.hip: workgroups per launch (0 = one per compute unit), K loop of every tile repeated krep times, triage bits
+   (results are garbage): 1 no epilogue, 2 no A staging, 4 no B staging, 8 no waits / barriers, 16 no MFMAs, 32 no operand split */
+int gs_panel_tall_debug(int grid, int krep, int triage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
