@@ -51,7 +51,7 @@ class GCondIO(C.Structure):
 
 
 # measurement knobs / debug hooks declared in include/gslim_internal.h (not product ABI)
-INTERNAL_SYMBOLS = ["gs_gemm_set_panel_tall", "gs_panel_tall_debug"]
+INTERNAL_SYMBOLS = ["gs_gemm_set_panel_tall", "gs_panel_tall_debug", "gs_panel_tall_trace"]
 
 _lib = None
 
@@ -108,6 +108,7 @@ def lib():
     L.gs_panel_debug.argtypes = [i, i]
     L.gs_gemm_set_panel_tall.argtypes = [i]
     L.gs_panel_tall_debug.argtypes = [i, i, i]
+    L.gs_panel_tall_trace.argtypes = [C.c_void_p]
     L.gs_reduce_slabs_f32.argtypes = [vp, vp, l, i, l, f, vp]
     L.gs_reduce_slabs_batched_f32.argtypes = [vp, l, vp, l, i, l, i, f, vp]
     L.gs_spmm_csr_f32.argtypes = [vp, vp, vp, i, vp, l, i, vp, l, vp]

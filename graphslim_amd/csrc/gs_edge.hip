@@ -477,14 +477,23 @@ __global__ void gs_pge_scale_uv_kernel(const float* __restrict__ U, const float*
 
 // engine-internal (gs_engine.hip): slabs must hold nsplit * (65536 + 256) floats, uv 2 n' 256 floats; *nsplit_out = slabs written.
 // GS_ERR_UNSUPPORTED when the shape is not covered (the caller then materialises both operands).
+// engine-internal: Us, Vs of the current (U, V, BatchNorm-1 statistics) — see gs_pge_scale_uv_kernel
+int gs_pge_scale_uv(const float* U, const float* V, const float* a1_tab, long total, int Ph, float* Us, float* Vs, hipStream_t s) {
+  hipLaunchKernelGGL(gs_pge_scale_uv_kernel, dim3(gs_cdiv(total, 256)), dim3(256), 0, s, U, V, a1_tab, total, Ph, Us, Vs);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// (uv_ready: [2][n][Ph] Us | Vs already computed by the forward — then `uv` is not written)
 int gs_dw1_generated(const float* E2, const float* de3, const float* gen_tab, const float* U, const float* V, const float* a1_tab,
                      int n, int r_lo, int nr, int Ph, int prec, float* uv, float* slabs, long slabs_cap, int* nsplit_out,
-                     hipStream_t s) {
+                     const float* uv_ready, hipStream_t s) {
   if (!g_edge_enabled || Ph != 256 || n < 16 || nr < 1 || prec < 0 || prec > 3) return GS_ERR_UNSUPPORTED;
   if (((uintptr_t)E2 | (uintptr_t)uv | (uintptr_t)gen_tab) & 15) return GS_ERR_UNSUPPORTED;
   gs_dw1_args a;
   a.E2 = E2; a.lde = Ph; a.de3 = de3; a.tab = gen_tab;
-  a.Us = uv; a.Vs = uv + (long)n * Ph + (long)r_lo * Ph;
+  const float* uvp = uv_ready ? uv_ready : uv;
+  a.Us = uvp; a.Vs = uvp + (long)n * Ph + (long)r_lo * Ph;
   a.n = n; a.spr = gs_cdiv(n, EG_BK); a.stages = nr * a.spr;
   // 512 workgroup slots (2 per CU) = 256 slabs x 2 halves; short sums (a rank's shard): at least 16 steps per slab
   int nsplit = a.stages >= 256 * 16 ? 256 : gs_cdiv(a.stages, 16);
@@ -494,7 +503,7 @@ int gs_dw1_generated(const float* E2, const float* de3, const float* gen_tab, co
   if ((long)nsplit * a.sOs > slabs_cap) return GS_ERR_UNSUPPORTED;
   a.out = slabs;
   const long total = (long)n * Ph;
-  hipLaunchKernelGGL(gs_pge_scale_uv_kernel, dim3(gs_cdiv(total, 256)), dim3(256), 0, s, U, V, a1_tab, total, Ph, uv, uv + total);
+  if (!uv_ready) hipLaunchKernelGGL(gs_pge_scale_uv_kernel, dim3(gs_cdiv(total, 256)), dim3(256), 0, s, U, V, a1_tab, total, Ph, uv, uv + total);
   const dim3 grid(nsplit, 1, 2), block(256);
   if (prec == 0) hipLaunchKernelGGL((gs_dw1_gen_kernel<0>), grid, block, 0, s, a);
   else if (prec == 1) hipLaunchKernelGGL((gs_dw1_gen_kernel<1>), grid, block, 0, s, a);

@@ -12,13 +12,14 @@ extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int
 extern "C" int gs_reduce_slabs_f32(float*, const float*, long, int, long, float, gs_stream_t);
 int gs_reduce_slabs_active(float*, long, const float*, long, int, long, int, const int*, int, gs_stream_t);
 struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; int table_ready; };
-struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; };
+struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; const float *Us, *Vs; };
 int gs_panel_marginals(const float*, long, const float*, long, const float*, long, int, int, int, int, float*, float*, int, void*,
                        const gs_panel_gen*, const gs_panel_a1*, hipStream_t);
 int gs_dw1_generated(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*,
-                     float*, long, int*, hipStream_t);
+                     float*, long, int*, const float*, hipStream_t);
+int gs_pge_scale_uv(const float*, const float*, const float*, long, int, float*, float*, hipStream_t);
 int gs_panel_forward_a1(const gs_panel_a1*, int, int, const float*, long, const float*, float*, long, int, int, float*, int*, int, void*,
-                        unsigned long long*, hipStream_t);
+                        unsigned long long*, int, hipStream_t);
 int gs_panel_tiles(int);
 struct gs_zg_args {
   const float* A; long sAm, sAk; const float* B; long sBk, sBn; int n, K, C; const float* rs; const float* bias;
@@ -142,6 +143,8 @@ struct gs_gcond {
   long og, obeta, P_base;            // offsets of bn.weight / bn.bias inside theta; parameter count without them
   float *theta_eff, *bn_s2;          // [P], [h]: s_j^2 for the distance statistics of the W1 gradient columns
   float* a1_tab;                     // [Ph][8] layer-0 bias / BatchNorm-1 constants of the generated A1 operand and mask (gs_panel.hip)
+  float* UsVs;                       // [2][n][Ph] folded layer-1 terms Us = s U + t, Vs = s V of the CURRENT forward (gs_pge_scale_uv): A1 = max(Us[c] + Vs[r], 0)
+  bool uvs_valid;
   bool a1_valid;                     // A1 holds the activations of the current U, V (false: the forward formed them in registers only)
   float* gen_tab;                    // [Ph][8] folded BatchNorm-2 / layer-3 constants of the generated dE2 operand (gs_panel.hip)
   // block structure (gs_gcond_set_block_structure): the synthetic graph is `blk_B` disconnected blocks of `blk_n` rows each
@@ -285,6 +288,8 @@ static size_t carve(gs_gcond* e, void* base) {
   e->bn_s2 = e->with_bn ? w.take<float>(h) : nullptr;
   e->gen_tab = w.take<float>(Ph * 8);
   e->a1_tab = w.take<float>(Ph * 8);
+  e->UsVs = w.take<float>(2 * n * Ph);
+  e->uvs_valid = false;
   e->a1_valid = false;
   e->bn2_slices = e->l3_slices = 1;
   e->chunk_fwd = w.take<float>((long)e->pge_chunks * 4 * Ph); e->chunk_bwd = w.take<float>((long)e->pge_chunks * 5 * Ph);
@@ -1061,7 +1066,8 @@ static int pge_backward_chunked(gs_gcond* e, int need_param_grads, gs_stream_t s
 // the layer-1 activations as a function of U, V (this rank's pair rows start at r_lo) — see gs_panel_a1 in gs_panel.hip
 static gs_panel_a1 pge_a1(const gs_gcond* e) {
   const float* pp = e->io.pge_params;
-  return gs_panel_a1{e->U, e->V + (long)e->r_lo * e->Ph, (long)e->Ph, pp + e->pb0, e->mu1, e->is1, pp + e->pg1, pp + e->pbe1, e->a1_tab};
+  return gs_panel_a1{e->U, e->V + (long)e->r_lo * e->Ph, (long)e->Ph, pp + e->pb0, e->mu1, e->is1, pp + e->pg1, pp + e->pbe1, e->a1_tab,
+                     e->uvs_valid ? e->UsVs : nullptr, e->uvs_valid ? e->UsVs + (long)e->n * e->Ph + (long)e->r_lo * e->Ph : nullptr};
 }
 
 // materialise A1 of the current U, V for this rank's pair rows if the forward did not (products that read it as an operand)
@@ -1103,6 +1109,13 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
     hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 32)), dim3(1024), 0, s, e->U, e->V, pp + e->pb0, n, Ph, e->mu1,
                        e->is1, e->sumU, e->sumV, pp + e->pg1, pp + e->pbe1, e->a1_tab);   // (+ the table of the generated A1)
     GS_LAUNCH_CHECK();
+    // the folded layer-1 terms of this forward (exact-split kernels of gs_panel2.hip and gs_dw1_generated: forward operand, backward
+    // mask and dW1 operand are then the SAME function max(Us[c] + Vs[r], 0) of the same bits)
+    e->uvs_valid = false;
+    if (e->operand_mode == 3 && Ph == 256 && n >= 128) {
+      GS_TRY(gs_pge_scale_uv(e->U, e->V, e->a1_tab, (long)n * Ph, Ph, e->UsVs, e->UsVs + (long)n * Ph, s));
+      e->uvs_valid = true;
+    }
     if (rows > 0) {
       // E2 = A1 W1^T + b1.  Preferred: A1 is formed in the product's operand path from U, V (gs_panel_forward_a1) and is not
       // written — feature epochs never read it (the backward regenerates the [A1 > 0] mask the same way); PGE epochs
@@ -1117,7 +1130,7 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       int tiles = 0;
       if (probe) GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s));
       const int rc = gs_panel_forward_a1(&a1, n, nr, pp + e->pW1, Ph, pp + e->pb1, e->E2, Ph, Ph, Ph, e->statp, &tiles, e->operand_mode,
-                                         e->bsplit_main, probe ? e->probe_span + 2 * e->probe_n : nullptr, s);
+                                         e->bsplit_main, probe ? e->probe_span + 2 * e->probe_n : nullptr, inference, s);
       if (rc == GS_OK) {
         // (tiles = the number of [2][Ph] partial-sum slabs the kernel wrote: one per 128-row tile, or one per workgroup — gs_panel2.hip)
       } else if (rc != GS_ERR_UNSUPPORTED) {
@@ -1645,7 +1658,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
         float* slabs = e->dE2 + 2L * n * Ph;
         int nsplit = 0;
         const int rc = gs_dw1_generated(e->E2, de3l, e->gen_tab, e->U, e->V, e->a1_tab, n, e->r_lo, nr, Ph, e->operand_mode, uv, slabs,
-                                        n2 * Ph - 2L * n * Ph, &nsplit, s);
+                                        n2 * Ph - 2L * n * Ph, &nsplit, e->uvs_valid ? e->UsVs : nullptr, s);
         if (rc == GS_OK) {
           GS_TRY(gs_reduce_slabs_f32(g + e->pW1, slabs, (long)Ph * Ph + Ph, nsplit, 65536 + 256, 0.f, stream));   // dW1 | db1
           return GS_OK;

@@ -54,6 +54,7 @@ struct gs_panel_args {
   // [A1 > 0] mask of the fused-marginals epilogue is recomputed from them (mask is not read).
   const float* a1_U; const float* a1_V; long a1_ld;     // U [n][ld], V already offset to this rank's first pair row r
   const float* a1_c;                 // [Ph][8]: per column {b0, mu1, is1, g1, be1, 0, 0, 0}
+  int a1_fold;                       // MGEN: a1_U / a1_V hold the folded terms Us, Vs (gs_pge_scale_uv_kernel)
   // row-list form (gs_panel_rows_kernel): row i of the product reads A[rowidx[i]] and writes C[rowidx[i]]; the row count is read
   // on the device (*m_dev, <= the M the grid was sized for) — the rows of H1 = relu(X W1 + b1) a rank's sampled blocks gather
   const int* rowidx; const int* m_dev;
@@ -187,7 +188,9 @@ __device__ __forceinline__ void panel_epilogue_marg(const gs_panel_args& p, cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) {       // register r: r index (r >> 2) of the wave's 4, c index (r & 3) of the half-wave's 4
         const float x = ((uc[r & 3] + vc[r >> 2]) + c0[0]) - c0[1];
-        v[r] = (ok[r] && fmaf(c0[3], x * c0[2], c1[0]) > 0.f) ? acc[j][r] : 0.f;
+        // (a1_fold: a1_U / a1_V are the folded terms Us, Vs and the activation is max(Us[c] + Vs[r], 0) — the forward's form)
+        const bool pos = p.a1_fold ? uc[r & 3] + vc[r >> 2] > 0.f : fmaf(c0[3], x * c0[2], c1[0]) > 0.f;
+        v[r] = (ok[r] && pos) ? acc[j][r] : 0.f;
       }
     } else {
       float mk[16];
@@ -225,7 +228,7 @@ __device__ __forceinline__ void panel_epilogue_marg(const gs_panel_args& p, cons
 // lgkmcnt(0), in front of the block's MFMAs (round-3 ISA reading; the product ran at 3x its MFMA floor).  Same values: same
 // operations in the same order per element.
 #define GS_TAB_K 256
-template <bool AGEN, bool FGEN, bool VTAB = false>
+template <bool AGEN, bool FGEN, bool VTAB = false, bool FOLD = false>
 __device__ __forceinline__ void panel_transform_a(const gs_panel_args& p, f32x4 (&a)[4], const float* __restrict__ tab,
                                                   const float* __restrict__ vs, float gen_d, int rsel, int kb, int h) {
   const int k0 = 32 * kb + 16 * h;
@@ -258,8 +261,12 @@ __device__ __forceinline__ void panel_transform_a(const gs_panel_args& p, f32x4 
       else vv = *reinterpret_cast<const f32x4*>(vs + rsel * p.K + k0 + 4 * t4);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float x = ((a[t4][t] + vv[t]) + b0[t]) - mu1[t];
-        a[t4][t] = fmaxf(fmaf(g1[t], x * is1[t], be1[t]), 0.f);
+        if constexpr (FOLD) {      // a holds Us[c][k], vv = Vs[r][k] (gs_pge_scale_uv_kernel): the folded form every exact-split kernel uses
+          a[t4][t] = fmaxf(a[t4][t] + vv[t], 0.f);
+        } else {
+          const float x = ((a[t4][t] + vv[t]) + b0[t]) - mu1[t];
+          a[t4][t] = fmaxf(fmaf(g1[t], x * is1[t], be1[t]), 0.f);
+        }
       }
     }
   }
@@ -271,7 +278,7 @@ __device__ __forceinline__ void panel_transform_a(const gs_panel_args& p, f32x4 
 // fourth round kept 75 CUs busy for a whole solo tile (43 us of 258) while 181 CUs idled; as 300 tiles of a quarter of the
 // work they take one short round on every CU.  Same arithmetic per output element either way (same k order).
 template <int MODE, int NT, int WN, bool MARG = false, bool AGEN = false, bool MGEN = false, bool FGEN = false, bool RIDX = false,
-          bool BITS = false>
+          bool BITS = false, bool FOLD = false>
 __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, int m0, int stat_row) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128, NTW = NT / WN, ROWS = 128 / WN;
   static_assert(!MARG || WN == 1, "the fused-marginals form uses 128-row tiles");
@@ -434,7 +441,7 @@ __device__ __forceinline__ void panel_tile(const gs_panel_args& p, char* smem, i
         if (ss + 2 < nsb_run) load_a(((sb + 2) % nsb) >> 1, a_nxt);
       }
       if (ss + 2 < nsb_run && !(p.triage & 32)) stage_b3((sb + 2) % nsb, slot == 0 ? 2 : slot - 1);      // slot of ss + 2 = (slot + 2) % 3
-      if (u == 0) panel_transform_a<AGEN, FGEN, true>(p, a_cur, gc, vs, gen_d, rsel, kb, h);
+      if (u == 0) panel_transform_a<AGEN, FGEN, true, FOLD>(p, a_cur, gc, vs, gen_d, rsel, kb, h);
       if (!(p.triage & 16) || ss == 0)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -625,13 +632,13 @@ __global__ __launch_bounds__(256, 2) void gs_panel_marg_kernel(gs_panel_args p) 
 }
 
 // forward product with the generated A1 operand: E2 = A1(U, V) W1^T + b1 (+ BN-2 column sums); same tiling as gs_panel_gemm_kernel
-template <int MODE, int NT>
+template <int MODE, int NT, bool FOLD = false>
 __global__ __launch_bounds__(256, 2) void gs_panel_fwdgen_kernel(gs_panel_args p) {
   constexpr int PN_N = 32 * NT, PN_STAGE = PN_N * 128;
   __shared__ __attribute__((aligned(16))) char smem[MODE == 3 ? 3 * PN_N * 96 + 8192 : 2 * PN_STAGE + PN_N * 4 + 256 * 32 + 2 * 256 * 4];
   const int b = blockIdx.x;
-  if (b < p.n_full) panel_tile<MODE, NT, 1, false, false, false, true>(p, smem, b * PN_BM, b);
-  else panel_tile<MODE, NT, 4, false, false, false, true>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
+  if (b < p.n_full) panel_tile<MODE, NT, 1, false, false, false, true, false, false, FOLD>(p, smem, b * PN_BM, b);
+  else panel_tile<MODE, NT, 4, false, false, false, true, false, false, FOLD>(p, smem, p.n_full * PN_BM + (b - p.n_full) * 32, b);
 }
 
 // gen_c[k][8] from the BatchNorm-2 / layer-3 quantities (one thread per column)
@@ -689,11 +696,11 @@ static long panel_prepare_b(const float* W, long ldw, int N, int K, int prec, vo
 // the tall (256-row, persistent) form of the exact-split products at N = 256: gs_panel2.hip
 int gs_tall_plain(const float* A, long lda, const void* Bimg, long ldb_bytes, const float* bias, int relu, float* C, long ldc, long c_rows,
                   int M, int K, const int* rowidx, const int* m_dev, long a_rows, hipStream_t s);
-int gs_tall_forward_a1(const float* U, const float* V, long ld, const float* table, int n, int nr, const void* Bimg, long ldb_bytes,
+int gs_tall_forward_a1(const float* Us, const float* Vs, long ld, int n, int nr, const void* Bimg, long ldb_bytes,
                        const float* bias, float* C, long ldc, int K, float* colstat, int* stat_slabs, unsigned long long* span,
-                       hipStream_t s);
-int gs_tall_marginals(const float* E2, const void* Bimg, long ldb_bytes, const float* gen_table, const float* de3, const float* U,
-                      const float* V, long ld, const float* a1_table, int n, int nr, int K, float* partU, float* partV, hipStream_t s);
+                       int alone, hipStream_t s);
+int gs_tall_marginals(const float* E2, const void* Bimg, long ldb_bytes, const float* gen_table, const float* de3, const float* Us,
+                      const float* Vs, long ld, int n, int nr, int K, float* partU, float* partV, hipStream_t s);
 
 static int g_panel_krep = 1, g_panel_triage = 0;
 extern "C" int gs_panel_debug(int krep, int triage) {      // measurement hook (tools/ab_panel.py), not part of the product ABI
@@ -845,7 +852,7 @@ struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3;
 // quantities (5 arrays of the hidden width) and the [width][8] float constants table {b0, mu1, is1, g1, be1, 0, 0, 0} per column,
 // which the CALLER fills (the engine's gs_pge_bn1_stats_kernel writes it next to mu1 / is1): with `a1` the marginals' [A1 > 0]
 // mask is recomputed from them (`mask` may be null), and gs_panel_forward_a1 forms the A operand of E2 = A1 W1^T + b1 from them.
-struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; };
+struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; const float *Us, *Vs; };      // Us, Vs: the folded terms (gs_pge_scale_uv_kernel) or null
 
 static int g_panel_a1gen = 1;
 // measurement knob: 0 = always materialise A1 (round-2 first form), 1 (default) = generate it in the operand / mask path
@@ -858,7 +865,8 @@ extern "C" int gs_gemm_set_panel_a1gen(int on) {
 // gs_gemm_desc.colstat ([gs_panel_tiles(nr * n)][2][N]).  GS_ERR_UNSUPPORTED when the shape is not covered (the caller then
 // materialises A1 and takes the plain product).
 int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, long ldw, const float* bias, float* C, long ldc, int N,
-                        int K, float* colstat, int* stat_slabs, int prec, void* scratch, unsigned long long* span, hipStream_t s) {
+                        int K, float* colstat, int* stat_slabs, int prec, void* scratch, unsigned long long* span, int alone,
+                        hipStream_t s) {
   if (!g_panel_a1gen || !g_panel_enabled || !a1 || !a1->table || n < 128 || nr < 1) return GS_ERR_UNSUPPORTED;   // (<= 2 r per tile)
   if ((N != 256 && N != 128) || K < 32 || K > 256 || (K & 31) || (ldw & 3) || (a1->ld & 3)) return GS_ERR_UNSUPPORTED;
   if ((double)nr * n * (double)ldc >= 4294967296.0 || (prec != 0 && !scratch) || prec < 0 || prec > 3) return GS_ERR_UNSUPPORTED;
@@ -877,8 +885,14 @@ int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, lo
   a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);
   if (stat_slabs) *stat_slabs = nf + nn;
   if (prec == 3 && N == 256 && g_panel_krep == 1 && !a.triage &&
-      gs_tall_forward_a1(a1->U, a1->V, a1->ld, a1->table, n, nr, a.B, a.ldb_bytes, bias, C, ldc, K, colstat, stat_slabs, span, s) == GS_OK)
+      gs_tall_forward_a1(a1->Us, a1->Vs, a1->ld, n, nr, a.B, a.ldb_bytes, bias, C, ldc, K, colstat, stat_slabs, span, alone, s) == GS_OK)
     return GS_OK;
+  if (prec == 3 && N == 256 && a1->Us && a1->Vs) {      // the folded form (what the 256-row kernels and gs_dw1_generated use): same bits everywhere
+    a.a1_U = a1->Us; a.a1_V = a1->Vs; a.A = a1->Us;
+    hipLaunchKernelGGL((gs_panel_fwdgen_kernel<3, 8, true>), grid, block, 0, s, a);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+  }
 #define GS_FWD_LAUNCH(MODE_)                                                                    \
   do {                                                                                          \
     if (N == 256) hipLaunchKernelGGL((gs_panel_fwdgen_kernel<MODE_, 8>), grid, block, 0, s, a); \
@@ -919,11 +933,12 @@ int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, con
   }
   if (a1) {
     a.a1_U = a1->U; a.a1_V = a1->V; a.a1_ld = a1->ld; a.a1_c = a1->table;
+    if (prec == 3 && N == 256 && a1->Us && a1->Vs) { a.a1_U = a1->Us; a.a1_V = a1->Vs; a.a1_fold = 1; }
   }
   const dim3 grid((unsigned)(gs_cdiv(nr, 16) * a.mg_ncb)), block(256);
   a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);
   if (prec == 3 && N == 256 && gen && a1 && lda == K &&
-      gs_tall_marginals(dE2, a.B, a.ldb_bytes, a.gen_c, a.gen_d, a1->U, a1->V, a1->ld, a1->table, n, nr, K, partU, partV, s) == GS_OK)
+      gs_tall_marginals(dE2, a.B, a.ldb_bytes, a.gen_c, a.gen_d, a1->Us, a1->Vs, a1->ld, n, nr, K, partU, partV, s) == GS_OK)
     return GS_OK;
 #define GS_MARG_LAUNCH(MODE_)                                                                                        \
   do {                                                                                                               \

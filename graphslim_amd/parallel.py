@@ -115,6 +115,17 @@ class Comm:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         if not isinstance(box[0], bytes):
             raise RuntimeError(f"graphslim_amd: rank 0 could not create an RCCL unique id ({box[0]})")
+        # ncclCommInitRank below is collective: a rank that cannot even load RCCL must not leave its peers waiting inside it.  Every
+        # rank probes its own binding (dlopen + symbols + a unique id it throws away: not collective) and all agree before any enters.
+        mine = 1.0
+        try:
+            check(lib().gs_comm_unique_id(C.create_string_buffer(128)))
+        except Exception:      # noqa: BLE001
+            mine = 0.0
+        flag = torch.tensor([mine], device=torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if float(flag) < 1.0:
+            raise RuntimeError("graphslim_amd: the library's RCCL binding is not usable on every rank" + ("" if mine else " (not on this one)"))
         idb = C.create_string_buffer(box[0], 128)
         h = C.c_void_p()
         check(lib().gs_comm_create_rccl(idb, rank, world, C.byref(h)))
@@ -258,31 +269,59 @@ class ShardedGCond:
     def verify_transport(self):
         """Before the first iteration of a multi-rank job: all-reduce a known vector through the library's transport and through
         torch.distributed and compare.  A transport that cannot be created or disagrees (an RCCL build this library's binding does
-        not fit) switches this rank — and, through the agreement all-reduce, every rank — to the host-side phase list over
-        torch.distributed, loudly."""
+        not fit) switches EVERY rank to the host-side phase list over torch.distributed, loudly.
+
+        Every rank issues the same sequence of torch.distributed collectives whatever happens locally (a rank whose
+        library call raised used to skip the reference all-reduces while its peers were inside them):
+          1. [unique-id broadcast inside Comm.rccl — reached by every rank, rank 0 broadcasts its error text if it has one]
+          2. flag MIN all-reduce: "my communicator exists" — nobody touches the library transport unless all ranks have one
+          3. the library all-reduces (only if 2 agreed), each in its own try
+          4. the two reference all-reduces over torch.distributed — ALWAYS
+          5. flag MIN all-reduce: "my results agree" — ALWAYS
+        GS_SHARDED_DRIVER=python skips the library transport altogether."""
         import sys
         dist, group = self.col.dist, self.col.group
         if dist is None or dist.get_world_size(group) == 1:
             return True
+        if self.driver == "python":
+            return False
         dev = self.eng.dev
-        ok = 1.0
+        on_gpu = dist.get_backend(group) == "nccl"
+
+        def agree(ok):
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev if on_gpu else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return float(flag) >= 1.0
+
+        def complain(what, e):
+            print(f"graphslim_amd.parallel: rank {self.rank}: {what} ({e!r})", file=sys.stderr, flush=True)
+
+        have = True
         try:
-            t = torch.arange(4096, device=dev, dtype=torch.float32) * float(self.rank + 1)
-            d = torch.arange(64, device=dev, dtype=torch.float64) * float(self.rank + 1)
-            rt, rd = t.clone(), d.clone()
-            self.comm.allreduce(t, 7)
-            self.comm.allreduce(d, 7)
-            dist.all_reduce(rt, op=dist.ReduceOp.SUM, group=group)
-            dist.all_reduce(rd, op=dist.ReduceOp.SUM, group=group)
+            _ = self.comm                      # (collective for RCCL: every rank gets here)
+        except Exception as e:                 # noqa: BLE001
+            complain("library transport could not be created", e)
+            have = False
+        all_have = agree(have)                 # 2.
+        t = torch.arange(4096, device=dev, dtype=torch.float32) * float(self.rank + 1)
+        d = torch.arange(64, device=dev, dtype=torch.float64) * float(self.rank + 1)
+        rt, rd = t.clone(), d.clone()
+        ok = all_have
+        if all_have:                           # 3.
+            try:
+                self.comm.allreduce(t, 7)
+                self.comm.allreduce(d, 7)
+            except Exception as e:             # noqa: BLE001
+                complain("library all-reduce failed", e)
+                ok = False
+        dist.all_reduce(rt, op=dist.ReduceOp.SUM, group=group)      # 4.
+        dist.all_reduce(rd, op=dist.ReduceOp.SUM, group=group)
+        if on_gpu:
             torch.cuda.synchronize(dev)
-            if not (torch.equal(t, rt) and torch.equal(d, rd)):
-                ok = 0.0
-        except Exception as e:      # noqa: BLE001
-            print(f"graphslim_amd.parallel: rank {self.rank}: library transport failed ({e!r})", file=sys.stderr, flush=True)
-            ok = 0.0
-        flag = torch.tensor([ok], device=dev if dist.get_backend(group) == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if float(flag) < 1.0:
+        if ok and not (torch.equal(t, rt) and torch.equal(d, rd)):
+            complain("library all-reduce disagrees with torch.distributed", None)
+            ok = False
+        if not agree(ok):                      # 5.
             print(f"graphslim_amd.parallel: rank {self.rank}: falling back to the host-side phase list over torch.distributed",
                   file=sys.stderr, flush=True)
             self.driver = "python"

@@ -13,6 +13,10 @@ int gs_gemm_set_panel_tall(int on);
    (results are garbage): 1 no epilogue, 2 no A staging, 4 no B staging, 8 no waits / barriers, 16 no MFMAs, 32 no operand split */
 int gs_panel_tall_debug(int grid, int krep, int triage);
 
+/* csrc/gs_panel2.hip: the next plain-product launches record s_memtime stamps (3 per 16-k step of waves 0 and 4) of their first 16
+   workgroups into buf ([16][2816] 32-bit words, device memory); null switches it off (tools/trace_tall.py) */
+int gs_panel_tall_trace(void* buf);
+
 #ifdef __cplusplus
 }
 #endif

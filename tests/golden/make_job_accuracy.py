@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Job-level accuracy fixture (VERDICT r03 "next" 3): WHOLE GCond jobs of the CPU oracle (oracle/gcond_oracle.py, the restatement
+pinned by the reference's goldens G1-G22) on a configuration it can finish, one job per seed, and the evaluation-GCN test accuracy
+of each condensed graph (graphslim/evaluation/eval_agent.py:266-291 protocol, graphslim/condensation/gcond.py:40-81 schedule).
+
+Configuration "arxiv-gate" (graphslim_amd/workloads.py): the ogbn-arxiv hyper-parameters (SGC T = 2, h = 256, PGE h = 256,
+lr_feat = lr_adj = 0.01, fan-out [10, 5], inner_loop 3) on the ogbn-arxiv-shaped synthetic graph at scale 0.05 (N = 8 467, C = 40)
+with reduction rate 0.03 -> n' = 136, so the job runs through the SAME kernels as the headline shape (PGE width 256, n' >= 128).
+Schedule: JOB["epochs"] epochs x JOB["outer"] outer iterations (epochs 0-9 update the PGE, 10.. the features, gcond.py:58-61), then
+JOB["run_eval"] evaluation GCNs of JOB["eval_epochs"] epochs on the sparsified condensed graph.
+
+Writes tests/golden/job_accuracy.json.  tests/test_gpu_reduce.py::test_job_level_accuracy_against_the_oracle runs the same jobs
+on the HIP engine (its own sampler, its own evaluation GCN) and gates |mean difference| <= 0.3 pp + 2 standard errors.
+usage (build container, CPU): python tests/golden/make_job_accuracy.py [first_seed last_seed]   (~4 min per seed on 8 cores)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from graphslim_amd import workloads as W  # noqa: E402
+from graphslim_amd.host import init_pge_params, init_sgc_params, random_init_indices, seed_everything  # noqa: E402
+from oracle import gcond_oracle as O  # noqa: E402
+
+JOB = dict(workload="arxiv-gate", scale=0.05, data_seed=1, epochs=16, outer=10, inner=3, threshold=0.01, eval_epochs=150,
+           run_eval=3, lr_model=0.01)
+OUT = os.path.join(ROOT, "tests", "golden", "job_accuracy.json")
+
+
+def oracle_job(p, seed):
+    """One whole job of the oracle: returns (test accuracies of the evaluation runs, mean matching loss of the last epoch)."""
+    d = p["data"]
+    x, y = d.feat_full, d.labels_full
+    nfeat, nclass = x.shape[1], d.nclass
+    rp, col, val = p["csr"]
+    idx_train, labels_train = d.idx_train.numpy(), d.labels_train.numpy()
+    seed_everything(seed)
+    sel = random_init_indices(idx_train, labels_train, p["ncd"])
+    pge = init_pge_params(nfeat, p["ph"])
+    st = O.GCondState(x[sel].clone(), {"lin": pge[:6], "bn": pge[6:]}, torch.from_numpy(p["labels_syn"]), p["ncd"], nclass, p["lrf"],
+                      p["lra"], JOB["lr_model"], "SGC", 2)
+    rng = np.random.default_rng(seed)
+    loss_last = 0.0
+    for epoch in range(JOB["epochs"]):
+        st.new_epoch(init_sgc_params(nfeat, p["hidden"], nclass, p["T"]))
+        loss_last = 0.0
+        for _ in range(JOB["outer"]):
+            batches = [O.sample_blocks(rp, col, val, rng.permutation(p["pools"][c])[:256], list(p["fan"]), rng) for c in range(nclass)]
+            l, _, _, adj_inner = st.outer_iteration(epoch, batches, x, y, JOB["inner"])
+            loss_last += float(l) / (nclass * JOB["outer"])
+    adj = O.sparsify(adj_inner.detach().clone(), JOB["threshold"])
+    feat = st.feat_syn.detach().clone()
+    g = dict(feat_full=x, adj_full_norm=O.csr_to_torch(rp, col, val, d.num_nodes), idx_val=d.idx_val, labels_val=y[d.idx_val],
+             idx_test=d.idx_test, labels_test=y[d.idx_test])
+    accs = []
+    for i in range(JOB["run_eval"]):
+        seed_everything(seed + i)
+        accs.append(float(O.run_eval_gcn(feat, adj, torch.from_numpy(p["labels_syn"]), g, p["hidden"], nclass, JOB["eval_epochs"])[1]))
+    return accs, loss_last
+
+
+def main():
+    lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1, 10)
+    torch.set_num_threads(os.cpu_count())
+    p = W.build_problem(JOB["workload"], seed=JOB["data_seed"], scale=JOB["scale"])
+    blob = json.load(open(OUT)) if os.path.exists(OUT) else {"job": JOB, "shape": {}, "seeds": {}}
+    blob["job"] = JOB
+    blob["shape"] = dict(N=int(p["data"].num_nodes), n_train=int(len(p["data"].idx_train)), nclass=int(p["data"].nclass),
+                         n_syn=int(len(p["labels_syn"])), d=int(p["data"].feat_full.shape[1]))
+    for seed in range(lo, hi + 1):
+        t0 = time.time()
+        accs, loss = oracle_job(p, seed)
+        blob["seeds"][str(seed)] = dict(test_acc=accs, last_epoch_loss=loss)
+        print(f"seed {seed}: test accuracy {100 * np.mean(accs):.2f} % (runs {[round(100 * a, 2) for a in accs]}), last-epoch matching loss "
+              f"{loss:.4f}, {time.time() - t0:.0f} s", flush=True)
+        json.dump(blob, open(OUT, "w"), indent=1)
+    means = [np.mean(v["test_acc"]) for v in blob["seeds"].values()]
+    print(f"{len(means)} jobs: {100 * np.mean(means):.2f} +- {100 * np.std(means):.2f} % (std over seeds)")
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,8 @@ CSRC = os.path.join(ROOT, "graphslim_amd", "csrc")
 CASES = [
     ("gs_panel.hip", r"gs_panel_(gemm|rows|fwdgen|marg)_kernel", r"gs_panel_(gemm|rows)_kernelILi\dELi\dELb1E"),      # Lb1 = sign-bit epilogue (opt-in)
     ("gs_edge.hip", r"gs_(edge_gemm|dw1_gen)_kernel", None),
+    # the persistent 256-row kernels: every product instantiation (TRI = 0); the triage / trace instantiations (Li1, Li2) are measurement forms
+    ("gs_panel2.hip", r"gs_tall_kernel", r"gs_tall_kernelILi\dELb[01]ELi[12]E"),
 ]
 
 
@@ -36,4 +38,4 @@ def test_hot_kernels_need_no_scratch(src, must, may, tmp_path):
         if re.search(must, n) and not (may and re.search(may, n)):
             checked += 1
             assert sc == 0, f"{n} needs {sc} bytes of scratch per lane"
-    assert checked >= 8, (checked, names)
+    assert checked >= (5 if src == "gs_panel2.hip" else 8), (checked, names)

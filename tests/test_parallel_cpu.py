@@ -165,6 +165,69 @@ def test_library_exchange_entry_point_over_gloo_world2():
         assert bad == -1 and world == 2 and crank == rank                           # GS_ERR_ARG for a null buffer
 
 
+def _verify_worker(rank, world, port, q, scenario):
+    """ShardedGCond.verify_transport with the library transport broken on ONE rank only: both ranks must leave through the
+    same sequence of collectives and agree on the host-side phase list — no hang, no mismatched all-reduce."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from graphslim_amd import parallel
+    from graphslim_amd.parallel import Collective, Comm, ShardedGCond
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = FakeEngine(rank)
+    eng.dev = "cpu"
+    sh = ShardedGCond(eng, rank, world, [500, 30, 300, 256, 10], Collective(dist))
+
+    class HostComm:      # stands in for the library handle: all-reduce on the host tensors verify_transport builds (eng.dev = cpu)
+        def allreduce(self, t, tag=7):
+            if scenario == "allreduce_raises_on_rank1" and rank == 1:
+                raise RuntimeError("injected: library all-reduce failed")
+            if scenario == "wrong_sum_on_rank0" and rank == 0:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                t += 1
+                return
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def from_dist(dist_=None, group=None):
+        if scenario == "create_raises_on_rank1" and rank == 1:
+            raise RuntimeError("injected: communicator could not be created")
+        return HostComm()
+
+    parallel.Comm.from_dist = staticmethod(from_dist)
+    if scenario == "allreduce_raises_on_rank1" and rank == 0:
+        # rank 1 never enters the library all-reduce: rank 0's must not block on it — the stand-in makes the library call local there
+        HostComm.allreduce = lambda self, t, tag=7: t.mul_(1.0)
+    ok = sh.verify_transport()
+    # the job goes on over torch.distributed: one more collective proves the two ranks are still in step
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    q.put((rank, ok, sh.driver, float(t)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["healthy", "create_raises_on_rank1", "allreduce_raises_on_rank1", "wrong_sum_on_rank0"])
+def test_verify_transport_falls_back_on_every_rank_when_one_rank_fails(scenario):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_verify_worker, args=(r, 2, port, q, scenario)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = (True, "library") if scenario == "healthy" else (False, "python")
+    for rank, ok, driver, t in res:
+        assert (ok, driver) == want, (scenario, rank, ok, driver)
+        assert t == 3.0
+
+
 def test_null_transport_and_argument_checks():
     import ctypes as C
     from graphslim_amd import _lib

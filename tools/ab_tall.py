@@ -92,18 +92,20 @@ for wl in ("ogbn-arxiv", "reddit"):
                 eng.pge_backward_part(False, True, 2)
                 torch.cuda.synchronize()
                 margs.append(eng.buffer("ar_marg").clone())
-            same_m = torch.equal(margs[0], margs[1])
-            print(f"{wl}: fused marginals bitwise {same_m} (differing {int((margs[0] != margs[1]).sum())} of {margs[0].numel()}, "
+            # (the 256-row kernels regenerate the ReLU mask from the folded terms Us, Vs: same function, fp32 rounding differs)
+            dm = float((margs[0] - margs[1]).abs().max() / margs[0].abs().max())
+            print(f"{wl}: fused marginals max |diff| / max {dm:.2e} (differing {int((margs[0] != margs[1]).sum())} of {margs[0].numel()}, "
                   f"NaN {int(torch.isnan(margs[1]).sum())})", flush=True)
-            ok &= same_m
+            ok &= dm < 1e-5
     L.gs_gemm_set_panel_tall(1)
     a, b = res[0], res[1]
     print(f"{wl}: forward part 1 old {a[5]:.1f} us, tall {b[5]:.1f} us; backward part 2 old {a[6]:.1f} us, tall {b[6]:.1f} us")
-    same_e2 = torch.equal(a[0], b[0])
-    print(f"  E2 bitwise {same_e2} (differing {int((a[0] != b[0]).sum())} of {a[0].numel()}), "
+    de2 = float((a[0] - b[0]).abs().max() / a[0].abs().max())
+    same_e2 = de2 < 2e-6
+    print(f"  E2 max |diff| / max {de2:.2e} (differing {int((a[0] != b[0]).sum())} of {a[0].numel()}), "
           f"mu2 max rel {float(((a[1] - b[1]).abs() / a[1].abs().clamp_min(1e-6)).max()):.2e}, "
           f"is2 max rel {float(((a[2] - b[2]).abs() / a[2].abs()).max()):.2e}, e3 max abs {float((a[3] - b[3]).abs().max()):.2e}, "
           f"d_feat max rel-of-max {float((a[4] - b[4]).abs().max() / a[4].abs().max()):.2e}", flush=True)
     ok &= same_e2
     del eng
-print("ALL BITWISE" if ok else "MISMATCH")
+print("ALL OK" if ok else "MISMATCH")

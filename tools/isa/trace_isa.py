@@ -5,7 +5,7 @@ import re
 import sys
 
 s = open(sys.argv[1]).read()
-funcs = re.split(r'\n(?=_Z[^\n]*:\n)', s)
+funcs = re.split(r'\n(?=_Z[^\n]*:)', s)
 f = [x for x in funcs if sys.argv[2] in x.split(':')[0]][0]
 lines = f.split('\n')
 lo, hi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (0, len(lines))

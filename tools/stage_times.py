@@ -25,6 +25,13 @@ for env, fn in (("GS_H1_BITS", "gs_gcond_set_h1_bits"), ("GS_EDGE_KERNEL", "gs_g
         from graphslim_amd import _lib
         getattr(_lib.lib(), fn)(int(os.environ[env]))
         print(f"{fn}({os.environ[env]})")
+if os.environ.get("GS_TALL") is not None:      # 0: the 128-row exact-split kernels of gs_panel.hip; "1,GRID": persistent grid size
+    from graphslim_amd import _lib
+    v = os.environ["GS_TALL"].split(",")
+    _lib.lib().gs_gemm_set_panel_tall(int(v[0]))      # 0 off, 1 default, 16 + mask: sites (1 plain, 2 training forward, 4 inference forward, 8 marginals)
+    if len(v) > 1:
+        _lib.lib().gs_panel_tall_debug(int(v[1]), 1, int(v[2]) if len(v) > 2 else 0)
+    print(f"gs_gemm_set_panel_tall({os.environ['GS_TALL']})")
 p = bench.build_problem(name, seed=1)
 eng = bench.make_engine(p, "cuda:0")
 if mode:
