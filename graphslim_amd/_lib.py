@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
                 ("bias", vp), ("sbias_b1", C.c_long), ("relu", C.c_int), ("mask", vp), ("ldmask", C.c_long),
                 ("colstat", vp), ("bgen_mask", vp), ("bgen_ldm", C.c_long), ("bgen_idx", vp), ("bgen_w", vp), ("bgen_div", C.c_int),
                 ("prec", C.c_int), ("scratch", vp),
-                ("signbits", vp), ("ld_signbits", C.c_long), ("bgen_bits", vp), ("bgen_ldbits", C.c_long)]
+                ("signbits", vp), ("ld_signbits", C.c_long), ("bgen_bits", vp), ("bgen_ldbits", C.c_long), ("bgen_bits_edge", C.c_int)]
 
 
 class Blocks(C.Structure):
@@ -51,7 +51,7 @@ class GCondIO(C.Structure):
 
 
 # measurement knobs / debug hooks declared in include/gslim_internal.h (not product ABI)
-INTERNAL_SYMBOLS = ["gs_gemm_set_panel_tall", "gs_panel_tall_debug", "gs_panel_tall_trace"]
+INTERNAL_SYMBOLS = ["gs_gemm_set_panel_tall", "gs_panel_tall_debug", "gs_panel_tall_trace", "gs_gcond_set_edge_bits"]
 
 _lib = None
 
@@ -109,6 +109,7 @@ def lib():
     L.gs_gemm_set_panel_tall.argtypes = [i]
     L.gs_panel_tall_debug.argtypes = [i, i, i]
     L.gs_panel_tall_trace.argtypes = [C.c_void_p]
+    L.gs_gcond_set_edge_bits.argtypes = [i]
     L.gs_reduce_slabs_f32.argtypes = [vp, vp, l, i, l, f, vp]
     L.gs_reduce_slabs_batched_f32.argtypes = [vp, l, vp, l, i, l, i, f, vp]
     L.gs_spmm_csr_f32.argtypes = [vp, vp, vp, i, vp, l, i, vp, l, vp]

@@ -42,6 +42,7 @@ struct gs_edge_args {
   const int* col; const float* w; long sK;       // [class][sK] source node ids / edge weights
   const float* H1; long ldm;                     // mask rows: H1[src][n] > 0
   const unsigned* bits; long ldbits;             // BITS: the same predicate as sign bits, 8 words per source row (32 B instead of 1 KiB)
+  int bits_edge;                                 // the words are per EDGE SLOT (row class * sK + k), written by the hop-2 gather
   const float* Y; long sYc; int f2;              // Y1 rows: Y[class * sYc + (k / f2) * 256 + n]
   const int* kcount; int kchunk;
   float* out; long sOc, sOs;                     // slabs: out[class * sOc + slab * sOs + m * 256 + n]
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
       ra[1] = m_ok1 ? *reinterpret_cast<const f32x4*>(xr + 64) : f32x4{0.f, 0.f, 0.f, 0.f};
       const float* yr = Y + (long)(kk / p.f2) * 256 + 4 * quad;
       if constexpr (BITS) {
-        const unsigned* br = p.bits + (long)src * p.ldbits + (quad >> 3);
+        const unsigned* br = p.bits + (p.bits_edge ? (long)c * p.sK + kk : (long)src) * p.ldbits + (quad >> 3);
 #pragma unroll
         for (int i = 0; i < 4; ++i) mw[i] = br[2 * i];
       } else {
@@ -292,7 +293,7 @@ int gs_edge_launch(const gs_gemm_desc& d, hipStream_t s) {
   a.X = d.A; a.ldx = d.sAk; a.d = d.M;
   a.col = d.bgen_idx; a.w = d.bgen_w; a.sK = d.sGb1;
   a.H1 = d.bgen_mask; a.ldm = d.bgen_ldm;
-  a.bits = d.bgen_bits; a.ldbits = d.bgen_ldbits;
+  a.bits = d.bgen_bits; a.ldbits = d.bgen_ldbits; a.bits_edge = d.bgen_bits_edge;
   a.Y = d.B; a.sYc = d.sBb1; a.f2 = d.bgen_div;
   a.kcount = d.Kb; a.kchunk = d.kchunk;
   a.out = d.C; a.sOc = d.sCb1; a.sOs = d.sCb2;

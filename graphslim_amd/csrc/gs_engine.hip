@@ -77,6 +77,8 @@ struct gs_gcond {
   int *marker, *kcount;
   int *h1_flag, *h1_list, *h1_count;   // rows of H1full this rank's sampled blocks gather (sharded ranks: only those are computed)
   unsigned* H1bits;                    // [N][h / 32] sign bits of H1full, written by its product's epilogue: the edge product's mask
+  unsigned* edge_bits;                 // [C][cap1 * f2][h / 32] sign bits of the H1 row each hop-2 edge slot gathered (gs_ell_spmm_kernel): the
+                                       // edge product reads its ReLU mask from these 32 B per edge instead of the 1-KiB row of H1full
   int h1_rows_max;
   float *H1full, *P0, *rs0, *Sr, *rsr, *Zr, *gw_real, *Tm, *Y1, *Bmat, *slabs_r, *colpart, *colpart_r;
   // synthetic side
@@ -243,6 +245,7 @@ static size_t carve(gs_gcond* e, void* base) {
   }
   e->H1full = e->T == 2 ? w.take<float>(N * h) : nullptr;
   e->H1bits = (e->T == 2 && !e->gcn && h == 256) ? w.take<unsigned>(N * (h / 32)) : nullptr;
+  e->edge_bits = (e->T == 2 && !e->gcn && h == 256) ? w.take<unsigned>(C * cap1 * e->f2 * (h / 32)) : nullptr;
   if (e->T == 2 && !e->gcn) {
     e->h1_flag = w.take<int>(N); e->h1_list = w.take<int>(N); e->h1_count = w.take<int>(1);
   } else {
@@ -669,19 +672,22 @@ extern "C" int gs_gcond_stage_sample(gs_gcond* e, gs_stream_t stream) {
 // ================================================================================================
 // stage: real-side per-class gradients gw_real[c] (gcond_base.py:212-224), propagate-first form
 // ================================================================================================
-static void launch_ell(const int* col, const float* val, const int* nrows, int cap_rows, int f, long col_base_stride,
+// (ebits: per-edge sign bits of the gathered rows, see gs_ell_spmm_kernel; returns whether they were written — 16-byte path, F = 256)
+static bool launch_ell(const int* col, const float* val, const int* nrows, int cap_rows, int f, long col_base_stride,
                        const float* src, long ld_src, const float* rs_in, int F, float* out, long ld_out, float* rs_out, int C,
-                       hipStream_t s) {
+                       hipStream_t s, unsigned* ebits = nullptr) {
   long waves = (long)C * cap_rows;
   int blocks = gs_cdiv(waves, 4);
   const int F4 = (F + 3) & ~3;
   bool vec = (ld_src % 4 == 0) && (ld_out % 4 == 0) && ld_src >= F4 && ld_out >= F4 && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
+  const bool bits = vec && ebits && F == 256;
   if (vec)
     hipLaunchKernelGGL((gs_ell_spmm_kernel<4>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
-                       src, ld_src, rs_in, F, out, ld_out, rs_out, C);
+                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, bits ? ebits : (unsigned*)nullptr);
   else
     hipLaunchKernelGGL((gs_ell_spmm_kernel<1>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
-                       src, ld_src, rs_in, F, out, ld_out, rs_out, C);
+                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, (unsigned*)nullptr);
+  return bits;
 }
 
 // ---- the rows of H1 = relu(X W1 + b1) a rank needs: the hop-2 sources of ITS classes' blocks ---------------------------------
@@ -747,6 +753,11 @@ static int sum_f32(gs_gcond* e, const float* x, long n, float* out, hipStream_t 
   return GS_OK;
 }
 
+static int g_edge_bits = 0;      // the hop-2 gather also writes per-edge sign bits and the edge product reads those (0: the mask rows of H1full)
+extern "C" int gs_gcond_set_edge_bits(int on) {
+  g_edge_bits = on != 0;
+  return GS_OK;
+}
 static int g_h1_bits = 0;
 // measurement / test knob: 1 = H1's product also writes its sign bits and the edge product reads its ReLU mask from them (32 B
 // instead of 1 KiB per sampled edge); 0 (default) = the mask is read from the fp32 rows of H1full.  Same predicate, same bits out.
@@ -811,7 +822,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   }
   const float* src = e->io.X;
   long ld_src = e->ldx;
-  bool use_bits = false;
+  bool use_bits = false, have_ebits = false;
   if (e->T == 2) {   // H1full = relu(X W1 + b1) for every node once: theta is shared by all classes
     // (W1 transposed first so that both operands are k-contiguous — see the dY1 product)
     hipLaunchKernelGGL(gs_transpose_small_kernel, dim3(gs_cdiv(h, 32), gs_cdiv(d, 32)), dim3(32, 8), 0, s, th + e->oW1, d, h, e->W1mT);
@@ -857,7 +868,9 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       if (!e->probe2_ev[2 * e->probe2_n + q]) GS_HIP(hipEventCreate(&e->probe2_ev[2 * e->probe2_n + q]));
     GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n], s));
   }
-  launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, src, ld_src, nullptr, F, P0, Fp, rs0, Cl, s);
+  const bool want_ebits = g_edge_bits && e->T == 2 && e->cfg.dis_metric == 0 && e->edge_bits && !use_bits;
+  have_ebits = launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, src, ld_src, nullptr, F, P0, Fp, rs0, Cl, s,
+                                     want_ebits ? e->edge_bits + c0 * cap1 * f2 * 8 : nullptr);
   if (probe2) {
     GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n + 1], s));
     e->probe2_n++;
@@ -926,6 +939,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       gwd.B = Y1; gwd.sBb1 = (long)cap1 * h;
       gwd.bgen_mask = e->H1full; gwd.bgen_ldm = h; gwd.bgen_idx = b.col0; gwd.bgen_w = b.val0; gwd.bgen_div = f2;
       if (use_bits) { gwd.bgen_bits = e->H1bits; gwd.bgen_ldbits = h / 32; }
+      else if (have_ebits) { gwd.bgen_bits = e->edge_bits + c0 * cap1 * f2 * 8; gwd.bgen_ldbits = h / 32; gwd.bgen_bits_edge = 1; }
       gwd.prec = e->operand_mode;      // honoured by the dedicated edge kernel (gs_edge.hip); the tiled fallback is fp32
     }
     GS_TRY(gs_gemm_f32(&gwd, stream));
@@ -2278,6 +2292,7 @@ extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* 
       {"ar_gw_real", e->gw_real, C * e->P},  {"H1bits", e->H1bits, e->H1bits ? (long)e->N * (e->h / 32) : 0},
       // PGE layer-2 pre-activations of this rank's pair rows and the BatchNorm-2 batch statistics (kernel A/B tests)
       {"E2", e->E2, (long)(e->r_hi - e->r_lo) * n * Ph}, {"mu2", e->mu2, Ph}, {"is2", e->is2, Ph},
+      {"edge_bits", e->edge_bits, e->edge_bits ? (long)C * e->cap1 * e->f2 * (e->h / 32) : 0},
   };
   for (auto& t : tab)
     if (!strcmp(t.k, name)) {

@@ -10,12 +10,26 @@
 // rows >= nrows[c] are written as zeros so that fixed-capacity batched GEMMs downstream see exact
 // zeros in the padding.  One wave per row, VEC floats per lane per access, f gathers in flight.
 // ------------------------------------------------------------------------------------------------
+// sign bits of one gathered 256-wide row held as 4 consecutive columns per lane: the lane's nibble goes to bit 4 (lane & 7) of word
+// lane >> 3, the eight lanes of a word are OR-ed with three shuffles, lane 8 w stores word w (32 contiguous bytes per row)
+__device__ __forceinline__ void gs_ell_put_bits(unsigned* __restrict__ dst, const float4& x, int lane) {
+  unsigned v = ((x.x > 0.f ? 1u : 0u) | (x.y > 0.f ? 2u : 0u) | (x.z > 0.f ? 4u : 0u) | (x.w > 0.f ? 8u : 0u)) << (4 * (lane & 7));
+  v |= __shfl_xor(v, 1, 64);
+  v |= __shfl_xor(v, 2, 64);
+  v |= __shfl_xor(v, 4, 64);
+  if ((lane & 7) == 0) dst[lane >> 3] = v;
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict__ col, const float* __restrict__ val,
                                                           const int* __restrict__ nrows, int cap_rows, int f,
                                                           long col_base_stride, const float* __restrict__ src, long ld_src,
                                                           const float* __restrict__ rs_in, int F, float* __restrict__ out,
-                                                          long ld_out, float* __restrict__ rs_out, int nclass) {
+                                                          long ld_out, float* __restrict__ rs_out, int nclass,
+                                                          unsigned* __restrict__ ebits = nullptr) {
+  // ebits (VEC = 4, F = 256, optional): per edge slot (grow * f + j) the sign bits of the gathered source row, bit (n & 31) of word
+  // n >> 5 = [src[col_j][n] > 0] — 8 words = 32 B.  The hop-2 gather has every source row of H1 = relu(X W1 + b1) in registers; the
+  // edge product then reads its ReLU mask from these 32 B per edge instead of gathering the 1-KiB fp32 row again.
   // (VEC = 4 needs ld_src, ld_out multiples of 4 that cover F rounded up to 4 — the engine pads its row strides, so that widths
   // like 602 (reddit) or 1 433 (cora) take the 16-byte path too: the columns [F, round4(F)) carry zeros from X's padding)
   const int lane = threadIdx.x & 63;
@@ -59,6 +73,7 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
           acc.y = fmaf(w[u], x[u].y, acc.y);
           acc.z = fmaf(w[u], x[u].z, acc.z);
           acc.w = fmaf(w[u], x[u].w, acc.w);
+          if (ebits) gs_ell_put_bits(ebits + (ebase + j + u) * 8, x[u], lane);
         }
       }
       for (; j < f; ++j) {
@@ -68,6 +83,7 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
         acc.y = fmaf(w, x.y, acc.y);
         acc.z = fmaf(w, x.z, acc.z);
         acc.w = fmaf(w, x.w, acc.w);
+        if (ebits) gs_ell_put_bits(ebits + (ebase + j) * 8, x, lane);
       }
       *reinterpret_cast<float4*>(o + c0) = acc;
     } else {

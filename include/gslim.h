@@ -92,6 +92,9 @@ typedef struct gs_gemm_desc {
   long ld_signbits;
   const unsigned* bgen_bits;
   long bgen_ldbits;
+  /* 1: bgen_bits holds one row of words per EDGE SLOT (row = batch * sGb1 + k: the sign bits the hop-2 gather of the real side wrote
+     for the source row it had in registers) instead of one per source node (row = bgen_idx[k]) */
+  int bgen_bits_edge;
 } gs_gemm_desc;
 
 /* K-tile depth (16 or 32) of the small tiles and of the 128x128 tile (0 = by operand mode); a measurement knob (defaults 32 / 0). */

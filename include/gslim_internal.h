@@ -17,6 +17,10 @@ int gs_panel_tall_debug(int grid, int krep, int triage);
    workgroups into buf ([16][2816] 32-bit words, device memory); null switches it off (tools/trace_tall.py) */
 int gs_panel_tall_trace(void* buf);
 
+/* real side (T = 2): 1 = the hop-2 gather kernel also writes the sign bits of every gathered H1 row per edge slot and the
+   edge product reads its ReLU mask from those 32 B (bitwise the same gradients); 0 (default: measured 20 us slower on, profiles/r04/edge_bits_ab.txt) = the edge product gathers the 1-KiB mask rows */
+int gs_gcond_set_edge_bits(int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -547,6 +547,49 @@ def test_sign_bit_mask_of_h1_gives_bitwise_the_same_real_side_gradients(mode):
         _lib.check(L.gs_gcond_set_h1_bits(0))
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+def test_per_edge_sign_bits_of_the_hop2_gather_give_bitwise_the_same_real_side_gradients(mode):
+    """VERDICT r03 "next" 2a: the hop-2 gather kernel has every gathered row of H1 = relu(X W1 + b1) in registers and writes its
+    sign bits per edge slot (32 B); the edge product reads its ReLU mask from those instead of gathering the 1-KiB fp32 row of H1full
+    again per edge.  The real-side gradients must be bitwise those of the fp32-mask path, for the full class range and a class shard,
+    and the words must be exactly [H1full[src(e)] > 0] for every live edge slot."""
+    import bench
+    from graphslim_amd import _lib
+    from graphslim_amd.host import init_sgc_params
+    L = _lib.lib()
+    p = bench.build_problem("ogbn-arxiv", seed=1, scale=0.25)
+    C = p["data"].nclass
+    eng = bench.make_engine(p, DEV)
+    eng.set_operand_mode(mode)
+    bench.init_state(p, eng)
+    torch.manual_seed(9)
+    eng.set_model(init_sgc_params(p["data"].feat_full.shape[1], p["hidden"], C, p["T"]))
+    try:
+        for c_lo, c_hi in ((0, C), (7, 10)):
+            eng.set_shard(c_lo, c_hi, 0, len(p["labels_syn"]))
+            eng.stage_sample()
+            _lib.check(L.gs_gcond_set_edge_bits(0))
+            eng.stage_real_grads()
+            ref = eng.view("gw_real").clone().reshape(C, -1)[c_lo:c_hi]
+            _lib.check(L.gs_gcond_set_edge_bits(1))
+            eng.view("edge_bits", torch.int32).fill_(-1)
+            eng.stage_real_grads()
+            torch.cuda.synchronize()
+            got = eng.view("gw_real").reshape(C, -1)[c_lo:c_hi]
+            assert float(ref.abs().max()) > 0 and torch.equal(got, ref), (mode, c_lo, c_hi)
+            # the words against the mask rows, for the live slots of the first class of the range
+            blk = eng.get_blocks()
+            f2 = blk.col0.shape[2]
+            n1 = int(blk.n1[c_lo])
+            src = blk.col0[c_lo, :n1].reshape(-1).long()
+            h1 = eng.view("H1full").reshape(p["data"].bench_n, -1)
+            words = eng.view("edge_bits", torch.int32).reshape(C, -1, 8)[c_lo, :n1 * f2].long() & 0xFFFFFFFF
+            bits = ((words[:, :, None] >> torch.arange(32, device=DEV)) & 1).reshape(n1 * f2, -1).bool()
+            assert torch.equal(bits, h1[src] > 0), (mode, c_lo, c_hi)
+    finally:
+        _lib.check(L.gs_gcond_set_edge_bits(0))
+
+
 @pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16x6", 2e-5), ("bf16x3", 1e-3), ("bf16", 3e-2)])
 @pytest.mark.parametrize("scale", [1.0, 0.13])
 def test_pge_epoch_backward_on_generated_operands(mode, tol, scale):
