@@ -28,7 +28,21 @@ sys.path.insert(0, ROOT)
 from graphslim_amd.workloads import (WORKLOADS, blocks_to_batches, build_problem, init_state, make_engine, new_model,  # noqa: E402,F401
                                       run_steps)
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "pmc_panel_summary.json")
+
+
+def newest_profile(fname, key=None):
+    """The newest committed round's profiles/rNN/<fname> (that holds `key`, if given): (path relative to the repo, parsed JSON) or
+    (None, None).  The counter summaries cannot be sampled inside bench.py (PMC needs rocprofv3); a literal round in the path would
+    silently go stale."""
+    import glob
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*")), reverse=True):
+        f = os.path.join(d, fname)
+        if os.path.exists(f):
+            blob = json.load(open(f))
+            if key is None or key in blob:
+                return os.path.relpath(f, ROOT), blob
+    return None, None
+
 
 
 def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20, span=None):
@@ -63,14 +77,16 @@ def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20, span=None):
     sec = span[0] / 1e3 / span[1] if span and span[1] else bracket
     flops = 2.0 * rows * ph * ph
     traffic, src = None, None
-    kname = {"f32": "gs_panel_fwdgen_kernel<0, 8>", "bf16x3": "gs_panel_fwdgen_kernel<1, 8>", "bf16": "gs_panel_fwdgen_kernel<2, 8>",
-             "bf16x6": "gs_panel_fwdgen_kernel<3, 8>"}[mode]
+    # bf16x6 at the panel shape: the inference pass runs the persistent 256-row kernel (csrc/gs_panel2.hip), the training pass — beside
+    # the real-side stream — the 128-row kernel with the same folded operand (csrc/gs_panel.hip); the timed launches are both
+    kname = {"f32": "gs_panel_fwdgen_kernel<0, 8, false>", "bf16x3": "gs_panel_fwdgen_kernel<1, 8, false>",
+             "bf16": "gs_panel_fwdgen_kernel<2, 8, false>", "bf16x6": "gs_tall_kernel<1, false, 0, true>"}[mode]
     if ph != 256 or n < 128:
         kname = "PGE layer-2 product (row-panel / tile route of this shape)"
-    if (n, ph) == (454, 256) and os.path.exists(PMC_SUMMARY):
-        rec = json.load(open(PMC_SUMMARY)).get(kname)
-        if rec:
-            traffic, src = int(rec["hbm_bytes_per_launch"]), "profiles/r03/pmc_panel_summary.json"
+    if (n, ph) == (454, 256):
+        path, blob = newest_profile("pmc_panel_summary.json", kname)
+        if blob:
+            traffic, src = int(blob[kname]["hbm_bytes_per_launch"]), path
     # algorithmic bytes: E2 written once; U, V (n' x Ph each) and the weight block read once — A1 is formed in registers
     alg_bytes = rows * ph * 4.0 + (2 * n * ph + ph * ph + ph) * 4.0
     extra = {}
@@ -89,8 +105,14 @@ def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20, span=None):
         # the split / bf16 modes need 3/16 or 1/16 of the fp32 pipe time: the launch is bounded by its E2 write stream
         peak, bound, unit = 8000.0, "hbm", "GB/s"
         ach = alg_bytes / sec / 1e9
-    return {"bound": bound, "kernel": f"{kname} (PGE layer 2: E2 = A1(U, V) W1^T + b1 with fused BN-2 column sums; {mode} operands)",
-            "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
+    if mode == "bf16x6" and ph == 256 and n >= 128:
+        kname += " (inference pass) / gs_panel_fwdgen_kernel<3, 8, true> (training pass)"
+    # the same launch priced on its ALGORITHMIC flops (2 n'^2 Ph^2: what the reference's fp32 product needs), against the peak of the
+    # pipe it runs on — beside `frac`, which for the exact split counts the six executed bf16 products
+    frac_alg = (flops / sec / 1e12) / peak if bound == "mfma" else ach / peak
+    return {"bound": bound, "kernel": f"{kname} (PGE layer 2: E2 = A1 W1^T + b1 with fused BN-2 column sums, A1 generated; {mode} operands)",
+            "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "frac_algorithmic": round(frac_alg, 4),
+            "traffic": traffic,
             "traffic_source": src, "avg_launch_us": round(sec * 1e6, 2),
             "avg_launch_source": ("device span (first workgroup start .. last workgroup end, s_memrealtime) of the launches inside "
                                   "the timed steps" if span and span[1] else "HIP-event bracket inside the timed steps"),
@@ -100,7 +122,6 @@ def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20, span=None):
             "isolated_span_us": round(iso_span_ms / max(iso_span_k, 1) * 1e3, 2) if iso_span_k else None, **extra}
 
 
-PMC_HBM = os.path.join(ROOT, "profiles", "r03", "pmc_bench_hbm_per_kernel.json")
 
 
 def roofline_hbm(eng, spmm_ms, spmm_launches):
@@ -124,10 +145,16 @@ def roofline_hbm(eng, spmm_ms, spmm_launches):
     alg = 4.0 * (rows + 1) + 8.0 * nnz + 4.0 * F * distinct + 4.0 * F * rows
     sec = spmm_ms / 1e3 / spmm_launches
     traffic, src = None, None
-    if os.path.exists(PMC_HBM) and base.shapes.n_nodes == 169343 and F == 256:      # (the committed counter pass is of the headline shape)
-        rec = json.load(open(PMC_HBM)).get("gs_ell_spmm_kernel<4>")
-        if rec:
-            traffic, src = int(rec["hbm_bytes_per_launch"]), "profiles/r03/pmc_bench_hbm_per_kernel.json (average over the hop-2 and hop-1 launches)"
+    if base.shapes.n_nodes == 169343 and F == 256:      # (the committed counter passes are of the headline shape)
+        # hop 2's OWN dispatches (tools/gpu/pmc_dispatches.sh splits them from the hop-1 launches of the same kernel); older rounds
+        # only hold the average over both
+        path, blob = newest_profile("pmc_hop2_dispatches.json", "hbm_bytes_per_launch")
+        if blob:
+            traffic, src = int(blob["hbm_bytes_per_launch"]), path + " (the hop-2 dispatches only)"
+        else:
+            path, blob = newest_profile("pmc_bench_hbm_per_kernel.json", "gs_ell_spmm_kernel<4>")
+            if blob:
+                traffic, src = int(blob["gs_ell_spmm_kernel<4>"]["hbm_bytes_per_launch"]), path + " (average over the hop-2 and hop-1 launches)"
     ach = alg / sec / 1e9
     # the same launch with nothing else on the chip (the real-side stage run back to back on one stream: its kernels are in order)
     base.set_overlap(0)

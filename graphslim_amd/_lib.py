@@ -51,28 +51,29 @@ class GCondIO(C.Structure):
 
 
 # measurement knobs / debug hooks declared in include/gslim_internal.h (not product ABI)
-INTERNAL_SYMBOLS = ["gs_gemm_set_panel_tall", "gs_panel_tall_debug", "gs_panel_tall_trace", "gs_gcond_set_edge_bits"]
+INTERNAL_SYMBOLS = ["gs_gemm_set_panel_tall", "gs_panel_tall_debug", "gs_panel_tall_trace", "gs_gcond_set_edge_bits", "gs_gcond_set_knob",
+                    "gs_gcond_get_knob", "gs_gemm_set_tuning", "gs_gemm_set_small", "gs_gemm_set_panel", "gs_gemm_set_edge_kernel", "gs_gemm_set_panel_narrow_tail", "gs_gemm_set_panel_marg", "gs_gemm_set_panel_a1gen", "gs_panel_debug", "gs_gcond_set_folded_reductions", "gs_gcond_set_h1_bits", "gs_gcond_set_fused_chains", "gs_gcond_set_h1_rows", "gs_gcond_set_dw1_generated", "gs_gcond_set_aux_priority", "gs_sample_set_cand_cap"]
 
 _lib = None
 
 # every symbol include/gslim.h declares (tests/test_abi.py checks the list against the header)
 SYMBOLS = [
-    "gs_version", "gs_last_error", "gs_gemm_f32", "gs_gemm_group_f32", "gs_gemm_tiles_m", "gs_gemm_route", "gs_gemm_set_tuning", "gs_gemm_set_small", "gs_gemm_set_panel", "gs_gemm_set_edge_kernel", "gs_gemm_set_panel_narrow_tail", "gs_gemm_set_panel_marg", "gs_gemm_set_panel_a1gen", "gs_panel_debug", "gs_reduce_slabs_f32", "gs_reduce_slabs_batched_f32",
-    "gs_spmm_csr_f32", "gs_gather_rows_f32", "gs_sample_blocks", "gs_dense_gcn_norm_fwd", "gs_dense_gcn_norm_bwd",
-    "gs_adam_step_f32", "gs_gcond_workspace_bytes", "gs_gcond_create", "gs_gcond_destroy", "gs_gcond_new_epoch",
-    "gs_gcond_set_blocks", "gs_gcond_outer_step", "gs_gcond_outer_step_ex", "gs_gcond_set_identity_structure", "gs_gcond_read_loss", "gs_gcond_stage_sample",
+    "gs_version", "gs_last_error", "gs_gemm_f32", "gs_gemm_group_f32", "gs_gemm_tiles_m", "gs_gemm_route", "gs_reduce_slabs_f32",
+    "gs_reduce_slabs_batched_f32", "gs_spmm_csr_f32", "gs_gather_rows_f32", "gs_sample_blocks", "gs_dense_gcn_norm_fwd", "gs_dense_gcn_norm_bwd",
+    "gs_adam_step_f32", "gs_gcond_workspace_bytes", "gs_gcond_create", "gs_gcond_destroy", "gs_gcond_new_epoch", "gs_gcond_set_blocks",
+    "gs_gcond_outer_step", "gs_gcond_outer_step_ex", "gs_gcond_set_identity_structure", "gs_gcond_read_loss", "gs_gcond_stage_sample",
     "gs_gcond_stage_real_grads", "gs_gcond_stage_real_async", "gs_gcond_stage_pge_forward", "gs_gcond_stage_syn_match",
-    "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer",
-    "gs_gcond_get_blocks", "gs_gcond_set_shard", "gs_gcond_set_overlap", "gs_gcond_set_folded_reductions", "gs_gcond_set_operand_mode", "gs_gcond_set_full_neighbour", "gs_gcond_set_forward_reuse", "gs_gcond_probe", "gs_gcond_probe_read", "gs_gcond_probe_read_spans", "gs_gcond_probe_read_spmm", "gs_gcond_invalidate_forward",
-    "gs_gcond_forward_cached", "gs_gcond_adopt_cached_forward", "gs_gcond_stage_pge_forward_part", "gs_gcond_stage_pge_backward_part",
-    "gs_gcond_stage_syn_finish", "gs_gcond_stage_inner_steps", "gs_bias_act_f32", "gs_log_softmax_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
-    "gs_edge_pair_sum_f32", "gs_bn_scratch_bytes", "gs_bn_relu_fwd_f32", "gs_bn_relu_bwd_f32", "gs_edge_score_f32",
-    "gs_edge_scatter_sym_f32", "gs_edge_score_bwd_f32", "gs_segment_sum_rows_f32", "gs_colsum_tall_f32", "gs_mul_f32", "gs_mul_bwd_f32", "gs_mix_heads_f32", "gs_mix_heads_bwd_f32", "gs_sym_sigmoid_f32",
-    "gs_sym_sigmoid_bwd_f32", "gs_bn_running_update_f32", "gs_bn_relu_eval_f32", "gs_ot_spectrum_f32", "gs_ot_value_f32",
-    "gs_scale_cols_f32", "gs_ot_divdiff_f32", "gs_clamp_finite_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
-    "gs_comm_unique_id", "gs_comm_create_rccl", "gs_comm_create_callback", "gs_comm_create_null", "gs_comm_destroy", "gs_comm_rank",
-    "gs_comm_world", "gs_comm_allreduce", "gs_comm_set_timing", "gs_comm_read_timing", "gs_gcond_outer_step_sharded",
-    "gs_gcond_outer_step_sharded_ex", "gs_sample_set_cand_cap", "gs_gcond_set_h1_rows", "gs_gcond_set_fused_chains", "gs_gcond_set_h1_bits", "gs_gcond_set_aux_priority", "gs_gcond_set_dw1_generated",
+    "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer", "gs_gcond_get_blocks", "gs_gcond_set_shard",
+    "gs_gcond_set_overlap", "gs_gcond_set_operand_mode", "gs_gcond_set_full_neighbour", "gs_gcond_set_forward_reuse", "gs_gcond_probe",
+    "gs_gcond_probe_read", "gs_gcond_probe_read_spans", "gs_gcond_probe_read_spmm", "gs_gcond_invalidate_forward", "gs_gcond_forward_cached",
+    "gs_gcond_adopt_cached_forward", "gs_gcond_stage_pge_forward_part", "gs_gcond_stage_pge_backward_part", "gs_gcond_stage_syn_finish",
+    "gs_gcond_stage_inner_steps", "gs_bias_act_f32", "gs_log_softmax_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
+    "gs_edge_pair_sum_f32", "gs_bn_scratch_bytes", "gs_bn_relu_fwd_f32", "gs_bn_relu_bwd_f32", "gs_edge_score_f32", "gs_edge_scatter_sym_f32",
+    "gs_edge_score_bwd_f32", "gs_segment_sum_rows_f32", "gs_colsum_tall_f32", "gs_mul_f32", "gs_mul_bwd_f32", "gs_mix_heads_f32",
+    "gs_mix_heads_bwd_f32", "gs_sym_sigmoid_f32", "gs_sym_sigmoid_bwd_f32", "gs_bn_running_update_f32", "gs_bn_relu_eval_f32", "gs_ot_spectrum_f32",
+    "gs_ot_value_f32", "gs_scale_cols_f32", "gs_ot_divdiff_f32", "gs_clamp_finite_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
+    "gs_comm_unique_id", "gs_comm_create_rccl", "gs_comm_create_callback", "gs_comm_create_null", "gs_comm_destroy", "gs_comm_rank", "gs_comm_world",
+    "gs_comm_allreduce", "gs_comm_set_timing", "gs_comm_read_timing", "gs_gcond_outer_step_sharded", "gs_gcond_outer_step_sharded_ex",
 ]
 
 # gs_allreduce_fn of include/gslim.h: int fn(void* user, void* buf, long count, int dtype, gs_stream_t stream)
@@ -110,6 +111,8 @@ def lib():
     L.gs_panel_tall_debug.argtypes = [i, i, i]
     L.gs_panel_tall_trace.argtypes = [C.c_void_p]
     L.gs_gcond_set_edge_bits.argtypes = [i]
+    L.gs_gcond_set_knob.argtypes = [vp, i, i]
+    L.gs_gcond_get_knob.argtypes = [vp, i]
     L.gs_reduce_slabs_f32.argtypes = [vp, vp, l, i, l, f, vp]
     L.gs_reduce_slabs_batched_f32.argtypes = [vp, l, vp, l, i, l, i, f, vp]
     L.gs_spmm_csr_f32.argtypes = [vp, vp, vp, i, vp, l, i, vp, l, vp]

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/gslim.h"
+#include "../../include/gslim_internal.h"
 
 #define GS_WAVE 64
 

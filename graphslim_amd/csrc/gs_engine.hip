@@ -77,6 +77,7 @@ struct gs_gcond {
   int *marker, *kcount;
   int *h1_flag, *h1_list, *h1_count;   // rows of H1full this rank's sampled blocks gather (sharded ranks: only those are computed)
   unsigned* H1bits;                    // [N][h / 32] sign bits of H1full, written by its product's epilogue: the edge product's mask
+  int knob[GS_KNOB_COUNT];             // per-engine value of a measurement knob (gs_gcond_set_knob), -1 = follow the process default
   unsigned* edge_bits;                 // [C][cap1 * f2][h / 32] sign bits of the H1 row each hop-2 edge slot gathered (gs_ell_spmm_kernel): the
                                        // edge product reads its ReLU mask from these 32 B per edge instead of the 1-KiB row of H1full
   int h1_rows_max;
@@ -293,6 +294,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->a1_tab = w.take<float>(Ph * 8);
   e->UsVs = w.take<float>(2 * n * Ph);
   e->uvs_valid = false;
+  for (int i = 0; i < GS_KNOB_COUNT; ++i) e->knob[i] = -1;
   e->a1_valid = false;
   e->bn2_slices = e->l3_slices = 1;
   e->chunk_fwd = w.take<float>((long)e->pge_chunks * 4 * Ph); e->chunk_bwd = w.take<float>((long)e->pge_chunks * 5 * Ph);
@@ -349,7 +351,15 @@ extern "C" int gs_gcond_workspace_bytes(const gs_gcond_config* cfg, size_t* byte
   return GS_OK;
 }
 
+// Engine-level measurement knobs: a process-wide default (the gs_gcond_set_<knob>(int) setters of include/gslim_internal.h) that an
+// engine follows unless it has its own value (gs_gcond_set_knob): two engines with different settings do not see each other.
+static inline int knob_of(const gs_gcond* e, int id, int process_default) { return e->knob[id] >= 0 ? e->knob[id] : process_default; }
 static int g_dw1_generated = 1;
+static int g_fused_chains = 1;      // gs_gcond_set_fused_chains
+static int g_defer_last_stage = 1;  // gs_gcond_set_folded_reductions
+static int g_edge_bits = 0;         // the hop-2 gather also writes per-edge sign bits and the edge product reads those (0: the mask rows of H1full)
+static int g_h1_bits = 0;
+static int g_h1_rows = 1;
 // measurement / test knob: 1 (default) = PGE epochs run the backward of layer 2 on generated operands (marginals as in feature epochs,
 // dW1 | db1 by gs_dw1_gen_kernel); 0 = dE2 and A1 are materialised for a general tiled product (round 2's form)
 extern "C" int gs_gcond_set_dw1_generated(int on) {
@@ -611,10 +621,19 @@ extern "C" int gs_gcond_set_shard(gs_gcond* e, int c_lo, int c_hi, int r_lo, int
 static inline bool sharded_c(const gs_gcond* e) { return e->c_lo != 0 || e->c_hi != e->C; }
 static inline bool sharded_r(const gs_gcond* e) { return e->r_lo != 0 || e->r_hi != e->n; }
 
-static int g_fused_chains = 1;      // gs_gcond_set_fused_chains
-static int g_defer_last_stage = 1;
 // measurement knob: 1 (default) = the last stage of the BN-2 / layer-3 statistics reductions is folded into its consumer
 // launch (unsharded engines); 0 = separate launch.  Same bits either way.
+extern "C" int gs_gcond_set_knob(gs_gcond* e, int knob, int value) {
+  if (!e || knob < 0 || knob >= GS_KNOB_COUNT) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_knob: null engine or unknown knob %d", knob);
+  e->knob[knob] = value < 0 ? -1 : (value != 0);
+  return GS_OK;
+}
+extern "C" int gs_gcond_get_knob(const gs_gcond* e, int knob) {
+  if (!e || knob < 0 || knob >= GS_KNOB_COUNT) return -1;
+  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage};
+  return knob_of(e, knob, def[knob]);
+}
+
 extern "C" int gs_gcond_set_folded_reductions(int on) {
   g_defer_last_stage = on != 0;
   return GS_OK;
@@ -753,12 +772,10 @@ static int sum_f32(gs_gcond* e, const float* x, long n, float* out, hipStream_t 
   return GS_OK;
 }
 
-static int g_edge_bits = 0;      // the hop-2 gather also writes per-edge sign bits and the edge product reads those (0: the mask rows of H1full)
 extern "C" int gs_gcond_set_edge_bits(int on) {
   g_edge_bits = on != 0;
   return GS_OK;
 }
-static int g_h1_bits = 0;
 // measurement / test knob: 1 = H1's product also writes its sign bits and the edge product reads its ReLU mask from them (32 B
 // instead of 1 KiB per sampled edge); 0 (default) = the mask is read from the fp32 rows of H1full.  Same predicate, same bits out.
 // Measured at the headline shape (round 3): the real side is 10-17 us SLOWER with the bits (the 128 ballots + 4-byte scattered
@@ -768,7 +785,6 @@ extern "C" int gs_gcond_set_h1_bits(int on) {
   return GS_OK;
 }
 
-static int g_h1_rows = 1;
 // measurement knob: 1 (default) = a sharded rank computes only the H1 rows its blocks gather; 0 = every rank computes all N rows
 extern "C" int gs_gcond_set_h1_rows(int on) {
   g_h1_rows = on != 0;
@@ -833,8 +849,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     const long slots = (long)Cl * cap1 * f2;
     int rows_rc = GS_ERR_UNSUPPORTED;
     // (the sign bits are an output of the row-panel kernel: asked for only where the product takes that route)
-    const bool want_bits = g_h1_bits && e->H1bits && e->cfg.dis_metric == 0;
-    if (g_h1_rows && !e->S_full && e->h1_flag && slots < (long)e->N) {
+    const bool want_bits = knob_of(e, GS_KNOB_H1_BITS, g_h1_bits) && e->H1bits && e->cfg.dis_metric == 0;
+    if (knob_of(e, GS_KNOB_H1_ROWS, g_h1_rows) && !e->S_full && e->h1_flag && slots < (long)e->N) {
       GS_HIP(hipMemsetAsync(e->h1_flag, 0, sizeof(int) * (size_t)e->N, s));
       GS_HIP(hipMemsetAsync(e->h1_count, 0, sizeof(int), s));
       hipLaunchKernelGGL(gs_h1_mark_kernel, dim3(gs_cdiv(slots, 256)), dim3(256), 0, s, b.col0, b.val0, b.n1, cap1, f2, Cl, e->h1_flag);
@@ -868,7 +884,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       if (!e->probe2_ev[2 * e->probe2_n + q]) GS_HIP(hipEventCreate(&e->probe2_ev[2 * e->probe2_n + q]));
     GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n], s));
   }
-  const bool want_ebits = g_edge_bits && e->T == 2 && e->cfg.dis_metric == 0 && e->edge_bits && !use_bits;
+  const bool want_ebits = knob_of(e, GS_KNOB_EDGE_BITS, g_edge_bits) && e->T == 2 && e->cfg.dis_metric == 0 && e->edge_bits && !use_bits;
   have_ebits = launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, src, ld_src, nullptr, F, P0, Fp, rs0, Cl, s,
                                      want_ebits ? e->edge_bits + c0 * cap1 * f2 * 8 : nullptr);
   if (probe2) {
@@ -1164,7 +1180,7 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
         e->probe_n++;
       }
       // (unsharded: the last reduction stage is folded into gs_bn2_from_sums; sharded ranks exchange e->sums in between)
-      e->bn2_slices = reduce_parts(e, e->statp, tiles, 2, 2, s, g_defer_last_stage && !sharded_r(e));
+      e->bn2_slices = reduce_parts(e, e->statp, tiles, 2, 2, s, knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e));
       GS_LAUNCH_CHECK();
     } else {
       GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 2 * Ph, s));
@@ -1622,7 +1638,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
       else
         hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(nblk), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2, pp + e->pg2,
                            pp + e->pbe2, pp + e->pw2, rows, Ph, e->rows_per_block, e->parts);
-      e->l3_slices = reduce_parts(e, e->parts, nblk, 3, 3, s, g_defer_last_stage && !sharded_r(e));
+      e->l3_slices = reduce_parts(e, e->parts, nblk, 3, 3, s, knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e));
     } else {
       GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 3 * Ph, s));
       e->l3_slices = 1;
@@ -1633,7 +1649,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
   if (part == 2) {
     // one launch: the layer-3 statistics as floats (dw2, dbe2, dg2), the constants table of the generated dE2 operand where
     // that form applies (feature epochs), and W1^T
-    const bool want_gen = (!need_param_grads || g_dw1_generated) && Ph <= 256 && rows > 0;
+    const bool want_gen = (!need_param_grads || knob_of(e, GS_KNOB_DW1_GENERATED, g_dw1_generated)) && Ph <= 256 && rows > 0;
     hipLaunchKernelGGL(gs_pge_bwd_prep_kernel, dim3(gs_cdiv(Ph, 32), gs_cdiv(Ph, 32)), dim3(32, 8), 0, s,
                        e->l3_slices > 1 ? e->sums2 : e->sums, e->l3_slices, Ph, g + e->pw2, g + e->pbe2, g + e->pg2, e->mu2, e->is2,
                        pp + e->pg2, pp + e->pbe2, pp + e->pw2, 1.f / (float)n2, want_gen ? e->gen_tab : (float*)nullptr, pp + e->pW1,
@@ -1878,7 +1894,7 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int C = e->C, n = e->n, d = e->d, h = e->h, F = e->F;
   if (e->cfg.inner_loop == 0) return GS_OK;
-  if (g_fused_chains && !e->gcn && !e->with_bn && !e->blk_pos && C <= 64) return inner_steps_fused(e, stream);
+  if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && !e->gcn && !e->with_bn && !e->blk_pos && C <= 64) return inner_steps_fused(e, stream);
   const float* X = e->io.feat_syn;
   float* th_true = e->io.model_params;                 // Adam steps these ...
   const float* th = model_th(e);                       // ... the products read these (the BatchNorm-folded image under with_bn)

@@ -35,7 +35,6 @@
 // LDS (one object, all 160 KB): [3 B sub-stages x 24 KB][A: 2 buffers x 8 waves x 4 KB][12 table rows x 1 KB][per-row scalars 4 KB]
 // [8 KB epilogue scratch of waves 6, 7 (MARG)].
 #include "gs_common.h"
-#include "../../include/gslim_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

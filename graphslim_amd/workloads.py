@@ -16,6 +16,9 @@ WORKLOADS = {
     "cora-r1.0": ("cora", 1.0, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
     "citeseer-r0.005": ("citeseer", 0.005, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
     "pubmed-r0.005": ("pubmed", 0.005, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
+    # graphslim/configs/gcond/flickr.json at r = 0.5 %: inductive + two transforms + fan-out [15, 8] (loader.py:197-210), d = 500 (not a
+    # multiple of 32: H1 = relu(X W1 + b1) runs on the general tile), C = 7, n' = 223 — full-size parity case
+    "flickr": ("flickr", 0.005, 2, 256, 256, 10, 1, 0.005, 0.005, (15, 8)),
     # job-level accuracy gate (tests/golden/make_job_accuracy.py): the ogbn-arxiv hyper-parameters at graph scale 0.05 with a rate
     # that keeps n' >= 128 (n' = 136): a whole job the CPU oracle finishes in minutes, through the headline shape's kernels
     "arxiv-gate": ("ogbn-arxiv", 0.03, 2, 256, 256, 10, 3, 0.01, 0.01, (10, 5)),

@@ -11,6 +11,13 @@
  * beyond the call, except gs_gcond_* which borrows the buffers named in gs_gcond_io until
  * gs_gcond_destroy.  `stream` is a hipStream_t (0 = default stream); calls are asynchronous on it.
  * Indices are int32, values fp32 (fp32 accumulation; BatchNorm statistics accumulate in fp64).
+ *
+ * Threading.  Functions without a handle (gs_gemm_f32, gs_spmm_csr_f32, gs_adam_step_f32, ...) keep no state between calls and are
+ * re-entrant: any thread may call them, concurrently, on any stream.  A gs_gcond / gs_comm handle is NOT internally locked: one
+ * thread at a time per handle (different handles may be driven from different threads concurrently — the multi-rank tests do);
+ * every state an engine carries between calls lives behind its handle.  What is process-global is ONLY the set of measurement
+ * knobs and debug hooks declared in gslim_internal.h: they are not part of this ABI, default to the product configuration, are not
+ * thread-safe, and a product build never calls them (the engine-level ones can be pinned per engine with gs_gcond_set_knob).
  */
 #ifndef GSLIM_H
 #define GSLIM_H
@@ -97,31 +104,6 @@ typedef struct gs_gemm_desc {
   int bgen_bits_edge;
 } gs_gemm_desc;
 
-/* K-tile depth (16 or 32) of the small tiles and of the 128x128 tile (0 = by operand mode); a measurement knob (defaults 32 / 0). */
-int gs_gemm_set_tuning(int bk_small, int bk_big);
-/* Routing of latency-bound products to the one-tile-per-workgroup kernel (32x32 tile, K split over the 4 waves, fragments
-   fetched straight from global memory): taken when the 32x32 tile count is <= max_tiles and the product is <= max_gflop
-   (defaults 8192 / 1.5); max_tiles = 0 switches it off.  A measurement knob. */
-int gs_gemm_set_small(long max_tiles, double max_gflop);
-/* route eligible products to the row-panel kernel (default 1); 0 sends them to the 128x128 tile (A/B measurements) */
-int gs_gemm_set_panel(int enable);
-/* route the real-side edge product (generated B, gathered K, N == 256) to its dedicated kernel (default 1: exact split done once at
-   LDS-write time, hardware-transposed fragment reads); 2 = the same kernel with the split at fragment-read time (round 2's form,
-   bitwise the same result); 0 = 128x128 tile */
-int gs_gemm_set_edge_kernel(int enable);
-/* the row-panel kernel finishes the last partial round of a launch in 32-row tiles (default 1); 0 = 128-row tiles throughout */
-int gs_gemm_set_panel_narrow_tail(int on);
-/* PGE backward marginals (engine-internal product dY1 = (dE2 W1) * [A1 > 0], needed only through its row / column sums):
-   0 = materialise dY1 and reduce it, 1 = sums fused into the row-panel product's epilogue on a materialised dE2,
-   2 (default) = as 1 with dE2 formed from E2 in the operand path where it applies (feature epochs).  A measurement knob. */
-int gs_gemm_set_panel_marg(int level);
-/* PGE layer-1 activations A1 = relu(BN1(U[c] + V[r] + b0)): 1 (default) = formed from U, V inside the layer-2 product's
-   operand path and inside the marginals' mask (A1 is written only when dW1 needs it); 0 = always materialised first.
-   Both forms give bitwise the same results (tests/test_gpu_panel.py).  A measurement knob. */
-int gs_gemm_set_panel_a1gen(int on);
-/* row-panel kernel measurement hooks (tools/trace_panel.py): the K loop repeated krep times; triage bit 0 = no stores,
-   bit 1 = per-workgroup placement / timing trace into desc.scratch.  krep = 1, triage = 0 restores the product path. */
-int gs_panel_debug(int krep, int triage);
 /* which kernel gs_gemm_f32 launches for this descriptor: 0 = 128x32 tile, 1 = 32x128, 2 = 64x64, 3 = 128x128, 4 = the
    one-tile-per-workgroup latency kernel, 5 = the row-panel kernel (128 rows x all 256 columns per workgroup; PGE layer 2,
    its backward and the SGC transform), 6 = the real-side edge-product kernel — test hook: parity tests assert the instantiation a shape exercises */
@@ -394,9 +376,6 @@ int gs_gcond_set_operand_mode(gs_gcond* e, int mode);
  * gathers their rows; NULL returns to neighbour sampling.  GS_ERR_UNSUPPORTED for ntrans = 2 / GCN (a ReLU between the
  * transforms would need one full-graph SpMM per class and iteration in the backward). */
 int gs_gcond_set_full_neighbour(gs_gcond* e, const float* S_full, long ld, const float* rs_full);
-/* 1 (default): unsharded engines fold the last stage of the BatchNorm-2 / layer-3 statistics reductions into the consuming
-   launch (two launches fewer per PGE pass); 0 = separate launches.  Bitwise the same results.  A measurement knob. */
-int gs_gcond_set_folded_reductions(int on);
 /* One outer-loop iteration; adds the matching loss to the device-side accumulator. */
 int gs_gcond_outer_step(gs_gcond* e, int epoch, gs_stream_t stream);
 /* The sibling gradient-matching methods reuse train_class unchanged and differ in the update rule and in whether a
@@ -477,32 +456,11 @@ int gs_gcond_outer_step_sharded(gs_gcond* e, int epoch, gs_comm* comm, gs_stream
 int gs_gcond_outer_step_sharded_ex(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_comm* comm,
                                    gs_stream_t stream);
 
-/* Measurement knob: 1 (default) = a sharded rank computes only the rows of H1 = relu(X W1 + b1) (models/sgc.py:38-43) that the
- * sampled blocks of ITS classes gather (marked and compacted on the device); 0 = every rank computes all N rows.  Same values. */
-int gs_gcond_set_h1_rows(int on);
 
-/* Measurement / test knob: 1 (default) = the latency-bound chains run as fused launches (csrc/gs_chain.hip: the inner SGC steps of
- * gcond.py:63-72 with logits + softmax + NLL gradient in one launch, the two n' x n' x h products re-associated into n' x n' x C
- * ones, Adam in the epilogue of the gradient products; the synthetic match's logits + softmax in one launch); 0 = one launch per
- * product (first form).  Same values up to fp32 re-association. */
-int gs_gcond_set_fused_chains(int on);
 
-/* Measurement / test knob: 1 = the product H1 = relu(X W1 + b1) also writes its sign bits (gs_gemm_desc.signbits) and the
- * real-side edge product reads its ReLU mask from them (gs_gemm_desc.bgen_bits: 32 B instead of 1 KiB per sampled edge); 0 (default:
- * measured faster, the mask rows are L2-resident) = the mask comes from the fp32 rows.  Same predicate: bitwise the same gradients. */
-int gs_gcond_set_h1_bits(int on);
 
-/* Measurement / test knob: 1 (default) = PGE epochs compute dW1 | db1 of the structure generator's second layer from generated
- * operands (dE2 from E2, the layer-1 activations from U, V: nothing materialised); 0 = round 2's form (both operands written to
- * memory for a general tiled product).  Same values up to fp32 rounding of the folded BatchNorm-1 affine. */
-int gs_gcond_set_dw1_generated(int on);
 
-/* Priority of the second (real-side) stream of engines created AFTER the call: -1 = highest (default), 0 = normal, 1 = lowest. */
-int gs_gcond_set_aux_priority(int level);
 
-/* Test hook of the sampler's seed selection (gs_sample_blocks): members of the crossing key bin that are ranked directly
- * (1 .. 2048, default 2048); a small value forces the second histogram level on ordinary pools.  Same seeds either way. */
-int gs_sample_set_cand_cap(int cap);
 
 /* Named views into engine-owned scratch for the parity tests (device pointer + element count):
  * "gw_real" [C][|theta|], "gw_syn" [C][|theta|], "loss" [1], "d_feat" [n'][d] (total gradient wrt X~),

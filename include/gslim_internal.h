@@ -2,6 +2,7 @@
    not thread-safe, and exist for the A/B tools under tools/ and the bitwise form-against-form tests; a product build may drop them. */
 #ifndef GSLIM_INTERNAL_H
 #define GSLIM_INTERNAL_H
+#include "gslim.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -20,6 +21,79 @@ int gs_panel_tall_trace(void* buf);
 /* real side (T = 2): 1 = the hop-2 gather kernel also writes the sign bits of every gathered H1 row per edge slot and the
    edge product reads its ReLU mask from those 32 B (bitwise the same gradients); 0 (default: measured 20 us slower on, profiles/r04/edge_bits_ab.txt) = the edge product gathers the 1-KiB mask rows */
 int gs_gcond_set_edge_bits(int on);
+
+
+/* ---- moved here from gslim.h in round 4: process-global measurement knobs and debug hooks ---- */
+/* K-tile depth (16 or 32) of the small tiles and of the 128x128 tile (0 = by operand mode); a measurement knob (defaults 32 / 0). */
+int gs_gemm_set_tuning(int bk_small, int bk_big);
+
+/* Routing of latency-bound products to the one-tile-per-workgroup kernel (32x32 tile, K split over the 4 waves, fragments
+   fetched straight from global memory): taken when the 32x32 tile count is <= max_tiles and the product is <= max_gflop
+   (defaults 8192 / 1.5); max_tiles = 0 switches it off.  A measurement knob. */
+int gs_gemm_set_small(long max_tiles, double max_gflop);
+
+/* route eligible products to the row-panel kernel (default 1); 0 sends them to the 128x128 tile (A/B measurements) */
+int gs_gemm_set_panel(int enable);
+
+/* route the real-side edge product (generated B, gathered K, N == 256) to its dedicated kernel (default 1: exact split done once at
+   LDS-write time, hardware-transposed fragment reads); 2 = the same kernel with the split at fragment-read time (round 2's form,
+   bitwise the same result); 0 = 128x128 tile */
+int gs_gemm_set_edge_kernel(int enable);
+
+/* the row-panel kernel finishes the last partial round of a launch in 32-row tiles (default 1); 0 = 128-row tiles throughout */
+int gs_gemm_set_panel_narrow_tail(int on);
+
+/* PGE backward marginals (engine-internal product dY1 = (dE2 W1) * [A1 > 0], needed only through its row / column sums):
+   0 = materialise dY1 and reduce it, 1 = sums fused into the row-panel product's epilogue on a materialised dE2,
+   2 (default) = as 1 with dE2 formed from E2 in the operand path where it applies (feature epochs).  A measurement knob. */
+int gs_gemm_set_panel_marg(int level);
+
+/* PGE layer-1 activations A1 = relu(BN1(U[c] + V[r] + b0)): 1 (default) = formed from U, V inside the layer-2 product's
+   operand path and inside the marginals' mask (A1 is written only when dW1 needs it); 0 = always materialised first.
+   Both forms give bitwise the same results (tests/test_gpu_panel.py).  A measurement knob. */
+int gs_gemm_set_panel_a1gen(int on);
+
+/* row-panel kernel measurement hooks (tools/trace_panel.py): the K loop repeated krep times; triage bit 0 = no stores,
+   bit 1 = per-workgroup placement / timing trace into desc.scratch.  krep = 1, triage = 0 restores the product path. */
+int gs_panel_debug(int krep, int triage);
+
+/* 1 (default): unsharded engines fold the last stage of the BatchNorm-2 / layer-3 statistics reductions into the consuming
+   launch (two launches fewer per PGE pass); 0 = separate launches.  Bitwise the same results.  A measurement knob. */
+int gs_gcond_set_folded_reductions(int on);
+
+/* Measurement / test knob: 1 = the product H1 = relu(X W1 + b1) also writes its sign bits (gs_gemm_desc.signbits) and the
+ * real-side edge product reads its ReLU mask from them (gs_gemm_desc.bgen_bits: 32 B instead of 1 KiB per sampled edge); 0 (default:
+ * measured faster, the mask rows are L2-resident) = the mask comes from the fp32 rows.  Same predicate: bitwise the same gradients. */
+int gs_gcond_set_h1_bits(int on);
+
+/* Measurement / test knob: 1 (default) = the latency-bound chains run as fused launches (csrc/gs_chain.hip: the inner SGC steps of
+ * gcond.py:63-72 with logits + softmax + NLL gradient in one launch, the two n' x n' x h products re-associated into n' x n' x C
+ * ones, Adam in the epilogue of the gradient products; the synthetic match's logits + softmax in one launch); 0 = one launch per
+ * product (first form).  Same values up to fp32 re-association. */
+int gs_gcond_set_fused_chains(int on);
+
+/* Measurement knob: 1 (default) = a sharded rank computes only the rows of H1 = relu(X W1 + b1) (models/sgc.py:38-43) that the
+ * sampled blocks of ITS classes gather (marked and compacted on the device); 0 = every rank computes all N rows.  Same values. */
+int gs_gcond_set_h1_rows(int on);
+
+/* Measurement / test knob: 1 (default) = PGE epochs compute dW1 | db1 of the structure generator's second layer from generated
+ * operands (dE2 from E2, the layer-1 activations from U, V: nothing materialised); 0 = round 2's form (both operands written to
+ * memory for a general tiled product).  Same values up to fp32 rounding of the folded BatchNorm-1 affine. */
+int gs_gcond_set_dw1_generated(int on);
+
+/* Priority of the second (real-side) stream of engines created AFTER the call: -1 = highest (default), 0 = normal, 1 = lowest. */
+int gs_gcond_set_aux_priority(int level);
+
+/* Test hook of the sampler's seed selection (gs_sample_blocks): members of the crossing key bin that are ranked directly
+ * (1 .. 2048, default 2048); a small value forces the second histogram level on ordinary pools.  Same seeds either way. */
+int gs_sample_set_cand_cap(int cap);
+
+/* Engine-level knobs per ENGINE (the int-only setters above change the process-wide default an engine follows while its own value is
+   -1): knob ids below, value 0 / 1, -1 = follow the default again.  gs_gcond_get_knob returns the value in effect (-1: bad arguments). */
+enum { GS_KNOB_FUSED_CHAINS = 0, GS_KNOB_H1_ROWS = 1, GS_KNOB_H1_BITS = 2, GS_KNOB_EDGE_BITS = 3, GS_KNOB_DW1_GENERATED = 4,
+       GS_KNOB_FOLDED_REDUCTIONS = 5, GS_KNOB_COUNT = 6 };
+int gs_gcond_set_knob(gs_gcond* e, int knob, int value);
+int gs_gcond_get_knob(const gs_gcond* e, int knob);
 
 #ifdef __cplusplus
 }

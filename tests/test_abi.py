@@ -26,6 +26,22 @@ def test_header_symbols_are_exported(L):
     for s in declared:
         assert hasattr(L, s), s
     assert L.gs_version() >= 100
+    # no process-global knob setter or debug hook is left in the product header: they live in gslim_internal.h
+    assert not [s for s in declared if re.search(r"^gs_(gemm|sample)_set_|_debug$|_trace$", s)], declared
+
+
+def test_internal_header_symbols_are_exported(L):
+    """include/gslim_internal.h — the measurement knobs and debug hooks, NOT product ABI — declares exactly _lib.INTERNAL_SYMBOLS,
+    compiles as plain C on top of gslim.h, and every one of them is exported."""
+    from graphslim_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "gslim_internal.h")).read()
+    declared = set(re.findall(r"^(?:int|void|size_t|const char\*)\s+(gs_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(_lib.INTERNAL_SYMBOLS), declared ^ set(_lib.INTERNAL_SYMBOLS)
+    assert not (declared & set(_lib.SYMBOLS))
+    for s in declared:
+        assert hasattr(L, s), s
+    subprocess.run(["gcc", "-x", "c", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-"],
+                   input=b'#include "gslim_internal.h"\nint main(void){return GS_KNOB_COUNT == 6 ? 0 : 1;}\n', check=True)
 
 
 def test_struct_layouts_match_the_header(L):

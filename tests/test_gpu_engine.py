@@ -547,6 +547,48 @@ def test_sign_bit_mask_of_h1_gives_bitwise_the_same_real_side_gradients(mode):
         _lib.check(L.gs_gcond_set_h1_bits(0))
 
 
+def test_two_engines_with_different_knob_settings_do_not_see_each_other():
+    """engine-level measurement knobs are per engine (gs_gcond_set_knob); the int-only setters of
+    include/gslim_internal.h only move the process default an engine follows while it has no value of its own."""
+    import bench
+    from graphslim_amd import _lib
+    from graphslim_amd.host import init_sgc_params
+    L = _lib.lib()
+    KNOB_H1_ROWS, KNOB_H1_BITS = 1, 2
+    p = bench.build_problem("ogbn-arxiv", seed=1, scale=0.25)
+    C = p["data"].nclass
+    engs = []
+    for _ in range(2):
+        eng = bench.make_engine(p, DEV)
+        eng.set_operand_mode("bf16x6")
+        bench.init_state(p, eng)
+        torch.manual_seed(9)
+        eng.set_model(init_sgc_params(p["data"].feat_full.shape[1], p["hidden"], C, p["T"]))
+        engs.append(eng)
+    a, b = engs
+    try:
+        assert L.gs_gcond_get_knob(a.h, KNOB_H1_BITS) == 0 and L.gs_gcond_get_knob(b.h, KNOB_H1_BITS) == 0      # product default
+        _lib.check(L.gs_gcond_set_knob(a.h, KNOB_H1_BITS, 1))
+        assert L.gs_gcond_get_knob(a.h, KNOB_H1_BITS) == 1 and L.gs_gcond_get_knob(b.h, KNOB_H1_BITS) == 0
+        for eng in engs:
+            eng.view("H1bits", torch.int32).zero_()
+            eng.stage_sample()
+            eng.stage_real_grads()
+        torch.cuda.synchronize()
+        assert int((a.view("H1bits", torch.int32) != 0).sum()) > 0          # engine a wrote (and read) the sign bits
+        assert int((b.view("H1bits", torch.int32) != 0).sum()) == 0         # engine b never did
+        assert torch.equal(a.view("gw_real"), b.view("gw_real"))            # same gradients either way (same blocks: same seed)
+        # the process default moves only the engine that has no value of its own
+        _lib.check(L.gs_gcond_set_knob(b.h, KNOB_H1_ROWS, 0))
+        _lib.check(L.gs_gcond_set_h1_rows(1))
+        assert L.gs_gcond_get_knob(a.h, KNOB_H1_ROWS) == 1 and L.gs_gcond_get_knob(b.h, KNOB_H1_ROWS) == 0
+        _lib.check(L.gs_gcond_set_knob(b.h, KNOB_H1_ROWS, -1))
+        assert L.gs_gcond_get_knob(b.h, KNOB_H1_ROWS) == 1
+        assert L.gs_gcond_set_knob(a.h, 99, 1) < 0 and L.gs_gcond_get_knob(None, 0) == -1
+    finally:
+        _lib.check(L.gs_gcond_set_h1_rows(1))
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x6"])
 def test_per_edge_sign_bits_of_the_hop2_gather_give_bitwise_the_same_real_side_gradients(mode):
     """VERDICT r03 "next" 2a: the hop-2 gather kernel has every gathered row of H1 = relu(X W1 + b1) in registers and writes its

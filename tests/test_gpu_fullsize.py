@@ -165,6 +165,19 @@ def test_cora_r10_full_size_generated_forms_at_width_128(epoch):
     check(run_config("cora-r1.0", epoch), adj_tol=1e-3 if epoch == 0 else 2e-4)
 
 
+def test_flickr_r0005_inductive_two_transforms_full_size():
+    """graphslim/configs/gcond/flickr.json: the one upstream configuration that combines the inductive setting (train sub-graph,
+    loader.py:125), two transforms and the wide fan-out [15, 8] (it had no full-size oracle test)."""
+    check(run_config("flickr", 10))
+    check(run_config("flickr", 0))
+
+
+def test_cora_r05_full_size():
+    """BASELINE configs[0]'s workload (Cora, r = 0.5 -> n' = 70) on the GPU path, feature- and PGE-update iterations."""
+    check(run_config("cora", 10))
+    check(run_config("cora", 0))
+
+
 def test_cora_r025_full_size():
     """BASELINE configs[1] in its fp32 form (the bf16 operand mode of the same config: test_gpu_operand_modes.py)."""
     check(run_config("cora-r0.25", 10))
