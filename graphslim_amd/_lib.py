@@ -73,7 +73,7 @@ SYMBOLS = [
     "gs_mix_heads_bwd_f32", "gs_sym_sigmoid_f32", "gs_sym_sigmoid_bwd_f32", "gs_bn_running_update_f32", "gs_bn_relu_eval_f32", "gs_ot_spectrum_f32",
     "gs_ot_value_f32", "gs_scale_cols_f32", "gs_ot_divdiff_f32", "gs_clamp_finite_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
     "gs_comm_unique_id", "gs_comm_create_rccl", "gs_comm_create_callback", "gs_comm_create_null", "gs_comm_destroy", "gs_comm_rank", "gs_comm_world",
-    "gs_comm_allreduce", "gs_comm_set_timing", "gs_comm_read_timing", "gs_gcond_outer_step_sharded", "gs_gcond_outer_step_sharded_ex",
+    "gs_comm_allreduce", "gs_comm_set_timing", "gs_comm_read_timing", "gs_comm_read_timing2", "gs_gcond_outer_step_sharded", "gs_gcond_outer_step_sharded_ex",
 ]
 
 # gs_allreduce_fn of include/gslim.h: int fn(void* user, void* buf, long count, int dtype, gs_stream_t stream)

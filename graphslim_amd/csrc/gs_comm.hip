@@ -171,16 +171,25 @@ extern "C" int gs_comm_set_timing(gs_comm* c, int on) {
 // calls / bytes / summed microseconds per exchange point since timing was switched on (arrays of GS_COMM_TAGS = 8; tags:
 // 0 BN-2 sums, 1 pair scores, 2 [dX~ | d adj | loss_c], 3 BN-2 backward sums, 4 marginals (+ dW1 | db1), 5 other).
 // Synchronises the recorded events.
-extern "C" int gs_comm_read_timing(gs_comm* c, long* calls, long* bytes, double* total_us) {
+// timed_calls (optional): per exchange point the number of calls total_us covers — the event pool holds GS_COMM_MAX_EVENTS pairs, calls
+// beyond it are counted in `calls` / `bytes` but not timed (dividing total_us by `calls` under-reported long windows)
+extern "C" int gs_comm_read_timing2(gs_comm* c, long* calls, long* bytes, double* total_us, long* timed_calls) {
   if (!c || !calls || !bytes || !total_us) GS_FAIL(GS_ERR_ARG, "gs_comm_read_timing: null argument");
-  for (int t = 0; t < GS_COMM_TAGS; ++t) { calls[t] = c->calls[t]; bytes[t] = c->bytes[t]; total_us[t] = 0.0; }
+  for (int t = 0; t < GS_COMM_TAGS; ++t) {
+    calls[t] = c->calls[t]; bytes[t] = c->bytes[t]; total_us[t] = 0.0;
+    if (timed_calls) timed_calls[t] = 0;
+  }
   for (int i = 0; i < c->n_ev; ++i) {
     float ms = 0.f;
     GS_HIP(hipEventSynchronize(c->ev[2 * i + 1]));
     GS_HIP(hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]));
     total_us[c->ev_tag[i]] += 1e3 * (double)ms;
+    if (timed_calls) timed_calls[c->ev_tag[i]] += 1;
   }
   return GS_OK;
+}
+extern "C" int gs_comm_read_timing(gs_comm* c, long* calls, long* bytes, double* total_us) {
+  return gs_comm_read_timing2(c, calls, bytes, total_us, nullptr);
 }
 
 // all-reduce(sum) in place on `stream`.  dtype: 0 = fp32, 1 = fp64.  tag: exchange point (bookkeeping only).

@@ -77,6 +77,7 @@ struct gs_gcond {
   int *marker, *kcount;
   int *h1_flag, *h1_list, *h1_count;   // rows of H1full this rank's sampled blocks gather (sharded ranks: only those are computed)
   unsigned* H1bits;                    // [N][h / 32] sign bits of H1full, written by its product's epilogue: the edge product's mask
+  double* sum_part;                    // [128] scratch of sum_f32
   int knob[GS_KNOB_COUNT];             // per-engine value of a measurement knob (gs_gcond_set_knob), -1 = follow the process default
   unsigned* edge_bits;                 // [C][cap1 * f2][h / 32] sign bits of the H1 row each hop-2 edge slot gathered (gs_ell_spmm_kernel): the
                                        // edge product reads its ReLU mask from these 32 B per edge instead of the 1-KiB row of H1full
@@ -242,6 +243,7 @@ static size_t carve(gs_gcond* e, void* base) {
     long nch_r = gs_cdiv(cap1 * f2, 256) > 72 ? gs_cdiv(cap1 * f2, 256) : 72;
     long nch_s = gs_cdiv(n, 256) > 72 ? gs_cdiv(n, 256) : 72;
     e->colpart = w.take<float>(C * nch_s * (h > 0 ? h : 1));
+    e->sum_part = w.take<double>(128);      // sum_f32's 128 partial sums (it used to borrow colpart, which tiny shapes undersize)
     e->colpart_r = w.take<float>(C * nch_r * (h > 0 ? h : 1));      // the real-side branch may run on its own stream
   }
   e->H1full = e->T == 2 ? w.take<float>(N * h) : nullptr;
@@ -765,7 +767,7 @@ __global__ __launch_bounds__(64) void gs_sum_stage2_kernel(const double* __restr
   if (threadIdx.x == 0) out[0] = (float)s;
 }
 static int sum_f32(gs_gcond* e, const float* x, long n, float* out, hipStream_t s) {
-  double* part = reinterpret_cast<double*>(e->colpart);      // (free here: its users ran earlier on this stream)
+  double* part = e->sum_part;
   hipLaunchKernelGGL(gs_sum_stage1_kernel, dim3(128), dim3(256), 0, s, x, n, part);
   hipLaunchKernelGGL(gs_sum_stage2_kernel, dim3(1), dim3(64), 0, s, (const double*)part, 128, out);
   GS_LAUNCH_CHECK();

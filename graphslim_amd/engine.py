@@ -20,7 +20,10 @@ METRICS = {"ours": 0, "mse": 1, "cos": 2}
 # ("bf16x6": every fp32 operand = h + m + l with 8 + 8 + 8 significant bits, six bf16 MFMA products, fp32 accumulation — fp32-level
 # error, measured <= the fp32 MFMA's own against fp64, every parity gate of the fp32 path incl. the headline-shape accuracy gate);
 # "f32" selects the fp32 matrix pipe (1/16 of the bf16 rate).  The C library's own default stays 0 = fp32.
+_OPERAND_MODE_NAMES = ("f32", "bf16x3", "bf16", "bf16x6")
 DEFAULT_OPERAND_MODE = os.environ.get("GS_OPERAND_MODE", "bf16x6")
+if DEFAULT_OPERAND_MODE not in _OPERAND_MODE_NAMES:      # (an unknown value used to reach ctypes as a str and fail there, opaquely)
+    raise ValueError(f"GS_OPERAND_MODE={DEFAULT_OPERAND_MODE!r}: expected one of {', '.join(_OPERAND_MODE_NAMES)}")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -456,6 +459,8 @@ class GCondEngine:
     def set_operand_mode(self, mode):
         """Operand form of the row-panel products (gs_gcond_set_operand_mode): 'f32' (fp32 MFMA), 'bf16x6' (DEFAULT_OPERAND_MODE: exact
         three-way bf16 split, 6 bf16 MFMAs, fp32 accumulate: fp32-level error), 'bf16x3' (two-way split, 3 MFMAs), 'bf16'."""
+        if mode not in self.OPERAND_MODES and mode not in self.OPERAND_MODES.values():
+            raise ValueError(f"operand mode {mode!r}: expected one of {', '.join(self.OPERAND_MODES)}")
         check(self.L.gs_gcond_set_operand_mode(self.h, self.OPERAND_MODES.get(mode, mode)))
         self.operand_mode = mode
 

@@ -188,9 +188,11 @@ class Comm:
 
     def timing_report(self):
         """{exchange point: {"calls", "bytes" (per call), "avg_us"}} since set_timing(True) (synchronises the recorded events)."""
-        calls, nbytes, us = (C.c_long * 8)(), (C.c_long * 8)(), (C.c_double * 8)()
-        check(lib().gs_comm_read_timing(self.h, calls, nbytes, us))
-        return {self.TAGS[t]: {"calls": calls[t], "bytes": nbytes[t] // max(calls[t], 1), "avg_us": round(us[t] / max(calls[t], 1), 2)}
+        calls, nbytes, us, timed = (C.c_long * 8)(), (C.c_long * 8)(), (C.c_double * 8)(), (C.c_long * 8)()
+        check(lib().gs_comm_read_timing2(self.h, calls, nbytes, us, timed))
+        # avg_us over the calls that WERE timed (the library's event pool is finite: "timed_calls" < "calls" says the window was longer)
+        return {self.TAGS[t]: {"calls": calls[t], "bytes": nbytes[t] // max(calls[t], 1), "avg_us": round(us[t] / max(timed[t], 1), 2),
+                               "timed_calls": timed[t]}
                 for t in range(8) if calls[t]}
 
     def __del__(self):

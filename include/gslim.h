@@ -364,9 +364,14 @@ int gs_gcond_adopt_cached_forward(gs_gcond* e, gs_stream_t stream);
  * runs on the second stream, the class gradients stay on the caller's stream; on = 0: one stream.  Results are identical;
  * measured 2.12 / 2.30 / 2.36 ms per iteration for 1 / 2 / 0 at the bench shape (profiles/r02/ab_overlap.txt). */
 int gs_gcond_set_overlap(gs_gcond* e, int on);
-/* Operand precision of the three row-panel products of the iteration (PGE layer 2 forward, its backward dY1, the SGC
- * transform H1 = relu(X W1 + b1)): 0 = exact fp32 (default = the reference's precision), 1 = split bf16 x3 with fp32
- * accumulation, 2 = bf16 operands (BASELINE.json configs[1]).  See gs_gemm_desc.prec.  Everything else stays fp32. */
+/* Operand form of the large contractions of the iteration (PGE layer 2 forward, its backward, dW1 in PGE epochs, the SGC
+ * transform H1 = relu(X W1 + b1), the real-side edge product): 0 = fp32 matrix pipe (the LIBRARY's default = the reference's
+ * arithmetic), 1 = two-way bf16 split, 3 products (operands to 2^-16), 2 = bf16 operands (BASELINE.json configs[1]), 3 = three-way
+ * bf16 split, 6 of the 9 cross products (operands represented exactly; the dropped terms and the fp32 accumulation leave an error
+ * measured equal to the fp32 pipe's, tests/test_gpu_panel.py — not bitwise fp32).  See gs_gemm_desc.prec.  Everything else stays
+ * fp32.  NOTE the split: a C caller gets mode 0 unless it asks; the Python host mirror (graphslim_amd.engine.DEFAULT_OPERAND_MODE,
+ * environment GS_OPERAND_MODE) selects 3 for every engine it creates, and bench.py's headline value is measured in mode 3 (its
+ * `dtype` field says so; `operand_modes` carries mode 0 beside it). */
 int gs_gcond_set_operand_mode(gs_gcond* e, int mode);
 /* Full-neighbour mode (dataset/loader.py:204 `sizes = [-1, -1]`, commented out upstream; SURVEY section 8e "mode F") for SGC with
  * ntrans = 1: the model is linear up to the softmax, so the 2-hop full-neighbourhood block product of a seed is row `seed` of
@@ -452,6 +457,8 @@ int gs_comm_world(const gs_comm* c);
 int gs_comm_allreduce(gs_comm* c, void* buf, long count, int dtype, int tag, gs_stream_t stream);
 int gs_comm_set_timing(gs_comm* c, int on);                           /* event pairs around every exchange from now on */
 int gs_comm_read_timing(gs_comm* c, long* calls, long* bytes, double* total_us);   /* host arrays [8]; synchronises */
+/* the same + timed_calls[8]: how many of `calls` total_us covers (the event pool holds 8 192 pairs; later calls are counted, not timed) */
+int gs_comm_read_timing2(gs_comm* c, long* calls, long* bytes, double* total_us, long* timed_calls);
 int gs_gcond_outer_step_sharded(gs_gcond* e, int epoch, gs_comm* comm, gs_stream_t stream);
 int gs_gcond_outer_step_sharded_ex(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_comm* comm,
                                    gs_stream_t stream);
