@@ -18,6 +18,7 @@ int gs_panel_marginals(const float*, long, const float*, long, const float*, lon
 int gs_dw1_generated(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*,
                      float*, long, int*, const float*, hipStream_t);
 int gs_pge_scale_uv(const float*, const float*, const float*, long, int, float*, float*, hipStream_t);
+int gs_gemm_group2_f32(const gs_gemm_desc* descs, const gs_gemm_desc* second, int n, gs_stream_t stream);
 int gs_panel_forward_a1(const gs_panel_a1*, int, int, const float*, long, const float*, float*, long, int, int, float*, int*, int, void*,
                         unsigned long long*, int, hipStream_t);
 int gs_panel_tiles(int);
@@ -1482,6 +1483,9 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     if (e->T == 2) GS_HIP(hipMemsetAsync(e->d_feat, 0, sizeof(float) * (long)n * d, s));
   }
   const float* Dl = Dv + e->oWl;   // + c*P : d/d gWl_c
+  // two-segment / regrouped launches of the second-order chain (VERDICT r03 "next" 5), same knob as the fused inner steps
+  const bool merge = knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && !e->blk_pos;
+  bool ds_done = false;
   if (Cl > 0) {
     float* dH2 = e->T == 2 ? e->dH2 + c0 * n * C : nullptr; float* dHp = e->T == 2 ? e->dHp + c0 * n * h : nullptr;
     float* A1m = e->T == 2 ? e->A1m + c0 * n * h : nullptr; float* Bc = e->T == 2 ? e->Bc + c0 * n * C : nullptr;
@@ -1540,21 +1544,43 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       // Ug[lo:hi] = Q[lo:hi] Bc_c + S[lo:hi] D2_c
       qu[1] = mk(e->Q, n, 1, Bc, C, 1, e->Ug, C, mx, C, n);
       qu[1].nb1 = Cl; qu[1].offA = off_lon; qu[1].Mb = ncls; qu[1].sBb1 = (long)n * C; qu[1].offC = off_loC;
-      GS_TRY(gs_gemm_group_f32(qu, 2, stream));
       gs_gemm_desc u2 = mk(e->Ss, F, 1, Dl, C, 1, e->Ug, C, mx, C, F);
       u2.nb1 = Cl; u2.offA = off_loF; u2.Mb = ncls; u2.sBb1 = P; u2.offC = off_loC; u2.beta = 1.f;
-      GS_TRY(gs_gemm_f32(&u2, stream));
+      if (merge) {
+        // one launch: dQ ; Ug = Q Bc followed by Ug += S D2 in the workgroup that owns the tile ; dS[lo:hi] = G Dl_c^T (reads only G
+        // and D: it used to sit behind the V kernel) — bitwise the launch-per-product values (gs_gemm_group2_f32)
+        gs_gemm_desc m3[3], s3[3];
+        m3[0] = qu[0]; m3[1] = qu[1];
+        m3[2] = mk(e->Gs, C, 1, Dl, 1, C, e->dSs, F, mx, F, C);
+        m3[2].nb1 = Cl; m3[2].offA = off_loC; m3[2].Mb = ncls; m3[2].sBb1 = P; m3[2].offC = off_loF;
+        memset(s3, 0, sizeof(s3));
+        s3[1] = u2;
+        GS_TRY(gs_gemm_group2_f32(m3, s3, 3, stream));
+        ds_done = true;
+      } else {
+        GS_TRY(gs_gemm_group_f32(qu, 2, stream));
+        GS_TRY(gs_gemm_f32(&u2, stream));
+      }
     } else {
       gs_gemm_desc u = mk(e->Ss, F, 1, Dl, C, 1, e->Ug, C, mx, C, F);
       u.nb1 = Cl; u.offA = off_loF; u.Mb = ncls; u.sBb1 = P; u.offC = off_loC;
-      GS_TRY(gs_gemm_f32(&u, stream));
+      if (merge) {      // {Ug = S D2, dS[lo:hi] = G Dl_c^T}: independent, one launch
+        gs_gemm_desc m2[2];
+        m2[0] = u;
+        m2[1] = mk(e->Gs, C, 1, Dl, 1, C, e->dSs, F, mx, F, C);
+        m2[1].nb1 = Cl; m2[1].offA = off_loC; m2[1].Mb = ncls; m2[1].sBb1 = P; m2[1].offC = off_loF;
+        GS_TRY(gs_gemm_group_f32(m2, 2, stream));
+        ds_done = true;
+      } else {
+        GS_TRY(gs_gemm_f32(&u, stream));
+      }
     }
   }
   hipLaunchKernelGGL(gs_syn_v_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Ps, e->Gs, e->Ug, e->rsq, e->D, P, e->obl, bl,
                      e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->c_lo, e->c_hi, e->Vs, e->drs);
   GS_LAUNCH_CHECK();
   {  // dS[lo:hi] = G[lo:hi] Dl_c^T ;  dS += V Wl^T
-    if (Cl > 0) {
+    if (Cl > 0 && !ds_done) {
       gs_gemm_desc a = mk(e->Gs, C, 1, Dl, 1, C, e->dSs, F, mx, F, C);
       a.nb1 = Cl; a.offA = off_loC; a.Mb = ncls; a.sBb1 = P; a.offC = off_loF;
       GS_TRY(gs_gemm_f32(&a, stream));
@@ -1595,10 +1621,14 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     GS_TRY(block_dadj(e, A, e->dQ, e->dAn, stream));
   } else {  // dA^ = dQ A^T + A^T dQ ; then through dense_gcn_norm (both linear in dQ: partial sums stay partial sums)
     gs_gemm_desc a = mk(e->dQ, n, 1, A, 1, n, e->dAn, n, n, n, n);
-    GS_TRY(gs_gemm_f32(&a, stream));
     gs_gemm_desc b = mk(A, 1, n, e->dQ, n, 1, e->dAn, n, n, n, n);
     b.beta = 1.f;
-    GS_TRY(gs_gemm_f32(&b, stream));
+    if (merge) {
+      GS_TRY(gs_gemm_group2_f32(&a, &b, 1, stream));
+    } else {
+      GS_TRY(gs_gemm_f32(&a, stream));
+      GS_TRY(gs_gemm_f32(&b, stream));
+    }
   }
   if (e->identity) return GS_OK;     // adj_syn is the constant identity: nothing upstream of A^
   return gs_dense_gcn_norm_bwd(e->adj_raw, e->rnorm, e->dAn, n, e->d_adj, stream);

@@ -414,6 +414,16 @@ struct gs_gemm_group_arg {
   int z0[GS_GROUP_MAX + 1];   // first blockIdx.z of each group
   int n;
 };
+// the same with an optional SECOND product per member that accumulates into the member's output (beta = 1, same M / N / batching /
+// output addressing): C = A1 B1 ; C += A2 B2 by the workgroup that owns the tile — the thread that stored an element of the first
+// product is the one that reads it back for the second, so the result is bitwise that of two dependent launches
+struct gs_gemm_group2_arg {
+  gs_gemm_desc d[GS_GROUP_MAX];
+  gs_gemm_desc d2[GS_GROUP_MAX];
+  int z0[GS_GROUP_MAX + 1];
+  int has2[GS_GROUP_MAX];
+  int n;
+};
 
 __device__ __forceinline__ void gs_small_any(const gs_gemm_desc& p, int b, float (&red)[4][16][64]) {
   const bool av = p.sAk == 1, bv = p.sBk == 1;   // block-uniform
@@ -430,6 +440,20 @@ __global__ __launch_bounds__(256) void gs_gemm_small_group_kernel(gs_gemm_group_
   else if (z < g.z0[2]) gs_small_any(g.d[1], z - g.z0[1], red);
   else if (z < g.z0[3]) gs_small_any(g.d[2], z - g.z0[2], red);
   else gs_small_any(g.d[3], z - g.z0[3], red);
+}
+
+__global__ __launch_bounds__(256) void gs_gemm_small_group2_kernel(gs_gemm_group2_arg g) {
+  __shared__ float red[4][16][64];
+  const int z = blockIdx.z;
+  int i = 0;
+  if (z >= g.z0[3]) i = 3;
+  else if (z >= g.z0[2]) i = 2;
+  else if (z >= g.z0[1]) i = 1;
+  gs_small_any(g.d[i], z - g.z0[i], red);
+  if (g.has2[i]) {
+    __syncthreads();      // the partial-sum scratch is reused (and this thread's own stores of the first product are ordered before its loads)
+    gs_small_any(g.d2[i], z - g.z0[i], red);
+  }
 }
 
 bool gs_edge_eligible(const gs_gemm_desc& p);             // gs_edge.hip
@@ -677,6 +701,54 @@ extern "C" int gs_gemm_f32(const gs_gemm_desc* d, gs_stream_t stream) {
     case 2: return launch_gemm<64, 64, 32, 32>(p, nbatch, s);
     default: return launch_gemm<128, 128, 64, 64>(p, nbatch, s);   // (128x64 / 64x128 at 4 waves/SIMD measured within +-5 %)
   }
+}
+
+static bool small_route(const gs_gemm_desc& p, int nbatch);
+// engine-internal: members descs[i] (mutually independent) with an optional dependent second product second[i] (second[i].A == null:
+// none) accumulating into the same output with beta = 1.  One launch when everything is routed to the latency-oriented kernel,
+// otherwise the same products one launch after the other — bitwise the same values either way.
+int gs_gemm_group2_f32(const gs_gemm_desc* descs, const gs_gemm_desc* second, int n, gs_stream_t stream) {
+  if (n <= 0) return GS_OK;
+  bool groupable = n <= GS_GROUP_MAX;
+  gs_gemm_group2_arg a;
+  int gx = 1, gy = 1, z = 0;
+  long valid = 0;
+  for (int i = 0; groupable && i < n; ++i) {
+    gs_gemm_desc p = descs[i];
+    if (!p.A || !p.B || !p.C || p.K < 0) { groupable = false; break; }
+    if (p.nb1 < 1) p.nb1 = 1;
+    if (p.nb2 < 1) p.nb2 = 1;
+    const int nbatch = p.nb1 * p.nb2;
+    if (p.M <= 0 || p.N <= 0 || !small_route(p, nbatch)) { groupable = false; break; }
+    a.d[i] = p; a.has2[i] = 0; a.d2[i] = p;
+    if (second && second[i].A) {
+      gs_gemm_desc q = second[i];
+      if (q.nb1 < 1) q.nb1 = 1;
+      if (q.nb2 < 1) q.nb2 = 1;
+      if (q.C != p.C || q.M != p.M || q.N != p.N || q.nb1 != p.nb1 || q.nb2 != p.nb2 || q.ldc != p.ldc || q.sCb1 != p.sCb1 || q.sCb2 != p.sCb2 ||
+          q.offC != p.offC || q.Mb != p.Mb || q.beta != 1.f || q.kchunk > 0 || p.kchunk > 0 || !small_route(q, nbatch)) { groupable = false; break; }
+      a.d2[i] = q; a.has2[i] = 1;
+    }
+    a.z0[i] = z;
+    z += nbatch;
+    valid += (long)gs_cdiv(p.N, 32) * gs_cdiv(p.M, 32) * nbatch;
+    gx = gx > gs_cdiv(p.N, 32) ? gx : gs_cdiv(p.N, 32);
+    gy = gy > gs_cdiv(p.M, 32) ? gy : gs_cdiv(p.M, 32);
+  }
+  if (groupable && (z > 65535 || (long)gx * gy * z > 4 * valid)) groupable = false;
+  if (!groupable) {
+    for (int i = 0; i < n; ++i) {
+      GS_TRY(gs_gemm_f32(&descs[i], stream));
+      if (second && second[i].A) GS_TRY(gs_gemm_f32(&second[i], stream));
+    }
+    return GS_OK;
+  }
+  for (int i = n; i <= GS_GROUP_MAX; ++i) a.z0[i] = z;
+  for (int i = n; i < GS_GROUP_MAX; ++i) { a.d[i] = a.d[0]; a.d2[i] = a.d[0]; a.has2[i] = 0; }
+  a.n = n;
+  hipLaunchKernelGGL(gs_gemm_small_group2_kernel, dim3(gx, gy, z), dim3(256), 0, (hipStream_t)stream, a);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
 }
 
 // Independent products in one launch when every one of them is routed to the latency-oriented kernel; otherwise (or for a

@@ -203,3 +203,69 @@ def test_exact_three_way_split_has_the_error_of_the_fp32_mfma(E, M, K, N):
           f"3-way split {errs['bf16x6'][0]:.3e} / {errs['bf16x6'][1]:.3e}")
     assert errs["bf16x6"][0] <= 1.5 * errs["f32"][0] + 1.2e-7, errs
     assert errs["bf16x6"][1] <= 1.5 * errs["f32"][1], errs
+
+
+# ---- round 4: the persistent 256-row kernels of csrc/gs_panel2.hip against the 128-row kernels of csrc/gs_panel.hip ----------------
+@pytest.mark.parametrize("M,K", [(206116, 256), (169343, 128), (2053, 64), (4096 + 37, 256), (300, 128), (64 * 4 * 3 + 1, 512)])
+def test_tall_plain_product_is_bitwise_the_128_row_kernel(E, M, K):
+    """Same 16-k sub-blocks in the same order, same six products small-terms-first: the persistent 256-row kernel (full, 128-row and
+    64-row tiles, ragged last rows dropped by the buffer stores' bounds check) gives bitwise the 128-row kernel's product."""
+    from graphslim_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(M + K)
+    A, W, b = torch.randn(M, K, device=DEV), torch.randn(256, K, device=DEV) / np.sqrt(K), torch.randn(256, device=DEV)
+    try:
+        L.gs_gemm_set_panel_tall(0)
+        ref = run(E, A, W, 3, bias=b, relu=1)
+        L.gs_gemm_set_panel_tall(1)
+        got = run(E, A, W, 3, bias=b, relu=1)
+    finally:
+        L.gs_gemm_set_panel_tall(1)
+    assert not torch.isnan(got).any()
+    assert torch.equal(got, ref), (M, K, int((got != ref).sum()))
+    want = (A.double() @ W.double().T + b.double()).clamp_min(0)
+    assert err(got, want) <= 2e-6
+
+
+@pytest.mark.parametrize("workload", ["ogbn-arxiv", "reddit"])
+def test_tall_forward_and_marginals_against_the_128_row_kernels(workload):
+    """PGE layer-2 forward with the generated operand and the fused marginals of its backward on the persistent 256-row kernels (all
+    call sites: mask 16 + 15) against the 128-row kernels (off).  Both use the folded layer-1 form max(Us[c] + Vs[r], 0) in this mode,
+    so E2 is bitwise equal; the BatchNorm-2 partial sums are grouped per workgroup instead of per tile (statistics equal to fp32
+    summation order), and on ONE forward state the fused marginals are bitwise equal."""
+    import bench
+    from graphslim_amd import _lib
+    L = _lib.lib()
+    p = bench.build_problem(workload, seed=1)
+    eng = bench.make_engine(p, DEV)
+    bench.init_state(p, eng)
+    bench.new_model(p, eng)
+    eng.set_operand_mode("bf16x6")
+    eng.outer_step(10)
+    res = {}
+    try:
+        for tall in (0, 31):
+            L.gs_gemm_set_panel_tall(tall)
+            for part in (1, 2, 3):
+                eng.pge_forward_part(False, part)
+            torch.cuda.synchronize()
+            res[tall] = (eng.buffer("E2").clone(), eng.buffer("mu2").clone(), eng.buffer("is2").clone(), eng.buffer("e3").clone())
+            if tall == 0:
+                eng.stage_syn_match()
+                eng.pge_backward_part(False, True, 1)
+                margs = []
+                for tb in (0, 31):
+                    L.gs_gemm_set_panel_tall(tb)
+                    eng.view("ar_marg").fill_(float("nan"))
+                    eng.pge_backward_part(False, True, 2)
+                    torch.cuda.synchronize()
+                    margs.append(eng.view("ar_marg").clone())
+                n, ph = eng.shapes.n_syn, eng.shapes.pge_hidden
+                a, b = margs[0][:2 * n * ph], margs[1][:2 * n * ph]
+                assert not torch.isnan(b).any() and torch.equal(a, b), int((a != b).sum())
+    finally:
+        L.gs_gemm_set_panel_tall(1)
+    (e0, mu0, is0, s0), (e1, mu1, is1, s1) = res[0], res[31]
+    assert torch.equal(e0, e1), int((e0 != e1).sum())
+    assert float(((mu0 - mu1).abs() / (mu0.abs() + 1e-3)).max()) <= 1e-5 and float(((is0 - is1).abs() / is0.abs()).max()) <= 1e-6
+    assert float((s0 - s1).abs().max()) <= 1e-5 * float(s0.abs().max())
