@@ -4,9 +4,8 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/${1:-acc4}
 mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_reduce.py -x -q -m gpu -s -k "job_level_accuracy" > $O/test_job_level_accuracy.log 2>&1
-tail -4 $O/test_job_level_accuracy.log
-for s in $(seq 1 ${2:-15}); do
+if [ -z "$4" ]; then timeout 900 python -m pytest tests/test_gpu_reduce.py -x -q -m gpu -s -k "job_level_accuracy_against" > $O/test_job_level_accuracy.log 2>&1; tail -4 $O/test_job_level_accuracy.log; fi
+for s in $(seq ${3:-1} ${2:-15}); do
   for g in 1 0; do
     GS_DW1_GEN=$g GRAPHSLIM_AMD_SYNTHETIC=1 timeout 200 python tools/full_runs.py ogbn-arxiv:0.005:seed$s 2>/dev/null | grep FULL | sed "s/^FULL/FULL dw1_generated=$g/" >> $O/full_runs_dw1_ab.txt
   done
