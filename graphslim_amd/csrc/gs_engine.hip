@@ -7,6 +7,7 @@
 #include <new>
 
 #include "gs_kernels.h"
+#include "gs_match.h"
 
 extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int, long, int, float, gs_stream_t);
 extern "C" int gs_reduce_slabs_f32(float*, const float*, long, int, long, float, gs_stream_t);
@@ -363,6 +364,7 @@ static int g_defer_last_stage = 1;  // gs_gcond_set_folded_reductions
 static int g_edge_bits = 0;         // the hop-2 gather also writes per-edge sign bits and the edge product reads those (0: the mask rows of H1full)
 static int g_h1_bits = 0;
 static int g_h1_rows = 1;
+static int g_match_class = 1;      // per-class products of the synthetic match as two chained launches (gs_match.hip); 0 = the batched products
 // measurement / test knob: 1 (default) = PGE epochs run the backward of layer 2 on generated operands (marginals as in feature epochs,
 // dW1 | db1 by gs_dw1_gen_kernel); 0 = dE2 and A1 are materialised for a general tiled product (round 2's form)
 extern "C" int gs_gcond_set_dw1_generated(int on) {
@@ -633,7 +635,7 @@ extern "C" int gs_gcond_set_knob(gs_gcond* e, int knob, int value) {
 }
 extern "C" int gs_gcond_get_knob(const gs_gcond* e, int knob) {
   if (!e || knob < 0 || knob >= GS_KNOB_COUNT) return -1;
-  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage};
+  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_match_class};
   return knob_of(e, knob, def[knob]);
 }
 
@@ -1336,6 +1338,25 @@ extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_
   return gs_gcond_stage_pge_forward_part(e, inference, 3, stream);
 }
 
+// match_loss of this rank's Cl classes and D = d loss / d gw_syn (condensation/utils.py:12-106): one launch (a workgroup per class)
+// when the chains are fused and the per-class statistics row fits its LDS image, else statistics / finalize / apply
+static int match_distance(gs_gcond* e, const float* gwr, const float* gws, float* stats, float* ab, float* Dv, int Cl, hipStream_t s) {
+  const long P = e->P, c0 = e->c_lo;
+  if (Cl <= 0) return GS_OK;
+  if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && e->pd.total_cols <= GS_DIST_FUSED_COLS) {
+    hipLaunchKernelGGL(gs_dist_fused_kernel, dim3(Cl), dim3(1024), 0, s, gwr, gws, P, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
+                       e->io.syn_hi + c0, e->n, ab, e->loss_c + c0, Dv, (const float*)e->bn_s2);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+  }
+  hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, Cl), dim3(256), 0, s, gwr, gws, P, e->pd, stats);
+  hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(Cl), dim3(256), 0, s, stats, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
+                     e->io.syn_hi + c0, e->n, ab, e->loss_c + c0, (const float*)e->bn_s2);
+  hipLaunchKernelGGL(gs_dist_apply_kernel, dim3(gs_cdiv((long)Cl * P, 256)), dim3(256), 0, s, gwr, gws, P, e->pd, ab, Dv, Cl);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 // ================================================================================================
 // stage: synthetic side — gw_syn per class, matching loss, closed-form d loss / d X~ (direct path)
 // and d loss / d A^ -> d adj     (gcond_base.py:226-239 + autograd through them).
@@ -1393,11 +1414,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       if (e->cfg.dis_metric != 0) GS_TRY(colsum_batched(e, dHp, (long)n * h, n, nullptr, h, Cl, gws + e->ob1, P, stream));
       float* stats = e->stats + c0 * e->pd.total_cols * 3; float* ab = e->ab + c0 * e->pd.total_cols * 2;
       if (e->join_pending) { GS_HIP(hipStreamWaitEvent(s, e->ev_join, 0)); e->join_pending = false; }
-      hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, Cl), dim3(256), 0, s, gwr, gws, P, e->pd, stats);
-      hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(Cl), dim3(256), 0, s, stats, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
-                         e->io.syn_hi + c0, n, ab, e->loss_c + c0, (const float*)e->bn_s2);
-      hipLaunchKernelGGL(gs_dist_apply_kernel, dim3(gs_cdiv((long)Cl * P, 256)), dim3(256), 0, s, gwr, gws, P, e->pd, ab, Dv, Cl);
-      GS_LAUNCH_CHECK();
+      GS_TRY(match_distance(e, gwr, gws, stats, ab, Dv, Cl, s));
       // A1m_c = (S1 D1_c + Db1_c) * mask ; dS1 slabs_c = dH1p_c D1_c^T ; dA[lo:hi] = T[lo:hi] A1m_c^T ; R[lo:hi] = A[lo:hi] A1m_c
       gs_gemm_desc mx2[2];
       mx2[0] = mk(e->S1, d, 1, Dv + e->oW1, h, 1, A1m, h, n, h, d);
@@ -1489,6 +1506,8 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   if (Cl > 0) {
     float* dH2 = e->T == 2 ? e->dH2 + c0 * n * C : nullptr; float* dHp = e->T == 2 ? e->dHp + c0 * n * h : nullptr;
     float* A1m = e->T == 2 ? e->A1m + c0 * n * h : nullptr; float* Bc = e->T == 2 ? e->Bc + c0 * n * C : nullptr;
+    // two chained launches for the per-class products of the two-transform model (gs_match.hip) instead of six batched ones
+    const bool mclass = e->T == 2 && knob_of(e, GS_KNOB_MATCH_CLASS, g_match_class) && !e->blk_pos && gs_match_class_eligible(n, h, d, C);
     {
       // gWl_c, gbl_c and (T = 2) dH2_c = Q[lo:hi]^T G[lo:hi] only read G: one launch
       gs_gemm_desc g3[3];
@@ -1496,13 +1515,22 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       g3[0].nb1 = Cl; g3[0].offA = off_loF; g3[0].offB = off_loC; g3[0].Kb = ncls; g3[0].sCb1 = P;
       g3[1] = mk(e->rsq, 0, 1, e->Gs, C, 1, gws + e->obl, C, 1, C, mx);
       g3[1].nb1 = Cl; g3[1].offA = off_lo; g3[1].offB = off_loC; g3[1].Kb = ncls; g3[1].sCb1 = P;
-      if (e->T == 2) {
+      if (e->T == 2 && !mclass) {
         g3[2] = mk(e->Q, 1, n, e->Gs, C, 1, dH2, C, n, C, mx);
         g3[2].nb1 = Cl; g3[2].offA = off_lon; g3[2].offB = off_loC; g3[2].Kb = ncls; g3[2].sCb1 = (long)n * C;
       }
-      GS_TRY(gs_gemm_group_f32(g3, e->T == 2 ? 3 : 2, stream));
+      GS_TRY(gs_gemm_group_f32(g3, e->T == 2 && !mclass ? 3 : 2, stream));
     }
-    if (e->T == 2) {
+    if (mclass) {
+      // T = G Wl^T once (rows partition by class), then dHp_c = (Q[lo:hi]^T T[lo:hi]) * mask ; gW1_c = X^T dHp_c ; gb1_c in ONE launch
+      float* Tm = e->A1m;      // (the A1m_c buffers are not written on this path)
+      gs_gemm_desc t = mk(e->Gs, C, 1, Wl, 1, C, Tm, h, n, h, C);
+      GS_TRY(gs_gemm_f32(&t, stream));
+      gs_match1_args a1;
+      a1.Q = e->Q; a1.T = Tm; a1.mask = e->H1s; a1.X = X; a1.lo = off_lo; a1.nc = ncls; a1.dHp = dHp; a1.s_dhp = (long)n * h;
+      a1.gW1 = gws + e->oW1; a1.s_gw = P; a1.gb1 = e->cfg.dis_metric != 0 ? gws + e->ob1 : nullptr; a1.n = n; a1.h = h; a1.d = d; a1.ldx = d;
+      GS_TRY(gs_match_first(&a1, Cl, s));
+    } else if (e->T == 2) {
       // dHp_c = (dH2_c W2^T) * mask ; gW1_c = X^T dHp_c ; gb1_c = colsum
       gs_gemm_desc b = mk(dH2, C, 1, Wl, 1, C, dHp, h, n, h, C);
       b.nb1 = Cl; b.sAb1 = (long)n * C; b.sCb1 = (long)n * h; b.mask = e->H1s; b.ldmask = h;
@@ -1518,25 +1546,29 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       e->join_pending = false;
     }
     float* stats = e->stats + c0 * e->pd.total_cols * 3; float* ab = e->ab + c0 * e->pd.total_cols * 2;
-    hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, Cl), dim3(256), 0, s, gwr, gws, P, e->pd, stats);
-    hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(Cl), dim3(256), 0, s, stats, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
-                       e->io.syn_hi + c0, n, ab, e->loss_c + c0, (const float*)e->bn_s2);
-    hipLaunchKernelGGL(gs_dist_apply_kernel, dim3(gs_cdiv((long)Cl * P, 256)), dim3(256), 0, s, gwr, gws, P, e->pd, ab, Dv, Cl);
-    GS_LAUNCH_CHECK();
+    GS_TRY(match_distance(e, gwr, gws, stats, ab, Dv, Cl, s));
     // ---- second-order backward, per-class part ------------------------------------------------------
     if (e->T == 2) {
       // A1m_c = (X D1_c + Db1_c) * mask ; dX slabs_c = dHp_c D1_c^T ; Bc = A1m_c W2
-      gs_gemm_desc ax[2];
-      ax[0] = mk(X, d, 1, Dv + e->oW1, h, 1, A1m, h, n, h, d);
-      ax[0].nb1 = Cl; ax[0].sBb1 = P; ax[0].sCb1 = (long)n * h; ax[0].bias = Dv + e->ob1; ax[0].sbias_b1 = P; ax[0].mask = e->H1s;
-      ax[0].ldmask = h;
-      ax[1] = mk(dHp, h, 1, Dv + e->oW1, 1, h, e->slabs_x, d, n, d, h);
-      ax[1].nb1 = Cl; ax[1].sAb1 = (long)n * h; ax[1].sBb1 = P; ax[1].sCb1 = (long)n * d;
-      GS_TRY(gs_gemm_group_f32(ax, 2, stream));          // independent of each other
-      GS_TRY(gs_reduce_slabs_f32(e->d_feat, e->slabs_x, (long)n * d, Cl, (long)n * d, 0.f, stream));
-      gs_gemm_desc b = mk(A1m, h, 1, Wl, C, 1, Bc, C, n, C, h);
-      b.nb1 = Cl; b.sAb1 = (long)n * h; b.sCb1 = (long)n * C;
-      GS_TRY(gs_gemm_f32(&b, stream));
+      if (mclass) {      // one launch; A1m_c stays in the accumulator registers of the wave that feeds it to Bc
+        gs_match2_args a2;
+        a2.X = X; a2.D = Dv; a2.mask = e->H1s; a2.Wl = Wl; a2.dHp = dHp; a2.sD = P; a2.oW1 = e->oW1; a2.ob1 = e->ob1; a2.s_dhp = (long)n * h;
+        a2.Bc = Bc; a2.s_bc = (long)n * C; a2.slabs = e->slabs_x; a2.s_slab = (long)n * d; a2.n = n; a2.h = h; a2.d = d; a2.ldx = d; a2.C = C;
+        GS_TRY(gs_match_second(&a2, Cl, s));
+        GS_TRY(gs_reduce_slabs_f32(e->d_feat, e->slabs_x, (long)n * d, Cl, (long)n * d, 0.f, stream));
+      } else {
+        gs_gemm_desc ax[2];
+        ax[0] = mk(X, d, 1, Dv + e->oW1, h, 1, A1m, h, n, h, d);
+        ax[0].nb1 = Cl; ax[0].sBb1 = P; ax[0].sCb1 = (long)n * h; ax[0].bias = Dv + e->ob1; ax[0].sbias_b1 = P; ax[0].mask = e->H1s;
+        ax[0].ldmask = h;
+        ax[1] = mk(dHp, h, 1, Dv + e->oW1, 1, h, e->slabs_x, d, n, d, h);
+        ax[1].nb1 = Cl; ax[1].sAb1 = (long)n * h; ax[1].sBb1 = P; ax[1].sCb1 = (long)n * d;
+        GS_TRY(gs_gemm_group_f32(ax, 2, stream));          // independent of each other
+        GS_TRY(gs_reduce_slabs_f32(e->d_feat, e->slabs_x, (long)n * d, Cl, (long)n * d, 0.f, stream));
+        gs_gemm_desc b = mk(A1m, h, 1, Wl, C, 1, Bc, C, n, C, h);
+        b.nb1 = Cl; b.sAb1 = (long)n * h; b.sCb1 = (long)n * C;
+        GS_TRY(gs_gemm_f32(&b, stream));
+      }
       // dQ[lo:hi] = G[lo:hi] Bc_c^T
       gs_gemm_desc qu[2];
       qu[0] = mk(e->Gs, C, 1, Bc, 1, C, e->dQ, n, mx, n, C);

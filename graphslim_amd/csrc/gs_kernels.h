@@ -405,6 +405,168 @@ __global__ void gs_dist_apply_kernel(const float* __restrict__ gw_real, const fl
   D[idx] = o[0] * gw_real[idx] + o[1] * gw_syn[idx];
 }
 
+// The three launches above as ONE (a workgroup of 1024 threads per class: statistics -> (alpha, beta) and the class's loss -> D): the
+// per-class parameter vector is ~170 KB, so the second pass over gw_real / gw_syn hits L2, and two launch latencies leave the
+// critical path between the stream join and the second-order products.  Same formulas; the column sums are grouped differently
+// (1024 / CB row groups instead of 256 / CB), so values agree with the three-launch form to fp32 re-association.
+// Requires total_cols <= GS_DIST_FUSED_COLS.
+#define GS_DIST_FUSED_COLS 1024
+__global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __restrict__ gw_real, const float* __restrict__ gw_syn,
+                                                             long P_total, gs_pdesc pd, int metric, const int* __restrict__ syn_lo,
+                                                             const int* __restrict__ syn_hi, int n_syn, float* __restrict__ ab,
+                                                             float* __restrict__ loss_c, float* __restrict__ D,
+                                                             const float* __restrict__ colscale2) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const float* R0 = gw_real + (long)c * P_total;
+  const float* S0 = gw_syn + (long)c * P_total;
+  __shared__ float sh[3][1024 * 4];
+  __shared__ float st[GS_DIST_FUSED_COLS][3];
+  __shared__ float abl[GS_DIST_FUSED_COLS][2];
+  __shared__ double red[3][1024];
+  const int nc = syn_hi[c] - syn_lo[c];
+  const float coeff = (float)nc / (float)n_syn;
+  // ---- column statistics into LDS
+  for (int p = 0; p < pd.nparams; ++p) {
+    const int rows = pd.rows[p], cols = pd.cols[p];
+    const float* R = R0 + pd.off[p];
+    const float* S = S0 + pd.off[p];
+    if (metric == 0 && pd.is_bias[p]) {      // 'ours' skips one-dimensional parameters (utils.py:86-88): (alpha, beta) = 0 below
+      for (int k = tid; k < cols; k += 1024) { st[pd.col_off[p] + k][0] = 0.f; st[pd.col_off[p] + k][1] = 0.f; st[pd.col_off[p] + k][2] = 0.f; }
+      continue;
+    }
+    if ((cols & 3) == 0 && cols >= 16) {
+      const int Q = cols >> 2;
+      int CB = 1;
+      while (CB < Q && CB < 1024) CB <<= 1;
+      const int tx = tid % CB, ty = tid / CB, nty = 1024 / CB;
+      for (int q0 = 0; q0 < Q; q0 += CB) {
+        const int q = q0 + tx;
+        float dot[4] = {0.f, 0.f, 0.f, 0.f}, nr2[4] = {0.f, 0.f, 0.f, 0.f}, ns2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (q < Q)
+#pragma unroll 4
+          for (int i = ty; i < rows; i += nty) {
+            const gs_f32x4u r = *reinterpret_cast<const gs_f32x4u*>(R + (long)i * cols + 4 * q);
+            const gs_f32x4u s_ = *reinterpret_cast<const gs_f32x4u*>(S + (long)i * cols + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              dot[e] = fmaf(r[e], s_[e], dot[e]);
+              nr2[e] = fmaf(r[e], r[e], nr2[e]);
+              ns2[e] = fmaf(s_[e], s_[e], ns2[e]);
+            }
+          }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sh[0][tid * 4 + e] = dot[e];
+          sh[1][tid * 4 + e] = nr2[e];
+          sh[2][tid * 4 + e] = ns2[e];
+        }
+        __syncthreads();
+        // 12 sums per column quad, each over the nty row groups in order: one thread per (quad, statistic, element)
+        for (int u = tid; u < CB * 12; u += 1024) {
+          const int qq = u / 12, w = u - qq * 12, which = w >> 2, e = w & 3;
+          if (q0 + qq < Q) {
+            float a = 0.f;
+            for (int g = 0; g < nty; ++g) a += sh[which][(g * CB + qq) * 4 + e];
+            st[pd.col_off[p] + 4 * (q0 + qq) + e][which] = a;
+          }
+        }
+        __syncthreads();
+      }
+    } else {
+      // narrow parameter (a bias is [len x 1]): every thread takes strided rows of one column, tree sum over the block in a fixed order
+      for (int k = 0; k < cols; ++k) {
+        float dot = 0.f, nr2 = 0.f, ns2 = 0.f;
+        for (int i = tid; i < rows; i += 1024) {
+          const float r = R[(long)i * cols + k], s = S[(long)i * cols + k];
+          dot = fmaf(r, s, dot);
+          nr2 = fmaf(r, r, nr2);
+          ns2 = fmaf(s, s, ns2);
+        }
+        sh[0][tid] = dot; sh[1][tid] = nr2; sh[2][tid] = ns2;
+        __syncthreads();
+        for (int w = 512; w > 0; w >>= 1) {
+          if (tid < w) { sh[0][tid] += sh[0][tid + w]; sh[1][tid] += sh[1][tid + w]; sh[2][tid] += sh[2][tid + w]; }
+          __syncthreads();
+        }
+        if (tid < 3) st[pd.col_off[p] + k][tid] = sh[tid][0];
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+  // ---- (alpha, beta) per column and the class's loss (the arithmetic of gs_dist_finalize_kernel)
+  double l = 0.0, sd = 0.0, sr = 0.0, ss = 0.0;
+  for (int p = 0; p < pd.nparams; ++p)
+    for (int k = tid; k < pd.cols[p]; k += 1024) {
+      const int ci = pd.col_off[p] + k;
+      float dot = st[ci][0], nr2 = st[ci][1], ns2 = st[ci][2];
+      const float sc2 = (colscale2 && p == 0) ? colscale2[k] : 1.f;
+      dot *= sc2; nr2 *= sc2; ns2 *= sc2;
+      float a = 0.f, b = 0.f;
+      if (metric == 0) {
+        if (!pd.is_bias[p]) {
+          const float nr = sqrtf(nr2), ns = sqrtf(ns2);
+          const float q = nr * ns + 1e-6f;
+          l += 1.0 - (double)(dot / q);
+          a = -1.f / q;
+          b = ns > 0.f ? dot * nr / (ns * q * q) : 0.f;
+        }
+        a *= coeff * sc2; b *= coeff * sc2;
+      } else if (metric == 1) {
+        l += (double)ns2 - 2.0 * (double)dot + (double)nr2;
+        a = -2.f * coeff; b = 2.f * coeff;
+      } else {
+        sd += dot; sr += nr2; ss += ns2;
+      }
+      abl[ci][0] = a; abl[ci][1] = b;
+    }
+  red[0][tid] = metric == 2 ? sd : l;
+  red[1][tid] = sr;
+  red[2][tid] = ss;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if (tid < w) { red[0][tid] += red[0][tid + w]; red[1][tid] += red[1][tid + w]; red[2][tid] += red[2][tid + w]; }
+    __syncthreads();
+  }
+  if (metric == 2) {
+    const float dot = (float)red[0][0], nr = sqrtf((float)red[1][0]), ns = sqrtf((float)red[2][0]);
+    const float q = nr * ns + 1e-6f;
+    const float a = -1.f / q, b = ns > 0.f ? dot * nr / (ns * q * q) : 0.f;
+    for (int k = tid; k < pd.total_cols; k += 1024) { abl[k][0] = a * coeff; abl[k][1] = b * coeff; }
+    if (tid == 0) loss_c[c] = nc == 0 ? 0.f : coeff * (1.f - dot / q);
+  } else if (tid == 0) {
+    loss_c[c] = nc == 0 ? 0.f : coeff * (float)red[0][0];
+  }
+  __syncthreads();
+  if (nc == 0)      // class without synthetic nodes: no term
+    for (int k = tid; k < pd.total_cols; k += 1024) { abl[k][0] = 0.f; abl[k][1] = 0.f; }
+  __syncthreads();
+  float* o = ab + (long)c * pd.total_cols * 2;
+  for (int k = tid; k < pd.total_cols; k += 1024) { o[k * 2] = abl[k][0]; o[k * 2 + 1] = abl[k][1]; }
+  // ---- D = alpha r + beta s
+  float* Dc = D + (long)c * P_total;
+  for (int p = 0; p < pd.nparams; ++p) {
+    const int rows = pd.rows[p], cols = pd.cols[p], co = pd.col_off[p];
+    const long off = pd.off[p], tot = (long)rows * cols;
+    if ((cols & 3) == 0) {
+      for (long i4 = tid; i4 < (tot >> 2); i4 += 1024) {
+        const int k = (int)((i4 * 4) % cols);
+        const gs_f32x4u r = *reinterpret_cast<const gs_f32x4u*>(R0 + off + i4 * 4);
+        const gs_f32x4u s_ = *reinterpret_cast<const gs_f32x4u*>(S0 + off + i4 * 4);
+        gs_f32x4u v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = abl[co + k + e][0] * r[e] + abl[co + k + e][1] * s_[e];
+        *reinterpret_cast<gs_f32x4u*>(Dc + off + i4 * 4) = v;
+      }
+    } else {
+      for (long i = tid; i < tot; i += 1024) {
+        const int k = (int)(i % cols);
+        Dc[off + i] = abl[co + k][0] * R0[off + i] + abl[co + k][1] * S0[off + i];
+      }
+    }
+  }
+}
+
 // with_bn (gcond_base.py:261-285 check_bn, models/sgc.py:27-33): the BatchNorm1d between the two SGC transforms always runs in
 // eval mode with its initial running statistics (0, 1), i.e. y = x * s + beta with s = bn.weight / sqrt(1 + eps).  It is folded
 // into the first transform: W1' = W1 diag(s), b1' = b1 * s + beta — every stage then runs on theta' = [W1', b1', W2, b2] as if

@@ -431,8 +431,8 @@ def test_h1_rows_of_a_class_shard_are_the_full_product():
 
 @pytest.mark.parametrize("workload,scale", [("ogbn-arxiv", 0.25), ("cora", 1.0), ("reddit", 0.2)])
 def test_fused_chains_against_the_launch_per_product_form(workload, scale):
-    """csrc/gs_chain.hip against the first form (gs_gcond_set_fused_chains 0 / 1) from identical state: the matching stage is the
-    same code either way (bitwise), PGE.inference + the inner SGC steps differ by fp32 re-association (T = 2: products re-associated
+    """csrc/gs_chain.hip against the first form (gs_gcond_set_fused_chains 0 / 1) from identical state: the matching stage's
+    products are the same either way, its distance is one launch instead of three (column sums re-grouped), PGE.inference + the inner SGC steps differ by fp32 re-association (T = 2: products re-associated
     through the C-wide operand, Adam in the gradient products' epilogue; T = 1: logits + softmax + NLL gradient in one launch with
     the K range dealt to 4 or 8 waves)."""
     import bench
@@ -466,8 +466,9 @@ def test_fused_chains_against_the_launch_per_product_form(workload, scale):
         a, b = run(0), run(1)
     finally:
         _lib.check(L.gs_gcond_set_fused_chains(1))
-    for k in ("loss", "Ps", "d_feat", "d_adj"):
-        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["Ps"], b["Ps"])
+    for k in ("loss", "d_feat", "d_adj"):      # (the one-launch matching distance groups its column sums differently)
+        assert float((a[k] - b[k]).abs().max()) <= 1e-5 * float(a[k].abs().max()), k
     gmax = float(a["g_model"].abs().max())
     assert float((a["g_model"] - b["g_model"]).abs().max()) <= 1e-3 * gmax      # the LAST step's gradient (after inner_loop - 1 updates)
     # Adam's first steps move every entry by ~lr: compare on that scale
@@ -587,6 +588,57 @@ def test_two_engines_with_different_knob_settings_do_not_see_each_other():
         assert L.gs_gcond_set_knob(a.h, 99, 1) < 0 and L.gs_gcond_get_knob(None, 0) == -1
     finally:
         _lib.check(L.gs_gcond_set_h1_rows(1))
+
+
+@pytest.mark.parametrize("workload,scale,shard,metric", [("ogbn-arxiv", 1.0, None, "ours"), ("ogbn-arxiv", 0.13, None, "mse"),
+                                                         ("ogbn-arxiv", 0.25, (7, 19), "ours"), ("flickr", 1.0, None, "ours"),
+                                                         ("arxiv-gate", 0.05, None, "cos")])
+def test_chained_class_products_of_the_match_agree_with_the_batched_products(workload, scale, shard, metric):
+    """csrc/gs_match.hip: the per-class products of the two-transform match (dHp_c, gW1_c, gb1_c; A1m_c -> Bc_c, dX slabs) as two
+    launches that chain products through the MFMA accumulator registers, against the six batched products they replace (knob
+    GS_KNOB_MATCH_CLASS): same fp32 products re-associated -> gw_syn, the matching loss, d loss / d X~ and d loss / d adj to 2e-5
+    of each tensor's max.  Shapes: the headline (n' = 454, d = 128, C = 40), ragged n' / class shards / C <= 32 / d = 500, and the
+    metrics that also match the bias gradients (mse, cos: gb1_c comes from the first launch)."""
+    from graphslim_amd import _lib
+    from graphslim_amd import workloads as W
+    from graphslim_amd.engine import EngineShapes, GCondEngine
+    from graphslim_amd.host import init_sgc_params
+    import numpy as np
+    L = _lib.lib()
+    KNOB_MATCH_CLASS = 6
+    p = W.build_problem(workload, seed=1, scale=scale)
+    d, C = p["data"].feat_full.shape[1], p["data"].nclass
+    sh = EngineShapes(p["data"].bench_n, d, C, len(p["labels_syn"]), p["T"], p["hidden"], p["ph"], 256, p["fan"][0], p["fan"][1])
+    cls_ptr = np.concatenate([[0], np.cumsum([len(q) for q in p["pools"]])])
+    eng = GCondEngine(sh, p["data"].bench_feat, p["csr"], cls_ptr, np.concatenate(p["pools"]), p["labels_syn"], p["ranges"],
+                      lr_feat=p["lrf"], lr_adj=p["lra"], lr_model=0.01, inner_loop=p["inner"], dis_metric=metric, seed=1, device=DEV)
+    W.init_state(p, eng)
+    torch.manual_seed(3)
+    eng.set_model(init_sgc_params(d, p["hidden"], C, p["T"]))
+    if shard:
+        eng.set_shard(shard[0], shard[1], 0, len(p["labels_syn"]))
+    eng.stage_sample()
+    eng.stage_real_grads()
+    eng.stage_pge_forward(False)
+    out = {}
+    for on in (0, 1):
+        _lib.check(L.gs_gcond_set_knob(eng.h, KNOB_MATCH_CLASS, on))
+        assert L.gs_gcond_get_knob(eng.h, KNOB_MATCH_CLASS) == on
+        for name in ("gw_syn", "d_feat", "d_adj", "loss_c"):
+            eng.view(name).fill_(float("nan"))
+        eng.stage_syn_match()
+        torch.cuda.synchronize()
+        out[on] = {name: eng.view(name).clone() for name in ("gw_syn", "d_feat", "d_adj", "loss_c")}
+    lo, hi = shard if shard else (0, C)
+    for name in ("gw_syn", "d_feat", "d_adj", "loss_c"):
+        a, b = out[0][name], out[1][name]
+        if name == "gw_syn":
+            a, b = a.reshape(C, -1)[lo:hi], b.reshape(C, -1)[lo:hi]
+        elif name == "loss_c":
+            a, b = a[lo:hi], b[lo:hi]
+        assert not torch.isnan(b).any() and float(a.abs().max()) > 0, name
+        err = float((a - b).abs().max() / a.abs().max())
+        assert err < 2e-5, (name, err)
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x6"])
