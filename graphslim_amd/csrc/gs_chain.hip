@@ -202,3 +202,4 @@ int gs_chain_group(const gs_gemm_desc* descs, int n, const gs_adam_ep* adam, hip
   GS_LAUNCH_CHECK();
   return GS_OK;
 }
+

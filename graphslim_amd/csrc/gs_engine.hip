@@ -364,7 +364,8 @@ static int g_defer_last_stage = 1;  // gs_gcond_set_folded_reductions
 static int g_edge_bits = 0;         // the hop-2 gather also writes per-edge sign bits and the edge product reads those (0: the mask rows of H1full)
 static int g_h1_bits = 0;
 static int g_h1_rows = 1;
-static int g_match_class = 1;      // per-class products of the synthetic match as two chained launches (gs_match.hip); 0 = the batched products
+static int g_chained_products = 1;  // the per-class products of the synthetic match chained through the MFMA accumulator registers, two
+                                    // launches (gs_match.hip); 0 = the six batched products
 // measurement / test knob: 1 (default) = PGE epochs run the backward of layer 2 on generated operands (marginals as in feature epochs,
 // dW1 | db1 by gs_dw1_gen_kernel); 0 = dE2 and A1 are materialised for a general tiled product (round 2's form)
 extern "C" int gs_gcond_set_dw1_generated(int on) {
@@ -635,7 +636,7 @@ extern "C" int gs_gcond_set_knob(gs_gcond* e, int knob, int value) {
 }
 extern "C" int gs_gcond_get_knob(const gs_gcond* e, int knob) {
   if (!e || knob < 0 || knob >= GS_KNOB_COUNT) return -1;
-  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_match_class};
+  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_chained_products};
   return knob_of(e, knob, def[knob]);
 }
 
@@ -1507,7 +1508,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     float* dH2 = e->T == 2 ? e->dH2 + c0 * n * C : nullptr; float* dHp = e->T == 2 ? e->dHp + c0 * n * h : nullptr;
     float* A1m = e->T == 2 ? e->A1m + c0 * n * h : nullptr; float* Bc = e->T == 2 ? e->Bc + c0 * n * C : nullptr;
     // two chained launches for the per-class products of the two-transform model (gs_match.hip) instead of six batched ones
-    const bool mclass = e->T == 2 && knob_of(e, GS_KNOB_MATCH_CLASS, g_match_class) && !e->blk_pos && gs_match_class_eligible(n, h, d, C);
+    const bool mclass = e->T == 2 && knob_of(e, GS_KNOB_CHAINED_PRODUCTS, g_chained_products) && !e->blk_pos && gs_match_class_eligible(n, h, d, C);
     {
       // gWl_c, gbl_c and (T = 2) dH2_c = Q[lo:hi]^T G[lo:hi] only read G: one launch
       gs_gemm_desc g3[3];
@@ -1929,6 +1930,8 @@ static int inner_steps_fused(gs_gcond* e, gs_stream_t stream) {
     GS_TRY(gs_gemm_f32(&a, stream));                                                     // H1 = relu(X W1 + b1)
     gs_gemm_desc t = mk(e->H1s, h, 1, th + e->oWl, C, 1, Tm, C, n, C, h);
     GS_TRY(gs_gemm_f32(&t, stream));                                                     // T = H1 Wl
+    // (H1 -> T and R -> dH1 chained through the accumulator registers as in gs_match.hip were measured: 15 workgroups carry each
+    // pair, 15.1 / 13.6 us against 5.0 + 5.4 / 8.0 + 4.8 us for the launches of 120 / 30 tiles — profiles/r04/inner_step_chained_pairs_not_kept.txt)
     // (logits and softmax stay two launches here: fused, the 15 row-block workgroups of n' = 454 carry the whole K = n' product —
     // 14.6 us against 6.6 + 4.4 for the 30-tile product and the wave-per-row softmax)
     float* Zl = e->Ps;      // [n x C] logits (the matching stage's softmax buffer: free here)
@@ -2373,6 +2376,8 @@ extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* 
       // PGE layer-2 pre-activations of this rank's pair rows and the BatchNorm-2 batch statistics (kernel A/B tests)
       {"E2", e->E2, (long)(e->r_hi - e->r_lo) * n * Ph}, {"mu2", e->mu2, Ph}, {"is2", e->is2, Ph},
       {"edge_bits", e->edge_bits, e->edge_bits ? (long)C * e->cap1 * e->f2 * (e->h / 32) : 0},
+      // hidden activations of the synthetic rows and their gradient as the last inner step left them (two-transform models)
+      {"H1s", e->H1s, e->H1s ? n * e->h : 0}, {"dH1m", e->dH1m, e->dH1m ? n * e->h : 0},
   };
   for (auto& t : tab)
     if (!strcmp(t.k, name)) {

@@ -100,12 +100,13 @@ __global__ __launch_bounds__(256, 2) void gs_match_first_kernel(gs_match1_args p
   if (p.gb1 && blockIdx.z == 0 && tid < 32) p.gb1[(long)c * p.s_gw + col0 + tid] = ((cs[0][tid] + cs[1][tid]) + cs[2][tid]) + cs[3][tid];
 }
 
-// grid (ceil(n / 32), Cl); 4 waves.  HT = h / 128 hidden tiles per wave, CT = ceil(C / 32) <= 2.
+// grid (ceil(n / 32), Cl); 4 waves.  HT = h / 128 hidden tiles per wave, CT = ceil(C / 32) <= 2.  Fragment loads run one round
+// (32 k) ahead of the MFMAs in two register buffers; the first round of the next product is requested before the current one ends.
 template <int HT, int CT>
 __global__ __launch_bounds__(256, 2) void gs_match_second_kernel(gs_match2_args p) {
   __shared__ float red[4][16 * CT][64];
   __shared__ float zt[32][32 * CT + 1];
-  constexpr int QS = 8;
+  constexpr int QS = 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
   const int c = blockIdx.y, r0 = blockIdx.x * 32, n = p.n, h = p.h, d = p.d;
   const float* __restrict__ D1 = p.D + (long)c * p.sD + p.oW1;
@@ -120,8 +121,7 @@ __global__ __launch_bounds__(256, 2) void gs_match_second_kernel(gs_match2_args 
 #pragma unroll
     for (int r = 0; r < 16; ++r) a1[i][r] = 0.f;
   const float* __restrict__ xr = p.X + (long)rl * p.ldx;
-  for (int k0 = 0; k0 < d; k0 += 8 * QS) {
-    float xb[QS][4], da[HT][QS][4];
+  auto load1 = [&](int k0, float (&xb)[QS][4], float (&da)[HT][QS][4]) {
 #pragma unroll
     for (int q = 0; q < QS; ++q) {
       const int ks = k0 + 8 * q;
@@ -132,6 +132,8 @@ __global__ __launch_bounds__(256, 2) void gs_match_second_kernel(gs_match2_args 
         for (int i = 0; i < HT; ++i) small_frag<false>(D1 + hb + 32 * i + li, h, ks + 4 * kh, d, whole, da[i][q]);
       }
     }
+  };
+  auto mma1 = [&](int k0, const float (&xb)[QS][4], const float (&da)[HT][QS][4]) {
 #pragma unroll
     for (int q = 0; q < QS; ++q)
       if (k0 + 8 * q < d) {
@@ -140,6 +142,16 @@ __global__ __launch_bounds__(256, 2) void gs_match_second_kernel(gs_match2_args 
 #pragma unroll
           for (int i = 0; i < HT; ++i) a1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[i][q][u], xb[q][u], a1[i], 0, 0, 0);
       }
+  };
+  {
+    float xb0[QS][4], da0[HT][QS][4], xb1[QS][4], da1[HT][QS][4];
+    load1(0, xb0, da0);
+    for (int k0 = 0; k0 < d; k0 += 16 * QS) {
+      if (k0 + 8 * QS < d) load1(k0 + 8 * QS, xb1, da1);
+      mma1(k0, xb0, da0);
+      if (k0 + 16 * QS < d) load1(k0 + 16 * QS, xb0, da0);
+      if (k0 + 8 * QS < d) mma1(k0 + 8 * QS, xb1, da1);
+    }
   }
   // Wl fragments of the next product (A operand: m = class, k = hidden = this wave's accumulator rows) and the epilogue operands
   float wa[HT][16][CT];
@@ -162,6 +174,20 @@ __global__ __launch_bounds__(256, 2) void gs_match_second_kernel(gs_match2_args 
       a1[i][4 * g + 2] = mv.z > 0.f ? a1[i][4 * g + 2] + bv.z : 0.f;
       a1[i][4 * g + 3] = mv.w > 0.f ? a1[i][4 * g + 3] + bv.w : 0.f;
     }
+  // the third product's operands: both k-contiguous (k = hidden); its first round is requested here, ahead of the second product
+  const float* __restrict__ hp = p.dHp + (long)c * p.s_dhp + (long)rl * h;
+  float* __restrict__ slab = p.slabs + (long)c * p.s_slab;
+  const int jt = (d + 31) >> 5;
+  auto load3 = [&](const float* dr, int k0, float (&ha)[QS][4], float (&db)[QS][4]) {
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      small_frag<true>(hp, 1, k0 + 8 * q + 4 * kh, h, true, ha[q]);
+      small_frag<true>(dr, 1, k0 + 8 * q + 4 * kh, h, true, db[q]);
+    }
+  };
+  float ha0[QS][4], db0[QS][4], ha1[QS][4], db1[QS][4];
+  const float* __restrict__ dr = D1 + (long)min(32 * wave + li, d - 1) * h;
+  if (wave < jt) load3(dr, 0, ha0, db0);
   // ---- Bc^T [C x 32 rows] = Wl^T A1m^T over this wave's hidden range; the four waves' partials are summed in wave order
   f32x16 bc[CT];
 #pragma unroll
@@ -193,26 +219,26 @@ __global__ __launch_bounds__(256, 2) void gs_match_second_kernel(gs_match2_args 
       Bc[(long)(r0 + row) * p.C + cc] = zt[row][cc];
     }
   }
-  // ---- dX slab tile [32 rows x 32 features] = dHp_c[rows] D1_c^T : both operands k-contiguous (k = hidden)
-  const float* __restrict__ hp = p.dHp + (long)c * p.s_dhp + (long)rl * h;
-  float* __restrict__ slab = p.slabs + (long)c * p.s_slab;
-  const int jt = (d + 31) >> 5;
+  // ---- dX slab tile [32 rows x 32 features] = dHp_c[rows] D1_c^T
   for (int t = wave; t < jt; t += 4) {
-    const float* __restrict__ dr = D1 + (long)min(32 * t + li, d - 1) * h;
     f32x16 ax;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ax[r] = 0.f;
-    for (int k0 = 0; k0 < h; k0 += 8 * QS) {      // h is a multiple of 128
-      float ha[QS][4], db[QS][4];
-#pragma unroll
-      for (int q = 0; q < QS; ++q) {
-        small_frag<true>(hp, 1, k0 + 8 * q + 4 * kh, h, true, ha[q]);
-        small_frag<true>(dr, 1, k0 + 8 * q + 4 * kh, h, true, db[q]);
-      }
+    auto mma3 = [&](const float (&ha)[QS][4], const float (&db)[QS][4]) {
 #pragma unroll
       for (int q = 0; q < QS; ++q)
 #pragma unroll
         for (int u = 0; u < 4; ++u) ax = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[q][u], db[q][u], ax, 0, 0, 0);
+    };
+    for (int k0 = 0; k0 < h; k0 += 16 * QS) {      // h is a multiple of 128: whole double rounds
+      load3(dr, k0 + 8 * QS, ha1, db1);
+      mma3(ha0, db0);
+      const bool more = k0 + 16 * QS < h;
+      const float* drn = dr;
+      if (!more && t + 4 < jt) drn = D1 + (long)min(32 * (t + 4) + li, d - 1) * h;      // the next tile's first round
+      if (more || t + 4 < jt) load3(drn, more ? k0 + 16 * QS : 0, ha0, db0);
+      mma3(ha1, db1);
+      dr = drn;
     }
     const int j = 32 * t + li;
 #pragma unroll

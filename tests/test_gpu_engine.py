@@ -596,7 +596,7 @@ def test_two_engines_with_different_knob_settings_do_not_see_each_other():
 def test_chained_class_products_of_the_match_agree_with_the_batched_products(workload, scale, shard, metric):
     """csrc/gs_match.hip: the per-class products of the two-transform match (dHp_c, gW1_c, gb1_c; A1m_c -> Bc_c, dX slabs) as two
     launches that chain products through the MFMA accumulator registers, against the six batched products they replace (knob
-    GS_KNOB_MATCH_CLASS): same fp32 products re-associated -> gw_syn, the matching loss, d loss / d X~ and d loss / d adj to 2e-5
+    GS_KNOB_CHAINED_PRODUCTS): same fp32 products re-associated -> gw_syn, the matching loss, d loss / d X~ and d loss / d adj to 2e-5
     of each tensor's max.  Shapes: the headline (n' = 454, d = 128, C = 40), ragged n' / class shards / C <= 32 / d = 500, and the
     metrics that also match the bias gradients (mse, cos: gb1_c comes from the first launch)."""
     from graphslim_amd import _lib
@@ -605,7 +605,7 @@ def test_chained_class_products_of_the_match_agree_with_the_batched_products(wor
     from graphslim_amd.host import init_sgc_params
     import numpy as np
     L = _lib.lib()
-    KNOB_MATCH_CLASS = 6
+    KNOB_CHAINED_PRODUCTS = 6
     p = W.build_problem(workload, seed=1, scale=scale)
     d, C = p["data"].feat_full.shape[1], p["data"].nclass
     sh = EngineShapes(p["data"].bench_n, d, C, len(p["labels_syn"]), p["T"], p["hidden"], p["ph"], 256, p["fan"][0], p["fan"][1])
@@ -622,9 +622,10 @@ def test_chained_class_products_of_the_match_agree_with_the_batched_products(wor
     eng.stage_pge_forward(False)
     out = {}
     for on in (0, 1):
-        _lib.check(L.gs_gcond_set_knob(eng.h, KNOB_MATCH_CLASS, on))
-        assert L.gs_gcond_get_knob(eng.h, KNOB_MATCH_CLASS) == on
-        for name in ("gw_syn", "d_feat", "d_adj", "loss_c"):
+        _lib.check(L.gs_gcond_set_knob(eng.h, KNOB_CHAINED_PRODUCTS, on))
+        assert L.gs_gcond_get_knob(eng.h, KNOB_CHAINED_PRODUCTS) == on
+        eng.view("gw_syn").zero_()      # ('ours' never writes the bias gradients it does not match)
+        for name in ("d_feat", "d_adj", "loss_c"):
             eng.view(name).fill_(float("nan"))
         eng.stage_syn_match()
         torch.cuda.synchronize()

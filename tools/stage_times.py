@@ -36,10 +36,10 @@ p = bench.build_problem(name, seed=1)
 eng = bench.make_engine(p, "cuda:0")
 if mode:
     eng.set_operand_mode(mode)
-if os.environ.get("GS_MATCH_CLASS") is not None:      # 0: the batched per-class products of the match; 1: the two chained launches
+if os.environ.get("GS_CHAINED") is not None:      # 0: the batched per-class products of the match; 1: the two chained launches
     from graphslim_amd import _lib
-    _lib.check(_lib.lib().gs_gcond_set_knob(eng.h, 6, int(os.environ["GS_MATCH_CLASS"])))
-    print(f"knob MATCH_CLASS = {os.environ['GS_MATCH_CLASS']}")
+    _lib.check(_lib.lib().gs_gcond_set_knob(eng.h, 6, int(os.environ["GS_CHAINED"])))
+    print(f"knob CHAINED_PRODUCTS = {os.environ['GS_CHAINED']}")
 print(f"workload {name}, operand mode {eng.operand_mode}")
 bench.init_state(p, eng)
 bench.new_model(p, eng)
