@@ -2132,6 +2132,13 @@ extern "C" int gs_gcond_set_structure(gs_gcond* e, const float* adj, int inferen
 static inline int xchg(gs_comm* comm, void* buf, long count, int f64, int tag, gs_stream_t stream) {
   return comm ? gs_comm_allreduce(comm, buf, count, f64, tag, stream) : GS_OK;
 }
+// the PGE exchanges (BN-2 sums, pair scores, BN-2 backward sums, marginals | dW1) exist only when the PGE's pair rows are sharded:
+// a rank that holds every pair row (gs_gcond_set_shard with r = [0, n'): "replicated PGE") already has the complete values, and
+// ONE exchange per iteration is left (the class-partial [d_feat | d_adj | loss_c] of the matching stage)
+// (a single-rank communicator still takes every exchange: the identity, but it exercises the transport on each buffer)
+static inline int xchg_pge(const gs_gcond* e, gs_comm* comm, void* buf, long count, int f64, int tag, gs_stream_t stream) {
+  return (sharded_r(e) || (comm && gs_comm_world(comm) == 1)) ? xchg(comm, buf, count, f64, tag, stream) : GS_OK;
+}
 
 static int real_async(gs_gcond* e, gs_stream_t stream, bool fork_recorded);
 extern "C" int gs_gcond_stage_real_async(gs_gcond* e, gs_stream_t stream) {
@@ -2180,9 +2187,9 @@ static int real_async(gs_gcond* e, gs_stream_t stream, bool fork_recorded) {
 static int pge_forward_x(gs_gcond* e, int inference, gs_comm* comm, gs_stream_t stream) {
   if (!comm) return gs_gcond_stage_pge_forward(e, inference, stream);
   GS_TRY(gs_gcond_stage_pge_forward_part(e, inference, 1, stream));
-  GS_TRY(xchg(comm, e->sums, 2L * e->Ph, 1, 0, stream));
+  GS_TRY(xchg_pge(e, comm, e->sums, 2L * e->Ph, 1, 0, stream));
   GS_TRY(gs_gcond_stage_pge_forward_part(e, inference, 2, stream));
-  GS_TRY(xchg(comm, e->e3, (long)e->n * e->n, 0, 1, stream));
+  GS_TRY(xchg_pge(e, comm, e->e3, (long)e->n * e->n, 0, 1, stream));
   return gs_gcond_stage_pge_forward_part(e, inference, 3, stream);
 }
 
@@ -2193,11 +2200,11 @@ static int pge_backward_x(gs_gcond* e, int need_param_grads, int need_feat_grad,
   hipStream_t s = (hipStream_t)stream;
   const long Ph = e->Ph, nm = 2L * e->n * Ph, nw = Ph * Ph + Ph;
   GS_TRY(gs_gcond_stage_pge_backward_part(e, need_param_grads, need_feat_grad, 1, stream));
-  GS_TRY(xchg(comm, e->sums, 3L * Ph, 1, 3, stream));
+  GS_TRY(xchg_pge(e, comm, e->sums, 3L * Ph, 1, 3, stream));
   GS_TRY(gs_gcond_stage_pge_backward_part(e, need_param_grads, need_feat_grad, 2, stream));
-  const bool w1 = need_param_grads && gs_comm_world(comm) > 1;
+  const bool w1 = need_param_grads && gs_comm_world(comm) > 1 && sharded_r(e);
   if (w1) GS_HIP(hipMemcpyAsync(e->ar_marg + nm, e->d_pge + e->pW1, sizeof(float) * nw, hipMemcpyDeviceToDevice, s));
-  GS_TRY(xchg(comm, e->ar_marg, nm + (w1 ? nw : 0), 0, 4, stream));
+  GS_TRY(xchg_pge(e, comm, e->ar_marg, nm + (w1 ? nw : 0), 0, 4, stream));
   if (w1) GS_HIP(hipMemcpyAsync(e->d_pge + e->pW1, e->ar_marg + nm, sizeof(float) * nw, hipMemcpyDeviceToDevice, s));
   return gs_gcond_stage_pge_backward_part(e, need_param_grads, need_feat_grad, 3, stream);
 }
@@ -2227,10 +2234,10 @@ static int outer_step_impl(gs_gcond* e, int step_pge, int step_feat, int run_inf
     hipStream_t s = (hipStream_t)stream;
     GS_HIP(hipEventRecord(e->ev_fork, s));
     GS_TRY(gs_gcond_stage_pge_forward_part(e, 0, 1, stream));
-    GS_TRY(xchg(comm, e->sums, 2L * e->Ph, 1, 0, stream));
+    GS_TRY(xchg_pge(e, comm, e->sums, 2L * e->Ph, 1, 0, stream));
     GS_TRY(real_async(e, stream, true));
     GS_TRY(gs_gcond_stage_pge_forward_part(e, 0, 2, stream));
-    GS_TRY(xchg(comm, e->e3, (long)e->n * e->n, 0, 1, stream));
+    GS_TRY(xchg_pge(e, comm, e->e3, (long)e->n * e->n, 0, 1, stream));
     GS_TRY(gs_gcond_stage_pge_forward_part(e, 0, 3, stream));
   } else {
     GS_TRY(gs_gcond_stage_real_async(e, stream));
@@ -2378,6 +2385,8 @@ extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* 
       {"edge_bits", e->edge_bits, e->edge_bits ? (long)C * e->cap1 * e->f2 * (e->h / 32) : 0},
       // hidden activations of the synthetic rows and their gradient as the last inner step left them (two-transform models)
       {"H1s", e->H1s, e->H1s ? n * e->h : 0}, {"dH1m", e->dH1m, e->dH1m ? n * e->h : 0},
+      // PGE backward intermediates where they are materialised (diagnosis: tools/diag_panel_stages.py)
+      {"dE2", e->dE2, n * n * Ph}, {"A1", e->A1, n * n * Ph}, {"dY1", e->dY1, n * n * Ph}, {"W1T", e->W1T, Ph * Ph}, {"de3", e->de3, n * n},
   };
   for (auto& t : tab)
     if (!strcmp(t.k, name)) {

@@ -210,16 +210,26 @@ class ShardedGCond:
     gs_gcond_outer_step with the all-reduces issued by the library through `comm`); `phases` / `outer_step_py` keep the same
     iteration as a host-side phase list over a torch.distributed Collective (the first form; tests compare the two)."""
 
-    parallelism = "class-parallel + PGE pair-row sharding, all-reduce(sum) issued inside the library (gs_comm)"
+    PARALLELISM = {"rows": "class-parallel + PGE pair-row sharding, 5-7 all-reduce(sum) per iteration issued inside the library (gs_comm)",
+                   "replicated": "class-parallel, PGE replicated on every rank, ONE all-reduce(sum) per iteration issued inside the library (gs_comm)"}
 
-    def __init__(self, engine, rank, world, pool_sizes, collective: Collective = None, comm: Comm = None):
+    def __init__(self, engine, rank, world, pool_sizes, collective: Collective = None, comm: Comm = None, pge=None):
+        """pge: "rows" — the PGE's n'^2 pair rows are split over the ranks (4 more exchange points per PGE pass pair: BatchNorm-2
+        sums, pair scores, BatchNorm-2 backward sums, marginals); "replicated" — every rank runs the whole PGE on the all-reduced
+        d_adj (bitwise the same on every rank: same code, same inputs), and the class-partial [d_feat | d_adj | loss_c] of the
+        matching stage is the ONLY exchange of the iteration (VERDICT r03 "next" 6: <= 4 exchanges).  Default: GS_PGE_SHARDING or
+        "rows"."""
         self.eng, self.rank, self.world = engine, rank, world
+        self.pge = pge or os.environ.get("GS_PGE_SHARDING", "rows")
+        if self.pge not in self.PARALLELISM:
+            raise ValueError(f"ShardedGCond: pge must be one of {sorted(self.PARALLELISM)}, got {self.pge!r}")
+        self.parallelism = self.PARALLELISM[self.pge]
         self.col = collective if collective is not None else Collective(None)
         self._comm = comm          # built on first use: the transport that fits the Collective's process group
         self.driver = os.environ.get("GS_SHARDED_DRIVER", "library")      # "python": the host-side phase list (first form)
         s = engine.shapes
         self.class_ranges = split_classes([min(s.bcap, int(p)) for p in pool_sizes], world)
-        self.row_ranges = split_even(s.n_syn, world)
+        self.row_ranges = split_even(s.n_syn, world) if self.pge == "rows" else [(0, s.n_syn)] * world
         (c_lo, c_hi), (r_lo, r_hi) = self.class_ranges[rank], self.row_ranges[rank]
         engine.set_shard(c_lo, c_hi, r_lo, r_hi)
         f64 = torch.float64
@@ -236,16 +246,19 @@ class ShardedGCond:
         pge_epoch = epoch % 50 < 10
         np_, nf = pge_epoch, not pge_epoch
 
+        rows = self.pge == "rows"      # (the PGE exchange points exist only when its pair rows are sharded)
+
         def fwd(inference):
-            return [(lambda: e.pge_forward_part(inference, 1), "ar_bn2"), (lambda: e.pge_forward_part(inference, 2), "e3"),
+            return [(lambda: e.pge_forward_part(inference, 1), "ar_bn2" if rows else None),
+                    (lambda: e.pge_forward_part(inference, 2), "e3" if rows else None),
                     (lambda: e.pge_forward_part(inference, 3), None)]
 
         ph = [(e.stage_real_async, None)]      # second stream: overlaps the PGE forward and its two exchanges
         ph += [(e.adopt_cached_forward, None)] if e.forward_cached() else fwd(False)
         ph += [(e.stage_syn_match, "ar_syn"), (e.syn_finish, None),
-               (lambda: e.pge_backward_part(np_, nf, 1), "ar_l3"),
-               (lambda: e.pge_backward_part(np_, nf, 2), "ar_marg")]
-        if pge_epoch:
+               (lambda: e.pge_backward_part(np_, nf, 1), "ar_l3" if rows else None),
+               (lambda: e.pge_backward_part(np_, nf, 2), "ar_marg" if rows else None)]
+        if pge_epoch and rows:
             ph += [(lambda: None, "ar_w1")]
         ph += [(lambda: e.pge_backward_part(np_, nf, 3), None), (lambda: e.stage_update(epoch), None)]
         ph += fwd(True) + [(e.inner_steps, None)]
@@ -423,11 +436,11 @@ def active_dist():
     return None
 
 
-def make_engine(p, dev, rank, world):
+def make_engine(p, dev, rank, world, pge=None):
     """bench.py entry: this rank's sharded engine over torch.distributed (process group already initialised)."""
     import torch.distributed as dist
     from .workloads import make_engine as _make
     eng = _make(p, dev)
-    sh = ShardedGCond(eng, rank, world, [len(q) for q in p["pools"]], Collective(dist))
+    sh = ShardedGCond(eng, rank, world, [len(q) for q in p["pools"]], Collective(dist), pge=pge)
     sh.verify_transport()
     return sh

@@ -15,6 +15,7 @@ from graphslim_amd.parallel import Comm, ShardedGCond  # noqa: E402
 wl = sys.argv[1] if len(sys.argv) > 1 else "ogbn-arxiv"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 worlds = [int(w) for w in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8]
+PGE = sys.argv[4] if len(sys.argv) > 4 else None      # "rows" (default) | "replicated": how the PGE is laid over the ranks
 if os.environ.get("GS_H1_ROWS") is not None:      # A/B of the row-list H1 product of a class shard
     from graphslim_amd import _lib
     _lib.lib().gs_gcond_set_h1_rows(int(os.environ["GS_H1_ROWS"]))
@@ -46,11 +47,12 @@ def timed3(e):
 
 
 base = timed3(eng)
+print(f"PGE sharding: {PGE or os.environ.get('GS_PGE_SHARDING', 'rows')}")
 print(f"fused single-GPU outer step: {base:.3f} ms (host issue {host_ms:.3f} ms)")
 for world in worlds:
     ts, hs = [], []
     for r in range(world):
-        sh = ShardedGCond(eng, r, world, pools, comm=Comm.null(r, world))      # the library's one-call sharded iteration, exchanges = no-ops
+        sh = ShardedGCond(eng, r, world, pools, comm=Comm.null(r, world), pge=PGE)      # the library's one-call sharded iteration, exchanges = no-ops
         bench.init_state(p, eng)
         ts.append(timed3(sh))
         hs.append(round(host_ms, 3))
