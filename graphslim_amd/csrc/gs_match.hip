@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void gs_match_first_kernel(gs_match1_args p
   if (p.gb1 && blockIdx.z == 0 && tid < 32) p.gb1[(long)c * p.s_gw + col0 + tid] = ((cs[0][tid] + cs[1][tid]) + cs[2][tid]) + cs[3][tid];
 }
 
-// grid (ceil(n / 32), Cl); 4 waves.  HT = h / 128 hidden tiles per wave, CT = ceil(C / 32) <= 2.  Fragment loads run one round
+// grid ceil(n / 32) * Cl (flat); 4 waves.  HT = h / 128 hidden tiles per wave, CT = ceil(C / 32) <= 2.  Fragment loads run one round
 // (32 k) ahead of the MFMAs in two register buffers; the first round of the next product is requested before the current one ends.
 template <int HT, int CT>
 __global__ __launch_bounds__(256, 2) void gs_match_second_kernel(gs_match2_args p) {
@@ -108,7 +108,15 @@ __global__ __launch_bounds__(256, 2) void gs_match_second_kernel(gs_match2_args 
   __shared__ float zt[32][32 * CT + 1];
   constexpr int QS = 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
-  const int c = blockIdx.y, r0 = blockIdx.x * 32, n = p.n, h = p.h, d = p.d;
+  // flat grid, XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so XCD x takes the CONTIGUOUS chunk x of the class-major
+  // tile sequence — the 15 row blocks of a class run on one XCD and find D1_c (read twice per workgroup) in that XCD's L2
+  int tile;
+  {
+    const int T = gridDim.x, L = blockIdx.x, xcd = L & 7, slot = L >> 3, q = T >> 3, r = T & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int nrb = (p.n + 31) >> 5;
+  const int c = tile / nrb, r0 = (tile - c * nrb) * 32, n = p.n, h = p.h, d = p.d;
   const float* __restrict__ D1 = p.D + (long)c * p.sD + p.oW1;
   const float* __restrict__ Db1 = p.D + (long)c * p.sD + p.ob1;
   const int rl = min(r0 + li, n - 1);            // this lane's row where rows are the lane dimension
@@ -261,7 +269,7 @@ int gs_match_first(const gs_match1_args* a, int Cl, hipStream_t s) {
 
 int gs_match_second(const gs_match2_args* a, int Cl, hipStream_t s) {
   if (Cl <= 0) return GS_OK;
-  const dim3 grid(gs_cdiv(a->n, 32), Cl);
+  const dim3 grid(gs_cdiv(a->n, 32) * Cl);
   const bool c2 = a->C > 32;
   if (a->h == 256) {
     if (c2) hipLaunchKernelGGL((gs_match_second_kernel<2, 2>), grid, dim3(256), 0, s, *a);

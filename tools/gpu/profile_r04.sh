@@ -33,6 +33,7 @@ find $O -name "*agent_info.csv" -delete; find $O -name "*kernel_trace.csv" -dele
 timeout 300 python tools/stage_times.py ogbn-arxiv 2>/dev/null | grep -v "^/opt" > $O/stage_times.txt
 timeout 300 python tools/stage_times.py ogbn-arxiv f32 2>/dev/null | grep -v "^/opt" >> $O/stage_times.txt
 timeout 600 python tools/virtual_scale.py > $O/virtual_scale.txt 2>&1
+timeout 600 python tools/virtual_scale.py ogbn-arxiv 30 1,2,4,8 replicated > $O/virtual_scale_replicated.txt 2>&1
 timeout 300 python tools/host_issue.py > $O/host_issue.txt 2>&1
 timeout 600 python bench.py --workload reddit --no-cpu-baseline --eval-epochs 0 > $O/bench_reddit.json 2>/dev/null
 timeout 600 python bench.py --workload cora --no-cpu-baseline --eval-epochs 0 > $O/bench_cora.json 2>/dev/null
