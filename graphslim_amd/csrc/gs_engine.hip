@@ -636,7 +636,7 @@ extern "C" int gs_gcond_set_knob(gs_gcond* e, int knob, int value) {
 }
 extern "C" int gs_gcond_get_knob(const gs_gcond* e, int knob) {
   if (!e || knob < 0 || knob >= GS_KNOB_COUNT) return -1;
-  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_chained_products};
+  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_chained_products, 0};
   return knob_of(e, knob, def[knob]);
 }
 
@@ -2232,8 +2232,12 @@ static int outer_step_impl(gs_gcond* e, int step_pge, int step_feat, int run_inf
     // was still feeding the second stream.  So the fork point is recorded, the first part of the PGE forward (its long product)
     // goes to the main queue, THEN the real-side branch to the second stream, then the rest of the forward.
     hipStream_t s = (hipStream_t)stream;
-    GS_HIP(hipEventRecord(e->ev_fork, s));
+    // (knob FORK_LATE: the real-side branch starts only when the forward's long product has finished — that product then has the
+    // chip to itself, e.g. as a persistent grid — instead of beside it)
+    const bool late = knob_of(e, GS_KNOB_FORK_LATE, 0) != 0;
+    if (!late) GS_HIP(hipEventRecord(e->ev_fork, s));
     GS_TRY(gs_gcond_stage_pge_forward_part(e, 0, 1, stream));
+    if (late) GS_HIP(hipEventRecord(e->ev_fork, s));
     GS_TRY(xchg_pge(e, comm, e->sums, 2L * e->Ph, 1, 0, stream));
     GS_TRY(real_async(e, stream, true));
     GS_TRY(gs_gcond_stage_pge_forward_part(e, 0, 2, stream));

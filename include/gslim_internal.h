@@ -91,7 +91,7 @@ int gs_sample_set_cand_cap(int cap);
 /* Engine-level knobs per ENGINE (the int-only setters above change the process-wide default an engine follows while its own value is
    -1): knob ids below, value 0 / 1, -1 = follow the default again.  gs_gcond_get_knob returns the value in effect (-1: bad arguments). */
 enum { GS_KNOB_FUSED_CHAINS = 0, GS_KNOB_H1_ROWS = 1, GS_KNOB_H1_BITS = 2, GS_KNOB_EDGE_BITS = 3, GS_KNOB_DW1_GENERATED = 4,
-       GS_KNOB_FOLDED_REDUCTIONS = 5, GS_KNOB_CHAINED_PRODUCTS = 6, GS_KNOB_COUNT = 7 };
+       GS_KNOB_FOLDED_REDUCTIONS = 5, GS_KNOB_CHAINED_PRODUCTS = 6, GS_KNOB_FORK_LATE = 7, GS_KNOB_COUNT = 8 };
 int gs_gcond_set_knob(gs_gcond* e, int knob, int value);
 int gs_gcond_get_knob(const gs_gcond* e, int knob);
 

@@ -36,6 +36,10 @@ p = bench.build_problem(name, seed=1)
 eng = bench.make_engine(p, "cuda:0")
 if mode:
     eng.set_operand_mode(mode)
+if os.environ.get("GS_FORK_LATE") is not None:      # 1: the real-side branch is forked AFTER the training forward's long product
+    from graphslim_amd import _lib
+    _lib.check(_lib.lib().gs_gcond_set_knob(eng.h, 7, int(os.environ["GS_FORK_LATE"])))
+    print(f"knob FORK_LATE = {os.environ['GS_FORK_LATE']}")
 if os.environ.get("GS_CHAINED") is not None:      # 0: the batched per-class products of the match; 1: the two chained launches
     from graphslim_amd import _lib
     _lib.check(_lib.lib().gs_gcond_set_knob(eng.h, 6, int(os.environ["GS_CHAINED"])))
