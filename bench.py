@@ -312,6 +312,8 @@ def main():
                          "by row-sharded SpMM once before the timed region, seed-row gathers per iteration; not the headline")
     ap.add_argument("--eval-epochs", type=int, default=200,
                     help="condensation epochs of the bounded job behind `eval_acc` (0 = off; the reference schedule is 600)")
+    ap.add_argument("--pge-sharding", default=None, choices=["rows", "replicated"],
+                    help="N > 1: PGE pair rows split over the ranks (7 exchanges per iteration) or the PGE replicated (1 exchange); default GS_PGE_SHARDING or rows")
     ap.add_argument("--no-modes", action="store_true", help="skip the tagged runs in the other operand modes (profiling: one mode per trace)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -343,7 +345,7 @@ def main():
         raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     p = build_problem(args.workload, seed=1, scale=args.scale)
     from graphslim_amd import parallel
-    eng = parallel.make_engine(p, dev, rank, world) if world > 1 else make_engine(p, dev)
+    eng = parallel.make_engine(p, dev, rank, world, pge=args.pge_sharding) if world > 1 else make_engine(p, dev)
     init_state(p, eng)
     getattr(eng, "eng", eng).set_operand_mode(args.operand_mode)
     full_nb = None
