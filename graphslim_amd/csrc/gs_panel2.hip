@@ -619,7 +619,10 @@ __global__ __launch_bounds__(512, 2) void gs_tall_kernel(gs_tall_args p) {
   tp_iter it;
   it.u = (int)(units * blockIdx.x / gridDim.x);
   it.u_hi = (int)(units * (blockIdx.x + 1) / gridDim.x);
-  it.pre = p.phases ? (int)((blockIdx.x >> 3) & (FORM == TP_MARG ? 1 : 3)) : 0;
+  it.pre = (p.phases & 1) ? (int)((blockIdx.x >> 3) & (FORM == TP_MARG ? 1 : 3)) : 0;
+  // measurement: static issue priority for one half of the workgroup (the two waves of a SIMD arbitrate VALU issue by priority, then age)
+  if ((p.phases & 2) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if ((p.phases & 4) && wave < 4) __builtin_amdgcn_s_setprio(1);
 
   // table rows of 256 floats.  MARG: rows 0..6 = the [K][8] constants rows of the dE2 transform as a structure of arrays (see
   // gs_panel.hip); FGEN: rows 0..5 = the tiles' Vs rows (two sets); row 11 = the bias (PLAIN, FGEN)
@@ -685,7 +688,8 @@ extern "C" int gs_panel_tall_debug(int grid, int krep, int triage) {
   g_tall_grid = grid < 0 ? 0 : grid;
   g_tall_krep = krep < 1 ? 1 : krep;
   g_tall_triage = triage & 63;
-  g_tall_phases = (triage & 64) ? 0 : 1;      // bit 6: every share starts with a full tile (tile boundaries coincide chip-wide)
+  g_tall_phases = ((triage & 64) ? 0 : 1) | ((triage & 256) ? 2 : 0) | ((triage & 512) ? 4 : 0);      // bit 6: every share starts with a full tile (tile
+                                    // boundaries coincide chip-wide); bit 8 / 9: static s_setprio 1 for waves 4-7 / waves 0-3
   g_tall_split = (triage & 128) ? 0 : 1;      // bit 7: every wave runs a step in the order [MFMA, prepare]
   return GS_OK;
 }
