@@ -83,3 +83,21 @@ __device__ __forceinline__ uint32_t gs_rand_u32(uint64_t seed, uint32_t a, uint3
 __device__ __forceinline__ uint32_t gs_rand_below(uint64_t seed, uint32_t a, uint32_t b, uint32_t c, uint32_t n) {
   return (uint32_t)(((uint64_t)gs_rand_u32(seed, a, b, c) * (uint64_t)n) >> 32);
 }
+
+#ifdef __HIPCC__
+// One element of the image of the exact three-way bf16 split the exact-split row-panel kernels consume (gs_panel.hip,
+// gs_panel2.hip): W [N][K] (element (n, k)) -> [N][K/16 sub-blocks][plane h, m, l][k half 0, 1][8] bf16, where the sub-block of k is
+// 2 (k >> 5) + ((k >> 3) & 1), its half (k >> 4) & 1, its element k & 7.  h = bf16(w), m = bf16(w - h), l = bf16(w - h - m):
+// 8 + 8 + 8 significant bits = the 24 of an fp32, so h + m + l == w exactly.  Shared by the stand-alone split kernel and by the
+// launches that fold the split of a PGE weight into a kernel that runs before the product anyway (gs_kernels.h).
+__device__ __forceinline__ void gs_split3_store(float w, int n, int k, int K, __bf16* __restrict__ out) {
+  const __bf16 hb = (__bf16)w;
+  const float r1 = w - (float)hb;
+  const __bf16 mb = (__bf16)r1;
+  const __bf16 lb = (__bf16)(r1 - (float)mb);
+  const int sb = 2 * (k >> 5) + ((k >> 3) & 1), half = (k >> 4) & 1, e = k & 7;
+  __bf16* o = out + ((long)n * (K >> 4) + sb) * 48 + half * 8 + e;
+  o[0] = hb; o[16] = mb; o[32] = lb;
+}
+#endif
+

@@ -12,8 +12,9 @@
 extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int, long, int, float, gs_stream_t);
 extern "C" int gs_reduce_slabs_f32(float*, const float*, long, int, long, float, gs_stream_t);
 int gs_reduce_slabs_active(float*, long, const float*, long, int, long, int, const int*, int, gs_stream_t);
+int gs_reduce_slabs_pair(float*, const float*, long, int, long, float*, const float*, long, int, long, gs_stream_t);
 struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; int table_ready; };
-struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; const float *Us, *Vs; };
+struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; const float *Us, *Vs; int b_ready; };
 int gs_panel_marginals(const float*, long, const float*, long, const float*, long, int, int, int, int, float*, float*, int, void*,
                        const gs_panel_gen*, const gs_panel_a1*, hipStream_t);
 int gs_dw1_generated(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, int, float*,
@@ -1103,7 +1104,7 @@ static int pge_backward_chunked(gs_gcond* e, int need_param_grads, gs_stream_t s
 static gs_panel_a1 pge_a1(const gs_gcond* e) {
   const float* pp = e->io.pge_params;
   return gs_panel_a1{e->U, e->V + (long)e->r_lo * e->Ph, (long)e->Ph, pp + e->pb0, e->mu1, e->is1, pp + e->pg1, pp + e->pbe1, e->a1_tab,
-                     e->uvs_valid ? e->UsVs : nullptr, e->uvs_valid ? e->UsVs + (long)e->n * e->Ph + (long)e->r_lo * e->Ph : nullptr};
+                     e->uvs_valid ? e->UsVs : nullptr, e->uvs_valid ? e->UsVs + (long)e->n * e->Ph + (long)e->r_lo * e->Ph : nullptr, 0};
 }
 
 // materialise A1 of the current U, V for this rank's pair rows if the forward did not (products that read it as an operand)
@@ -1142,21 +1143,28 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       uv[1] = uv[0]; uv[1].B = pp + e->pW0 + d; uv[1].C = e->V;
       GS_TRY(gs_gemm_group_f32(uv, 2, stream));          // independent: one launch
     }
-    hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 32)), dim3(1024), 0, s, e->U, e->V, pp + e->pb0, n, Ph, e->mu1,
-                       e->is1, e->sumU, e->sumV, pp + e->pg1, pp + e->pbe1, e->a1_tab);   // (+ the table of the generated A1)
-    GS_LAUNCH_CHECK();
     // the folded layer-1 terms of this forward (exact-split kernels of gs_panel2.hip and gs_dw1_generated: forward operand, backward
-    // mask and dW1 operand are then the SAME function max(Us[c] + Vs[r], 0) of the same bits)
+    // mask and dW1 operand are then the SAME function max(Us[c] + Vs[r], 0) of the same bits) and the split image of W1 for the
+    // layer-2 product come out of the statistics launch (round 4: were two launches of their own per pass; same bits)
+    const bool fold_uv = e->operand_mode == 3 && Ph == 256 && n >= 128;
+    const bool pre_split = knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && e->operand_mode == 3 && rows > 0 && (Ph & 31) == 0;
+    const bool fold_here = fold_uv && knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains);
+    hipLaunchKernelGGL(gs_pge_bn1_stats_kernel, dim3(gs_cdiv(Ph, 32) + (pre_split ? gs_cdiv((long)Ph * Ph, 1024) : 0)), dim3(1024), 0, s, e->U,
+                       e->V, pp + e->pb0, n, Ph, e->mu1, e->is1, e->sumU, e->sumV, pp + e->pg1, pp + e->pbe1, e->a1_tab,   // (+ the table of the generated A1)
+                       fold_here ? e->UsVs : (float*)nullptr, fold_here ? e->UsVs + (long)n * Ph : (float*)nullptr, pp + e->pW1,
+                       pre_split ? (__bf16*)e->bsplit_main : (__bf16*)nullptr);
+    GS_LAUNCH_CHECK();
     e->uvs_valid = false;
-    if (e->operand_mode == 3 && Ph == 256 && n >= 128) {
-      GS_TRY(gs_pge_scale_uv(e->U, e->V, e->a1_tab, (long)n * Ph, Ph, e->UsVs, e->UsVs + (long)n * Ph, s));
+    if (fold_uv) {
+      if (!fold_here) GS_TRY(gs_pge_scale_uv(e->U, e->V, e->a1_tab, (long)n * Ph, Ph, e->UsVs, e->UsVs + (long)n * Ph, s));
       e->uvs_valid = true;
     }
     if (rows > 0) {
       // E2 = A1 W1^T + b1.  Preferred: A1 is formed in the product's operand path from U, V (gs_panel_forward_a1) and is not
       // written — feature epochs never read it (the backward regenerates the [A1 > 0] mask the same way); PGE epochs
       // materialise it lazily for dW1 (ensure_a1).
-      const gs_panel_a1 a1 = pge_a1(e);
+      gs_panel_a1 a1 = pge_a1(e);
+      a1.b_ready = pre_split ? 1 : 0;
       const bool probe = e->probing && e->probe_n < 256;
       if (probe) {
         for (int q = 0; q < 2; ++q)
@@ -1715,10 +1723,12 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
     // one launch: the layer-3 statistics as floats (dw2, dbe2, dg2), the constants table of the generated dE2 operand where
     // that form applies (feature epochs), and W1^T
     const bool want_gen = (!need_param_grads || knob_of(e, GS_KNOB_DW1_GENERATED, g_dw1_generated)) && Ph <= 256 && rows > 0;
+    // (mode 3: the split image of W1^T for the marginals product comes out of the prep launch)
+    const bool pre_split = knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && e->operand_mode == 3 && rows > 0 && (Ph & 31) == 0;
     hipLaunchKernelGGL(gs_pge_bwd_prep_kernel, dim3(gs_cdiv(Ph, 32), gs_cdiv(Ph, 32)), dim3(32, 8), 0, s,
                        e->l3_slices > 1 ? e->sums2 : e->sums, e->l3_slices, Ph, g + e->pw2, g + e->pbe2, g + e->pg2, e->mu2, e->is2,
                        pp + e->pg2, pp + e->pbe2, pp + e->pw2, 1.f / (float)n2, want_gen ? e->gen_tab : (float*)nullptr, pp + e->pW1,
-                       e->W1T);
+                       e->W1T, pre_split ? (__bf16*)e->bsplit_main : (__bf16*)nullptr);
     if (sharded_r(e)) GS_HIP(hipMemsetAsync(e->ar_marg, 0, sizeof(float) * 2 * (long)n * Ph, s));
     if (need_param_grads) {
       GS_TRY(sum_f32(e, e->de3, n2, g + e->pb2, s));   // db2 = sum de3 (replicated)
@@ -1735,12 +1745,13 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
         gs_panel_gen gen = {e->mu2, e->is2, pp + e->pg2, pp + e->pbe2, pp + e->pw2, g + e->pbe2, g + e->pg2, de3l, (long)n2, e->gen_tab, 1};
         float* partV = e->dY1;
         float* partU = e->dY1 + (size_t)ncb0 * nr * Ph;
-        const gs_panel_a1 a1 = pge_a1(e);
+        gs_panel_a1 a1 = pge_a1(e);
+        a1.b_ready = pre_split ? 1 : 0;
         const int rc = gs_panel_marginals(e->E2, Ph, e->W1T, Ph, e->a1_valid ? e->A1 : nullptr, Ph, n, nr, Ph, Ph, partU, partV,
                                           e->operand_mode, e->bsplit_main, &gen, &a1, s);
         if (rc == GS_OK) {
-          GS_TRY(gs_reduce_slabs_f32(e->rowsum_c, partU, (long)n * Ph, nrb0, (long)n * Ph, 0.f, stream));
-          GS_TRY(gs_reduce_slabs_f32(e->colsum_r + (long)e->r_lo * Ph, partV, (long)nr * Ph, ncb0, (long)nr * Ph, 0.f, stream));
+          GS_TRY(gs_reduce_slabs_pair(e->rowsum_c, partU, (long)n * Ph, nrb0, (long)n * Ph, e->colsum_r + (long)e->r_lo * Ph, partV, (long)nr * Ph,
+                                      ncb0, (long)nr * Ph, stream));      // both marginals' partial sums: one launch
           fused_done = true;
         } else if (rc != GS_ERR_UNSUPPORTED) {
           return rc;
@@ -1787,7 +1798,8 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
         float* partU = e->dY1 + (size_t)ncb * nr * Ph;           // [nrb][n][Ph]
         int rc = GS_ERR_UNSUPPORTED;
         if (((size_t)ncb * nr + (size_t)nrb * n) * Ph <= (size_t)n2 * Ph) {
-          const gs_panel_a1 a1 = pge_a1(e);
+          gs_panel_a1 a1 = pge_a1(e);
+          a1.b_ready = pre_split ? 1 : 0;
           rc = gs_panel_marginals(e->dE2, Ph, e->W1T, Ph, e->a1_valid ? e->A1 : nullptr, Ph, n, nr, Ph, Ph, partU, partV,
                                   e->operand_mode, e->bsplit_main, nullptr, &a1, s);
         }

@@ -527,6 +527,48 @@ __global__ void gs_reduce_slabs_v4_kernel(float* __restrict__ out, const float* 
   *o = s;
 }
 
+extern "C" int gs_reduce_slabs_f32(float* out, const float* slabs, long n, int n_slabs, long slab_stride, float beta, gs_stream_t stream);
+// two independent slab reductions (beta = 0) in ONE launch: blockIdx.y selects the reduction; same summation order as
+// gs_reduce_slabs_v4_kernel (bitwise the two-launch values)
+__global__ void gs_reduce_slabs_pair_kernel(float* __restrict__ out0, const float* __restrict__ slabs0, long n4_0, int ns0, long stride4_0,
+                                            float* __restrict__ out1, const float* __restrict__ slabs1, long n4_1, int ns1, long stride4_1) {
+  const bool second = blockIdx.y != 0;
+  const long n4 = second ? n4_1 : n4_0, stride4 = second ? stride4_1 : stride4_0;
+  const int ns = second ? ns1 : ns0;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4* sl = reinterpret_cast<const float4*>(second ? slabs1 : slabs0) + i;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = 0;
+  for (; k + 8 <= ns; k += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = sl[(long)(k + u) * stride4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  for (; k < ns; ++k) {
+    const float4 v = sl[(long)k * stride4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(second ? out1 : out0)[i] = s;
+}
+
+// engine-internal: out0 = sum of ns0 slabs, out1 = sum of ns1 slabs (fixed order); one launch when both are 16-byte shaped
+int gs_reduce_slabs_pair(float* out0, const float* slabs0, long n0, int ns0, long stride0, float* out1, const float* slabs1, long n1, int ns1,
+                         long stride1, gs_stream_t stream) {
+  const bool v4 = ((n0 | n1 | stride0 | stride1) & 3) == 0 && ((((uintptr_t)out0) | ((uintptr_t)slabs0) | ((uintptr_t)out1) | ((uintptr_t)slabs1)) & 15) == 0;
+  if (!v4 || n0 <= 0 || n1 <= 0 || ns0 < 1 || ns1 < 1) {
+    GS_TRY(gs_reduce_slabs_f32(out0, slabs0, n0, ns0, stride0, 0.f, stream));
+    return gs_reduce_slabs_f32(out1, slabs1, n1, ns1, stride1, 0.f, stream);
+  }
+  const long m = n0 > n1 ? n0 : n1;
+  hipLaunchKernelGGL(gs_reduce_slabs_pair_kernel, dim3(gs_cdiv(m >> 2, 256), 2), dim3(256), 0, (hipStream_t)stream, out0, slabs0, n0 >> 2, ns0,
+                     stride0 >> 2, out1, slabs1, n1 >> 2, ns1, stride1 >> 2);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 extern "C" int gs_reduce_slabs_f32(float* out, const float* slabs, long n, int n_slabs, long slab_stride, float beta,
                                    gs_stream_t stream) {
   if (n <= 0) return GS_OK;

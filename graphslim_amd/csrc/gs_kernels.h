@@ -762,12 +762,25 @@ __global__ __launch_bounds__(1024) void gs_pge_bn1_stats_kernel(const float* __r
                                                                 float* __restrict__ mu1, float* __restrict__ is1,
                                                                 float* __restrict__ sumU, float* __restrict__ sumV,
                                                                 const float* __restrict__ g1, const float* __restrict__ be1,
-                                                                float* __restrict__ a1_tab) {
+                                                                float* __restrict__ a1_tab, float* __restrict__ Us = nullptr,
+                                                                float* __restrict__ Vs = nullptr, const float* __restrict__ W1 = nullptr,
+                                                                __bf16* __restrict__ w1_split = nullptr) {
   // a1_tab (optional): [Ph][8] = {b0, mu1, is1, g1, be1, 0, 0, 0} per column — the constants of the generated layer-1
-  // activations (gs_panel.hip, gs_panel_a1), written here so that no separate table launch is needed
+  // activations (gs_panel.hip, gs_panel_a1), written here so that no separate table launch is needed.
+  // Us, Vs (optional, round 4): the workgroup also writes the folded layer-1 terms of its 32 columns (the arithmetic of
+  // gs_pge_scale_uv_kernel, bitwise: Us = s U + t, Vs = s V, s = g1 is1, t = s (b0 - mu1) + be1) — one launch less per PGE pass.
+  // w1_split (optional): workgroups beyond the ceil(Ph / 32) statistics workgroups write the exact three-way bf16 split image of the
+  // layer-2 weight W1 [Ph][Ph] (independent work folded into this launch: the layer-2 product then starts without its own split launch)
+  const int nstat = (Ph + 31) / 32;
+  if ((int)blockIdx.x >= nstat) {
+    const long idx = (long)(blockIdx.x - nstat) * 1024 + threadIdx.x;
+    if (w1_split && idx < (long)Ph * Ph) gs_split3_store(W1[idx], (int)(idx / Ph), (int)(idx % Ph), Ph, w1_split);
+    return;
+  }
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int k = min(blockIdx.x * 32 + tx, Ph - 1);
   __shared__ double sh[2][GS_BN1_RG][32];
+  __shared__ float fold[2][32];
   double su = 0, sv = 0;
   for (int i0 = ty; i0 < n; i0 += 8 * GS_BN1_RG) {
     float u[8], v[8];
@@ -818,6 +831,20 @@ __global__ __launch_bounds__(1024) void gs_pge_bn1_stats_kernel(const float* __r
     if (a1_tab) {
       float* o = a1_tab + 8 * k;
       o[0] = b0[k]; o[1] = mu1[k]; o[2] = is1[k]; o[3] = g1[k]; o[4] = be1[k]; o[5] = o[6] = o[7] = 0.f;
+    }
+    const float m1 = (float)(mu + mv + (double)b0[k]), i1 = (float)(1.0 / sqrt(vu / n + vv / n + 1e-5));      // = mu1[k], is1[k]
+    const float sc = g1[k] * i1;
+    fold[0][tx] = sc;
+    fold[1][tx] = fmaf(sc, b0[k] - m1, be1[k]);
+  }
+  if (Us) {      // (kernel argument: uniform)
+    __syncthreads();
+    if (blockIdx.x * 32 + tx < Ph) {
+      const float sc = fold[0][tx], t = fold[1][tx];
+      for (int i = ty; i < n; i += GS_BN1_RG) {
+        Us[(long)i * Ph + k] = fmaf(sc, U[(long)i * Ph + k], t);
+        Vs[(long)i * Ph + k] = sc * V[(long)i * Ph + k];
+      }
     }
   }
 }
@@ -1374,7 +1401,10 @@ __global__ void gs_pge_bwd_prep_kernel(const double* __restrict__ sums, int slic
                                        float* __restrict__ dbe2, float* __restrict__ dg2, const float* __restrict__ mu2,
                                        const float* __restrict__ is2, const float* __restrict__ g2, const float* __restrict__ be2,
                                        const float* __restrict__ w2, float invN, float* __restrict__ gen_table,
-                                       const float* __restrict__ W1, float* __restrict__ W1T) {
+                                       const float* __restrict__ W1, float* __restrict__ W1T,
+                                       __bf16* __restrict__ w1t_split = nullptr) {
+  // w1t_split (optional, round 4): also the exact three-way bf16 split image of W1^T (B operand of the marginals product in mode 3:
+  // that launch then needs no split launch of its own)
   __shared__ float t[32][33];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
@@ -1384,7 +1414,10 @@ __global__ void gs_pge_bwd_prep_kernel(const double* __restrict__ sums, int slic
   __syncthreads();
   for (int j = threadIdx.y; j < 32; j += blockDim.y) {
     const int c = c0 + j, r = r0 + threadIdx.x;
-    if (c < Ph && r < Ph) W1T[(long)c * Ph + r] = t[threadIdx.x][j];
+    if (c < Ph && r < Ph) {
+      W1T[(long)c * Ph + r] = t[threadIdx.x][j];
+      if (w1t_split) gs_split3_store(t[threadIdx.x][j], c, r, Ph, w1t_split);
+    }
   }
   if (blockIdx.y == 0 && threadIdx.y == 0) {
     const int k = c0 + threadIdx.x;

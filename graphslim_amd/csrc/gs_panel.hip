@@ -670,19 +670,16 @@ __global__ void gs_panel_split_b3_kernel(const float* __restrict__ W, long ldb, 
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (row, k)
   if (idx >= (long)N * K) return;
   const int n = (int)(idx / K), k = (int)(idx % K);
-  const float w = W[(long)n * ldb + k];
-  const __bf16 hb = (__bf16)w;
-  const float r1 = w - (float)hb;
-  const __bf16 mb = (__bf16)r1;
-  const __bf16 lb = (__bf16)(r1 - (float)mb);
-  const int sb = 2 * (k >> 5) + ((k >> 3) & 1), half = (k >> 4) & 1, e = k & 7;
-  __bf16* o = out + ((long)n * (K >> 4) + sb) * 48 + half * 8 + e;
-  o[0] = hb; o[16] = mb; o[32] = lb;
+  gs_split3_store(W[(long)n * ldb + k], n, k, K, out);
 }
 
 // pre-split image of B for the operand mode (no-op for exact fp32); returns the row pitch in bytes
-static long panel_prepare_b(const float* W, long ldw, int N, int K, int prec, void* scratch, hipStream_t s, const void** Bout) {
+// (b_ready: the caller has already written the three-way split image of W into `scratch` on this stream — gs_pge_bn1_fold_kernel,
+// gs_pge_bwd_prep_kernel — so the stand-alone split launch is skipped; mode 3 only)
+static long panel_prepare_b(const float* W, long ldw, int N, int K, int prec, void* scratch, hipStream_t s, const void** Bout,
+                            bool b_ready = false) {
   if (prec == 0) { *Bout = W; return ldw * 4; }
+  if (prec == 3 && b_ready) { *Bout = scratch; return (long)K * 6; }
   const dim3 grid(gs_cdiv((long)N * K, 256)), block(256);
   *Bout = scratch;
   if (prec == 3) {
@@ -852,7 +849,8 @@ struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3;
 // quantities (5 arrays of the hidden width) and the [width][8] float constants table {b0, mu1, is1, g1, be1, 0, 0, 0} per column,
 // which the CALLER fills (the engine's gs_pge_bn1_stats_kernel writes it next to mu1 / is1): with `a1` the marginals' [A1 > 0]
 // mask is recomputed from them (`mask` may be null), and gs_panel_forward_a1 forms the A operand of E2 = A1 W1^T + b1 from them.
-struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; const float *Us, *Vs; };      // Us, Vs: the folded terms (gs_pge_scale_uv_kernel) or null
+struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; const float *Us, *Vs; int b_ready; };      // Us, Vs: the folded
+      // terms (gs_pge_scale_uv_kernel) or null; b_ready: `scratch` already holds the three-way split image of the product's W
 
 static int g_panel_a1gen = 1;
 // measurement knob: 0 = always materialise A1 (round-2 first form), 1 (default) = generate it in the operand / mask path
@@ -882,7 +880,7 @@ int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, lo
   panel_split(a.M, &nf, &nn);
   a.n_full = nf;
   const dim3 grid(nf + nn), block(256);
-  a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);
+  a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B, a1->b_ready != 0);
   if (stat_slabs) *stat_slabs = nf + nn;
   if (prec == 3 && N == 256 && g_panel_krep == 1 && !a.triage &&
       gs_tall_forward_a1(a1->Us, a1->Vs, a1->ld, n, nr, a.B, a.ldb_bytes, bias, C, ldc, K, colstat, stat_slabs, span, alone, s) == GS_OK)
@@ -910,6 +908,7 @@ int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, lo
 int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, const float* mask, long ldmask, int n, int nr, int N,
                        int K, float* partU, float* partV, int prec, void* scratch, const gs_panel_gen* gen, const gs_panel_a1* a1,
                        hipStream_t s) {
+  const bool b_ready = a1 && a1->b_ready;
   if (a1 && (!g_panel_a1gen || !a1->table || (a1->ld & 3))) a1 = nullptr;
   if (!a1 && !mask) return GS_ERR_UNSUPPORTED;
   // (generated operand: modes 0 and 3 at N = 256 — the up-front bf16 conversions of modes 1 and 2 next to it need more than 256
@@ -936,7 +935,7 @@ int gs_panel_marginals(const float* dE2, long lda, const float* W, long ldw, con
     if (prec == 3 && N == 256 && a1->Us && a1->Vs) { a.a1_U = a1->Us; a.a1_V = a1->Vs; a.a1_fold = 1; }
   }
   const dim3 grid((unsigned)(gs_cdiv(nr, 16) * a.mg_ncb)), block(256);
-  a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B);
+  a.ldb_bytes = panel_prepare_b(W, ldw, N, K, prec, scratch, s, &a.B, b_ready);
   if (prec == 3 && N == 256 && gen && a1 && lda == K &&
       gs_tall_marginals(dE2, a.B, a.ldb_bytes, a.gen_c, a.gen_d, a1->Us, a1->Vs, a1->ld, n, nr, K, partU, partV, s) == GS_OK)
     return GS_OK;

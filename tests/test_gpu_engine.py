@@ -597,6 +597,50 @@ def test_two_engines_with_different_knob_settings_do_not_see_each_other():
         _lib.check(L.gs_gcond_set_h1_rows(1))
 
 
+@pytest.mark.parametrize("workload,scale,mode", [("ogbn-arxiv", 1.0, "bf16x6"), ("ogbn-arxiv", 0.13, "bf16x6"), ("cora", 1.0, "bf16x6"),
+                                                 ("ogbn-arxiv", 0.25, "f32")])
+def test_launches_folded_into_the_pge_passes_give_bitwise_the_same_values(workload, scale, mode):
+    """Round 4: the BatchNorm-1 statistics launch also writes the folded layer-1 terms Us | Vs and (extra workgroups) the three-way
+    split image of W1; the backward's prep launch also writes the split image of W1^T; the two marginal slab reductions are one
+    launch.  Against the launch-per-piece form (knob GS_KNOB_FUSED_CHAINS 0) from identical inputs — the same d_adj is injected —
+    every value of the PGE forward and backward is bitwise the same (n' >= 128 with P_h = 256: persistent kernels; n' = 59 and
+    P_h = 128: the other routes; the fp32 pipe: nothing is folded)."""
+    from graphslim_amd import _lib
+    from graphslim_amd import workloads as W
+    from graphslim_amd.host import init_sgc_params
+    L = _lib.lib()
+    KNOB_FUSED_CHAINS = 0
+    p = W.build_problem(workload, seed=1, scale=scale)
+    d, C = p["data"].feat_full.shape[1], p["data"].nclass
+    eng = W.make_engine(p, DEV)
+    eng.set_operand_mode(mode)
+    W.init_state(p, eng)
+    torch.manual_seed(3)
+    eng.set_model(init_sgc_params(d, p["hidden"], C, p["T"]))
+    n = len(p["labels_syn"])
+    g = torch.Generator(device="cpu").manual_seed(5)
+    d_adj = (torch.randn(n * n, generator=g) * 1e-3).to(DEV)
+    out = {}
+    for on in (0, 1):
+        _lib.check(L.gs_gcond_set_knob(eng.h, KNOB_FUSED_CHAINS, on))
+        for pge_epoch in (False, True):
+            for name in ("E2", "e3", "adj_norm", "d_pge", "ar_marg"):
+                eng.view(name).fill_(float("nan"))
+            eng.stage_pge_forward(False)
+            eng.view("d_adj").copy_(d_adj)
+            eng.view("d_feat").zero_()
+            eng.stage_pge_backward(pge_epoch, True)
+            torch.cuda.synchronize()
+            out[(on, pge_epoch)] = {k: eng.buffer(k).clone() for k in ("E2", "mu2", "is2", "e3", "adj_norm", "ar_marg", "d_pge", "d_feat")}
+    for pge_epoch in (False, True):
+        a, b = out[(0, pge_epoch)], out[(1, pge_epoch)]
+        for k in a:
+            if k == "d_pge" and not pge_epoch:
+                continue      # (feature epochs leave the weight gradients they do not need unwritten)
+            assert not torch.isnan(b[k]).any() and float(b[k].abs().max()) > 0, (k, pge_epoch)
+            assert torch.equal(a[k], b[k]), (k, pge_epoch, float((a[k] - b[k]).abs().max()))
+
+
 @pytest.mark.parametrize("workload,scale,shard,metric", [("ogbn-arxiv", 1.0, None, "ours"), ("ogbn-arxiv", 0.13, None, "mse"),
                                                          ("ogbn-arxiv", 0.25, (7, 19), "ours"), ("flickr", 1.0, None, "ours"),
                                                          ("arxiv-gate", 0.05, None, "cos")])
