@@ -81,6 +81,9 @@ struct gs_gcond {
   int *h1_flag, *h1_list, *h1_count;   // rows of H1full this rank's sampled blocks gather (sharded ranks: only those are computed)
   unsigned* H1bits;                    // [N][h / 32] sign bits of H1full, written by its product's epilogue: the edge product's mask
   double* sum_part;                    // [128] scratch of sum_f32
+  bool l3_direct;                    // part 1 of the PGE backward left the statistics partials for part 2's prep launch to reduce
+  bool bn2_done;                     // part 1 of the PGE forward has already left the BatchNorm-2 statistics (unsharded, fused)
+  bool fold_finish;                  // this call of the matching stage also books the loss (set by the fused outer step only)
   int knob[GS_KNOB_COUNT];             // per-engine value of a measurement knob (gs_gcond_set_knob), -1 = follow the process default
   unsigned* edge_bits;                 // [C][cap1 * f2][h / 32] sign bits of the H1 row each hop-2 edge slot gathered (gs_ell_spmm_kernel): the
                                        // edge product reads its ReLU mask from these 32 B per edge instead of the 1-KiB row of H1full
@@ -300,6 +303,9 @@ static size_t carve(gs_gcond* e, void* base) {
   e->UsVs = w.take<float>(2 * n * Ph);
   e->uvs_valid = false;
   for (int i = 0; i < GS_KNOB_COUNT; ++i) e->knob[i] = -1;
+  e->fold_finish = false;
+  e->bn2_done = false;
+  e->l3_direct = false;
   e->a1_valid = false;
   e->bn2_slices = e->l3_slices = 1;
   e->chunk_fwd = w.take<float>((long)e->pge_chunks * 4 * Ph); e->chunk_bwd = w.take<float>((long)e->pge_chunks * 5 * Ph);
@@ -1194,15 +1200,26 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
         e->probe_n++;
       }
       // (unsharded: the last reduction stage is folded into gs_bn2_from_sums; sharded ranks exchange e->sums in between)
-      e->bn2_slices = reduce_parts(e, e->statp, tiles, 2, 2, s, knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e));
+      e->bn2_done = false;
+      if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e)) {
+        // round 4: both reduction stages and the statistics in ONE launch, same grouping of the sums (bitwise the three-launch values)
+        hipLaunchKernelGGL(gs_bn2_stats_fold_kernel, dim3(gs_cdiv(Ph, 32)), dim3(1024), 0, s, (const float*)e->statp, tiles, tiles > 64 ? 32 : 1,
+                           n2, Ph, e->mu2, e->is2);
+        e->bn2_done = true;
+        e->bn2_slices = 1;
+      } else {
+        e->bn2_slices = reduce_parts(e, e->statp, tiles, 2, 2, s, knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e));
+      }
       GS_LAUNCH_CHECK();
     } else {
       GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 2 * Ph, s));
       e->bn2_slices = 1;
+      e->bn2_done = false;
     }
     return GS_OK;
   }
   if (part == 2) {
+    if (!e->bn2_done)
     hipLaunchKernelGGL(gs_bn2_from_sums_kernel, dim3(gs_cdiv(Ph, 64)), dim3(64), 0, s, e->bn2_slices > 1 ? e->sums2 : e->sums,
                        e->bn2_slices, n2, Ph, e->mu2, e->is2);
     if (sharded_r(e)) GS_HIP(hipMemsetAsync(e->e3, 0, sizeof(float) * n2, s));
@@ -1451,7 +1468,8 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     }
     { gs_gemm_desc g = mk(e->Rmat, h, 1, Wl, C, 1, e->Ug, C, n, C, h); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }   // Ug += R W2
     hipLaunchKernelGGL(gs_syn_v_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Ps, e->Gs, e->Ug, e->ones, e->D, P, e->obl, bl,
-                       e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->c_lo, e->c_hi, e->Vs, e->drs);
+                       e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->c_lo, e->c_hi, e->Vs, e->drs,
+                       e->fold_finish ? (const float*)e->loss_c : (const float*)nullptr, C, e->loss_sum, e->loss_last, e->steps);
     GS_LAUNCH_CHECK();
     { gs_gemm_desc g = mk(e->Vs, C, 1, Wl, 1, C, e->dSs, h, n, h, C); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }    // dS2 += V W2^T
     {
@@ -1618,7 +1636,8 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     }
   }
   hipLaunchKernelGGL(gs_syn_v_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Ps, e->Gs, e->Ug, e->rsq, e->D, P, e->obl, bl,
-                     e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->c_lo, e->c_hi, e->Vs, e->drs);
+                     e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->c_lo, e->c_hi, e->Vs, e->drs,
+                     e->fold_finish ? (const float*)e->loss_c : (const float*)nullptr, C, e->loss_sum, e->loss_last, e->steps);
   GS_LAUNCH_CHECK();
   {  // dS[lo:hi] = G[lo:hi] Dl_c^T ;  dS += V Wl^T
     if (Cl > 0 && !ds_done) {
@@ -1711,10 +1730,15 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
       else
         hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(nblk), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2, pp + e->pg2,
                            pp + e->pbe2, pp + e->pw2, rows, Ph, e->rows_per_block, e->parts);
+      // (unsharded + fused: both reduction stages ride in part 2's prep launch — gs_pge_bwd_prep_fold_kernel)
+      e->l3_direct = knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e);
+      if (e->l3_direct) e->l3_slices = 1;
+      else
       e->l3_slices = reduce_parts(e, e->parts, nblk, 3, 3, s, knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e));
     } else {
       GS_HIP(hipMemsetAsync(e->sums, 0, sizeof(double) * 3 * Ph, s));
       e->l3_slices = 1;
+      e->l3_direct = false;
     }
     GS_LAUNCH_CHECK();
     return GS_OK;
@@ -1725,6 +1749,12 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
     const bool want_gen = (!need_param_grads || knob_of(e, GS_KNOB_DW1_GENERATED, g_dw1_generated)) && Ph <= 256 && rows > 0;
     // (mode 3: the split image of W1^T for the marginals product comes out of the prep launch)
     const bool pre_split = knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && e->operand_mode == 3 && rows > 0 && (Ph & 31) == 0;
+    if (e->l3_direct && rows > 0) {
+      const int nt = gs_cdiv(Ph, 32);
+      hipLaunchKernelGGL(gs_pge_bwd_prep_fold_kernel, dim3(nt + nt * nt), dim3(1024), 0, s, (const double*)e->parts, nblk, nblk > 64 ? 32 : 1, Ph,
+                         g + e->pw2, g + e->pbe2, g + e->pg2, e->mu2, e->is2, pp + e->pg2, pp + e->pbe2, pp + e->pw2, 1.f / (float)n2,
+                         want_gen ? e->gen_tab : (float*)nullptr, pp + e->pW1, e->W1T, pre_split ? (__bf16*)e->bsplit_main : (__bf16*)nullptr);
+    } else
     hipLaunchKernelGGL(gs_pge_bwd_prep_kernel, dim3(gs_cdiv(Ph, 32), gs_cdiv(Ph, 32)), dim3(32, 8), 0, s,
                        e->l3_slices > 1 ? e->sums2 : e->sums, e->l3_slices, Ph, g + e->pw2, g + e->pbe2, g + e->pg2, e->mu2, e->is2,
                        pp + e->pg2, pp + e->pbe2, pp + e->pw2, 1.f / (float)n2, want_gen ? e->gen_tab : (float*)nullptr, pp + e->pW1,
@@ -1856,10 +1886,14 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
   if (need_feat_grad) {   // d_feat += dU W0[:, :d] + dV W0[:, d:]
     gs_gemm_desc a = mk(e->dU, Ph, 1, pp + e->pW0, 2L * d, 1, e->d_feat, d, n, d, Ph);
     a.beta = 1.f;
-    GS_TRY(gs_gemm_f32(&a, stream));
     gs_gemm_desc b = mk(e->dV, Ph, 1, pp + e->pW0 + d, 2L * d, 1, e->d_feat, d, n, d, Ph);
     b.beta = 1.f;
-    GS_TRY(gs_gemm_f32(&b, stream));
+    if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains)) {      // both products by the workgroup that owns the tile: one launch, same bits
+      GS_TRY(gs_gemm_group2_f32(&a, &b, 1, stream));
+    } else {
+      GS_TRY(gs_gemm_f32(&a, stream));
+      GS_TRY(gs_gemm_f32(&b, stream));
+    }
   }
   return GS_OK;
 }
@@ -2264,9 +2298,15 @@ static int outer_step_impl(gs_gcond* e, int step_pge, int step_feat, int run_inf
         GS_TRY(pge_forward_x(e, 0, comm, stream));
     }
   }
-  GS_TRY(gs_gcond_stage_syn_match(e, stream));
+  // (unsharded: the loss bookkeeping rides in the matching stage's V kernel — every class loss is final there; sharded ranks sum the
+  // class partials first)
+  e->fold_finish = !comm && !sharded_c(e) && e->c_hi > e->c_lo && knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains);
+  const bool folded = e->fold_finish;
+  const int rc_match = gs_gcond_stage_syn_match(e, stream);
+  e->fold_finish = false;
+  GS_TRY(rc_match);
   GS_TRY(xchg(comm, e->ar_syn, (long)e->n * e->d + (long)e->n * e->n + e->C, 0, 2, stream));
-  GS_TRY(gs_gcond_stage_syn_finish(e, stream));
+  if (!folded) GS_TRY(gs_gcond_stage_syn_finish(e, stream));
   // only the gradient of a group that is stepped is consumed (zero_grad() discards the rest unread, gcond.py:54-61)
   if (!e->identity && (step_pge || step_feat)) GS_TRY(pge_backward_x(e, step_pge, step_feat, comm, stream));
   if (step_pge)

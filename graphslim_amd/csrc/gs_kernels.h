@@ -165,7 +165,18 @@ __global__ __launch_bounds__(256) void gs_syn_v_kernel(const float* __restrict__
                                                        const float* __restrict__ bl, const int* __restrict__ labels,
                                                        const int* __restrict__ syn_lo, const int* __restrict__ syn_hi, int n,
                                                        int C, int c_lo, int c_hi, float* __restrict__ V,
-                                                       float* __restrict__ drs) {
+                                                       float* __restrict__ drs, const float* __restrict__ loss_c = nullptr,
+                                                       int n_loss = 0, double* __restrict__ loss_sum = nullptr,
+                                                       float* __restrict__ loss_last = nullptr, long* __restrict__ steps = nullptr) {
+  // loss_c (optional): the iteration's loss bookkeeping (gs_loss_accum_kernel's arithmetic) by the first thread of the launch — the
+  // class losses are final before this kernel (unsharded engines inside gs_gcond_outer_step: one launch less at the end of the stage)
+  if (loss_c && blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int c = 0; c < n_loss; ++c) s += loss_c[c];
+    *loss_last = s;
+    *loss_sum += (double)s;
+    *steps += 1;
+  }
   const int lane = threadIdx.x & 63;
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (i >= n) return;
@@ -944,6 +955,50 @@ __global__ void gs_bn2_from_sums_kernel(const double* __restrict__ sums, int sli
   is2[k] = (float)(1.0 / sqrt(v + 1e-5));
 }
 
+// gs_sum_parts_f32_kernel (both stages) + gs_bn2_from_sums_kernel in ONE launch: the BatchNorm-2 batch statistics straight from the
+// layer-2 product's per-tile column sums part[blk][2][Ph] (fp32), with the SAME grouping of the fp64 sums (S slices of
+// ceil(nblk / S) blocks, 8 interleaved row groups per slice, slices combined as in gs_sum_slices) — bitwise the three-launch values.
+// grid ceil(Ph / 32), block 1024 = 32 columns x 32 slices; S = 32 (nblk > 64) or 1.
+__global__ __launch_bounds__(1024) void gs_bn2_stats_fold_kernel(const float* __restrict__ part, int nblk, int S, long rows, int Ph,
+                                                                 float* __restrict__ mu2, float* __restrict__ is2) {
+  const int tx = threadIdx.x & 31, z = threadIdx.x >> 5;
+  const int k = min(blockIdx.x * 32 + tx, Ph - 1);
+  const int per = (nblk + S - 1) / S, b0 = z * per, b1 = min(nblk, b0 + per);
+  __shared__ double sh[2][32][32];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    double s = 0;
+    if (z < S) {
+      double s8[8];
+#pragma unroll
+      for (int ty = 0; ty < 8; ++ty) {
+        double a = 0;
+        for (int b = b0 + ty; b < b1; b += 8) a += (double)part[((long)b * 2 + q) * Ph + k];
+        s8[ty] = a;
+      }
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s += s8[g];
+    }
+    sh[q][z][tx] = s;
+  }
+  __syncthreads();
+  if (z != 0 || blockIdx.x * 32 + tx >= Ph) return;
+  double tot[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (S <= 1) { tot[q] = sh[q][0][tx]; continue; }
+    double t = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += ((sh[q][g][tx] + sh[q][g + 8][tx]) + sh[q][g + 16][tx]) + sh[q][g + 24][tx];
+    tot[q] = t;
+  }
+  const double m = tot[0] / rows;
+  double v = tot[1] / rows - m * m;
+  if (v < 0) v = 0;
+  mu2[k] = (float)m;
+  is2[k] = (float)(1.0 / sqrt(v + 1e-5));
+}
+
 // e3[row] = sum_k relu(g2*(E2-mu2)*is2+be2) * w2[k] + b2      (one wave per pair)
 __global__ __launch_bounds__(256) void gs_pge_layer3_kernel(const float* __restrict__ E2, const float* __restrict__ mu2,
                                                             const float* __restrict__ is2, const float* __restrict__ g2,
@@ -1428,6 +1483,67 @@ __global__ void gs_pge_bwd_prep_kernel(const double* __restrict__ sums, int slic
       if (gen_table) gs_panel_gen_row(mu2[k], is2[k], g2[k], be2[k], w2[k], b, c, invN, gen_table + 8 * k);
     }
   }
+}
+// gs_sum_parts_kernel (both stages) + gs_pge_bwd_prep_kernel in ONE launch (unsharded engines): the first ceil(Ph / 32) workgroups
+// reduce the layer-3 statistics partials part[blk][3][Ph] (fp64) with the SAME grouping as the two reduction stages (bitwise their
+// values) and finish dw2 | dbe2 | dg2 and the constants table; the others transpose one 32 x 32 tile of W1 each (+ the split image).
+__global__ __launch_bounds__(1024) void gs_pge_bwd_prep_fold_kernel(const double* __restrict__ part, int nblk, int S, int Ph,
+                                                                    float* __restrict__ dw2, float* __restrict__ dbe2,
+                                                                    float* __restrict__ dg2, const float* __restrict__ mu2,
+                                                                    const float* __restrict__ is2, const float* __restrict__ g2,
+                                                                    const float* __restrict__ be2, const float* __restrict__ w2, float invN,
+                                                                    float* __restrict__ gen_table, const float* __restrict__ W1,
+                                                                    float* __restrict__ W1T, __bf16* __restrict__ w1t_split) {
+  const int tx = threadIdx.x & 31, z = threadIdx.x >> 5;
+  const int nstat = (Ph + 31) / 32;
+  __shared__ double sh[3][32][32];
+  if ((int)blockIdx.x >= nstat) {
+    float (*t)[33] = reinterpret_cast<float (*)[33]>(&sh[0][0][0]);
+    const int nt = (Ph + 31) / 32, idx = blockIdx.x - nstat;
+    const int c0 = (idx % nt) * 32, r0 = (idx / nt) * 32;
+    {
+      const int r = r0 + z, c = c0 + tx;
+      t[z][tx] = (r < Ph && c < Ph) ? W1[(long)r * Ph + c] : 0.f;
+    }
+    __syncthreads();
+    const int c = c0 + z, r = r0 + tx;
+    if (c < Ph && r < Ph) {
+      W1T[(long)c * Ph + r] = t[tx][z];
+      if (w1t_split) gs_split3_store(t[tx][z], c, r, Ph, w1t_split);
+    }
+    return;
+  }
+  const int k = min(blockIdx.x * 32 + tx, Ph - 1);
+  const int per = (nblk + S - 1) / S, b0 = z * per, b1 = min(nblk, b0 + per);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    double s = 0;
+    if (z < S) {
+      double s8[8];
+#pragma unroll
+      for (int ty = 0; ty < 8; ++ty) {
+        double a = 0;
+        for (int b = b0 + ty; b < b1; b += 8) a += part[((long)b * 3 + q) * Ph + k];
+        s8[ty] = a;
+      }
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s += s8[g];
+    }
+    sh[q][z][tx] = s;
+  }
+  __syncthreads();
+  if (z != 0 || blockIdx.x * 32 + tx >= Ph) return;
+  float tot[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (S <= 1) { tot[q] = (float)sh[q][0][tx]; continue; }
+    double t = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += ((sh[q][g][tx] + sh[q][g + 8][tx]) + sh[q][g + 16][tx]) + sh[q][g + 24][tx];
+    tot[q] = (float)t;
+  }
+  dw2[k] = tot[0]; dbe2[k] = tot[1]; dg2[k] = tot[2];
+  if (gen_table) gs_panel_gen_row(mu2[k], is2[k], g2[k], be2[k], w2[k], tot[1], tot[2], invN, gen_table + 8 * k);
 }
 __global__ void gs_pge_bn1_bwd_uv_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                          const float* __restrict__ rowsum_c, const float* __restrict__ colsum_r,
