@@ -1201,7 +1201,9 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       }
       // (unsharded: the last reduction stage is folded into gs_bn2_from_sums; sharded ranks exchange e->sums in between)
       e->bn2_done = false;
-      if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e)) {
+      // (<= 256 partial rows — the persistent kernel's one per workgroup: 8 workgroups sum them as fast as the 512 of the two-stage
+      // form; the 128-row kernel's 1 611 rows took them 36 us)
+      if (tiles <= 256 && knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e)) {
         // round 4: both reduction stages and the statistics in ONE launch, same grouping of the sums (bitwise the three-launch values)
         hipLaunchKernelGGL(gs_bn2_stats_fold_kernel, dim3(gs_cdiv(Ph, 32)), dim3(1024), 0, s, (const float*)e->statp, tiles, tiles > 64 ? 32 : 1,
                            n2, Ph, e->mu2, e->is2);
@@ -1731,7 +1733,7 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
         hipLaunchKernelGGL(gs_pge_l3_bwd_stats_kernel, dim3(nblk), dim3(256), 0, s, e->E2, de3l, e->mu2, e->is2, pp + e->pg2,
                            pp + e->pbe2, pp + e->pw2, rows, Ph, e->rows_per_block, e->parts);
       // (unsharded + fused: both reduction stages ride in part 2's prep launch — gs_pge_bwd_prep_fold_kernel)
-      e->l3_direct = knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e);
+      e->l3_direct = nblk <= 256 && knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e);      // (few partial rows only: 3 221 at n' = 454 took the 8 workgroups 100 us)
       if (e->l3_direct) e->l3_slices = 1;
       else
       e->l3_slices = reduce_parts(e, e->parts, nblk, 3, 3, s, knob_of(e, GS_KNOB_FOLDED_REDUCTIONS, g_defer_last_stage) && !sharded_r(e));
