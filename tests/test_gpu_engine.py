@@ -693,6 +693,34 @@ def test_chained_class_products_of_the_match_agree_with_the_batched_products(wor
         assert err < 2e-5, (name, err)
 
 
+def test_fork_order_knob_changes_nothing_but_the_schedule():
+    """GS_KNOB_FORK_LATE (measurement knob: the real-side branch forked after the training forward's long product instead of beside it)
+    only moves an event: two engines stepped through PGE and feature epochs with either order hold bitwise the same state."""
+    import bench
+    from graphslim_amd import _lib
+    from graphslim_amd.host import init_sgc_params
+    L = _lib.lib()
+    KNOB_FORK_LATE = 7
+    p = bench.build_problem("ogbn-arxiv", seed=1, scale=0.25)
+    d, C = p["data"].feat_full.shape[1], p["data"].nclass
+    torch.manual_seed(2)
+    theta = init_sgc_params(d, p["hidden"], C, p["T"])
+    engs = []
+    for late in (0, 1):
+        eng = bench.make_engine(p, DEV)
+        bench.init_state(p, eng)
+        eng.set_model(theta)
+        _lib.check(L.gs_gcond_set_knob(eng.h, KNOB_FORK_LATE, late))
+        assert L.gs_gcond_get_knob(eng.h, KNOB_FORK_LATE) == late
+        for epoch in (0, 0, 10, 10):
+            eng.outer_step(epoch)
+        torch.cuda.synchronize()
+        engs.append(eng)
+    a, b = engs
+    assert a.read_loss() == b.read_loss()
+    assert torch.equal(a.feat_syn, b.feat_syn) and torch.equal(a.pge_params, b.pge_params) and torch.equal(a.model_params, b.model_params)
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x6"])
 def test_per_edge_sign_bits_of_the_hop2_gather_give_bitwise_the_same_real_side_gradients(mode):
     """VERDICT r03 "next" 2a: the hop-2 gather kernel has every gathered row of H1 = relu(X W1 + b1) in registers and writes its

@@ -4,7 +4,7 @@
 # one-call sharded iteration, other workloads, whole jobs.  Outputs -> gpurun_out/prof4 (copied to profiles/r04).
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/prof4
+O=gpurun_out/${1:-prof4}
 mkdir -p $O
 nproc > $O/host.txt; lscpu | grep "Model name" >> $O/host.txt
 timeout 600 python bench.py > $O/bench_arxiv.json 2> $O/bench_arxiv.err

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Timeline of ONE outer iteration from a rocprofv3 kernel_trace.csv: kernels in start order per queue with start offset,
-duration, gap to the previous kernel of the same queue and grid size.  An iteration = from one gs_loss_accum_kernel launch
-to the next.  usage: timeline_csv.py kernel_trace.csv [which_iteration_from_the_end=3]"""
+duration, gap to the previous kernel of the same queue and grid size.  An iteration = from one launch of the matching stage's last
+kernel (gs_norm_bwd_out_kernel; the loss bookkeeping that used to follow it rides in the V kernel since round 4) to the next — so a
+printed "iteration" starts with the PGE backward.  usage: timeline_csv.py kernel_trace.csv [which_iteration_from_the_end=3]"""
 import csv
 import re
 import sys
@@ -11,6 +12,8 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows = [r for r in csv.DictReader(open(path))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "gs_loss_accum_kernel" in r["Kernel_Name"]]
+if len(marks) <= back:
+    marks = [i for i, r in enumerate(rows) if "gs_norm_bwd_out_kernel" in r["Kernel_Name"]]
 lo, hi = marks[-back - 1], marks[-back]
 seg = rows[lo + 1:hi + 1]
 t0 = int(seg[0]["Start_Timestamp"])
