@@ -726,6 +726,11 @@ bool gs_panel_eligible(const gs_gemm_desc& p) {
   return true;
 }
 
+static int g_panel_fwd_pad = 0;     // gs_panel_set_fwd_lds_pad
+extern "C" int gs_panel_set_fwd_lds_pad(int bytes) {
+  g_panel_fwd_pad = bytes < 0 ? 0 : bytes;
+  return GS_OK;
+}
 static int g_panel_slots = 0;       // resident workgroups per launch: 2 per CU (registers: 2 waves / SIMD; LDS: 2 x 65 KB)
 static int g_panel_narrow = 1;      // finish the last partial round in 32-row tiles (0: 128-row tiles throughout)
 
@@ -887,7 +892,9 @@ int gs_panel_forward_a1(const gs_panel_a1* a1, int n, int nr, const float* W, lo
     return GS_OK;
   if (prec == 3 && N == 256 && a1->Us && a1->Vs) {      // the folded form (what the 256-row kernels and gs_dw1_generated use): same bits everywhere
     a.a1_U = a1->Us; a.a1_V = a1->Vs; a.A = a1->Us;
-    hipLaunchKernelGGL((gs_panel_fwdgen_kernel<3, 8, true>), grid, block, 0, s, a);
+    // (measurement knob gs_panel_set_fwd_lds_pad: dynamic LDS added to the TRAINING pass's launch — 80 KB static + pad > 80 KB leaves ONE
+    // workgroup per CU, i.e. half of the register file and LDS free for the real-side stream's kernels running beside it)
+    hipLaunchKernelGGL((gs_panel_fwdgen_kernel<3, 8, true>), grid, block, alone ? 0 : g_panel_fwd_pad, s, a);
     GS_LAUNCH_CHECK();
     return GS_OK;
   }

@@ -53,6 +53,10 @@ int gs_gemm_set_panel_marg(int level);
    Both forms give bitwise the same results (tests/test_gpu_panel.py).  A measurement knob. */
 int gs_gemm_set_panel_a1gen(int on);
 
+/* dynamic LDS (bytes) added to the training pass's 128-row forward launch (it runs beside the real-side stream): 80 KB static + a pad
+   above 80 KB in total leaves one workgroup per CU instead of two.  0 (default) = none.  Same values either way. */
+int gs_panel_set_fwd_lds_pad(int bytes);
+
 /* row-panel kernel measurement hooks (tools/trace_panel.py): the K loop repeated krep times; triage bit 0 = no stores,
    bit 1 = per-workgroup placement / timing trace into desc.scratch.  krep = 1, triage = 0 restores the product path. */
 int gs_panel_debug(int krep, int triage);

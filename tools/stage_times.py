@@ -25,6 +25,10 @@ for env, fn in (("GS_H1_BITS", "gs_gcond_set_h1_bits"), ("GS_EDGE_KERNEL", "gs_g
         from graphslim_amd import _lib
         getattr(_lib.lib(), fn)(int(os.environ[env]))
         print(f"{fn}({os.environ[env]})")
+if os.environ.get("GS_FWD_PAD") is not None:      # dynamic LDS pad of the training pass's 128-row forward launch (one workgroup per CU above 0)
+    from graphslim_amd import _lib
+    _lib.lib().gs_panel_set_fwd_lds_pad(int(os.environ["GS_FWD_PAD"]))
+    print(f"gs_panel_set_fwd_lds_pad({os.environ['GS_FWD_PAD']})")
 if os.environ.get("GS_TALL") is not None:      # 0: the 128-row exact-split kernels of gs_panel.hip; "1,GRID": persistent grid size
     from graphslim_amd import _lib
     v = os.environ["GS_TALL"].split(",")
