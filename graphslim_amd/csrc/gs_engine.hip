@@ -81,6 +81,7 @@ struct gs_gcond {
   int *h1_flag, *h1_list, *h1_count;   // rows of H1full this rank's sampled blocks gather (sharded ranks: only those are computed)
   unsigned* H1bits;                    // [N][h / 32] sign bits of H1full, written by its product's epilogue: the edge product's mask
   double* sum_part;                    // [128] scratch of sum_f32
+  bool skip_dfeat;                   // this call of the matching stage need not leave d loss / d X~ (set by the fused outer step only)
   bool l3_direct;                    // part 1 of the PGE backward left the statistics partials for part 2's prep launch to reduce
   bool bn2_done;                     // part 1 of the PGE forward has already left the BatchNorm-2 statistics (unsharded, fused)
   bool fold_finish;                  // this call of the matching stage also books the loss (set by the fused outer step only)
@@ -306,6 +307,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->fold_finish = false;
   e->bn2_done = false;
   e->l3_direct = false;
+  e->skip_dfeat = false;
   e->a1_valid = false;
   e->bn2_slices = e->l3_slices = 1;
   e->chunk_fwd = w.take<float>((long)e->pge_chunks * 4 * Ph); e->chunk_bwd = w.take<float>((long)e->pge_chunks * 5 * Ph);
@@ -1582,9 +1584,10 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       if (mclass) {      // one launch; A1m_c stays in the accumulator registers of the wave that feeds it to Bc
         gs_match2_args a2;
         a2.X = X; a2.D = Dv; a2.mask = e->H1s; a2.Wl = Wl; a2.dHp = dHp; a2.sD = P; a2.oW1 = e->oW1; a2.ob1 = e->ob1; a2.s_dhp = (long)n * h;
-        a2.Bc = Bc; a2.s_bc = (long)n * C; a2.slabs = e->slabs_x; a2.s_slab = (long)n * d; a2.n = n; a2.h = h; a2.d = d; a2.ldx = d; a2.C = C;
+        a2.Bc = Bc; a2.s_bc = (long)n * C; a2.slabs = e->skip_dfeat ? nullptr : e->slabs_x; a2.s_slab = (long)n * d; a2.n = n; a2.h = h; a2.d = d;
+        a2.ldx = d; a2.C = C;
         GS_TRY(gs_match_second(&a2, Cl, s));
-        GS_TRY(gs_reduce_slabs_f32(e->d_feat, e->slabs_x, (long)n * d, Cl, (long)n * d, 0.f, stream));
+        if (!e->skip_dfeat) GS_TRY(gs_reduce_slabs_f32(e->d_feat, e->slabs_x, (long)n * d, Cl, (long)n * d, 0.f, stream));
       } else {
         gs_gemm_desc ax[2];
         ax[0] = mk(X, d, 1, Dv + e->oW1, h, 1, A1m, h, n, h, d);
@@ -1667,6 +1670,9 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     ab2[0].mask = e->H1s; ab2[0].ldmask = h;
     ab2[1] = mk(e->dSs, h, 1, e->H1s, 1, h, e->dQ, n, n, n, h);     // dQ += dS H1^T
     ab2[1].beta = 1.f;
+    if (e->skip_dfeat) {      // (PGE epochs of the fused step: d loss / d X~ is not consumed — only dQ is needed from here on)
+      GS_TRY(gs_gemm_f32(&ab2[1], stream));
+    } else {
     if (e->blk_pos) {
       GS_TRY(block_apply(e, e->blk_X, true, e->dSs, h, e->dH1m, e->H1s, h, stream));
       GS_TRY(gs_gemm_f32(&ab2[1], stream));
@@ -1676,6 +1682,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     gs_gemm_desc c = mk(e->dH1m, h, 1, th + e->oW1, 1, h, e->d_feat, d, n, d, h);   // dX += dH1m W1^T
     c.beta = 1.f;
     GS_TRY(gs_gemm_f32(&c, stream));
+    }
   }
   hipLaunchKernelGGL(gs_add_rowvec_kernel, dim3(gs_cdiv((long)n * n, 256)), dim3(256), 0, s, e->dQ, e->drs, n, n);
   GS_LAUNCH_CHECK();
@@ -2303,9 +2310,14 @@ static int outer_step_impl(gs_gcond* e, int step_pge, int step_feat, int run_inf
   // (unsharded: the loss bookkeeping rides in the matching stage's V kernel — every class loss is final there; sharded ranks sum the
   // class partials first)
   e->fold_finish = !comm && !sharded_c(e) && e->c_hi > e->c_lo && knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains);
+  // (two-transform model, chained class products: the pieces of the stage that only feed d loss / d X~ are skipped when X~ is not
+  // stepped — zero_grad() discards that gradient unread, gcond.py:54-61)
+  e->skip_dfeat = !step_feat && !e->gcn && e->T == 2 && !e->blk_pos && knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) &&
+                  knob_of(e, GS_KNOB_CHAINED_PRODUCTS, g_chained_products) && gs_match_class_eligible(e->n, e->h, e->d, e->C);
   const bool folded = e->fold_finish;
   const int rc_match = gs_gcond_stage_syn_match(e, stream);
   e->fold_finish = false;
+  e->skip_dfeat = false;
   GS_TRY(rc_match);
   GS_TRY(xchg(comm, e->ar_syn, (long)e->n * e->d + (long)e->n * e->n + e->C, 0, 2, stream));
   if (!folded) GS_TRY(gs_gcond_stage_syn_finish(e, stream));

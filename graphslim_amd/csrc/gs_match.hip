@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void gs_match_second_kernel(gs_match2_args 
   };
   float ha0[QS][4], db0[QS][4], ha1[QS][4], db1[QS][4];
   const float* __restrict__ dr = D1 + (long)min(32 * wave + li, d - 1) * h;
-  if (wave < jt) load3(dr, 0, ha0, db0);
+  if (wave < jt && p.slabs) load3(dr, 0, ha0, db0);
   // ---- Bc^T [C x 32 rows] = Wl^T A1m^T over this wave's hidden range; the four waves' partials are summed in wave order
   f32x16 bc[CT];
 #pragma unroll
@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void gs_match_second_kernel(gs_match2_args 
     }
   }
   // ---- dX slab tile [32 rows x 32 features] = dHp_c[rows] D1_c^T
+  if (!p.slabs) return;      // (d loss / d X~ not wanted: PGE epochs of the fused step)
   for (int t = wave; t < jt; t += 4) {
     f32x16 ax;
 #pragma unroll

@@ -88,3 +88,5 @@ for label, fn in stages:
 print(f"sum of the feature-epoch stages (no overlap, sampling excluded): {tot:.1f} us")
 it = timed(lambda: eng.outer_step(10), 40)
 print(f"outer_step (feature epoch, two streams + prefetched sampling): {it:.1f} us")
+it0 = timed(lambda: eng.outer_step(0), 40)
+print(f"outer_step (PGE epoch, two streams + prefetched sampling): {it0:.1f} us")
