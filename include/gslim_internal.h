@@ -11,7 +11,9 @@ extern "C" {
    csrc/gs_panel.hip everywhere (bitwise the same products; BN-2 partial sums grouped per tile instead of per workgroup) */
 int gs_gemm_set_panel_tall(int on);
 /* csrc/gs_panel2.hip: workgroups per launch (0 = one per compute unit), K loop of every tile repeated krep times, triage bits
-   (results are garbage): 1 no epilogue, 2 no A staging, 4 no B staging, 8 no waits / barriers, 16 no MFMAs, 32 no operand split */
+   (results are garbage): 1 no epilogue, 2 no A staging, 4 no B staging, 8 no waits / barriers, 16 no MFMAs, 32 no operand split;
+   scheduling bits (results unchanged): 64 every share starts with a full tile, 128 every wave runs a step as [MFMA, prepare], 256 / 512
+   static s_setprio 1 for waves 4-7 / 0-3, 1024 every wave interleaves the next sub-step's operand preparation with its MFMAs */
 int gs_panel_tall_debug(int grid, int krep, int triage);
 
 /* csrc/gs_panel2.hip: the next plain-product launches record s_memtime stamps (3 per 16-k step of waves 0 and 4) of their first 16
