@@ -14,7 +14,7 @@ void gs_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gs_last_error(void) { return g_err; }
-extern "C" int gs_version(void) { return 300; }   // 100 * round + revision: round 3 added gs_comm / the sharded one-call iteration, the fused chains, row-list H1
+extern "C" int gs_version(void) { return 400; }   // 100 * round + revision: round 4 added the persistent 256-row exact-split kernels, the register-chained class products, the replicated-PGE layout; knobs moved to gslim_internal.h
 
 // ------------------------------------------------------------------------------------------------
 // CSR SpMM:  Y[i,:] = sum_e val[e] * X[col[e],:]
