@@ -560,14 +560,28 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
     const int rows = pd.rows[p], cols = pd.cols[p], co = pd.col_off[p];
     const long off = pd.off[p], tot = (long)rows * cols;
     if ((cols & 3) == 0) {
-      for (long i4 = tid; i4 < (tot >> 2); i4 += 1024) {
-        const int k = (int)((i4 * 4) % cols);
-        const gs_f32x4u r = *reinterpret_cast<const gs_f32x4u*>(R0 + off + i4 * 4);
-        const gs_f32x4u s_ = *reinterpret_cast<const gs_f32x4u*>(S0 + off + i4 * 4);
-        gs_f32x4u v;
+      // four 16-byte pieces per thread and pass, all eight loads requested before the first is used (one round trip per pass instead
+      // of four: the loop walked ~11 dependent round trips for W1 at 1024 threads)
+      const long n4 = tot >> 2;
+      for (long b4 = tid; b4 < n4; b4 += 4096) {
+        gs_f32x4u r[4], s_[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = abl[co + k + e][0] * r[e] + abl[co + k + e][1] * s_[e];
-        *reinterpret_cast<gs_f32x4u*>(Dc + off + i4 * 4) = v;
+        for (int u = 0; u < 4; ++u) {
+          const long i4 = min(b4 + (long)u * 1024, n4 - 1);
+          r[u] = *reinterpret_cast<const gs_f32x4u*>(R0 + off + i4 * 4);
+          s_[u] = *reinterpret_cast<const gs_f32x4u*>(S0 + off + i4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long i4 = b4 + (long)u * 1024;
+          if (i4 < n4) {
+            const int k = (int)((i4 * 4) % cols);
+            gs_f32x4u v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = abl[co + k + e][0] * r[u][e] + abl[co + k + e][1] * s_[u][e];
+            *reinterpret_cast<gs_f32x4u*>(Dc + off + i4 * 4) = v;
+          }
+        }
       }
     } else {
       for (long i = tid; i < tot; i += 1024) {
