@@ -108,6 +108,7 @@ struct gs_gcond {
   double* loss_sum;
   float* loss_last;
   long* steps;
+  double* dist_part; int* dist_cnt;
   long *off_lo, *off_loF, *off_loC, *off_lon;
   int* ncls;
   float* ones;
@@ -324,6 +325,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->loss_sum = w.take<double>(1); e->loss_last = w.take<float>(1); e->steps = w.take<long>(1);
   e->off_lo = w.take<long>(C); e->off_loF = w.take<long>(C); e->off_loC = w.take<long>(C); e->off_lon = w.take<long>(C);
   e->ncls = w.take<int>(C); e->ones = w.take<float>(n > C * bcap ? n : C * bcap);
+  e->dist_part = w.take<double>(C * GS_DIST_SPLIT); e->dist_cnt = w.take<int>(C);      // gs_dist_fused_kernel: loss shares, arrival counters
   if (e->gcn) {
     e->P0g = w.take<float>(C * cap1 * d); e->T2r = w.take<float>(C * cap1 * C); e->dT2r = w.take<float>(C * cap1 * C);
     e->dH1r = w.take<float>(C * cap1 * h); e->S1 = w.take<float>(n * d); e->dS1 = w.take<float>(n * d);
@@ -448,6 +450,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
     (void)hipMemsetAsync(e->loss_sum, 0, sizeof(double), s);
     (void)hipMemsetAsync(e->loss_last, 0, sizeof(float), s);
     (void)hipMemsetAsync(e->steps, 0, sizeof(long), s);
+    (void)hipMemsetAsync(e->dist_cnt, 0, sizeof(int) * C, s);
     if (e->marker)
       hipLaunchKernelGGL(gs_fill_int_kernel, dim3(gs_cdiv((long)C * e->N, 256)), dim3(256), 0, s, e->marker, (long)C * e->N,
                          0x7fffffff);
@@ -1374,8 +1377,10 @@ static int match_distance(gs_gcond* e, const float* gwr, const float* gws, float
   const long P = e->P, c0 = e->c_lo;
   if (Cl <= 0) return GS_OK;
   if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && e->pd.total_cols <= GS_DIST_FUSED_COLS) {
-    hipLaunchKernelGGL(gs_dist_fused_kernel, dim3(Cl), dim3(1024), 0, s, gwr, gws, P, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
-                       e->io.syn_hi + c0, e->n, ab, e->loss_c + c0, Dv, (const float*)e->bn_s2);
+    const int G = e->cfg.dis_metric == 2 || e->pd.nparams < 2 ? 1 : GS_DIST_SPLIT;      // ('cos' couples all columns of a class)
+    hipLaunchKernelGGL(gs_dist_fused_kernel, dim3(Cl, G), dim3(1024), 0, s, gwr, gws, P, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
+                       e->io.syn_hi + c0, e->n, ab, e->loss_c + c0, Dv, (const float*)e->bn_s2, e->dist_part + c0 * GS_DIST_SPLIT,
+                       e->dist_cnt + c0);
     GS_LAUNCH_CHECK();
     return GS_OK;
   }

@@ -416,37 +416,59 @@ __global__ void gs_dist_apply_kernel(const float* __restrict__ gw_real, const fl
   D[idx] = o[0] * gw_real[idx] + o[1] * gw_syn[idx];
 }
 
-// The three launches above as ONE (a workgroup of 1024 threads per class: statistics -> (alpha, beta) and the class's loss -> D): the
-// per-class parameter vector is ~170 KB, so the second pass over gw_real / gw_syn hits L2, and two launch latencies leave the
-// critical path between the stream join and the second-order products.  Same formulas; the column sums are grouped differently
-// (1024 / CB row groups instead of 256 / CB), so values agree with the three-launch form to fp32 re-association.
-// Requires total_cols <= GS_DIST_FUSED_COLS.
+// The three launches above as ONE.  grid (classes, G): for 'ours' / 'mse' every column's (alpha, beta) depends on that column's own
+// statistics only, so a class is shared by G = GS_DIST_SPLIT workgroups of 1024 threads — workgroups 0 .. G-2 take column ranges of
+// parameter 0 (W1, 3/4 of the vector), workgroup G-1 every other parameter — each running statistics -> (alpha, beta) -> D on ITS
+// columns (the second pass over gw_real / gw_syn hits L2) and leaving its share of the class's loss in `part`; the workgroup that
+// finishes last (an integer counter per class, reset for the next launch) adds the G shares in workgroup order: fixed order, no
+// float atomics.  'cos' couples all columns: G = 1.  A class's ~170 KB go through G CUs instead of one (one CU: 24 us for 40 classes).
+// Same formulas as the three-launch form; the column sums are grouped differently (1024 / CB row groups), so values agree with it to
+// fp32 re-association.  Requires total_cols <= GS_DIST_FUSED_COLS.
 #define GS_DIST_FUSED_COLS 1024
+#define GS_DIST_SPLIT 4
 __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __restrict__ gw_real, const float* __restrict__ gw_syn,
                                                              long P_total, gs_pdesc pd, int metric, const int* __restrict__ syn_lo,
                                                              const int* __restrict__ syn_hi, int n_syn, float* __restrict__ ab,
                                                              float* __restrict__ loss_c, float* __restrict__ D,
-                                                             const float* __restrict__ colscale2) {
-  const int c = blockIdx.x, tid = threadIdx.x;
+                                                             const float* __restrict__ colscale2, double* __restrict__ part,
+                                                             int* __restrict__ counter) {
+  const int c = blockIdx.x, g = blockIdx.y, G = gridDim.y, tid = threadIdx.x;
   const float* R0 = gw_real + (long)c * P_total;
   const float* S0 = gw_syn + (long)c * P_total;
   __shared__ float sh[3][1024 * 4];
   __shared__ float st[GS_DIST_FUSED_COLS][3];
   __shared__ float abl[GS_DIST_FUSED_COLS][2];
   __shared__ double red[3][1024];
+  __shared__ int last_flag;
   const int nc = syn_hi[c] - syn_lo[c];
   const float coeff = (float)nc / (float)n_syn;
+  // this workgroup's columns of parameter p: [k_lo, k_hi) (multiples of 4 inside a wide parameter)
+  auto range = [&](int p, int& k_lo, int& k_hi) {
+    const int cols = pd.cols[p];
+    k_lo = 0; k_hi = cols;
+    if (G == 1) return;
+    if (p == 0 && pd.nparams > 1) {
+      if (g == G - 1) { k_hi = 0; return; }
+      const int Q = (cols + 3) >> 2, per = (Q + G - 2) / (G - 1);
+      k_lo = min(cols, 4 * per * g); k_hi = min(cols, 4 * per * (g + 1));
+    } else if (g != G - 1) {
+      k_hi = 0;
+    }
+  };
   // ---- column statistics into LDS
   for (int p = 0; p < pd.nparams; ++p) {
     const int rows = pd.rows[p], cols = pd.cols[p];
+    int k_lo, k_hi;
+    range(p, k_lo, k_hi);
+    if (k_hi <= k_lo) continue;      // (block-uniform)
     const float* R = R0 + pd.off[p];
     const float* S = S0 + pd.off[p];
     if (metric == 0 && pd.is_bias[p]) {      // 'ours' skips one-dimensional parameters (utils.py:86-88): (alpha, beta) = 0 below
-      for (int k = tid; k < cols; k += 1024) { st[pd.col_off[p] + k][0] = 0.f; st[pd.col_off[p] + k][1] = 0.f; st[pd.col_off[p] + k][2] = 0.f; }
+      for (int k = k_lo + tid; k < k_hi; k += 1024) { st[pd.col_off[p] + k][0] = 0.f; st[pd.col_off[p] + k][1] = 0.f; st[pd.col_off[p] + k][2] = 0.f; }
       continue;
     }
     if ((cols & 3) == 0 && cols >= 16) {
-      const int Q = cols >> 2;
+      const int q_lo = k_lo >> 2, Q = (k_hi - k_lo) >> 2;
       int CB = 1;
       while (CB < Q && CB < 1024) CB <<= 1;
       const int tx = tid % CB, ty = tid / CB, nty = 1024 / CB;
@@ -456,8 +478,8 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
         if (q < Q)
 #pragma unroll 4
           for (int i = ty; i < rows; i += nty) {
-            const gs_f32x4u r = *reinterpret_cast<const gs_f32x4u*>(R + (long)i * cols + 4 * q);
-            const gs_f32x4u s_ = *reinterpret_cast<const gs_f32x4u*>(S + (long)i * cols + 4 * q);
+            const gs_f32x4u r = *reinterpret_cast<const gs_f32x4u*>(R + (long)i * cols + 4 * (q_lo + q));
+            const gs_f32x4u s_ = *reinterpret_cast<const gs_f32x4u*>(S + (long)i * cols + 4 * (q_lo + q));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               dot[e] = fmaf(r[e], s_[e], dot[e]);
@@ -477,15 +499,15 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
           const int qq = u / 12, w = u - qq * 12, which = w >> 2, e = w & 3;
           if (q0 + qq < Q) {
             float a = 0.f;
-            for (int g = 0; g < nty; ++g) a += sh[which][(g * CB + qq) * 4 + e];
-            st[pd.col_off[p] + 4 * (q0 + qq) + e][which] = a;
+            for (int gq = 0; gq < nty; ++gq) a += sh[which][(gq * CB + qq) * 4 + e];
+            st[pd.col_off[p] + 4 * (q_lo + q0 + qq) + e][which] = a;
           }
         }
         __syncthreads();
       }
     } else {
       // narrow parameter (a bias is [len x 1]): every thread takes strided rows of one column, tree sum over the block in a fixed order
-      for (int k = 0; k < cols; ++k) {
+      for (int k = k_lo; k < k_hi; ++k) {
         float dot = 0.f, nr2 = 0.f, ns2 = 0.f;
         for (int i = tid; i < rows; i += 1024) {
           const float r = R[(long)i * cols + k], s = S[(long)i * cols + k];
@@ -505,10 +527,12 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
     }
   }
   __syncthreads();
-  // ---- (alpha, beta) per column and the class's loss (the arithmetic of gs_dist_finalize_kernel)
+  // ---- (alpha, beta) per column and this workgroup's share of the class's loss (the arithmetic of gs_dist_finalize_kernel)
   double l = 0.0, sd = 0.0, sr = 0.0, ss = 0.0;
-  for (int p = 0; p < pd.nparams; ++p)
-    for (int k = tid; k < pd.cols[p]; k += 1024) {
+  for (int p = 0; p < pd.nparams; ++p) {
+    int k_lo, k_hi;
+    range(p, k_lo, k_hi);
+    for (int k = k_lo + tid; k < k_hi; k += 1024) {
       const int ci = pd.col_off[p] + k;
       float dot = st[ci][0], nr2 = st[ci][1], ns2 = st[ci][2];
       const float sc2 = (colscale2 && p == 0) ? colscale2[k] : 1.f;
@@ -529,8 +553,10 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
       } else {
         sd += dot; sr += nr2; ss += ns2;
       }
+      if (nc == 0) { a = 0.f; b = 0.f; }      // class without synthetic nodes: no term
       abl[ci][0] = a; abl[ci][1] = b;
     }
+  }
   red[0][tid] = metric == 2 ? sd : l;
   red[1][tid] = sr;
   red[2][tid] = ss;
@@ -539,54 +565,74 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
     if (tid < w) { red[0][tid] += red[0][tid + w]; red[1][tid] += red[1][tid + w]; red[2][tid] += red[2][tid + w]; }
     __syncthreads();
   }
-  if (metric == 2) {
+  if (metric == 2) {      // (G == 1: every column is this workgroup's)
     const float dot = (float)red[0][0], nr = sqrtf((float)red[1][0]), ns = sqrtf((float)red[2][0]);
     const float q = nr * ns + 1e-6f;
-    const float a = -1.f / q, b = ns > 0.f ? dot * nr / (ns * q * q) : 0.f;
-    for (int k = tid; k < pd.total_cols; k += 1024) { abl[k][0] = a * coeff; abl[k][1] = b * coeff; }
+    const float a = nc == 0 ? 0.f : -1.f / q * coeff, b = nc == 0 ? 0.f : (ns > 0.f ? dot * nr / (ns * q * q) : 0.f) * coeff;
+    for (int k = tid; k < pd.total_cols; k += 1024) { abl[k][0] = a; abl[k][1] = b; }
     if (tid == 0) loss_c[c] = nc == 0 ? 0.f : coeff * (1.f - dot / q);
-  } else if (tid == 0) {
-    loss_c[c] = nc == 0 ? 0.f : coeff * (float)red[0][0];
+    __syncthreads();
+  } else if (G == 1) {
+    if (tid == 0) loss_c[c] = nc == 0 ? 0.f : coeff * (float)red[0][0];
+  } else {
+    // the class's loss = the G shares in workgroup order, added by whichever workgroup finishes last
+    if (tid == 0) {
+      part[(long)c * G + g] = red[0][0];
+      __threadfence();
+      last_flag = atomicAdd(counter + c, 1) == G - 1;
+    }
+    __syncthreads();
+    if (last_flag && tid == 0) {
+      __threadfence();
+      double tot = 0.0;
+      for (int q = 0; q < G; ++q) tot += __builtin_nontemporal_load(part + (long)c * G + q);
+      loss_c[c] = nc == 0 ? 0.f : coeff * (float)tot;
+      counter[c] = 0;
+    }
   }
-  __syncthreads();
-  if (nc == 0)      // class without synthetic nodes: no term
-    for (int k = tid; k < pd.total_cols; k += 1024) { abl[k][0] = 0.f; abl[k][1] = 0.f; }
-  __syncthreads();
+  // ---- this workgroup's columns of (alpha, beta) and of D = alpha r + beta s
   float* o = ab + (long)c * pd.total_cols * 2;
-  for (int k = tid; k < pd.total_cols; k += 1024) { o[k * 2] = abl[k][0]; o[k * 2 + 1] = abl[k][1]; }
-  // ---- D = alpha r + beta s
   float* Dc = D + (long)c * P_total;
   for (int p = 0; p < pd.nparams; ++p) {
     const int rows = pd.rows[p], cols = pd.cols[p], co = pd.col_off[p];
-    const long off = pd.off[p], tot = (long)rows * cols;
+    int k_lo, k_hi;
+    range(p, k_lo, k_hi);
+    if (k_hi <= k_lo) continue;
+    for (int k = k_lo + tid; k < k_hi; k += 1024) { o[(co + k) * 2] = abl[co + k][0]; o[(co + k) * 2 + 1] = abl[co + k][1]; }
+    const long off = pd.off[p];
     if ((cols & 3) == 0) {
-      // four 16-byte pieces per thread and pass, all eight loads requested before the first is used (one round trip per pass instead
-      // of four: the loop walked ~11 dependent round trips for W1 at 1024 threads)
-      const long n4 = tot >> 2;
+      // four 16-byte pieces per thread and pass, all eight loads requested before the first is used
+      const int q_lo = k_lo >> 2, Q = (k_hi - k_lo) >> 2;
+      const long n4 = (long)rows * Q;
       for (long b4 = tid; b4 < n4; b4 += 4096) {
         gs_f32x4u r[4], s_[4];
+        long at[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const long i4 = min(b4 + (long)u * 1024, n4 - 1);
-          r[u] = *reinterpret_cast<const gs_f32x4u*>(R0 + off + i4 * 4);
-          s_[u] = *reinterpret_cast<const gs_f32x4u*>(S0 + off + i4 * 4);
+          const long row = i4 / Q;
+          at[u] = off + row * cols + 4 * (q_lo + (int)(i4 - row * Q));
+          r[u] = *reinterpret_cast<const gs_f32x4u*>(R0 + at[u]);
+          s_[u] = *reinterpret_cast<const gs_f32x4u*>(S0 + at[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const long i4 = b4 + (long)u * 1024;
-          if (i4 < n4) {
-            const int k = (int)((i4 * 4) % cols);
+          if (b4 + (long)u * 1024 < n4) {
+            const int k = (int)((at[u] - off) % cols);
             gs_f32x4u v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = abl[co + k + e][0] * r[u][e] + abl[co + k + e][1] * s_[u][e];
-            *reinterpret_cast<gs_f32x4u*>(Dc + off + i4 * 4) = v;
+            *reinterpret_cast<gs_f32x4u*>(Dc + at[u]) = v;
           }
         }
       }
     } else {
-      for (long i = tid; i < tot; i += 1024) {
-        const int k = (int)(i % cols);
-        Dc[off + i] = abl[co + k][0] * R0[off + i] + abl[co + k][1] * S0[off + i];
+      const int W = k_hi - k_lo;
+      for (long i = tid; i < (long)rows * W; i += 1024) {
+        const long row = i / W;
+        const int k = k_lo + (int)(i - row * W);
+        const long at = off + row * cols + k;
+        Dc[at] = abl[co + k][0] * R0[at] + abl[co + k][1] * S0[at];
       }
     }
   }
