@@ -21,6 +21,8 @@ int gs_dw1_generated(const float*, const float*, const float*, const float*, con
                      float*, long, int*, const float*, hipStream_t);
 int gs_pge_scale_uv(const float*, const float*, const float*, long, int, float*, float*, hipStream_t);
 int gs_gemm_group2_f32(const gs_gemm_desc* descs, const gs_gemm_desc* second, int n, gs_stream_t stream);
+int gs_gemm_group2_tiles_f32(const gs_gemm_desc*, const gs_gemm_desc*, int, const int*, const int*, int, int, gs_stream_t);
+#define GS_MAX_CLASSES_TILES 1024
 int gs_panel_forward_a1(const gs_panel_a1*, int, int, const float*, long, const float*, float*, long, int, int, float*, int*, int, void*,
                         unsigned long long*, int, hipStream_t);
 int gs_panel_tiles(int);
@@ -81,6 +83,7 @@ struct gs_gcond {
   int *h1_flag, *h1_list, *h1_count;   // rows of H1full this rank's sampled blocks gather (sharded ranks: only those are computed)
   unsigned* H1bits;                    // [N][h / 32] sign bits of H1full, written by its product's epilogue: the edge product's mask
   double* sum_part;                    // [128] scratch of sum_f32
+  bool tiles_ok;                     // tile_b / tile_my / tile_start are filled (C <= GS_MAX_CLASSES_TILES)
   bool skip_dfeat;                   // this call of the matching stage need not leave d loss / d X~ (set by the fused outer step only)
   bool l3_direct;                    // part 1 of the PGE backward left the statistics partials for part 2's prep launch to reduce
   bool bn2_done;                     // part 1 of the PGE forward has already left the BatchNorm-2 statistics (unsharded, fused)
@@ -109,6 +112,8 @@ struct gs_gcond {
   float* loss_last;
   long* steps;
   double* dist_part; int* dist_cnt;
+  int *tile_b, *tile_my;             // the 32-row M tiles that exist over the classes' synthetic rows (class, tile within the class)
+  int tile_start[GS_MAX_CLASSES_TILES + 1];      // first entry of each class in that list (host)
   long *off_lo, *off_loF, *off_loC, *off_lon;
   int* ncls;
   float* ones;
@@ -326,6 +331,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->off_lo = w.take<long>(C); e->off_loF = w.take<long>(C); e->off_loC = w.take<long>(C); e->off_lon = w.take<long>(C);
   e->ncls = w.take<int>(C); e->ones = w.take<float>(n > C * bcap ? n : C * bcap);
   e->dist_part = w.take<double>(C * GS_DIST_SPLIT); e->dist_cnt = w.take<int>(C);      // gs_dist_fused_kernel: loss shares, arrival counters
+  e->tile_b = w.take<int>(n / 32 + C + 1); e->tile_my = w.take<int>(n / 32 + C + 1);
   if (e->gcn) {
     e->P0g = w.take<float>(C * cap1 * d); e->T2r = w.take<float>(C * cap1 * C); e->dT2r = w.take<float>(C * cap1 * C);
     e->dH1r = w.take<float>(C * cap1 * h); e->S1 = w.take<float>(n * d); e->dS1 = w.take<float>(n * d);
@@ -436,6 +442,25 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
     (void)hipMemcpyAsync(e->off_loC, oC, C * sizeof(long), hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(e->off_lon, on, C * sizeof(long), hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(e->ncls, nc, C * sizeof(int), hipMemcpyHostToDevice, s);
+    {      // list of the M tiles that exist (gs_gemm_group2_tiles_f32): class-major
+      const int cap = e->n / 32 + C + 1;
+      int* tb = new int[cap];
+      int* tm = new int[cap];
+      int t = 0;
+      e->tile_start[0] = 0;
+      for (int c = 0; c < C; ++c) {
+        if (C <= GS_MAX_CLASSES_TILES)
+          for (int m = 0; m * 32 < nc[c] && t < cap; ++m) { tb[t] = c; tm[t] = m; ++t; }
+        if (c < GS_MAX_CLASSES_TILES) e->tile_start[c + 1] = t;
+      }
+      e->tiles_ok = C <= GS_MAX_CLASSES_TILES;
+      if (t > 0) {
+        (void)hipMemcpyAsync(e->tile_b, tb, t * sizeof(int), hipMemcpyHostToDevice, s);
+        (void)hipMemcpyAsync(e->tile_my, tm, t * sizeof(int), hipMemcpyHostToDevice, s);
+        (void)hipStreamSynchronize(s);      // (the host arrays are freed below)
+      }
+      delete[] tb; delete[] tm;
+    }
     hipLaunchKernelGGL(gs_fill_kernel, dim3(gs_cdiv(e->n > C * e->bcap ? e->n : C * e->bcap, 256)), dim3(256), 0, s, e->ones,
                        (long)(e->n > C * e->bcap ? e->n : C * e->bcap), 1.f);
     (void)one;
@@ -1624,7 +1649,12 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
         m3[2].nb1 = Cl; m3[2].offA = off_loC; m3[2].Mb = ncls; m3[2].sBb1 = P; m3[2].offC = off_loF;
         memset(s3, 0, sizeof(s3));
         s3[1] = u2;
-        GS_TRY(gs_gemm_group2_f32(m3, s3, 3, stream));
+        if (e->tiles_ok) {      // only the M tiles that exist (class sizes differ by an order of magnitude)
+          const int t0 = e->tile_start[e->c_lo], t1 = e->tile_start[e->c_hi];
+          GS_TRY(gs_gemm_group2_tiles_f32(m3, s3, 3, e->tile_b + t0, e->tile_my + t0, t1 - t0, e->c_lo, stream));
+        } else {
+          GS_TRY(gs_gemm_group2_f32(m3, s3, 3, stream));
+        }
         ds_done = true;
       } else {
         GS_TRY(gs_gemm_group_f32(qu, 2, stream));
@@ -1882,11 +1912,17 @@ extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grad
   }
   if (part != 3) GS_FAIL(GS_ERR_ARG, "gs_gcond_stage_pge_backward_part: part must be 1, 2 or 3");
   if (e->pge_chunks == 1) {   // (the chunked backward has already left dU, dV and the BN-1 parameter gradients)
+  if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains)) {      // dU | dV out of the same launch (bitwise the two-launch values)
+    hipLaunchKernelGGL(gs_pge_bn1_bwd_cols_kernel, dim3(gs_cdiv(Ph, 32)), dim3(1024), 0, s, e->U, e->V, e->rowsum_c, e->colsum_r,
+                       pp + e->pb0, e->mu1, e->is1, n, Ph, g + e->pg1, g + e->pbe1, pp + e->pg1, (const float*)e->sumU, (const float*)e->sumV,
+                       e->dU, e->dV);
+  } else {
   hipLaunchKernelGGL(gs_pge_bn1_bwd_cols_kernel, dim3(gs_cdiv(Ph, 32)), dim3(1024), 0, s, e->U, e->V, e->rowsum_c, e->colsum_r,
                      pp + e->pb0, e->mu1, e->is1, n, Ph, g + e->pg1, g + e->pbe1);
   hipLaunchKernelGGL(gs_pge_bn1_bwd_uv_kernel, dim3(gs_cdiv((long)n * Ph, 256)), dim3(256), 0, s, e->U, e->V, e->rowsum_c,
                      e->colsum_r, pp + e->pb0, e->mu1, e->is1, pp + e->pg1, e->sumU, e->sumV, g + e->pg1, g + e->pbe1, n, Ph,
                      e->dU, e->dV);
+  }
   }
   GS_LAUNCH_CHECK();
   if (need_param_grads) {

@@ -456,6 +456,35 @@ __global__ __launch_bounds__(256) void gs_gemm_small_group2_kernel(gs_gemm_group
   }
 }
 
+// gs_gemm_small_group2_kernel for members that are batched over classes of very different row counts (Mb): the launch enumerates
+// the M tiles that exist — tile_b[t] = batch, tile_my[t] = its M tile, built once on the host from the class sizes — instead of
+// max-size tiles for every class (40 classes x 4 tiles where 48 exist: three quarters of the workgroups used to exit at once).
+// grid (widest member's N tiles, tiles, members).  Same values as the rectangular launch.
+__global__ __launch_bounds__(256) void gs_gemm_small_group2_tiles_kernel(gs_gemm_group2_arg g, const int* __restrict__ tile_b,
+                                                                         const int* __restrict__ tile_my, int b_first) {
+  __shared__ float red[4][16][64];
+  const int i = blockIdx.z;
+  const gs_gemm_desc& p = g.d[i];
+  if ((int)blockIdx.x * 32 >= p.N) return;
+  const int b = tile_b[blockIdx.y] - b_first, by = tile_my[blockIdx.y];
+  {
+    const bool av = p.sAk == 1, bv = p.sBk == 1;
+    if (av && bv) gs_small_tile<true, true>(p, blockIdx.x, by, b, red);
+    else if (av) gs_small_tile<true, false>(p, blockIdx.x, by, b, red);
+    else if (bv) gs_small_tile<false, true>(p, blockIdx.x, by, b, red);
+    else gs_small_tile<false, false>(p, blockIdx.x, by, b, red);
+  }
+  if (g.has2[i]) {
+    __syncthreads();
+    const gs_gemm_desc& q = g.d2[i];
+    const bool av = q.sAk == 1, bv = q.sBk == 1;
+    if (av && bv) gs_small_tile<true, true>(q, blockIdx.x, by, b, red);
+    else if (av) gs_small_tile<true, false>(q, blockIdx.x, by, b, red);
+    else if (bv) gs_small_tile<false, true>(q, blockIdx.x, by, b, red);
+    else gs_small_tile<false, false>(q, blockIdx.x, by, b, red);
+  }
+}
+
 bool gs_edge_eligible(const gs_gemm_desc& p);             // gs_edge.hip
 int gs_edge_launch(const gs_gemm_desc& d, hipStream_t s);
 bool gs_panel_eligible(const gs_gemm_desc& p);            // gs_panel.hip
@@ -789,6 +818,40 @@ int gs_gemm_group2_f32(const gs_gemm_desc* descs, const gs_gemm_desc* second, in
   for (int i = n; i < GS_GROUP_MAX; ++i) { a.d[i] = a.d[0]; a.d2[i] = a.d[0]; a.has2[i] = 0; }
   a.n = n;
   hipLaunchKernelGGL(gs_gemm_small_group2_kernel, dim3(gx, gy, z), dim3(256), 0, (hipStream_t)stream, a);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+// engine-internal: gs_gemm_group2_f32 for members that all run over the SAME batches with per-batch row counts (Mb, nb2 = 1), given the
+// list of M tiles that exist (tile_b: batch index + b_first, tile_my: M tile; n_tiles entries).  Falls back to gs_gemm_group2_f32.
+int gs_gemm_group2_tiles_f32(const gs_gemm_desc* descs, const gs_gemm_desc* second, int n, const int* tile_b, const int* tile_my, int n_tiles,
+                             int b_first, gs_stream_t stream) {
+  if (n <= 0 || n_tiles <= 0) return GS_OK;
+  bool ok = n <= GS_GROUP_MAX && tile_b && tile_my;
+  gs_gemm_group2_arg a;
+  int gx = 1;
+  for (int i = 0; ok && i < n; ++i) {
+    gs_gemm_desc p = descs[i];
+    if (!p.A || !p.B || !p.C || p.K < 0 || !p.Mb || p.nb1 < 1 || p.nb2 > 1 || p.kchunk > 0 || p.M <= 0 || p.N <= 0) { ok = false; break; }
+    if (p.nb1 != descs[0].nb1 || p.Mb != descs[0].Mb) { ok = false; break; }
+    p.nb2 = 1;
+    if (!small_route(p, p.nb1)) { ok = false; break; }
+    a.d[i] = p; a.has2[i] = 0; a.d2[i] = p;
+    if (second && second[i].A) {
+      gs_gemm_desc q = second[i];
+      if (q.nb1 < 1) q.nb1 = 1;
+      q.nb2 = 1;
+      if (q.C != p.C || q.M != p.M || q.N != p.N || q.nb1 != p.nb1 || q.ldc != p.ldc || q.sCb1 != p.sCb1 || q.offC != p.offC || q.Mb != p.Mb ||
+          q.beta != 1.f || q.kchunk > 0 || !small_route(q, p.nb1)) { ok = false; break; }
+      a.d2[i] = q; a.has2[i] = 1;
+    }
+    gx = gx > gs_cdiv(p.N, 32) ? gx : gs_cdiv(p.N, 32);
+  }
+  if (!ok || n_tiles > 65535) return gs_gemm_group2_f32(descs, second, n, stream);
+  for (int i = 0; i <= GS_GROUP_MAX; ++i) a.z0[i] = 0;
+  for (int i = n; i < GS_GROUP_MAX; ++i) { a.d[i] = a.d[0]; a.d2[i] = a.d[0]; a.has2[i] = 0; }
+  a.n = n;
+  hipLaunchKernelGGL(gs_gemm_small_group2_tiles_kernel, dim3(gx, n_tiles, n), dim3(256), 0, (hipStream_t)stream, a, tile_b, tile_my, b_first);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

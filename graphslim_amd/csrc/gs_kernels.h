@@ -1455,17 +1455,35 @@ __global__ __launch_bounds__(256) void gs_pge_marginals_fused_kernel(const float
   }
 }
 
+// dU | dV of one element from the marginals and the column gradients (shared by the stand-alone kernel and the fold in the columns
+// kernel: one expression, one rounding)
+__device__ __forceinline__ void gs_bn1_bwd_uv_elem(float u, float v, float rc, float cr, float n, float N, float kk, float shf, float sU,
+                                                   float sV, float i1, float dbe, float dg, float& du, float& dv) {
+#pragma clang fp contract(off)      // (no mul + add fusion: the two call sites must round alike whatever surrounds them)
+  const float xr = (n * u + sV + shf) * i1;   // sum over r of xhat[r, c]
+  const float xc = (n * v + sU + shf) * i1;   // sum over c of xhat[r, c]
+  du = kk * (rc - n * dbe / N - xr * dg / N);
+  dv = kk * (cr - n * dbe / N - xc * dg / N);
+}
+
 // BN-1 backward from the marginals (see oracle/analytic.py:pge_bwd); block = 32 columns x 8 row groups
 __global__ __launch_bounds__(1024) void gs_pge_bn1_bwd_cols_kernel(const float* __restrict__ U, const float* __restrict__ V,
                                                                    const float* __restrict__ rowsum_c,
                                                                    const float* __restrict__ colsum_r,
                                                                    const float* __restrict__ b0, const float* __restrict__ mu1,
                                                                    const float* __restrict__ is1, int n, int Ph,
-                                                                   float* __restrict__ dg1, float* __restrict__ dbe1) {
+                                                                   float* __restrict__ dg1, float* __restrict__ dbe1,
+                                                                   const float* __restrict__ g1 = nullptr,
+                                                                   const float* __restrict__ sumU = nullptr,
+                                                                   const float* __restrict__ sumV = nullptr, float* __restrict__ dU = nullptr,
+                                                                   float* __restrict__ dV = nullptr) {
+  // dU (optional, round 4): the workgroup also writes dU | dV of its 32 columns (the arithmetic of gs_pge_bn1_bwd_uv_kernel on the
+  // float values of dg1 / dbe1 it has just formed: bitwise that kernel's output) — one launch less in the PGE backward.
   // 32 columns x 32 row groups, 4 rows x 4 arrays of loads in flight per thread (tiny matrices, critical path)
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int k = min(blockIdx.x * 32 + tx, Ph - 1);
   __shared__ double sh[3][GS_BN1_RG][32];
+  __shared__ float bc[2][32];
   double sb = 0, su = 0, sv = 0;
   for (int i0 = ty; i0 < n; i0 += 4 * GS_BN1_RG) {
     float rc[4], u[4], v[4], cr[4];
@@ -1489,8 +1507,25 @@ __global__ __launch_bounds__(1024) void gs_pge_bn1_bwd_cols_kernel(const float* 
   if (ty == 0 && blockIdx.x * 32 + tx < Ph) {
     sb = su = sv = 0;
     for (int q = 0; q < GS_BN1_RG; ++q) { sb += sh[0][q][tx]; su += sh[1][q][tx]; sv += sh[2][q][tx]; }
-    dbe1[k] = (float)sb;
-    dg1[k] = (float)((su + sv + ((double)b0[k] - (double)mu1[k]) * sb) * (double)is1[k]);
+    const float dbe = (float)sb, dg = (float)((su + sv + ((double)b0[k] - (double)mu1[k]) * sb) * (double)is1[k]);
+    dbe1[k] = dbe;
+    dg1[k] = dg;
+    if (dU) { bc[0][tx] = dbe; bc[1][tx] = dg; }
+  }
+  if (!dU) return;      // (kernel argument: uniform)
+  __syncthreads();
+  if (blockIdx.x * 32 + tx >= Ph) return;
+  const float dbe = bc[0][tx], dg = bc[1][tx];
+  const float N = (float)n * (float)n;
+  const float kk = g1[k] * is1[k];
+  const float shf = (float)n * (b0[k] - mu1[k]);
+  const float sU = sumU[k], sV = sumV[k], i1 = is1[k];
+  for (int i = ty; i < n; i += GS_BN1_RG) {
+    const long o = (long)i * Ph + k;
+    float du, dv;
+    gs_bn1_bwd_uv_elem(U[o], V[o], rowsum_c[o], colsum_r[o], (float)n, N, kk, shf, sU, sV, i1, dbe, dg, du, dv);
+    dU[o] = du;
+    dV[o] = dv;
   }
 }
 // out[c][r] = in[r][c] for a small matrix (weights): lets a product that wants W^T as its n-contiguous operand run with both
@@ -1618,10 +1653,10 @@ __global__ void gs_pge_bn1_bwd_uv_kernel(const float* __restrict__ U, const floa
   const float N = (float)n * (float)n;
   const float kk = g1[k] * is1[k];
   const float sh = (float)n * (b0[k] - mu1[k]);
-  const float xr = ((float)n * U[idx] + sumV[k] + sh) * is1[k];   // sum over r of xhat[r, c]
-  const float xc = ((float)n * V[idx] + sumU[k] + sh) * is1[k];   // sum over c of xhat[r, c]
-  dU[idx] = kk * (rowsum_c[idx] - (float)n * dbe1[k] / N - xr * dg1[k] / N);
-  dV[idx] = kk * (colsum_r[idx] - (float)n * dbe1[k] / N - xc * dg1[k] / N);
+  float du, dv;
+  gs_bn1_bwd_uv_elem(U[idx], V[idx], rowsum_c[idx], colsum_r[idx], (float)n, N, kk, sh, sumU[k], sumV[k], is1[k], dbe1[k], dg1[k], du, dv);
+  dU[idx] = du;
+  dV[idx] = dv;
 }
 // column sums of a small [rows x cols] matrix, fp64 accumulation.  One workgroup = 64 columns x 4 row groups: the first form
 // walked all rows in ONE thread per column (106 us for 454 x 256 on the critical path of the PGE epochs).
