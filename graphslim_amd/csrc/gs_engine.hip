@@ -111,7 +111,8 @@ struct gs_gcond {
   double* loss_sum;
   float* loss_last;
   long* steps;
-  double* dist_part; int* dist_cnt;
+  double* dist_part;                 // gs_dist_fused_kernel: [C][GS_DIST_SPLIT] shares of the class losses
+  int dist_shares;                   // > 0: the last distance launch left this many loss shares per class for the V kernel to add
   int *tile_b, *tile_my;             // the 32-row M tiles that exist over the classes' synthetic rows (class, tile within the class)
   int tile_start[GS_MAX_CLASSES_TILES + 1];      // first entry of each class in that list (host)
   long *off_lo, *off_loF, *off_loC, *off_lon;
@@ -311,6 +312,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->uvs_valid = false;
   for (int i = 0; i < GS_KNOB_COUNT; ++i) e->knob[i] = -1;
   e->fold_finish = false;
+  e->dist_shares = 0;
   e->bn2_done = false;
   e->l3_direct = false;
   e->skip_dfeat = false;
@@ -330,7 +332,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->loss_sum = w.take<double>(1); e->loss_last = w.take<float>(1); e->steps = w.take<long>(1);
   e->off_lo = w.take<long>(C); e->off_loF = w.take<long>(C); e->off_loC = w.take<long>(C); e->off_lon = w.take<long>(C);
   e->ncls = w.take<int>(C); e->ones = w.take<float>(n > C * bcap ? n : C * bcap);
-  e->dist_part = w.take<double>(C * GS_DIST_SPLIT); e->dist_cnt = w.take<int>(C);      // gs_dist_fused_kernel: loss shares, arrival counters
+  e->dist_part = w.take<double>(C * GS_DIST_SPLIT);
   e->tile_b = w.take<int>(n / 32 + C + 1); e->tile_my = w.take<int>(n / 32 + C + 1);
   if (e->gcn) {
     e->P0g = w.take<float>(C * cap1 * d); e->T2r = w.take<float>(C * cap1 * C); e->dT2r = w.take<float>(C * cap1 * C);
@@ -475,7 +477,6 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
     (void)hipMemsetAsync(e->loss_sum, 0, sizeof(double), s);
     (void)hipMemsetAsync(e->loss_last, 0, sizeof(float), s);
     (void)hipMemsetAsync(e->steps, 0, sizeof(long), s);
-    (void)hipMemsetAsync(e->dist_cnt, 0, sizeof(int) * C, s);
     if (e->marker)
       hipLaunchKernelGGL(gs_fill_int_kernel, dim3(gs_cdiv((long)C * e->N, 256)), dim3(256), 0, s, e->marker, (long)C * e->N,
                          0x7fffffff);
@@ -1404,11 +1405,12 @@ static int match_distance(gs_gcond* e, const float* gwr, const float* gws, float
   if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && e->pd.total_cols <= GS_DIST_FUSED_COLS) {
     const int G = e->cfg.dis_metric == 2 || e->pd.nparams < 2 ? 1 : GS_DIST_SPLIT;      // ('cos' couples all columns of a class)
     hipLaunchKernelGGL(gs_dist_fused_kernel, dim3(Cl, G), dim3(1024), 0, s, gwr, gws, P, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
-                       e->io.syn_hi + c0, e->n, ab, e->loss_c + c0, Dv, (const float*)e->bn_s2, e->dist_part + c0 * GS_DIST_SPLIT,
-                       e->dist_cnt + c0);
+                       e->io.syn_hi + c0, e->n, ab, e->loss_c + c0, Dv, (const float*)e->bn_s2, e->dist_part + c0 * GS_DIST_SPLIT);
+    e->dist_shares = G > 1 ? G : 0;      // (the V kernel of this stage call finishes loss_c from the shares)
     GS_LAUNCH_CHECK();
     return GS_OK;
   }
+  e->dist_shares = 0;
   hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, Cl), dim3(256), 0, s, gwr, gws, P, e->pd, stats);
   hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(Cl), dim3(256), 0, s, stats, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
                      e->io.syn_hi + c0, e->n, ab, e->loss_c + c0, (const float*)e->bn_s2);
@@ -1503,7 +1505,8 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     { gs_gemm_desc g = mk(e->Rmat, h, 1, Wl, C, 1, e->Ug, C, n, C, h); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }   // Ug += R W2
     hipLaunchKernelGGL(gs_syn_v_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Ps, e->Gs, e->Ug, e->ones, e->D, P, e->obl, bl,
                        e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->c_lo, e->c_hi, e->Vs, e->drs,
-                       e->fold_finish ? (const float*)e->loss_c : (const float*)nullptr, C, e->loss_sum, e->loss_last, e->steps);
+                       e->fold_finish ? (const float*)e->loss_c : (const float*)nullptr, C, e->loss_sum, e->loss_last, e->steps,
+                     e->dist_shares ? (const double*)e->dist_part : (const double*)nullptr, e->dist_shares, e->loss_c);
     GS_LAUNCH_CHECK();
     { gs_gemm_desc g = mk(e->Vs, C, 1, Wl, 1, C, e->dSs, h, n, h, C); g.beta = 1.f; GS_TRY(gs_gemm_f32(&g, stream)); }    // dS2 += V W2^T
     {
@@ -1677,7 +1680,8 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   }
   hipLaunchKernelGGL(gs_syn_v_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Ps, e->Gs, e->Ug, e->rsq, e->D, P, e->obl, bl,
                      e->io.labels_syn, e->io.syn_lo, e->io.syn_hi, n, C, e->c_lo, e->c_hi, e->Vs, e->drs,
-                     e->fold_finish ? (const float*)e->loss_c : (const float*)nullptr, C, e->loss_sum, e->loss_last, e->steps);
+                     e->fold_finish ? (const float*)e->loss_c : (const float*)nullptr, C, e->loss_sum, e->loss_last, e->steps,
+                     e->dist_shares ? (const double*)e->dist_part : (const double*)nullptr, e->dist_shares, e->loss_c);
   GS_LAUNCH_CHECK();
   {  // dS[lo:hi] = G[lo:hi] Dl_c^T ;  dS += V Wl^T
     if (Cl > 0 && !ds_done) {

@@ -167,12 +167,23 @@ __global__ __launch_bounds__(256) void gs_syn_v_kernel(const float* __restrict__
                                                        int C, int c_lo, int c_hi, float* __restrict__ V,
                                                        float* __restrict__ drs, const float* __restrict__ loss_c = nullptr,
                                                        int n_loss = 0, double* __restrict__ loss_sum = nullptr,
-                                                       float* __restrict__ loss_last = nullptr, long* __restrict__ steps = nullptr) {
+                                                       float* __restrict__ loss_last = nullptr, long* __restrict__ steps = nullptr,
+                                                       const double* __restrict__ parts = nullptr, int n_parts = 0,
+                                                       float* __restrict__ loss_out = nullptr) {
+  // parts (optional): [C][n_parts] shares of the class losses left by gs_dist_fused_kernel; loss_out = the loss_c buffer to finish
   // loss_c (optional): the iteration's loss bookkeeping (gs_loss_accum_kernel's arithmetic) by the first thread of the launch — the
   // class losses are final before this kernel (unsharded engines inside gs_gcond_outer_step: one launch less at the end of the stage)
+  if (parts && blockIdx.x == 0 && threadIdx.x == 0) {      // the classes' losses from the distance kernel's shares (workgroup order)
+    for (int c = c_lo; c < c_hi; ++c) {
+      double tot = 0.0;
+      for (int q = 0; q < n_parts; ++q) tot += parts[(long)c * n_parts + q];
+      const int ncl = syn_hi[c] - syn_lo[c];
+      loss_out[c] = ncl == 0 ? 0.f : (float)ncl / (float)n * (float)tot;
+    }
+  }
   if (loss_c && blockIdx.x == 0 && threadIdx.x == 0) {
     float s = 0.f;
-    for (int c = 0; c < n_loss; ++c) s += loss_c[c];
+    for (int c = 0; c < n_loss; ++c) s += parts ? loss_out[c] : loss_c[c];
     *loss_last = s;
     *loss_sum += (double)s;
     *steps += 1;
@@ -419,9 +430,8 @@ __global__ void gs_dist_apply_kernel(const float* __restrict__ gw_real, const fl
 // The three launches above as ONE.  grid (classes, G): for 'ours' / 'mse' every column's (alpha, beta) depends on that column's own
 // statistics only, so a class is shared by G = GS_DIST_SPLIT workgroups of 1024 threads — workgroups 0 .. G-2 take column ranges of
 // parameter 0 (W1, 3/4 of the vector), workgroup G-1 every other parameter — each running statistics -> (alpha, beta) -> D on ITS
-// columns (the second pass over gw_real / gw_syn hits L2) and leaving its share of the class's loss in `part`; the workgroup that
-// finishes last (an integer counter per class, reset for the next launch) adds the G shares in workgroup order: fixed order, no
-// float atomics.  'cos' couples all columns: G = 1.  A class's ~170 KB go through G CUs instead of one (one CU: 24 us for 40 classes).
+// columns (W1's share stays in registers between the two passes) and leaving its share of the class's loss in `part`: gs_syn_v_kernel
+// adds the G shares in workgroup order (fixed order, no float atomics) and writes loss_c.  'cos' couples all columns: G = 1.  A class's ~170 KB go through G CUs instead of one (one CU: 24 us for 40 classes).
 // Same formulas as the three-launch form; the column sums are grouped differently (1024 / CB row groups), so values agree with it to
 // fp32 re-association.  Requires total_cols <= GS_DIST_FUSED_COLS.
 #define GS_DIST_FUSED_COLS 1024
@@ -430,8 +440,7 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
                                                              long P_total, gs_pdesc pd, int metric, const int* __restrict__ syn_lo,
                                                              const int* __restrict__ syn_hi, int n_syn, float* __restrict__ ab,
                                                              float* __restrict__ loss_c, float* __restrict__ D,
-                                                             const float* __restrict__ colscale2, double* __restrict__ part,
-                                                             int* __restrict__ counter) {
+                                                             const float* __restrict__ colscale2, double* __restrict__ part) {
   const int c = blockIdx.x, g = blockIdx.y, G = gridDim.y, tid = threadIdx.x;
   const float* R0 = gw_real + (long)c * P_total;
   const float* S0 = gw_syn + (long)c * P_total;
@@ -439,7 +448,6 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
   __shared__ float st[GS_DIST_FUSED_COLS][3];
   __shared__ float abl[GS_DIST_FUSED_COLS][2];
   __shared__ double red[3][1024];
-  __shared__ int last_flag;
   const int nc = syn_hi[c] - syn_lo[c];
   const float coeff = (float)nc / (float)n_syn;
   // this workgroup's columns of parameter p: [k_lo, k_hi) (multiples of 4 inside a wide parameter)
@@ -456,6 +464,8 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
     }
   };
   // ---- column statistics into LDS
+  bool keep = false;                   // (block-uniform) parameter 0's share of this workgroup stays in keep_r / keep_s
+  gs_f32x4u keep_r[4], keep_s[4];
   for (int p = 0; p < pd.nparams; ++p) {
     const int rows = pd.rows[p], cols = pd.cols[p];
     int k_lo, k_hi;
@@ -472,6 +482,48 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
       int CB = 1;
       while (CB < Q && CB < 1024) CB <<= 1;
       const int tx = tid % CB, ty = tid / CB, nty = 1024 / CB;
+      if (p == 0 && G > 1 && Q <= CB && rows <= 4 * nty) {
+        // this workgroup's whole share of W1 fits its registers (<= 4 rows x 4 columns per thread, both vectors): D is formed from
+        // them below instead of from a second pass over memory
+        keep = true;
+        float dot[4] = {0.f, 0.f, 0.f, 0.f}, nr2[4] = {0.f, 0.f, 0.f, 0.f}, ns2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = ty + j * nty;
+          if (tx < Q && i < rows) {
+            keep_r[j] = *reinterpret_cast<const gs_f32x4u*>(R + (long)i * cols + 4 * (q_lo + tx));
+            keep_s[j] = *reinterpret_cast<const gs_f32x4u*>(S + (long)i * cols + 4 * (q_lo + tx));
+          } else {
+            keep_r[j] = gs_f32x4u{0.f, 0.f, 0.f, 0.f};
+            keep_s[j] = gs_f32x4u{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)      // (row order ty, ty + nty, ...: the order of the loop below)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dot[e] = fmaf(keep_r[j][e], keep_s[j][e], dot[e]);
+            nr2[e] = fmaf(keep_r[j][e], keep_r[j][e], nr2[e]);
+            ns2[e] = fmaf(keep_s[j][e], keep_s[j][e], ns2[e]);
+          }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sh[0][tid * 4 + e] = dot[e];
+          sh[1][tid * 4 + e] = nr2[e];
+          sh[2][tid * 4 + e] = ns2[e];
+        }
+        __syncthreads();
+        for (int u = tid; u < CB * 12; u += 1024) {
+          const int qq = u / 12, w = u - qq * 12, which = w >> 2, e = w & 3;
+          if (qq < Q) {
+            float a = 0.f;
+            for (int gq = 0; gq < nty; ++gq) a += sh[which][(gq * CB + qq) * 4 + e];
+            st[pd.col_off[p] + 4 * (q_lo + qq) + e][which] = a;
+          }
+        }
+        __syncthreads();
+        continue;
+      }
       for (int q0 = 0; q0 < Q; q0 += CB) {
         const int q = q0 + tx;
         float dot[4] = {0.f, 0.f, 0.f, 0.f}, nr2[4] = {0.f, 0.f, 0.f, 0.f}, ns2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -575,20 +627,9 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
   } else if (G == 1) {
     if (tid == 0) loss_c[c] = nc == 0 ? 0.f : coeff * (float)red[0][0];
   } else {
-    // the class's loss = the G shares in workgroup order, added by whichever workgroup finishes last
-    if (tid == 0) {
-      part[(long)c * G + g] = red[0][0];
-      __threadfence();
-      last_flag = atomicAdd(counter + c, 1) == G - 1;
-    }
-    __syncthreads();
-    if (last_flag && tid == 0) {
-      __threadfence();
-      double tot = 0.0;
-      for (int q = 0; q < G; ++q) tot += __builtin_nontemporal_load(part + (long)c * G + q);
-      loss_c[c] = nc == 0 ? 0.f : coeff * (float)tot;
-      counter[c] = 0;
-    }
+    // this workgroup's share of the class's loss; gs_syn_v_kernel (the next kernel of the stage that has a free thread) adds the G
+    // shares in workgroup order and writes loss_c[c] — no float atomics, no in-kernel rendezvous (fence + counter: 10 000 cycles)
+    if (tid == 0) part[(long)c * G + g] = red[0][0];
   }
   // ---- this workgroup's columns of (alpha, beta) and of D = alpha r + beta s
   float* o = ab + (long)c * pd.total_cols * 2;
@@ -600,6 +641,26 @@ __global__ __launch_bounds__(1024) void gs_dist_fused_kernel(const float* __rest
     if (k_hi <= k_lo) continue;
     for (int k = k_lo + tid; k < k_hi; k += 1024) { o[(co + k) * 2] = abl[co + k][0]; o[(co + k) * 2 + 1] = abl[co + k][1]; }
     const long off = pd.off[p];
+    if (p == 0 && keep) {
+      const int q_lo = k_lo >> 2, Q = (k_hi - k_lo) >> 2;
+      int CB = 1;
+      while (CB < Q && CB < 1024) CB <<= 1;
+      const int tx = tid % CB, ty = tid / CB, nty = 1024 / CB;
+      if (tx < Q) {
+        const int k = 4 * (q_lo + tx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = ty + j * nty;
+          if (i < rows) {
+            gs_f32x4u v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = abl[co + k + e][0] * keep_r[j][e] + abl[co + k + e][1] * keep_s[j][e];
+            *reinterpret_cast<gs_f32x4u*>(Dc + off + (long)i * cols + k) = v;
+          }
+        }
+      }
+      continue;
+    }
     if ((cols & 3) == 0) {
       // four 16-byte pieces per thread and pass, all eight loads requested before the first is used
       const int q_lo = k_lo >> 2, Q = (k_hi - k_lo) >> 2;
