@@ -4,6 +4,8 @@
 train_class / match_loss, the model steps and the real-side sampling run in the HIP engine on the block-diagonal graph of the
 B structures (graphslim_amd/structure.py lays it out); the edge MLP with its training-mode BatchNorm runs forward and backward
 in csrc/gs_structgen.hip + gs_gemm_f32.  This file is the host loop: RNG draw order, update rule, window bookkeeping."""
+from collections import deque
+
 import numpy as np
 import torch
 from tqdm import trange
@@ -13,19 +15,6 @@ from ..evaluation.utils import verbose_time_memory
 from ..host import init_edge_mlp_params, init_sgc_params, msgc_edges, msgc_labels, normalize_adj_sparse
 from ..structure import BatchLayout, EdgeStructureGenerator
 from .gcond_base import GCondBase
-
-
-class FixLenList:
-    """msgc.py:239-247."""
-
-    def __init__(self, lenth):
-        self.lenth = lenth
-        self.data = []
-
-    def append(self, element):
-        self.data.append(element)
-        if len(self.data) > self.lenth:
-            del self.data[0]
 
 
 class MSGCLoop:
@@ -140,7 +129,8 @@ class MSGC(GCondBase):
         y_rep = self.y_syn.repeat(B).to(dev)
         best_val = 0
         args.window = args.patience = 20                                                  # :87
-        losses, x_syns, adj_t_syns = FixLenList(args.window), FixLenList(args.window), FixLenList(args.window)
+        # the last `window` epochs' loss / X~ / structure (msgc.py:238-247 keeps a bounded list): a bounded deque
+        losses, x_syns, adj_t_syns = (deque(maxlen=args.window) for _ in range(3))
         for it in trange(args.epochs):
             # basic_model.initialize() re-draws the weights in place; optimizer_basic_model (built once, :90) keeps its moments
             eng.set_model(init_sgc_params(d, args.hidden, nclass, args.ntrans), keep_optimizer=it > 0)
@@ -151,12 +141,12 @@ class MSGC(GCondBase):
             losses.append(loss_avg)
             x_syns.append(loop.x.cpu())
             adj_t_syns.append(loop.inner_structure().cpu())                          # the NORMALISED batch, as upstream keeps it
-            loss_window = sum(losses.data) / len(losses.data)
+            loss_window = sum(losses) / len(losses)
             if args.verbose:
-                print(f"loss:{loss_window:.4f} feat:{float(x_syns.data[-1].sum()):.4f} adj:{float(adj_t_syns.data[-1].sum()):.4f}")
+                print(f"loss:{loss_window:.4f} feat:{float(x_syns[-1].sum()):.4f} adj:{float(adj_t_syns[-1].sum()):.4f}")
             if it in args.checkpoints:                                                    # :126-130
-                best_x = sum(x_syns.data) / len(x_syns.data)
-                best_adj = sum(adj_t_syns.data) / len(adj_t_syns.data)
+                best_x = sum(x_syns) / len(x_syns)
+                best_adj = sum(adj_t_syns) / len(adj_t_syns)
                 data.feat_syn, data.adj_syn, data.labels_syn = best_x.to(dev), best_adj.to(dev), y_rep
                 best_val = self.intermediate_evaluation(best_val, loss_window)
         self.feat_syn = loop.x
