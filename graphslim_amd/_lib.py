@@ -51,8 +51,12 @@ class GCondIO(C.Structure):
 
 
 # measurement knobs / debug hooks declared in include/gslim_internal.h (not product ABI)
-INTERNAL_SYMBOLS = ["gs_panel_set_fwd_lds_pad", "gs_gemm_set_panel_tall", "gs_panel_tall_debug", "gs_panel_tall_trace", "gs_gcond_set_edge_bits", "gs_gcond_set_knob",
+INTERNAL_SYMBOLS = ["gs_panel_set_fwd_lds_pad", "gs_gemm_set_panel_tall", "gs_panel_tall_debug", "gs_panel_tall_trace", "gs_gcond_set_edge_bits", "gs_gcond_set_edge_plan", "gs_gcond_set_ell_xcd", "gs_gcond_set_knob",
                     "gs_gcond_get_knob", "gs_gemm_set_tuning", "gs_gemm_set_small", "gs_gemm_set_panel", "gs_gemm_set_edge_kernel", "gs_gemm_set_panel_narrow_tail", "gs_gemm_set_panel_marg", "gs_gemm_set_panel_a1gen", "gs_panel_debug", "gs_gcond_set_folded_reductions", "gs_gcond_set_h1_bits", "gs_gcond_set_fused_chains", "gs_gcond_set_h1_rows", "gs_gcond_set_dw1_generated", "gs_gcond_set_aux_priority", "gs_sample_set_cand_cap"]
+
+# engine-level knob ids of include/gslim_internal.h (gs_gcond_set_knob / gs_gcond_get_knob); tests/test_abi.py pins them to the enum
+KNOBS = {"FUSED_CHAINS": 0, "H1_ROWS": 1, "H1_BITS": 2, "EDGE_BITS": 3, "DW1_GENERATED": 4, "FOLDED_REDUCTIONS": 5,
+         "CHAINED_PRODUCTS": 6, "FORK_LATE": 7, "EDGE_PLAN": 8}
 
 _lib = None
 
@@ -72,7 +76,7 @@ SYMBOLS = [
     "gs_edge_score_bwd_f32", "gs_segment_sum_rows_f32", "gs_colsum_tall_f32", "gs_mul_f32", "gs_mul_bwd_f32", "gs_mix_heads_f32",
     "gs_mix_heads_bwd_f32", "gs_sym_sigmoid_f32", "gs_sym_sigmoid_bwd_f32", "gs_bn_running_update_f32", "gs_bn_relu_eval_f32", "gs_ot_spectrum_f32",
     "gs_ot_value_f32", "gs_scale_cols_f32", "gs_ot_divdiff_f32", "gs_clamp_finite_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
-    "gs_comm_unique_id", "gs_comm_create_rccl", "gs_comm_create_callback", "gs_comm_create_null", "gs_comm_destroy", "gs_comm_rank", "gs_comm_world",
+    "gs_comm_unique_id", "gs_comm_probe", "gs_comm_create_rccl", "gs_comm_create_callback", "gs_comm_create_null", "gs_comm_destroy", "gs_comm_rank", "gs_comm_world",
     "gs_comm_allreduce", "gs_comm_set_timing", "gs_comm_read_timing", "gs_comm_read_timing2", "gs_gcond_outer_step_sharded", "gs_gcond_outer_step_sharded_ex",
 ]
 
@@ -111,6 +115,8 @@ def lib():
     L.gs_panel_tall_debug.argtypes = [i, i, i]
     L.gs_panel_tall_trace.argtypes = [C.c_void_p]
     L.gs_gcond_set_edge_bits.argtypes = [i]
+    L.gs_gcond_set_edge_plan.argtypes = [i]
+    L.gs_gcond_set_ell_xcd.argtypes = [i]
     L.gs_gcond_set_knob.argtypes = [vp, i, i]
     L.gs_gcond_get_knob.argtypes = [vp, i]
     L.gs_reduce_slabs_f32.argtypes = [vp, vp, l, i, l, f, vp]
@@ -183,6 +189,7 @@ def lib():
     L.gs_edge_score_bwd_f32.argtypes = [vp, vp, vp, vp, vp, l, i, i, vp, vp, l, vp]
     L.gs_segment_sum_rows_f32.argtypes = [vp, l, vp, vp, i, i, vp, l, vp]
     L.gs_comm_unique_id.argtypes = [vp]
+    L.gs_comm_probe.argtypes = [vp]
     L.gs_comm_create_rccl.argtypes = [vp, i, i, C.POINTER(vp)]
     L.gs_comm_create_callback.argtypes = [ALLREDUCE_FN, vp, i, i, C.POINTER(vp)]
     L.gs_comm_create_null.argtypes = [i, i, C.POINTER(vp)]

@@ -32,9 +32,10 @@ struct rccl_api {
   int (*CommDestroy)(rccl_comm_t);
   int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t);
   const char* (*GetErrorString)(int);
+  int (*GetVersion)(int*);
 };
 
-rccl_api g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+rccl_api g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
 int load_rccl() {
   if (g_rccl.handle) return GS_OK;
@@ -59,6 +60,7 @@ int load_rccl() {
   a.CommDestroy = (int (*)(rccl_comm_t))dlsym(h, "ncclCommDestroy");
   a.AllReduce = (int (*)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(h, "ncclAllReduce");
   a.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  a.GetVersion = (int (*)(int*))dlsym(h, "ncclGetVersion");      // rccl.h: ncclGetVersion(int* version) — optional, allocates nothing
   if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce)
     GS_FAIL(GS_ERR_STATE, "gs_comm: librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce");
   g_rccl = a;
@@ -85,6 +87,19 @@ struct gs_comm {
   hipEvent_t* ev;        // [2 * GS_COMM_MAX_EVENTS], created lazily
   int* ev_tag;
 };
+
+// Is the RCCL binding usable in this process?  dlopen + the entry points + ncclGetVersion: allocates nothing and starts no bootstrap
+// thread (ncclGetUniqueId does: ADVICE r04) — what every rank checks before any of them enters the collective ncclCommInitRank.
+extern "C" int gs_comm_probe(int* rccl_version) {
+  GS_TRY(load_rccl());
+  int v = 0;
+  if (g_rccl.GetVersion) {
+    const int rc = g_rccl.GetVersion(&v);
+    if (rc != 0) GS_FAIL(GS_ERR_STATE, "ncclGetVersion failed: %s", rccl_err(rc));
+  }
+  if (rccl_version) *rccl_version = v;
+  return GS_OK;
+}
 
 extern "C" int gs_comm_unique_id(void* id128) {
   if (!id128) GS_FAIL(GS_ERR_ARG, "gs_comm_unique_id: null argument");

@@ -46,7 +46,65 @@ struct gs_edge_args {
   const float* Y; long sYc; int f2;              // Y1 rows: Y[class * sYc + (k / f2) * 256 + n]
   const int* kcount; int kchunk;
   float* out; long sOc, sOs;                     // slabs: out[class * sOc + slab * sOs + m * 256 + n]
+  const int* plan; int nclass;                   // balanced slabs (gs_edge_plan_kernel): [nclass + 1] first slab of a class, then [nclass] its
+                                                 // slab length; slab b of the launch writes out[b * sOs + ...] (null: nsplit slabs of kchunk per class)
 };
+
+// ---- balanced K slabs (round 5) ---------------------------------------------------------------------------------------------------
+// The edge lists of the classes differ in length (n1[c] * f2 live slots: 7 400 .. 11 800 at ogbn-arxiv) and a launch of (class x
+// fixed-length slab) workgroups left 22 % of the chip's 512 workgroup slots empty while the others ran 63 K steps (profiles/r04: the
+// longest kernel of the iteration).  The plan cuts the chip's slots over the classes in proportion to their step counts, so that every
+// workgroup runs about total_steps / slots steps: plan[c] = first slab of class c (plan[nclass] = slabs in use), plan[nclass + 1 + c] =
+// slab length of class c (a multiple of the 16-edge step).  Also writes kcount[c] = n1[c] * f2 (gs_kcount_kernel's job).  One wave.
+__global__ __launch_bounds__(64) void gs_edge_plan_kernel(const int* __restrict__ n1, int f2, int nclass, int target, int* __restrict__ kcount,
+                                                          int* __restrict__ plan) {
+  __shared__ int steps[64], nsl[64];
+  const int c = threadIdx.x;
+  int st = 0;
+  if (c < nclass) {
+    const int k = n1[c] * f2;
+    kcount[c] = k;
+    st = (k + EG_BK - 1) / EG_BK;
+  }
+  steps[c] = st;
+  __syncthreads();
+  long total = 0;
+  for (int i = 0; i < nclass; ++i) total += steps[i];
+  int mine = 0, chunk = EG_BK;
+  if (c < nclass && st > 0) {
+    mine = (int)(((long)target * st) / (total > 0 ? total : 1));
+    if (mine < 1) mine = 1;
+    const int per = (st + mine - 1) / mine;          // steps per slab
+    mine = (st + per - 1) / per;                     // slabs that are not empty
+    chunk = per * EG_BK;
+  }
+  nsl[c] = mine;
+  __syncthreads();
+  if (c < nclass) {
+    int base = 0;
+    for (int i = 0; i < c; ++i) base += nsl[i];
+    plan[c] = base;
+    plan[nclass + 1 + c] = chunk;
+    if (c == nclass - 1) plan[nclass] = base + mine;
+  }
+}
+
+// sum of a class's slabs in slab order (fixed order: reproducible), 16-byte accesses; a class without live edges gets zeros
+__global__ void gs_reduce_slabs_plan_kernel(float* __restrict__ out, long out_stride, const float* __restrict__ slabs, long n4,
+                                            long slab_stride, const int* __restrict__ plan) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int b = blockIdx.y;
+  const int lo = plan[b], hi = plan[b + 1];
+  const float4* sl = reinterpret_cast<const float4*>(slabs) + i;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = lo; k < hi; ++k) {
+    const float4 v = sl[(long)k * (slab_stride >> 2)];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(out + (long)b * out_stride)[i] = s;
+}
+
 
 // One K step (16 rows of both LDS images of `stage`) of a workgroup's 128 x 256 tile: wave w owns rows [32 w, 32 w + 32) x 256 columns,
 // 8 MFMA tiles.  Shared by the edge product and the PGE dW1 product below (same stage layout, same arithmetic).
@@ -165,10 +223,21 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
-  const int slab = blockIdx.x, c = blockIdx.y, m0 = blockIdx.z * 128;
+  int slab = blockIdx.x, c = blockIdx.y, kchunk = p.kchunk;
+  const int m0 = blockIdx.z * 128;
+  float* __restrict__ out;
+  if (p.plan) {      // balanced slabs: blockIdx.x counts the launch's slabs, class by class
+    if ((int)blockIdx.x >= p.plan[p.nclass]) return;
+    c = 0;
+    while (c + 1 < p.nclass && p.plan[c + 1] <= (int)blockIdx.x) ++c;      // (wave-uniform: scalar loads of <= 64 words)
+    slab = (int)blockIdx.x - p.plan[c];
+    kchunk = p.plan[p.nclass + 1 + c];
+    out = p.out + (long)blockIdx.x * p.sOs;
+  } else {
+    out = p.out + (long)c * p.sOc + (long)slab * p.sOs;
+  }
   const int kc = p.kcount[c];
-  const int k_lo = slab * p.kchunk, k_hi = min(kc, k_lo + p.kchunk);
-  float* __restrict__ out = p.out + (long)c * p.sOc + (long)slab * p.sOs;
+  const int k_lo = slab * kchunk, k_hi = min(kc, k_lo + kchunk);
   f32x16 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -288,7 +357,28 @@ bool gs_edge_eligible(const gs_gemm_desc& p) {
   return true;
 }
 
-int gs_edge_launch(const gs_gemm_desc& d, hipStream_t s) {
+// plan / planned launch / planned reduction (engine-internal, csrc/gs_engine.hip): `plan` holds 2 nclass + 1 ints, `max_slabs` bounds
+// the slabs the plan may use (target + nclass fit the slab buffer)
+int gs_edge_plan(const int* n1, int f2, int nclass, int target, int* kcount, int* plan, hipStream_t s) {
+  if (nclass < 1 || nclass > 64 || target < 1) GS_FAIL(GS_ERR_ARG, "gs_edge_plan: 1 <= nclass <= 64, target >= 1");
+  hipLaunchKernelGGL(gs_edge_plan_kernel, dim3(1), dim3(64), 0, s, n1, f2, nclass, target, kcount, plan);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+int gs_reduce_slabs_plan(float* out, long out_stride, const float* slabs, long n, long slab_stride, int nbatch, const int* plan,
+                         hipStream_t s) {
+  if (n <= 0 || nbatch <= 0) return GS_OK;
+  hipLaunchKernelGGL(gs_reduce_slabs_plan_kernel, dim3(gs_cdiv(n >> 2, 256), nbatch), dim3(256), 0, s, out, out_stride, slabs, n >> 2,
+                     slab_stride, plan);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+static int edge_launch(const gs_gemm_desc& d, const int* plan, int max_slabs, hipStream_t s);
+int gs_edge_launch(const gs_gemm_desc& d, hipStream_t s) { return edge_launch(d, nullptr, 0, s); }
+int gs_edge_launch_plan(const gs_gemm_desc& d, const int* plan, int max_slabs, hipStream_t s) { return edge_launch(d, plan, max_slabs, s); }
+
+static int edge_launch(const gs_gemm_desc& d, const int* plan, int max_slabs, hipStream_t s) {
   gs_edge_args a;
   a.X = d.A; a.ldx = d.sAk; a.d = d.M;
   a.col = d.bgen_idx; a.w = d.bgen_w; a.sK = d.sGb1;
@@ -297,7 +387,8 @@ int gs_edge_launch(const gs_gemm_desc& d, hipStream_t s) {
   a.Y = d.B; a.sYc = d.sBb1; a.f2 = d.bgen_div;
   a.kcount = d.Kb; a.kchunk = d.kchunk;
   a.out = d.C; a.sOc = d.sCb1; a.sOs = d.sCb2;
-  const dim3 grid(d.nb2, d.nb1, gs_cdiv(d.M, 128)), block(256);
+  a.plan = plan; a.nclass = d.nb1;
+  const dim3 grid(plan ? max_slabs : d.nb2, plan ? 1 : d.nb1, gs_cdiv(d.M, 128)), block(256);
   const bool bits = d.bgen_bits != nullptr && d.bgen_ldbits >= 8;
 #define GS_EDGE_LAUNCH(MODE_)                                                                    \
   do {                                                                                           \

@@ -12,6 +12,10 @@
 extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int, long, int, float, gs_stream_t);
 extern "C" int gs_reduce_slabs_f32(float*, const float*, long, int, long, float, gs_stream_t);
 int gs_reduce_slabs_active(float*, long, const float*, long, int, long, int, const int*, int, gs_stream_t);
+bool gs_edge_eligible(const gs_gemm_desc& p);                                                      // gs_edge.hip
+int gs_edge_plan(const int* n1, int f2, int nclass, int target, int* kcount, int* plan, hipStream_t s);
+int gs_edge_launch_plan(const gs_gemm_desc& d, const int* plan, int max_slabs, hipStream_t s);
+int gs_reduce_slabs_plan(float* out, long out_stride, const float* slabs, long n, long slab_stride, int nbatch, const int* plan, hipStream_t s);
 int gs_reduce_slabs_pair(float*, const float*, long, int, long, float*, const float*, long, int, long, gs_stream_t);
 struct gs_panel_gen { const float *mu2, *is2, *g2, *be2, *w2, *dbe2, *dg2, *de3; long total_rows; float* table; int table_ready; };
 struct gs_panel_a1 { const float *U, *V; long ld; const float *b0, *mu1, *is1, *g1, *be1; float* table; const float *Us, *Vs; int b_ready; };
@@ -77,6 +81,9 @@ struct gs_gcond {
   gs_pdesc pd;
   int max_nc;
   int nsplit_r, kchunk_r, nsplit_w, kchunk_w, nblk_stats, rows_per_block;
+  int edge_target, edge_cap;           // balanced slabs of the real-side edge product: slabs aimed at / slabs the buffer holds (gs_edge_plan)
+  int* edge_plan;                      // [2 C + 1] device ints
+  bool real_beside;                    // this real-side stage runs beside the training pass of the PGE forward (fused step, forward recomputed)
   // real side
   gs_blocks blk;
   int *marker, *kcount;
@@ -223,6 +230,10 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   // against 670 (512) and 660 (1 024).
   e->kchunk_r = (long)e->C * gs_cdiv((long)e->cap1 * e->f2, 1024) * gs_cdiv(e->d, 128) >= 400 ? 1024 : 512;
   e->nsplit_r = gs_cdiv((long)e->cap1 * e->f2, e->kchunk_r);
+  // balanced slabs (round 5, gs_edge.hip): the 512 resident workgroup slots (2 per compute unit) per 128-feature tile, cut over the
+  // classes in proportion to their live edge counts on the device; the buffer holds `edge_cap` slabs (the plan uses <= target + C)
+  e->edge_target = 512 / gs_cdiv(e->d, 128) > 0 ? 512 / gs_cdiv(e->d, 128) : 1;
+  e->edge_cap = e->C * e->nsplit_r > e->edge_target + e->C ? e->C * e->nsplit_r : e->edge_target + e->C;
   // dW1 = dE2^T A1 over K = n'^2 pair rows: Ph/128 x Ph/128 output tiles per slab; aim at one full round of the 768
   // resident 128x128 workgroups (2 048 gave 404 workgroups at n' = 454: half the chip idle)
   {
@@ -273,9 +284,11 @@ static size_t carve(gs_gcond* e, void* base) {
   e->Zr = w.take<float>(C * bcap * C); e->gw_real = w.take<float>(C * P);
   if (e->T == 2) {
     e->Tm = w.take<float>(C * bcap * h); e->Y1 = w.take<float>(C * cap1 * h);
-    e->Bmat = w.take<float>(C * cap1 * f2 * h); e->slabs_r = w.take<float>(C * e->nsplit_r * d * h);
+    e->Bmat = w.take<float>(C * cap1 * f2 * h); e->slabs_r = w.take<float>((long)e->edge_cap * d * h);
+    e->edge_plan = w.take<int>(2 * C + 1);
   } else {
     e->Tm = e->Y1 = e->Bmat = e->slabs_r = nullptr;
+    e->edge_plan = nullptr;
   }
   e->adj_raw = w.take<float>(n2); e->adj_norm = w.take<float>(n2); e->rnorm = w.take<float>(2 * n);
   e->Q = w.take<float>(n2); e->rsq = w.take<float>(n);
@@ -383,6 +396,7 @@ static int g_defer_last_stage = 1;  // gs_gcond_set_folded_reductions
 static int g_edge_bits = 0;         // the hop-2 gather also writes per-edge sign bits and the edge product reads those (0: the mask rows of H1full)
 static int g_h1_bits = 0;
 static int g_h1_rows = 1;
+static int g_edge_plan = 1;         // real-side edge product on balanced slabs (gs_edge_plan); 0 = fixed-length slabs per class (the form of rounds 2-4)
 static int g_chained_products = 1;  // the per-class products of the synthetic match chained through the MFMA accumulator registers, two
                                     // launches (gs_match.hip); 0 = the six batched products
 // measurement / test knob: 1 (default) = PGE epochs run the backward of layer 2 on generated operands (marginals as in feature epochs,
@@ -490,7 +504,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->have_blocks = false;
   e->c_lo = 0; e->c_hi = e->C; e->r_lo = 0; e->r_hi = e->n;
   e->aux = nullptr; e->ev_fork = e->ev_join = e->ev_prefetch = nullptr; e->join_pending = false;
-  e->reuse_fwd = false; e->fwd_cached = false;
+  e->reuse_fwd = false; e->fwd_cached = false; e->real_beside = false;
   e->blk_cur = 0; e->prefetched = false; e->identity = false;
   e->probing = false; e->probe_n = 0; e->probe2_n = 0;
   for (int i = 0; i < 2 * 256; ++i) e->probe2_ev[i] = nullptr;
@@ -674,7 +688,7 @@ extern "C" int gs_gcond_set_knob(gs_gcond* e, int knob, int value) {
 }
 extern "C" int gs_gcond_get_knob(const gs_gcond* e, int knob) {
   if (!e || knob < 0 || knob >= GS_KNOB_COUNT) return -1;
-  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_chained_products, 0};
+  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_chained_products, 0, g_edge_plan != 0};
   return knob_of(e, knob, def[knob]);
 }
 
@@ -736,20 +750,28 @@ extern "C" int gs_gcond_stage_sample(gs_gcond* e, gs_stream_t stream) {
 // stage: real-side per-class gradients gw_real[c] (gcond_base.py:212-224), propagate-first form
 // ================================================================================================
 // (ebits: per-edge sign bits of the gathered rows, see gs_ell_spmm_kernel; returns whether they were written — 16-byte path, F = 256)
+static int g_ell_xcd = 1;
+extern "C" int gs_gcond_set_ell_xcd(int on) {
+  g_ell_xcd = on != 0;
+  return GS_OK;
+}
 static bool launch_ell(const int* col, const float* val, const int* nrows, int cap_rows, int f, long col_base_stride,
                        const float* src, long ld_src, const float* rs_in, int F, float* out, long ld_out, float* rs_out, int C,
                        hipStream_t s, unsigned* ebits = nullptr) {
   long waves = (long)C * cap_rows;
   int blocks = gs_cdiv(waves, 4);
+  // class -> XCD affinity of the gather's workgroups (gs_ell_spmm_kernel; g_ell_xcd: measurement knob, default on)
+  const int xcd = (g_ell_xcd && cap_rows % 4 == 0 && C > 1) ? 1 : 0;
+  if (xcd) blocks = 8 * gs_cdiv(C, 8) * (cap_rows / 4);
   const int F4 = (F + 3) & ~3;
   bool vec = (ld_src % 4 == 0) && (ld_out % 4 == 0) && ld_src >= F4 && ld_out >= F4 && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
   const bool bits = vec && ebits && F == 256;
   if (vec)
     hipLaunchKernelGGL((gs_ell_spmm_kernel<4>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
-                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, bits ? ebits : (unsigned*)nullptr);
+                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, bits ? ebits : (unsigned*)nullptr, xcd);
   else
     hipLaunchKernelGGL((gs_ell_spmm_kernel<1>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
-                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, (unsigned*)nullptr);
+                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, (unsigned*)nullptr, xcd);
   return bits;
 }
 
@@ -818,6 +840,10 @@ static int sum_f32(gs_gcond* e, const float* x, long n, float* out, hipStream_t 
 
 extern "C" int gs_gcond_set_edge_bits(int on) {
   g_edge_bits = on != 0;
+  return GS_OK;
+}
+extern "C" int gs_gcond_set_edge_plan(int on) {
+  g_edge_plan = on < 0 ? 0 : on;      // 0 off, 1 on (default number of slabs), > 1: on with that many slabs aimed at (measurement)
   return GS_OK;
 }
 // measurement / test knob: 1 = H1's product also writes its sign bits and the edge product reads its ReLU mask from them (32 B
@@ -969,7 +995,18 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       hipLaunchKernelGGL(gs_csc_spmm_t_kernel, dim3(gs_cdiv((long)Cl * cap1, 4)), dim3(256), 0, s, b.tptr1, b.tedge1, b.val1, b.n1,
                          cap1, bcap, f1, Tm, h, Y1, Cl);
     const bool fused = (e->cfg.dis_metric == 0);   // 'ours' needs no bias gradient -> Bmat is generated inside the GEMM
-    if (fused)
+    // balanced slabs (knob EDGE_PLAN, default on): the chip's workgroup slots are cut over the classes by their live edge counts
+    const bool plan = fused && Cl <= 64 && knob_of(e, GS_KNOB_EDGE_PLAN, g_edge_plan != 0) && e->edge_plan && ((long)d * h) % 4 == 0 &&
+                      P % 4 == 0 && e->oW1 % 4 == 0;
+    if (plan) {
+      // beside the training forward the match head of the main stream needs workgroup slots while the edge product runs: 7/8 of the
+      // slots measured best (profiles/r05/stage_times_edge_sweep.txt: 384 .. 512 slabs -> 1 547 / 1 541 / 1 534 / 1 574 / 1 609 us per
+      // iteration, fixed slabs 1 556); alone on the chip (forward reuse, staged calls) every slot
+      int target = g_edge_plan > 1 ? g_edge_plan / gs_cdiv(d, 128) : (e->real_beside ? e->edge_target - e->edge_target / 8 : e->edge_target);
+      if (target > e->edge_cap - Cl) target = e->edge_cap - Cl;
+      GS_TRY(gs_edge_plan(b.n1, f2, Cl, target < 1 ? 1 : target, kcount, e->edge_plan, s));
+    }
+    else if (fused)
       hipLaunchKernelGGL(gs_kcount_kernel, dim3(gs_cdiv(Cl, 64)), dim3(64), 0, s, b.n1, f2, Cl, kcount);
     else
       hipLaunchKernelGGL(gs_make_bmat_kernel, dim3(gs_cdiv((long)Cl * cap1 * f2, 4)), dim3(256), 0, s, b.col0, b.val0, b.n1, cap1,
@@ -1001,6 +1038,11 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       if (use_bits) { gwd.bgen_bits = e->H1bits; gwd.bgen_ldbits = h / 32; }
       else if (have_ebits) { gwd.bgen_bits = e->edge_bits + c0 * cap1 * f2 * 8; gwd.bgen_ldbits = h / 32; gwd.bgen_bits_edge = 1; }
       gwd.prec = e->operand_mode;      // honoured by the dedicated edge kernel (gs_edge.hip); the tiled fallback is fp32
+    }
+    if (plan && gs_edge_eligible(gwd)) {
+      GS_TRY(gs_edge_launch_plan(gwd, e->edge_plan, e->edge_cap, s));
+      GS_TRY(gs_reduce_slabs_plan(gw + e->oW1, P, e->slabs_r, (long)d * h, (long)d * h, Cl, e->edge_plan, s));
+      return GS_OK;
     }
     GS_TRY(gs_gemm_f32(&gwd, stream));
     if (((long)d * h) % 4 == 0 && P % 4 == 0 && e->oW1 % 4 == 0)   // 16-byte form that skips the slabs beyond each class's edge count
@@ -2339,7 +2381,10 @@ static int outer_step_impl(gs_gcond* e, int step_pge, int step_feat, int run_inf
     GS_TRY(gs_gcond_stage_pge_forward_part(e, 0, 1, stream));
     if (late) GS_HIP(hipEventRecord(e->ev_fork, s));
     GS_TRY(xchg_pge(e, comm, e->sums, 2L * e->Ph, 1, 0, stream));
-    GS_TRY(real_async(e, stream, true));
+    e->real_beside = true;
+    const int rc_real = real_async(e, stream, true);
+    e->real_beside = false;
+    GS_TRY(rc_real);
     GS_TRY(gs_gcond_stage_pge_forward_part(e, 0, 2, stream));
     GS_TRY(xchg_pge(e, comm, e->e3, (long)e->n * e->n, 0, 1, stream));
     GS_TRY(gs_gcond_stage_pge_forward_part(e, 0, 3, stream));
@@ -2498,6 +2543,7 @@ extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* 
       // PGE layer-2 pre-activations of this rank's pair rows and the BatchNorm-2 batch statistics (kernel A/B tests)
       {"E2", e->E2, (long)(e->r_hi - e->r_lo) * n * Ph}, {"mu2", e->mu2, Ph}, {"is2", e->is2, Ph},
       {"edge_bits", e->edge_bits, e->edge_bits ? (long)C * e->cap1 * e->f2 * (e->h / 32) : 0},
+      {"edge_plan", e->edge_plan, e->edge_plan ? 2L * C + 1 : 0},      // balanced slabs of the last real-side stage (ints)
       // hidden activations of the synthetic rows and their gradient as the last inner step left them (two-transform models)
       {"H1s", e->H1s, e->H1s ? n * e->h : 0}, {"dH1m", e->dH1m, e->dH1m ? n * e->h : 0},
       // PGE backward intermediates where they are materialised (diagnosis: tools/diag_panel_stages.py)

@@ -26,16 +26,31 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
                                                           long col_base_stride, const float* __restrict__ src, long ld_src,
                                                           const float* __restrict__ rs_in, int F, float* __restrict__ out,
                                                           long ld_out, float* __restrict__ rs_out, int nclass,
-                                                          unsigned* __restrict__ ebits = nullptr) {
+                                                          unsigned* __restrict__ ebits = nullptr, int xcd_map = 0) {
   // ebits (VEC = 4, F = 256, optional): per edge slot (grow * f + j) the sign bits of the gathered source row, bit (n & 31) of word
   // n >> 5 = [src[col_j][n] > 0] — 8 words = 32 B.  The hop-2 gather has every source row of H1 = relu(X W1 + b1) in registers; the
   // edge product then reads its ReLU mask from these 32 B per edge instead of gathering the 1-KiB fp32 row again.
   // (VEC = 4 needs ld_src, ld_out multiples of 4 that cover F rounded up to 4 — the engine pads its row strides, so that widths
   // like 602 (reddit) or 1 433 (cora) take the 16-byte path too: the columns [F, round4(F)) carry zeros from X's padding)
   const int lane = threadIdx.x & 63;
-  const long grow = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // (c, row)
-  if (grow >= (long)nclass * cap_rows) return;
-  const int c = (int)(grow / cap_rows), row = (int)(grow - (long)c * cap_rows);
+  long grow = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // (c, row)
+  int c, row;
+  if (xcd_map) {
+    // class -> XCD affinity (round 5; speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, so workgroup b
+    // lands on the XCD of b % 8 — the rows of class c all go to workgroups with b % 8 = c % 8 (cap_rows % 4 == 0: a workgroup's 4 waves
+    // are 4 rows of one class).  A class's gathered source rows repeat 1.6x inside the class (ogbn-arxiv: 8 700 gathers, 5 400 distinct)
+    // and its output rows are the next hop's sources: both now meet in ONE XCD's L2 instead of being spread over eight.
+    const int b = blockIdx.x, x = b & 7, i = b >> 3, rq = cap_rows >> 2;
+    const int slot = i / rq;
+    c = x + 8 * slot;
+    row = 4 * (i - slot * rq) + (threadIdx.x >> 6);
+    if (c >= nclass) return;
+    grow = (long)c * cap_rows + row;
+  } else {
+    if (grow >= (long)nclass * cap_rows) return;
+    c = (int)(grow / cap_rows);
+    row = (int)(grow - (long)c * cap_rows);
+  }
   float* o = out + grow * ld_out;
   if (row >= nrows[c]) {
     for (int c0 = lane * VEC; c0 < F; c0 += 64 * VEC)

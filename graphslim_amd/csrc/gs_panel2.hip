@@ -389,15 +389,25 @@ __device__ __forceinline__ void tall_tile(const gs_tall_args& p, char* smem, tp_
           mfma();
         } else if constexpr (EARLY == 1) {
           issue();
+          if constexpr (TRACE) {      // stamp 2: the loads are issued
+            __builtin_amdgcn_sched_barrier(0);
+            if ((wave & 3) == 0) tp_stamp(smem, wave, S.tstep);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           prep();
           __builtin_amdgcn_sched_barrier(0);
-          if (TRACE && (wave & 3) == 0) { asm volatile("" :: "v"(nh), "v"(nm), "v"(nl)); tp_stamp(smem, wave, S.tstep); }      // stamp 2: between the parts
+          if (TRACE && (wave & 3) == 0) { asm volatile("" :: "v"(nh), "v"(nm), "v"(nl)); tp_stamp(smem, wave, S.tstep); }      // stamp 3: between the parts
           mfma();
         } else {
           mfma();
           __builtin_amdgcn_sched_barrier(0);
-          if (TRACE && (wave & 3) == 0) { asm volatile("" :: "v"(acc[NTW - 1])); tp_stamp(smem, wave, S.tstep); }
+          if (TRACE && (wave & 3) == 0) { asm volatile("" :: "v"(acc[NTW - 1])); tp_stamp(smem, wave, S.tstep); }      // stamp 2: between the parts
           issue();
+          if constexpr (TRACE) {      // stamp 3: the loads are issued
+            __builtin_amdgcn_sched_barrier(0);
+            if ((wave & 3) == 0) tp_stamp(smem, wave, S.tstep);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           prep();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -781,6 +791,7 @@ int gs_tall_forward_a1(const float* Us, const float* Vs, long ld, int n, int nr,
   a.span = span; a.krep = g_tall_krep; a.triage = g_tall_triage; a.phases = g_tall_phases;
   const dim3 grid(tall_grid(gs_cdiv(a.M, 64), 4)), block(512);
   if (g_tall_split == 2) hipLaunchKernelGGL((gs_tall_kernel<TP_FGEN, false, 0, 2>), grid, block, 0, s, a);      // (measurement: interleaved form)
+  else if (g_tall_triage || g_tall_krep != 1) TP_LAUNCH(TP_FGEN, false, 1);      // (measurement: phases switched off, results are garbage)
   else TP_LAUNCH(TP_FGEN, false, 0);
   GS_LAUNCH_CHECK();
   if (stat_slabs) *stat_slabs = (int)grid.x;
@@ -804,7 +815,8 @@ int gs_tall_marginals(const float* E2, const void* Bimg, long ldb_bytes, const f
   a.a1_U = Us; a.a1_V = Vs; a.a1_ld = ld; a.n = n; a.nr = nr;
   a.gen_c = gen_table; a.gen_d = de3; a.partU = partU; a.partV = partV; a.H = H; a.ncb = ncb; a.krep = g_tall_krep; a.triage = g_tall_triage; a.phases = g_tall_phases;
   const dim3 grid(tall_grid((long)ncb * H, 2)), block(512);
-  hipLaunchKernelGGL((gs_tall_kernel<TP_MARG, false, 0, false>), grid, block, 0, s, a);      // (the [prepare, MFMA] order does not fit its register budget)
+  if (g_tall_triage || g_tall_krep != 1) hipLaunchKernelGGL((gs_tall_kernel<TP_MARG, false, 1, 0>), grid, block, 0, s, a);      // (measurement)
+  else hipLaunchKernelGGL((gs_tall_kernel<TP_MARG, false, 0, 0>), grid, block, 0, s, a);      // (the [prepare, MFMA] order does not fit its register budget)
   GS_LAUNCH_CHECK();
   return GS_OK;
 }

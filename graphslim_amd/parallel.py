@@ -116,10 +116,11 @@ class Comm:
         if not isinstance(box[0], bytes):
             raise RuntimeError(f"graphslim_amd: rank 0 could not create an RCCL unique id ({box[0]})")
         # ncclCommInitRank below is collective: a rank that cannot even load RCCL must not leave its peers waiting inside it.  Every
-        # rank probes its own binding (dlopen + symbols + a unique id it throws away: not collective) and all agree before any enters.
+        # rank probes its own binding (gs_comm_probe: dlopen + symbols + ncclGetVersion — allocates nothing, starts no bootstrap
+        # thread, not collective) and all agree before any enters.
         mine = 1.0
         try:
-            check(lib().gs_comm_unique_id(C.create_string_buffer(128)))
+            check(lib().gs_comm_probe(None))
         except Exception:      # noqa: BLE001
             mine = 0.0
         flag = torch.tensor([mine], device=torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu")

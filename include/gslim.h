@@ -448,6 +448,8 @@ int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream);      /* the SGC
 typedef struct gs_comm gs_comm;
 typedef int (*gs_allreduce_fn)(void* user, void* buf, long count, int dtype, gs_stream_t stream);
 int gs_comm_unique_id(void* id128);                                   /* host: 128 bytes out */
+int gs_comm_probe(int* rccl_version);                                 /* is the RCCL binding usable here? (dlopen + symbols + ncclGetVersion: allocates
+                                                                         nothing, not collective); rccl_version may be null */
 int gs_comm_create_rccl(const void* id128, int rank, int world, gs_comm** out);
 int gs_comm_create_callback(gs_allreduce_fn fn, void* user, int rank, int world, gs_comm** out);
 int gs_comm_create_null(int rank, int world, gs_comm** out);

@@ -87,6 +87,17 @@ int gs_gcond_set_h1_rows(int on);
  * memory for a general tiled product).  Same values up to fp32 rounding of the folded BatchNorm-1 affine. */
 int gs_gcond_set_dw1_generated(int on);
 
+/* Measurement / test knob: 1 (default) = the real-side edge product (csrc/gs_edge.hip) runs on BALANCED K slabs: the chip's 512 resident
+ * workgroup slots are cut over the classes in proportion to their live edge counts (a device-side plan, one launch in place of the
+ * kcount launch), so every workgroup runs about the same number of 16-edge steps; 0 = a fixed slab length for every class (rounds
+ * 2-4: 22 % of the slots stayed empty at ogbn-arxiv).  Same sums in a different (fixed) slab partition: equal up to fp32 re-association. */
+int gs_gcond_set_edge_plan(int on);
+
+/* Measurement knob: 1 (default) = the workgroups of the real-side ELL gathers (hop 2, hop 1) are mapped so that every row of a class
+ * is processed on ONE XCD (workgroup id % 8 = class % 8): a class's repeated source rows and the next hop's sources meet in one L2;
+ * 0 = rows in memory order over all XCDs.  Same values (every row is computed by the same code either way). */
+int gs_gcond_set_ell_xcd(int on);
+
 /* Priority of the second (real-side) stream of engines created AFTER the call: -1 = highest (default), 0 = normal, 1 = lowest. */
 int gs_gcond_set_aux_priority(int level);
 
@@ -97,7 +108,7 @@ int gs_sample_set_cand_cap(int cap);
 /* Engine-level knobs per ENGINE (the int-only setters above change the process-wide default an engine follows while its own value is
    -1): knob ids below, value 0 / 1, -1 = follow the default again.  gs_gcond_get_knob returns the value in effect (-1: bad arguments). */
 enum { GS_KNOB_FUSED_CHAINS = 0, GS_KNOB_H1_ROWS = 1, GS_KNOB_H1_BITS = 2, GS_KNOB_EDGE_BITS = 3, GS_KNOB_DW1_GENERATED = 4,
-       GS_KNOB_FOLDED_REDUCTIONS = 5, GS_KNOB_CHAINED_PRODUCTS = 6, GS_KNOB_FORK_LATE = 7, GS_KNOB_COUNT = 8 };
+       GS_KNOB_FOLDED_REDUCTIONS = 5, GS_KNOB_CHAINED_PRODUCTS = 6, GS_KNOB_FORK_LATE = 7, GS_KNOB_EDGE_PLAN = 8, GS_KNOB_COUNT = 9 };
 int gs_gcond_set_knob(gs_gcond* e, int knob, int value);
 int gs_gcond_get_knob(const gs_gcond* e, int knob);
 

@@ -40,8 +40,12 @@ def test_internal_header_symbols_are_exported(L):
     assert not (declared & set(_lib.SYMBOLS))
     for s in declared:
         assert hasattr(L, s), s
+    # the enum's size is EVALUATED at compile time (`-fsyntax-only` never ran the old comparison) against the Python mirror
     subprocess.run(["gcc", "-x", "c", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-"],
-                   input=b'#include "gslim_internal.h"\nint main(void){return GS_KNOB_COUNT == 6 ? 0 : 1;}\n', check=True)
+                   input=('#include "gslim_internal.h"\n_Static_assert(GS_KNOB_COUNT == %d, "GS_KNOB_COUNT drifted from '
+                          'graphslim_amd._lib.KNOBS");\n' % len(_lib.KNOBS)).encode() +
+                   "".join('_Static_assert(GS_KNOB_%s == %d, "knob id");\n' % (k, v) for k, v in _lib.KNOBS.items()).encode() +
+                   b"int main(void){return 0;}\n", check=True)
 
 
 def test_struct_layouts_match_the_header(L):

@@ -764,6 +764,80 @@ def test_per_edge_sign_bits_of_the_hop2_gather_give_bitwise_the_same_real_side_g
         _lib.check(L.gs_gcond_set_edge_bits(0))
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+def test_balanced_edge_slabs_give_the_fixed_slab_gradients(mode):
+    """Round 5: the real-side edge product (gcond_base.py:223 through relu and the hop-2 block; csrc/gs_edge.hip) on BALANCED K slabs —
+    a device-side plan cuts the chip's 512 workgroup slots over the classes by their live edge counts (knob GS_KNOB_EDGE_PLAN) —
+    against the fixed-length slabs of rounds 2-4: the same fp32 sums in another fixed partition, so gw_real agrees to 2e-6 of each
+    class's max, for the full class range and for class shards (few classes: long lists in many slabs; one class), the plan uses every
+    slot it may, and two runs of the same plan are bitwise equal."""
+    import bench
+    from graphslim_amd import _lib
+    from graphslim_amd.host import init_sgc_params
+    L = _lib.lib()
+    p = bench.build_problem("ogbn-arxiv", seed=1, scale=0.25)
+    C = p["data"].nclass
+    eng = bench.make_engine(p, DEV)
+    eng.set_operand_mode(mode)
+    bench.init_state(p, eng)
+    torch.manual_seed(9)
+    eng.set_model(init_sgc_params(p["data"].feat_full.shape[1], p["hidden"], C, p["T"]))
+    KNOB = _lib.KNOBS["EDGE_PLAN"]
+    assert L.gs_gcond_get_knob(eng.h, KNOB) == 1      # the product default
+    try:
+        for c_lo, c_hi in ((0, C), (7, 10), (3, 4)):
+            eng.set_shard(c_lo, c_hi, 0, len(p["labels_syn"]))
+            eng.stage_sample()
+            _lib.check(L.gs_gcond_set_knob(eng.h, KNOB, 0))
+            eng.stage_real_grads()
+            ref = eng.view("gw_real").clone().reshape(C, -1)[c_lo:c_hi]
+            _lib.check(L.gs_gcond_set_knob(eng.h, KNOB, 1))
+            eng.stage_real_grads()
+            got = eng.view("gw_real").clone().reshape(C, -1)[c_lo:c_hi]
+            eng.stage_real_grads()
+            torch.cuda.synchronize()
+            again = eng.view("gw_real").reshape(C, -1)[c_lo:c_hi]
+            assert float(ref.abs().max()) > 0
+            err = float(((got - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max())
+            assert err <= 2e-6, (mode, c_lo, c_hi, err)
+            assert torch.equal(got, again), (mode, c_lo, c_hi)
+            target = 512      # (a staged call: the stage has the chip to itself; beside the training forward the engine aims at 7/8)
+            plan = eng.view("edge_plan", torch.int32)[:2 * (c_hi - c_lo) + 1].cpu().numpy()
+            Cl = c_hi - c_lo
+            base, chunk = plan[:Cl + 1], plan[Cl + 1:]
+            n1 = eng.get_blocks().n1[c_lo:c_hi].cpu().numpy()
+            f2 = eng.get_blocks().col0.shape[2]
+            steps = -(-(n1 * f2) // 16)
+            slabs = np.diff(base)
+            assert base[0] == 0 and (slabs >= 1).all() and (chunk % 16 == 0).all()
+            assert ((slabs - 1) * chunk < n1 * f2).all() and (slabs * chunk >= n1 * f2).all()      # a partition: no empty slab, nothing left out
+            assert 0.8 * target <= base[-1] <= target + Cl, base[-1]                           # (d = 128: one feature tile)
+            per = chunk // 16
+            assert per.max() <= -(-steps.sum() // base[-1]) + 1, (per, steps.sum())            # every workgroup runs ~ total / slabs steps
+    finally:
+        _lib.check(L.gs_gcond_set_knob(eng.h, KNOB, -1))
+
+
+def test_every_knob_reports_its_process_default():
+    """gs_gcond_get_knob's table of process defaults is hand-ordered; a fresh engine must report the documented default for
+    every knob id of include/gslim_internal.h (graphslim_amd._lib.KNOBS, pinned to the enum by tests/test_abi.py)."""
+    import bench
+    from graphslim_amd import _lib
+    L = _lib.lib()
+    p = bench.build_problem("ogbn-arxiv", seed=1, scale=0.05)
+    eng = bench.make_engine(p, DEV)
+    want = {"FUSED_CHAINS": 1, "H1_ROWS": 1, "H1_BITS": 0, "EDGE_BITS": 0, "DW1_GENERATED": 1, "FOLDED_REDUCTIONS": 1, "CHAINED_PRODUCTS": 1,
+            "FORK_LATE": 0, "EDGE_PLAN": 1}
+    assert set(want) == set(_lib.KNOBS)
+    for name, k in _lib.KNOBS.items():
+        assert L.gs_gcond_get_knob(eng.h, k) == want[name], name
+        _lib.check(L.gs_gcond_set_knob(eng.h, k, 1 - want[name]))
+        assert L.gs_gcond_get_knob(eng.h, k) == 1 - want[name], name
+        _lib.check(L.gs_gcond_set_knob(eng.h, k, -1))
+        assert L.gs_gcond_get_knob(eng.h, k) == want[name], name
+    assert L.gs_gcond_get_knob(eng.h, len(_lib.KNOBS)) == -1
+
+
 @pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16x6", 2e-5), ("bf16x3", 1e-3), ("bf16", 3e-2)])
 @pytest.mark.parametrize("scale", [1.0, 0.13])
 def test_pge_epoch_backward_on_generated_operands(mode, tol, scale):

@@ -20,7 +20,8 @@ if os.environ.get("GS_SMALL"):      # routing sweep: "max_tiles,max_gflop" of th
     _lib.lib().gs_gemm_set_small(C.c_long(int(t)), C.c_double(float(g)))
 for env, fn in (("GS_H1_BITS", "gs_gcond_set_h1_bits"), ("GS_EDGE_KERNEL", "gs_gemm_set_edge_kernel"),
                 ("GS_FUSED_CHAINS", "gs_gcond_set_fused_chains"), ("GS_H1_ROWS", "gs_gcond_set_h1_rows"), ("GS_AUX_PRIORITY", "gs_gcond_set_aux_priority"),
-                ("GS_DW1_GEN", "gs_gcond_set_dw1_generated"), ("GS_EDGE_BITS", "gs_gcond_set_edge_bits")):   # A/B knobs of the library
+                ("GS_DW1_GEN", "gs_gcond_set_dw1_generated"), ("GS_EDGE_BITS", "gs_gcond_set_edge_bits"),
+                ("GS_EDGE_PLAN", "gs_gcond_set_edge_plan"), ("GS_ELL_XCD", "gs_gcond_set_ell_xcd")):   # A/B knobs of the library
     if os.environ.get(env):
         from graphslim_amd import _lib
         getattr(_lib.lib(), fn)(int(os.environ[env]))
@@ -90,3 +91,8 @@ it = timed(lambda: eng.outer_step(10), 40)
 print(f"outer_step (feature epoch, two streams + prefetched sampling): {it:.1f} us")
 it0 = timed(lambda: eng.outer_step(0), 40)
 print(f"outer_step (PGE epoch, two streams + prefetched sampling): {it0:.1f} us")
+eng.set_forward_reuse(True)      # what GCond.reduce runs: the training forward adopted from the previous iteration's inference forward
+itr = timed(lambda: eng.outer_step(10), 40)
+itr0 = timed(lambda: eng.outer_step(0), 40)
+eng.set_forward_reuse(False)
+print(f"outer_step with forward reuse (feature epoch / PGE epoch): {itr:.1f} / {itr0:.1f} us")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-step timeline of the persistent 256-row kernel (csrc/gs_panel2.hip, plain product): three s_memtime stamps per 16-k step of
+"""Per-step timeline of the persistent 256-row kernel (csrc/gs_panel2.hip, plain product): four s_memtime stamps per 16-k step of
 waves 0 (runs [loads, prepare, MFMA]) and 4 (runs [MFMA, loads, prepare]) of the first workgroups -> cycles spent waiting for loads,
 at the barrier, in the first and in the second part of a step.  usage: trace_tall.py [M K]"""
 import ctypes as C
@@ -34,19 +34,22 @@ L.gs_panel_tall_trace(None)
 t = buf.cpu().numpy().astype(np.int64).reshape(16, 2, 1408) & 0xFFFFFFFF
 nsb = K // 16
 for wg in (0, 1, 9, 15):
-    for half, name in ((0, "wave 0 [loads, prepare | MFMA]"), (1, "wave 4 [MFMA | loads, prepare]")):
+    for half, name, parts in ((0, "wave 0 [loads | prepare | MFMA]", ("loads", "prepare", "MFMA+wait")),
+                              (1, "wave 4 [MFMA | loads | prepare]", ("MFMA", "loads", "prepare+wait"))):
         s = t[wg, half]
-        n = int((s != 0).sum()) // 3
+        n = int((s != 0).sum()) // 4
         if n < 2:
             continue
-        st = s[:3 * n].reshape(n, 3)          # arrive, release, mid
-        arrive, release, mid = st[:, 0], st[:, 1], st[:, 2]
+        st = s[:4 * n].reshape(n, 4)          # arrive, release, after the first piece, after the second piece
+        arrive = st[:, 0]
         nxt = np.append(arrive[1:], arrive[-1])
-        bar = (release - arrive) % (1 << 32)
-        p1 = (mid - release) % (1 << 32)
-        p2 = (nxt - mid) % (1 << 32)
+        bar = (st[:, 1] - st[:, 0]) % (1 << 32)
+        a = (st[:, 2] - st[:, 1]) % (1 << 32)
+        b = (st[:, 3] - st[:, 2]) % (1 << 32)
+        c = (nxt - st[:, 3]) % (1 << 32)
         tot = (nxt - arrive) % (1 << 32)
-        print(f"wg {wg} {name}: {n} steps, {nsb} per tile; cycles per step (median): total {np.median(tot[:-1]):.0f}, barrier {np.median(bar):.0f}, "
-              f"first part {np.median(p1):.0f}, second part + waits {np.median(p2[:-1]):.0f}")
+        m = slice(0, n - 1)
+        print(f"wg {wg} {name}: {n} steps, {nsb} per tile; cycles per step (median): total {np.median(tot[m]):.0f}, barrier {np.median(bar[m]):.0f}, "
+              f"{parts[0]} {np.median(a[m]):.0f}, {parts[1]} {np.median(b[m]):.0f}, {parts[2]} {np.median(c[m]):.0f}")
         for i0 in range(0, min(n - 1, 2 * nsb + 4), 1):
-            print(f"   step {i0:3d}: barrier {bar[i0]:6d}  part1 {p1[i0]:6d}  part2+wait {p2[i0]:6d}  total {tot[i0]:6d}")
+            print(f"   step {i0:3d}: barrier {bar[i0]:6d}  {parts[0]} {a[i0]:6d}  {parts[1]} {b[i0]:6d}  {parts[2]} {c[i0]:6d}  total {tot[i0]:6d}")
