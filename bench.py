@@ -31,30 +31,33 @@ from graphslim_amd.workloads import (WORKLOADS, blocks_to_batches, build_problem
 
 
 def newest_profile(fname, key=None):
-    """The newest committed round's profiles/rNN/<fname> (that holds `key`, if given): (path relative to the repo, parsed JSON) or
-    (None, None).  The counter summaries cannot be sampled inside bench.py (PMC needs rocprofv3); a literal round in the path would
-    silently go stale."""
+    """The newest committed round's profiles/rNN/<fname> (that holds a key STARTING WITH `key`, if given — kernel names carry template
+    arguments that change between builds): (path relative to the repo, parsed JSON, matched key) or (None, None, None).
+    The counter summaries cannot be sampled inside bench.py (PMC needs rocprofv3); a literal round in the path would silently go
+    stale."""
     import glob
     for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*")), reverse=True):
         f = os.path.join(d, fname)
         if os.path.exists(f):
             blob = json.load(open(f))
-            if key is None or key in blob:
-                return os.path.relpath(f, ROOT), blob
-    return None, None
+            if key is None:
+                return os.path.relpath(f, ROOT), blob, None
+            hit = [k for k in blob if k.startswith(key)]
+            if hit:
+                return os.path.relpath(f, ROOT), blob, hit[0]
+    return None, None, None
 
 
-
-def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20, span=None):
-    """Dominant kernel: the PGE layer-2 contraction E2[n'^2, Ph] = A1[n'^2, Ph] W1^T + b1 on the matrix cores — the row-panel
-    kernel with the generated A1 operand, gs_panel_fwdgen_kernel<0, 8> in the default exact-fp32 mode (csrc/gs_panel.hip);
-    algorithmic FLOPs = 2 n'^2 Ph^2 per launch.  `achieved` uses the IN-SITU duration: HIP events recorded by the engine on
-    the launch stream around every launch of that product inside the timed outer iterations (training forward — which shares
-    the chip with the real-side stream — and inference pass).  `isolated_launch_us` is the same launch, bracketed the same
-    way, with nothing else on the chip (the PGE forward's first part run back to back).  `traffic` cannot be sampled inside
-    bench.py (PMC needs rocprofv3): it is read from the committed counter summary of the same kernel at the same shape
-    (`traffic_source`), FETCH_SIZE already doubled as the gfx950 calibration requires (profiles/r02/copy_calib: every read
-    pattern reports exactly half its bytes)."""
+def roofline(eng, passes, mode="f32", reps=20):
+    """Dominant product: the PGE layer-2 contraction E2[n'^2, Ph] = A1[n'^2, Ph] W1^T + b1 on the matrix cores (A1 generated in the
+    operand path, BN-2 column sums in the epilogue; parametrized_adj.py:57-64), 2 n'^2 Ph^2 algorithmic flops per launch.  It is
+    launched twice per iteration by TWO kernels, reported separately: the inference pass on the persistent
+    256-row kernel (csrc/gs_panel2.hip, alone on the chip) = the top-level entry, and the training pass on the 128-row kernel
+    (csrc/gs_panel.hip, beside the real-side stream) = `training_pass`.  `passes` = {pass: (event bracket ms, launches, device span
+    ms, spans)} from the engine's probe, recorded on the launch stream around every launch INSIDE the timed steps; `achieved` is
+    priced on the device span (first workgroup's start .. last workgroup's end, what a kernel trace reports as the duration).
+    `peak` is the guide's dense bf16 peak; `sustained_peak` is what THIS chip's matrix pipe delivers on random operands under its
+    power limit (tools/micro/issue_order.hip, newest profiles/rNN/mfma_sustained.json): the launch's real ceiling."""
     n, ph = eng.shapes.n_syn, eng.shapes.pge_hidden
     rows = n * n
     base = getattr(eng, "eng", eng)
@@ -69,57 +72,68 @@ def roofline(eng, insitu_ms, insitu_launches, mode="f32", reps=20, span=None):
     iso_span_ms, iso_span_k = base.probe_read_spans()
     base.probe(False)
     iso = iso_ms / 1e3 / max(iso_k, 1)
-    bracket = insitu_ms / 1e3 / insitu_launches if insitu_launches else iso
-    # `achieved` is priced on the in-situ HIP-event bracket when the kernel's own span is unavailable; with the span (the
-    # kernel stamps its first workgroup's start and last workgroup's end) on that, which is what the committed rocprofv3 kernel
-    # trace reports as the duration.  The bracket is kept beside it: in the training forward it also contains the time the
-    # launch waits for compute units held by the real-side stream's resident workgroups.
-    sec = span[0] / 1e3 / span[1] if span and span[1] else bracket
     flops = 2.0 * rows * ph * ph
-    traffic, src = None, None
-    # bf16x6 at the panel shape: the inference pass runs the persistent 256-row kernel (csrc/gs_panel2.hip), the training pass — beside
-    # the real-side stream — the 128-row kernel with the same folded operand (csrc/gs_panel.hip); the timed launches are both
-    kname = {"f32": "gs_panel_fwdgen_kernel<0, 8, false>", "bf16x3": "gs_panel_fwdgen_kernel<1, 8, false>",
-             "bf16": "gs_panel_fwdgen_kernel<2, 8, false>", "bf16x6": "gs_tall_kernel<1, false, 0, true>"}[mode]
-    if ph != 256 or n < 128:
-        kname = "PGE layer-2 product (row-panel / tile route of this shape)"
-    if (n, ph) == (454, 256):
-        path, blob = newest_profile("pmc_panel_summary.json", kname)
-        if blob:
-            traffic, src = int(blob[kname]["hbm_bytes_per_launch"]), path
     # algorithmic bytes: E2 written once; U, V (n' x Ph each) and the weight block read once — A1 is formed in registers
     alg_bytes = rows * ph * 4.0 + (2 * n * ph + ph * ph + ph) * 4.0
-    extra = {}
+    tall = mode == "bf16x6" and ph == 256 and n >= 128
+    knames = {"inference": "gs_tall_kernel<1, false, 0," if tall else {"f32": "gs_panel_fwdgen_kernel<0, 8,", "bf16x3": "gs_panel_fwdgen_kernel<1, 8,",
+                                                                        "bf16": "gs_panel_fwdgen_kernel<2, 8,", "bf16x6": "gs_panel_fwdgen_kernel<3, 8,"}[mode],
+              "training": {"f32": "gs_panel_fwdgen_kernel<0, 8,", "bf16x3": "gs_panel_fwdgen_kernel<1, 8,", "bf16": "gs_panel_fwdgen_kernel<2, 8,",
+                           "bf16x6": "gs_panel_fwdgen_kernel<3, 8,"}[mode]}
     if mode == "f32":
-        peak, bound, unit = 157.3, "mfma", "TFLOP/s"     # fp32 matrix peak (MI355X_MICROARCH.md chip table)
-        ach = flops / sec / 1e12
+        peak, bound, unit, mult = 157.3, "mfma", "TFLOP/s", 1.0      # fp32 matrix peak (MI355X_MICROARCH.md chip table)
     elif mode == "bf16x6":
         # the exact split executes SIX bf16 products per fp32 product: that is the algorithm's work on the bf16 pipe (dense peak
-        # 2 500 TFLOP/s, MI355X_MICROARCH.md); the fp32-equivalent rate is reported beside it
-        peak, bound, unit = 2500.0, "mfma", "TFLOP/s"
-        ach = 6.0 * flops / sec / 1e12
+        # 2 500 TFLOP/s, MI355X_MICROARCH.md)
+        peak, bound, unit, mult = 2500.0, "mfma", "TFLOP/s", 6.0
+    else:
+        # the split / bf16 modes need 3/16 or 1/16 of the fp32 pipe time: the launch is bounded by its E2 write stream
+        peak, bound, unit, mult = 8000.0, "hbm", "GB/s", 0.0
+    sus_path, sus, _ = newest_profile("mfma_sustained.json") if bound == "mfma" and mode == "bf16x6" else (None, None, None)
+
+    def entry(tag):
+        bracket_ms, k, span_ms, ks = passes.get(tag, (0.0, 0, 0.0, 0))
+        if not k:
+            return None
+        sec = span_ms / 1e3 / ks if ks else bracket_ms / 1e3 / k
+        ach = mult * flops / sec / 1e12 if bound == "mfma" else alg_bytes / sec / 1e9
+        out = {"kernel": knames[tag] + " ...>" if ph == 256 and n >= 128 else "PGE layer-2 product (row-panel / tile route of this shape)",
+               "avg_launch_us": round(sec * 1e6, 2), "launches_timed": int(k),
+               "avg_launch_source": ("device span (first workgroup start .. last workgroup end, s_memrealtime) of the launches inside the timed steps"
+                                     if ks else "HIP-event bracket inside the timed steps"),
+               "event_bracket_us": round(bracket_ms / k * 1e3, 2),
+               "achieved": round(ach, 3), "frac": round(ach / peak, 4),
+               # the same launch priced on its ALGORITHMIC flops (what the reference's fp32 product needs) against the peak of the pipe it runs on
+               "frac_algorithmic": round((flops / sec / 1e12) / peak if bound == "mfma" else ach / peak, 4)}
+        if sus:
+            out["frac_of_sustained_peak"] = round(ach / sus["loop_with_operand_preparation_TFLOPs"], 4)
+        out["traffic"], out["traffic_source"] = None, None
+        if (n, ph) == (454, 256):
+            path, blob, hit = newest_profile("pmc_panel_summary.json", knames[tag])
+            if blob:
+                out["traffic"], out["traffic_source"] = int(blob[hit]["hbm_bytes_per_launch"]), f"{path} [{hit}]"
+        return out
+
+    inf, trn = entry("inference"), entry("training")
+    top = inf or trn or {}
+    extra = {}
+    if mode == "bf16x6":
+        sec = top.get("avg_launch_us", iso * 1e6) / 1e6
         extra = {"executed_flops_per_launch": 6.0 * flops, "fp32_equivalent_tflops": round(flops / sec / 1e12, 2),
                  "fp32_equivalent_over_fp32_matrix_peak": round(flops / sec / 1e12 / 157.3, 4),
                  "hbm_GBps_of_algorithmic_bytes": round(alg_bytes / sec / 1e9, 1)}
-    else:
-        # the split / bf16 modes need 3/16 or 1/16 of the fp32 pipe time: the launch is bounded by its E2 write stream
-        peak, bound, unit = 8000.0, "hbm", "GB/s"
-        ach = alg_bytes / sec / 1e9
-    if mode == "bf16x6" and ph == 256 and n >= 128:
-        kname += " (inference pass) / gs_panel_fwdgen_kernel<3, 8, true> (training pass)"
-    # the same launch priced on its ALGORITHMIC flops (2 n'^2 Ph^2: what the reference's fp32 product needs), against the peak of the
-    # pipe it runs on — beside `frac`, which for the exact split counts the six executed bf16 products
-    frac_alg = (flops / sec / 1e12) / peak if bound == "mfma" else ach / peak
-    return {"bound": bound, "kernel": f"{kname} (PGE layer 2: E2 = A1 W1^T + b1 with fused BN-2 column sums, A1 generated; {mode} operands)",
-            "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "frac_algorithmic": round(frac_alg, 4),
-            "traffic": traffic,
-            "traffic_source": src, "avg_launch_us": round(sec * 1e6, 2),
-            "avg_launch_source": ("device span (first workgroup start .. last workgroup end, s_memrealtime) of the launches inside "
-                                  "the timed steps" if span and span[1] else "HIP-event bracket inside the timed steps"),
-            "event_bracket_us": round(bracket * 1e6, 2), "launches_timed": int(insitu_launches),
-            "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
-            "isolated_launch_us": round(iso * 1e6, 2),
-            "isolated_span_us": round(iso_span_ms / max(iso_span_k, 1) * 1e3, 2) if iso_span_k else None, **extra}
+        if sus:
+            extra["sustained_peak"] = {"TFLOPs": sus["loop_with_operand_preparation_TFLOPs"], "mfma_only_TFLOPs": sus["mfma_only_TFLOPs"],
+                                       "source": sus_path, "what": sus["what"]}
+    out = {"bound": bound, "peak": peak, "unit": unit,
+           "product": f"PGE layer 2: E2 = A1 W1^T + b1 with fused BN-2 column sums, A1 generated; {mode} operands; the inference pass (this entry) "
+                      "and the training pass (`training_pass`) are two kernels, each with its own time",
+           **top, "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+           "isolated_launch_us": round(iso * 1e6, 2),
+           "isolated_span_us": round(iso_span_ms / max(iso_span_k, 1) * 1e3, 2) if iso_span_k else None, **extra}
+    if inf and trn:
+        out["training_pass"] = trn
+    return out
 
 
 
@@ -148,13 +162,13 @@ def roofline_hbm(eng, spmm_ms, spmm_launches):
     if base.shapes.n_nodes == 169343 and F == 256:      # (the committed counter passes are of the headline shape)
         # hop 2's OWN dispatches (tools/gpu/pmc_dispatches.sh splits them from the hop-1 launches of the same kernel); older rounds
         # only hold the average over both
-        path, blob = newest_profile("pmc_hop2_dispatches.json", "hbm_bytes_per_launch")
+        path, blob, _ = newest_profile("pmc_hop2_dispatches.json", "hbm_bytes_per_launch")
         if blob:
             traffic, src = int(blob["hbm_bytes_per_launch"]), path + " (the hop-2 dispatches only)"
         else:
-            path, blob = newest_profile("pmc_bench_hbm_per_kernel.json", "gs_ell_spmm_kernel<4>")
+            path, blob, hit = newest_profile("pmc_bench_hbm_per_kernel.json", "gs_ell_spmm_kernel<4>")
             if blob:
-                traffic, src = int(blob["gs_ell_spmm_kernel<4>"]["hbm_bytes_per_launch"]), path + " (average over the hop-2 and hop-1 launches)"
+                traffic, src = int(blob[hit]["hbm_bytes_per_launch"]), path + " (average over the hop-2 and hop-1 launches)"
     ach = alg / sec / 1e9
     # the same launch with nothing else on the chip (the real-side stage run back to back on one stream: its kernels are in order)
     base.set_overlap(0)
@@ -239,7 +253,7 @@ def engine_match_loss(p, eng):
 
 def cpu_baseline(p, eng, timeout_s=420):
     """The oracle (a CPU port of the reference path, pinned against reference golden vectors) on a bounded sample:
-    1 warm-up + 1 timed outer iteration of the same workload on the blocks the engine sampled, with the engine's own
+    1 warm-up + 10 timed outer iterations of the same workload on the blocks the engine sampled, with the engine's own
     (X~, theta_PGE, theta): its matching loss is compared with the engine's (`parity_rel_err`, gate 1e-4).  Runs in a
     child process (no GPU) with a hard time limit so that the default bench finishes within minutes."""
     import subprocess
@@ -277,7 +291,9 @@ def cpu_baseline_child(path):
     p = build_problem(blob["workload"], seed=1)
     X, Y = p["data"].bench_feat, p["data"].bench_labels
     pge = blob["pge"]
-    n_timed = int(os.environ.get("GS_CPU_BASELINE_ITERS", "5"))
+    # bounded sample: ~3 s per iteration on 32 host cores -> 10 timed iterations are ~30 s of CPU work, the upper end of what the default
+    # run may spend here (the first round's 5 became 10 in round 5; 20 would be a minute of the run's few)
+    n_timed = int(os.environ.get("GS_CPU_BASELINE_ITERS", "10"))
     times, loss = [], None
     # every pass starts from the engine's state (same blocks, X~, theta_PGE, theta): pass 0 is the warm-up, passes 1 .. n are timed
     for _ in range(1 + n_timed):
@@ -396,8 +412,7 @@ def main():
     run_steps(p, eng, args.steps, args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    probe_ms, probe_k = base.probe_read()
-    probe_span = base.probe_read_spans()
+    probe_passes = {"training": base.probe_read_pass(False), "inference": base.probe_read_pass(True)}
     spmm_ms, spmm_k = base.probe_read_spmm()
     hbm = roofline_hbm(eng, spmm_ms, spmm_k) if rank == 0 else None
     base.probe(False)
@@ -485,7 +500,7 @@ def main():
                        "parallelism": getattr(eng, "parallelism", "single"),
                        "iters_per_sec_with_forward_reuse": round(args.steps / dt_reuse, 3)},
         }
-        out["roofline"] = roofline(eng, probe_ms, probe_k, args.operand_mode, span=probe_span)
+        out["roofline"] = roofline(eng, probe_passes, args.operand_mode)
         if hbm:
             out["roofline_hbm"] = hbm
         if acc:

@@ -69,14 +69,14 @@ SYMBOLS = [
     "gs_gcond_stage_real_grads", "gs_gcond_stage_real_async", "gs_gcond_stage_pge_forward", "gs_gcond_stage_syn_match",
     "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer", "gs_gcond_get_blocks", "gs_gcond_set_shard",
     "gs_gcond_set_overlap", "gs_gcond_set_operand_mode", "gs_gcond_set_full_neighbour", "gs_gcond_set_forward_reuse", "gs_gcond_probe",
-    "gs_gcond_probe_read", "gs_gcond_probe_read_spans", "gs_gcond_probe_read_spmm", "gs_gcond_invalidate_forward", "gs_gcond_forward_cached",
+    "gs_gcond_probe_read", "gs_gcond_probe_read_spans", "gs_gcond_probe_read_pass", "gs_gcond_probe_read_spmm", "gs_gcond_invalidate_forward", "gs_gcond_forward_cached",
     "gs_gcond_adopt_cached_forward", "gs_gcond_stage_pge_forward_part", "gs_gcond_stage_pge_backward_part", "gs_gcond_stage_syn_finish",
     "gs_gcond_stage_inner_steps", "gs_bias_act_f32", "gs_log_softmax_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
     "gs_edge_pair_sum_f32", "gs_bn_scratch_bytes", "gs_bn_relu_fwd_f32", "gs_bn_relu_bwd_f32", "gs_edge_score_f32", "gs_edge_scatter_sym_f32",
     "gs_edge_score_bwd_f32", "gs_segment_sum_rows_f32", "gs_colsum_tall_f32", "gs_mul_f32", "gs_mul_bwd_f32", "gs_mix_heads_f32",
     "gs_mix_heads_bwd_f32", "gs_sym_sigmoid_f32", "gs_sym_sigmoid_bwd_f32", "gs_bn_running_update_f32", "gs_bn_relu_eval_f32", "gs_ot_spectrum_f32",
     "gs_ot_value_f32", "gs_scale_cols_f32", "gs_ot_divdiff_f32", "gs_clamp_finite_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
-    "gs_comm_unique_id", "gs_comm_probe", "gs_comm_create_rccl", "gs_comm_create_callback", "gs_comm_create_null", "gs_comm_destroy", "gs_comm_rank", "gs_comm_world",
+    "gs_comm_unique_id", "gs_comm_probe", "gs_comm_create_rccl", "gs_comm_create_callback", "gs_comm_create_null", "gs_comm_ipc_arena", "gs_comm_create_ipc", "gs_comm_ipc_error", "gs_comm_destroy", "gs_comm_rank", "gs_comm_world",
     "gs_comm_allreduce", "gs_comm_set_timing", "gs_comm_read_timing", "gs_comm_read_timing2", "gs_gcond_outer_step_sharded", "gs_gcond_outer_step_sharded_ex",
 ]
 
@@ -150,6 +150,7 @@ def lib():
     L.gs_gcond_probe.argtypes = [vp, i]
     L.gs_gcond_probe_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.gs_gcond_probe_read_spans.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    L.gs_gcond_probe_read_pass.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.gs_gcond_probe_read_spmm.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.gs_gcond_invalidate_forward.argtypes = [vp]
     L.gs_gcond_forward_cached.argtypes = [vp]
@@ -190,6 +191,9 @@ def lib():
     L.gs_segment_sum_rows_f32.argtypes = [vp, l, vp, vp, i, i, vp, l, vp]
     L.gs_comm_unique_id.argtypes = [vp]
     L.gs_comm_probe.argtypes = [vp]
+    L.gs_comm_ipc_arena.argtypes = [C.c_size_t, C.POINTER(vp), vp]
+    L.gs_comm_create_ipc.argtypes = [vp, vp, C.c_size_t, i, i, vp, C.POINTER(vp)]
+    L.gs_comm_ipc_error.argtypes = [vp, C.POINTER(i)]
     L.gs_comm_create_rccl.argtypes = [vp, i, i, C.POINTER(vp)]
     L.gs_comm_create_callback.argtypes = [ALLREDUCE_FN, vp, i, i, C.POINTER(vp)]
     L.gs_comm_create_null.argtypes = [i, i, C.POINTER(vp)]

@@ -2,7 +2,7 @@
 // all-reduce(sum) of a contiguous engine buffer, issued by the library itself on the engine's stream, so that a rank makes ONE
 // host call per outer iteration (gs_gcond_outer_step_sharded, gs_engine.hip).
 //
-// Three transports behind one handle:
+// Four transports behind one handle:
 //   rccl      ncclAllReduce on a communicator this library creates with ncclCommInitRank (one process per GPU, xGMI).  RCCL is
 //             bound with dlopen / dlsym — the copy PyTorch-ROCm has already loaded if there is one — so that libgslim_hip.so has
 //             no link-time dependency on it and loads on machines without RCCL (single-GPU use never touches this file's RCCL
@@ -10,6 +10,13 @@
 //             ncclUniqueId, :187 ncclGetUniqueId, :220 ncclCommInitRank, :611 ncclAllReduce).
 //   callback  the caller's function performs the exchange (tests: torch.distributed over gloo between processes that share one
 //             GPU — RCCL refuses several ranks per device — and an in-process sum between virtual ranks).
+//   ipc       (round 5) one-shot PEER-READ all-reduce for the sub-MB joins of the iteration: every rank owns an arena of device memory
+//             (a flag, an arrival counter, two data slots), exports it with hipIpcGetMemHandle and maps every other rank's arena
+//             (hipIpcOpenMemHandle: xGMI peer access between the GPUs of a node).  One launch per exchange: copy the contribution into
+//             the own slot, publish the flag, wait for every peer's flag, read every peer's slot over the fabric and add them IN RANK
+//             ORDER (so that all replicas end with bitwise the same sums), write the result in place.  No ring, no proxy thread, no
+//             host round trip: SURVEY section 8e asks for exactly this for messages of <= 1.2 MB.  Larger exchanges go to a fallback
+//             communicator (RCCL or callback) when one is given.
 //   null      no exchange (world 1, and timing-only virtual ranks: tools/virtual_scale.py).
 // The reference has no distributed code: nothing here replaces a reference line.
 #include <dlfcn.h>
@@ -71,7 +78,10 @@ const char* rccl_err(int rc) { return g_rccl.GetErrorString ? g_rccl.GetErrorStr
 
 }  // namespace
 
-enum { GS_COMM_NULL = 0, GS_COMM_RCCL = 1, GS_COMM_CALLBACK = 2 };
+enum { GS_COMM_NULL = 0, GS_COMM_RCCL = 1, GS_COMM_CALLBACK = 2, GS_COMM_IPC = 3 };
+#define GS_IPC_MAX_WORLD 16
+#define GS_IPC_HEADER 4096      /* bytes in front of the data slots: [0] flag (u64), [64] arrival counter (u32), [128] error word (u32) */
+#define GS_IPC_GRID 32          /* workgroups per exchange: resident whatever else runs (a waiting workgroup must never keep a peer's writer off the chip) */
 #define GS_COMM_TAGS 8
 #define GS_COMM_MAX_EVENTS 8192
 
@@ -86,6 +96,12 @@ struct gs_comm {
   int n_ev;
   hipEvent_t* ev;        // [2 * GS_COMM_MAX_EVENTS], created lazily
   int* ev_tag;
+  // ipc transport
+  char* arena[GS_IPC_MAX_WORLD];      // every rank's arena as mapped HERE (own: the allocation itself)
+  size_t slot_bytes;                  // capacity of one data slot
+  unsigned long long seq;             // exchanges issued so far
+  gs_comm* fallback;                  // exchanges beyond slot_bytes (not owned)
+  bool own_arena;
 };
 
 // Is the RCCL binding usable in this process?  dlopen + the entry points + ncclGetVersion: allocates nothing and starts no bootstrap
@@ -152,6 +168,142 @@ extern "C" int gs_comm_create_null(int rank, int world, gs_comm** out) {
   return GS_OK;
 }
 
+// ---- ipc transport ---------------------------------------------------------------------------------------------------------------
+struct gs_ipc_args {
+  char* arena[GS_IPC_MAX_WORLD];
+  int rank, world;
+  unsigned long long seq;      // this exchange (1-based)
+  size_t slot_bytes;
+  void* buf; long count;       // in place; count elements of 4 (fp32) or 8 (fp64) bytes
+  int f64;
+};
+
+template <typename T>
+__device__ __forceinline__ void ipc_reduce(const gs_ipc_args& a, int par) {
+  typedef T vec4 __attribute__((ext_vector_type(16 / sizeof(T))));
+  constexpr int VE = 16 / sizeof(T);
+  const long nv = a.count / VE;
+  T* buf = (T*)a.buf;
+  const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long i = t0; i < nv; i += stride) {
+    vec4 acc = *reinterpret_cast<const vec4*>(a.arena[0] + GS_IPC_HEADER + par * a.slot_bytes + i * 16);
+    for (int r = 1; r < a.world; ++r) acc += *reinterpret_cast<const vec4*>(a.arena[r] + GS_IPC_HEADER + par * a.slot_bytes + i * 16);
+    *reinterpret_cast<vec4*>(buf + i * VE) = acc;
+  }
+  for (long i = nv * VE + t0; i < a.count; i += stride) {
+    T acc = *reinterpret_cast<const T*>(a.arena[0] + GS_IPC_HEADER + par * a.slot_bytes + i * sizeof(T));
+    for (int r = 1; r < a.world; ++r) acc += *reinterpret_cast<const T*>(a.arena[r] + GS_IPC_HEADER + par * a.slot_bytes + i * sizeof(T));
+    buf[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gs_ipc_allreduce_kernel(gs_ipc_args a) {
+  const int par = (int)(a.seq & 1);
+  char* mine = a.arena[a.rank];
+  // 1. my contribution -> my slot (the slot of this parity was last read in exchange seq - 2: every peer has since published seq - 1)
+  {
+    const long nb16 = (a.count * (a.f64 ? 8 : 4)) / 16, tail0 = nb16 * 16, nbytes = a.count * (a.f64 ? 8 : 4);
+    const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    for (long i = t0; i < nb16; i += stride)
+      *reinterpret_cast<i32x4*>(mine + GS_IPC_HEADER + par * a.slot_bytes + i * 16) = *reinterpret_cast<const i32x4*>((const char*)a.buf + i * 16);
+    for (long i = tail0 + 4 * t0; i < nbytes; i += 4 * stride)
+      *reinterpret_cast<int*>(mine + GS_IPC_HEADER + par * a.slot_bytes + i) = *reinterpret_cast<const int*>((const char*)a.buf + i);
+  }
+  __threadfence_system();      // my stores are visible to the other devices before the flag below can be
+  __syncthreads();
+  // 2. the last workgroup to arrive publishes the flag (arrival counter: monotonic, gridDim.x per exchange)
+  if (threadIdx.x == 0) {
+    const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(mine + 64), 1u);
+    if (old + 1u == (unsigned)(a.seq * gridDim.x))
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // 3. wait for every rank's flag (bounded: ~2 s; a rank that never arrives must not hang the device — the error word says so)
+  if ((int)threadIdx.x < a.world) {
+    const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(a.arena[threadIdx.x]);
+    long spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+      __builtin_amdgcn_s_sleep(32);
+      if (++spins > 4000000L) {
+        __hip_atomic_store(reinterpret_cast<unsigned*>(mine + 128), 1u + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: nothing read below may come from a line cached before the flags
+  // 4. the sum, ranks in ascending order on every rank: the replicas end with bitwise the same values
+  if (a.f64) ipc_reduce<double>(a, par);
+  else ipc_reduce<float>(a, par);
+}
+
+// This rank's arena: device memory on the current device (uncached where the runtime offers it: the slots are written once and read
+// once by other devices), zeroed; `handle64` receives the 64 bytes every other rank opens it with (hipIpcMemHandle_t).
+extern "C" int gs_comm_ipc_arena(size_t slot_bytes, void** arena, void* handle64) {
+  if (!arena || !handle64 || slot_bytes < 16) GS_FAIL(GS_ERR_ARG, "gs_comm_ipc_arena: bad argument");
+  slot_bytes = (slot_bytes + 255) & ~(size_t)255;
+  const size_t total = GS_IPC_HEADER + 2 * slot_bytes;
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, total, hipDeviceMallocUncached) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipExtMallocWithFlags(&p, total, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      GS_HIP(hipMalloc(&p, total));
+    }
+  }
+  GS_HIP(hipMemset(p, 0, total));
+  GS_HIP(hipDeviceSynchronize());
+  hipIpcMemHandle_t h;
+  const hipError_t rc = hipIpcGetMemHandle(&h, p);
+  if (rc != hipSuccess) {
+    (void)hipFree(p);
+    GS_FAIL(GS_ERR_STATE, "gs_comm_ipc_arena: hipIpcGetMemHandle failed: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed on hosts with dmabuf IPC only)",
+            hipGetErrorString(rc));
+  }
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  memcpy(handle64, &h, 64);
+  *arena = p;
+  return GS_OK;
+}
+
+// handles: [world][64] — every rank's handle in rank order (this rank's own entry is ignored: `arena` is used).  The communicator
+// takes ownership of `arena`.  fallback (optional, not owned): carries the exchanges that do not fit a slot.
+extern "C" int gs_comm_create_ipc(void* arena, const void* handles, size_t slot_bytes, int rank, int world, gs_comm* fallback, gs_comm** out) {
+  if (!arena || !handles || !out || world < 1 || world > GS_IPC_MAX_WORLD || rank < 0 || rank >= world || slot_bytes < 16)
+    GS_FAIL(GS_ERR_ARG, "gs_comm_create_ipc: bad argument (world <= %d)", GS_IPC_MAX_WORLD);
+  gs_comm* c = new_comm(GS_COMM_IPC, rank, world);
+  if (!c) GS_FAIL(GS_ERR_STATE, "gs_comm_create_ipc: out of host memory");
+  c->slot_bytes = (slot_bytes + 255) & ~(size_t)255;
+  c->fallback = fallback;
+  c->own_arena = true;
+  for (int r = 0; r < world; ++r) {
+    if (r == rank) { c->arena[r] = (char*)arena; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const char*)handles + 64 * r, 64);
+    void* p = nullptr;
+    const hipError_t rc = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (rc != hipSuccess) {
+      for (int q = 0; q < r; ++q)
+        if (q != rank && c->arena[q]) (void)hipIpcCloseMemHandle(c->arena[q]);
+      (void)hipFree(arena);
+      delete c;
+      GS_FAIL(GS_ERR_STATE, "gs_comm_create_ipc: hipIpcOpenMemHandle(rank %d) failed: %s", r, hipGetErrorString(rc));
+    }
+    c->arena[r] = (char*)p;
+  }
+  *out = c;
+  return GS_OK;
+}
+
+// 0 = every exchange so far found all its peers; r + 1 = a wait for rank r's flag timed out (the sums of that exchange are wrong)
+extern "C" int gs_comm_ipc_error(gs_comm* c, int* code) {
+  if (!c || !code || c->kind != GS_COMM_IPC) GS_FAIL(GS_ERR_ARG, "gs_comm_ipc_error: not an ipc communicator");
+  unsigned v = 0;
+  GS_HIP(hipMemcpy(&v, c->arena[c->rank] + 128, 4, hipMemcpyDeviceToHost));
+  *code = (int)v;
+  return GS_OK;
+}
+
 extern "C" void gs_comm_destroy(gs_comm* c) {
   if (!c) return;
   if (c->ev) {
@@ -161,6 +313,12 @@ extern "C" void gs_comm_destroy(gs_comm* c) {
     delete[] c->ev_tag;
   }
   if (c->kind == GS_COMM_RCCL && c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl);
+  if (c->kind == GS_COMM_IPC) {
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < c->world; ++r)
+      if (r != c->rank && c->arena[r]) (void)hipIpcCloseMemHandle(c->arena[r]);
+    if (c->own_arena && c->arena[c->rank]) (void)hipFree(c->arena[c->rank]);
+  }
   delete c;
 }
 
@@ -228,6 +386,23 @@ extern "C" int gs_comm_allreduce(gs_comm* c, void* buf, long count, int dtype, i
   } else if (c->kind == GS_COMM_CALLBACK) {
     const int rc = c->fn(c->user, buf, count, dtype, stream);
     if (rc != 0) GS_FAIL(GS_ERR_STATE, "gs_comm: the caller's all-reduce callback failed (%d)", rc);
+  } else if (c->kind == GS_COMM_IPC) {
+    const size_t nbytes = (size_t)count * (dtype ? 8 : 4);
+    if (nbytes > c->slot_bytes || (((uintptr_t)buf) & 15)) {
+      // (the count is the same on every rank, so every rank takes this branch together)
+      if (!c->fallback) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_comm (ipc): an exchange of %zu bytes does not fit the %zu-byte slots and no fallback "
+                                                    "communicator was given", nbytes, c->slot_bytes);
+      c->calls[tag] -= 1; c->bytes[tag] -= (long)nbytes;      // (counted by this handle above; the fallback does not double-count for us)
+      const int rc = gs_comm_allreduce(c->fallback, buf, count, dtype, tag, stream);
+      c->calls[tag] += 1; c->bytes[tag] += (long)nbytes;
+      if (rc != GS_OK) return rc;
+    } else {
+      gs_ipc_args a;
+      for (int r = 0; r < GS_IPC_MAX_WORLD; ++r) a.arena[r] = r < c->world ? c->arena[r] : nullptr;
+      a.rank = c->rank; a.world = c->world; a.seq = ++c->seq; a.slot_bytes = c->slot_bytes; a.buf = buf; a.count = count; a.f64 = dtype;
+      hipLaunchKernelGGL(gs_ipc_allreduce_kernel, dim3(GS_IPC_GRID), dim3(256), 0, s, a);
+      GS_LAUNCH_CHECK();
+    }
   }
   if (tm) {
     GS_HIP(hipEventRecord(c->ev[2 * c->n_ev + 1], s));

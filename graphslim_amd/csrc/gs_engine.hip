@@ -148,6 +148,7 @@ struct gs_gcond {
   // in-situ timing of the dominant kernel (PGE layer-2 GEMM): event pairs recorded around its launches while probing
   bool probing;
   int probe_n;
+  unsigned char probe_pass[256];       // 1: the probed launch was the inference pass, 0: the training pass
   hipEvent_t probe_ev[2 * 256];
   int probe2_n;
   hipEvent_t probe2_ev[2 * 256];     // the same for the hop-2 gather SpMM of the real side (gs_ell_spmm_kernel), on ITS stream
@@ -1251,7 +1252,7 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       }
       e->a1_valid = false;
       int tiles = 0;
-      if (probe) GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s));
+      if (probe) { e->probe_pass[e->probe_n] = inference ? 1 : 0; GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s)); }
       const int rc = gs_panel_forward_a1(&a1, n, nr, pp + e->pW1, Ph, pp + e->pb1, e->E2, Ph, Ph, Ph, e->statp, &tiles, e->operand_mode,
                                          e->bsplit_main, probe ? e->probe_span + 2 * e->probe_n : nullptr, inference, s);
       if (rc == GS_OK) {
@@ -2481,6 +2482,27 @@ extern "C" int gs_gcond_probe_read_spans(gs_gcond* e, double* total_ms, long* la
     if (h[2 * i + 1] > h[2 * i] && h[2 * i] != ~0ull) { t += (double)(h[2 * i + 1] - h[2 * i]) * 1e-5; ++k; }
   *total_ms = t;
   *launches = k;
+  return GS_OK;
+}
+
+// The same two figures for ONE pass of the probed product (pass 0: training forward, 1: inference forward): HIP-event bracket [ms],
+// launches, device-side span [ms] and the launches that recorded one.  bench.py reports the two kernels separately.
+extern "C" int gs_gcond_probe_read_pass(gs_gcond* e, int pass, double* bracket_ms, long* launches, double* span_ms, long* span_launches) {
+  if (!e || !bracket_ms || !launches || !span_ms || !span_launches) GS_FAIL(GS_ERR_ARG, "gs_gcond_probe_read_pass: null argument");
+  unsigned long long h[2 * 256];
+  GS_HIP(hipDeviceSynchronize());
+  GS_HIP(hipMemcpy(h, e->probe_span, sizeof(h), hipMemcpyDeviceToHost));
+  double tb = 0, ts = 0;
+  long kb = 0, ks = 0;
+  for (int i = 0; i < e->probe_n; ++i) {
+    if ((int)e->probe_pass[i] != (pass != 0)) continue;
+    float ms = 0.f;
+    GS_HIP(hipEventSynchronize(e->probe_ev[2 * i + 1]));
+    GS_HIP(hipEventElapsedTime(&ms, e->probe_ev[2 * i], e->probe_ev[2 * i + 1]));
+    tb += ms; ++kb;
+    if (h[2 * i + 1] > h[2 * i] && h[2 * i] != ~0ull) { ts += (double)(h[2 * i + 1] - h[2 * i]) * 1e-5; ++ks; }
+  }
+  *bracket_ms = tb; *launches = kb; *span_ms = ts; *span_launches = ks;
   return GS_OK;
 }
 

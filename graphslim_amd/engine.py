@@ -394,6 +394,13 @@ class GCondEngine:
         check(self.L.gs_gcond_probe_read_spans(self.h, C.byref(t), C.byref(k)))
         return t.value, k.value
 
+    def probe_read_pass(self, inference):
+        """One pass of the probed product (False: training forward, True: inference forward): (event bracket [ms], launches, device span
+        [ms], launches that recorded a span) since probe(True)."""
+        tb, kb, ts, ks = C.c_double(), C.c_long(), C.c_double(), C.c_long()
+        check(self.L.gs_gcond_probe_read_pass(self.h, int(bool(inference)), C.byref(tb), C.byref(kb), C.byref(ts), C.byref(ks)))
+        return tb.value, kb.value, ts.value, ks.value
+
     def probe_read_spmm(self):
         """(summed HIP-event bracket [ms], launches) of the hop-2 gather SpMM of the real side since probe(True)."""
         t, k = C.c_double(), C.c_long()

@@ -133,6 +133,40 @@ class Comm:
         return cls(h, "rccl")
 
     @classmethod
+    def ipc(cls, dist, group=None, slot_bytes=2 << 20, fallback=None):
+        """The one-shot peer-read transport (gs_comm_create_ipc): every rank allocates its arena on ITS current device, the 64-byte
+        hipIpc handles travel over torch.distributed, every rank maps every other rank's arena.  `fallback`: a Comm for exchanges
+        beyond slot_bytes (kept alive by the returned object).  Every rank reaches the same collectives whatever fails locally."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        arena, handle, err = C.c_void_p(), C.create_string_buffer(64), None
+        try:
+            check(lib().gs_comm_ipc_arena(slot_bytes, C.byref(arena), handle))
+        except Exception as e:      # noqa: BLE001 — must still reach the gather below
+            err = repr(e)
+        box = [None] * world
+        dist.all_gather_object(box, (handle.raw, err), group=group)
+        bad = [(r, b[1]) for r, b in enumerate(box) if b[1]]
+        if bad:
+            raise RuntimeError(f"graphslim_amd: the ipc transport is not usable on every rank: {bad}")
+        handles = C.create_string_buffer(b"".join(b[0] for b in box), 64 * world)
+        h, err = C.c_void_p(), None
+        try:
+            check(lib().gs_comm_create_ipc(arena, handles, slot_bytes, rank, world, fallback.h if fallback is not None else None, C.byref(h)))
+        except Exception as e:      # noqa: BLE001
+            err = repr(e)
+        box = [None] * world
+        dist.all_gather_object(box, err, group=group)
+        if any(box):
+            raise RuntimeError(f"graphslim_amd: the ipc transport could not map every rank's arena: {[(r, b) for r, b in enumerate(box) if b]}")
+        return cls(h, "ipc", keep=fallback)
+
+    def ipc_error(self):
+        """0, or r + 1 when an exchange of this ipc communicator gave up waiting for rank r (gs_comm_ipc_error)."""
+        code = C.c_int()
+        check(lib().gs_comm_ipc_error(self.h, C.byref(code)))
+        return code.value
+
+    @classmethod
     def rccl_world1(cls):
         """A one-rank RCCL communicator (the 1-GPU test leg of the RCCL binding)."""
         buf = C.create_string_buffer(128)
@@ -167,15 +201,20 @@ class Comm:
         return cls(h, "callback", keep=(cb, fn))
 
     @classmethod
-    def from_dist(cls, dist=None, group=None):
+    def from_dist(cls, dist=None, group=None, slot_bytes=2 << 20):
         """The transport that fits the process group: none -> null, nccl -> RCCL inside the library, anything else (gloo) ->
-        callback onto dist.all_reduce."""
+        callback onto dist.all_reduce.  GS_COMM_TRANSPORT=ipc puts the one-shot peer-read transport in front of that one (which
+        stays as the fallback for exchanges beyond slot_bytes)."""
         if dist is None or dist.get_world_size(group) == 1:
             return cls.null()
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         if dist.get_backend(group) == "nccl" and os.environ.get("GS_COMM", "rccl") == "rccl":
-            return cls.rccl(dist, group)
-        return cls.callback(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group), rank, world)
+            base = cls.rccl(dist, group)
+        else:
+            base = cls.callback(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group), rank, world)
+        if os.environ.get("GS_COMM_TRANSPORT") == "ipc":
+            return cls.ipc(dist, group, slot_bytes, fallback=base)
+        return base
 
     def allreduce(self, t, tag=7):
         check(lib().gs_comm_allreduce(self.h, ptr(t), t.numel(), 1 if t.dtype == torch.float64 else 0, tag, stream()))
@@ -274,7 +313,10 @@ class ShardedGCond:
     @property
     def comm(self):
         if self._comm is None:
-            self._comm = Comm.from_dist(self.col.dist, self.col.group)
+            s = self.eng.shapes      # the largest join of an iteration: [dX~ | d adj | loss_c], the marginals, dW1 | db1, the pair scores
+            ph = s.pge_hidden
+            largest = 4 * max(s.n_syn * s.d + s.n_syn * s.n_syn + s.nclass, 2 * s.n_syn * ph, ph * ph + ph, s.n_syn * s.n_syn)
+            self._comm = Comm.from_dist(self.col.dist, self.col.group, slot_bytes=max(largest, 1 << 16))
         return self._comm
 
     def outer_step(self, epoch):

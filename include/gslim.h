@@ -356,6 +356,8 @@ int gs_gcond_probe_read_spmm(gs_gcond* e, double* total_ms, long* launches);   /
    launches whose kernel records one (the generated-A1 forward): the kernel's duration as a rocprofv3 kernel trace reports it.
    The HIP-event bracket above additionally contains the time the launch queued behind the other stream's resident workgroups. */
 int gs_gcond_probe_read_spans(gs_gcond* e, double* total_ms, long* launches);
+/* the same per pass of the probed product (0: training forward, 1: inference forward): event bracket, launches, device span, spans recorded */
+int gs_gcond_probe_read_pass(gs_gcond* e, int pass, double* bracket_ms, long* launches, double* span_ms, long* span_launches);
 int gs_gcond_invalidate_forward(gs_gcond* e);
 int gs_gcond_forward_cached(gs_gcond* e);
 int gs_gcond_adopt_cached_forward(gs_gcond* e, gs_stream_t stream);
@@ -434,7 +436,7 @@ int gs_gcond_stage_syn_finish(gs_gcond* e, gs_stream_t stream);       /* books t
 int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream);      /* the SGC steps of gs_gcond_stage_inner, without PGE.inference */
 
 /* ---- the exchange itself, inside the library -----------------------------------------------------------------------
- * gs_comm: all-reduce(sum) between the ranks of a sharded run, issued by the library on the engine's stream.  Transports:
+ * gs_comm: all-reduce(sum) between the ranks of a sharded run, issued by the library on the engine's stream.  Transports (+ ipc, below):
  *   rccl      ncclAllReduce (RCCL over xGMI; bound with dlopen, the library has no link-time dependency on it).  Rank 0 calls
  *             gs_comm_unique_id and hands the 128 bytes to every rank (host side: any broadcast, e.g. torch.distributed);
  *             every rank then calls gs_comm_create_rccl with its device current.
@@ -453,6 +455,16 @@ int gs_comm_probe(int* rccl_version);                                 /* is the 
 int gs_comm_create_rccl(const void* id128, int rank, int world, gs_comm** out);
 int gs_comm_create_callback(gs_allreduce_fn fn, void* user, int rank, int world, gs_comm** out);
 int gs_comm_create_null(int rank, int world, gs_comm** out);
+/* ipc transport: a one-shot peer-read all-reduce over arenas every rank maps from every other rank (hipIpc; xGMI peer access between
+   the GPUs of one node) for the sub-MB joins — one launch per exchange, no host round trip, ranks summed in ascending order on every
+   rank (bitwise equal replicas).  gs_comm_ipc_arena allocates THIS rank's arena on the current device (two slots of slot_bytes) and
+   returns the 64-byte handle the other ranks open it with; the host side gathers the handles of all ranks in rank order
+   ([world][64], e.g. torch.distributed.all_gather_object) and calls gs_comm_create_ipc (world <= 16), which takes ownership of the
+   arena.  Exchanges larger than slot_bytes go to `fallback` (an RCCL / callback communicator, may be NULL: GS_ERR_UNSUPPORTED then).
+   gs_comm_ipc_error: 0, or r + 1 when a wait for rank r's flag timed out (~2 s: that exchange's sums are wrong, nothing hangs). */
+int gs_comm_ipc_arena(size_t slot_bytes, void** arena, void* handle64);
+int gs_comm_create_ipc(void* arena, const void* handles, size_t slot_bytes, int rank, int world, gs_comm* fallback, gs_comm** out);
+int gs_comm_ipc_error(gs_comm* c, int* code);
 void gs_comm_destroy(gs_comm* c);
 int gs_comm_rank(const gs_comm* c);
 int gs_comm_world(const gs_comm* c);

@@ -17,6 +17,43 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def ipc_transport_checks(rank, world, local):
+    """The one-shot peer-read all-reduce by itself (gs_comm_create_ipc): sizes from one element to the largest join of the headline
+    iteration, fp32 and fp64, odd counts (scalar tails), many exchanges back to back on one stream (slot parity, flag sequence), sums
+    checked against the closed form, every rank's result bitwise the same; an exchange beyond the slots goes to the fallback."""
+    from graphslim_amd.parallel import Comm
+    dev = f"cuda:{local}"
+    ok = True
+    base = Comm.callback(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), rank, world)
+    comm = Comm.ipc(dist, None, slot_bytes=1_100_000, fallback=base)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for rep in range(3):
+        for n, dt in ((1, torch.float32), (5, torch.float32), (1000, torch.float32), (264_000 + rep, torch.float32), (512, torch.float64),
+                      (3, torch.float64), (137_001, torch.float64)):
+            parts = [torch.randn(n, generator=g, dtype=dt) for _ in range(world)]      # same draws on every rank
+            want = parts[0].clone()
+            for q in parts[1:]:
+                want += q                                                               # rank order, like the kernel
+            t = parts[rank].to(dev)
+            comm.allreduce(t, tag=2)
+            torch.cuda.synchronize()
+            if not torch.equal(t.cpu(), want):
+                print(f"rank {rank}: ipc all-reduce of {n} x {dt} differs: max {float((t.cpu() - want).abs().max())}")
+                ok = False
+    big = torch.full((400_000,), float(rank + 1), device=dev)      # 1.6 MB > the slots: the fallback carries it
+    comm.allreduce(big, tag=5)
+    torch.cuda.synchronize()
+    if not torch.equal(big.cpu(), torch.full((400_000,), world * (world + 1) / 2.0)):
+        print(f"rank {rank}: the fallback exchange is wrong")
+        ok = False
+    if comm.ipc_error() != 0:
+        print(f"rank {rank}: ipc exchange timed out waiting for rank {comm.ipc_error() - 1}")
+        ok = False
+    dist.barrier()
+    del comm
+    return ok
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))
@@ -43,10 +80,15 @@ def main():
         eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
         return eng
 
+    ok = True
+    if os.environ.get("GS_COMM_TRANSPORT") == "ipc":
+        ok = ipc_transport_checks(rank, world, local) and ok
     eng = build()
     sh = ShardedGCond(eng, rank, world, [len(q) for q in p["pools"]], Collective(dist))
+    if os.environ.get("GS_COMM_TRANSPORT") == "ipc" and sh.comm.kind != "ipc":
+        print(f"rank {rank}: GS_COMM_TRANSPORT=ipc but the engine's transport is {sh.comm.kind}")
+        ok = False
     ref = build() if rank == 0 else None
-    ok = True
     for epoch in (0, 10):
         eng.set_model(p["theta"])
         if ref is not None:
@@ -60,6 +102,9 @@ def main():
                     print(f"rank 0: loss mismatch {l1} vs {l0}")
                     ok = False
     torch.cuda.synchronize()
+    if sh.comm.kind == "ipc" and sh.comm.ipc_error() != 0:
+        print(f"rank {rank}: an ipc exchange of the sharded run timed out waiting for rank {sh.comm.ipc_error() - 1}")
+        ok = False
     if ref is not None:
         for name, a, b, tol in (("feat_syn", eng.feat_syn, ref.feat_syn, 2e-4), ("adj_syn", eng.adj_syn, ref.adj_syn, 2e-4),
                                 ("model", eng.model_params, ref.model_params, 5e-4)):

@@ -813,7 +813,7 @@ def test_balanced_edge_slabs_give_the_fixed_slab_gradients(mode):
             assert ((slabs - 1) * chunk < n1 * f2).all() and (slabs * chunk >= n1 * f2).all()      # a partition: no empty slab, nothing left out
             assert 0.8 * target <= base[-1] <= target + Cl, base[-1]                           # (d = 128: one feature tile)
             per = chunk // 16
-            assert per.max() <= -(-steps.sum() // base[-1]) + 1, (per, steps.sum())            # every workgroup runs ~ total / slabs steps
+            assert per.max() <= 1.25 * steps.sum() / base[-1] + 1, (per, steps.sum())          # every workgroup runs ~ total / slabs steps (rounded up per class)
     finally:
         _lib.check(L.gs_gcond_set_knob(eng.h, KNOB, -1))
 

@@ -52,8 +52,15 @@ if os.environ.get("GS_CHAINED") is not None:      # 0: the batched per-class pro
 print(f"workload {name}, operand mode {eng.operand_mode}")
 bench.init_state(p, eng)
 bench.new_model(p, eng)
+step = eng.outer_step
+if os.environ.get("GS_SHARD"):      # "rank,world[,layout]": the stages of ONE virtual rank of a sharded run (no exchange): the Amdahl table
+    from graphslim_amd.parallel import Comm, ShardedGCond
+    v = os.environ["GS_SHARD"].split(",")
+    sh = ShardedGCond(eng, int(v[0]), int(v[1]), [len(q) for q in p["pools"]], comm=Comm.null(int(v[0]), int(v[1])), pge=v[2] if len(v) > 2 else None)
+    step = sh.outer_step
+    print(f"virtual rank {v[0]} of {v[1]} ({sh.pge} layout): classes {sh.class_ranges[int(v[0])]}, pair rows {sh.row_ranges[int(v[0])]}")
 for _ in range(3):
-    eng.outer_step(10)
+    step(10)
 torch.cuda.synchronize()
 
 
@@ -87,12 +94,12 @@ for label, fn in stages:
         tot += us
     print(f"{label:52s} {us:8.1f} us")
 print(f"sum of the feature-epoch stages (no overlap, sampling excluded): {tot:.1f} us")
-it = timed(lambda: eng.outer_step(10), 40)
+it = timed(lambda: step(10), 40)
 print(f"outer_step (feature epoch, two streams + prefetched sampling): {it:.1f} us")
-it0 = timed(lambda: eng.outer_step(0), 40)
+it0 = timed(lambda: step(0), 40)
 print(f"outer_step (PGE epoch, two streams + prefetched sampling): {it0:.1f} us")
 eng.set_forward_reuse(True)      # what GCond.reduce runs: the training forward adopted from the previous iteration's inference forward
-itr = timed(lambda: eng.outer_step(10), 40)
-itr0 = timed(lambda: eng.outer_step(0), 40)
+itr = timed(lambda: step(10), 40)
+itr0 = timed(lambda: step(0), 40)
 eng.set_forward_reuse(False)
 print(f"outer_step with forward reuse (feature epoch / PGE epoch): {itr:.1f} / {itr0:.1f} us")
