@@ -44,11 +44,11 @@ class _GradMatch(GCondBase):
             raise NotImplementedError("graphslim_amd: with_bn with condense_model = 'GCN' has no reference behaviour to match — upstream's "
                                       "train_class raises RuntimeError ('running_mean should contain n' elements not hidden', "
                                       "models/base.py:65 on the 3-D output of layers.py:41-47); with_bn is built for SGC")
-        if with_bn and not (args.condense_model == "SGC" and args.ntrans == 2 and args.dis_metric == "ours"):
+        if with_bn and not (args.condense_model == "SGC" and args.ntrans == 2):
             # models/sgc.py:27-33 puts BatchNorm layers between transforms only (ntrans >= 2); built for the shipped depth.  Their
-            # weight / bias are 1-D parameters: distance 0 under 'ours' (utils.py:98-101), but part of the mse / cos distances,
-            # whose second-order terms are not built.
-            raise NotImplementedError("graphslim_amd: with_bn is built for condense_model SGC with ntrans = 2 and dis_metric 'ours'")
+            # weight / bias are 1-D parameters: distance 0 under 'ours' (utils.py:98-101), part of the mse / cos distances (round 5:
+            # the engine maps the folded model's gradients onto the true parameters for those, goldens G16 / G23).
+            raise NotImplementedError("graphslim_amd: with_bn is built for condense_model SGC with ntrans = 2")
         if float(getattr(args, "dropout", 0.0) or 0.0) != 0.0 and not (args.condense_model == "SGC" and args.ntrans == 1):
             # models/sgc.py:38-43 and models/base.py:51-78 apply F.dropout(training=True) after every transform BUT THE LAST, inside
             # train_class and the inner loop.  With SGC and one transform there is no such layer: the value is accepted and — exactly as

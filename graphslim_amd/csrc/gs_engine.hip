@@ -160,7 +160,7 @@ struct gs_gcond {
   int operand_mode;
   float *bsplit_main, *bsplit_aux;   // pre-split B operands (bf16 hi | lo) of the products on the main / the real-side stream
   int bn2_slices, l3_slices;         // slices of e->sums2 the consumer of a deferred last reduction stage adds up (1: e->sums is final)
-  // with_bn (SGC, ntrans = 2, 'ours'): theta = [W1, b1, W2, b2, bn.weight, bn.bias]; every stage reads the FOLDED parameters
+  // with_bn (SGC, ntrans = 2): theta = [W1, b1, W2, b2, bn.weight, bn.bias]; every stage reads the FOLDED parameters
   // theta_eff = [W1 diag(s), b1 s + bn.bias, W2, b2] (gs_bn_fold_kernel), refreshed whenever theta changes
   // full-neighbour mode (SGC, ntrans = 1; gs_gcond_set_full_neighbour): S_full = A^ A^ X and rs_full = A^ A^ 1 of the whole graph,
   // computed once by the caller (X never changes): the real-side class gradient needs their seed rows only
@@ -168,6 +168,7 @@ struct gs_gcond {
   bool with_bn;
   long og, obeta, P_base;            // offsets of bn.weight / bn.bias inside theta; parameter count without them
   float *theta_eff, *bn_s2;          // [P], [h]: s_j^2 for the distance statistics of the W1 gradient columns
+  float *gw_true_r, *gw_true_s;      // [C][P] each (with_bn under 'mse' / 'cos'): the class gradients mapped to the TRUE parameters
   float* a1_tab;                     // [Ph][8] layer-0 bias / BatchNorm-1 constants of the generated A1 operand and mask (gs_panel.hip)
   float* UsVs;                       // [2][n][Ph] folded layer-1 terms Us = s U + t, Vs = s V of the CURRENT forward (gs_pge_scale_uv): A1 = max(Us[c] + Vs[r], 0)
   bool uvs_valid;
@@ -320,6 +321,9 @@ static size_t carve(gs_gcond* e, void* base) {
   e->probe_span = w.take<unsigned long long>(2 * 256);
   e->theta_eff = e->with_bn ? w.take<float>(P) : nullptr;
   e->bn_s2 = e->with_bn ? w.take<float>(h) : nullptr;
+  const bool bn_true = e->with_bn && e->cfg.dis_metric != 0;
+  e->gw_true_r = bn_true ? w.take<float>(C * P) : nullptr;
+  e->gw_true_s = bn_true ? w.take<float>(C * P) : nullptr;
   e->gen_tab = w.take<float>(Ph * 8);
   e->a1_tab = w.take<float>(Ph * 8);
   e->UsVs = w.take<float>(2 * n * Ph);
@@ -372,9 +376,9 @@ static int check_cfg(const gs_gcond_config* c) {
   if (c->bcap < 1 || c->bcap > 256 || c->f1 < 1 || c->f1 > 16 || c->f2 < 1 || c->f2 > 16)
     GS_FAIL(GS_ERR_ARG, "gs_gcond: bcap in [1,256], fan-outs in [1,16]");
   if (c->dis_metric < 0 || c->dis_metric > 2) GS_FAIL(GS_ERR_ARG, "DC error: unknown distance function");
-  if (c->with_bn && (c->condense_model != 0 || c->ntrans != 2 || c->dis_metric != 0))
-    GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: with_bn is built for condense_model SGC with ntrans = 2 and dis_metric 'ours' (the BatchNorm "
-                                "weight / bias are 1-D parameters: distance 0 there; mse / cos would need their second-order terms)");
+  if (c->with_bn && (c->condense_model != 0 || c->ntrans != 2))
+    GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: with_bn is built for condense_model SGC with ntrans = 2 (models/sgc.py:27-33 puts BatchNorm "
+                                "layers between transforms only; GCN + with_bn raises upstream, golden G22)");
   if (c->inner_loop < 0) GS_FAIL(GS_ERR_ARG, "gs_gcond: negative inner_loop");
   return GS_OK;
 }
@@ -1442,13 +1446,34 @@ extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_
 
 // match_loss of this rank's Cl classes and D = d loss / d gw_syn (condensation/utils.py:12-106): one launch (a workgroup per class)
 // when the chains are fused and the per-class statistics row fits its LDS image, else statistics / finalize / apply
+static int match_distance_folded(gs_gcond* e, const float* gwr, const float* gws, float* stats, float* ab, float* Dv, int Cl, const float* s2,
+                                 hipStream_t s);
 static int match_distance(gs_gcond* e, const float* gwr, const float* gws, float* stats, float* ab, float* Dv, int Cl, hipStream_t s) {
+  if (Cl <= 0) { e->dist_shares = 0; return GS_OK; }
+  if (!(e->with_bn && e->cfg.dis_metric != 0)) return match_distance_folded(e, gwr, gws, stats, ab, Dv, Cl, e->bn_s2, s);
+  // with_bn under 'mse' / 'cos': the distance runs on the gradients of the TRUE parameters (BatchNorm weight / bias included), then
+  // D is mapped back onto the folded model (gs_kernels.h: gs_bn_unfold_class_grads_kernel / gs_bn_fold_class_D_kernel)
+  const long P = e->P, c0 = e->c_lo;
+  const float* th = e->io.model_params;
+  float* tr = e->gw_true_r + c0 * P; float* ts = e->gw_true_s + c0 * P;
+  const dim3 grid(gs_cdiv(e->h, 32), Cl), block(256);
+  hipLaunchKernelGGL(gs_bn_unfold_class_grads_kernel, grid, block, 0, s, gwr, P, th, tr, P, e->d, e->h, e->oW1, e->ob1, e->og, e->obeta, e->P_base);
+  hipLaunchKernelGGL(gs_bn_unfold_class_grads_kernel, grid, block, 0, s, gws, P, th, ts, P, e->d, e->h, e->oW1, e->ob1, e->og, e->obeta, e->P_base);
+  GS_LAUNCH_CHECK();
+  GS_TRY(match_distance_folded(e, tr, ts, stats, ab, Dv, Cl, nullptr, s));
+  hipLaunchKernelGGL(gs_bn_fold_class_D_kernel, grid, block, 0, s, Dv, P, th, e->d, e->h, e->oW1, e->ob1, e->og, e->obeta);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
+static int match_distance_folded(gs_gcond* e, const float* gwr, const float* gws, float* stats, float* ab, float* Dv, int Cl, const float* s2,
+                                 hipStream_t s) {
   const long P = e->P, c0 = e->c_lo;
   if (Cl <= 0) return GS_OK;
   if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && e->pd.total_cols <= GS_DIST_FUSED_COLS) {
     const int G = e->cfg.dis_metric == 2 || e->pd.nparams < 2 ? 1 : GS_DIST_SPLIT;      // ('cos' couples all columns of a class)
     hipLaunchKernelGGL(gs_dist_fused_kernel, dim3(Cl, G), dim3(1024), 0, s, gwr, gws, P, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
-                       e->io.syn_hi + c0, e->n, ab, e->loss_c + c0, Dv, (const float*)e->bn_s2, e->dist_part + c0 * GS_DIST_SPLIT);
+                       e->io.syn_hi + c0, e->n, ab, e->loss_c + c0, Dv, s2, e->dist_part + c0 * GS_DIST_SPLIT);
     e->dist_shares = G > 1 ? G : 0;      // (the V kernel of this stage call finishes loss_c from the shares)
     GS_LAUNCH_CHECK();
     return GS_OK;
@@ -1456,7 +1481,7 @@ static int match_distance(gs_gcond* e, const float* gwr, const float* gws, float
   e->dist_shares = 0;
   hipLaunchKernelGGL(gs_dist_stats_kernel, dim3(e->pd.nparams, Cl), dim3(256), 0, s, gwr, gws, P, e->pd, stats);
   hipLaunchKernelGGL(gs_dist_finalize_kernel, dim3(Cl), dim3(256), 0, s, stats, e->pd, e->cfg.dis_metric, e->io.syn_lo + c0,
-                     e->io.syn_hi + c0, e->n, ab, e->loss_c + c0, (const float*)e->bn_s2);
+                     e->io.syn_hi + c0, e->n, ab, e->loss_c + c0, s2);
   hipLaunchKernelGGL(gs_dist_apply_kernel, dim3(gs_cdiv((long)Cl * P, 256)), dim3(256), 0, s, gwr, gws, P, e->pd, ab, Dv, Cl);
   GS_LAUNCH_CHECK();
   return GS_OK;

@@ -736,6 +736,59 @@ __global__ void gs_bn_fold_kernel(const float* __restrict__ theta, int d, int h,
   theta_eff[idx] = v;
 }
 
+// with_bn under dis_metric 'mse' / 'cos' (round 5; condensation/utils.py:41-60: both metrics run over EVERY parameter, the 1-D BatchNorm
+// weight / bias included): the per-class gradients of the FOLDED model [W1', b1', W2, b2] (what the real side and the synthetic side
+// compute) are mapped to the gradients of the true parameters [W1, b1, W2, b2, bn.weight, bn.bias] before the distance,
+//     tW1[:, j] = gW1'[:, j] s_j ;  tb1_j = gb1'_j s_j ;  t bn.bias_j = gb1'_j ;  t bn.weight_j = (sum_i gW1'_ij W1_ij + gb1'_j b1_j) rs,
+// with s_j = bn.weight_j rs, rs = 1 / sqrt(1 + eps) — a LINEAR map J(theta) of the folded gradient, the same for the real and the
+// synthetic side.  The distance then yields D_t = d loss / d t_syn, and gs_bn_fold_class_D_kernel applies J^T:
+//     D_W1'[i][j] = D_tW1[i][j] s_j + W1[i][j] D_tg[j] rs ;  D_b1'[j] = D_tb1[j] s_j + b1[j] D_tg[j] rs + D_tbeta[j]
+// so that the second-order chain behind it runs on the folded model unchanged.  Grid (ceil(h / 32), classes), 256 threads.
+__global__ __launch_bounds__(256) void gs_bn_unfold_class_grads_kernel(const float* __restrict__ g, long sg, const float* __restrict__ theta,
+                                                                       float* __restrict__ t, long st, int d, int h, long oW1, long ob1,
+                                                                       long og, long obeta, long P_base) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + tx;
+  const float rs = 1.f / sqrtf(1.f + 1e-5f);
+  const float* gc = g + (long)blockIdx.y * sg;
+  float* tc = t + (long)blockIdx.y * st;
+  __shared__ double sh[8][32];
+  double acc = 0.0;
+  const float sj = j < h ? theta[og + j] * rs : 0.f;
+  if (j < h)
+    for (int i = ty; i < d; i += 8) {
+      const float gw = gc[oW1 + (long)i * h + j];
+      tc[oW1 + (long)i * h + j] = gw * sj;
+      acc += (double)gw * (double)theta[oW1 + (long)i * h + j];
+    }
+  sh[ty][tx] = acc;
+  __syncthreads();
+  if (j < h && ty == 0) {
+    double tot = 0.0;
+    for (int q = 0; q < 8; ++q) tot += sh[q][tx];
+    const float gb = gc[ob1 + j];
+    tc[ob1 + j] = gb * sj;
+    tc[obeta + j] = gb;
+    tc[og + j] = (float)((tot + (double)gb * (double)theta[ob1 + j]) * (double)rs);
+  }
+  // the other parameters (W2, b2: everything of the folded model outside W1 | b1) are the same in both models
+  if (blockIdx.x == 0)
+    for (long k = threadIdx.x; k < P_base; k += 256)
+      if (!(k >= oW1 && k < oW1 + (long)d * h) && !(k >= ob1 && k < ob1 + h)) tc[k] = gc[k];
+}
+
+__global__ __launch_bounds__(256) void gs_bn_fold_class_D_kernel(float* __restrict__ D, long sD, const float* __restrict__ theta, int d, int h,
+                                                                 long oW1, long ob1, long og, long obeta) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + tx;
+  if (j >= h) return;
+  const float rs = 1.f / sqrtf(1.f + 1e-5f);
+  float* Dc = D + (long)blockIdx.y * sD;
+  const float sj = theta[og + j] * rs, dg = Dc[og + j] * rs;
+  for (int i = ty; i < d; i += 8) Dc[oW1 + (long)i * h + j] = fmaf(Dc[oW1 + (long)i * h + j], sj, theta[oW1 + (long)i * h + j] * dg);
+  if (ty == 0) Dc[ob1 + j] = fmaf(Dc[ob1 + j], sj, fmaf(theta[ob1 + j], dg, Dc[obeta + j]));
+}
+
 // inner-step gradients of the folded model -> gradients of the true parameters (in place on g; g has room for bn.weight / bn.bias):
 //   gW1[:, j] = gW1'[:, j] s_j ; gb1_j = gb1'_j s_j ; g bn.bias_j = gb1'_j ;
 //   g bn.weight_j = sum_i dpre'_ij pre_ij / sqrt(1 + eps),  pre = X W1 + b1 with the TRUE W1, b1

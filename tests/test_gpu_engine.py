@@ -84,21 +84,24 @@ def test_train_class_against_reference_golden(golden_dir, tag, metric):
         o += k
 
 
-def test_with_bn_against_reference_golden(golden_dir):
-    """G16 (gcond_base.py:261-285 check_bn, models/sgc.py:27-33): SGC with an eval-mode BatchNorm1d between its two transforms,
-    bn.weight / bn.bias away from (1, 0).  The engine folds the affine map into the first transform (gs_bn_fold_kernel), prices
-    the W1 gradient columns at their true scale in the distance statistics, and un-folds the inner-step gradients: real-side
-    gradients, loss, d loss / d A^, d loss / d X~, d loss / d theta_PGE and the parameters after two inner steps of the reference."""
+@pytest.mark.parametrize("fname,tag,metric", [("g16_with_bn", "bn", "ours"), ("g23_with_bn_mse_cos", "bn_mse", "mse"),
+                                               ("g23_with_bn_mse_cos", "bn_cos", "cos")])
+def test_with_bn_against_reference_golden(golden_dir, fname, tag, metric):
+    """G16 / G23 (gcond_base.py:261-285 check_bn, models/sgc.py:27-33): SGC with an eval-mode BatchNorm1d between its two transforms,
+    bn.weight / bn.bias away from (1, 0).  The engine folds the affine map into the first transform (gs_bn_fold_kernel) and un-folds
+    the inner-step gradients; under 'ours' (G16) it prices the W1 gradient columns at their true scale in the distance statistics,
+    under 'mse' / 'cos' (G23, round 5: the 1-D BatchNorm parameters are part of those distances, condensation/utils.py:41-60) it maps
+    the class gradients onto the true parameters before the distance and D back onto the folded model: real-side gradients, loss,
+    d loss / d A^, d loss / d X~, d loss / d theta_PGE and the parameters after two inner steps of the reference."""
     from graphslim_amd.engine import BlockSet
-    g = load_golden(golden_dir, "g16_with_bn")
-    tag = "bn"
+    g = load_golden(golden_dir, fname)
     batches, (n, nclass, d, hidden, t), _ = rebuild_batches(g, tag)
     labels_syn = g[f"{tag}_labels_syn"]
     _, ncd, ranges = O.generate_labels_syn(g[f"{tag}_y"][g[f"{tag}_idx_train"]], float(g[f"{tag}_rate"]))
     ranges = [tuple(ranges[c]) for c in range(nclass)]
     ph = g[f"{tag}_pge2"].shape[0]
     f1, f2 = [int(s) for s in g[f"{tag}_sizes"]]
-    eng = make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, with_bn=True, inner=2)
+    eng = make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, with_bn=True, inner=2, metric=metric)
     eng.set_feat(T(g[f"{tag}_feat_syn"]))
     eng.set_pge([T(g[f"{tag}_pge{i}"]) for i in range(10)])
     theta = [T(g[f"{tag}_theta{i}"]) for i in range(6)]
@@ -127,9 +130,9 @@ def test_with_bn_against_reference_golden(golden_dir):
     close(eng.adj_syn.cpu(), g[f"{tag}_adj_inner"], 2e-5, "inference adjacency")
     for i, q in enumerate(eng.get_model()):
         close(q.cpu(), g[f"{tag}_theta_after{i}"], 2e-3, f"theta[{i}] after two inner steps")
-    # mse / cos would need the second-order terms of the 1-D BatchNorm parameters: refused, not silently wrong
+    # BatchNorm layers exist between transforms only (models/sgc.py:27-33): one transform has none — refused, not silently ignored
     with pytest.raises(RuntimeError):
-        make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, with_bn=True, metric="mse")
+        make_engine(n, nclass, d, hidden, 1, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, with_bn=True, metric=metric)
 
 
 def _problem(t, seed, n=400, nclass=5, d=12, hidden=24, ph=16, rate=0.25, f1=4, f2=3, bcap=16):
@@ -811,7 +814,7 @@ def test_balanced_edge_slabs_give_the_fixed_slab_gradients(mode):
             slabs = np.diff(base)
             assert base[0] == 0 and (slabs >= 1).all() and (chunk % 16 == 0).all()
             assert ((slabs - 1) * chunk < n1 * f2).all() and (slabs * chunk >= n1 * f2).all()      # a partition: no empty slab, nothing left out
-            assert 0.8 * target <= base[-1] <= target + Cl, base[-1]                           # (d = 128: one feature tile)
+            assert 0.7 * min(target, steps.sum()) <= base[-1] <= target + Cl, (base[-1], steps.sum())      # (d = 128: one feature tile; a slab is >= one step)
             per = chunk // 16
             assert per.max() <= 1.25 * steps.sum() / base[-1] + 1, (per, steps.sum())          # every workgroup runs ~ total / slabs steps (rounded up per class)
     finally:

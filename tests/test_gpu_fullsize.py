@@ -33,7 +33,30 @@ def rel_max(got, ref):
     return float((got - ref).abs().max() / (ref.abs().max() + 1e-300))
 
 
-def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged"):
+class _ReluTies:
+    """oracle.RELU_HOOK for the PGE's ReLUs: records the inputs within `tol` of zero (first training forward only) and, when `flip` names
+    some of them (layer, flat index), gates those elements the OTHER way (value x * gate, gradient gate — what an fp32 forward whose
+    sum lands on the other side of zero computes)."""
+
+    def __init__(self, tol=1e-6, flip=()):
+        self.tol, self.flip, self.found, self.calls = tol, set(flip), [], {}
+
+    def __call__(self, layer, e):
+        k = self.calls.get(layer, 0)
+        self.calls[layer] = k + 1
+        gate = (e > 0)
+        if k == 0:      # the training forward of the iteration (the later calls are the inference pass after the update)
+            near = torch.nonzero(e.detach().abs().reshape(-1) < self.tol).reshape(-1).tolist()
+            self.found += [(layer, i) for i in near]
+            idx = [i for (ly, i) in self.flip if ly == layer]
+            if idx:
+                gate = gate.clone().reshape(-1)
+                gate[idx] = ~gate[idx]
+                gate = gate.reshape(e.shape)
+        return e * gate.to(e.dtype)
+
+
+def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", relu_flip=None):
     """driver: "staged" = the stage entry points one by one; "fused" = ONE gs_gcond_outer_step call (what bench.py times: two
     streams, blocks sampled inside the call); "fused_reuse" = the same with forward reuse on, compared on the SECOND call (the
     one that adopts the cached inference forward of the first)."""
@@ -79,8 +102,14 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged"):
     st = O.GCondState(xs0, {"lin": pge0[:6], "bn": pge0[6:]}, torch.from_numpy(p["labels_syn"]), p["ncd"], p["data"].nclass,
                       p["lrf"], p["lra"], 0.01, "SGC", 2)
     st.new_epoch([t.clone() for t in theta])
-    ref_loss, ref_gfeat, ref_gpge, _ = st.outer_iteration(epoch, batches, p["data"].bench_feat, p["data"].bench_labels, 0)
-    out = dict(loss=loss, ref_loss=float(ref_loss), rel_loss=abs(loss - float(ref_loss)) / abs(float(ref_loss)),
+    hook = None
+    if relu_flip is not None:
+        hook = O.RELU_HOOK = _ReluTies(flip=relu_flip)
+    try:
+        ref_loss, ref_gfeat, ref_gpge, _ = st.outer_iteration(epoch, batches, p["data"].bench_feat, p["data"].bench_labels, 0)
+    finally:
+        O.RELU_HOOK = None
+    out = dict(relu_ties=hook.found if hook else None, loss=loss, ref_loss=float(ref_loss), rel_loss=abs(loss - float(ref_loss)) / abs(float(ref_loss)),
                g_feat=rel_max(g_feat, ref_gfeat), g_pge=[], n=n, name=name, epoch=epoch)
     o = 0
     for i, (shp, ref) in enumerate(zip(eng.pge_shapes(), ref_gpge)):
@@ -175,20 +204,29 @@ def test_flickr_r0005_inductive_two_transforms_full_size():
 def test_cora_r05_full_size():
     """BASELINE configs[0]'s workload (Cora, r = 0.5 -> n' = 70) on the GPU path, feature- and PGE-update iterations.
 
-    Strict gates on the fp32 pipe (the reference's arithmetic).  In the default operand form (exact three-way split) the forward is
-    fp32-accurate too (E2 within 6e-7 of the fp32 product's), but ONE of the 627 200 inputs of the PGE's second ReLU lies 3.3e-7
-    from zero and lands on the other side (profiles/r04/cora_r05_panel_vs_general_single_relu_flip.txt: dE2 differs by 2e-6 on that
-    element and by 4e-10 elsewhere).  With only n'^2 = 4 900 pair rows one flipped element is 1.4e-3 of max |dW1| — a property of the
-    ReLU at a rounding-distance tie, not of the operand form — so the gradient gates of that run are 1e-2; loss, structure and the
-    Adam step keep their gates."""
+    Strict gates (1e-3 on every gradient) on the fp32 pipe AND in the default operand form (exact three-way split).  One of the
+    627 200 inputs of the PGE's second ReLU lies 3.3e-7 from zero here — a tie at rounding distance that two fp32 forwards with
+    different summation orders resolve differently (profiles/r04/cora_r05_panel_vs_general_single_relu_flip.txt: dE2 differs by 2e-6
+    on that element and by 4e-10 elsewhere; with only n'^2 = 4 900 pair rows one flipped gate is 1.4e-3 of max |dW1|).  Round 4 gated
+    that run at a blanket 1e-2; now (VERDICT r04 "next" 8) the oracle reports its ReLU inputs within 1e-6 of zero and the engine must
+    meet the STRICT gates against the oracle with those ties resolved one way or the other — nothing else is loosened."""
+    import itertools
     check(run_config("cora", 10, operand_mode="f32"))
     check(run_config("cora", 0, operand_mode="f32"))
     for epoch in (10, 0):
-        r = run_config("cora", epoch)
-        print(r)
-        assert r["rel_loss"] <= 1e-4 and r["g_feat"] <= 1e-3 and r["adj"] <= 2e-5 and r["model_bad_frac"] <= 1e-3, r
-        assert all(e <= 1e-2 for _, e in r["g_pge"]), r
-        assert r["upd_well_max"] <= 1e-2 and r["upd_any_frac"] <= 1e-2, r
+        r = run_config("cora", epoch, relu_flip=())
+        ties = r["relu_ties"]
+        print(f"cora r = 0.5, epoch {epoch}: ReLU inputs of the PGE within 1e-6 of zero in the oracle's forward: {ties}")
+        assert len(ties) <= 4, ties
+        ok = all(e <= 1e-3 for _, e in r["g_pge"])
+        for k in range(1, len(ties) + 1):
+            for flip in itertools.combinations(ties, k):
+                if ok:
+                    break
+                r = run_config("cora", epoch, relu_flip=flip)
+                ok = all(e <= 1e-3 for _, e in r["g_pge"])
+                print(f"   with the tie(s) {flip} resolved the other way: d theta_PGE errors {[round(e, 6) for _, e in r['g_pge']]}")
+        check(r)
 
 
 def test_cora_r025_full_size():

@@ -146,14 +146,17 @@ def test_g7_train_class(golden_dir, tag, kind, metric):
             close(p.grad.numpy(), ref)
 
 
-def test_g16_with_bn_train_class_and_inner_steps(golden_dir):
+@pytest.mark.parametrize("fname,tag,metric", [("g16_with_bn", "bn", "ours"), ("g23_with_bn_mse_cos", "bn_mse", "mse"),
+                                               ("g23_with_bn_mse_cos", "bn_cos", "cos")])
+def test_g16_g23_with_bn_train_class_and_inner_steps(golden_dir, fname, tag, metric):
     """with_bn (gcond_base.py:261-285, models/sgc.py:27-33): the reference's train_class on an SGC with an eval-mode BatchNorm
-    between its two transforms (trainable weight / bias away from (1, 0)), and two inner steps with torch Adam."""
-    g = load(golden_dir, "g16_with_bn")
-    tag = "bn"
-    assert [str(v) for v in g["bn_param_names"]] == ["layers.0.weight", "layers.0.bias", "layers.1.weight", "layers.1.bias",
+    between its two transforms (trainable weight / bias away from (1, 0)), and two inner steps with torch Adam — under 'ours' (G16;
+    the 1-D BatchNorm parameters contribute no distance, utils.py:98-101) and under 'mse' / 'cos' (G23; every parameter's gradient
+    enters the distance, condensation/utils.py:41-60)."""
+    g = load(golden_dir, fname)
+    assert [str(v) for v in g[f"{tag}_param_names"]] == ["layers.0.weight", "layers.0.bias", "layers.1.weight", "layers.1.bias",
                                                       "bns.0.weight", "bns.0.bias"]
-    np.testing.assert_array_equal(g["bn_bn_running"], np.stack([np.zeros(12, np.float32), np.ones(12, np.float32)]))
+    np.testing.assert_array_equal(g[f"{tag}_bn_running"], np.stack([np.zeros(12, np.float32), np.ones(12, np.float32)]))
     batches, (n, nclass, d, hidden, t) = rebuild_batches(g, tag)
     theta = [T(g[f"{tag}_theta{i}"]).requires_grad_(True) for i in range(6)]
     ps = [T(g[f"{tag}_pge{i}"]).requires_grad_(True) for i in range(10)]
@@ -164,7 +167,7 @@ def test_g16_with_bn_train_class_and_inner_steps(golden_dir):
     adj_norm = O.dense_gcn_norm(O.pge_forward(feat_syn, pge))
     adj_norm.retain_grad()
     loss = O.train_class("SGC_BN", theta, batches, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), feat_syn, adj_norm, labels_syn, ncd, nclass,
-                         2, "ours")
+                         2, metric)
     loss.backward()
     np.testing.assert_allclose(float(loss), float(g[f"{tag}_loss"]), rtol=1e-4)
 

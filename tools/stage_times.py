@@ -75,16 +75,28 @@ def timed(fn, reps=30):
     return (time.perf_counter() - t0) / reps * 1e6
 
 
+def fwd(inference):      # (a pair-row shard runs the forward / backward in three parts, with an exchange between them in a real run)
+    if os.environ.get("GS_SHARD"):
+        return lambda: [eng.pge_forward_part(inference, k) for k in (1, 2, 3)]
+    return lambda: eng.stage_pge_forward(inference)
+
+
+def bwd(param_grads):
+    if os.environ.get("GS_SHARD"):
+        return lambda: [eng.pge_backward_part(param_grads, True, k) for k in (1, 2, 3)]
+    return lambda: eng.stage_pge_backward(param_grads, True)
+
+
 stages = [
     ("sample (next blocks)", eng.stage_sample),
     ("real-side gradients", eng.stage_real_grads),
-    ("PGE forward (training)", lambda: eng.stage_pge_forward(False)),
+    ("PGE forward (training)", fwd(False)),
     ("synthetic match (fwd + class terms + 2nd-order bwd)", eng.stage_syn_match),
     ("loss bookkeeping", eng.syn_finish),
-    ("PGE backward (feature epoch)", lambda: eng.stage_pge_backward(False, True)),
-    ("PGE backward (PGE epoch)", lambda: eng.stage_pge_backward(True, True)),
+    ("PGE backward (feature epoch)", bwd(False)),
+    ("PGE backward (PGE epoch)", bwd(True)),
     ("Adam (feature epoch)", lambda: eng.stage_update(10)),
-    ("PGE forward (inference)", lambda: eng.stage_pge_forward(True)),
+    ("PGE forward (inference)", fwd(True)),
     ("inner SGC steps", eng.inner_steps),
 ]
 tot = 0.0
