@@ -33,7 +33,8 @@ class GemmDesc(C.Structure):
 class Blocks(C.Structure):
     _fields_ = [("C", C.c_int), ("bcap", C.c_int), ("f1", C.c_int), ("f2", C.c_int), ("cap1", C.c_int),
                 ("n_seed", vp), ("n1", vp), ("nid1", vp), ("col1", vp), ("val1", vp), ("tptr1", vp), ("tedge1", vp),
-                ("col0", vp), ("val0", vp)]
+                ("col0", vp), ("val0", vp), ("nmid", C.c_int), ("fm", C.c_int * 3), ("capm", C.c_int * 3), ("nm", vp * 3), ("nidm", vp * 3),
+                ("colm", vp * 3), ("valm", vp * 3), ("tptrm", vp * 3), ("tedgem", vp * 3), ("scrm", vp * 3)]
 
 
 class GCondConfig(C.Structure):
@@ -41,7 +42,8 @@ class GCondConfig(C.Structure):
                 ("ntrans", C.c_int), ("hidden", C.c_int), ("pge_hidden", C.c_int), ("bcap", C.c_int), ("f1", C.c_int),
                 ("f2", C.c_int), ("dis_metric", C.c_int), ("inner_loop", C.c_int),
                 ("lr_feat", C.c_float), ("lr_adj", C.c_float), ("lr_model", C.c_float), ("seed", C.c_uint64),
-                ("external_blocks", C.c_int), ("condense_model", C.c_int), ("pge_chunks", C.c_int), ("with_bn", C.c_int)]
+                ("external_blocks", C.c_int), ("condense_model", C.c_int), ("pge_chunks", C.c_int), ("with_bn", C.c_int),
+                ("nlayers", C.c_int), ("fmid", C.c_int * 3)]
 
 
 class GCondIO(C.Structure):

@@ -35,8 +35,18 @@ class _GradMatch(GCondBase):
         if args.condense_model not in ("SGC", "GCN"):
             raise NotImplementedError(f"graphslim_amd: condense_model must be SGC or GCN (got {args.condense_model})")
         depth = 2 if args.condense_model == "GCN" else args.ntrans      # models/gcn.py:8-23 vs models/sgc.py:16-35
-        if args.nlayers != 2:
-            raise NotImplementedError("graphslim_amd: nlayers (propagations) must be 2")
+        # `--nlayers` K (models/sgc.py:45-51 propagates K times; dataset/loader.py:197-210 samples K hops): 2 everywhere in the shipped
+        # configs; 3 .. 5 for SGC (goldens G24).  K = 1 has no reference behaviour to match: PyG's NeighborSampler.sample returns the
+        # single hop's Adj tuple itself instead of a list, and gcond_base.py:213 `[adj[0] for adj in adjs]` then indexes its
+        # e_id = None — TypeError in the first train_class call.
+        if args.nlayers == 1:
+            raise NotImplementedError("graphslim_amd: nlayers = 1 has no reference behaviour to match — upstream's train_class fails on the "
+                                      "single Adj tuple PyG's NeighborSampler returns for one hop (gcond_base.py:213)")
+        if args.nlayers not in (2, 3, 4, 5):
+            raise NotImplementedError(f"graphslim_amd: nlayers must be 2 .. 5 (dataset/loader.py:197-210 knows no other), got {args.nlayers}")
+        if args.nlayers != 2 and args.condense_model != "SGC":
+            raise NotImplementedError("graphslim_amd: nlayers != 2 is built for condense_model SGC (a K-layer GCN is another model: "
+                                      "models/gcn.py:8-23)")
         with_bn = bool(getattr(args, "with_bn", False))
         if with_bn and args.condense_model == "GCN":
             # no reference behaviour to match: in train_class the synthetic forward hands the DENSE adj_syn to GraphConvolution.forward,
@@ -64,11 +74,13 @@ class _GradMatch(GCondBase):
         feat_init = self.init()                                   # gcond.py:29 (np.random draws)
         csr = normalize_adj_sparse(adj)                           # gcond.py:33
         pools = data.class_pools(args.setting)
-        sizes = (15, 8) if args.dataset in ("reddit", "flickr") else (10, 5)     # loader.py:197-210
+        sizes = {2: (15, 8) if args.dataset in ("reddit", "flickr") else (10, 5), 3: (15, 10, 5), 4: (15, 10, 5, 5),
+                 5: (15, 10, 5, 5, 5)}[args.nlayers]                             # loader.py:197-210
         nclass = data.nclass
         ranges = [tuple(self.syn_class_indices.get(c, (0, 0))) for c in range(nclass)]
         shapes = EngineShapes(features.shape[0], self.d, nclass, self.nnodes_syn, depth, args.hidden, self.pge_hidden,
-                              256, sizes[0], sizes[1], model=args.condense_model, pge_chunks=self.pge_chunks, with_bn=with_bn)
+                              256, sizes[0], sizes[-1], model=args.condense_model, pge_chunks=self.pge_chunks, with_bn=with_bn,
+                              fmid=tuple(sizes[1:-1]))
         cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
         eng = self.engine = GCondEngine(shapes, features, csr, cls_ptr, np.concatenate(pools), labels_syn, ranges,
                                         lr_feat=args.lr_feat, lr_adj=args.lr_adj, lr_model=args.lr,
@@ -77,8 +89,8 @@ class _GradMatch(GCondBase):
         if getattr(args, "neighbour_mode", "sampled") == "full":
             # extension (SURVEY section 8e "mode F"; loader.py:204 keeps `sizes = [-1, -1]` commented out): exact 2-hop full
             # neighbourhoods for SGC with one transform — two row-sharded full-graph SpMMs once per job
-            if not (args.condense_model == "SGC" and args.ntrans == 1):
-                raise NotImplementedError("graphslim_amd: neighbour_mode = 'full' is built for condense_model SGC with ntrans = 1")
+            if not (args.condense_model == "SGC" and args.ntrans == 1 and args.nlayers == 2):
+                raise NotImplementedError("graphslim_amd: neighbour_mode = 'full' is built for condense_model SGC with ntrans = 1, nlayers = 2")
             from ..parallel import RowShard, active_dist
             from .full_neighbour import full_neighbour_operators
             S_full, rs_full, dt = full_neighbour_operators(csr, features, self.device, RowShard(active_dist()))

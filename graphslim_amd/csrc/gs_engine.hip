@@ -83,6 +83,9 @@ struct gs_gcond {
   int nsplit_r, kchunk_r, nsplit_w, kchunk_w, nblk_stats, rows_per_block;
   int edge_target, edge_cap;           // balanced slabs of the real-side edge product: slabs aimed at / slabs the buffer holds (gs_edge_plan)
   int* edge_plan;                      // [2 C + 1] device ints
+  int K, nmid, fmid[GS_MAX_MID], capm[GS_MAX_MID], capL;      // propagations (nlayers), middle hops, their fan-outs / frontier capacities, rows of the outermost block
+  float *Pmid[GS_MAX_MID], *rsmid[GS_MAX_MID], *Ymid[GS_MAX_MID];   // per middle hop m: the forward rows / row sums of frontier m - 1 ([C][cap(m-1)]), the backward rows of frontier m ([C][capm[m]][h])
+  float *Apow, *Apow_t;                // nlayers != 2: [K][n'^2] powers A^, A^^2, .. of the normalised structure (training / scratch)
   bool real_beside;                    // this real-side stage runs beside the training pass of the PGE forward (fused step, forward recomputed)
   // real side
   gs_blocks blk;
@@ -184,6 +187,14 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   e->cfg = c;
   e->N = c.n_nodes; e->d = c.d; e->ldx = c.ldx; e->C = c.nclass; e->n = c.n_syn; e->T = c.ntrans; e->h = c.hidden;
   e->Ph = c.pge_hidden; e->bcap = c.bcap; e->f1 = c.f1; e->f2 = c.f2; e->cap1 = c.bcap * (1 + c.f1);
+  e->K = c.nlayers > 0 ? c.nlayers : 2;
+  e->nmid = e->K > 2 ? e->K - 2 : 0;
+  e->capL = e->cap1;
+  for (int m = 0; m < GS_MAX_MID; ++m) {
+    e->fmid[m] = m < e->nmid ? c.fmid[m] : 0;
+    e->capm[m] = m < e->nmid ? e->capL * (1 + e->fmid[m]) : 0;
+    if (m < e->nmid) e->capL = e->capm[m];
+  }
   e->gcn = (c.condense_model == 1);
   e->pge_chunks = c.pge_chunks > 1 ? c.pge_chunks : 1;
   if (e->gcn) e->T = 2;                       // GCN: two GraphConvolution layers, same parameter layout as SGC T = 2
@@ -230,8 +241,9 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   // -12 us fp32 / -33 us bf16x3 per iteration against 512, half the slab traffic), else 512 (few classes: keep the slots
   // busy); 768 and 1 408 measured worse at arxiv (a part-filled second round / idle slots): 706 / 758 us for the real-side stage
   // against 670 (512) and 660 (1 024).
-  e->kchunk_r = (long)e->C * gs_cdiv((long)e->cap1 * e->f2, 1024) * gs_cdiv(e->d, 128) >= 400 ? 1024 : 512;
-  e->nsplit_r = gs_cdiv((long)e->cap1 * e->f2, e->kchunk_r);
+  e->kchunk_r = (long)e->C * gs_cdiv((long)e->capL * e->f2, 1024) * gs_cdiv(e->d, 128) >= 400 ? 1024 : 512;
+  if (e->nmid) e->kchunk_r = 1024 * (1 << (2 * e->nmid));      // (more hops: the edge lists grow ~16x per hop; the balanced plan carries them)
+  e->nsplit_r = gs_cdiv((long)e->capL * e->f2, e->kchunk_r);
   // balanced slabs (round 5, gs_edge.hip): the 512 resident workgroup slots (2 per compute unit) per 128-feature tile, cut over the
   // classes in proportion to their live edge counts on the device; the buffer holds `edge_cap` slabs (the plan uses <= target + C)
   e->edge_target = 512 / gs_cdiv(e->d, 128) > 0 ? 512 / gs_cdiv(e->d, 128) : 1;
@@ -253,21 +265,32 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
 static size_t carve(gs_gcond* e, void* base) {
   Carver w{(char*)base, 0};
   const long C = e->C, n = e->n, d = e->d, h = e->h, Ph = e->Ph, F = e->F, P = e->P, N = e->N;
-  const long bcap = e->bcap, cap1 = e->cap1, f1 = e->f1, f2 = e->f2, n2 = n * n;
+  const long bcap = e->bcap, cap1 = e->cap1, f1 = e->f1, f2 = e->f2, n2 = n * n, capL = e->capL;
   for (int q = 0; q < 2; ++q) {
     gs_blocks& b = e->blkbuf[q];
+    memset(&b, 0, sizeof(b));
     b.C = e->C; b.bcap = e->bcap; b.f1 = e->f1; b.f2 = e->f2; b.cap1 = e->cap1;
     b.n_seed = w.take<int>(C); b.n1 = w.take<int>(C); b.nid1 = w.take<int>(C * cap1);
     b.col1 = w.take<int>(C * bcap * f1); b.val1 = w.take<float>(C * bcap * f1);
     b.tptr1 = w.take<int>(C * (cap1 + 1)); b.tedge1 = w.take<int>(C * bcap * f1);
-    b.col0 = w.take<int>(C * cap1 * f2); b.val0 = w.take<float>(C * cap1 * f2);
+    b.nmid = e->nmid;
+    long capp = cap1;
+    for (int m = 0; m < e->nmid; ++m) {      // middle hops (nlayers >= 3)
+      const long fm = e->fmid[m], capc = e->capm[m];
+      b.fm[m] = (int)fm; b.capm[m] = (int)capc;
+      b.nm[m] = w.take<int>(C); b.nidm[m] = w.take<int>(C * capc);
+      b.colm[m] = w.take<int>(C * capp * fm); b.valm[m] = w.take<float>(C * capp * fm);
+      b.tptrm[m] = w.take<int>(C * (capc + 1)); b.tedgem[m] = w.take<int>(C * capp * fm); b.scrm[m] = w.take<int>(C * (capc + 1));
+      capp = capc;
+    }
+    b.col0 = w.take<int>(C * capL * f2); b.val0 = w.take<float>(C * capL * f2);
   }
   e->blk = e->blkbuf[0];
   e->marker = e->cfg.external_blocks ? nullptr : w.take<int>(C * N);
   e->kcount = w.take<int>(C);
   {
     // chunk counts of colsum_batched: <= 64 chunks of >= 8 rows, or rows/256 chunks
-    long nch_r = gs_cdiv(cap1 * f2, 256) > 72 ? gs_cdiv(cap1 * f2, 256) : 72;
+    long nch_r = gs_cdiv(capL * f2, 256) > 72 ? gs_cdiv(capL * f2, 256) : 72;
     long nch_s = gs_cdiv(n, 256) > 72 ? gs_cdiv(n, 256) : 72;
     e->colpart = w.take<float>(C * nch_s * (h > 0 ? h : 1));
     e->sum_part = w.take<double>(128);      // sum_f32's 128 partial sums (it used to borrow colpart, which tiny shapes undersize)
@@ -275,18 +298,31 @@ static size_t carve(gs_gcond* e, void* base) {
   }
   e->H1full = e->T == 2 ? w.take<float>(N * h) : nullptr;
   e->H1bits = (e->T == 2 && !e->gcn && h == 256) ? w.take<unsigned>(N * (h / 32)) : nullptr;
-  e->edge_bits = (e->T == 2 && !e->gcn && h == 256) ? w.take<unsigned>(C * cap1 * e->f2 * (h / 32)) : nullptr;
+  e->edge_bits = (e->T == 2 && !e->gcn && h == 256 && !e->nmid) ? w.take<unsigned>(C * cap1 * e->f2 * (h / 32)) : nullptr;
   if (e->T == 2 && !e->gcn) {
     e->h1_flag = w.take<int>(N); e->h1_list = w.take<int>(N); e->h1_count = w.take<int>(1);
   } else {
     e->h1_flag = e->h1_list = e->h1_count = nullptr;
   }
-  e->P0 = w.take<float>(C * cap1 * e->Fp); e->rs0 = w.take<float>(C * cap1);
+  e->P0 = w.take<float>(C * capL * e->Fp); e->rs0 = w.take<float>(C * capL);
+  {
+    long capp = cap1;
+    for (int m = 0; m < GS_MAX_MID; ++m) {
+      e->Pmid[m] = e->rsmid[m] = e->Ymid[m] = nullptr;
+      if (m >= e->nmid) continue;
+      e->Pmid[m] = w.take<float>(C * capp * e->Fp); e->rsmid[m] = w.take<float>(C * capp);
+      if (e->T == 2) e->Ymid[m] = w.take<float>(C * (long)e->capm[m] * h);
+      capp = e->capm[m];
+    }
+  }
   e->Sr = w.take<float>(C * bcap * e->Fp); e->rsr = w.take<float>(C * bcap);
   e->Zr = w.take<float>(C * bcap * C); e->gw_real = w.take<float>(C * P);
   if (e->T == 2) {
     e->Tm = w.take<float>(C * bcap * h); e->Y1 = w.take<float>(C * cap1 * h);
-    e->Bmat = w.take<float>(C * cap1 * f2 * h); e->slabs_r = w.take<float>((long)e->edge_cap * d * h);
+    // (the materialised per-edge operand: only the metrics that need the bias gradient use it — with more than two hops it would be
+    // tens of GB, so it exists there only when it is needed)
+    e->Bmat = (e->nmid == 0 || e->cfg.dis_metric != 0) ? w.take<float>(C * capL * f2 * h) : nullptr;
+    e->slabs_r = w.take<float>((long)e->edge_cap * d * h);
     e->edge_plan = w.take<int>(2 * C + 1);
   } else {
     e->Tm = e->Y1 = e->Bmat = e->slabs_r = nullptr;
@@ -294,6 +330,8 @@ static size_t carve(gs_gcond* e, void* base) {
   }
   e->adj_raw = w.take<float>(n2); e->adj_norm = w.take<float>(n2); e->rnorm = w.take<float>(2 * n);
   e->Q = w.take<float>(n2); e->rsq = w.take<float>(n);
+  e->Apow = e->K != 2 ? w.take<float>(n2 * (e->K + 1)) : nullptr;
+  e->Apow_t = e->K != 2 ? w.take<float>(n2 * 2) : nullptr;
   e->H1s = e->T == 2 ? w.take<float>(n * h) : nullptr;
   e->Ss = w.take<float>(n * F); e->Zs = w.take<float>(n * C); e->Ps = w.take<float>(n * C); e->Gs = w.take<float>(n * C);
   e->gw_syn = w.take<float>(C * P); e->stats = w.take<float>(C * e->pd.total_cols * 3);
@@ -380,6 +418,14 @@ static int check_cfg(const gs_gcond_config* c) {
     GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: with_bn is built for condense_model SGC with ntrans = 2 (models/sgc.py:27-33 puts BatchNorm "
                                 "layers between transforms only; GCN + with_bn raises upstream, golden G22)");
   if (c->inner_loop < 0) GS_FAIL(GS_ERR_ARG, "gs_gcond: negative inner_loop");
+  if (c->nlayers != 0 && c->nlayers != 2) {
+    // models/sgc.py:45-51 propagates nlayers times, dataset/loader.py:205-210 samples as many hops; nlayers = 1 has no reference run
+    // (PyG's sampler hands train_class the single hop's Adj tuple instead of a list: gcond_base.py:213 fails on it)
+    if (c->nlayers < 3 || c->nlayers > 2 + GS_MAX_MID) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nlayers must be 2 .. %d", 2 + GS_MAX_MID);
+    if (c->condense_model != 0) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nlayers != 2 is built for condense_model SGC");
+    for (int m = 0; m < c->nlayers - 2; ++m)
+      if (c->fmid[m] < 1 || c->fmid[m] > 16) GS_FAIL(GS_ERR_ARG, "gs_gcond: middle fan-outs in [1, 16]");
+  }
   return GS_OK;
 }
 
@@ -621,13 +667,23 @@ extern "C" int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* b, gs_stream_t 
   if (!e || !b) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_blocks: null argument");
   e->prefetched = false;
   const gs_blocks& d = e->blk;
-  if (b->C != d.C || b->bcap != d.bcap || b->f1 != d.f1 || b->f2 != d.f2 || b->cap1 != d.cap1)
+  if (b->C != d.C || b->bcap != d.bcap || b->f1 != d.f1 || b->f2 != d.f2 || b->cap1 != d.cap1 || b->nmid != d.nmid)
     GS_FAIL(GS_ERR_ARG, "gs_gcond_set_blocks: block geometry differs from the engine's");
+  for (int m = 0; m < d.nmid; ++m)
+    if (b->fm[m] != d.fm[m] || b->capm[m] != d.capm[m]) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_blocks: middle hop %d differs from the engine's", m);
   hipStream_t s = (hipStream_t)stream;
   const long C = d.C, bcap = d.bcap, f1 = d.f1, f2 = d.f2, cap1 = d.cap1;
 #define CP(f, cnt, T) GS_HIP(hipMemcpyAsync(d.f, b->f, (cnt) * sizeof(T), hipMemcpyDeviceToDevice, s))
   CP(n_seed, C, int); CP(n1, C, int); CP(nid1, C * cap1, int); CP(col1, C * bcap * f1, int); CP(val1, C * bcap * f1, float);
-  CP(tptr1, C * (cap1 + 1), int); CP(tedge1, C * bcap * f1, int); CP(col0, C * cap1 * f2, int); CP(val0, C * cap1 * f2, float);
+  CP(tptr1, C * (cap1 + 1), int); CP(tedge1, C * bcap * f1, int);
+  long capp = cap1;
+  for (int m = 0; m < d.nmid; ++m) {
+    const long fm = d.fm[m], capc = d.capm[m];
+    CP(nm[m], C, int); CP(nidm[m], C * capc, int); CP(colm[m], C * capp * fm, int); CP(valm[m], C * capp * fm, float);
+    CP(tptrm[m], C * (capc + 1), int); CP(tedgem[m], C * capp * fm, int);
+    capp = capc;
+  }
+  CP(col0, C * capp * f2, int); CP(val0, C * capp * f2, float);
 #undef CP
   e->have_blocks = true;
   return GS_OK;
@@ -708,7 +764,15 @@ static gs_blocks blocks_view(const gs_gcond* e) {
   const long c0 = e->c_lo, bcap = b.bcap, f1 = b.f1, f2 = b.f2, cap1 = b.cap1;
   b.C = e->c_hi - e->c_lo;
   b.n_seed += c0; b.n1 += c0; b.nid1 += c0 * cap1; b.col1 += c0 * bcap * f1; b.val1 += c0 * bcap * f1;
-  b.tptr1 += c0 * (cap1 + 1); b.tedge1 += c0 * bcap * f1; b.col0 += c0 * cap1 * f2; b.val0 += c0 * cap1 * f2;
+  b.tptr1 += c0 * (cap1 + 1); b.tedge1 += c0 * bcap * f1;
+  long capp = cap1;
+  for (int m = 0; m < b.nmid; ++m) {
+    const long fm = b.fm[m], capc = b.capm[m];
+    b.nm[m] += c0; b.nidm[m] += c0 * capc; b.colm[m] += c0 * capp * fm; b.valm[m] += c0 * capp * fm;
+    b.tptrm[m] += c0 * (capc + 1); b.tedgem[m] += c0 * capp * fm; b.scrm[m] += c0 * (capc + 1);
+    capp = capc;
+  }
+  b.col0 += c0 * capp * f2; b.val0 += c0 * capp * f2;
   return b;
 }
 
@@ -874,9 +938,13 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   if (Cl == 0) return GS_OK;
   const long P = e->P, c0 = e->c_lo;
   const gs_blocks b = blocks_view(e);
+  // nlayers >= 3: the outermost block has one row per node of the LAST middle frontier (capL rows per class, nL[c] live)
+  const int nmid = b.nmid, capL = e->capL;
+  const int* nL = nmid ? b.nm[nmid - 1] : b.n1;
+  if (nmid && (e->S_full || e->gcn)) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nlayers != 2 with the full-neighbour mode or the GCN condense model");
   // class-major scratch of this rank's classes
   const long Fp = e->Fp;
-  float* P0 = e->P0 + c0 * cap1 * Fp; float* rs0 = e->rs0 + c0 * cap1;
+  float* P0 = e->P0 + c0 * capL * Fp; float* rs0 = e->rs0 + c0 * capL;
   float* Sr = e->Sr + c0 * bcap * Fp; float* rsr = e->rsr + c0 * bcap;
   float* Zr = e->Zr + c0 * bcap * C; float* gw = e->gw_real + c0 * P;
   const float* th = model_th(e);
@@ -921,14 +989,14 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     // Unsharded, the 40 classes' blocks touch (nearly) every node: all N rows in one product.  A sharded rank's few classes
     // gather fewer slots than there are nodes: their distinct sources are listed (mark + compact) and only those rows of H1full
     // are produced — same arithmetic per row, so every value downstream is bitwise the full product's.
-    const long slots = (long)Cl * cap1 * f2;
+    const long slots = (long)Cl * capL * f2;
     int rows_rc = GS_ERR_UNSUPPORTED;
     // (the sign bits are an output of the row-panel kernel: asked for only where the product takes that route)
     const bool want_bits = knob_of(e, GS_KNOB_H1_BITS, g_h1_bits) && e->H1bits && e->cfg.dis_metric == 0;
     if (knob_of(e, GS_KNOB_H1_ROWS, g_h1_rows) && !e->S_full && e->h1_flag && slots < (long)e->N) {
       GS_HIP(hipMemsetAsync(e->h1_flag, 0, sizeof(int) * (size_t)e->N, s));
       GS_HIP(hipMemsetAsync(e->h1_count, 0, sizeof(int), s));
-      hipLaunchKernelGGL(gs_h1_mark_kernel, dim3(gs_cdiv(slots, 256)), dim3(256), 0, s, b.col0, b.val0, b.n1, cap1, f2, Cl, e->h1_flag);
+      hipLaunchKernelGGL(gs_h1_mark_kernel, dim3(gs_cdiv(slots, 256)), dim3(256), 0, s, b.col0, b.val0, nL, capL, f2, Cl, e->h1_flag);
       hipLaunchKernelGGL(gs_h1_compact_kernel, dim3(gs_cdiv(e->N, 2048)), dim3(256), 0, s, e->h1_flag, e->N, e->h1_list, e->h1_count);
       GS_LAUNCH_CHECK();
       rows_rc = gs_panel_rows(e->io.X, e->ldx, e->W1mT, d, th + e->ob1, 1, e->H1full, h, h, d, e->h1_list, e->h1_count, (int)slots,
@@ -960,13 +1028,21 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n], s));
   }
   const bool want_ebits = knob_of(e, GS_KNOB_EDGE_BITS, g_edge_bits) && e->T == 2 && e->cfg.dis_metric == 0 && e->edge_bits && !use_bits;
-  have_ebits = launch_ell(b.col0, b.val0, b.n1, cap1, f2, 0, src, ld_src, nullptr, F, P0, Fp, rs0, Cl, s,
+  have_ebits = launch_ell(b.col0, b.val0, nL, capL, f2, 0, src, ld_src, nullptr, F, P0, Fp, rs0, Cl, s,
                                      want_ebits ? e->edge_bits + c0 * cap1 * f2 * 8 : nullptr);
   if (probe2) {
     GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n + 1], s));
     e->probe2_n++;
   }
-  launch_ell(b.col1, b.val1, b.n_seed, bcap, f1, cap1, P0, Fp, rs0, F, Sr, Fp, rsr, Cl, s);
+  // middle hops, outermost first: frontier m - 1 <- frontier m (rows of class c live in [c][cap(m-1)])
+  const float* Pin = P0; const float* rsin = rs0;
+  for (int m = nmid - 1; m >= 0; --m) {
+    const int capp = m == 0 ? cap1 : b.capm[m - 1];
+    float* Pm = e->Pmid[m] + c0 * capp * Fp; float* rsm = e->rsmid[m] + c0 * capp;
+    launch_ell(b.colm[m], b.valm[m], m == 0 ? b.n1 : b.nm[m - 1], capp, b.fm[m], b.capm[m], Pin, Fp, rsin, F, Pm, Fp, rsm, Cl, s);
+    Pin = Pm; rsin = rsm;
+  }
+  launch_ell(b.col1, b.val1, b.n_seed, bcap, f1, cap1, Pin, Fp, rsin, F, Sr, Fp, rsr, Cl, s);
   }
   GS_LAUNCH_CHECK();
   {  // Z = S Wl  (all classes at once), then G in place
@@ -988,8 +1064,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   }
   if (e->T == 2) {
     // Y1 = A1^T Tm ; Bmat = per-edge masked contribution ; gW1_c = X[col0]^T Bmat_c ; gb1_c = colsum
-    const long K = (long)cap1 * f2;
-    float* Tm = e->Tm + c0 * bcap * h; float* Y1 = e->Y1 + c0 * cap1 * h; float* Bmat = e->Bmat + c0 * K * h;
+    const long K = (long)capL * f2;
+    float* Tm = e->Tm + c0 * bcap * h; float* Y1 = e->Y1 + c0 * cap1 * h; float* Bmat = e->Bmat ? e->Bmat + c0 * K * h : nullptr;
     int* kcount = e->kcount + c0;
     gs_gemm_desc g = mk(Zr, C, 1, th + e->oWl, 1, C, Tm, h, Cl * bcap, h, C);      // Tm = G W2^T
     GS_TRY(gs_gemm_f32(&g, stream));
@@ -999,6 +1075,19 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     else
       hipLaunchKernelGGL(gs_csc_spmm_t_kernel, dim3(gs_cdiv((long)Cl * cap1, 4)), dim3(256), 0, s, b.tptr1, b.tedge1, b.val1, b.n1,
                          cap1, bcap, f1, Tm, h, Y1, Cl);
+    // middle hops: Y(m) = A(m)^T Y(m - 1) down to the rows of the outermost block (CSC of every middle block)
+    const float* YL = Y1;
+    for (int m = 0; m < nmid; ++m) {
+      const int capp = m == 0 ? cap1 : b.capm[m - 1];
+      float* Ym = e->Ymid[m] + c0 * (long)b.capm[m] * h;
+      if (h == 256)
+        hipLaunchKernelGGL(gs_csc_spmm_t_v4_kernel, dim3(gs_cdiv((long)Cl * b.capm[m], 4)), dim3(256), 0, s, b.tptrm[m], b.tedgem[m], b.valm[m],
+                           b.nm[m], b.capm[m], capp, b.fm[m], YL, Ym, Cl);
+      else
+        hipLaunchKernelGGL(gs_csc_spmm_t_kernel, dim3(gs_cdiv((long)Cl * b.capm[m], 4)), dim3(256), 0, s, b.tptrm[m], b.tedgem[m], b.valm[m],
+                           b.nm[m], b.capm[m], capp, b.fm[m], YL, h, Ym, Cl);
+      YL = Ym;
+    }
     const bool fused = (e->cfg.dis_metric == 0);   // 'ours' needs no bias gradient -> Bmat is generated inside the GEMM
     // balanced slabs (knob EDGE_PLAN, default on): the chip's workgroup slots are cut over the classes by their live edge counts
     const bool plan = fused && Cl <= 64 && knob_of(e, GS_KNOB_EDGE_PLAN, g_edge_plan != 0) && e->edge_plan && ((long)d * h) % 4 == 0 &&
@@ -1009,13 +1098,13 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       // iteration, fixed slabs 1 556); alone on the chip (forward reuse, staged calls) every slot
       int target = g_edge_plan > 1 ? g_edge_plan / gs_cdiv(d, 128) : (e->real_beside ? e->edge_target - e->edge_target / 8 : e->edge_target);
       if (target > e->edge_cap - Cl) target = e->edge_cap - Cl;
-      GS_TRY(gs_edge_plan(b.n1, f2, Cl, target < 1 ? 1 : target, kcount, e->edge_plan, s));
+      GS_TRY(gs_edge_plan(nL, f2, Cl, target < 1 ? 1 : target, kcount, e->edge_plan, s));
     }
     else if (fused)
-      hipLaunchKernelGGL(gs_kcount_kernel, dim3(gs_cdiv(Cl, 64)), dim3(64), 0, s, b.n1, f2, Cl, kcount);
+      hipLaunchKernelGGL(gs_kcount_kernel, dim3(gs_cdiv(Cl, 64)), dim3(64), 0, s, nL, f2, Cl, kcount);
     else
-      hipLaunchKernelGGL(gs_make_bmat_kernel, dim3(gs_cdiv((long)Cl * cap1 * f2, 4)), dim3(256), 0, s, b.col0, b.val0, b.n1, cap1,
-                         f2, e->H1full, (long)h, Y1, h, Bmat, kcount, Cl);
+      hipLaunchKernelGGL(gs_make_bmat_kernel, dim3(gs_cdiv((long)Cl * capL * f2, 4)), dim3(256), 0, s, b.col0, b.val0, nL, capL,
+                         f2, e->H1full, (long)h, YL, h, Bmat, kcount, Cl);
     GS_LAUNCH_CHECK();
     // K slabs: the engine's choice fills the chip with ALL classes (derive()); a class shard has fewer classes, so its slabs are
     // shortened until the launch again has ~512 workgroups (one workgroup = one class x slab x 128-feature tile is bound by ONE
@@ -1038,7 +1127,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     gwd.nb1 = Cl; gwd.nb2 = nsplit; gwd.kchunk = kchunk; gwd.Kb = kcount;
     gwd.sBb1 = K * h; gwd.sCb1 = (long)nsplit * d * h; gwd.sCb2 = (long)d * h;
     if (fused) {   // B(k, :) = val0[k] * [H1full[col0[k]] > 0] * Y1[k / f2]
-      gwd.B = Y1; gwd.sBb1 = (long)cap1 * h;
+      gwd.B = YL; gwd.sBb1 = (long)capL * h;
       gwd.bgen_mask = e->H1full; gwd.bgen_ldm = h; gwd.bgen_idx = b.col0; gwd.bgen_w = b.val0; gwd.bgen_div = f2;
       if (use_bits) { gwd.bgen_bits = e->H1bits; gwd.bgen_ldbits = h / 32; }
       else if (have_ebits) { gwd.bgen_bits = e->edge_bits + c0 * cap1 * f2 * 8; gwd.bgen_ldbits = h / 32; gwd.bgen_bits_edge = 1; }
@@ -1446,6 +1535,44 @@ extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_
 
 // match_loss of this rank's Cl classes and D = d loss / d gw_syn (condensation/utils.py:12-106): one launch (a workgroup per class)
 // when the chains are fused and the per-class statistics row fits its LDS image, else statistics / finalize / apply
+// ---- nlayers != 2 (models/sgc.py:45-51: K propagations): Q = A^^K and d A^ from d Q (oracle/analytic.py: adj_power / adj_power_bwd) ----
+// The powers A^^2 .. A^^(K-1) stay in e->Apow + i n'^2 (the backward needs them); n'^3 products of a few hundred rows: latency-bound.
+static int adj_powers(gs_gcond* e, const float* A, float* Qout, gs_stream_t stream) {
+  const int n = e->n;
+  const long n2 = (long)n * n;
+  const float* prev = A;
+  for (int i = 2; i <= e->K; ++i) {
+    float* out = i == e->K ? Qout : e->Apow + (long)i * n2;
+    gs_gemm_desc g = mk(prev, n, 1, A, n, 1, out, n, n, n, n);
+    GS_TRY(gs_gemm_f32(&g, stream));
+    prev = out;
+  }
+  return GS_OK;
+}
+// dA = sum over the K positions of A^ in the product: (A^^i)^T dQ (A^^(K-1-i))^T, i = 0 .. K-1 (powers from adj_powers of the SAME A)
+static int adj_powers_bwd(gs_gcond* e, const float* A, const float* dQ, float* dA, gs_stream_t stream) {
+  const int n = e->n, K = e->K;
+  const long n2 = (long)n * n;
+  auto pw = [&](int i) -> const float* { return i == 1 ? A : e->Apow + (long)i * n2; };
+  {      // i = 0: dQ (A^^(K-1))^T
+    gs_gemm_desc g = mk(dQ, n, 1, pw(K - 1), 1, n, dA, n, n, n, n);
+    GS_TRY(gs_gemm_f32(&g, stream));
+  }
+  for (int i = 1; i < K - 1; ++i) {      // (A^^i)^T [dQ (A^^(K-1-i))^T]
+    gs_gemm_desc t = mk(dQ, n, 1, pw(K - 1 - i), 1, n, e->Apow_t, n, n, n, n);
+    GS_TRY(gs_gemm_f32(&t, stream));
+    gs_gemm_desc g = mk(pw(i), 1, n, e->Apow_t, n, 1, dA, n, n, n, n);
+    g.beta = 1.f;
+    GS_TRY(gs_gemm_f32(&g, stream));
+  }
+  {      // i = K - 1: (A^^(K-1))^T dQ
+    gs_gemm_desc g = mk(pw(K - 1), 1, n, dQ, n, 1, dA, n, n, n, n);
+    g.beta = 1.f;
+    GS_TRY(gs_gemm_f32(&g, stream));
+  }
+  return GS_OK;
+}
+
 static int match_distance_folded(gs_gcond* e, const float* gwr, const float* gws, float* stats, float* ab, float* Dv, int Cl, const float* s2,
                                  hipStream_t s);
 static int match_distance(gs_gcond* e, const float* gwr, const float* gws, float* stats, float* ab, float* Dv, int Cl, hipStream_t s) {
@@ -1603,7 +1730,11 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       Hin = e->H1s;
     }
     if (e->blk_pos) {
+      if (e->K != 2) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nlayers != 2 with a block structure");
       GS_TRY(block_square(e, A, e->Q, stream));
+      if (e->T == 2) GS_TRY(gs_gemm_f32(&qh[1], stream));
+    } else if (e->K != 2) {      // Q = A^^K
+      GS_TRY(adj_powers(e, A, e->Q, stream));
       if (e->T == 2) GS_TRY(gs_gemm_f32(&qh[1], stream));
     } else {
       GS_TRY(gs_gemm_group_f32(qh, e->T == 2 ? 2 : 1, stream));
@@ -1795,6 +1926,8 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   GS_LAUNCH_CHECK();
   if (e->blk_pos) {
     GS_TRY(block_dadj(e, A, e->dQ, e->dAn, stream));
+  } else if (e->K != 2) {
+    GS_TRY(adj_powers_bwd(e, A, e->dQ, e->dAn, stream));
   } else {  // dA^ = dQ A^T + A^T dQ ; then through dense_gcn_norm (both linear in dQ: partial sums stay partial sums)
     gs_gemm_desc a = mk(e->dQ, n, 1, A, 1, n, e->dAn, n, n, n, n);
     gs_gemm_desc b = mk(A, 1, n, e->dQ, n, 1, e->dAn, n, n, n, n);
@@ -2068,8 +2201,12 @@ static int inner_steps_fused(gs_gcond* e, gs_stream_t stream) {
   const float* A = e->adj_norm_in;
   float* g = e->g_model;
   {
-    gs_gemm_desc q = mk(A, n, 1, A, n, 1, e->Qin, n, n, n, n);
-    GS_TRY(gs_gemm_f32(&q, stream));
+    if (e->K != 2) {
+      GS_TRY(adj_powers(e, A, e->Qin, stream));      // (the training powers are not needed any more: the backward has run)
+    } else {
+      gs_gemm_desc q = mk(A, n, 1, A, n, 1, e->Qin, n, n, n, n);
+      GS_TRY(gs_gemm_f32(&q, stream));
+    }
     hipLaunchKernelGGL(gs_rowsum_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Qin, n, n, e->rsq_in);
     GS_LAUNCH_CHECK();
     if (e->T == 1) {   // S = Q X does not depend on theta: once per outer iteration
@@ -2165,6 +2302,8 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
   {
     if (e->blk_pos) {
       GS_TRY(block_square(e, A, e->Qin, stream));
+    } else if (e->K != 2) {
+      GS_TRY(adj_powers(e, A, e->Qin, stream));
     } else {
       gs_gemm_desc g = mk(A, n, 1, A, n, 1, e->Qin, n, n, n, n);
       GS_TRY(gs_gemm_f32(&g, stream));

@@ -319,22 +319,32 @@ __global__ __launch_bounds__(256) void gs_sample_hop1_kernel(const int* __restri
   }
 }
 
+// the frontier the outermost hop samples from: hop 1's, or the last middle hop's (nlayers >= 3)
+__device__ __forceinline__ void last_frontier(const gs_blocks& blk, const int*& n_last, const int*& nid_last, int& cap_last) {
+  if (blk.nmid > 0) { n_last = blk.nm[blk.nmid - 1]; nid_last = blk.nidm[blk.nmid - 1]; cap_last = blk.capm[blk.nmid - 1]; }
+  else { n_last = blk.n1; nid_last = blk.nid1; cap_last = blk.cap1; }
+}
+
 __global__ __launch_bounds__(256) void gs_sample_hop2_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                              const float* __restrict__ val, gs_blocks blk, uint64_t seed,
                                                              uint32_t step, int class_key0) {
   const int c = blockIdx.y, tid = threadIdx.x;
   const int l = blockIdx.x * 256 + tid;
-  const int f2 = blk.f2, cap1 = blk.cap1;
+  const int f2 = blk.f2;
+  const int* n_last; const int* nid_last; int cap1;
+  last_frontier(blk, n_last, nid_last, cap1);
   __shared__ int s_sel[256 * GS_MAX_F];
   if (l >= cap1) return;
   const long base = ((long)c * cap1 + l) * f2;
-  if (l >= blk.n1[c]) {
+  if (l >= n_last[c]) {
     for (int j = 0; j < f2; ++j) { blk.col0[base + j] = 0; blk.val0[base + j] = 0.f; }
     return;
   }
-  const int v = blk.nid1[(long)c * cap1 + l];
+  const int v = nid_last[(long)c * cap1 + l];
   const int e0 = rowptr[v], deg = rowptr[v + 1] - e0;
-  const int k = sample_row(deg, f2, s_sel + tid * GS_MAX_F, seed ^ 0x2222ull, step, (uint32_t)((class_key0 + c) * 65536 + l));
+  // (two hops: the key of rounds 1-4; more hops: rows beyond 65 535 exist, the class moves into the seed)
+  const int k = blk.nmid > 0 ? sample_row(deg, f2, s_sel + tid * GS_MAX_F, seed ^ 0x2222ull ^ ((uint64_t)(class_key0 + c) << 40), step, (uint32_t)l)
+                             : sample_row(deg, f2, s_sel + tid * GS_MAX_F, seed ^ 0x2222ull, step, (uint32_t)((class_key0 + c) * 65536 + l));
   for (int j = 0; j < f2; ++j) {
     if (j < k) {
       int e = e0 + s_sel[tid * GS_MAX_F + j];
@@ -345,6 +355,137 @@ __global__ __launch_bounds__(256) void gs_sample_hop2_kernel(const int* __restri
       blk.val0[base + j] = 0.f;
     }
   }
+}
+
+// ---- a MIDDLE hop (nlayers >= 3; dataset/loader.py:205-210): frontier m - 1 (hop 1's for m = 0) -> frontier m ---------------------------
+// One workgroup per class.  Every node of the previous frontier keeps <= fm neighbours (Floyd, like the other hops); the new frontier
+// holds the previous one first (same local ids) and then every new node in the order of its FIRST edge slot (row-major over the
+// block: the order PyG's relabelling produces) — a global atomicMin of slot indices on the class's marker row, then chunked exclusive
+// scans over the slots; the CSC of the block (lists ascending by slot: a fixed summation order for the transposed product) is built
+// in global memory with the per-level scratch `scrm`.  Frontiers of 4 096 .. 270 000 nodes do not fit LDS: everything is global.
+__global__ __launch_bounds__(256) void gs_sample_mid_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                            const float* __restrict__ val, int n_nodes, int* marker, gs_blocks blk, int m,
+                                                            uint64_t seed, uint32_t step, int class_key0) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int f = blk.fm[m], capc = blk.capm[m];
+  const int capp = m == 0 ? blk.cap1 : blk.capm[m - 1];
+  const int np = (m == 0 ? blk.n1 : blk.nm[m - 1])[c];
+  const int* nidp = (m == 0 ? blk.nid1 : blk.nidm[m - 1]) + (long)c * capp;
+  int* colm = blk.colm[m] + (long)c * capp * f;
+  float* valm = blk.valm[m] + (long)c * capp * f;
+  int* nidc = blk.nidm[m] + (long)c * capc;
+  int* tptr = blk.tptrm[m] + (long)c * (capc + 1);
+  int* tedge = blk.tedgem[m] + (long)c * capp * f;
+  int* cur = blk.scrm[m] + (long)c * (capc + 1);
+  int* mk = marker + (long)c * n_nodes;
+  __shared__ int s_tmp[4];
+  __shared__ int s_carry;
+  const uint64_t sd = seed ^ (0x3333ull + (uint64_t)m) ^ ((uint64_t)(class_key0 + c) << 40);
+  // 1. the targets keep their local ids; 2. every target row samples its neighbours (global ids for now)
+  for (int r = tid; r < capp; r += 256) {
+    if (r < np) {
+      const int v = nidp[r];
+      nidc[r] = v;
+      mk_store(&mk[v], r - GS_MARK_BIAS);
+      const int e0 = rowptr[v], deg = rowptr[v + 1] - e0;
+      int sel[GS_MAX_F];
+      const int k = sample_row(deg, f, sel, sd, step, (uint32_t)r);
+      for (int j = 0; j < f; ++j) {
+        if (j < k) { colm[(long)r * f + j] = col[e0 + sel[j]]; valm[(long)r * f + j] = val[e0 + sel[j]]; }
+        else { colm[(long)r * f + j] = -1; valm[(long)r * f + j] = 0.f; }
+      }
+    } else {
+      for (int j = 0; j < f; ++j) { colm[(long)r * f + j] = -1; valm[(long)r * f + j] = 0.f; }
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  // 3. first occurrence (lowest slot) of every node that is not a target
+  const long nslots = (long)np * f;
+  for (long sl = tid; sl < nslots; sl += 256) {
+    const int g = colm[sl];
+    if (g >= 0) atomicMin(&mk[g], (int)sl);
+  }
+  __threadfence();
+  __syncthreads();
+  // 4. new local ids in slot order (chunks of 256 slots, running carry)
+  if (tid == 0) s_carry = np;
+  __syncthreads();
+  for (long base = 0; base < nslots; base += 256) {
+    const long sl = base + tid;
+    int g = -1, win = 0;
+    if (sl < nslots) {
+      g = colm[sl];
+      win = g >= 0 && mk_load(&mk[g]) == (int)sl;
+    }
+    int tot = 0;
+    const int ex = block_excl_scan_256(win, s_tmp, &tot);
+    const int carry = s_carry;
+    if (win) {
+      const int lid = carry + ex;
+      nidc[lid] = g;
+      mk_store(&mk[g], lid - GS_MARK_BIAS);
+    }
+    __syncthreads();
+    if (tid == 0) s_carry = carry + tot;
+    __syncthreads();
+  }
+  const int nc = s_carry;
+  __threadfence();
+  __syncthreads();
+  // 5. local ids into the block; in-degree counts
+  for (int i = tid; i <= capc; i += 256) { cur[i] = 0; }
+  __threadfence();
+  __syncthreads();
+  for (long sl = tid; sl < (long)capp * f; sl += 256) {
+    const int g = sl < nslots ? colm[sl] : -1;
+    if (g >= 0 && valm[sl] != 0.f) {
+      const int lid = mk_load(&mk[g]) + GS_MARK_BIAS;
+      colm[sl] = lid;
+      atomicAdd(&cur[lid], 1);
+    } else {
+      colm[sl] = 0;      // padding: (0, 0.f) like the other blocks
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  // 6. the marker row goes back to FREE
+  for (int i = tid; i < nc; i += 256) mk_store(&mk[nidc[i]], GS_MARK_FREE);
+  // 7. CSC: exclusive scan of the counts (chunks of 256 nodes), fill with atomic cursors, sort every list ascending
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base <= capc; base += 256) {
+    const int i = base + tid;
+    const int cnt = i <= capc ? cur[i] : 0;
+    int tot = 0;
+    const int ex = block_excl_scan_256(cnt, s_tmp, &tot);
+    const int carry = s_carry;
+    if (i <= capc) { tptr[i] = carry + ex; cur[i] = carry + ex; }
+    __syncthreads();
+    if (tid == 0) s_carry = carry + tot;
+    __syncthreads();
+  }
+  __threadfence();
+  __syncthreads();
+  for (long sl = tid; sl < nslots; sl += 256) {
+    // (a live slot is recognised by its weight: padding carries exactly 0.f, an edge of the normalised adjacency never does)
+    if (valm[sl] != 0.f) {
+      const int pos = atomicAdd(&cur[colm[sl]], 1);
+      tedge[pos] = (int)sl;
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  for (int l = tid; l < nc; l += 256) {
+    const int a = tptr[l], b = tptr[l + 1];
+    for (int i = a + 1; i < b; ++i) {
+      const int x = tedge[i];
+      int q = i - 1;
+      while (q >= a && tedge[q] > x) { tedge[q + 1] = tedge[q]; --q; }
+      tedge[q + 1] = x;
+    }
+  }
+  if (tid == 0) blk.nm[m][c] = nc;
 }
 
 // members of the crossing key bin that are ranked directly (<= 2048: the LDS candidate list); larger bins get a second 12-bit
@@ -373,7 +514,15 @@ int gs_sample_blocks_ex(const int* rowptr, const int* col, const float* val, int
     GS_LAUNCH_CHECK();
     return GS_OK;
   }
-  hipLaunchKernelGGL(gs_sample_hop2_kernel, dim3(gs_cdiv(b.cap1, 256), b.C), dim3(256), 0, s, rowptr, col, val, b, seed,
+  if (b.nmid < 0 || b.nmid > GS_MAX_MID) GS_FAIL(GS_ERR_ARG, "gs_sample_blocks: 0 <= nmid <= %d", GS_MAX_MID);
+  int cap_last = b.cap1;
+  for (int m = 0; m < b.nmid; ++m) {
+    if (b.fm[m] < 1 || b.fm[m] > GS_MAX_F || b.capm[m] != cap_last * (1 + b.fm[m]))
+      GS_FAIL(GS_ERR_ARG, "gs_sample_blocks: middle hop %d: fan-out in [1, %d], capm = cap(m-1) * (1 + fm)", m, GS_MAX_F);
+    hipLaunchKernelGGL(gs_sample_mid_kernel, dim3(b.C), dim3(256), 0, s, rowptr, col, val, n_nodes, marker, b, m, seed, step, class_key0);
+    cap_last = b.capm[m];
+  }
+  hipLaunchKernelGGL(gs_sample_hop2_kernel, dim3(gs_cdiv(cap_last, 256), b.C), dim3(256), 0, s, rowptr, col, val, b, seed,
                      step, class_key0);
   GS_LAUNCH_CHECK();
   return GS_OK;

@@ -121,10 +121,10 @@ def adam_step(p, g, m, v, lr, step, weight_decay=0.0, betas=(0.9, 0.999), eps=1e
 
 
 class BlockSet:
-    """Device arrays of a gs_blocks (class-major, fixed capacity)."""
+    """Device arrays of a gs_blocks (class-major, fixed capacity).  fmid: fan-outs of the middle hops (nlayers >= 3)."""
 
-    def __init__(self, nclass, bcap, f1, f2, device):
-        self.C, self.bcap, self.f1, self.f2 = nclass, bcap, f1, f2
+    def __init__(self, nclass, bcap, f1, f2, device, fmid=()):
+        self.C, self.bcap, self.f1, self.f2, self.fmid = nclass, bcap, f1, f2, tuple(int(f) for f in fmid)
         self.cap1 = bcap * (1 + f1)
         i32 = dict(device=device, dtype=torch.int32)
         f32 = dict(device=device, dtype=torch.float32)
@@ -135,61 +135,118 @@ class BlockSet:
         self.val1 = torch.zeros(nclass, bcap, f1, **f32)
         self.tptr1 = torch.zeros(nclass, self.cap1 + 1, **i32)
         self.tedge1 = torch.zeros(nclass, bcap * f1, **i32)
-        self.col0 = torch.zeros(nclass, self.cap1, f2, **i32)
-        self.val0 = torch.zeros(nclass, self.cap1, f2, **f32)
+        self.capm, capp = [], self.cap1
+        for m, fm in enumerate(self.fmid):      # middle hop m: frontier m - 1 (capp rows) <- frontier m (capc nodes)
+            capc = capp * (1 + fm)
+            self.capm.append(capc)
+            setattr(self, f"nm{m}", torch.zeros(nclass, **i32))
+            setattr(self, f"nidm{m}", torch.zeros(nclass, capc, **i32))
+            setattr(self, f"colm{m}", torch.zeros(nclass, capp, fm, **i32))
+            setattr(self, f"valm{m}", torch.zeros(nclass, capp, fm, **f32))
+            setattr(self, f"tptrm{m}", torch.zeros(nclass, capc + 1, **i32))
+            setattr(self, f"tedgem{m}", torch.zeros(nclass, capp * fm, **i32))
+            setattr(self, f"scrm{m}", torch.zeros(nclass, capc + 1, **i32))
+            capp = capc
+        self.cap_last = capp                    # rows of the outermost block per class
+        self.col0 = torch.zeros(nclass, capp, f2, **i32)
+        self.val0 = torch.zeros(nclass, capp, f2, **f32)
 
-    FIELDS = ("n_seed", "n1", "nid1", "col1", "val1", "tptr1", "tedge1", "col0", "val0")
+    BASE_FIELDS = ("n_seed", "n1", "nid1", "col1", "val1", "tptr1", "tedge1", "col0", "val0")
+    MID_FIELDS = ("nm", "nidm", "colm", "valm", "tptrm", "tedgem")
+
+    @property
+    def FIELDS(self):
+        return self.BASE_FIELDS + tuple(f"{k}{m}" for m in range(len(self.fmid)) for k in self.MID_FIELDS)
+
+    @property
+    def n_last(self):
+        """[C] live rows of the outermost block (the last frontier's size)."""
+        return getattr(self, f"nm{len(self.fmid) - 1}") if self.fmid else self.n1
 
     def struct(self):
         b = Blocks()
         b.C, b.bcap, b.f1, b.f2, b.cap1 = self.C, self.bcap, self.f1, self.f2, self.cap1
-        for f in self.FIELDS:
+        for f in self.BASE_FIELDS:
             setattr(b, f, ptr(getattr(self, f)))
+        b.nmid = len(self.fmid)
+        for m, fm in enumerate(self.fmid):
+            b.fm[m], b.capm[m] = fm, self.capm[m]
+            for k in self.MID_FIELDS + ("scrm",):
+                getattr(b, k)[m] = ptr(getattr(self, f"{k}{m}"))
         return b
 
     @classmethod
     def from_struct(cls, b, device):
         """Copies of the engine-owned block arrays."""
-        out = cls(b.C, b.bcap, b.f1, b.f2, device)
-        for f in cls.FIELDS:
+        out = cls(b.C, b.bcap, b.f1, b.f2, device, fmid=[b.fm[m] for m in range(b.nmid)])
+        for f in cls.BASE_FIELDS:
             t = getattr(out, f)
             t.copy_(device_view(getattr(b, f), t.numel(), t.dtype, device).reshape(t.shape))
+        for m in range(b.nmid):
+            for k in cls.MID_FIELDS:
+                t = getattr(out, f"{k}{m}")
+                t.copy_(device_view(getattr(b, k)[m], t.numel(), t.dtype, device).reshape(t.shape))
         return out
 
     @classmethod
-    def from_batches(cls, batches, bcap, f1, f2, device):
-        """Parity mode: lay out reference-style batches (batch_size, n_id, [blk0 (n1 x n2), blk1 (B x n1)]) with CSR
-        blocks (rowptr, col, val, shape) into the engine's ELL layout.  Host-side data shuffling only."""
+    def from_batches(cls, batches, bcap, f1, f2, device, fmid=()):
+        """Parity mode: lay out reference-style batches (batch_size, n_id, [outermost block, .., innermost block]) with CSR blocks
+        (rowptr, col, val, shape) into the engine's ELL layout.  Host-side data shuffling only."""
         ncls = len(batches)
-        out = cls(ncls, bcap, f1, f2, "cpu")
-        for c, (bs, n_id, (blk0, blk1)) in enumerate(batches):
-            rp1, c1, v1, (B, n1) = blk1
-            rp0, c0, v0, (n1b, n2) = blk0
-            assert B == bs and n1b == n1 and B <= bcap and n1 <= out.cap1
+        out = cls(ncls, bcap, f1, f2, "cpu", fmid=fmid)
+        nm = len(out.fmid)
+
+        def csc(rp, col, rows, fan, n_src, tptr, tedge):
+            parents = [[] for _ in range(n_src)]
+            for r in range(rows):
+                for j, e in enumerate(range(int(rp[r]), int(rp[r + 1]))):
+                    parents[int(col[e])].append(r * fan + j)
+            pos = 0
+            for l in range(n_src):
+                tptr[l] = pos
+                for sl in sorted(parents[l]):
+                    tedge[pos] = sl
+                    pos += 1
+            tptr[n_src:] = pos
+
+        for c, (bs, n_id, blocks) in enumerate(batches):
+            assert len(blocks) == 2 + nm
+            rp1, c1, v1, (B, n1) = blocks[-1]
+            assert B == bs and B <= bcap and n1 <= out.cap1
             out.n_seed[c], out.n1[c] = B, n1
             out.nid1[c, :n1] = torch.from_numpy(np.asarray(n_id[:n1]).astype(np.int32))
-            parents = [[] for _ in range(n1)]
             for b in range(B):
                 lo, hi = int(rp1[b]), int(rp1[b + 1])
                 assert hi - lo <= f1
                 for j, e in enumerate(range(lo, hi)):
                     out.col1[c, b, j] = int(c1[e])
                     out.val1[c, b, j] = float(v1[e])
-                    parents[int(c1[e])].append(b * f1 + j)
-            pos = 0
-            for l in range(n1):
-                out.tptr1[c, l] = pos
-                for s in sorted(parents[l]):
-                    out.tedge1[c, pos] = s
-                    pos += 1
-            out.tptr1[c, n1:] = pos
-            for l in range(n1):
+            csc(rp1, c1, B, f1, n1, out.tptr1[c], out.tedge1[c])
+            rows = n1
+            for m in range(nm):      # middle hop m is blocks[-2 - m]: rows = frontier m - 1, columns = frontier m
+                rpm, cm, vm, (r_, ncur) = blocks[-2 - m]
+                fm = out.fmid[m]
+                assert r_ == rows and ncur <= out.capm[m]
+                getattr(out, f"nm{m}")[c] = ncur
+                getattr(out, f"nidm{m}")[c, :ncur] = torch.from_numpy(np.asarray(n_id[:ncur]).astype(np.int32))
+                colm, valm = getattr(out, f"colm{m}"), getattr(out, f"valm{m}")
+                for r in range(rows):
+                    lo, hi = int(rpm[r]), int(rpm[r + 1])
+                    assert hi - lo <= fm
+                    for j, e in enumerate(range(lo, hi)):
+                        colm[c, r, j] = int(cm[e])
+                        valm[c, r, j] = float(vm[e])
+                csc(rpm, cm, rows, fm, ncur, getattr(out, f"tptrm{m}")[c], getattr(out, f"tedgem{m}")[c])
+                rows = ncur
+            rp0, c0, v0, (r_, n2) = blocks[0]
+            assert r_ == rows
+            for l in range(rows):
                 lo, hi = int(rp0[l]), int(rp0[l + 1])
                 assert hi - lo <= f2
                 for j, e in enumerate(range(lo, hi)):
                     out.col0[c, l, j] = int(n_id[int(c0[e])])
                     out.val0[c, l, j] = float(v0[e])
-        for f in cls.FIELDS:
+        for f in out.FIELDS + tuple(f"scrm{m}" for m in range(nm)):
             setattr(out, f, getattr(out, f).to(device))
         return out
 
@@ -234,6 +291,12 @@ class EngineShapes:
     model: str = "SGC"     # condense model: SGC (ntrans transforms) or GCN (two layers)
     pge_chunks: int = 1    # 5 = the chunked PGE of reddit r >= 0.01 (parametrized_adj.py:41-55)
     with_bn: bool = False  # SGC ntrans = 2 with an (always eval-mode) BatchNorm1d between the transforms (models/sgc.py:27-33)
+    fmid: tuple = ()       # `--nlayers` >= 3 (SGC): fan-outs of the hops BETWEEN f1 (from the seeds) and f2 (outermost), e.g. (10,) for
+                           # loader.py:206's [15, 10, 5] with f1 = 15, f2 = 5; nlayers = 2 + len(fmid) propagations on both sides
+
+    @property
+    def nlayers(self):
+        return 2 + len(self.fmid)
 
 
 def model_param_count(d, hidden, nclass, ntrans):
@@ -287,7 +350,8 @@ class GCondEngine:
         self.adj_syn = torch.zeros(s.n_syn, s.n_syn, dtype=torch.float32, device=dev)
         cfg = GCondConfig(s.n_nodes, d, self.ldx, s.nclass, s.n_syn, s.ntrans, s.hidden, s.pge_hidden, s.bcap, s.f1, s.f2,
                           METRICS[dis_metric], inner_loop, lr_feat, lr_adj, lr_model, seed, 1 if external_blocks else 0,
-                          {"SGC": 0, "GCN": 1}[s.model], int(s.pge_chunks), 1 if s.with_bn else 0)
+                          {"SGC": 0, "GCN": 1}[s.model], int(s.pge_chunks), 1 if s.with_bn else 0, s.nlayers,
+                          (C.c_int * 3)(*(list(s.fmid) + [0] * (3 - len(s.fmid)))))
         nbytes = C.c_size_t()
         check(L.gs_gcond_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
         self.workspace_bytes = nbytes.value

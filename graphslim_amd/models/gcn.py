@@ -98,11 +98,13 @@ def evaluation_args(args):
 
 
 class GCN:
-    """2-layer GCN: per layer adj @ (x @ W) + b, ReLU between, log_softmax (models/base.py:51-78)."""
+    """GCN of `nlayers` GraphConvolution layers (models/gcn.py:8-23; 2 in every shipped configuration, 3 .. 5 with `--nlayers`): per
+    layer adj @ (x @ W) + b, ReLU between, log_softmax (models/base.py:51-78)."""
 
     def __init__(self, nfeat, nhid, nclass, args, mode="train"):
-        if getattr(args, "nlayers", 2) != 2:
-            raise NotImplementedError("graphslim_amd.GCN: only nlayers = 2 (the GCond evaluation configuration)")
+        self.nlayers = int(getattr(args, "nlayers", 2))
+        if self.nlayers < 2 or self.nlayers > 5:
+            raise NotImplementedError("graphslim_amd.GCN: nlayers must be 2 .. 5")
         if getattr(args, "with_bn", False):
             # The reference's evaluation GCN cannot run with_bn on a condensed graph: GraphConvolution.forward returns a 3-D
             # tensor [1, n', hidden] for a dense adjacency (layers.py:41-47) and BatchNorm1d(hidden) rejects it — RuntimeError in
@@ -125,7 +127,8 @@ class GCN:
         if self.dropout != 0:
             raise NotImplementedError("graphslim_amd.GCN: dropout > 0 is outside the built path")
         self.metric = args.metric
-        self.sizes = [nfeat * nhid, nhid, nhid * nclass, nclass]
+        self.shapes = [(nfeat, nhid), (nhid,)] + [(nhid, nhid), (nhid,)] * (self.nlayers - 2) + [(nhid, nclass), (nclass,)]
+        self.sizes = [int(np.prod(shp)) for shp in self.shapes]
         self.P = torch.zeros(sum(self.sizes), dtype=torch.float32, device=self.device)
         self.ldc = _pad4(nclass)
         # row-block sharding of the full-graph passes (parallel.RowShard); a single-GPU run owns every row
@@ -136,12 +139,12 @@ class GCN:
     # -- parameters -----------------------------------------------------------------------------------
     def initialize(self):
         """models/base.py:44-49 -> GraphConvolution.reset_parameters (layers.py:29-33): torch-CPU draws, W then b."""
-        ps = host.init_gcn_params(self.nfeat, self.nhid, self.nclass, 2)
+        ps = host.init_gcn_params(self.nfeat, self.nhid, self.nclass, self.nlayers)
         self.P.copy_(torch.cat([p.reshape(-1) for p in ps]).to(self.device))
 
     def _views(self, flat):
         o, out = 0, []
-        for n, shp in zip(self.sizes, [(self.nfeat, self.nhid), (self.nhid,), (self.nhid, self.nclass), (self.nclass,)]):
+        for n, shp in zip(self.sizes, self.shapes):
             out.append(flat[o:o + n].view(shp))
             o += n
         return out
@@ -165,9 +168,120 @@ class GCN:
         return self
 
     # -- forward passes -------------------------------------------------------------------------------
+    # -- nlayers >= 3: the same passes with the hidden layers in between (each one full-graph aggregation of width h) -----
+    def _hidden_layers(self, G, keep=False):
+        """H_1 = relu(S W1 + b1), H_l = relu(A^ (H_(l-1) W_l) + b_l) for l = 2 .. nlayers - 1 on the full graph; returns the
+        last one (keep: the list of all of them, for the backward pass)."""
+        if self.shard.world > 1:
+            raise NotImplementedError("graphslim_amd.GCN: nlayers != 2 is not row-sharded")
+        ps = self.parameters()
+        d, h, dev = self.nfeat, self.nhid, self.device
+        N = G.S.shape[0]
+        H = torch.empty(N, h, device=dev)
+        gemm(G.S, ps[0], H, N, h, d, (G.S.stride(0), 1), (h, 1), h, bias=ps[1], relu=1)
+        Hs = [H]
+        csr = G.target(None)[0]
+        for l in range(1, self.nlayers - 1):
+            T = torch.empty(N, h, device=dev)
+            gemm(H, ps[2 * l], T, N, h, h, (h, 1), (h, 1), h)
+            H = torch.zeros(N, h, device=dev)
+            spmm_csr(*csr, T, F=h, out=H)
+            check(_lib.lib().gs_bias_act_f32(ptr(H), h, ptr(ps[2 * l + 1]), N, h, 1, stream()))
+            Hs.append(H)
+        return Hs if keep else H
+
+    def _train_step_dense_deep(self, X, A, labels_i32, opt):
+        """_train_step_dense for nlayers >= 3: H_l = relu(A^ (H_(l-1) W_l) + b_l), Z = A^ (H_(K-1) W_K) + b_K and its backward."""
+        ps = self.parameters()
+        K, n, Cn, dev = self.nlayers, X.shape[0], self.nclass, self.device
+        L = _lib.lib()
+        Hs, Hin, win = [], X, self.nfeat
+        for l in range(K):
+            W, b = ps[2 * l], ps[2 * l + 1]
+            wout = W.shape[1]
+            T = torch.empty(n, wout, device=dev)
+            gemm(Hin, W, T, n, wout, win, (win, 1), (wout, 1), wout)
+            H = torch.empty(n, wout, device=dev)
+            gemm(A, T, H, n, wout, n, (n, 1), (wout, 1), wout, bias=b, relu=1 if l < K - 1 else 0)
+            Hs.append(H)
+            Hin, win = H, wout
+        Z = Hs[-1]
+        G = torch.empty(n, Cn, device=dev)
+        lossr = torch.empty(n, device=dev)
+        check(L.gs_softmax_nll_grad_f32(ptr(Z), Cn, ptr(labels_i32), n, Cn, ptr(G), ptr(lossr), stream()))
+        g = torch.empty_like(self.P)
+        gs = self._views(g)
+        dZ = G                                                           # d loss / d pre-activation of layer l (masked below l = K)
+        for l in range(K - 1, -1, -1):
+            W = ps[2 * l]
+            win, wout = W.shape
+            check(L.gs_colsum_f32(ptr(dZ), wout, n, wout, ptr(gs[2 * l + 1]), stream()))
+            dT = torch.empty(n, wout, device=dev)
+            gemm(A, dZ, dT, n, wout, n, (1, n), (wout, 1), wout)          # A^T dZ
+            Hprev = X if l == 0 else Hs[l - 1]
+            gemm(Hprev, dT, gs[2 * l], win, wout, n, (1, win), (wout, 1), wout)      # H_(l-1)^T dT
+            if l > 0:
+                dH = torch.empty(n, win, device=dev)
+                gemm(dT, W, dH, n, win, wout, (wout, 1), (1, wout), win, mask=Hprev, ldmask=win)   # (dT W^T) * [H_(l-1) > 0]
+                dZ = dH
+        opt["step"] += 1
+        adam_step(self.P, g, opt["m"], opt["v"], opt["lr"], opt["step"], weight_decay=self.weight_decay)
+        return lossr
+
+    def _train_step_graph_deep(self, G, idx, labels_i32, opt):
+        """_train_step_graph for nlayers >= 3 (S = A^ X cached: layer 1 needs no aggregation; every hidden layer one of width h)."""
+        ps = self.parameters()
+        K, d, h, Cn, ldc, dev = self.nlayers, self.nfeat, self.nhid, self.nclass, self.ldc, self.device
+        L = _lib.lib()
+        N = G.S.shape[0]
+        Hs = self._hidden_layers(G, keep=True)
+        H = Hs[-1]
+        T2 = torch.zeros(N, ldc, device=dev)
+        gemm(H, ps[-2], T2, N, Cn, h, (h, 1), (Cn, 1), ldc)
+        csr, nt = G.target(idx)[0], G.target(idx)[1]
+        Z = torch.zeros(nt, ldc, device=dev)
+        spmm_csr(*csr, T2, F=ldc, out=Z)
+        check(L.gs_bias_act_f32(ptr(Z), ldc, ptr(ps[-1]), nt, Cn, 0, stream()))
+        Gz = torch.empty(nt, Cn, device=dev)
+        lossr = torch.empty(nt, device=dev)
+        check(L.gs_softmax_nll_grad_f32(ptr(Z), ldc, ptr(labels_i32), nt, Cn, ptr(Gz), ptr(lossr), stream()))
+        g = torch.empty_like(self.P)
+        gs = self._views(g)
+        ones = self._ones(max(N, nt))
+        gemm_tn_splitk(ones, 1, Gz, Cn, gs[-1], 1, Cn, nt)
+        dT = spmm_csr(*G.target_t(idx), Gz, F=Cn)                         # (A^[idx, :])^T G   [N, C]
+        gemm_tn_splitk(H, h, dT, Cn, gs[-2], h, Cn, N)
+        dH = torch.empty(N, h, device=dev)
+        gemm(dT, ps[-2], dH, N, h, Cn, (Cn, 1), (1, Cn), h, mask=H, ldmask=h)
+        full_t = G.target_t(None)
+        for l in range(K - 2, 0, -1):                                     # hidden layers K - 1 .. 2 (0-based l: parameters 2 l, 2 l + 1)
+            gemm_tn_splitk(ones, 1, dH, h, gs[2 * l + 1], 1, h, N)
+            dTl = spmm_csr(*full_t, dH, F=h)                              # A^^T dZ_l
+            gemm_tn_splitk(Hs[l - 1], h, dTl, h, gs[2 * l], h, h, N)
+            dHn = torch.empty(N, h, device=dev)
+            gemm(dTl, ps[2 * l], dHn, N, h, h, (h, 1), (1, h), h, mask=Hs[l - 1], ldmask=h)
+            dH = dHn
+        gemm_tn_splitk(ones, 1, dH, h, gs[1], 1, h, N)
+        gemm_tn_splitk(G.S, G.S.stride(0), dH, h, gs[0], d, h, N)
+        opt["step"] += 1
+        adam_step(self.P, g, opt["m"], opt["v"], opt["lr"], opt["step"], weight_decay=self.weight_decay)
+        return lossr
+
     def _forward_graph(self, G, idx=None):
         """Full graph: Z = A^ (relu(S W1 + b1) W2) + b2 on the target rows `idx` (None = every row); S = A^ X is cached
         in `G`.  Returns logits [n_target, ldc] (row stride ldc >= nclass)."""
+        if self.nlayers != 2:
+            ps = self.parameters()
+            h, Cn, ldc, dev = self.nhid, self.nclass, self.ldc, self.device
+            H = self._hidden_layers(G)
+            T2 = torch.zeros(H.shape[0], ldc, device=dev)
+            gemm(H, ps[-2], T2, H.shape[0], Cn, h, (h, 1), (Cn, 1), ldc)
+            tgt = G.target(idx)
+            Z = torch.zeros(tgt[1], ldc, device=dev)
+            if tgt[1] > 0:
+                spmm_csr(*tgt[0], T2, F=ldc, out=Z)
+                check(_lib.lib().gs_bias_act_f32(ptr(Z), ldc, ptr(ps[-1]), tgt[1], Cn, 0, stream()))
+            return Z
         W1, b1, W2, b2 = self.parameters()
         d, h, Cn, ldc = self.nfeat, self.nhid, self.nclass, self.ldc
         dev = self.device
@@ -326,7 +440,11 @@ class GCN:
         for i in range(train_iters):
             if i == train_iters // 2 and self.lr > 0.001:           # base.py:153-154
                 opt = self._new_opt(self.lr * 0.1)
-            lossr = self._train_step_dense(feat, adj, labels, opt) if reduced else self._train_step_graph(Gt, idx_loss, labels, opt)
+            if self.nlayers != 2:
+                lossr = (self._train_step_dense_deep(feat, adj, labels, opt) if reduced
+                         else self._train_step_graph_deep(Gt, idx_loss, labels, opt))
+            else:
+                lossr = self._train_step_dense(feat, adj, labels, opt) if reduced else self._train_step_graph(Gt, idx_loss, labels, opt)
             if verbose and i % 100 == 0:
                 print("Epoch {}, training loss: {}".format(i, float(lossr.mean())))
             acc_val = self._accuracy(self._forward_graph(G, idx_val), labels_val, n_val)

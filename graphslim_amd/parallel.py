@@ -314,8 +314,8 @@ class ShardedGCond:
     def comm(self):
         if self._comm is None:
             s = self.eng.shapes      # the largest join of an iteration: [dX~ | d adj | loss_c], the marginals, dW1 | db1, the pair scores
-            ph = s.pge_hidden
-            largest = 4 * max(s.n_syn * s.d + s.n_syn * s.n_syn + s.nclass, 2 * s.n_syn * ph, ph * ph + ph, s.n_syn * s.n_syn)
+            n, d, ph, nc = (int(getattr(s, k, 0) or 0) for k in ("n_syn", "d", "pge_hidden", "nclass"))
+            largest = 4 * max(n * d + n * n + nc, 2 * n * ph, ph * ph + ph, n * n)
             self._comm = Comm.from_dist(self.col.dist, self.col.group, slot_bytes=max(largest, 1 << 16))
         return self._comm
 

@@ -22,6 +22,10 @@ WORKLOADS = {
     # job-level accuracy gate (tests/golden/make_job_accuracy.py): the ogbn-arxiv hyper-parameters at graph scale 0.05 with a rate
     # that keeps n' >= 128 (n' = 136): a whole job the CPU oracle finishes in minutes, through the headline shape's kernels
     "arxiv-gate": ("ogbn-arxiv", 0.03, 2, 256, 256, 10, 3, 0.01, 0.01, (10, 5)),
+    # `--nlayers 3` (dataset/loader.py:205-206: sizes [15, 10, 5]; models/sgc.py:45-51: three propagations on both sides) with the
+    # ogbn-arxiv hyper-parameters: a parity-test case (tests/test_gpu_fullsize.py), not a bench line
+    "arxiv-k3": ("ogbn-arxiv", 0.005, 2, 256, 256, 20, 3, 0.01, 0.01, (15, 10, 5)),
+    "cora-k3": ("cora", 0.5, 1, 256, 128, 20, 15, 1e-4, 1e-4, (15, 10, 5)),
 }
 
 
@@ -50,7 +54,7 @@ def make_engine(p, device, bcap=256):
     from graphslim_amd.engine import EngineShapes, GCondEngine
     d = p["data"].feat_full.shape[1]
     sh = EngineShapes(p["data"].bench_n, d, p["data"].nclass, len(p["labels_syn"]), p["T"], p["hidden"], p["ph"], bcap,
-                      p["fan"][0], p["fan"][1])
+                      p["fan"][0], p["fan"][-1], fmid=tuple(p["fan"][1:-1]))
     cls_ptr = np.concatenate([[0], np.cumsum([len(q) for q in p["pools"]])])
     eng = GCondEngine(sh, p["data"].bench_feat, p["csr"], cls_ptr, np.concatenate(p["pools"]), p["labels_syn"], p["ranges"],
                       lr_feat=p["lrf"], lr_adj=p["lra"], lr_model=0.01, inner_loop=p["inner"], seed=1, device=device)
@@ -87,29 +91,41 @@ def run_steps(p, eng, k, cycle_len):
 
 
 def blocks_to_batches(blk):
+    """The engine's sampled blocks (BlockSet) as reference-style batches (batch_size, n_id, [outermost block, .., innermost block]) with
+    CSR blocks (rowptr, col, val, shape) — what oracle.GCondState.outer_iteration takes.  The outermost hop's sources are global ids in
+    the engine (not de-duplicated): they are relabelled here the way PyG does it, targets first, then new nodes in first-seen order."""
     f = {k: getattr(blk, k).cpu().numpy() for k in blk.FIELDS}
+    nm = len(blk.fmid)
     out = []
     for c in range(blk.C):
         B, n1 = int(f["n_seed"][c]), int(f["n1"][c])
-        nid1 = f["nid1"][c, :n1]
-        v0, c0g = f["val0"][c, :n1].reshape(-1), f["col0"][c, :n1].reshape(-1)
-        keep = v0 != 0
-        rows0 = np.repeat(np.arange(n1), blk.f2)[keep]
-        uniq, inv = np.unique(np.concatenate([nid1, c0g[keep]]), return_inverse=True)
-        # targets first, then the new sources in first-seen order
-        pos = -np.ones(int(uniq.max()) + 1, dtype=np.int64)
-        pos[nid1] = np.arange(n1)
-        rest = c0g[keep][pos[c0g[keep]] < 0]
-        _, first = np.unique(rest, return_index=True)
-        new = rest[np.sort(first)]
-        pos[new] = n1 + np.arange(len(new))
-        n_id = np.concatenate([nid1, new])
-        rp0 = np.concatenate([[0], np.cumsum(np.bincount(rows0, minlength=n1))])
-        blk0 = (rp0, pos[c0g[keep]], v0[keep].astype(np.float32), (n1, len(n_id)))
         v1, c1 = f["val1"][c, :B].reshape(-1), f["col1"][c, :B].reshape(-1)
         k1 = v1 != 0
         rows1 = np.repeat(np.arange(B), blk.f1)[k1]
         rp1 = np.concatenate([[0], np.cumsum(np.bincount(rows1, minlength=B))])
-        blk1 = (rp1, c1[k1].astype(np.int64), v1[k1].astype(np.float32), (B, n1))
-        out.append((B, n_id, [blk0, blk1]))
+        blocks = [(rp1, c1[k1].astype(np.int64), v1[k1].astype(np.float32), (B, n1))]
+        rows, nid_last = n1, f["nid1"][c, :n1]
+        for m in range(nm):      # middle hop m: frontier m - 1 (rows) <- frontier m
+            ncur = int(f[f"nm{m}"][c])
+            vm, cm = f[f"valm{m}"][c, :rows].reshape(-1), f[f"colm{m}"][c, :rows].reshape(-1)
+            km = vm != 0
+            rr = np.repeat(np.arange(rows), blk.fmid[m])[km]
+            rpm = np.concatenate([[0], np.cumsum(np.bincount(rr, minlength=rows))])
+            blocks.insert(0, (rpm, cm[km].astype(np.int64), vm[km].astype(np.float32), (rows, ncur)))
+            rows, nid_last = ncur, f[f"nidm{m}"][c, :ncur]
+        v0, c0g = f["val0"][c, :rows].reshape(-1), f["col0"][c, :rows].reshape(-1)
+        keep = v0 != 0
+        rows0 = np.repeat(np.arange(rows), blk.f2)[keep]
+        uniq = np.unique(np.concatenate([nid_last, c0g[keep]]))
+        # targets first, then the new sources in first-seen order
+        pos = -np.ones(int(uniq.max()) + 1, dtype=np.int64)
+        pos[nid_last] = np.arange(rows)
+        rest = c0g[keep][pos[c0g[keep]] < 0]
+        _, first = np.unique(rest, return_index=True)
+        new = rest[np.sort(first)]
+        pos[new] = rows + np.arange(len(new))
+        n_id = np.concatenate([nid_last, new])
+        rp0 = np.concatenate([[0], np.cumsum(np.bincount(rows0, minlength=rows))])
+        blocks.insert(0, (rp0, pos[c0g[keep]], v0[keep].astype(np.float32), (rows, len(n_id))))
+        out.append((B, n_id, blocks))
     return out

@@ -144,7 +144,13 @@ int gs_gather_rows_f32(const float* X, long ldx, const int* idx, int n, int F, f
  * <= f1 neighbours per seed, the de-duplicated frontier (seeds first) keeps <= f2 neighbours per node;
  * edge values are the full-graph normalised weights.  Layout: class-major, fixed capacity, padded
  * entries carry val = 0 and index 0.  Outermost-hop sources stay GLOBAL ids (they index X directly).
+ * `--nlayers` K >= 3 (dataset/loader.py:205-210: sizes [15, 10, 5], [15, 10, 5, 5], [15, 10, 5, 5, 5]) adds nmid = K - 2 MIDDLE
+ * hops between hop 1 and the outermost one: middle hop m (0 = next to hop 1) keeps <= fm[m] neighbours of every node of the
+ * frontier before it, de-duplicates into a frontier of capacity capm[m] = cap(m-1) * (1 + fm[m]) (cap(-1) = cap1; its targets
+ * first, like every frontier) and carries the CSC of its block for the transposed product of the backward pass.  The outermost
+ * block col0 / val0 then has one row per node of the LAST middle frontier: [C][capm[nmid-1]][f2].
  * ------------------------------------------------------------------------------------------- */
+#define GS_MAX_MID 3
 typedef struct gs_blocks {
   int C, bcap, f1, f2, cap1;   /* cap1 = bcap*(1+f1) */
   int* n_seed;     /* [C]                 seeds actually drawn (min(bcap, pool size))            */
@@ -155,7 +161,16 @@ typedef struct gs_blocks {
   int* tptr1;      /* [C][cap1+1]         CSC of the hop-1 block: in-edges of frontier node l ... */
   int* tedge1;     /* [C][bcap*f1]        ... are slots tedge1[tptr1[l] .. tptr1[l+1]), ascending */
   int* col0;       /* [C][cap1][f2]       hop-2 block (frontier l <- source): GLOBAL node ids     */
-  float* val0;     /* [C][cap1][f2]                                                               */
+  float* val0;     /* [C][cap1][f2]         (with nmid > 0: [C][capm[nmid-1]][f2])                */
+  int nmid;                    /* middle hops (nlayers - 2); 0: the two-hop layout, nothing below is read */
+  int fm[GS_MAX_MID], capm[GS_MAX_MID];
+  int* nm[GS_MAX_MID];         /* [C]                     size of the frontier behind middle hop m       */
+  int* nidm[GS_MAX_MID];       /* [C][capm[m]]            its global ids (targets first)                 */
+  int* colm[GS_MAX_MID];       /* [C][cap(m-1)][fm[m]]    middle block: local ids into frontier m        */
+  float* valm[GS_MAX_MID];     /* [C][cap(m-1)][fm[m]]                                                   */
+  int* tptrm[GS_MAX_MID];      /* [C][capm[m] + 1]        CSC of the middle block ...                    */
+  int* tedgem[GS_MAX_MID];     /* [C][cap(m-1) * fm[m]]   ... slots ascending per node                   */
+  int* scrm[GS_MAX_MID];       /* [C][capm[m] + 1]        sampler scratch (fill cursors)                 */
 } gs_blocks;
 
 /* marker: [C * n_nodes] int32 scratch that must hold 0x7fffffff on entry; restored on exit. */
@@ -309,7 +324,11 @@ typedef struct gs_gcond_config {
   int with_bn;             /* 1: SGC (ntrans = 2) with a BatchNorm1d between its transforms (models/sgc.py:27-33), which GCond
                               always runs in eval mode with its initial running statistics (gcond_base.py:261-285 check_bn,
                               gcond.py:50): a per-column affine map with TRAINABLE weight / bias.  model_params then is
-                              [W1, b1, W2, b2, bn.weight (h), bn.bias (h)] (nn.Module.parameters() order); dis_metric 0 only */
+                              [W1, b1, W2, b2, bn.weight (h), bn.bias (h)] (nn.Module.parameters() order) */
+  int nlayers;             /* propagations K of the condensation model (models/sgc.py:45-51; `--nlayers`): 0 or 2 = two hops (f1, f2);
+                              3 .. 5 (SGC only) = K sampled hops on the real side — f1 from the seeds, fmid[0 .. K-3] between, f2
+                              outermost (dataset/loader.py:205-210) — and A^^K on the synthetic side */
+  int fmid[GS_MAX_MID];
 } gs_gcond_config;
 
 typedef struct gs_gcond_io {

@@ -7,8 +7,9 @@ fp64) and (2) every HIP kernel has a line here it can be compared with on the GP
 reference lines as oracle/gcond_oracle.py (gcond_base.py:156-241, condensation/utils.py:12-106,
 parametrized_adj.py:40-71, utils.py:429-439).  Never imported by the product path.
 
-Notation (SGC, K=2 propagations, T in {1,2} transforms):
-  Q = A^ A^,  rs = Q 1,  class rows [lo_c, hi_c) are contiguous in labels_syn (gcond_base.py:93-111).
+Notation (SGC, K propagations — `nlayers`, 2 unless stated — and T in {1,2} transforms):
+  Q = A^^K (K = 2: A^ A^),  rs = Q 1,  class rows [lo_c, hi_c) are contiguous in labels_syn (gcond_base.py:93-111).
+  Only Q enters the synthetic-side closed forms; d loss / d A^ follows from d loss / d Q by the product rule (adj_power_bwd).
 """
 from __future__ import annotations
 
@@ -64,10 +65,30 @@ def match_and_D(metric, gw_real, gw_syn):
 # ------------------------------------------------------------------------------------------------
 
 
+def adj_power(A, K):
+    Q = A
+    for _ in range(K - 1):
+        Q = Q @ A
+    return Q
+
+
+def adj_power_bwd(A, dQ, K):
+    """d loss / d A from d loss / d (A^K): sum over the K positions of A in the product, (A^i)^T dQ (A^(K-1-i))^T."""
+    pw = [torch.eye(A.shape[0], dtype=A.dtype)]
+    for _ in range(K - 1):
+        pw.append(pw[-1] @ A)
+    return sum(pw[i].T @ dQ @ pw[K - 1 - i].T for i in range(K))
+
+
 def real_class_grad(theta, X, batch, cls):
-    """batch = (B, n_id, [blk0 (n1 x n2), blk1 (B x n1)]) with dense block matrices (tests only).
+    """batch = (B, n_id, [blk0 (n1 x n2), blk1 (B x n1)]) with dense block matrices (tests only); with K > 2 hops the list is
+    outermost first as the sampler returns it and every block but the innermost composes into `A0` (the engine applies them one by one).
     T=1: S = A1 A0 X_g;  T=2: S = A1 A0 relu(X_g W1 + b1).  Returns gw list like model.parameters()."""
-    B, n_id, (A0, A1) = batch
+    B, n_id, blocks = batch
+    A1 = blocks[-1]
+    A0 = blocks[-2]
+    for blk in reversed(blocks[:-2]):      # three and more hops: the outer blocks compose (A0 <- A_mid ... A_outer)
+        A0 = A0 @ blk
     Xg = X[n_id]
     one = torch.ones(Xg.shape[0], dtype=X.dtype)
     rs = A1 @ (A0 @ one)
@@ -98,13 +119,13 @@ def real_class_grad(theta, X, batch, cls):
 # ------------------------------------------------------------------------------------------------
 
 
-def syn_match(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="ours"):
+def syn_match(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="ours", K=2):
     """class_ranges[c] = (lo, hi) rows of class c (empty classes allowed: lo == hi -> skipped, the
     reference would produce NaN there; GraphSlim never creates one because of max(...,1)).
     Returns (loss, dX, dA) with dX the gradient through the GNN input only (PGE path added later)."""
     n = Xs.shape[0]
     C = len(class_ranges)
-    Q = A @ A
+    Q = adj_power(A, K)
     rs = Q.sum(1)
     loss = torch.zeros((), dtype=Xs.dtype)
     dQ = torch.zeros_like(Q)
@@ -175,7 +196,7 @@ def syn_match(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="o
         dH1 = Q.T @ dS
         dQ = dQ + dS @ H1.T + drs[:, None]
         dX = dX + (dH1 * M) @ W1.T
-    dA = dQ @ A.T + A.T @ dQ
+    dA = adj_power_bwd(A, dQ, K)      # K = 2: dQ A^T + A^T dQ
     return loss, dX, dA
 
 
@@ -271,9 +292,9 @@ def pge_bwd(dAdj, X, lin, bn, c):
 # ------------------------------------------------------------------------------------------------
 
 
-def sgc_dense_grad(theta, Xs, A, labels):
+def sgc_dense_grad(theta, Xs, A, labels, K=2):
     n = Xs.shape[0]
-    Q = A @ A
+    Q = adj_power(A, K)
     rs = Q.sum(1)
     Y = torch.nn.functional.one_hot(labels, theta[-1].shape[0]).to(Xs.dtype)
     if len(theta) == 2:

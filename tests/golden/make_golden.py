@@ -398,12 +398,13 @@ def g6():
 # ---------------------------------------------------------------- G7 train_class ---------------
 
 
-def run_train_class(tag, n, nclass, d, hidden, T, rate, dataset, out, kind="SGC", dis_metric="ours", sizes=(4, 3), with_bn=False):
+def run_train_class(tag, n, nclass, d, hidden, T, rate, dataset, out, kind="SGC", dis_metric="ours", sizes=(4, 3), with_bn=False,
+                    nlayers=2):
     a, x, y = make_graph(n, nclass, d, 5, seed=41)
     per = [max(6, n // (4 * nclass)) + 2 * c for c in range(nclass)]
     data = FakeData(a, x, y, nclass, per, 10, 10, seed=2, sizes=sizes)
     args = args_obj(ntrans=T, hidden=hidden, reduction_rate=rate, dataset=dataset, condense_model=kind,
-                    dis_metric=dis_metric, with_bn=with_bn)
+                    dis_metric=dis_metric, with_bn=with_bn, nlayers=nlayers)
     torch.manual_seed(61)
     np.random.seed(61)
     agent = GCondBase("trans", data, args)
@@ -448,6 +449,18 @@ def g7():
     run_train_class("t1mse", 60, 3, 8, 16, 1, 0.5, "cora", out, dis_metric="mse")
     run_train_class("gcn", 60, 3, 8, 10, 1, 0.5, "cora", out, kind="GCN")
     save("g7_train_class", **out)
+
+
+def g24():
+    """nlayers != 2 (VERDICT r04 "missing" 2): `--nlayers 3` makes retrieve_class_sampler draw THREE hops (dataset/loader.py:205-206:
+    sizes [15, 10, 5]; here [4, 3, 2] on the tiny graph) and SGC.forward propagate three times on both sides (models/sgc.py:45-51:
+    the block list on the real side, adj_syn three times on the synthetic side) — train_class + backward of the reference for one and
+    two transforms.  (nlayers = 1 has no reference behaviour: PyG's NeighborSampler.sample returns the single hop's Adj tuple itself
+    instead of a list, and gcond_base.py:213 `[adj[0] for adj in adjs]` then indexes its e_id = None.)"""
+    out = {}
+    run_train_class("k3t1", 60, 3, 8, 16, 1, 0.5, "cora", out, sizes=(4, 3, 2), nlayers=3)
+    run_train_class("k3t2", 80, 4, 6, 12, 2, 0.4, "ogbn-arxiv", out, sizes=(4, 3, 2), nlayers=3)
+    save("g24_train_class_three_hops", **out)
 
 
 # ---------------------------------------------------------------- G8-G10 full reduce + eval ----
@@ -512,9 +525,10 @@ def g8():
 # ---------------------------------------------------------------- G9 fit_with_val trace --------
 
 
-def g9():
+def _fit_with_val_case(fname, nlayers):
     """models/base.py:80-225: GCN(mode='eval').fit_with_val(reduced=True) + test, transductive and inductive, with the
-    per-epoch validation accuracies captured through the model's metric hook."""
+    per-epoch validation accuracies captured through the model's metric hook.  nlayers = GraphConvolution layers (models/gcn.py:8-23:
+    `--nlayers` is shared by the condensation model's propagations and the evaluation GCN's depth)."""
     out = {}
     n, nclass, d, hidden, ns, iters = 120, 4, 10, 16, 12, 40
     a, x, y = make_graph(n, nclass, d, 6, seed=91)
@@ -533,7 +547,7 @@ def g9():
                idx_test=np_(data.idx_test), feat_syn=np_(feat_syn), adj_syn=np_(adj_syn), labels_syn=np_(labels_syn),
                meta=np.array([n, nclass, d, hidden, ns, iters]))
     for setting in ("trans", "ind"):
-        args = args_obj(hidden=hidden, setting=setting, lr=0.01, weight_decay=0.0, dropout=0.0)
+        args = args_obj(hidden=hidden, setting=setting, lr=0.01, weight_decay=0.0, dropout=0.0, nlayers=nlayers)
         RU.seed_everything(7)
         model = GCN(d, hidden, nclass, args, mode="eval")
         accs, inits = [], []
@@ -561,7 +575,18 @@ def g9():
             out[f"{setting}_init{i}"] = w
         for i, w in enumerate(model.parameters()):
             out[f"{setting}_final{i}"] = np_(w)
-    save("g9_fit_with_val", **out)
+    out["nlayers"] = np.array(nlayers)
+    save(fname, **out)
+
+
+
+def g9():
+    _fit_with_val_case("g9_fit_with_val", 2)
+
+
+def g25():
+    """The evaluation GCN with `--nlayers 3` (three GraphConvolution layers, models/gcn.py:8-23): fit_with_val + test traces."""
+    _fit_with_val_case("g25_fit_with_val_three_layers", 3)
 
 
 # ---------------------------------------------------------------- G10 sparsify + file layout ---
@@ -1081,6 +1106,6 @@ def g22():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16",
-                             "g17", "g18", "g19", "g20", "g21", "g22", "g23"]
+                             "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25"]
     for w in which:
         globals()[w]()

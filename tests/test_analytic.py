@@ -12,7 +12,7 @@ from oracle import gcond_oracle as O
 DT = torch.float64
 
 
-def tiny_problem(T, seed=0, n=70, nclass=4, d=6, hidden=9, rate=0.4):
+def tiny_problem(T, seed=0, n=70, nclass=4, d=6, hidden=9, rate=0.4, sizes=(3, 2)):
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     y = rng.integers(0, nclass, n)
@@ -29,7 +29,7 @@ def tiny_problem(T, seed=0, n=70, nclass=4, d=6, hidden=9, rate=0.4):
     batches = []
     for c in range(nclass):
         seeds = rng.permutation(idx_train[labels_train == c])[:8]
-        batches.append(O.sample_blocks(*csr, seeds, [3, 2], rng))
+        batches.append(O.sample_blocks(*csr, seeds, list(sizes), rng))
     theta = [p.to(DT) for p in O.init_sgc(d, hidden, nclass, T)]
     ns = len(labels_syn)
     xs = torch.randn(ns, d, dtype=DT)
@@ -46,32 +46,40 @@ def dense_batch(b):
 
 
 @pytest.mark.parametrize("T", [1, 2])
-def test_real_class_grad(T):
-    p = tiny_problem(T)
+@pytest.mark.parametrize("sizes", [(3, 2), (3, 2, 2), (2, 2, 2, 2)])
+def test_real_class_grad(T, sizes):
+    p = tiny_problem(T, sizes=sizes)
     for c in range(p["nclass"]):
         theta = [t.clone().requires_grad_(True) for t in p["theta"]]
-        ref, _ = O.class_real_grads("SGC", theta, p["x"], p["y"], p["batches"][c])
+        ref, _ = O.class_real_grads("SGC", theta, p["x"], p["y"], p["batches"][c], len(sizes))
         got = A.real_class_grad(p["theta"], p["x"], dense_batch(p["batches"][c]), c)
         for r, g in zip(ref, got):
             np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.parametrize("T", [1, 2])
-@pytest.mark.parametrize("metric", ["ours", "mse", "cos"])
-def test_syn_match_second_order(T, metric):
-    p = tiny_problem(T, seed=3)
+@pytest.mark.parametrize("metric,K", [("ours", 2), ("mse", 2), ("cos", 2), ("ours", 3), ("mse", 3), ("ours", 4), ("ours", 1)])
+def test_syn_match_second_order(T, metric, K):
+    """K = nlayers propagations (models/sgc.py:45-51): only Q = A^^K and the product rule for d A^ change (oracle/analytic.py)."""
+    p = tiny_problem(T, seed=3, sizes=(3, 2) if K <= 2 else (3, 2) + (2,) * (K - 2))
     theta = [t.clone().requires_grad_(True) for t in p["theta"]]
     xs = p["xs"].clone().requires_grad_(True)
     adj = O.pge_forward(xs.detach(), p["pge"])
     an = O.dense_gcn_norm(adj).clone().requires_grad_(True)
+    if K == 1:      # (no reference run exists for one hop — PyG hands train_class a bare Adj tuple —; the math is checked all the same)
+        p["batches"] = [(b[0], b[1][:b[2][-1][3][1]], b[2][-1:]) for b in p["batches"]]
     loss = O.train_class("SGC", theta, p["batches"], p["x"], p["y"], xs, an, p["labels_syn"], p["ncd"], p["nclass"],
-                         2, metric)
+                         K, metric)
     gx, ga = torch.autograd.grad(loss, [xs, an])
-    gw_real = [A.real_class_grad(p["theta"], p["x"], dense_batch(p["batches"][c]), c) for c in range(p["nclass"])]
+    if K == 1:
+        gw_real = [[g.detach() for g in O.class_real_grads("SGC", [t.clone().requires_grad_(True) for t in p["theta"]], p["x"], p["y"],
+                                                           p["batches"][c], 1)[0]] for c in range(p["nclass"])]
+    else:
+        gw_real = [A.real_class_grad(p["theta"], p["x"], dense_batch(p["batches"][c]), c) for c in range(p["nclass"])]
     ns = len(p["labels_syn"])
     ranges = [tuple(p["ranges"][c]) for c in range(p["nclass"])]
     coeffs = [p["ncd"][c] / ns for c in range(p["nclass"])]
-    l, dX, dA = A.syn_match(p["theta"], p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric)
+    l, dX, dA = A.syn_match(p["theta"], p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric, K=K)
     np.testing.assert_allclose(float(l), float(loss), rtol=1e-10)
     np.testing.assert_allclose(dX.numpy(), gx.numpy(), rtol=1e-7, atol=1e-11)
     np.testing.assert_allclose(dA.numpy(), ga.numpy(), rtol=1e-7, atol=1e-11)

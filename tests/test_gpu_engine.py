@@ -22,9 +22,9 @@ def close(got, ref, rtol=1e-3, what=""):
 
 
 def make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, x, f1, f2, bcap=32, metric="ours", inner=2, lrs=(0.01, 0.01, 0.01),
-                csr=None, pools=None, external=True, seed=1, model="SGC", with_bn=False):
+                csr=None, pools=None, external=True, seed=1, model="SGC", with_bn=False, fmid=()):
     from graphslim_amd.engine import EngineShapes, GCondEngine
-    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, ph, bcap, f1, f2, model=model, with_bn=with_bn)
+    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, ph, bcap, f1, f2, model=model, with_bn=with_bn, fmid=tuple(fmid))
     cls_ptr = cls_nodes = None
     if pools is not None:
         cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
@@ -33,32 +33,35 @@ def make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, x, f1, f2, bcap
                        lr_model=lrs[2], inner_loop=inner, dis_metric=metric, seed=seed, external_blocks=external, device=DEV)
 
 
-@pytest.mark.parametrize("tag,metric", [("t1", "ours"), ("t2", "ours"), ("t1mse", "mse"), ("gcn", "ours")])
+@pytest.mark.parametrize("tag,metric", [("t1", "ours"), ("t2", "ours"), ("t1mse", "mse"), ("gcn", "ours"), ("k3t1", "ours"), ("k3t2", "ours")])
 def test_train_class_against_reference_golden(golden_dir, tag, metric):
-    """G7: loss, d loss/d A^, d loss/d X~, d loss/d theta_PGE of the reference's train_class + backward."""
+    """G7: loss, d loss/d A^, d loss/d X~, d loss/d theta_PGE of the reference's train_class + backward.  G24 (tags k3*, round 5): the
+    same with `--nlayers 3` — three sampled hops (a MIDDLE block with its CSC between hop 1 and the outermost block) on the real side,
+    Q = A^^3 with the product rule for d A^ on the synthetic side (dataset/loader.py:205-206, models/sgc.py:45-51)."""
     from graphslim_amd.engine import BlockSet
-    g = load_golden(golden_dir, "g7_train_class")
+    g = load_golden(golden_dir, "g24_train_class_three_hops" if tag.startswith("k3") else "g7_train_class")
     batches, (n, nclass, d, hidden, t), _ = rebuild_batches(g, tag)
     labels_syn = g[f"{tag}_labels_syn"]
     _, ncd, ranges = O.generate_labels_syn(g[f"{tag}_y"][g[f"{tag}_idx_train"]], float(g[f"{tag}_rate"]))
     ranges = [tuple(ranges[c]) for c in range(nclass)]
     ph = g[f"{tag}_pge2"].shape[0]
-    f1, f2 = [int(s) for s in g[f"{tag}_sizes"]]
+    sizes = [int(s) for s in g[f"{tag}_sizes"]]
+    f1, f2, fmid = sizes[0], sizes[-1], tuple(sizes[1:-1])
     kind = "GCN" if tag == "gcn" else "SGC"
     if kind == "GCN":
         t = 2
-    eng = make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, metric=metric, model=kind)
+    eng = make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, metric=metric, model=kind, fmid=fmid)
     eng.set_feat(T(g[f"{tag}_feat_syn"]))
     eng.set_pge([T(g[f"{tag}_pge{i}"]) for i in range(10)])
     theta = [T(g[f"{tag}_theta{i}"]) for i in range(2 * t)]
     eng.set_model(theta)
-    eng.set_blocks(BlockSet.from_batches(batches, 32, f1, f2, DEV))
+    eng.set_blocks(BlockSet.from_batches(batches, 32, f1, f2, DEV, fmid=fmid))
     # real side
     eng.stage_real_grads()
     gw = eng.buffer("gw_real", (nclass, -1))
     for c in range(nclass):
         th = [p.clone().requires_grad_(True) for p in theta]
-        ref, _ = O.class_real_grads(kind, th, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), batches[c])
+        ref, _ = O.class_real_grads(kind, th, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), batches[c], len(sizes))
         if metric == "ours" and t == 2 and kind == "SGC":   # biases get distance 0 and D = 0 under 'ours' (utils.py:98-101): the costly
             ref[1] = torch.zeros_like(ref[1])   # first-layer bias gradient (a pass over all sampled edges) is not formed
         close(gw[c], torch.cat([r.reshape(-1) for r in ref]), 2e-4, f"gw_real class {c}")

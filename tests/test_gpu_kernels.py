@@ -276,6 +276,82 @@ def test_sampler_properties(E):
     assert abs(freq.mean() - p) < 1e-9 and freq.std() < 3.5 * np.sqrt(p * (1 - p) / T_)
 
 
+@pytest.mark.parametrize("fmid", [(6,), (4, 3)])
+def test_sampler_middle_hops(E, fmid):
+    """`--nlayers` 3 / 4 (dataset/loader.py:205-208): the hops BETWEEN hop 1 and the outermost one.  Every middle block keeps <= fm
+    neighbours per node of the frontier before it (all of them when deg <= fm, no repeats, full-graph weights bit exact), its frontier
+    holds the previous frontier first and then the new nodes ONCE each in the order of their first edge slot (PyG's relabelling order),
+    its CSC lists every node's in-edges in ascending slot order, the outermost block has one row per node of the last frontier, the
+    marker scratch is restored, and the same (seed, step) reproduces the blocks bit for bit."""
+    n, C = 3000, 5
+    a, x, y = sbm_graph(n, C, 4, 9, seed=5)
+    rp, col, val = O.normalize_adj_sparse(a)
+    rng = np.random.default_rng(1)
+    idx_train = np.sort(rng.permutation(n)[:1200])
+    pools = [idx_train[y[idx_train] == c] for c in range(C)]
+    pools[1] = pools[1][:9]
+    cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
+    cls_nodes = np.concatenate(pools)
+    i32 = lambda v: torch.as_tensor(np.asarray(v), dtype=torch.int32, device=DEV)
+    bcap, f1, f2 = 32, 5, 3
+    blocks = E.BlockSet(C, bcap, f1, f2, DEV, fmid=fmid)
+    marker = torch.full((C * n,), 0x7fffffff, dtype=torch.int32, device=DEV)
+    args = (i32(rp), i32(col), torch.as_tensor(val, device=DEV), n, i32(cls_ptr), i32(cls_nodes), marker, blocks)
+    E.sample_blocks(*args, 77, 3)
+    torch.cuda.synchronize()
+    assert int((marker != 0x7fffffff).sum()) == 0
+    A = sp.csr_matrix((val, col, rp), shape=(n, n))
+    nb = {v: dict(zip(A.indices[A.indptr[v]:A.indptr[v + 1]], A.data[A.indptr[v]:A.indptr[v + 1]])) for v in range(n)}
+    first = {f: getattr(blocks, f).cpu().numpy().copy() for f in blocks.FIELDS}
+    for c in range(C):
+        rows, nid_prev = int(first["n1"][c]), first["nid1"][c, :int(first["n1"][c])]
+        for m, fm in enumerate(fmid):
+            ncur = int(first[f"nm{m}"][c])
+            nid = first[f"nidm{m}"][c, :ncur]
+            colm, valm = first[f"colm{m}"][c], first[f"valm{m}"][c]
+            assert ncur >= rows and np.array_equal(nid[:rows], nid_prev) and len(set(nid.tolist())) == ncur
+            order = []                                            # first-seen order of the new nodes over the slots (row-major)
+            for r in range(rows):
+                v = int(nid_prev[r])
+                w = valm[r]
+                k = int((w != 0).sum())
+                assert k == min(len(nb[v]), fm) and np.all(w[k:] == 0) and np.all(colm[r, k:] == 0)
+                got = nid[colm[r, :k]]
+                assert len(set(got.tolist())) == k
+                for u, ww in zip(got, w[:k]):
+                    assert nb[v][int(u)] == ww
+                    if int(u) not in set(nid_prev.tolist()) and int(u) not in order:
+                        order.append(int(u))
+            assert np.all(valm[rows:] == 0)
+            assert order == nid[rows:].tolist()
+            tp, te = first[f"tptrm{m}"][c], first[f"tedgem{m}"][c]
+            slots = {(r * fm + j) for r in range(rows) for j in range(fm) if valm[r, j] != 0}
+            assert tp[0] == 0 and tp[ncur] == len(slots)
+            seen = set()
+            for l in range(ncur):
+                lst = te[tp[l]:tp[l + 1]]
+                assert np.all(np.diff(lst) > 0)
+                for s_ in lst:
+                    assert colm[s_ // fm, s_ % fm] == l
+                    seen.add(int(s_))
+            assert seen == slots
+            rows, nid_prev = ncur, nid
+        for l in range(rows):                                      # the outermost block: one row per node of the last frontier
+            v = int(nid_prev[l])
+            w = first["val0"][c, l]
+            k = int((w != 0).sum())
+            assert k == min(len(nb[v]), f2)
+            got = first["col0"][c, l, :k]
+            assert len(set(got.tolist())) == k
+            for u, ww in zip(got, w[:k]):
+                assert nb[v][int(u)] == ww
+        assert np.all(first["val0"][c, rows:] == 0)
+    E.sample_blocks(*args, 77, 3)
+    torch.cuda.synchronize()
+    for f in blocks.FIELDS:
+        assert np.array_equal(getattr(blocks, f).cpu().numpy(), first[f]), f
+
+
 def test_sampler_neighbour_subsets_are_uniform(E):
     """loader.py:216-223 / torch_sparse sample_adj semantics at the level the reference defines them (distributional):
     the <= f neighbours kept for a row are a UNIFORM f-subset of its neighbours — every neighbour is kept with probability f / deg

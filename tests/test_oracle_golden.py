@@ -114,9 +114,12 @@ def rebuild_batches(g, tag):
 
 
 @pytest.mark.parametrize("tag,kind,metric", [("t1", "SGC", "ours"), ("t2", "SGC", "ours"), ("t1mse", "SGC", "mse"),
-                                             ("gcn", "GCN", "ours")])
-def test_g7_train_class(golden_dir, tag, kind, metric):
-    g = load(golden_dir, "g7_train_class")
+                                             ("gcn", "GCN", "ours"), ("k3t1", "SGC", "ours"), ("k3t2", "SGC", "ours")])
+def test_g7_g24_train_class(golden_dir, tag, kind, metric):
+    """G7: the reference's train_class + backward (two hops); G24 (tags k3*): the same with `--nlayers 3` — three sampled hops on the
+    real side, adj_syn applied three times on the synthetic side (dataset/loader.py:205-206, models/sgc.py:45-51)."""
+    g = load(golden_dir, "g24_train_class_three_hops" if tag.startswith("k3") else "g7_train_class")
+    nlayers = len(g[f"{tag}_sizes"])
     batches, (n, nclass, d, hidden, t) = rebuild_batches(g, tag)
     nth = 4 if kind == "GCN" else 2 * t
     theta = [T(g[f"{tag}_theta{i}"]).requires_grad_(True) for i in range(nth)]
@@ -130,7 +133,7 @@ def test_g7_train_class(golden_dir, tag, kind, metric):
     adj_norm = O.dense_gcn_norm(adj_syn)
     adj_norm.retain_grad()
     loss = O.train_class(kind, theta, batches, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), feat_syn, adj_norm, labels_syn,
-                         ncd, nclass, 2, metric)
+                         ncd, nclass, nlayers, metric)
     loss.backward()
     # north_star gate: gradient-match loss within 1e-4 relative
     np.testing.assert_allclose(float(loss), float(g[f"{tag}_loss"]), rtol=1e-4)
@@ -238,11 +241,14 @@ def test_g8_full_reduce_and_evaluate(golden_dir, tag):
         list(g[f"{tag}_files"]) == ["adj_ogbn-arxiv_0.5_1.pt", "feat_ogbn-arxiv_0.5_1.pt", "label_ogbn-arxiv_0.5_1.pt"]
 
 
+@pytest.mark.parametrize("fname", ["g9_fit_with_val", "g25_fit_with_val_three_layers"])
 @pytest.mark.parametrize("setting", ["trans", "ind"])
-def test_g9_fit_with_val_trace(golden_dir, setting):
+def test_g9_g25_fit_with_val_trace(golden_dir, setting, fname):
     """models/base.py:80-225 replayed by the oracle from the reference's own initial weights: per-epoch validation
-    accuracy, best-validation restore, final weights and test accuracy."""
-    g = load(golden_dir, "g9_fit_with_val")
+    accuracy, best-validation restore, final weights and test accuracy — the two-layer evaluation GCN (G9) and the three-layer one of
+    `--nlayers 3` (G25, models/gcn.py:8-23)."""
+    g = load(golden_dir, fname)
+    nw = 2 * (int(g["nlayers"]) if "nlayers" in g else 2)
     n, nclass, d, hidden, ns, iters = [int(v) for v in g["meta"]]
     a = sp.coo_matrix((np.ones(len(g["a_row"])), (g["a_row"], g["a_col"])), shape=(n, n)).tocsr()
     x, y = T(g["x"]), T(g["y"])
@@ -254,7 +260,7 @@ def test_g9_fit_with_val_trace(golden_dir, setting):
         feat = x[idx_val]
         adj = O.csr_to_torch(*O.normalize_adj_sparse(a[np.ix_(idx_val, idx_val)]), len(idx_val))
         iv, it = torch.arange(len(idx_val)), torch.arange(len(idx_test))
-    init = [T(g[f"{setting}_init{i}"]) for i in range(4)]
+    init = [T(g[f"{setting}_init{i}"]) for i in range(nw)]
     trace = []
     best, w = O.fit_with_val(init, T(g["adj_syn"]), T(g["feat_syn"]), T(g["labels_syn"]), feat, adj, iv, y[idx_val], iters,
                              lr=0.01, weight_decay=5e-4, trace=trace)
@@ -264,7 +270,7 @@ def test_g9_fit_with_val_trace(golden_dir, setting):
     assert np.abs(got - ref).max() <= 1.0 / len(idx_val) + 1e-12
     assert abs(best - float(g[f"{setting}_best"])) <= 1.0 / len(idx_val) + 1e-12
     if np.array_equal(got, ref):
-        for i in range(4):
+        for i in range(nw):
             np.testing.assert_allclose(w[i].numpy(), g[f"{setting}_final{i}"], rtol=1e-3, atol=1e-5)
     if setting == "trans":
         acc = O.eval_test(w, x, adj, it, y[idx_test])

@@ -237,7 +237,7 @@ def _verify_worker(rank, world, port, q, scenario):
                 return
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
-    def from_dist(dist_=None, group=None):
+    def from_dist(dist_=None, group=None, slot_bytes=0):
         if scenario == "create_raises_on_rank1" and rank == 1:
             raise RuntimeError("injected: communicator could not be created")
         return HostComm()
