@@ -94,10 +94,11 @@ struct gs_gcond {
   unsigned* H1bits;                    // [N][h / 32] sign bits of H1full, written by its product's epilogue: the edge product's mask
   double* sum_part;                    // [128] scratch of sum_f32
   bool tiles_ok;                     // tile_b / tile_my / tile_start are filled (C <= GS_MAX_CLASSES_TILES)
-  bool skip_dfeat;                   // this call of the matching stage need not leave d loss / d X~ (set by the fused outer step only)
+  bool skip_dfeat;                   // this call of the matching stage need not leave d loss / d X~: set by outer_step_impl (sharded or not) around its
+                                     // stage call and cleared right behind it; a class shard zeroes d_feat first, so the exchanged buffer holds zeros
   bool l3_direct;                    // part 1 of the PGE backward left the statistics partials for part 2's prep launch to reduce
   bool bn2_done;                     // part 1 of the PGE forward has already left the BatchNorm-2 statistics (unsharded, fused)
-  bool fold_finish;                  // this call of the matching stage also books the loss (set by the fused outer step only)
+  bool fold_finish;                  // this call of the matching stage also books the loss (unsharded outer_step_impl only; cleared right behind the call)
   int knob[GS_KNOB_COUNT];             // per-engine value of a measurement knob (gs_gcond_set_knob), -1 = follow the process default
   unsigned* edge_bits;                 // [C][cap1 * f2][h / 32] sign bits of the H1 row each hop-2 edge slot gathered (gs_ell_spmm_kernel): the
                                        // edge product reads its ReLU mask from these 32 B per edge instead of the 1-KiB row of H1full

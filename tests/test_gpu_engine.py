@@ -1156,6 +1156,38 @@ def test_with_bn_reduce_api(tmp_path):
     assert 0.0 <= mean <= 1.0
 
 
+@pytest.mark.parametrize("ntrans", [1, 2])
+def test_three_hops_reduce_api(tmp_path, ntrans):
+    """`--nlayers 3` through the reference's own entry points (round 5): GCond.reduce samples [15, 10, 5] neighbours over three hops
+    (dataset/loader.py:205-206), the SGC condensation model propagates three times on both sides (models/sgc.py:45-51), checkpoints
+    and the final Evaluator run train the THREE-layer evaluation GCN (models/gcn.py:8-23: the flag is shared).  Sanity of the whole
+    path; parity is G24 / G25 and test_three_hops_against_the_oracle.  nlayers = 1 is refused like upstream fails (gcond_base.py:213)."""
+    import graphslim  # noqa: F401
+    from graphslim.config import cli
+    from graphslim.condensation import GCond
+    from graphslim.dataset import get_dataset
+    from graphslim.evaluation.eval_agent import Evaluator
+    argv = ["-D", "cora", "-M", "gcond", "-R", "0.5", "-G", "0", "--epochs", "12", "--eval_epochs", "30", "--run_eval", "2",
+            "--ntrans", str(ntrans), "--save_path", str(tmp_path)]
+    args = cli(argv + ["--nlayers", "3"], standalone_mode=False)
+    assert args.nlayers == 3 and args.condense_model == "SGC"
+    args.run_inter_eval, args.checkpoints, args.outer_loop, args.inner_loop = 1, [5, 11], 3, 2
+    graph = get_dataset(args.dataset, args)
+    __import__('graphslim_amd.host', fromlist=['seed_everything']).seed_everything(args.seed)
+    agent = GCond(setting=args.setting, data=graph, args=args)
+    reduced = agent.reduce(graph, verbose=False)
+    assert agent.engine.shapes.nlayers == 3 and agent.engine.shapes.fmid == (10,)
+    assert torch.isfinite(reduced.feat_syn).all() and torch.isfinite(reduced.adj_syn).all()
+    blk = agent.engine.get_blocks()
+    assert blk.fmid == (10,) and int(blk.n_last.min()) >= int(blk.n1.min()) > 0
+    mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
+    assert 0.0 <= mean <= 1.0
+    args1 = cli(argv + ["--nlayers", "1"], standalone_mode=False)
+    graph1 = get_dataset(args1.dataset, args1)
+    with pytest.raises(NotImplementedError):
+        GCond(setting=args1.setting, data=graph1, args=args1).reduce(graph1, verbose=False)
+
+
 def test_full_neighbour_mode_against_the_oracle_on_full_blocks():
     """Full-neighbour mode (SURVEY section 8e "mode F"; loader.py:204 `sizes = [-1, -1]`) for SGC with one transform: the engine
     draws the class seeds, gathers rows of S_full = A^ A^ X / rs_full = A^ A^ 1 (computed once with gs_spmm_csr_f32) — against the
