@@ -347,17 +347,18 @@ class _LockStep:
 
 @pytest.mark.parametrize("pge", ["rows", "replicated"])
 @pytest.mark.parametrize("driver", ["c", "py"])
-@pytest.mark.parametrize("t,world", [(1, 2), (2, 2), (2, 3), (2, 8)])
-def test_sharded_engines_reproduce_the_single_gpu_run(t, world, driver, pge):
+@pytest.mark.parametrize("t,world,fmid", [(1, 2, ()), (2, 2, ()), (2, 3, ()), (2, 8, ()), (2, 3, (3,)), (1, 2, (3, 2))])
+def test_sharded_engines_reproduce_the_single_gpu_run(t, world, driver, pge, fmid):
     """class-parallel + PGE pair-row sharding (or the PGE replicated on every rank: ONE exchange per iteration) with
-    all-reduce(sum) == the unsharded iteration (same sampled blocks because the sampler keys its RNG by the global class id)."""
+    all-reduce(sum) == the unsharded iteration (same sampled blocks because the sampler keys its RNG by the global class id).
+    fmid: middle hops (`--nlayers` 3 / 4): a class shard samples, gathers and back-propagates through its own middle blocks."""
     from graphslim_amd.parallel import Collective, ShardedGCond
     p = _problem(t, seed=21, nclass=5)
 
     def build():
         eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], t, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
                           p["f2"], bcap=p["bcap"], inner=2, lrs=(0.01, 0.005, 0.02), csr=p["csr"], pools=p["pools"],
-                          external=False, seed=5)
+                          external=False, seed=5, fmid=fmid)
         eng.set_feat(p["xs"])
         eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
         return eng
