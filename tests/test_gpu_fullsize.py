@@ -147,6 +147,14 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", re
         else:
             for q, v in zip(st.pge_param_list(), eng.get_pge()):
                 q.copy_(v.cpu())
+    # yardstick for the inference structure: the oracle against ITSELF from X~ (1 + 1e-7 noise) — BatchNorm over n'^2 pair rows divides
+    # by sqrt(var + 1e-5), so a column of E2 with (nearly) no variance amplifies fp32 rounding ~300x in the reference too
+    with torch.no_grad():
+        gq = torch.Generator().manual_seed(4321)
+        pd_ = {"lin": [q.detach() for q in st.pge["lin"]], "bn": [q.detach() for q in st.pge["bn"]]}
+        xs_now = st.feat_syn.detach()
+        out["adj_self"] = float((O.pge_forward(xs_now * (1 + 1e-7 * torch.randn(xs_now.shape, generator=gq)), pd_) -
+                                 O.pge_forward(xs_now, pd_)).abs().max())
     adj_inner = st.inference_and_inner(p["inner"])
     out["adj"] = float((eng.adj_syn.cpu() - adj_inner).abs().max())
     mdiff = torch.cat([(a.cpu() - b.detach()).abs().reshape(-1) for a, b in zip(eng.get_model(), st.model)])
@@ -155,8 +163,12 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", re
     return out
 
 
-def check(r, adj_tol=2e-5):
+def check(r, adj_tol=None):
+    """adj_tol None: 2e-5, or 4x what the oracle's own inference structure moves under a 1e-7 perturbation of X~ (`adj_self`) where
+    that is larger — a measured yardstick per configuration instead of round 4's hand-set 1e-3 / 2e-4 for cora r = 1.0."""
     print(r)
+    if adj_tol is None:
+        adj_tol = max(2e-5, 4.0 * r.get("adj_self", 0.0))
     assert r["rel_loss"] <= 1e-4, r
     assert r["g_feat"] <= 1e-3, r
     for i, e in r["g_pge"]:
@@ -191,7 +203,7 @@ def test_cora_r10_full_size_generated_forms_at_width_128(epoch):
     """Not a BASELINE config: cora at r = 1.0 gives n' = 140 >= 128 with the Planetoid PGE width 128, i.e. the generated-A1
     forward, the fused marginals with the regenerated mask and (feature epochs) the generated dE2 in their N = 128 instantiations
     — against the oracle like the configs above."""
-    check(run_config("cora-r1.0", epoch), adj_tol=1e-3 if epoch == 0 else 2e-4)
+    check(run_config("cora-r1.0", epoch))
 
 
 def test_flickr_r0005_inductive_two_transforms_full_size():
