@@ -641,11 +641,12 @@ def seed_everything(seed):
     torch.manual_seed(seed)
 
 
-def run_eval_gcn(feat_syn, adj_syn, labels_syn, g, hidden, nclass, eval_epochs, lr=0.01):
-    """One `test_with_val` / `Evaluator.test` run: GCN ctor draw + initialize() draw, fit, test."""
+def run_eval_gcn(feat_syn, adj_syn, labels_syn, g, hidden, nclass, eval_epochs, lr=0.01, nlayers=2):
+    """One `test_with_val` / `Evaluator.test` run: GCN ctor draw + initialize() draw, fit, test.  nlayers: GraphConvolution layers
+    (models/gcn.py:8-23; `--nlayers` is shared with the condensation model)."""
     d = feat_syn.shape[1]
-    init_gcn(d, hidden, nclass, 2)            # constructor draw (discarded by initialize())
-    params = init_gcn(d, hidden, nclass, 2)   # fit_with_val -> self.initialize()
+    init_gcn(d, hidden, nclass, nlayers)            # constructor draw (discarded by initialize())
+    params = init_gcn(d, hidden, nclass, nlayers)   # fit_with_val -> self.initialize()
     best_val, w = fit_with_val(params, adj_syn, feat_syn, labels_syn, g["feat_full"], g["adj_full_norm"],
                                g["idx_val"], g["labels_val"], eval_epochs, lr=lr)
     return best_val, eval_test(w, g["feat_full"], g["adj_full_norm"], g["idx_test"], g["labels_test"])

@@ -37,10 +37,15 @@ JOBS = {
     # seeds differ by 0.15 pp, so 40 seeds resolve 2 s.e. < 0.1 pp.  ~2 min per job on 8 cores.
     "cora-quiet": dict(workload="cora-r0.25", scale=1.0, data_seed=1, epochs=50, outer=20, inner=15, threshold=0.05, eval_epochs=150,
                        run_eval=3, lr_model=0.01),
+    # the same quiet job with `--nlayers 3` (three sampled hops [15, 10, 5], three propagations, three-layer evaluation GCN): the job-level
+    # check of round 5's breadth item — fewer seeds (each oracle job is ~3x the two-hop one)
+    "cora-quiet-k3": dict(workload="cora-r0.25-k3", scale=1.0, data_seed=1, epochs=50, outer=20, inner=15, threshold=0.05, eval_epochs=150,
+                          run_eval=3, lr_model=0.01, nlayers=3),
 }
 JOB = JOBS["arxiv-gate"]
 OUT = os.path.join(ROOT, "tests", "golden", "job_accuracy.json")
-OUTS = {"arxiv-gate": OUT, "cora-quiet": os.path.join(ROOT, "tests", "golden", "job_accuracy_cora.json")}
+OUTS = {"arxiv-gate": OUT, "cora-quiet": os.path.join(ROOT, "tests", "golden", "job_accuracy_cora.json"),
+        "cora-quiet-k3": os.path.join(ROOT, "tests", "golden", "job_accuracy_cora_three_hops.json")}
 
 
 def job_problem(job):
@@ -62,8 +67,10 @@ def oracle_job(p, seed, JOB=JOB):
     seed_everything(seed)
     sel = random_init_indices(idx_train, labels_train, p["ncd"])
     pge = init_pge_params(nfeat, p["ph"])
+    nl = len(p["fan"])      # hops sampled = propagations = layers of the evaluation GCN (`--nlayers`)
+    assert nl == JOB.get("nlayers", 2)
     st = O.GCondState(x[sel].clone(), {"lin": pge[:6], "bn": pge[6:]}, torch.from_numpy(p["labels_syn"]), p["ncd"], nclass, p["lrf"],
-                      p["lra"], JOB["lr_model"], "SGC", 2)
+                      p["lra"], JOB["lr_model"], "SGC", nl)
     rng = np.random.default_rng(seed)
     loss_last = 0.0
     for epoch in range(JOB["epochs"]):
@@ -80,7 +87,7 @@ def oracle_job(p, seed, JOB=JOB):
     accs = []
     for i in range(JOB["run_eval"]):
         seed_everything(seed + i)
-        accs.append(float(O.run_eval_gcn(feat, adj, torch.from_numpy(p["labels_syn"]), g, p["hidden"], nclass, JOB["eval_epochs"])[1]))
+        accs.append(float(O.run_eval_gcn(feat, adj, torch.from_numpy(p["labels_syn"]), g, p["hidden"], nclass, JOB["eval_epochs"], nlayers=nl)[1]))
     return accs, loss_last
 
 
