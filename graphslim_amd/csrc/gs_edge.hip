@@ -54,23 +54,11 @@ struct gs_edge_args {
 // The edge lists of the classes differ in length (n1[c] * f2 live slots: 7 400 .. 11 800 at ogbn-arxiv) and a launch of (class x
 // fixed-length slab) workgroups left 22 % of the chip's 512 workgroup slots empty while the others ran 63 K steps (profiles/r04: the
 // longest kernel of the iteration).  The plan cuts the chip's slots over the classes in proportion to their step counts, so that every
-// workgroup runs about total_steps / slots steps.
-//
-// Class -> XCD affinity (`nx` = 8): the slabs of one class gather the same source rows several times over (8.7 k edge slots on 5.4 k
-// distinct rows per class at ogbn-arxiv) and the hardware hands workgroup b to XCD b % 8 (MI355X_MICROARCH.md; an observed dispatch
-// order, so this is a speed matter only: the values do not depend on it), so consecutive workgroup ids spread a class over all eight
-// L2s.  The plan instead deals the classes onto the XCDs (longest list first onto the least loaded XCD) and lays the launch out as
-// workgroup b = x + nx * position: every slab of a class runs on one XCD and the repeats hit that L2.  nx = 1 is the plain class-by-class
-// order (class shards: fewer classes than XCDs would leave L2s idle).
-//
-// plan[0] = nx, plan[1] = positions in use (max over the XCDs), then four [nclass] rows: XCD of the class, its first position on that
-// XCD, its slabs, its slab length (a multiple of the 16-edge step).  Slab `i` of class c is workgroup (and slab buffer entry)
-// xcd[c] + nx * (first[c] + i); `lmax` = positions the launch and the slab buffer hold per XCD (>= nclass: gs_edge_plan checks).
-// Also writes kcount[c] = n1[c] * f2 (gs_kcount_kernel's job).  One wave.
-__global__ __launch_bounds__(64) void gs_edge_plan_kernel(const int* __restrict__ n1, int f2, int nclass, int target, int nx, int lmax,
-                                                          int* __restrict__ kcount, int* __restrict__ plan) {
-  __shared__ int steps[64], xcd[64], nsl[64], order[64];
-  __shared__ long load[8];
+// workgroup runs about total_steps / slots steps: plan[c] = first slab of class c (plan[nclass] = slabs in use), plan[nclass + 1 + c] =
+// slab length of class c (a multiple of the 16-edge step).  Also writes kcount[c] = n1[c] * f2 (gs_kcount_kernel's job).  One wave.
+__global__ __launch_bounds__(64) void gs_edge_plan_kernel(const int* __restrict__ n1, int f2, int nclass, int target, int* __restrict__ kcount,
+                                                          int* __restrict__ plan) {
+  __shared__ int steps[64], nsl[64];
   const int c = threadIdx.x;
   int st = 0;
   if (c < nclass) {
@@ -79,81 +67,25 @@ __global__ __launch_bounds__(64) void gs_edge_plan_kernel(const int* __restrict_
     st = (k + EG_BK - 1) / EG_BK;
   }
   steps[c] = st;
-  xcd[c] = 0;
   __syncthreads();
-  if (c < nclass) {      // rank by length, longest first (ties: lower class first)
-    int r = 0;
-    for (int i = 0; i < nclass; ++i) r += (steps[i] > st) || (steps[i] == st && i < c);
-    order[r] = c;
-  }
-  __syncthreads();
-  if (c == 0) {          // longest list onto the least loaded XCD (<= 64 x 8 scalar steps)
-    for (int x = 0; x < 8; ++x) load[x] = 0;
-    for (int r = 0; r < nclass && nx > 1; ++r) {
-      int best = 0;
-      for (int x = 1; x < nx; ++x) best = load[x] < load[best] ? x : best;
-      xcd[order[r]] = best;
-      load[best] += steps[order[r]];
-    }
-  }
-  __syncthreads();
-  const int x = xcd[c], slots = target / nx > 0 ? target / nx : 1;
   long total = 0;
-  int mine = 0;
-  if (c < nclass) {
-    for (int i = 0; i < nclass; ++i) total += xcd[i] == x ? steps[i] : 0;
-    mine = (int)(((long)slots * st) / (total > 0 ? total : 1));
-    if (mine < 1) mine = 1;
-  }
-  nsl[c] = mine;
-  __syncthreads();
-  if (c < nclass) {      // slots the floor left over go to the first classes of the XCD, one each
-    int sum = 0, before = 0;
-    for (int i = 0; i < nclass; ++i)
-      if (xcd[i] == x) { sum += nsl[i]; before += i < c; }
-    if (before < slots - sum) ++mine;
-  }
-  __syncthreads();
-  nsl[c] = mine;
-  __syncthreads();
-  if (c == 0) {          // more classes than slots on an XCD (every class keeps >= 1 slab): trim the largest until the launch holds them
-    for (int xx = 0; xx < nx; ++xx)
-      for (;;) {
-        int sum = 0, big = -1;
-        for (int i = 0; i < nclass; ++i)
-          if (xcd[i] == xx) { sum += nsl[i]; if (nsl[i] > 1 && (big < 0 || nsl[i] > nsl[big])) big = i; }
-        if (sum <= lmax || big < 0) break;
-        --nsl[big];
-      }
-  }
-  __syncthreads();
-  int chunk = EG_BK;
-  mine = nsl[c];
+  for (int i = 0; i < nclass; ++i) total += steps[i];
+  int mine = 0, chunk = EG_BK;
   if (c < nclass && st > 0) {
+    mine = (int)(((long)target * st) / (total > 0 ? total : 1));
+    if (mine < 1) mine = 1;
     const int per = (st + mine - 1) / mine;          // steps per slab
     mine = (st + per - 1) / per;                     // slabs that are not empty
     chunk = per * EG_BK;
   }
-  __syncthreads();
   nsl[c] = mine;
   __syncthreads();
   if (c < nclass) {
     int base = 0;
-    for (int i = 0; i < c; ++i) base += xcd[i] == x ? nsl[i] : 0;
-    plan[2 + c] = x;
-    plan[2 + nclass + c] = base;
-    plan[2 + 2 * nclass + c] = mine;
-    plan[2 + 3 * nclass + c] = chunk;
-  }
-  if (c == 0) {
-    int used = 0;
-    for (int xx = 0; xx < nx; ++xx) {
-      int sum = 0;
-      for (int i = 0; i < nclass; ++i) sum += xcd[i] == xx ? nsl[i] : 0;
-      used = sum > used ? sum : used;
-    }
-    plan[0] = nx;
-    plan[1] = used;
+    for (int i = 0; i < c; ++i) base += nsl[i];
+    plan[c] = base;
+    plan[nclass + 1 + c] = chunk;
+    if (c == nclass - 1) plan[nclass] = base + mine;
   }
 }
 
@@ -162,12 +94,12 @@ __global__ void gs_reduce_slabs_plan_kernel(float* __restrict__ out, long out_st
                                             long slab_stride, const int* __restrict__ plan) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  const int b = blockIdx.y, nb = gridDim.y;
-  const int nx = plan[0], x = plan[2 + b], lo = plan[2 + nb + b], n = plan[2 + 2 * nb + b];
+  const int b = blockIdx.y;
+  const int lo = plan[b], hi = plan[b + 1];
   const float4* sl = reinterpret_cast<const float4*>(slabs) + i;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = 0; k < n; ++k) {
-    const float4 v = sl[(long)(x + nx * (lo + k)) * (slab_stride >> 2)];
+  for (int k = lo; k < hi; ++k) {
+    const float4 v = sl[(long)k * (slab_stride >> 2)];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   reinterpret_cast<float4*>(out + (long)b * out_stride)[i] = s;
@@ -294,17 +226,12 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
   int slab = blockIdx.x, c = blockIdx.y, kchunk = p.kchunk;
   const int m0 = blockIdx.z * 128;
   float* __restrict__ out;
-  if (p.plan) {      // balanced slabs: workgroup b = XCD x + nx * position; the classes of an XCD follow each other along its positions
-    const int nx = p.plan[0], x = (int)blockIdx.x % nx, pos = (int)blockIdx.x / nx;
-    if (pos >= p.plan[1]) return;
-    c = -1;
-    for (int i = 0; i < p.nclass; ++i) {      // (wave-uniform: scalar loads of <= 3 x 64 words)
-      const int lo = p.plan[2 + p.nclass + i];
-      if (p.plan[2 + i] == x && pos >= lo && pos < lo + p.plan[2 + 2 * p.nclass + i]) c = i;
-    }
-    if (c < 0) return;
-    slab = pos - p.plan[2 + p.nclass + c];
-    kchunk = p.plan[2 + 3 * p.nclass + c];
+  if (p.plan) {      // balanced slabs: blockIdx.x counts the launch's slabs, class by class
+    if ((int)blockIdx.x >= p.plan[p.nclass]) return;
+    c = 0;
+    while (c + 1 < p.nclass && p.plan[c + 1] <= (int)blockIdx.x) ++c;      // (wave-uniform: scalar loads of <= 64 words)
+    slab = (int)blockIdx.x - p.plan[c];
+    kchunk = p.plan[p.nclass + 1 + c];
     out = p.out + (long)blockIdx.x * p.sOs;
   } else {
     out = p.out + (long)c * p.sOc + (long)slab * p.sOs;
@@ -430,12 +357,11 @@ bool gs_edge_eligible(const gs_gemm_desc& p) {
   return true;
 }
 
-// plan / planned launch / planned reduction (engine-internal, csrc/gs_engine.hip): `plan` holds 4 nclass + 2 ints, `max_slabs` = slabs
-// the buffer holds (a multiple of nx, >= nx * nclass; target + nclass positions keep every slot in use)
-int gs_edge_plan(const int* n1, int f2, int nclass, int target, int nx, int max_slabs, int* kcount, int* plan, hipStream_t s) {
-  if (nclass < 1 || nclass > 64 || target < 1 || (nx != 1 && nx != 8)) GS_FAIL(GS_ERR_ARG, "gs_edge_plan: 1 <= nclass <= 64, target >= 1, nx 1 | 8");
-  if (max_slabs / nx < nclass) GS_FAIL(GS_ERR_ARG, "gs_edge_plan: the slab buffer must hold nclass positions per XCD");
-  hipLaunchKernelGGL(gs_edge_plan_kernel, dim3(1), dim3(64), 0, s, n1, f2, nclass, target, nx, max_slabs / nx, kcount, plan);
+// plan / planned launch / planned reduction (engine-internal, csrc/gs_engine.hip): `plan` holds 2 nclass + 1 ints, `max_slabs` bounds
+// the slabs the plan may use (target + nclass fit the slab buffer)
+int gs_edge_plan(const int* n1, int f2, int nclass, int target, int* kcount, int* plan, hipStream_t s) {
+  if (nclass < 1 || nclass > 64 || target < 1) GS_FAIL(GS_ERR_ARG, "gs_edge_plan: 1 <= nclass <= 64, target >= 1");
+  hipLaunchKernelGGL(gs_edge_plan_kernel, dim3(1), dim3(64), 0, s, n1, f2, nclass, target, kcount, plan);
   GS_LAUNCH_CHECK();
   return GS_OK;
 }
@@ -462,7 +388,7 @@ static int edge_launch(const gs_gemm_desc& d, const int* plan, int max_slabs, hi
   a.kcount = d.Kb; a.kchunk = d.kchunk;
   a.out = d.C; a.sOc = d.sCb1; a.sOs = d.sCb2;
   a.plan = plan; a.nclass = d.nb1;
-  const dim3 grid(plan ? max_slabs - max_slabs % 8 : d.nb2, plan ? 1 : d.nb1, gs_cdiv(d.M, 128)), block(256);
+  const dim3 grid(plan ? max_slabs : d.nb2, plan ? 1 : d.nb1, gs_cdiv(d.M, 128)), block(256);
   const bool bits = d.bgen_bits != nullptr && d.bgen_ldbits >= 8;
 #define GS_EDGE_LAUNCH(MODE_)                                                                    \
   do {                                                                                           \

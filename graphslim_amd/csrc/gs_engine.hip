@@ -13,7 +13,7 @@ extern "C" int gs_reduce_slabs_batched_f32(float*, long, const float*, long, int
 extern "C" int gs_reduce_slabs_f32(float*, const float*, long, int, long, float, gs_stream_t);
 int gs_reduce_slabs_active(float*, long, const float*, long, int, long, int, const int*, int, gs_stream_t);
 bool gs_edge_eligible(const gs_gemm_desc& p);                                                      // gs_edge.hip
-int gs_edge_plan(const int* n1, int f2, int nclass, int target, int nx, int max_slabs, int* kcount, int* plan, hipStream_t s);
+int gs_edge_plan(const int* n1, int f2, int nclass, int target, int* kcount, int* plan, hipStream_t s);
 int gs_edge_launch_plan(const gs_gemm_desc& d, const int* plan, int max_slabs, hipStream_t s);
 int gs_reduce_slabs_plan(float* out, long out_stride, const float* slabs, long n, long slab_stride, int nbatch, const int* plan, hipStream_t s);
 int gs_reduce_slabs_pair(float*, const float*, long, int, long, float*, const float*, long, int, long, gs_stream_t);
@@ -249,8 +249,6 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   // classes in proportion to their live edge counts on the device; the buffer holds `edge_cap` slabs (the plan uses <= target + C)
   e->edge_target = 512 / gs_cdiv(e->d, 128) > 0 ? 512 / gs_cdiv(e->d, 128) : 1;
   e->edge_cap = e->C * e->nsplit_r > e->edge_target + e->C ? e->C * e->nsplit_r : e->edge_target + e->C;
-  if (e->edge_cap < 8 * e->C) e->edge_cap = 8 * e->C;      // (class -> XCD layout: every XCD's positions can hold every class)
-  e->edge_cap = (e->edge_cap + 7) / 8 * 8;
   // dW1 = dE2^T A1 over K = n'^2 pair rows: Ph/128 x Ph/128 output tiles per slab; aim at one full round of the 768
   // resident 128x128 workgroups (2 048 gave 404 workgroups at n' = 454: half the chip idle)
   {
@@ -326,7 +324,7 @@ static size_t carve(gs_gcond* e, void* base) {
     // tens of GB, so it exists there only when it is needed)
     e->Bmat = (e->nmid == 0 || e->cfg.dis_metric != 0) ? w.take<float>(C * capL * f2 * h) : nullptr;
     e->slabs_r = w.take<float>((long)e->edge_cap * d * h);
-    e->edge_plan = w.take<int>(4 * C + 2);
+    e->edge_plan = w.take<int>(2 * C + 1);
   } else {
     e->Tm = e->Y1 = e->Bmat = e->slabs_r = nullptr;
     e->edge_plan = nullptr;
@@ -450,7 +448,6 @@ static int g_defer_last_stage = 1;  // gs_gcond_set_folded_reductions
 static int g_edge_bits = 0;         // the hop-2 gather also writes per-edge sign bits and the edge product reads those (0: the mask rows of H1full)
 static int g_h1_bits = 0;
 static int g_h1_rows = 1;
-static int g_edge_xcd = 1;          // balanced slabs laid out class -> XCD (gs_edge_plan_kernel); 0 = class by class (measurement)
 static int g_edge_plan = 1;         // real-side edge product on balanced slabs (gs_edge_plan); 0 = fixed-length slabs per class (the form of rounds 2-4)
 static int g_chained_products = 1;  // the per-class products of the synthetic match chained through the MFMA accumulator registers, two
                                     // launches (gs_match.hip); 0 = the six batched products
@@ -915,10 +912,6 @@ extern "C" int gs_gcond_set_edge_bits(int on) {
   g_edge_bits = on != 0;
   return GS_OK;
 }
-extern "C" int gs_gcond_set_edge_xcd(int on) {
-  g_edge_xcd = on != 0;
-  return GS_OK;
-}
 extern "C" int gs_gcond_set_edge_plan(int on) {
   g_edge_plan = on < 0 ? 0 : on;      // 0 off, 1 on (default number of slabs), > 1: on with that many slabs aimed at (measurement)
   return GS_OK;
@@ -1106,10 +1099,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       // iteration, fixed slabs 1 556); alone on the chip (forward reuse, staged calls) every slot
       int target = g_edge_plan > 1 ? g_edge_plan / gs_cdiv(d, 128) : (e->real_beside ? e->edge_target - e->edge_target / 8 : e->edge_target);
       if (target > e->edge_cap - Cl) target = e->edge_cap - Cl;
-      // every slab of a class on one XCD's L2 (the class's slabs gather the same source rows several times over); class shards with
-      // fewer classes than two per XCD keep the plain order
-      const int nx = g_edge_xcd && Cl >= 16 && target >= 64 ? 8 : 1;
-      GS_TRY(gs_edge_plan(nL, f2, Cl, target < 1 ? 1 : target, nx, e->edge_cap, kcount, e->edge_plan, s));
+      GS_TRY(gs_edge_plan(nL, f2, Cl, target < 1 ? 1 : target, kcount, e->edge_plan, s));
     }
     else if (fused)
       hipLaunchKernelGGL(gs_kcount_kernel, dim3(gs_cdiv(Cl, 64)), dim3(64), 0, s, nL, f2, Cl, kcount);
@@ -2740,7 +2730,7 @@ extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* 
       // PGE layer-2 pre-activations of this rank's pair rows and the BatchNorm-2 batch statistics (kernel A/B tests)
       {"E2", e->E2, (long)(e->r_hi - e->r_lo) * n * Ph}, {"mu2", e->mu2, Ph}, {"is2", e->is2, Ph},
       {"edge_bits", e->edge_bits, e->edge_bits ? (long)C * e->cap1 * e->f2 * (e->h / 32) : 0},
-      {"edge_plan", e->edge_plan, e->edge_plan ? 4L * C + 2 : 0},      // balanced slabs of the last real-side stage (ints)
+      {"edge_plan", e->edge_plan, e->edge_plan ? 2L * C + 1 : 0},      // balanced slabs of the last real-side stage (ints)
       // hidden activations of the synthetic rows and their gradient as the last inner step left them (two-transform models)
       {"H1s", e->H1s, e->H1s ? n * e->h : 0}, {"dH1m", e->dH1m, e->dH1m ? n * e->h : 0},
       // PGE backward intermediates where they are materialised (diagnosis: tools/diag_panel_stages.py)

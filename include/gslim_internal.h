@@ -98,11 +98,6 @@ int gs_gcond_set_edge_plan(int on);
  * 0 = rows in memory order over all XCDs.  Same values (every row is computed by the same code either way). */
 int gs_gcond_set_ell_xcd(int on);
 
-/* Measurement knob: 1 (default) = the balanced slabs of the real-side edge product are laid out class -> XCD (every slab of a class on
- * one XCD: workgroup = XCD + 8 * position, csrc/gs_edge.hip gs_edge_plan_kernel) when the launch has >= 16 classes; 0 = class by class
- * over all XCDs.  The partition of a class's edge list — and with it the fp32 summation order — may differ between the two. */
-int gs_gcond_set_edge_xcd(int on);
-
 /* Priority of the second (real-side) stream of engines created AFTER the call: -1 = highest (default), 0 = normal, 1 = lowest. */
 int gs_gcond_set_aux_priority(int level);
 
