@@ -147,14 +147,26 @@ def _prop(adj, x):
     return adj @ x
 
 
-def sgc_forward(x, adj, params, nlayers=2):
-    """models/sgc.py:37-57: T x (x@W+b [relu]) then K propagations, log_softmax.
+# Dropout of the condensation model (models/sgc.py:42: F.dropout(x, self.dropout, training=self.training) behind every transform but
+# the last; the model is in training mode inside train_class and the inner steps, gcond.py:45, so each forward call draws a fresh mask:
+# one per class on the real batch, one per class on the synthetic graph, one per inner step).  DROPOUT = None: dropout 0 (every shipped
+# configuration).  Otherwise a callable DROPOUT(where, x) -> multiplier of x's shape (kept entries 1 / (1 - p), dropped entries 0), with
+# `where` = (kind, index, rows): kind "real" | "syn" | "inner", index = the class (real, syn) or the inner step, rows = the batch's node
+# ids n_id (real) or None (every synthetic row).  The golden test replays the reference's recorded masks through it (G26); the GPU
+# tests hand it the engine's counter-based masks (graphslim_amd.engine.dropout_keep).
+DROPOUT = None
+
+
+def sgc_forward(x, adj, params, nlayers=2, where=None):
+    """models/sgc.py:37-57: T x (x@W+b [relu, dropout]) then K propagations, log_softmax.
     `adj` is a dense tensor, one sparse tensor, or a list (outermost hop first)."""
     nl = len(params) // 2
     for i in range(nl):
         x = x @ params[2 * i] + params[2 * i + 1]
         if i != nl - 1:
             x = F.relu(x)
+            if DROPOUT is not None:
+                x = x * DROPOUT(where, x)
     for i in range(nlayers):
         x = _prop(adj[i] if isinstance(adj, (list, tuple)) else adj, x)
     return F.log_softmax(x, dim=1)
@@ -348,21 +360,23 @@ def block_to_torch(block, dtype=torch.float32):
 # --------------------------------------------------------------------------------------------
 
 
-def model_forward(kind, x, adj, params, nlayers):
+def model_forward(kind, x, adj, params, nlayers, where=None):
     if kind == "SGC":
-        return sgc_forward(x, adj, params, nlayers)
+        return sgc_forward(x, adj, params, nlayers, where)
+    if DROPOUT is not None:
+        raise NotImplementedError("oracle: dropout is restated for SGC without BatchNorm only")
     if kind == "SGC_BN":
         return sgc_bn_forward(x, adj, params, nlayers)
     return gcn_forward(x, adj, params)
 
 
-def class_real_grads(kind, params, features, labels, batch, nlayers=2):
+def class_real_grads(kind, params, features, labels, batch, nlayers=2, cls=None):
     """gcond_base.py:212-224: gradient of the real-batch NLL wrt model parameters (detached)."""
     batch_size, n_id, adjs = batch
     n_id = torch.as_tensor(n_id)
     dt = params[0].dtype
     adjs_t = [block_to_torch(a, dt) for a in adjs]
-    out = model_forward(kind, features[n_id], adjs_t, params, nlayers)
+    out = model_forward(kind, features[n_id], adjs_t, params, nlayers, ("real", cls, n_id))
     loss = F.nll_loss(out, labels[n_id[:batch_size]])
     gw = torch.autograd.grad(loss, params)
     return [g.detach().clone() for g in gw], loss.detach()
@@ -376,8 +390,8 @@ def train_class(kind, params, batches, features, labels, feat_syn, adj_syn_norm,
     loss = torch.zeros((), dtype=feat_syn.dtype)
     parts = []
     for c in range(nclass):
-        gw_real, _ = class_real_grads(kind, params, features, labels, batches[c], nlayers)
-        out_syn = model_forward(kind, feat_syn, adj_syn_norm, params, nlayers)
+        gw_real, _ = class_real_grads(kind, params, features, labels, batches[c], nlayers, c)
+        out_syn = model_forward(kind, feat_syn, adj_syn_norm, params, nlayers, ("syn", c, None))
         m = labels_syn == c
         loss_syn = F.nll_loss(out_syn[m], labels_syn[m])
         gw_syn = torch.autograd.grad(loss_syn, params, create_graph=True)
@@ -473,8 +487,8 @@ class GCondState:
                                                                  "bn": [p.detach() for p in self.pge["bn"]]})
                 adj_inner_norm = dense_gcn_norm(adj_inner)
         if run_inner:
-            for _ in range(inner_loop):
-                out = model_forward(self.kind, self.feat_syn.detach(), adj_inner_norm, self.model, self.nlayers)
+            for i in range(inner_loop):
+                out = model_forward(self.kind, self.feat_syn.detach(), adj_inner_norm, self.model, self.nlayers, ("inner", i, None))
                 gm = torch.autograd.grad(F.nll_loss(out, self.labels_syn), self.model)
                 self.opt_model.step(list(gm))
         return loss.detach(), grads[0].detach(), adj_inner
@@ -504,8 +518,8 @@ class GCondState:
             adj_inner = pge_forward(feat_inner, {"lin": [p.detach() for p in self.pge["lin"]],
                                                  "bn": [p.detach() for p in self.pge["bn"]]})
             adj_inner_norm = dense_gcn_norm(adj_inner)
-        for _ in range(inner_loop):
-            out = model_forward(self.kind, feat_inner, adj_inner_norm, self.model, self.nlayers)
+        for i in range(inner_loop):
+            out = model_forward(self.kind, feat_inner, adj_inner_norm, self.model, self.nlayers, ("inner", i, None))
             l_in = F.nll_loss(out, self.labels_syn)
             gm = torch.autograd.grad(l_in, self.model)
             self.opt_model.step(list(gm))

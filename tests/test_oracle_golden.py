@@ -198,6 +198,69 @@ def test_g16_g23_with_bn_train_class_and_inner_steps(golden_dir, fname, tag, met
         np.testing.assert_allclose(q.detach().numpy(), g[f"{tag}_theta_after{i}"], rtol=1e-4, atol=2e-5)
 
 
+def replay_masks(g, tag, nclass, p_drop, dtype=torch.float32):
+    """oracle DROPOUT hook that replays the multipliers the reference drew (golden G26: one per class on the real batch, one per class on
+    the synthetic graph — in train_class's call order — then one per inner step)."""
+    def hook(where, x):
+        kind, index, _rows = where
+        i = {"real": 2 * index, "syn": 2 * index + 1, "inner": 2 * nclass + index}[kind]
+        m = torch.from_numpy(g[f"{tag}_mask{i}"].astype(np.float32)).to(dtype) / (1.0 - p_drop)
+        assert m.shape == x.shape, (where[:2], m.shape, x.shape)
+        return m
+    return hook
+
+
+def test_g26_dropout_train_class_and_inner_steps(golden_dir):
+    """Dropout in the condensation model (models/sgc.py:42; training mode inside train_class and the inner steps, gcond.py:45): the
+    reference's train_class + backward and two inner steps on an SGC with two transforms and dropout 0.4, with the masks torch drew
+    recorded in the fixture and replayed here — pins WHERE the restatement applies dropout (behind relu, before the second transform),
+    WHEN it draws (per class: real batch then synthetic graph; once per inner step) and the 1 / (1 - p) scaling."""
+    g, tag = load(golden_dir, "g26_dropout"), "dr"
+    p_drop = float(g[f"{tag}_dropout"])
+    batches, (n, nclass, d, hidden, t) = rebuild_batches(g, tag)
+    theta = [T(g[f"{tag}_theta{i}"]).requires_grad_(True) for i in range(4)]
+    ps = [T(g[f"{tag}_pge{i}"]).requires_grad_(True) for i in range(10)]
+    pge = {"lin": ps[:6], "bn": ps[6:]}
+    feat_syn = T(g[f"{tag}_feat_syn"]).requires_grad_(True)
+    labels_syn = T(g[f"{tag}_labels_syn"])
+    _, ncd, _ = O.generate_labels_syn(g[f"{tag}_y"][g[f"{tag}_idx_train"]], float(g[f"{tag}_rate"]))
+    adj_norm = O.dense_gcn_norm(O.pge_forward(feat_syn, pge))
+    adj_norm.retain_grad()
+    O.DROPOUT = replay_masks(g, tag, nclass, p_drop)
+    try:
+        loss = O.train_class("SGC", theta, batches, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), feat_syn, adj_norm, labels_syn, ncd, nclass, 2,
+                             "ours")
+        loss.backward()
+        np.testing.assert_allclose(float(loss), float(g[f"{tag}_loss"]), rtol=1e-4)
+
+        def close(a, ref, rtol=2e-3):
+            np.testing.assert_allclose(a, ref, rtol=rtol, atol=1e-4 * np.abs(ref).max())
+
+        close(adj_norm.grad.numpy(), g[f"{tag}_dadj_norm"])
+        close(feat_syn.grad.numpy(), g[f"{tag}_dfeat"])
+        for i, p in enumerate(ps):
+            ref = g[f"{tag}_dpge{i}"]
+            if np.abs(ref).max() > 1e-6:
+                close(p.grad.numpy(), ref)
+        th = [T(g[f"{tag}_theta{i}"]).requires_grad_(True) for i in range(4)]
+        opt = O.Adam(th, 0.01)
+        with torch.no_grad():
+            adj_in = O.dense_gcn_norm(O.pge_forward(feat_syn.detach(), pge))
+        for it in range(2):
+            out = O.model_forward("SGC", feat_syn.detach(), adj_in, th, 2, ("inner", it, None))
+            li = torch.nn.functional.nll_loss(out, labels_syn)
+            np.testing.assert_allclose(float(li), float(g[f"{tag}_inner_losses"][it]), rtol=1e-5)
+            opt.step(torch.autograd.grad(li, th))
+        for i, q in enumerate(th):
+            np.testing.assert_allclose(q.detach().numpy(), g[f"{tag}_theta_after{i}"], rtol=1e-4, atol=2e-5)
+    finally:
+        O.DROPOUT = None
+    # without the masks the restatement lands somewhere else: the fixture gates the dropout path, not the dropout-free one
+    loss0 = O.train_class("SGC", [q.detach().requires_grad_(True) for q in theta], batches, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]),
+                          feat_syn, O.dense_gcn_norm(O.pge_forward(feat_syn, pge)), labels_syn, ncd, nclass, 2, "ours")
+    assert abs(float(loss0) - float(g[f"{tag}_loss"])) > 1e-2 * abs(float(g[f"{tag}_loss"]))
+
+
 @pytest.mark.parametrize("tag", ["cora_like", "arxiv_like"])
 def test_g8_full_reduce_and_evaluate(golden_dir, tag):
     """Replays a whole reference run (GCond.__init__ + reduce + intermediate evals + Evaluator.evaluate)."""
