@@ -43,7 +43,7 @@ class GCondConfig(C.Structure):
                 ("f2", C.c_int), ("dis_metric", C.c_int), ("inner_loop", C.c_int),
                 ("lr_feat", C.c_float), ("lr_adj", C.c_float), ("lr_model", C.c_float), ("seed", C.c_uint64),
                 ("external_blocks", C.c_int), ("condense_model", C.c_int), ("pge_chunks", C.c_int), ("with_bn", C.c_int),
-                ("nlayers", C.c_int), ("fmid", C.c_int * 3)]
+                ("nlayers", C.c_int), ("fmid", C.c_int * 3), ("dropout", C.c_float)]
 
 
 class GCondIO(C.Structure):
@@ -70,7 +70,8 @@ SYMBOLS = [
     "gs_gcond_outer_step", "gs_gcond_outer_step_ex", "gs_gcond_set_identity_structure", "gs_gcond_read_loss", "gs_gcond_stage_sample",
     "gs_gcond_stage_real_grads", "gs_gcond_stage_real_async", "gs_gcond_stage_pge_forward", "gs_gcond_stage_syn_match",
     "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer", "gs_gcond_get_blocks", "gs_gcond_set_shard",
-    "gs_gcond_set_overlap", "gs_gcond_set_operand_mode", "gs_gcond_set_full_neighbour", "gs_gcond_set_forward_reuse", "gs_gcond_probe",
+    "gs_gcond_set_overlap", "gs_gcond_set_operand_mode", "gs_gcond_set_full_neighbour", "gs_gcond_set_forward_reuse", "gs_gcond_set_dropout_iter",
+    "gs_gcond_get_dropout_iter", "gs_gcond_probe",
     "gs_gcond_probe_read", "gs_gcond_probe_read_spans", "gs_gcond_probe_read_pass", "gs_gcond_probe_read_spmm", "gs_gcond_invalidate_forward", "gs_gcond_forward_cached",
     "gs_gcond_adopt_cached_forward", "gs_gcond_stage_pge_forward_part", "gs_gcond_stage_pge_backward_part", "gs_gcond_stage_syn_finish",
     "gs_gcond_stage_inner_steps", "gs_bias_act_f32", "gs_log_softmax_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
@@ -149,6 +150,8 @@ def lib():
     L.gs_gcond_set_operand_mode.argtypes = [vp, i]
     L.gs_gcond_set_full_neighbour.argtypes = [vp, vp, l, vp]
     L.gs_gcond_set_forward_reuse.argtypes = [vp, i]
+    L.gs_gcond_set_dropout_iter.argtypes = [vp, C.c_uint64]
+    L.gs_gcond_get_dropout_iter.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.gs_gcond_probe.argtypes = [vp, i]
     L.gs_gcond_probe_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.gs_gcond_probe_read_spans.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]

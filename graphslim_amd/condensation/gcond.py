@@ -59,13 +59,17 @@ class _GradMatch(GCondBase):
             # weight / bias are 1-D parameters: distance 0 under 'ours' (utils.py:98-101), part of the mse / cos distances (round 5:
             # the engine maps the folded model's gradients onto the true parameters for those, goldens G16 / G23).
             raise NotImplementedError("graphslim_amd: with_bn is built for condense_model SGC with ntrans = 2")
-        if float(getattr(args, "dropout", 0.0) or 0.0) != 0.0 and not (args.condense_model == "SGC" and args.ntrans == 1):
+        dropout = float(getattr(args, "dropout", 0.0) or 0.0)
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError(f"graphslim_amd: dropout must be in [0, 1), got {dropout}")
+        if dropout != 0.0 and not (args.condense_model == "SGC" and not with_bn):
             # models/sgc.py:38-43 and models/base.py:51-78 apply F.dropout(training=True) after every transform BUT THE LAST, inside
-            # train_class and the inner loop.  With SGC and one transform there is no such layer: the value is accepted and — exactly as
-            # upstream — has no effect.  With a hidden layer the engine has no dropout stage, so a non-zero value must not be silently
-            # ignored; every configs/{gcond,doscond,gcondx,doscondx,msgc,sgdd}/*.json uses dropout = 0.
-            raise NotImplementedError("graphslim_amd: dropout != 0 in a condensation model with a hidden layer (SGC ntrans = 2, GCN) is "
-                                      "not built (the reference's gradient-matching configs all use dropout = 0)")
+            # train_class and the inner loop.  SGC: one transform has no such layer (the value is accepted and — exactly as upstream —
+            # has no effect); two transforms run the engine's dropout stage (golden G26; masks: graphslim_amd.engine.dropout_keep).
+            # The GCN condensation model and with_bn have no dropout stage: a non-zero value must not be silently ignored
+            # (ADVICE r01); every configs/{gcond,doscond,gcondx,doscondx,msgc,sgdd}/*.json uses dropout = 0.
+            raise NotImplementedError("graphslim_amd: dropout != 0 is built for condense_model SGC without with_bn (the reference's "
+                                      "gradient-matching configs all use dropout = 0)")
         labels_syn = np.asarray(data.labels_syn)
         if args.setting == "trans":
             features, adj = data.feat_full, data.adj_full
@@ -80,7 +84,7 @@ class _GradMatch(GCondBase):
         ranges = [tuple(self.syn_class_indices.get(c, (0, 0))) for c in range(nclass)]
         shapes = EngineShapes(features.shape[0], self.d, nclass, self.nnodes_syn, depth, args.hidden, self.pge_hidden,
                               256, sizes[0], sizes[-1], model=args.condense_model, pge_chunks=self.pge_chunks, with_bn=with_bn,
-                              fmid=tuple(sizes[1:-1]))
+                              fmid=tuple(sizes[1:-1]), dropout=dropout if depth == 2 else 0.0)
         cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
         eng = self.engine = GCondEngine(shapes, features, csr, cls_ptr, np.concatenate(pools), labels_syn, ranges,
                                         lr_feat=args.lr_feat, lr_adj=args.lr_adj, lr_model=args.lr,

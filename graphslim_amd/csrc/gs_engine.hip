@@ -170,6 +170,11 @@ struct gs_gcond {
   // computed once by the caller (X never changes): the real-side class gradient needs their seed rows only
   const float* S_full; long ldS; const float* rs_full;
   bool with_bn;
+  // dropout of the condensation model (models/sgc.py:42; SGC with two transforms): masks by gs_drop_mult4 (gs_kernels.h)
+  unsigned drop_thr;                 // 0: no dropout; else round((1 - p) 65536)
+  float drop_q;                      // 1 / (1 - p)
+  unsigned long long drop_iter;      // matching iterations so far (gs_gcond_set_dropout_iter): part of every mask's key
+  float* H1c;                        // [C][n'][h] the hidden activations of the synthetic graph under each class's mask
   long og, obeta, P_base;            // offsets of bn.weight / bn.bias inside theta; parameter count without them
   float *theta_eff, *bn_s2;          // [P], [h]: s_j^2 for the distance statistics of the W1 gradient columns
   float *gw_true_r, *gw_true_s;      // [C][P] each (with_bn under 'mse' / 'cos'): the class gradients mapped to the TRUE parameters
@@ -222,6 +227,14 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   }
   e->P_base = e->P;
   e->with_bn = c.with_bn != 0;
+  // dropout acts behind the hidden transform only (models/sgc.py:38-43): with one transform the value has no effect, as upstream
+  e->drop_thr = 0; e->drop_q = 1.f;
+  if (c.dropout > 0.f && e->T == 2) {
+    const double keep = 1.0 - (double)c.dropout;
+    long thr = (long)(keep * 65536.0 + 0.5);
+    e->drop_thr = (unsigned)(thr < 1 ? 1 : thr > 65535 ? 65535 : thr);
+    e->drop_q = (float)(1.0 / keep);
+  }
   e->og = e->obeta = 0;
   if (e->with_bn) {      // nn.Module.parameters() order: layers.*, then bns.0.weight, bns.0.bias (models/sgc.py:27-35)
     e->og = e->P; e->obeta = e->P + e->h;
@@ -322,7 +335,7 @@ static size_t carve(gs_gcond* e, void* base) {
     e->Tm = w.take<float>(C * bcap * h); e->Y1 = w.take<float>(C * cap1 * h);
     // (the materialised per-edge operand: only the metrics that need the bias gradient use it — with more than two hops it would be
     // tens of GB, so it exists there only when it is needed)
-    e->Bmat = (e->nmid == 0 || e->cfg.dis_metric != 0) ? w.take<float>(C * capL * f2 * h) : nullptr;
+    e->Bmat = (e->nmid == 0 || e->cfg.dis_metric != 0 || e->drop_thr) ? w.take<float>(C * capL * f2 * h) : nullptr;
     e->slabs_r = w.take<float>((long)e->edge_cap * d * h);
     e->edge_plan = w.take<int>(2 * C + 1);
   } else {
@@ -348,6 +361,7 @@ static size_t carve(gs_gcond* e, void* base) {
   } else {
     e->dH2 = e->dHp = e->A1m = e->Bc = e->dH1m = e->slabs_x = nullptr;
   }
+  e->H1c = e->drop_thr ? w.take<float>(C * n * h) : nullptr;
   e->U = w.take<float>(n * Ph); e->V = w.take<float>(n * Ph);
   e->mu1 = w.take<float>(Ph); e->is1 = w.take<float>(Ph); e->mu2 = w.take<float>(Ph); e->is2 = w.take<float>(Ph);
   e->sumU = w.take<float>(Ph); e->sumV = w.take<float>(Ph);
@@ -419,6 +433,13 @@ static int check_cfg(const gs_gcond_config* c) {
     GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: with_bn is built for condense_model SGC with ntrans = 2 (models/sgc.py:27-33 puts BatchNorm "
                                 "layers between transforms only; GCN + with_bn raises upstream, golden G22)");
   if (c->inner_loop < 0) GS_FAIL(GS_ERR_ARG, "gs_gcond: negative inner_loop");
+  if (!(c->dropout >= 0.f && c->dropout < 1.f)) GS_FAIL(GS_ERR_ARG, "gs_gcond: dropout must be in [0, 1)");
+  if (c->dropout > 0.f && !(c->condense_model == 0 && c->ntrans == 1)) {
+    // models/sgc.py:38-43: F.dropout behind every transform but the last, in training mode inside train_class and the inner steps
+    if (c->condense_model != 0 || c->with_bn)
+      GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: dropout != 0 is built for condense_model SGC without BatchNorm");
+    if (c->hidden % 4 != 0 || c->hidden > 1024) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: dropout != 0 needs hidden % 4 == 0, hidden <= 1024");
+  }
   if (c->nlayers != 0 && c->nlayers != 2) {
     // models/sgc.py:45-51 propagates nlayers times, dataset/loader.py:205-210 samples as many hops; nlayers = 1 has no reference run
     // (PyG's sampler hands train_class the single hop's Adj tuple instead of a list: gcond_base.py:213 fails on it)
@@ -552,6 +573,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   if (bad) { delete e; GS_FAIL(GS_ERR_ARG, "gs_gcond_create: class row ranges out of bounds"); }
   if (he != hipSuccess) { delete e; GS_FAIL(GS_ERR_HIP, "gs_gcond_create: initialisation failed: %s", hipGetErrorString(he)); }
   e->step_feat = e->step_pge = e->step_model = 0;
+  e->drop_iter = 0;
   e->sample_step = 0;
   e->have_blocks = false;
   e->c_lo = 0; e->c_hi = e->C; e->r_lo = 0; e->r_hi = e->n;
@@ -593,6 +615,17 @@ extern "C" int gs_gcond_set_forward_reuse(gs_gcond* e, int on) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   e->reuse_fwd = on != 0;
   e->fwd_cached = false;
+  return GS_OK;
+}
+
+extern "C" int gs_gcond_set_dropout_iter(gs_gcond* e, unsigned long long iter) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  e->drop_iter = iter;
+  return GS_OK;
+}
+extern "C" int gs_gcond_get_dropout_iter(gs_gcond* e, unsigned long long* iter) {
+  if (!e || !iter) GS_FAIL(GS_ERR_ARG, "gs_gcond_get_dropout_iter: null argument");
+  *iter = e->drop_iter;
   return GS_OK;
 }
 
@@ -827,7 +860,8 @@ extern "C" int gs_gcond_set_ell_xcd(int on) {
 }
 static bool launch_ell(const int* col, const float* val, const int* nrows, int cap_rows, int f, long col_base_stride,
                        const float* src, long ld_src, const float* rs_in, int F, float* out, long ld_out, float* rs_out, int C,
-                       hipStream_t s, unsigned* ebits = nullptr) {
+                       hipStream_t s, unsigned* ebits = nullptr, unsigned long long dkey0 = 0, int dclass0 = 0, unsigned dthr = 0,
+                       float dq = 1.f) {
   long waves = (long)C * cap_rows;
   int blocks = gs_cdiv(waves, 4);
   // class -> XCD affinity of the gather's workgroups (gs_ell_spmm_kernel; g_ell_xcd: measurement knob, default on)
@@ -836,6 +870,12 @@ static bool launch_ell(const int* col, const float* val, const int* nrows, int c
   const int F4 = (F + 3) & ~3;
   bool vec = (ld_src % 4 == 0) && (ld_out % 4 == 0) && ld_src >= F4 && ld_out >= F4 && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
   const bool bits = vec && ebits && F == 256;
+  if (dthr) {      // dropout on the gathered rows (the hop-2 gather of the hidden activations; 16-byte rows: checked at creation)
+    if (!vec) return false;
+    hipLaunchKernelGGL((gs_ell_spmm_kernel<4, true>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
+                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, (unsigned*)nullptr, xcd, dkey0, dclass0, dthr, dq);
+    return false;
+  }
   if (vec)
     hipLaunchKernelGGL((gs_ell_spmm_kernel<4>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
                        src, ld_src, rs_in, F, out, ld_out, rs_out, C, bits ? ebits : (unsigned*)nullptr, xcd);
@@ -993,7 +1033,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     const long slots = (long)Cl * capL * f2;
     int rows_rc = GS_ERR_UNSUPPORTED;
     // (the sign bits are an output of the row-panel kernel: asked for only where the product takes that route)
-    const bool want_bits = knob_of(e, GS_KNOB_H1_BITS, g_h1_bits) && e->H1bits && e->cfg.dis_metric == 0;
+    const bool want_bits = knob_of(e, GS_KNOB_H1_BITS, g_h1_bits) && e->H1bits && e->cfg.dis_metric == 0 && !e->drop_thr;
     if (knob_of(e, GS_KNOB_H1_ROWS, g_h1_rows) && !e->S_full && e->h1_flag && slots < (long)e->N) {
       GS_HIP(hipMemsetAsync(e->h1_flag, 0, sizeof(int) * (size_t)e->N, s));
       GS_HIP(hipMemsetAsync(e->h1_count, 0, sizeof(int), s));
@@ -1028,9 +1068,12 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       if (!e->probe2_ev[2 * e->probe2_n + q]) GS_HIP(hipEventCreate(&e->probe2_ev[2 * e->probe2_n + q]));
     GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n], s));
   }
-  const bool want_ebits = knob_of(e, GS_KNOB_EDGE_BITS, g_edge_bits) && e->T == 2 && e->cfg.dis_metric == 0 && e->edge_bits && !use_bits;
+  const bool want_ebits = knob_of(e, GS_KNOB_EDGE_BITS, g_edge_bits) && e->T == 2 && e->cfg.dis_metric == 0 && e->edge_bits && !use_bits &&
+                          !e->drop_thr;
+  // dropout (models/sgc.py:42): class c's batch draws its own mask over its n_id rows — here a function of (class, node id, column)
+  const unsigned long long dkey_r = e->drop_thr ? gs_drop_key0(e->cfg.seed, e->drop_iter, 0) : 0ull;
   have_ebits = launch_ell(b.col0, b.val0, nL, capL, f2, 0, src, ld_src, nullptr, F, P0, Fp, rs0, Cl, s,
-                                     want_ebits ? e->edge_bits + c0 * cap1 * f2 * 8 : nullptr);
+                                     want_ebits ? e->edge_bits + c0 * cap1 * f2 * 8 : nullptr, dkey_r, (int)c0, e->drop_thr, e->drop_q);
   if (probe2) {
     GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n + 1], s));
     e->probe2_n++;
@@ -1089,7 +1132,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
                            b.nm[m], b.capm[m], capp, b.fm[m], YL, h, Ym, Cl);
       YL = Ym;
     }
-    const bool fused = (e->cfg.dis_metric == 0);   // 'ours' needs no bias gradient -> Bmat is generated inside the GEMM
+    // 'ours' needs no bias gradient -> Bmat is generated inside the GEMM (dropout: the materialised form carries the mask)
+    const bool fused = (e->cfg.dis_metric == 0) && !e->drop_thr;
     // balanced slabs (knob EDGE_PLAN, default on): the chip's workgroup slots are cut over the classes by their live edge counts
     const bool plan = fused && Cl <= 64 && knob_of(e, GS_KNOB_EDGE_PLAN, g_edge_plan != 0) && e->edge_plan && ((long)d * h) % 4 == 0 &&
                       P % 4 == 0 && e->oW1 % 4 == 0;
@@ -1105,7 +1149,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       hipLaunchKernelGGL(gs_kcount_kernel, dim3(gs_cdiv(Cl, 64)), dim3(64), 0, s, nL, f2, Cl, kcount);
     else
       hipLaunchKernelGGL(gs_make_bmat_kernel, dim3(gs_cdiv((long)Cl * capL * f2, 4)), dim3(256), 0, s, b.col0, b.val0, nL, capL,
-                         f2, e->H1full, (long)h, YL, h, Bmat, kcount, Cl);
+                         f2, e->H1full, (long)h, YL, h, Bmat, kcount, Cl,
+                         e->drop_thr ? gs_drop_key0(e->cfg.seed, e->drop_iter, 0) : 0ull, (int)c0, e->drop_thr, e->drop_q);
     GS_LAUNCH_CHECK();
     // K slabs: the engine's choice fills the chip with ALL classes (derive()); a class shard has fewer classes, so its slabs are
     // shortened until the launch again has ~512 workgroups (one workgroup = one class x slab x 128-feature tile is bound by ONE
@@ -1742,8 +1787,28 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     }
     hipLaunchKernelGGL(gs_rowsum_kernel, dim3(gs_cdiv(n, 4)), dim3(256), 0, s, e->Q, n, n, e->rsq);
   }
+  // dropout (models/sgc.py:42): the synthetic forward of class c draws its own mask over all n' rows, so the hidden activations — and
+  // every product behind them — exist once per class: H1c[c] = H1 * multiplier_c.  Only the rows of class c of S = Q H1c[c] enter its
+  // loss (gcond_base.py:228-230), so the work stays that of one shared forward; the masked products run class by class on the generic
+  // kernels (no shipped configuration uses dropout: this path is built for parity, not tuned).
+  const bool drop = e->drop_thr != 0 && e->T == 2;
+  float* H1c = drop ? e->H1c + c0 * n * h : nullptr;
+  if (drop) {
+    if (e->blk_pos) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: dropout != 0 with a block structure");
+    if (Cl > 0)
+      hipLaunchKernelGGL(gs_drop_rows_kernel, dim3(gs_cdiv((long)Cl * n * (h / 4), 256)), dim3(256), 0, s, e->H1s, H1c, n, h, Cl,
+                         gs_drop_key0(e->cfg.seed, e->drop_iter, 1), (int)c0, e->drop_thr, e->drop_q);
+    GS_LAUNCH_CHECK();
+  }
   {  // S = Q Hin ; Z = S Wl ; P, G
-    if (e->blk_pos) {
+    if (drop) {      // S[lo:hi] = Q[lo:hi] H1c[c]
+      if (part) GS_HIP(hipMemsetAsync(e->Ss, 0, sizeof(float) * (long)n * F, s));
+      if (Cl > 0) {
+        gs_gemm_desc g = mk(e->Q, n, 1, H1c, h, 1, e->Ss, F, mx, F, n);
+        g.nb1 = Cl; g.offA = off_lon; g.Mb = ncls; g.sBb1 = (long)n * h; g.offC = off_loF;
+        GS_TRY(gs_gemm_f32(&g, stream));
+      }
+    } else if (e->blk_pos) {
       GS_TRY(block_apply(e, e->blk_X, false, Hin, F, e->Ss, nullptr, 0, stream));      // blk_X holds the blocks of Q (block_square)
     } else {
       gs_gemm_desc g = mk(e->Q, n, 1, Hin, F, 1, e->Ss, F, n, F, n);
@@ -1771,7 +1836,8 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     float* dH2 = e->T == 2 ? e->dH2 + c0 * n * C : nullptr; float* dHp = e->T == 2 ? e->dHp + c0 * n * h : nullptr;
     float* A1m = e->T == 2 ? e->A1m + c0 * n * h : nullptr; float* Bc = e->T == 2 ? e->Bc + c0 * n * C : nullptr;
     // two chained launches for the per-class products of the two-transform model (gs_match.hip) instead of six batched ones
-    const bool mclass = e->T == 2 && knob_of(e, GS_KNOB_CHAINED_PRODUCTS, g_chained_products) && !e->blk_pos && gs_match_class_eligible(n, h, d, C);
+    const bool mclass = e->T == 2 && knob_of(e, GS_KNOB_CHAINED_PRODUCTS, g_chained_products) && !e->blk_pos && !drop &&
+                        gs_match_class_eligible(n, h, d, C);
     {
       // gWl_c, gbl_c and (T = 2) dH2_c = Q[lo:hi]^T G[lo:hi] only read G: one launch
       gs_gemm_desc g3[3];
@@ -1798,6 +1864,10 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
       // dHp_c = (dH2_c W2^T) * mask ; gW1_c = X^T dHp_c ; gb1_c = colsum
       gs_gemm_desc b = mk(dH2, C, 1, Wl, 1, C, dHp, h, n, h, C);
       b.nb1 = Cl; b.sAb1 = (long)n * C; b.sCb1 = (long)n * h; b.mask = e->H1s; b.ldmask = h;
+      if (drop) {      // the classes' rows under each other: one product whose mask rows are the classes' own ([H1c > 0] / (1 - p))
+        b = mk(dH2, C, 1, Wl, 1, C, dHp, h, Cl * n, h, C);
+        b.mask = H1c; b.ldmask = h; b.alpha = e->drop_q;
+      }
       GS_TRY(gs_gemm_f32(&b, stream));
       gs_gemm_desc c = mk(X, 1, d, dHp, h, 1, gws + e->oW1, h, d, h, n);
       c.nb1 = Cl; c.sBb1 = (long)n * h; c.sCb1 = P;
@@ -1826,9 +1896,15 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
         ax[0] = mk(X, d, 1, Dv + e->oW1, h, 1, A1m, h, n, h, d);
         ax[0].nb1 = Cl; ax[0].sBb1 = P; ax[0].sCb1 = (long)n * h; ax[0].bias = Dv + e->ob1; ax[0].sbias_b1 = P; ax[0].mask = e->H1s;
         ax[0].ldmask = h;
+        if (drop) ax[0].mask = nullptr;      // (masked per class right behind the launch)
         ax[1] = mk(dHp, h, 1, Dv + e->oW1, 1, h, e->slabs_x, d, n, d, h);
         ax[1].nb1 = Cl; ax[1].sAb1 = (long)n * h; ax[1].sBb1 = P; ax[1].sCb1 = (long)n * d;
         GS_TRY(gs_gemm_group_f32(ax, 2, stream));          // independent of each other
+        if (drop) {
+          hipLaunchKernelGGL(gs_drop_mask_scale_kernel, dim3(gs_cdiv((long)Cl * n * h, 256)), dim3(256), 0, s, A1m, H1c, (long)Cl * n * h,
+                             e->drop_q);
+          GS_LAUNCH_CHECK();
+        }
         GS_TRY(gs_reduce_slabs_f32(e->d_feat, e->slabs_x, (long)n * d, Cl, (long)n * d, 0.f, stream));
         gs_gemm_desc b = mk(A1m, h, 1, Wl, C, 1, Bc, C, n, C, h);
         b.nb1 = Cl; b.sAb1 = (long)n * h; b.sCb1 = (long)n * C;
@@ -1909,6 +1985,27 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
     ab2[0].mask = e->H1s; ab2[0].ldmask = h;
     ab2[1] = mk(e->dSs, h, 1, e->H1s, 1, h, e->dQ, n, n, n, h);     // dQ += dS H1^T
     ab2[1].beta = 1.f;
+    if (drop) {      // class by class: dQ[lo:hi] += dS[lo:hi] H1c[c]^T ; dH1m = sum_c (Q[lo:hi]^T dS[lo:hi]) * [H1c[c] > 0] / (1 - p)
+      float* tmp = e->A1m + c0 * n * h;      // (the A1m_c buffers have been consumed)
+      if (Cl > 0) {
+        gs_gemm_desc dq = mk(e->dSs, h, 1, H1c, 1, h, e->dQ, n, mx, n, h);
+        dq.nb1 = Cl; dq.offA = off_loF; dq.Mb = ncls; dq.sBb1 = (long)n * h; dq.offC = off_lon; dq.beta = 1.f;
+        GS_TRY(gs_gemm_f32(&dq, stream));
+      }
+      if (!e->skip_dfeat) {
+        if (Cl > 0) {
+          gs_gemm_desc t = mk(e->Q, 1, n, e->dSs, h, 1, tmp, h, n, h, mx);
+          t.nb1 = Cl; t.offA = off_lon; t.offB = off_loF; t.Kb = ncls; t.sCb1 = (long)n * h;
+          GS_TRY(gs_gemm_f32(&t, stream));
+        }
+        hipLaunchKernelGGL(gs_drop_mask_reduce_kernel, dim3(gs_cdiv((long)n * h, 256)), dim3(256), 0, s, tmp, H1c, (long)n * h, Cl, e->drop_q,
+                           e->dH1m);
+        GS_LAUNCH_CHECK();
+        gs_gemm_desc c = mk(e->dH1m, h, 1, th + e->oW1, 1, h, e->d_feat, d, n, d, h);   // dX += dH1m W1^T
+        c.beta = 1.f;
+        GS_TRY(gs_gemm_f32(&c, stream));
+      }
+    } else
     if (e->skip_dfeat) {      // (PGE epochs of the fused step: d loss / d X~ is not consumed — only dQ is needed from here on)
       GS_TRY(gs_gemm_f32(&ab2[1], stream));
     } else {
@@ -2234,6 +2331,11 @@ static int inner_steps_fused(gs_gcond* e, gs_stream_t stream) {
     gs_gemm_desc a = mk(X, d, 1, th + e->oW1, h, 1, e->H1s, h, n, h, d);
     a.bias = th + e->ob1; a.relu = 1;
     GS_TRY(gs_gemm_f32(&a, stream));                                                     // H1 = relu(X W1 + b1)
+    if (e->drop_thr) {      // models/sgc.py:42 in the inner step's forward (gcond.py:67-72: the model is in training mode): a fresh mask per step
+      hipLaunchKernelGGL(gs_drop_rows_kernel, dim3(gs_cdiv((long)n * (h / 4), 256)), dim3(256), 0, s, e->H1s, e->H1s, n, h, 1,
+                         gs_drop_key0(e->cfg.seed, e->drop_iter, 2), it, e->drop_thr, e->drop_q);
+      GS_LAUNCH_CHECK();
+    }
     gs_gemm_desc t = mk(e->H1s, h, 1, th + e->oWl, C, 1, Tm, C, n, C, h);
     GS_TRY(gs_gemm_f32(&t, stream));                                                     // T = H1 Wl
     // (H1 -> T and R -> dH1 chained through the accumulator registers as in gs_match.hip were measured: 15 workgroups carry each
@@ -2249,7 +2351,7 @@ static int inner_steps_fused(gs_gcond* e, gs_stream_t stream) {
     gs_gemm_desc r = mk(e->Qin, 1, n, e->Gs, C, 1, R, C, n, C, n);
     GS_TRY(gs_gemm_f32(&r, stream));                                                     // R = Q^T G
     gs_gemm_desc dh = mk(R, C, 1, th + e->oWl, 1, C, e->dH1m, h, n, h, C);
-    dh.mask = e->H1s; dh.ldmask = h;
+    dh.mask = e->H1s; dh.ldmask = h; dh.alpha = e->drop_q;      // ([H1 > 0] covers relu and the mask; 1 / (1 - p) or 1)
     GS_TRY(gs_gemm_f32(&dh, stream));                                                    // dH1 = (R Wl^T) * [H1 > 0]
     gs_gemm_desc g4[4];
     g4[0] = mk(X, 1, d, e->dH1m, h, 1, g + e->oW1, h, d, h, n);                          // gW1 = X^T dH1
@@ -2325,6 +2427,12 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
       gs_gemm_desc a = mk(X, d, 1, th + e->oW1, h, 1, e->H1s, h, n, h, d);
       a.bias = th + e->ob1; a.relu = 1;
       GS_TRY(gs_gemm_f32(&a, stream));
+      if (e->drop_thr) {
+        if (e->blk_pos) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: dropout != 0 with a block structure");
+        hipLaunchKernelGGL(gs_drop_rows_kernel, dim3(gs_cdiv((long)n * (h / 4), 256)), dim3(256), 0, s, e->H1s, e->H1s, n, h, 1,
+                           gs_drop_key0(e->cfg.seed, e->drop_iter, 2), it, e->drop_thr, e->drop_q);
+        GS_LAUNCH_CHECK();
+      }
       if (e->blk_pos) {
         GS_TRY(block_apply(e, e->blk_X, false, e->H1s, h, e->S_in, nullptr, 0, stream));
       } else {
@@ -2348,7 +2456,7 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
         GS_TRY(block_apply(e, e->blk_X, true, e->dSs, h, e->dH1m, e->H1s, h, stream));  // (Q^T dS) * mask
       } else {
         gs_gemm_desc dh = mk(e->Qin, 1, n, e->dSs, h, 1, e->dH1m, h, n, h, n);           // (Q^T dS) * mask
-        dh.mask = e->H1s; dh.ldmask = h;
+        dh.mask = e->H1s; dh.ldmask = h; dh.alpha = e->drop_q;
         GS_TRY(gs_gemm_f32(&dh, stream));
       }
       gs_gemm_desc g2[2];
@@ -2524,7 +2632,14 @@ static int pge_backward_x(gs_gcond* e, int need_param_grads, int need_feat_grad,
 //   DosCondX (doscondx.py:42-49): identity structure, feat stepped, nothing else
 // comm != NULL: this rank's share of a sharded iteration (gs_gcond_set_shard), the all-reduce(sum) exchanges issued here on
 // `stream` between the parts — the whole iteration is this ONE host call per rank.
+static int outer_step_body(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_comm* comm, gs_stream_t stream);
 static int outer_step_impl(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_comm* comm,
+                           gs_stream_t stream) {
+  const int rc = outer_step_body(e, step_pge, step_feat, run_inference, run_inner, comm, stream);
+  if (rc == GS_OK) ++e->drop_iter;      // the next iteration's dropout masks (every stage of one iteration reads the same counter)
+  return rc;
+}
+static int outer_step_body(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_comm* comm,
                            gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   if (!comm && (sharded_c(e) || sharded_r(e)))

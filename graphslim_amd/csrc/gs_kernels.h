@@ -4,6 +4,70 @@
 #include "gs_common.h"
 
 // ------------------------------------------------------------------------------------------------
+// Dropout masks of the condensation model (models/sgc.py:42: F.dropout behind the hidden transform, training mode inside train_class
+// and the inner steps).  torch's generator cannot be replayed here, so the masks are a counter-based function of
+// (seed, iteration, kind, index, row, column) — the same Bernoulli(1 - p) entries scaled by 1 / (1 - p):
+//   key  = mix64(mix64(seed) + (iteration << 24) + (kind << 20) + index)      kind 0 = real batch of class `index`, 1 = synthetic
+//                                                                             graph for class `index`, 2 = inner step `index`
+//   word = mix64(key + (row << 8) + (column >> 2))                            row = the node's id in the graph (real) / the synthetic row
+//   kept = ((word >> 16 (column & 3)) & 0xffff) < thr,  thr = round((1 - p) 65536)
+// (splitmix64's finaliser; hidden <= 1024).  graphslim_amd/engine.py dropout_keep restates it for the parity tests.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ unsigned long long gs_mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// key0 = mix64(seed) + (iteration << 24) + (kind << 20): the kernels add the index
+__host__ __device__ __forceinline__ unsigned long long gs_drop_key0(unsigned long long seed, unsigned long long iter, int kind) {
+  return gs_mix64(seed) + (iter << 24) + ((unsigned long long)kind << 20);
+}
+// multipliers of columns col4 .. col4 + 3 (col4 % 4 == 0) of `row`
+__device__ __forceinline__ float4 gs_drop_mult4(unsigned long long key, long row, int col4, unsigned thr, float q) {
+  const unsigned long long w = gs_mix64(key + ((unsigned long long)row << 8) + (unsigned)(col4 >> 2));
+  float4 m;
+  m.x = ((unsigned)(w) & 0xffffu) < thr ? q : 0.f;
+  m.y = ((unsigned)(w >> 16) & 0xffffu) < thr ? q : 0.f;
+  m.z = ((unsigned)(w >> 32) & 0xffffu) < thr ? q : 0.f;
+  m.w = ((unsigned)(w >> 48) & 0xffffu) < thr ? q : 0.f;
+  return m;
+}
+__device__ __forceinline__ float gs_drop_mult1(unsigned long long key, long row, int col, unsigned thr, float q) {
+  const unsigned long long w = gs_mix64(key + ((unsigned long long)row << 8) + (unsigned)(col >> 2));
+  return ((unsigned)(w >> (16 * (col & 3))) & 0xffffu) < thr ? q : 0.f;
+}
+
+// out[c][i][:] = H[i][:] * multiplier(kind, class0 + c, row i)     (one masked copy of the shared hidden activations per class; Cl = 1 with
+// out == H: the inner step's mask in place).  h % 4 == 0.
+__global__ __launch_bounds__(256) void gs_drop_rows_kernel(const float* __restrict__ H, float* __restrict__ out, int n, int h, int Cl,
+                                                           unsigned long long key0, int index0, unsigned thr, float q) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (c, row, col4)
+  const int h4 = h >> 2;
+  if (i >= (long)Cl * n * h4) return;
+  const int c = (int)(i / ((long)n * h4));
+  const long r = i - (long)c * n * h4;
+  const int row = (int)(r / h4), col4 = 4 * (int)(r - (long)row * h4);
+  const float4 m = gs_drop_mult4(gs_mix64(key0 + (unsigned)(index0 + c)), row, col4, thr, q);
+  const float4 v = *reinterpret_cast<const float4*>(H + (long)row * h + col4);
+  *reinterpret_cast<float4*>(out + ((long)c * n + row) * h + col4) = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+}
+// buf = [Hc > 0] * q * buf   (the backward of relu + dropout: Hc = relu(.) * multiplier, so Hc > 0 <=> passed by both)
+__global__ __launch_bounds__(256) void gs_drop_mask_scale_kernel(float* __restrict__ buf, const float* __restrict__ Hc, long total, float q) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) buf[i] = Hc[i] > 0.f ? buf[i] * q : 0.f;
+}
+// out[i] = sum_c [Hc[c][i] > 0] * q * tmp[c][i]      (classes in order: a fixed summation order)
+__global__ __launch_bounds__(256) void gs_drop_mask_reduce_kernel(const float* __restrict__ tmp, const float* __restrict__ Hc, long nh, int Cl,
+                                                                  float q, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nh) return;
+  float s = 0.f;
+  for (int c = 0; c < Cl; ++c) s += Hc[(long)c * nh + i] > 0.f ? tmp[(long)c * nh + i] * q : 0.f;
+  out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
 // ELL block aggregation with gather (sampled-block SpMM, models/sgc.py:46-47 on the real batch).
 // out[(c,row), :] = sum_j val[(c,row,j)] * src[(base_c + col[(c,row,j)]) * ld_src + :]
 // rs_out[(c,row)]  = sum_j val * (rs_in ? rs_in[base_c + col] : 1)
@@ -20,13 +84,16 @@ __device__ __forceinline__ void gs_ell_put_bits(unsigned* __restrict__ dst, cons
   if ((lane & 7) == 0) dst[lane >> 3] = v;
 }
 
-template <int VEC>
+template <int VEC, bool DROP = false>
 __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict__ col, const float* __restrict__ val,
                                                           const int* __restrict__ nrows, int cap_rows, int f,
                                                           long col_base_stride, const float* __restrict__ src, long ld_src,
                                                           const float* __restrict__ rs_in, int F, float* __restrict__ out,
                                                           long ld_out, float* __restrict__ rs_out, int nclass,
-                                                          unsigned* __restrict__ ebits = nullptr, int xcd_map = 0) {
+                                                          unsigned* __restrict__ ebits = nullptr, int xcd_map = 0,
+                                                          unsigned long long dkey0 = 0, int dclass0 = 0, unsigned dthr = 0, float dq = 1.f) {
+  // DROP (VEC = 4 only): every gathered source row is multiplied by the dropout mask of (class dclass0 + c, source row, column) before it
+  // is summed — the hop-2 gather of H1 = relu(X W1 + b1) under models/sgc.py:42 (see gs_drop_mult4).
   // ebits (VEC = 4, F = 256, optional): per edge slot (grow * f + j) the sign bits of the gathered source row, bit (n & 31) of word
   // n >> 5 = [src[col_j][n] > 0] — 8 words = 32 B.  The hop-2 gather has every source row of H1 = relu(X W1 + b1) in registers; the
   // edge product then reads its ReLU mask from these 32 B per edge instead of gathering the 1-KiB fp32 row again.
@@ -70,6 +137,7 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
   // plain loop: identical sums)
   const int ecol = (lane < f) ? col[ebase + lane] : 0;
   const int evalb = (lane < f) ? __float_as_int(val[ebase + lane]) : 0;
+  const unsigned long long dkey = DROP ? gs_mix64(dkey0 + (unsigned)(dclass0 + c)) : 0ull;
   for (int c0 = lane * VEC; c0 < F; c0 += 64 * VEC) {
     if (VEC == 4) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -81,6 +149,10 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
         for (int u = 0; u < 4; ++u) {
           w[u] = __int_as_float(__builtin_amdgcn_readlane(evalb, j + u));
           x[u] = *reinterpret_cast<const float4*>(src + (cb + __builtin_amdgcn_readlane(ecol, j + u)) * ld_src + c0);
+          if (DROP) {
+            const float4 m = gs_drop_mult4(dkey, cb + __builtin_amdgcn_readlane(ecol, j + u), c0, dthr, dq);
+            x[u].x *= m.x; x[u].y *= m.y; x[u].z *= m.z; x[u].w *= m.w;
+          }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -93,7 +165,11 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
       }
       for (; j < f; ++j) {
         const float w = __int_as_float(__builtin_amdgcn_readlane(evalb, j));
-        const float4 x = *reinterpret_cast<const float4*>(src + (cb + __builtin_amdgcn_readlane(ecol, j)) * ld_src + c0);
+        float4 x = *reinterpret_cast<const float4*>(src + (cb + __builtin_amdgcn_readlane(ecol, j)) * ld_src + c0);
+        if (DROP) {
+          const float4 m = gs_drop_mult4(dkey, cb + __builtin_amdgcn_readlane(ecol, j), c0, dthr, dq);
+          x.x *= m.x; x.y *= m.y; x.z *= m.z; x.w *= m.w;
+        }
         acc.x = fmaf(w, x.x, acc.x);
         acc.y = fmaf(w, x.y, acc.y);
         acc.z = fmaf(w, x.z, acc.z);
@@ -934,7 +1010,8 @@ __global__ __launch_bounds__(256) void gs_make_bmat_kernel(const int* __restrict
                                                            const int* __restrict__ n1, int cap1, int f2,
                                                            const float* __restrict__ H1full, long ldh,
                                                            const float* __restrict__ Y1, int F, float* __restrict__ Bmat,
-                                                           int* __restrict__ kcount, int nclass) {
+                                                           int* __restrict__ kcount, int nclass, unsigned long long dkey0 = 0,
+                                                           int dclass0 = 0, unsigned dthr = 0, float dq = 1.f) {
   const int lane = threadIdx.x & 63;
   const long ge = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;     // (c, l, j)
   if (ge >= (long)nclass * cap1 * f2) return;
@@ -946,6 +1023,12 @@ __global__ __launch_bounds__(256) void gs_make_bmat_kernel(const int* __restrict
   const float* h = H1full + (long)col0[ge] * ldh;
   const float* y = Y1 + grow * F;
   float* o = Bmat + ge * F;
+  if (dthr) {      // dropout (models/sgc.py:42): the source row's mask of this class multiplies the ReLU indicator
+    const unsigned long long dkey = gs_mix64(dkey0 + (unsigned)(dclass0 + c));
+    const long srow = col0[ge];
+    for (int k = lane; k < F; k += 64) o[k] = (h[k] > 0.f) ? w * y[k] * gs_drop_mult1(dkey, srow, k, dthr, dq) : 0.f;
+    return;
+  }
   for (int k = lane; k < F; k += 64) o[k] = (h[k] > 0.f) ? w * y[k] : 0.f;
 }
 

@@ -293,10 +293,39 @@ class EngineShapes:
     with_bn: bool = False  # SGC ntrans = 2 with an (always eval-mode) BatchNorm1d between the transforms (models/sgc.py:27-33)
     fmid: tuple = ()       # `--nlayers` >= 3 (SGC): fan-outs of the hops BETWEEN f1 (from the seeds) and f2 (outermost), e.g. (10,) for
                            # loader.py:206's [15, 10, 5] with f1 = 15, f2 = 5; nlayers = 2 + len(fmid) propagations on both sides
+    dropout: float = 0.0   # models/sgc.py:42 (SGC, two transforms): masks by dropout_keep below; 0 in every shipped configuration
 
     @property
     def nlayers(self):
         return 2 + len(self.fmid)
+
+
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    """splitmix64's finaliser on uint64 arrays (csrc/gs_kernels.h gs_mix64)."""
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def dropout_keep(seed, iteration, kind, index, rows, hidden, p):
+    """The engine's dropout mask (csrc/gs_kernels.h gs_drop_mult4), restated: bool [len(rows), hidden], True = kept.  kind "real" (index
+    = class, rows = the batch's node ids), "syn" (index = class, rows = 0 .. n'-1) or "inner" (index = inner step, rows = 0 .. n'-1).
+    The multiplier is keep / (1 - p) in fp32.  Parity tests hand these masks to the oracle (oracle.gcond_oracle.DROPOUT)."""
+    kind_id = {"real": 0, "syn": 1, "inner": 2}[kind]
+    thr = min(max(int((1.0 - float(p)) * 65536.0 + 0.5), 1), 65535)
+    with np.errstate(over="ignore"):
+        key0 = _mix64(np.array([int(seed) & _M64], dtype=np.uint64))[0] + np.uint64((int(iteration) << 24) & _M64) + np.uint64(kind_id << 20)
+        key = _mix64(np.array([key0 + np.uint64(int(index))], dtype=np.uint64))[0]
+        rows = np.asarray(rows, dtype=np.uint64)[:, None]
+        col = np.arange(hidden, dtype=np.uint64)[None, :]
+        word = _mix64(key + (rows << np.uint64(8)) + (col >> np.uint64(2)))
+        u = (word >> (np.uint64(16) * (col & np.uint64(3)))) & np.uint64(0xFFFF)
+    return u < np.uint64(thr)
 
 
 def model_param_count(d, hidden, nclass, ntrans):
@@ -351,7 +380,7 @@ class GCondEngine:
         cfg = GCondConfig(s.n_nodes, d, self.ldx, s.nclass, s.n_syn, s.ntrans, s.hidden, s.pge_hidden, s.bcap, s.f1, s.f2,
                           METRICS[dis_metric], inner_loop, lr_feat, lr_adj, lr_model, seed, 1 if external_blocks else 0,
                           {"SGC": 0, "GCN": 1}[s.model], int(s.pge_chunks), 1 if s.with_bn else 0, s.nlayers,
-                          (C.c_int * 3)(*(list(s.fmid) + [0] * (3 - len(s.fmid)))))
+                          (C.c_int * 3)(*(list(s.fmid) + [0] * (3 - len(s.fmid)))), float(s.dropout))
         nbytes = C.c_size_t()
         check(L.gs_gcond_workspace_bytes(C.byref(cfg), C.byref(nbytes)))
         self.workspace_bytes = nbytes.value
@@ -417,6 +446,15 @@ class GCondEngine:
 
     def set_forward_reuse(self, on):
         check(self.L.gs_gcond_set_forward_reuse(self.h, int(on)))
+
+    def set_dropout_iter(self, it):
+        """The iteration counter inside the dropout masks' keys (gs_gcond_set_dropout_iter): resume, or pin the masks of staged calls."""
+        check(self.L.gs_gcond_set_dropout_iter(self.h, int(it)))
+
+    def dropout_iter(self):
+        v = C.c_uint64()
+        check(self.L.gs_gcond_get_dropout_iter(self.h, C.byref(v)))
+        return int(v.value)
 
     def forward_cached(self):
         return bool(self.L.gs_gcond_forward_cached(self.h))

@@ -302,6 +302,8 @@ class ShardedGCond:
             ph += [(lambda: None, "ar_w1")]
         ph += [(lambda: e.pge_backward_part(np_, nf, 3), None), (lambda: e.stage_update(epoch), None)]
         ph += fwd(True) + [(e.inner_steps, None)]
+        if getattr(e.shapes, "dropout", 0.0):      # (the one-call iteration advances the masks' iteration counter itself)
+            ph += [(lambda: e.set_dropout_iter(e.dropout_iter() + 1), None)]
         return ph
 
     def outer_step_py(self, epoch):

@@ -55,7 +55,7 @@ def make_engine(p, device, bcap=256):
     from graphslim_amd.engine import EngineShapes, GCondEngine
     d = p["data"].feat_full.shape[1]
     sh = EngineShapes(p["data"].bench_n, d, p["data"].nclass, len(p["labels_syn"]), p["T"], p["hidden"], p["ph"], bcap,
-                      p["fan"][0], p["fan"][-1], fmid=tuple(p["fan"][1:-1]))
+                      p["fan"][0], p["fan"][-1], fmid=tuple(p["fan"][1:-1]), dropout=float(p.get("dropout", 0.0)))
     cls_ptr = np.concatenate([[0], np.cumsum([len(q) for q in p["pools"]])])
     eng = GCondEngine(sh, p["data"].bench_feat, p["csr"], cls_ptr, np.concatenate(p["pools"]), p["labels_syn"], p["ranges"],
                       lr_feat=p["lrf"], lr_adj=p["lra"], lr_model=0.01, inner_loop=p["inner"], seed=1, device=device)

@@ -329,6 +329,13 @@ typedef struct gs_gcond_config {
                               3 .. 5 (SGC only) = K sampled hops on the real side — f1 from the seeds, fmid[0 .. K-3] between, f2
                               outermost (dataset/loader.py:205-210) — and A^^K on the synthetic side */
   int fmid[GS_MAX_MID];
+  float dropout;           /* models/base.py:20 / models/sgc.py:42: F.dropout behind every transform but the last, active inside train_class
+                              (one fresh mask per class on the real batch and one per class on the synthetic graph) and in every inner
+                              step (gcond.py:45: training mode).  0 (every shipped configuration): none.  In (0, 1): SGC with two
+                              transforms, no BatchNorm; with one transform there is no such layer and the value has no effect, as
+                              upstream.  torch's generator cannot be replayed, so the masks are the counter-based function of (seed,
+                              iteration, kind, class | step, row, column) stated in csrc/gs_kernels.h (gs_drop_mult4): Bernoulli(1 - p)
+                              entries scaled by 1 / (1 - p), p resolved to 1 / 65536 */
 } gs_gcond_config;
 
 typedef struct gs_gcond_io {
@@ -365,6 +372,11 @@ int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* blocks, gs_stream_t stream
  * cached pass instead of recomputing it (bitwise the same values).  Off by default; call gs_gcond_invalidate_forward after
  * writing X~ or theta_PGE from the host.  gs_gcond_forward_cached returns 1 when the next step would adopt. */
 int gs_gcond_set_forward_reuse(gs_gcond* e, int on);
+/* cfg.dropout != 0: the iteration counter inside every dropout mask's key — 0 at creation, advanced by every gs_gcond_outer_step* call
+ * (the staged calls read it and leave it alone).  Set it to resume a run at iteration i with the masks that run would have drawn, or
+ * to pin the masks of staged calls (parity tests). */
+int gs_gcond_set_dropout_iter(gs_gcond* e, unsigned long long iter);
+int gs_gcond_get_dropout_iter(gs_gcond* e, unsigned long long* iter);
 /* In-situ timing of the dominant kernel (PGE layer-2 GEMM, 2 n'^2 Ph^2 FLOP per launch): while on, HIP events are recorded
  * on the launch stream around each of its launches inside the outer steps (at most 256); _read synchronises them and
  * returns the summed duration [ms] and the launch count since the probe was switched on.  bench.py's roofline uses it. */

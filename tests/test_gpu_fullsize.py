@@ -56,14 +56,17 @@ class _ReluTies:
         return e * gate.to(e.dtype)
 
 
-def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", relu_flip=None, scale=1.0):
+def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", relu_flip=None, scale=1.0, dropout=0.0):
     """driver: "staged" = the stage entry points one by one; "fused" = ONE gs_gcond_outer_step call (what bench.py times: two
     streams, blocks sampled inside the call); "fused_reuse" = the same with forward reuse on, compared on the SECOND call (the
     one that adopts the cached inference forward of the first)."""
     import bench
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     p = bench.build_problem(name, seed=1, scale=scale)
+    p["dropout"] = dropout
     eng = bench.make_engine(p, DEV)
+    drop_it = 3
+    eng.set_dropout_iter(drop_it)
     if operand_mode is not None:
         eng.set_operand_mode(operand_mode)
     bench.init_state(p, eng)
@@ -72,6 +75,7 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", re
     if driver == "fused_reuse":
         eng.set_forward_reuse(True)
         eng.outer_step(epoch)
+        drop_it += 1
         torch.cuda.synchronize()
         assert eng.forward_cached()
         theta = [t.cpu().clone() for t in eng.get_model()]          # theta after the first call's inner steps
@@ -105,6 +109,15 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", re
     hook = None
     if relu_flip is not None:
         hook = O.RELU_HOOK = _ReluTies(flip=relu_flip)
+    if dropout:      # the engine's masks of this iteration (seed 1: workloads.make_engine), handed to the restatement
+        from graphslim_amd.engine import dropout_keep
+
+        def masks(where, x):
+            kind, index, rows = where
+            rows = np.arange(x.shape[0]) if rows is None else np.asarray(rows)
+            keep = dropout_keep(1, drop_it, kind, index, rows, x.shape[1], dropout)
+            return torch.from_numpy(keep).to(x.dtype) * torch.tensor(np.float32(1.0 / (1.0 - dropout))).to(x.dtype)
+        O.DROPOUT = masks
     try:
         ref_loss, ref_gfeat, ref_gpge, _ = st.outer_iteration(epoch, batches, p["data"].bench_feat, p["data"].bench_labels, 0)
     finally:
@@ -123,6 +136,7 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", re
         out["g_feat"] = 0.0          # (not computed by the fused call in a PGE epoch)
     if driver == "fused_reuse":      # the optimisers of both sides have stepped a different number of times: gradients only
         out.update(upd_well_max=0.0, upd_any_frac=0.0, adj=0.0, model_bad_frac=0.0, model_max=0.0)
+        O.DROPOUT = None
         return out
     # ---- the Adam step.  Its first step is lr * g / (|g| + eps) ~ lr * sign(g): entries whose gradient lies below the fp32
     # noise of the computation have an ill-conditioned sign, so the update is gated on the WELL-conditioned entries
@@ -155,7 +169,10 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", re
         xs_now = st.feat_syn.detach()
         out["adj_self"] = float((O.pge_forward(xs_now * (1 + 1e-7 * torch.randn(xs_now.shape, generator=gq)), pd_) -
                                  O.pge_forward(xs_now, pd_)).abs().max())
-    adj_inner = st.inference_and_inner(p["inner"])
+    try:
+        adj_inner = st.inference_and_inner(p["inner"])
+    finally:
+        O.DROPOUT = None
     out["adj"] = float((eng.adj_syn.cpu() - adj_inner).abs().max())
     mdiff = torch.cat([(a.cpu() - b.detach()).abs().reshape(-1) for a, b in zip(eng.get_model(), st.model)])
     out["model_bad_frac"] = float((mdiff > 0.02 * 0.01 * max(p["inner"], 1)).double().mean())
@@ -239,6 +256,15 @@ def test_cora_r05_full_size():
                 ok = all(e <= 1e-3 for _, e in r["g_pge"])
                 print(f"   with the tie(s) {flip} resolved the other way: d theta_PGE errors {[round(e, 6) for _, e in r['g_pge']]}")
         check(r)
+
+
+@pytest.mark.parametrize("name,epoch,driver", [("ogbn-arxiv", 10, "fused"), ("ogbn-arxiv", 0, "staged"), ("flickr", 10, "fused")])
+def test_dropout_full_size_against_the_oracle(name, epoch, driver):
+    """Dropout 0.5 in the condensation model (models/sgc.py:42) at the full ogbn-arxiv / flickr shapes (two transforms, hidden 256): the
+    engine's masks on the real batches' gathered hidden rows (8 700 rows x 256 per class) and on the synthetic graph, handed to the
+    oracle; the whole iteration — loss, gradients, the Adam step, PGE.inference and the inner steps under their own masks — to the
+    gates of the dropout-free configurations."""
+    check(run_config(name, epoch, driver=driver, dropout=0.5))
 
 
 @pytest.mark.parametrize("name,scale", [("arxiv-k3", 0.15), ("cora-k3", 1.0)])
