@@ -783,7 +783,7 @@ extern "C" int gs_gcond_set_knob(gs_gcond* e, int knob, int value) {
 }
 extern "C" int gs_gcond_get_knob(const gs_gcond* e, int knob) {
   if (!e || knob < 0 || knob >= GS_KNOB_COUNT) return -1;
-  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_chained_products, 0, g_edge_plan != 0};
+  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows != 0, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_chained_products, 0, g_edge_plan != 0};
   return knob_of(e, knob, def[knob]);
 }
 
@@ -967,7 +967,7 @@ extern "C" int gs_gcond_set_h1_bits(int on) {
 
 // measurement knob: 1 (default) = a sharded rank computes only the H1 rows its blocks gather; 0 = every rank computes all N rows
 extern "C" int gs_gcond_set_h1_rows(int on) {
-  g_h1_rows = on != 0;
+  g_h1_rows = on < 0 ? 0 : on;      // (2: the row list also when the blocks name more slots than there are nodes — measurement)
   return GS_OK;
 }
 
@@ -1034,13 +1034,14 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     int rows_rc = GS_ERR_UNSUPPORTED;
     // (the sign bits are an output of the row-panel kernel: asked for only where the product takes that route)
     const bool want_bits = knob_of(e, GS_KNOB_H1_BITS, g_h1_bits) && e->H1bits && e->cfg.dis_metric == 0 && !e->drop_thr;
-    if (knob_of(e, GS_KNOB_H1_ROWS, g_h1_rows) && !e->S_full && e->h1_flag && slots < (long)e->N) {
+    if (knob_of(e, GS_KNOB_H1_ROWS, g_h1_rows) && !e->S_full && e->h1_flag && (slots < (long)e->N || g_h1_rows > 1)) {
       GS_HIP(hipMemsetAsync(e->h1_flag, 0, sizeof(int) * (size_t)e->N, s));
       GS_HIP(hipMemsetAsync(e->h1_count, 0, sizeof(int), s));
       hipLaunchKernelGGL(gs_h1_mark_kernel, dim3(gs_cdiv(slots, 256)), dim3(256), 0, s, b.col0, b.val0, nL, capL, f2, Cl, e->h1_flag);
       hipLaunchKernelGGL(gs_h1_compact_kernel, dim3(gs_cdiv(e->N, 2048)), dim3(256), 0, s, e->h1_flag, e->N, e->h1_list, e->h1_count);
       GS_LAUNCH_CHECK();
-      rows_rc = gs_panel_rows(e->io.X, e->ldx, e->W1mT, d, th + e->ob1, 1, e->H1full, h, h, d, e->h1_list, e->h1_count, (int)slots,
+      rows_rc = gs_panel_rows(e->io.X, e->ldx, e->W1mT, d, th + e->ob1, 1, e->H1full, h, h, d, e->h1_list, e->h1_count,
+                              (int)(slots < (long)e->N ? slots : (long)e->N),
                               (long)e->N, e->operand_mode, e->bsplit_aux, want_bits ? e->H1bits : nullptr, h / 32, s);
       if (rows_rc != GS_OK && rows_rc != GS_ERR_UNSUPPORTED) return rows_rc;
       use_bits = rows_rc == GS_OK && want_bits;
