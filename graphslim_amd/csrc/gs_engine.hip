@@ -140,6 +140,15 @@ struct gs_gcond {
   // distance statistics: it runs on its own stream and joins through an event
   hipStream_t aux;
   hipEvent_t ev_fork, ev_join, ev_prefetch;   // ev_prefetch: the block set sampled ahead on aux is complete
+  // hoisted training forward (round 5): `adj_syn = pge(feat_syn)` of the NEXT iteration (gcond.py:48) depends only on (X~, theta_PGE),
+  // final once this iteration's optimiser has stepped — the outer step issues it on a third, lowest-priority stream beside the inner
+  // SGC steps (latency-bound launches on a few CUs) instead of at the top of the next call; the next call waits for ev_hoist
+  hipStream_t low;
+  hipEvent_t ev_inf, ev_hoist;
+  bool hoist_pending;                // a hoisted forward is (possibly) still in flight on `low`
+  bool fwd_hoisted;                  // ... and is the training forward of the current (X~, theta_PGE)
+  bool in_step;                      // inside gs_gcond_outer_step*: the stage entry points are being called by the step itself
+  bool hoisting;                     // the forward being issued is the hoisted one (its long product leaves compute units to the inner steps)
   bool overlap, join_pending;
   bool overlap_sampling_only;        // level 2 of gs_gcond_set_overlap: the second stream only samples the NEXT iteration's blocks
   // PGE.inference at the end of iteration i and the training forward of iteration i+1 are the same function of the
@@ -578,6 +587,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->have_blocks = false;
   e->c_lo = 0; e->c_hi = e->C; e->r_lo = 0; e->r_hi = e->n;
   e->aux = nullptr; e->ev_fork = e->ev_join = e->ev_prefetch = nullptr; e->join_pending = false;
+  e->low = nullptr; e->ev_inf = e->ev_hoist = nullptr; e->hoist_pending = e->fwd_hoisted = e->in_step = e->hoisting = false;
   e->reuse_fwd = false; e->fwd_cached = false; e->real_beside = false;
   e->blk_cur = 0; e->prefetched = false; e->identity = false;
   e->probing = false; e->probe_n = 0; e->probe2_n = 0;
@@ -596,6 +606,12 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
                (hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess) &&
                (hipEventCreateWithFlags(&e->ev_prefetch, hipEventDisableTiming) == hipSuccess);
   e->overlap_sampling_only = false;
+  if (hipStreamCreateWithPriority(&e->low, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_inf, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_hoist, hipEventDisableTiming) != hipSuccess) {
+    if (e->low) (void)hipStreamDestroy(e->low);
+    e->low = nullptr;      // (no hoisting then)
+  }
   *out = e;
   return GS_OK;
 }
@@ -603,6 +619,9 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
 extern "C" void gs_gcond_destroy(gs_gcond* e) {
   if (!e) return;
   if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); }
+  if (e->low) { (void)hipStreamSynchronize(e->low); (void)hipStreamDestroy(e->low); }
+  if (e->ev_inf) (void)hipEventDestroy(e->ev_inf);
+  if (e->ev_hoist) (void)hipEventDestroy(e->ev_hoist);
   for (int i = 0; i < 2 * 256; ++i) if (e->probe_ev[i]) (void)hipEventDestroy(e->probe_ev[i]);
   for (int i = 0; i < 2 * 256; ++i) if (e->probe2_ev[i]) (void)hipEventDestroy(e->probe2_ev[i]);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -611,8 +630,23 @@ extern "C" void gs_gcond_destroy(gs_gcond* e) {
   delete e;
 }
 
+// A hoisted forward lives between two consecutive gs_gcond_outer_step* calls only: every other entry point that reads or writes what it
+// touches waits for it on the host first and drops it (the next step then recomputes the forward at its top, as before).
+static int quiesce_hoist(gs_gcond* e) {
+  if (!e || e->in_step) return GS_OK;
+  if (e->hoist_pending) { GS_HIP(hipEventSynchronize(e->ev_hoist)); e->hoist_pending = false; }
+  e->fwd_hoisted = false;
+  return GS_OK;
+}
+static int g_hoist_fwd = 1;         // measurement knob: 0 = the training forward at the top of the next call (the form of rounds 1-4)
+extern "C" int gs_gcond_set_hoist_forward(int on) {
+  g_hoist_fwd = on < 0 ? 0 : on;
+  return GS_OK;
+}
+
 extern "C" int gs_gcond_set_forward_reuse(gs_gcond* e, int on) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   e->reuse_fwd = on != 0;
   e->fwd_cached = false;
   return GS_OK;
@@ -631,6 +665,7 @@ extern "C" int gs_gcond_get_dropout_iter(gs_gcond* e, unsigned long long* iter) 
 
 extern "C" int gs_gcond_invalidate_forward(gs_gcond* e) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   e->fwd_cached = false;
   return GS_OK;
 }
@@ -639,6 +674,7 @@ extern "C" int gs_gcond_invalidate_forward(gs_gcond* e) {
 // products only (gs_gemm_desc.prec); everything else stays fp32.  Switchable at any time (A/B measurements).
 extern "C" int gs_gcond_set_operand_mode(gs_gcond* e, int mode) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   if (mode < 0 || mode > 3)
     GS_FAIL(GS_ERR_ARG, "gs_gcond_set_operand_mode: mode must be 0 (fp32), 1 (2-way bf16 split, 3 products), 2 (bf16) or 3 (exact 3-way bf16 split, 6 products)");
   e->operand_mode = mode;
@@ -648,6 +684,7 @@ extern "C" int gs_gcond_set_operand_mode(gs_gcond* e, int mode) {
 
 extern "C" int gs_gcond_set_overlap(gs_gcond* e, int on) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   e->overlap = on && e->aux && e->ev_fork && e->ev_join && e->ev_prefetch;
   e->overlap_sampling_only = e->overlap && on == 2;
   return GS_OK;
@@ -763,6 +800,7 @@ static int colsum_batched(gs_gcond* e, const float* M, long batch_stride, int ro
 // ================================================================================================
 extern "C" int gs_gcond_set_shard(gs_gcond* e, int c_lo, int c_hi, int r_lo, int r_hi) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   if (c_lo < 0 || c_hi < c_lo || c_hi > e->C || r_lo < 0 || r_hi < r_lo || r_hi > e->n)
     GS_FAIL(GS_ERR_ARG, "gs_gcond_set_shard: ranges out of bounds");
   if (e->pge_chunks > 1 && (r_lo != 0 || r_hi != e->n))
@@ -778,6 +816,7 @@ static inline bool sharded_r(const gs_gcond* e) { return e->r_lo != 0 || e->r_hi
 // launch (unsharded engines); 0 = separate launch.  Same bits either way.
 extern "C" int gs_gcond_set_knob(gs_gcond* e, int knob, int value) {
   if (!e || knob < 0 || knob >= GS_KNOB_COUNT) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_knob: null engine or unknown knob %d", knob);
+  GS_TRY(quiesce_hoist(e));
   e->knob[knob] = value < 0 ? -1 : (value != 0);
   return GS_OK;
 }
@@ -1349,6 +1388,7 @@ static int ensure_a1(gs_gcond* e, hipStream_t s) {
 
 extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int part, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   hipStream_t s = (hipStream_t)stream;
   const int n = e->n, d = e->d, Ph = e->Ph, nr = e->r_hi - e->r_lo;
   const long n2 = (long)n * n, rows = (long)nr * n;
@@ -1394,7 +1434,8 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       int tiles = 0;
       if (probe) { e->probe_pass[e->probe_n] = inference ? 1 : 0; GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s)); }
       const int rc = gs_panel_forward_a1(&a1, n, nr, pp + e->pW1, Ph, pp + e->pb1, e->E2, Ph, Ph, Ph, e->statp, &tiles, e->operand_mode,
-                                         e->bsplit_main, probe ? e->probe_span + 2 * e->probe_n : nullptr, inference, s);
+                                         e->bsplit_main, probe ? e->probe_span + 2 * e->probe_n : nullptr,
+                                         e->hoisting ? 2 : inference, s);
       if (rc == GS_OK) {
         // (tiles = the number of [2][Ph] partial-sum slabs the kernel wrote: one per 128-row tile, or one per workgroup — gs_panel2.hip)
       } else if (rc != GS_ERR_UNSUPPORTED) {
@@ -1477,6 +1518,7 @@ static int adopt_cached_forward(gs_gcond* e, gs_stream_t stream) {
 
 extern "C" int gs_gcond_adopt_cached_forward(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   if (!e->fwd_cached) GS_FAIL(GS_ERR_STATE, "gs_gcond_adopt_cached_forward: no inference forward of the current state is cached");
   return adopt_cached_forward(e, stream);
 }
@@ -1668,6 +1710,7 @@ static int match_distance_folded(gs_gcond* e, const float* gwr, const float* gws
 // ================================================================================================
 extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   hipStream_t s = (hipStream_t)stream;
   const int C = e->C, Cl = e->c_hi - e->c_lo, n = e->n, d = e->d, h = e->h, F = e->F, mx = e->max_nc;
   const long P = e->P, c0 = e->c_lo;
@@ -2057,6 +2100,7 @@ extern "C" int gs_gcond_stage_syn_finish(gs_gcond* e, gs_stream_t stream) {
 extern "C" int gs_gcond_stage_pge_backward_part(gs_gcond* e, int need_param_grads, int need_feat_grad, int part,
                                                 gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   hipStream_t s = (hipStream_t)stream;
   const int n = e->n, d = e->d, Ph = e->Ph, nr = e->r_hi - e->r_lo;
   const long n2 = (long)n * n, rows = (long)nr * n;
@@ -2263,6 +2307,7 @@ extern "C" int gs_gcond_stage_pge_backward(gs_gcond* e, int need_param_grads, in
 // ================================================================================================
 extern "C" int gs_gcond_stage_update(gs_gcond* e, int epoch, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   if (epoch % 50 < 10)
     return gs_adam_step_f32(e->io.pge_params, e->d_pge, e->m_pge, e->v_pge, e->Ppge, e->cfg.lr_adj, 0.9f, 0.999f, 1e-8f, 0.f,
                             ++e->step_pge, stream);
@@ -2489,6 +2534,7 @@ __global__ void gs_eye_kernel(float* __restrict__ a, int n) {
 
 extern "C" int gs_gcond_set_identity_structure(gs_gcond* e, int on, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   e->identity = on != 0;
   e->fwd_cached = false;
   if (e->identity) {   // gcondx.py:30 / doscondx.py:30: self.adj_syn = torch.eye(n) is used as is (not re-normalised)
@@ -2513,6 +2559,7 @@ extern "C" int gs_gcond_set_identity_structure(gs_gcond* e, int on, gs_stream_t 
 // pos = NULL returns to dense products.  SGC only.
 extern "C" int gs_gcond_set_block_structure(gs_gcond* e, const int* pos, int B, int n_block, float* scratch) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  GS_TRY(quiesce_hoist(e));
   if (!pos) { e->blk_pos = nullptr; e->blk_B = e->blk_n = 0; return GS_OK; }
   if (e->gcn) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond_set_block_structure: built for the SGC condensation model");
   if (B < 1 || n_block < 1 || (long)B * n_block != e->n || !scratch) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_block_structure: bad argument");
@@ -2531,6 +2578,7 @@ extern "C" int gs_gcond_set_block_structure(gs_gcond* e, const int* pos, int B, 
 // iteration stage by stage and owns the optimiser steps of X~ and of its generator.
 extern "C" int gs_gcond_set_structure(gs_gcond* e, const float* adj, int inference, gs_stream_t stream) {
   if (!e || !adj) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_structure: null argument");
+  GS_TRY(quiesce_hoist(e));
   if (e->identity) GS_FAIL(GS_ERR_STATE, "gs_gcond_set_structure: the engine is in identity-structure mode");
   hipStream_t s = (hipStream_t)stream;
   const size_t bytes = sizeof(float) * (size_t)e->n * e->n;
@@ -2636,8 +2684,12 @@ static int pge_backward_x(gs_gcond* e, int need_param_grads, int need_feat_grad,
 static int outer_step_body(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_comm* comm, gs_stream_t stream);
 static int outer_step_impl(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_comm* comm,
                            gs_stream_t stream) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  e->in_step = true;
   const int rc = outer_step_body(e, step_pge, step_feat, run_inference, run_inner, comm, stream);
+  e->in_step = false;
   if (rc == GS_OK) ++e->drop_iter;      // the next iteration's dropout masks (every stage of one iteration reads the same counter)
+  else (void)quiesce_hoist(e);
   return rc;
 }
 static int outer_step_body(gs_gcond* e, int step_pge, int step_feat, int run_inference, int run_inner, gs_comm* comm,
@@ -2650,7 +2702,24 @@ static int outer_step_body(gs_gcond* e, int step_pge, int step_feat, int run_inf
     GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond_outer_step_sharded: the chunked PGE (pge_chunks > 1) cannot be sharded over pair rows");
   if (e->identity) { step_pge = 0; run_inference = 0; }
   const bool recompute_fwd = !e->identity && !(e->reuse_fwd && e->fwd_cached);
-  if (recompute_fwd && e->overlap && !e->overlap_sampling_only) {
+  // the training forward of this iteration was issued by the previous call beside its inner steps (see the end of this function)
+  const bool hoisted = recompute_fwd && e->fwd_hoisted && e->hoist_pending && !comm;
+  if (e->hoist_pending && !hoisted) {      // (not what this call needs: wait for it, then compute as usual)
+    GS_HIP(hipStreamWaitEvent((hipStream_t)stream, e->ev_hoist, 0));
+    e->hoist_pending = false;
+  }
+  e->fwd_hoisted = false;
+  if (hoisted) {
+    // the real-side branch forks behind the previous call's inner steps (it reads theta); the main stream takes up the forward's
+    // results where the third stream left them.  (The edge product plans for the whole chip: by the time it runs the hoisted
+    // forward has finished — it started an inner loop earlier.)
+    e->real_beside = g_hoist_fwd == 2;     // (2: the 7/8 slab plan of the un-hoisted step — measurement: 1 467 against 1 449-1 458 us)
+    const int rc_real = gs_gcond_stage_real_async(e, stream);
+    e->real_beside = false;
+    GS_TRY(rc_real);
+    GS_HIP(hipStreamWaitEvent((hipStream_t)stream, e->ev_hoist, 0));
+    e->hoist_pending = false;
+  } else if (recompute_fwd && e->overlap && !e->overlap_sampling_only) {
     // Issue order: the two branches are independent, and the host needs ~3 us per launch.  A class shard's real-side branch is
     // ~20 short launches: enqueued first (round-3 trace of rank 2 of 8) they left the main queue EMPTY for 195 us while the host
     // was still feeding the second stream.  So the fork point is recorded, the first part of the PGE forward (its long product)
@@ -2705,6 +2774,27 @@ static int outer_step_body(gs_gcond* e, int step_pge, int step_feat, int run_inf
   if (run_inference) GS_TRY(pge_forward_x(e, 1, comm, stream));
   if (run_inner) {
     if (!e->identity && !run_inference) GS_FAIL(GS_ERR_ARG, "gs_gcond_outer_step_ex: inner steps need the inference pass");
+    // Hoist: gcond.py:48 of the NEXT iteration, `adj_syn = pge(feat_syn)`, reads (X~, theta_PGE) only — both final now — while the
+    // inner steps (gcond.py:67-72) are ~20 dependent launches on a few compute units.  The same launches, the same inputs, the same
+    // buffers as at the top of the next call (bitwise the same values), issued on the lowest-priority stream so that the inner
+    // steps' small launches take compute units as they free up.  Not with forward reuse (nothing to recompute), not sharded (the
+    // forward's exchanges stay in the next call), not without the second stream.
+    const bool hoist = g_hoist_fwd && !comm && !sharded_c(e) && !sharded_r(e) && !e->identity && run_inference && !e->reuse_fwd &&
+                       e->overlap && !e->overlap_sampling_only && e->low && e->cfg.inner_loop > 0;
+    if (hoist) {
+      hipStream_t s = (hipStream_t)stream;
+      GS_HIP(hipEventRecord(e->ev_inf, s));
+      GS_HIP(hipStreamWaitEvent(e->low, e->ev_inf, 0));
+      const bool cached = e->fwd_cached;
+      e->hoisting = true;
+      const int rc_fwd = gs_gcond_stage_pge_forward(e, 0, (gs_stream_t)e->low);
+      e->hoisting = false;
+      GS_TRY(rc_fwd);
+      e->fwd_cached = cached;
+      GS_HIP(hipEventRecord(e->ev_hoist, e->low));
+      e->hoist_pending = true;
+      e->fwd_hoisted = true;
+    }
     GS_TRY(gs_gcond_stage_inner_steps(e, stream));
   }
   return GS_OK;
@@ -2830,6 +2920,7 @@ extern "C" int gs_gcond_read_loss(gs_gcond* e, double* loss_sum, long* steps, gs
 
 extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* count) {
   if (!e || !name || !ptr || !count) GS_FAIL(GS_ERR_ARG, "gs_gcond_buffer: null argument");
+  GS_TRY(quiesce_hoist(e));
   const long n = e->n, C = e->C, Ph = e->Ph;
   struct { const char* k; void* p; long c; } tab[] = {
       {"gw_real", e->gw_real, C * e->P},   {"gw_syn", e->gw_syn, C * e->P},     {"loss", e->loss_last, 1},

@@ -789,7 +789,11 @@ int gs_tall_forward_a1(const float* Us, const float* Vs, long ld, int n, int nr,
   a.B = Bimg; a.ldb_bytes = ldb_bytes; a.C = C; a.ldc = ldc; a.c_rows = (long)nr * n; a.M = nr * n; a.K = K;
   a.bias = bias; a.colstat = colstat; a.a1_U = Us; a.a1_V = Vs; a.a1_ld = ld; a.n = n; a.nr = nr;
   a.span = span; a.krep = g_tall_krep; a.triage = g_tall_triage; a.phases = g_tall_phases;
-  const dim3 grid(tall_grid(gs_cdiv(a.M, 64), 4)), block(512);
+  dim3 grid(tall_grid(gs_cdiv(a.M, 64), 4)), block(512);
+  // alone == 2: the pass runs beside a chain of latency-bound launches (the inner SGC steps while the next iteration's training forward
+  // is hoisted, gs_engine.hip): the persistent grid leaves one compute unit in eight to them — a full grid made every one of their
+  // ~20 small launches wait for a workgroup of this kernel to retire (inner steps 140 -> 323 us, profiles/r05/timeline_hoisted_full_grid.txt)
+  if (alone == 2 && g_tall_grid == 0) { const int cus = tall_cus(); if ((int)grid.x > cus - cus / 8) grid.x = cus - cus / 8; }
   if (g_tall_split == 2) hipLaunchKernelGGL((gs_tall_kernel<TP_FGEN, false, 0, 2>), grid, block, 0, s, a);      // (measurement: interleaved form)
   else if (g_tall_triage || g_tall_krep != 1) TP_LAUNCH(TP_FGEN, false, 1);      // (measurement: phases switched off, results are garbage)
   else TP_LAUNCH(TP_FGEN, false, 0);

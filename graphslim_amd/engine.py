@@ -434,6 +434,7 @@ class GCondEngine:
         return [(ph, 2 * d), (ph,), (ph, ph), (ph,), (1, ph), (1,), (ph,), (ph,), (ph,), (ph,)]
 
     def set_pge(self, params):
+        self.L.gs_gcond_invalidate_forward(self.h)      # (first: waits for a forward the last outer step issued ahead — it reads these)
         self.pge_params.copy_(torch.cat([p.reshape(-1).float() for p in params]).to(self.dev))
         self.L.gs_gcond_invalidate_forward(self.h)
 
@@ -441,6 +442,7 @@ class GCondEngine:
         return _split(self.pge_params, self.pge_shapes())
 
     def set_feat(self, x):
+        self.L.gs_gcond_invalidate_forward(self.h)      # (first: waits for a forward the last outer step issued ahead — it reads X~)
         self.feat_syn.copy_(x.to(self.dev, torch.float32))
         self.L.gs_gcond_invalidate_forward(self.h)
 

@@ -369,8 +369,10 @@ int gs_gcond_new_epoch(gs_gcond* e, gs_stream_t stream);
 int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* blocks, gs_stream_t stream);
 /* PGE.inference at the end of iteration i (gcond.py:63-65) and `adj_syn = pge(self.feat_syn)` at the start of iteration i+1
  * (gcond.py:48) evaluate the same function on the same (X~, theta_PGE).  With forward reuse on, gs_gcond_outer_step adopts the
- * cached pass instead of recomputing it (bitwise the same values).  Off by default; call gs_gcond_invalidate_forward after
- * writing X~ or theta_PGE from the host.  gs_gcond_forward_cached returns 1 when the next step would adopt. */
+ * cached pass instead of recomputing it (bitwise the same values).  Off by default; call gs_gcond_invalidate_forward BEFORE and
+ * after writing X~ or theta_PGE from the host (before: without forward reuse an outer step issues the next iteration's training
+ * forward ahead, beside its inner steps, and that forward reads both — the call waits for it).  gs_gcond_forward_cached returns 1
+ * when the next step would adopt. */
 int gs_gcond_set_forward_reuse(gs_gcond* e, int on);
 /* cfg.dropout != 0: the iteration counter inside every dropout mask's key — 0 at creation, advanced by every gs_gcond_outer_step* call
  * (the staged calls read it and leave it alone).  Set it to resume a run at iteration i with the masks that run would have drawn, or

@@ -98,6 +98,12 @@ int gs_gcond_set_edge_plan(int on);
  * 0 = rows in memory order over all XCDs.  Same values (every row is computed by the same code either way). */
 int gs_gcond_set_ell_xcd(int on);
 
+/* Measurement knob: 1 (default) = gs_gcond_outer_step* issues the NEXT iteration's training forward of the PGE (gcond.py:48: a function
+ * of X~ and theta_PGE only, both final once the optimiser has stepped) on a third, lowest-priority stream beside its inner SGC steps;
+ * the next call waits for it instead of computing it.  Same launches on the same inputs: bitwise the same values.  0 = the forward
+ * at the top of the next call (the form of rounds 1-4).  Unsharded engines without forward reuse only. */
+int gs_gcond_set_hoist_forward(int on);
+
 /* Priority of the second (real-side) stream of engines created AFTER the call: -1 = highest (default), 0 = normal, 1 = lowest. */
 int gs_gcond_set_aux_priority(int level);
 
