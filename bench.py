@@ -48,12 +48,14 @@ def newest_profile(fname, key=None):
     return None, None, None
 
 
-def roofline(eng, passes, mode="f32", reps=20):
+def roofline(eng, passes, mode="f32", reps=20, hoisted=False):
     """Dominant product: the PGE layer-2 contraction E2[n'^2, Ph] = A1[n'^2, Ph] W1^T + b1 on the matrix cores (A1 generated in the
     operand path, BN-2 column sums in the epilogue; parametrized_adj.py:57-64), 2 n'^2 Ph^2 algorithmic flops per launch.  It is
     launched twice per iteration by TWO kernels, reported separately: the inference pass on the persistent
-    256-row kernel (csrc/gs_panel2.hip, alone on the chip) = the top-level entry, and the training pass on the 128-row kernel
-    (csrc/gs_panel.hip, beside the real-side stream) = `training_pass`.  `passes` = {pass: (event bracket ms, launches, device span
+    256-row kernel (csrc/gs_panel2.hip, alone on the chip) = the top-level entry, and the training pass = `training_pass`: with one
+    GPU it is the NEXT iteration's pass, issued beside the inner steps on the same persistent kernel with 7/8 of the compute units
+    (`hoisted`; gs_engine.hip outer_step_body) — sharded ranks run it at the top of the iteration on the 128-row kernel
+    (csrc/gs_panel.hip, beside the real-side stream).  `passes` = {pass: (event bracket ms, launches, device span
     ms, spans)} from the engine's probe, recorded on the launch stream around every launch INSIDE the timed steps; `achieved` is
     priced on the device span (first workgroup's start .. last workgroup's end, what a kernel trace reports as the duration).
     `peak` is the guide's dense bf16 peak; `sustained_peak` is what THIS chip's matrix pipe delivers on random operands under its
@@ -78,7 +80,8 @@ def roofline(eng, passes, mode="f32", reps=20):
     tall = mode == "bf16x6" and ph == 256 and n >= 128
     knames = {"inference": "gs_tall_kernel<1, false, 0," if tall else {"f32": "gs_panel_fwdgen_kernel<0, 8,", "bf16x3": "gs_panel_fwdgen_kernel<1, 8,",
                                                                         "bf16": "gs_panel_fwdgen_kernel<2, 8,", "bf16x6": "gs_panel_fwdgen_kernel<3, 8,"}[mode],
-              "training": {"f32": "gs_panel_fwdgen_kernel<0, 8,", "bf16x3": "gs_panel_fwdgen_kernel<1, 8,", "bf16": "gs_panel_fwdgen_kernel<2, 8,",
+              "training": "gs_tall_kernel<1, false, 0," if tall and hoisted else
+                          {"f32": "gs_panel_fwdgen_kernel<0, 8,", "bf16x3": "gs_panel_fwdgen_kernel<1, 8,", "bf16": "gs_panel_fwdgen_kernel<2, 8,",
                            "bf16x6": "gs_panel_fwdgen_kernel<3, 8,"}[mode]}
     if mode == "f32":
         peak, bound, unit, mult = 157.3, "mfma", "TFLOP/s", 1.0      # fp32 matrix peak (MI355X_MICROARCH.md chip table)
@@ -107,6 +110,9 @@ def roofline(eng, passes, mode="f32", reps=20):
                "frac_algorithmic": round((flops / sec / 1e12) / peak if bound == "mfma" else ach / peak, 4)}
         if sus:
             out["frac_of_sustained_peak"] = round(ach / sus["loop_with_operand_preparation_TFLOPs"], 4)
+        if tag == "training" and hoisted:
+            out["where"] = ("the next iteration's training forward, issued on a third stream beside this iteration's inner steps"
+                            + (": the persistent kernel on 7/8 of the compute units (peak and fractions are the whole chip's)" if tall else ""))
         out["traffic"], out["traffic_source"] = None, None
         if (n, ph) == (454, 256):
             path, blob, hit = newest_profile("pmc_panel_summary.json", knames[tag])
@@ -501,9 +507,13 @@ def main():
                                    f"inner_loop {p['inner']}, GPU sampler", "N": int(p['data'].bench_n),
                        "nnz": int(p['csr'][0][-1]), "scale": args.scale, "mean_match_loss": loss_sum / max(k, 1) / p['data'].nclass,
                        "parallelism": getattr(eng, "parallelism", "single"),
-                       "iters_per_sec_with_forward_reuse": round(args.steps / dt_reuse, 3)},
+                       "iters_per_sec_with_forward_reuse": round(args.steps / dt_reuse, 3),
+                       "schedule": ("every iteration runs its own training forward of the PGE (gcond.py:48) and its own inference pass (gcond.py:64); "
+                                    "the training forward is issued beside the PREVIOUS iteration's inner steps (it reads X~ and theta_PGE only, "
+                                    "final once the optimiser has stepped) and the blocks are sampled one iteration ahead: K timed steps contain "
+                                    "K of each") if world == 1 else "sharded: every stage inside its own iteration; blocks sampled one iteration ahead"},
         }
-        out["roofline"] = roofline(eng, probe_passes, args.operand_mode)
+        out["roofline"] = roofline(eng, probe_passes, args.operand_mode, hoisted=(world == 1))
         if hbm:
             out["roofline_hbm"] = hbm
         if acc:
