@@ -72,7 +72,7 @@ SYMBOLS = [
     "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer", "gs_gcond_get_blocks", "gs_gcond_set_shard",
     "gs_gcond_set_overlap", "gs_gcond_set_operand_mode", "gs_gcond_set_full_neighbour", "gs_gcond_set_forward_reuse", "gs_gcond_set_dropout_iter",
     "gs_gcond_get_dropout_iter", "gs_gcond_probe",
-    "gs_gcond_probe_read", "gs_gcond_probe_read_spans", "gs_gcond_probe_read_pass", "gs_gcond_probe_read_spmm", "gs_gcond_invalidate_forward", "gs_gcond_forward_cached",
+    "gs_gcond_probe_read", "gs_gcond_probe_read_spans", "gs_gcond_probe_read_pass", "gs_gcond_probe_read_spmm", "gs_gcond_invalidate_forward", "gs_gcond_forward_cached", "gs_gcond_forward_hoisted",
     "gs_gcond_adopt_cached_forward", "gs_gcond_stage_pge_forward_part", "gs_gcond_stage_pge_backward_part", "gs_gcond_stage_syn_finish",
     "gs_gcond_stage_inner_steps", "gs_bias_act_f32", "gs_log_softmax_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
     "gs_edge_pair_sum_f32", "gs_bn_scratch_bytes", "gs_bn_relu_fwd_f32", "gs_bn_relu_bwd_f32", "gs_edge_score_f32", "gs_edge_scatter_sym_f32",
@@ -152,6 +152,7 @@ def lib():
     L.gs_gcond_set_operand_mode.argtypes = [vp, i]
     L.gs_gcond_set_full_neighbour.argtypes = [vp, vp, l, vp]
     L.gs_gcond_set_forward_reuse.argtypes = [vp, i]
+    L.gs_gcond_forward_hoisted.argtypes = [vp]
     L.gs_gcond_set_dropout_iter.argtypes = [vp, C.c_uint64]
     L.gs_gcond_get_dropout_iter.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.gs_gcond_probe.argtypes = [vp, i]

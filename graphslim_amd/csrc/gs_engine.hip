@@ -1614,6 +1614,7 @@ static int block_apply(gs_gcond* e, const float* Qb, bool transpose, const float
 }
 
 extern "C" int gs_gcond_forward_cached(gs_gcond* e) { return e && e->reuse_fwd && e->fwd_cached ? 1 : 0; }
+extern "C" int gs_gcond_forward_hoisted(gs_gcond* e) { return e && e->fwd_hoisted && e->hoist_pending ? 1 : 0; }
 
 extern "C" int gs_gcond_stage_pge_forward(gs_gcond* e, int inference, gs_stream_t stream) {
   if (e && (sharded_r(e))) GS_FAIL(GS_ERR_STATE, "gs_gcond_stage_pge_forward: sharded engines must run the _part entry points with all-reduces in between");

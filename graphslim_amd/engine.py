@@ -461,6 +461,10 @@ class GCondEngine:
     def forward_cached(self):
         return bool(self.L.gs_gcond_forward_cached(self.h))
 
+    def forward_hoisted(self):
+        """The last outer step issued the next iteration's training forward ahead and the next call will take it up."""
+        return bool(self.L.gs_gcond_forward_hoisted(self.h))
+
     def adopt_cached_forward(self):
         check(self.L.gs_gcond_adopt_cached_forward(self.h, self._s()))
 

@@ -374,6 +374,10 @@ int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* blocks, gs_stream_t stream
  * forward ahead, beside its inner steps, and that forward reads both — the call waits for it).  gs_gcond_forward_cached returns 1
  * when the next step would adopt. */
 int gs_gcond_set_forward_reuse(gs_gcond* e, int on);
+/* 1 when the last gs_gcond_outer_step* call issued the NEXT iteration's training forward ahead (beside its inner steps, on the engine's
+ * third stream) and the next call will wait for it instead of computing it: unsharded engines without forward reuse, inner steps on.
+ * Any other entry point that touches what that pass reads or writes waits for it and drops it. */
+int gs_gcond_forward_hoisted(gs_gcond* e);
 /* cfg.dropout != 0: the iteration counter inside every dropout mask's key — 0 at creation, advanced by every gs_gcond_outer_step* call
  * (the staged calls read it and leave it alone).  Set it to resume a run at iteration i with the masks that run would have drawn, or
  * to pin the masks of staged calls (parity tests). */

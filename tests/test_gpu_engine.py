@@ -967,11 +967,13 @@ def test_hoisted_training_forward_changes_nothing_but_the_schedule(workload, sca
             x0 = eng.feat_syn.clone()
             for i, epoch in enumerate((0, 0, 10, 10, 0, 10)):
                 eng.outer_step(epoch)
+                assert eng.forward_hoisted() == bool(hoist)
                 if poke and i == 1:
                     eng.buffer("adj_norm")                    # a host read between two steps: the hoisted pass is waited for and dropped
                 if poke and i == 3:
                     eng.set_feat(eng.feat_syn.clone())        # a host write of X~ (same values): invalidated, recomputed
             eng.outer_step_ex(True, True, True, False)        # (DosCond's rule: no inner steps, nothing to hoist beside)
+            assert not eng.forward_hoisted()
             eng.outer_step(10)
             torch.cuda.synchronize()
             assert not torch.equal(eng.feat_syn, x0)

@@ -58,7 +58,9 @@ class _ReluTies:
 
 def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", relu_flip=None, scale=1.0, dropout=0.0):
     """driver: "staged" = the stage entry points one by one; "fused" = ONE gs_gcond_outer_step call (what bench.py times: two
-    streams, blocks sampled inside the call); "fused_reuse" = the same with forward reuse on, compared on the SECOND call (the
+    streams, blocks sampled inside the call); "fused_hoisted" = the same compared on the SECOND call, whose training forward the first
+    call issued ahead beside its inner steps (the persistent kernel on 7/8 of the compute units at this shape; the test asserts that
+    the hoisted pass was pending); "fused_reuse" = the same with forward reuse on, compared on the SECOND call (the
     one that adopts the cached inference forward of the first)."""
     import bench
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
@@ -72,12 +74,13 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", re
     bench.init_state(p, eng)
     torch.manual_seed(123)
     theta = bench.new_model(p, eng)
-    if driver == "fused_reuse":
-        eng.set_forward_reuse(True)
+    if driver in ("fused_reuse", "fused_hoisted"):
+        if driver == "fused_reuse":
+            eng.set_forward_reuse(True)
         eng.outer_step(epoch)
         drop_it += 1
         torch.cuda.synchronize()
-        assert eng.forward_cached()
+        assert eng.forward_cached() == (driver == "fused_reuse") and eng.forward_hoisted() == (driver == "fused_hoisted")
         theta = [t.cpu().clone() for t in eng.get_model()]          # theta after the first call's inner steps
     xs0, pge0 = eng.feat_syn.cpu().clone(), [t.cpu().clone() for t in eng.get_pge()]
     n, d = xs0.shape
@@ -134,7 +137,7 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", re
         o += k
     if driver != "staged" and epoch % 50 < 10:
         out["g_feat"] = 0.0          # (not computed by the fused call in a PGE epoch)
-    if driver == "fused_reuse":      # the optimisers of both sides have stepped a different number of times: gradients only
+    if driver in ("fused_reuse", "fused_hoisted"):      # the optimisers of both sides have stepped a different number of times: gradients only
         out.update(upd_well_max=0.0, upd_any_frac=0.0, adj=0.0, model_bad_frac=0.0, model_max=0.0)
         O.DROPOUT = None
         return out
@@ -196,11 +199,12 @@ def check(r, adj_tol=None):
     assert r["model_bad_frac"] <= 1e-3, r
 
 
-@pytest.mark.parametrize("driver", ["fused", "fused_reuse"])
+@pytest.mark.parametrize("driver", ["fused", "fused_hoisted", "fused_reuse"])
 @pytest.mark.parametrize("epoch", [10, 0])
 def test_fused_outer_step_full_size(epoch, driver):
     """the call bench.py times — gs_gcond_outer_step, real side on the second stream, blocks sampled inside
-    the call, forward reuse off and on — against the oracle at the full ogbn-arxiv shape, on the blocks that call drew."""
+    the call, forward reuse off and on, and the call whose training forward the previous call issued ahead — against the oracle at the
+    full ogbn-arxiv shape, on the blocks that call drew."""
     check(run_config("ogbn-arxiv", epoch, driver=driver))
 
 
