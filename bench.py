@@ -407,6 +407,15 @@ def main():
         acc = eval_accuracy(p, eng_job, args.eval_epochs)
         del eng_job
         torch.cuda.empty_cache()
+    else:
+        # no bounded job in front (multi-rank runs, --eval-epochs 0): one second of the same iterations, untimed, so that the W warm-up
+        # steps and the K timed ones do not start on a chip that was idle a moment ago (profiles/r05/bench_repeat.txt: 528 it/s in
+        # the 50 timed steps of one cold process whose `sustained` figure was 669)
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 1.0:
+            run_steps(p, eng, 10, 10)
+            torch.cuda.synchronize()
+        eng.read_loss()
     run_steps(p, eng, args.warmup, max(args.warmup, 1))
     eng.read_loss()
     barrier()
