@@ -411,11 +411,18 @@ def main():
         # no bounded job in front (multi-rank runs, --eval-epochs 0): one second of the same iterations, untimed, so that the W warm-up
         # steps and the K timed ones do not start on a chip that was idle a moment ago (profiles/r05/bench_repeat.txt: 528 it/s in
         # the 50 timed steps of one cold process whose `sustained` figure was 669)
+        # (on an engine of its own, like the bounded job: the timed engine's state stays what the seeds make it)
+        eng_pre = make_engine(p, dev)
+        eng_pre.set_operand_mode(args.operand_mode)
+        init_state(p, eng_pre)
+        if args.full_neighbour:
+            eng_pre.set_full_neighbour(S_full, rs_full)
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < 1.0:
-            run_steps(p, eng, 10, 10)
+            run_steps(p, eng_pre, 10, 10)
             torch.cuda.synchronize()
-        eng.read_loss()
+        del eng_pre
+        torch.cuda.empty_cache()
     run_steps(p, eng, args.warmup, max(args.warmup, 1))
     eng.read_loss()
     barrier()
