@@ -411,7 +411,9 @@ def main():
         # no bounded job in front (multi-rank runs, --eval-epochs 0): one second of the same iterations, untimed, so that the W warm-up
         # steps and the K timed ones do not start on a chip that was idle a moment ago (profiles/r05/bench_repeat.txt: 528 it/s in
         # the 50 timed steps of one cold process whose `sustained` figure was 669)
-        # (on an engine of its own, like the bounded job: the timed engine's state stays what the seeds make it)
+        # (on an engine of its own, like the bounded job, and with the host generators put back afterwards — the loop is bounded by
+        # time, its theta draws are not a fixed number: the timed engine's state stays what the seeds make it)
+        rng_keep = (torch.get_rng_state(), np.random.get_state())
         eng_pre = make_engine(p, dev)
         eng_pre.set_operand_mode(args.operand_mode)
         init_state(p, eng_pre)
@@ -423,6 +425,8 @@ def main():
             torch.cuda.synchronize()
         del eng_pre
         torch.cuda.empty_cache()
+        torch.set_rng_state(rng_keep[0])
+        np.random.set_state(rng_keep[1])
     run_steps(p, eng, args.warmup, max(args.warmup, 1))
     eng.read_loss()
     barrier()
