@@ -283,6 +283,14 @@ def test_three_hops_against_the_oracle(name, scale):
     check(run_config(name, 10, scale=scale, driver="fused"))
 
 
+def test_three_hops_with_dropout_against_the_oracle():
+    """`--nlayers 3` together with dropout in the condensation model: the masks act on the hidden rows the OUTERMOST of three gathers
+    reads (keyed by node id) and on the per-edge indicator of the backward through three blocks, on the synthetic side on Q = A^^3 —
+    a whole fused iteration and a staged PGE-epoch iteration at 15 % of the ogbn-arxiv shape."""
+    check(run_config("arxiv-k3", 10, scale=0.15, driver="fused", dropout=0.3))
+    check(run_config("arxiv-k3", 0, scale=0.15, dropout=0.3))
+
+
 def test_cora_r025_full_size():
     """BASELINE configs[1] in its fp32 form (the bf16 operand mode of the same config: test_gpu_operand_modes.py)."""
     check(run_config("cora-r0.25", 10))
