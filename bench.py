@@ -53,7 +53,7 @@ def roofline(eng, passes, mode="f32", reps=20, hoisted=False):
     operand path, BN-2 column sums in the epilogue; parametrized_adj.py:57-64), 2 n'^2 Ph^2 algorithmic flops per launch.  It is
     launched twice per iteration by TWO kernels, reported separately: the inference pass on the persistent
     256-row kernel (csrc/gs_panel2.hip, alone on the chip) = the top-level entry, and the training pass = `training_pass`: with one
-    GPU it is the NEXT iteration's pass, issued beside the inner steps on the same persistent kernel with 7/8 of the compute units
+    GPU it is the NEXT iteration's pass, issued beside the inner steps on the same persistent kernel with 13/16 of the compute units
     (`hoisted`; gs_engine.hip outer_step_body) — sharded ranks run it at the top of the iteration on the 128-row kernel
     (csrc/gs_panel.hip, beside the real-side stream).  `passes` = {pass: (event bracket ms, launches, device span
     ms, spans)} from the engine's probe, recorded on the launch stream around every launch INSIDE the timed steps; `achieved` is
@@ -112,7 +112,7 @@ def roofline(eng, passes, mode="f32", reps=20, hoisted=False):
             out["frac_of_sustained_peak"] = round(ach / sus["loop_with_operand_preparation_TFLOPs"], 4)
         if tag == "training" and hoisted:
             out["where"] = ("the next iteration's training forward, issued on a third stream beside this iteration's inner steps"
-                            + (": the persistent kernel on 7/8 of the compute units (peak and fractions are the whole chip's)" if tall else ""))
+                            + (": the persistent kernel on 13/16 of the compute units (peak and fractions are the whole chip's)" if tall else ""))
         out["traffic"], out["traffic_source"] = None, None
         if (n, ph) == (454, 256):
             path, blob, hit = newest_profile("pmc_panel_summary.json", knames[tag])

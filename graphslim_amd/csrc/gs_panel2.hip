@@ -709,9 +709,9 @@ static int g_tall_krep = 1, g_tall_triage = 0, g_tall_phases = 1;
 static unsigned* g_tall_trace = nullptr;
 static int g_tall_split = 1;      // 1: waves 0-3 [prepare, MFMA], waves 4-7 [MFMA, prepare]; 0: every wave [MFMA, prepare]
 
-static int g_tall_hoist_share = 7;      // compute units (in eighths) the hoisted pass's persistent grid takes (gs_tall_forward_a1, alone = 2)
-extern "C" int gs_panel_set_hoist_share(int eighths) {
-  g_tall_hoist_share = eighths < 1 ? 1 : (eighths > 8 ? 8 : eighths);
+static int g_tall_hoist_share = 13;     // compute units (in sixteenths) the hoisted pass's persistent grid takes (gs_tall_forward_a1, alone = 2)
+extern "C" int gs_panel_set_hoist_share(int sixteenths) {
+  g_tall_hoist_share = sixteenths < 1 ? 1 : (sixteenths > 16 ? 16 : sixteenths);
   return GS_OK;
 }
 extern "C" int gs_gemm_set_panel_tall(int on) {
@@ -796,9 +796,9 @@ int gs_tall_forward_a1(const float* Us, const float* Vs, long ld, int n, int nr,
   a.span = span; a.krep = g_tall_krep; a.triage = g_tall_triage; a.phases = g_tall_phases;
   dim3 grid(tall_grid(gs_cdiv(a.M, 64), 4)), block(512);
   // alone == 2: the pass runs beside a chain of latency-bound launches (the inner SGC steps while the next iteration's training forward
-  // is hoisted, gs_engine.hip): the persistent grid leaves one compute unit in eight to them — a full grid made every one of their
+  // is hoisted, gs_engine.hip): the persistent grid leaves three compute units in sixteen to them (sweep: profiles/r05/stage_times_hoist_share.txt) — a full grid made every one of their
   // ~20 small launches wait for a workgroup of this kernel to retire (inner steps 140 -> 323 us, profiles/r05/timeline_hoisted_full_grid.txt)
-  if (alone == 2 && g_tall_grid == 0) { const int cap = tall_cus() * g_tall_hoist_share / 8; if ((int)grid.x > cap) grid.x = cap > 0 ? cap : 1; }
+  if (alone == 2 && g_tall_grid == 0) { const int cap = tall_cus() * g_tall_hoist_share / 16; if ((int)grid.x > cap) grid.x = cap > 0 ? cap : 1; }
   if (g_tall_split == 2) hipLaunchKernelGGL((gs_tall_kernel<TP_FGEN, false, 0, 2>), grid, block, 0, s, a);      // (measurement: interleaved form)
   else if (g_tall_triage || g_tall_krep != 1) TP_LAUNCH(TP_FGEN, false, 1);      // (measurement: phases switched off, results are garbage)
   else TP_LAUNCH(TP_FGEN, false, 0);

@@ -10,9 +10,9 @@ extern "C" {
 /* exact-split products at N = 256 on the persistent 256-row kernel of csrc/gs_panel2.hip (default 1); 0 = the 128-row kernels of
    csrc/gs_panel.hip everywhere (bitwise the same products; BN-2 partial sums grouped per tile instead of per workgroup) */
 int gs_gemm_set_panel_tall(int on);
-/* Measurement knob: the share of the compute units (in eighths, default 7) the persistent grid of the HOISTED training forward takes
- * (gs_gcond_set_hoist_forward): the rest stays free for the inner steps' small launches running beside it. */
-int gs_panel_set_hoist_share(int eighths);
+/* Measurement knob: the share of the compute units (in sixteenths, default 13) the persistent grid of the HOISTED training forward
+ * takes (gs_gcond_set_hoist_forward): the rest stays free for the inner steps' small launches running beside it. */
+int gs_panel_set_hoist_share(int sixteenths);
 /* csrc/gs_panel2.hip: workgroups per launch (0 = one per compute unit), K loop of every tile repeated krep times, triage bits
    (results are garbage): 1 no epilogue, 2 no A staging, 4 no B staging, 8 no waits / barriers, 16 no MFMAs, 32 no operand split;
    scheduling bits (results unchanged): 64 every share starts with a full tile, 128 every wave runs a step as [MFMA, prepare], 256 / 512

@@ -59,7 +59,7 @@ class _ReluTies:
 def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", relu_flip=None, scale=1.0, dropout=0.0):
     """driver: "staged" = the stage entry points one by one; "fused" = ONE gs_gcond_outer_step call (what bench.py times: two
     streams, blocks sampled inside the call); "fused_hoisted" = the same compared on the SECOND call, whose training forward the first
-    call issued ahead beside its inner steps (the persistent kernel on 7/8 of the compute units at this shape; the test asserts that
+    call issued ahead beside its inner steps (the persistent kernel on 13/16 of the compute units at this shape; the test asserts that
     the hoisted pass was pending); "fused_reuse" = the same with forward reuse on, compared on the SECOND call (the
     one that adopts the cached inference forward of the first)."""
     import bench
