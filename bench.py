@@ -328,6 +328,8 @@ def main():
     ap.add_argument("--workload", default="ogbn-arxiv", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink N for smoke runs (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prerun", action="store_true", help="skip the one second of untimed iterations that stands in for the bounded job when "
+                                                             "that job does not run (profiling runs: the kernel statistics then cover the warm-up and timed steps only)")
     ap.add_argument("--sustain-s", type=float, default=2.0, help="seconds of extra back-to-back iterations for the `sustained` field (0 = off)")
     ap.add_argument("--operand-mode", default=None, choices=["f32", "bf16x6", "bf16x3", "bf16"],
                     help="operand form of the five large contractions for the HEADLINE run (default: the engine's default, the exact "
@@ -407,7 +409,7 @@ def main():
         acc = eval_accuracy(p, eng_job, args.eval_epochs)
         del eng_job
         torch.cuda.empty_cache()
-    else:
+    elif not args.no_prerun:
         # no bounded job in front (multi-rank runs, --eval-epochs 0): one second of the same iterations, untimed, so that the W warm-up
         # steps and the K timed ones do not start on a chip that was idle a moment ago (profiles/r05/bench_repeat.txt: 528 it/s in
         # the 50 timed steps of one cold process whose `sustained` figure was 669)

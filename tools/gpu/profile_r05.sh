@@ -10,12 +10,12 @@ nproc > $O/host.txt; lscpu | grep "Model name" >> $O/host.txt
 timeout 600 python bench.py > $O/bench_arxiv.json 2> $O/bench_arxiv.err
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_arxiv_driver_args.json 2>/dev/null
 timeout 600 python bench.py --operand-mode f32 --no-cpu-baseline --eval-epochs 0 > $O/bench_arxiv_f32.json 2>/dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --sustain-s 0 --eval-epochs 0 --no-modes > $O/bench_under_rocprof.json 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --sustain-s 0 --eval-epochs 0 --no-modes --no-prerun > $O/bench_under_rocprof.json 2>/dev/null
 cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/bench_arxiv_kernel_stats.csv
 f=$(ls $O/kt/*/*kernel_trace.csv | head -1); python3 tools/timeline_csv.py $f 70 > $O/timeline_noreuse.txt 2>/dev/null; python3 tools/timeline_csv.py $f 12 > $O/timeline_reuse.txt 2>/dev/null
 rm -rf $O/kt
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_bench_$c -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain-s 0 --eval-epochs 0 --no-modes > /dev/null 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_bench_$c -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain-s 0 --eval-epochs 0 --no-modes --no-prerun > /dev/null 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_panel_$c -- python3 tools/probe_panel.py > /dev/null 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_dw1_$c -- python3 tools/probe_dw1.py > /dev/null 2>&1
 done
