@@ -892,7 +892,12 @@ extern "C" int gs_gcond_stage_sample(gs_gcond* e, gs_stream_t stream) {
 // stage: real-side per-class gradients gw_real[c] (gcond_base.py:212-224), propagate-first form
 // ================================================================================================
 // (ebits: per-edge sign bits of the gathered rows, see gs_ell_spmm_kernel; returns whether they were written — 16-byte path, F = 256)
+static int g_pad_zero = 0;          // measurement knob: 1 = the gathers feeding another gather also zero their padding rows (rounds 1-4)
 static int g_ell_xcd = 1;
+extern "C" int gs_gcond_set_pad_zero(int on) {
+  g_pad_zero = on != 0;
+  return GS_OK;
+}
 extern "C" int gs_gcond_set_ell_xcd(int on) {
   g_ell_xcd = on != 0;
   return GS_OK;
@@ -900,7 +905,7 @@ extern "C" int gs_gcond_set_ell_xcd(int on) {
 static bool launch_ell(const int* col, const float* val, const int* nrows, int cap_rows, int f, long col_base_stride,
                        const float* src, long ld_src, const float* rs_in, int F, float* out, long ld_out, float* rs_out, int C,
                        hipStream_t s, unsigned* ebits = nullptr, unsigned long long dkey0 = 0, int dclass0 = 0, unsigned dthr = 0,
-                       float dq = 1.f) {
+                       float dq = 1.f, int pad_zero = 1) {
   long waves = (long)C * cap_rows;
   int blocks = gs_cdiv(waves, 4);
   // class -> XCD affinity of the gather's workgroups (gs_ell_spmm_kernel; g_ell_xcd: measurement knob, default on)
@@ -912,15 +917,15 @@ static bool launch_ell(const int* col, const float* val, const int* nrows, int c
   if (dthr) {      // dropout on the gathered rows (the hop-2 gather of the hidden activations; 16-byte rows: checked at creation)
     if (!vec) return false;
     hipLaunchKernelGGL((gs_ell_spmm_kernel<4, true>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
-                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, (unsigned*)nullptr, xcd, dkey0, dclass0, dthr, dq);
+                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, (unsigned*)nullptr, xcd, dkey0, dclass0, dthr, dq, pad_zero);
     return false;
   }
   if (vec)
     hipLaunchKernelGGL((gs_ell_spmm_kernel<4>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
-                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, bits ? ebits : (unsigned*)nullptr, xcd);
+                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, bits ? ebits : (unsigned*)nullptr, xcd, 0ull, 0, 0u, 1.f, pad_zero);
   else
     hipLaunchKernelGGL((gs_ell_spmm_kernel<1>), dim3(blocks), dim3(256), 0, s, col, val, nrows, cap_rows, f, col_base_stride,
-                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, (unsigned*)nullptr, xcd);
+                       src, ld_src, rs_in, F, out, ld_out, rs_out, C, (unsigned*)nullptr, xcd, 0ull, 0, 0u, 1.f, pad_zero);
   return bits;
 }
 
@@ -1113,7 +1118,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   // dropout (models/sgc.py:42): class c's batch draws its own mask over its n_id rows — here a function of (class, node id, column)
   const unsigned long long dkey_r = e->drop_thr ? gs_drop_key0(e->cfg.seed, e->drop_iter, 0) : 0ull;
   have_ebits = launch_ell(b.col0, b.val0, nL, capL, f2, 0, src, ld_src, nullptr, F, P0, Fp, rs0, Cl, s,
-                                     want_ebits ? e->edge_bits + c0 * cap1 * f2 * 8 : nullptr, dkey_r, (int)c0, e->drop_thr, e->drop_q);
+                                     want_ebits ? e->edge_bits + c0 * cap1 * f2 * 8 : nullptr, dkey_r, (int)c0, e->drop_thr, e->drop_q,
+                                     g_pad_zero);      // (P0's padding rows are never read: the next gather walks live indices)
   if (probe2) {
     GS_HIP(hipEventRecord(e->probe2_ev[2 * e->probe2_n + 1], s));
     e->probe2_n++;
@@ -1123,7 +1129,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   for (int m = nmid - 1; m >= 0; --m) {
     const int capp = m == 0 ? cap1 : b.capm[m - 1];
     float* Pm = e->Pmid[m] + c0 * capp * Fp; float* rsm = e->rsmid[m] + c0 * capp;
-    launch_ell(b.colm[m], b.valm[m], m == 0 ? b.n1 : b.nm[m - 1], capp, b.fm[m], b.capm[m], Pin, Fp, rsin, F, Pm, Fp, rsm, Cl, s);
+    launch_ell(b.colm[m], b.valm[m], m == 0 ? b.n1 : b.nm[m - 1], capp, b.fm[m], b.capm[m], Pin, Fp, rsin, F, Pm, Fp, rsm, Cl, s, nullptr, 0ull,
+               0, 0u, 1.f, g_pad_zero);
     Pin = Pm; rsin = rsm;
   }
   launch_ell(b.col1, b.val1, b.n_seed, bcap, f1, cap1, Pin, Fp, rsin, F, Sr, Fp, rsr, Cl, s);

@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
                                                           const float* __restrict__ rs_in, int F, float* __restrict__ out,
                                                           long ld_out, float* __restrict__ rs_out, int nclass,
                                                           unsigned* __restrict__ ebits = nullptr, int xcd_map = 0,
-                                                          unsigned long long dkey0 = 0, int dclass0 = 0, unsigned dthr = 0, float dq = 1.f) {
+                                                          unsigned long long dkey0 = 0, int dclass0 = 0, unsigned dthr = 0, float dq = 1.f,
+                                                          int pad_zero = 1) {
+  // pad_zero = 0: rows >= nrows[c] are left unwritten — the output is only ever read through the next gather's live indices (the
+  // outermost and middle hops of the real side: a third of the capacity rows are padding, round 5).
   // DROP (VEC = 4 only): every gathered source row is multiplied by the dropout mask of (class dclass0 + c, source row, column) before it
   // is summed — the hop-2 gather of H1 = relu(X W1 + b1) under models/sgc.py:42 (see gs_drop_mult4).
   // ebits (VEC = 4, F = 256, optional): per edge slot (grow * f + j) the sign bits of the gathered source row, bit (n & 31) of word
@@ -120,6 +123,7 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
   }
   float* o = out + grow * ld_out;
   if (row >= nrows[c]) {
+    if (!pad_zero) return;
     for (int c0 = lane * VEC; c0 < F; c0 += 64 * VEC)
       for (int q = 0; q < VEC; ++q)
         if (c0 + q < (VEC == 4 ? (int)ld_out : F)) o[c0 + q] = 0.f;
@@ -980,7 +984,8 @@ __global__ __launch_bounds__(256) void gs_csc_spmm_t_v4_kernel(const int* __rest
   if (grow >= (long)nclass * cap1) return;
   const int c = (int)(grow / cap1), l = (int)(grow - (long)c * cap1);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (l < n1[c]) {
+  if (l >= n1[c]) return;      // (padding rows of Y are never read: the edge product / the next block's CSC walk live edges only)
+  {
     const int* tp = tptr + (long)c * (cap1 + 1);
     const int* te = tedge + (long)c * bcap * f1;
     const float* vv = val1 + (long)c * bcap * f1;

@@ -101,6 +101,11 @@ int gs_gcond_set_edge_plan(int on);
  * 0 = rows in memory order over all XCDs.  Same values (every row is computed by the same code either way). */
 int gs_gcond_set_ell_xcd(int on);
 
+/* Measurement knob: 0 (default) = the real side's gathers whose output is only read through the NEXT gather's live indices (outermost
+ * and middle hops) leave their padding rows unwritten (a third of the capacity rows); 1 = they write zeros there (rounds 1-4).  Same
+ * values: nothing reads those rows.  (The transposed gathers of the backward skip their padding rows unconditionally.) */
+int gs_gcond_set_pad_zero(int on);
+
 /* Measurement knob: 1 (default) = gs_gcond_outer_step* issues the NEXT iteration's training forward of the PGE (gcond.py:48: a function
  * of X~ and theta_PGE only, both final once the optimiser has stepped) on a third, lowest-priority stream beside its inner SGC steps;
  * the next call waits for it instead of computing it.  Same launches on the same inputs: bitwise the same values.  0 = the forward
