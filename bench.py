@@ -101,7 +101,7 @@ def roofline(eng, passes, mode="f32", reps=20, hoisted=False):
         sec = span_ms / 1e3 / ks if ks else bracket_ms / 1e3 / k
         ach = mult * flops / sec / 1e12 if bound == "mfma" else alg_bytes / sec / 1e9
         out = {"kernel": knames[tag] + " ...>" if ph == 256 and n >= 128 else "PGE layer-2 product (row-panel / tile route of this shape)",
-               "avg_launch_us": round(sec * 1e6, 2), "launches_timed": int(k),
+               "avg_launch_us": round(sec * 1e6, 2), "launches_timed": int(ks if ks else k), "event_brackets_timed": int(k),
                "avg_launch_source": ("device span (first workgroup start .. last workgroup end, s_memrealtime) of the launches inside the timed steps"
                                      if ks else "HIP-event bracket inside the timed steps"),
                "event_bracket_us": round(bracket_ms / k * 1e3, 2),
@@ -433,7 +433,10 @@ def main():
     eng.read_loss()
     barrier()
     base = getattr(eng, "eng", eng)      # the engine behind a ShardedGCond
-    base.probe(True)                     # event pairs around the dominant kernel's launches inside the timed steps
+    # the dominant kernel's launches inside the timed steps: device-side spans on every launch; HIP-event brackets (two stream markers
+    # each: with one on every launch the probe cost 18 us per step, profiles/r05/probe_cost.txt) on every 4th launch of the dominant
+    # product's passes and of the hop-2 gather when the timed region has >= 16 steps, else on every launch
+    base.probe(4 if args.steps >= 16 else True)
     if world > 1:                        # event pairs around every exchange: per-join communication time
         if eng.driver == "python":
             eng.col.timing = True

@@ -162,6 +162,8 @@ struct gs_gcond {
   bool probing;
   int probe_n;
   unsigned char probe_pass[256];       // 1: the probed launch was the inference pass, 0: the training pass
+  unsigned char probe_has_ev[256];     // the launch also carries a HIP-event bracket (every probe_stride-th launch of its pass)
+  int probe_stride, probe_seen[2], probe2_seen;
   hipEvent_t probe_ev[2 * 256];
   int probe2_n;
   hipEvent_t probe2_ev[2 * 256];     // the same for the hop-2 gather SpMM of the real side (gs_ell_spmm_kernel), on ITS stream
@@ -591,6 +593,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->reuse_fwd = false; e->fwd_cached = false; e->real_beside = false;
   e->blk_cur = 0; e->prefetched = false; e->identity = false;
   e->probing = false; e->probe_n = 0; e->probe2_n = 0;
+  e->probe_stride = 1; e->probe_seen[0] = e->probe_seen[1] = e->probe2_seen = 0;
   for (int i = 0; i < 2 * 256; ++i) e->probe2_ev[i] = nullptr;
   e->operand_mode = 0;
   e->S_full = nullptr; e->ldS = 0; e->rs_full = nullptr;
@@ -1107,7 +1110,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
                        b.nid1, cap1, b.n_seed, bcap, F, Sr, Fp, rsr, Cl);
   } else {
   // hop 2 (outermost): frontier rows <- global sources;  hop 1: seeds <- frontier
-  const bool probe2 = e->probing && e->probe2_n < 256;
+  // (event brackets cost two stream markers per launch, ~8 us on this chain: they are recorded on every probe_stride-th launch)
+  const bool probe2 = e->probing && e->probe2_n < 256 && (e->probe2_seen++ % e->probe_stride) == 0;
   if (probe2) {
     for (int q = 0; q < 2; ++q)
       if (!e->probe2_ev[2 * e->probe2_n + q]) GS_HIP(hipEventCreate(&e->probe2_ev[2 * e->probe2_n + q]));
@@ -1432,14 +1436,18 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
       // materialise it lazily for dW1 (ensure_a1).
       gs_panel_a1 a1 = pge_a1(e);
       a1.b_ready = pre_split ? 1 : 0;
+      // device-side spans (two atomics per workgroup, no stream traffic) on every probed launch; the HIP-event bracket — two stream
+      // markers, ~5 us of this chain per launch — on every probe_stride-th launch of its pass
       const bool probe = e->probing && e->probe_n < 256;
-      if (probe) {
+      const bool probe_ev = probe && (e->probe_seen[inference ? 1 : 0]++ % e->probe_stride) == 0;
+      if (probe_ev) {
         for (int q = 0; q < 2; ++q)
           if (!e->probe_ev[2 * e->probe_n + q]) GS_HIP(hipEventCreate(&e->probe_ev[2 * e->probe_n + q]));
       }
       e->a1_valid = false;
       int tiles = 0;
-      if (probe) { e->probe_pass[e->probe_n] = inference ? 1 : 0; GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s)); }
+      if (probe) { e->probe_pass[e->probe_n] = inference ? 1 : 0; e->probe_has_ev[e->probe_n] = probe_ev ? 1 : 0; }
+      if (probe_ev) GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s));
       const int rc = gs_panel_forward_a1(&a1, n, nr, pp + e->pW1, Ph, pp + e->pb1, e->E2, Ph, Ph, Ph, e->statp, &tiles, e->operand_mode,
                                          e->bsplit_main, probe ? e->probe_span + 2 * e->probe_n : nullptr,
                                          e->hoisting ? 2 : inference, s);
@@ -1453,14 +1461,12 @@ extern "C" int gs_gcond_stage_pge_forward_part(gs_gcond* e, int inference, int p
         g.bias = pp + e->pb1;
         g.colstat = e->statp;            // BN-2 batch statistics come out of the epilogue: no second pass over E2
         g.prec = e->operand_mode; g.scratch = e->bsplit_main;
-        if (probe) GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s));
+        if (probe_ev) GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n], s));
         GS_TRY(gs_gemm_f32(&g, stream));
         tiles = gs_gemm_tiles_m(&g);
       }
-      if (probe) {
-        GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n + 1], s));
-        e->probe_n++;
-      }
+      if (probe_ev) GS_HIP(hipEventRecord(e->probe_ev[2 * e->probe_n + 1], s));
+      if (probe) e->probe_n++;
       // (unsharded: the last reduction stage is folded into gs_bn2_from_sums; sharded ranks exchange e->sums in between)
       e->bn2_done = false;
       // (<= 256 partial rows — the persistent kernel's one per workgroup: 8 workgroups sum them as fast as the 512 of the two-stage
@@ -2838,6 +2844,8 @@ extern "C" int gs_gcond_probe(gs_gcond* e, int on) {
   if (on) {
     e->probe_n = 0;
     e->probe2_n = 0;
+    e->probe_stride = on > 1 ? on : 1;      // (on > 1: HIP-event brackets on every on-th launch only; the device-side spans on all)
+    e->probe_seen[0] = e->probe_seen[1] = e->probe2_seen = 0;
     // (every event the probe may record exists before the first probed launch: creating them lazily put ~300 hipEventCreate calls
     // into the first probed steps — the timed ones of bench.py)
     for (int i = 0; i < 2 * 256; ++i) {
@@ -2881,10 +2889,12 @@ extern "C" int gs_gcond_probe_read_pass(gs_gcond* e, int pass, double* bracket_m
   long kb = 0, ks = 0;
   for (int i = 0; i < e->probe_n; ++i) {
     if ((int)e->probe_pass[i] != (pass != 0)) continue;
-    float ms = 0.f;
-    GS_HIP(hipEventSynchronize(e->probe_ev[2 * i + 1]));
-    GS_HIP(hipEventElapsedTime(&ms, e->probe_ev[2 * i], e->probe_ev[2 * i + 1]));
-    tb += ms; ++kb;
+    if (e->probe_has_ev[i]) {
+      float ms = 0.f;
+      GS_HIP(hipEventSynchronize(e->probe_ev[2 * i + 1]));
+      GS_HIP(hipEventElapsedTime(&ms, e->probe_ev[2 * i], e->probe_ev[2 * i + 1]));
+      tb += ms; ++kb;
+    }
     if (h[2 * i + 1] > h[2 * i] && h[2 * i] != ~0ull) { ts += (double)(h[2 * i + 1] - h[2 * i]) * 1e-5; ++ks; }
   }
   *bracket_ms = tb; *launches = kb; *span_ms = ts; *span_launches = ks;
@@ -2894,14 +2904,16 @@ extern "C" int gs_gcond_probe_read_pass(gs_gcond* e, int pass, double* bracket_m
 extern "C" int gs_gcond_probe_read(gs_gcond* e, double* total_ms, long* launches) {
   if (!e || !total_ms || !launches) GS_FAIL(GS_ERR_ARG, "gs_gcond_probe_read: null argument");
   double t = 0;
+  long k = 0;
   for (int i = 0; i < e->probe_n; ++i) {
+    if (!e->probe_has_ev[i]) continue;
     float ms = 0.f;
     GS_HIP(hipEventSynchronize(e->probe_ev[2 * i + 1]));
     GS_HIP(hipEventElapsedTime(&ms, e->probe_ev[2 * i], e->probe_ev[2 * i + 1]));
-    t += ms;
+    t += ms; ++k;
   }
   *total_ms = t;
-  *launches = e->probe_n;
+  *launches = k;
   return GS_OK;
 }
 

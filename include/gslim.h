@@ -386,7 +386,8 @@ int gs_gcond_get_dropout_iter(gs_gcond* e, unsigned long long* iter);
 /* In-situ timing of the dominant kernel (PGE layer-2 GEMM, 2 n'^2 Ph^2 FLOP per launch): while on, HIP events are recorded
  * on the launch stream around each of its launches inside the outer steps (at most 256); _read synchronises them and
  * returns the summed duration [ms] and the launch count since the probe was switched on.  bench.py's roofline uses it. */
-int gs_gcond_probe(gs_gcond* e, int on);
+int gs_gcond_probe(gs_gcond* e, int on);      /* on > 1: the event brackets on every on-th launch only (two stream markers per bracket cost
+                                               * ~5 us of the dependent chain); the device-side spans of _read_spans / _read_pass on every launch */
 int gs_gcond_probe_read(gs_gcond* e, double* total_ms, long* launches);
 int gs_gcond_probe_read_spmm(gs_gcond* e, double* total_ms, long* launches);   /* the hop-2 gather SpMM of the real side, on its own stream */
 /* Device-side spans of the same launches (first workgroup start .. last workgroup end, s_memrealtime at 100 MHz), for the
