@@ -14,7 +14,7 @@ def per_dispatch(d, counter):
     rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and "gs_ell_spmm_kernel<4>" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and "gs_ell_spmm_kernel<4" in r["Kernel_Name"]:
                 rows.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     return rows
 
