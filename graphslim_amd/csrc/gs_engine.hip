@@ -1121,6 +1121,9 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
                           !e->drop_thr;
   // dropout (models/sgc.py:42): class c's batch draws its own mask over its n_id rows — here a function of (class, node id, column)
   const unsigned long long dkey_r = e->drop_thr ? gs_drop_key0(e->cfg.seed, e->drop_iter, 0) : 0ull;
+  if (e->drop_thr && !(ld_src % 4 == 0 && Fp % 4 == 0 && ld_src >= ((F + 3) & ~3) && Fp >= ((F + 3) & ~3) &&
+                       (((uintptr_t)src | (uintptr_t)P0) % 16 == 0)))      // (the masked gather exists in the 16-byte form only)
+    GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: dropout needs 16-byte rows in the hop-2 gather (hidden %% 4 == 0, aligned buffers)");
   have_ebits = launch_ell(b.col0, b.val0, nL, capL, f2, 0, src, ld_src, nullptr, F, P0, Fp, rs0, Cl, s,
                                      want_ebits ? e->edge_bits + c0 * cap1 * f2 * 8 : nullptr, dkey_r, (int)c0, e->drop_thr, e->drop_q,
                                      g_pad_zero);      // (P0's padding rows are never read: the next gather walks live indices)
