@@ -80,10 +80,12 @@ def adj_power_bwd(A, dQ, K):
     return sum(pw[i].T @ dQ @ pw[K - 1 - i].T for i in range(K))
 
 
-def real_class_grad(theta, X, batch, cls):
+def real_class_grad(theta, X, batch, cls, mult=None):
     """batch = (B, n_id, [blk0 (n1 x n2), blk1 (B x n1)]) with dense block matrices (tests only); with K > 2 hops the list is
     outermost first as the sampler returns it and every block but the innermost composes into `A0` (the engine applies them one by one).
-    T=1: S = A1 A0 X_g;  T=2: S = A1 A0 relu(X_g W1 + b1).  Returns gw list like model.parameters()."""
+    T=1: S = A1 A0 X_g;  T=2: S = A1 A0 relu(X_g W1 + b1).  Returns gw list like model.parameters().
+    mult (T = 2): the dropout multiplier of this forward (models/sgc.py:42; [len(n_id), h], kept entries 1 / (1 - p), dropped 0) — it
+    scales the hidden activations and, with the ReLU indicator, their backward."""
     B, n_id, blocks = batch
     A1 = blocks[-1]
     A0 = blocks[-2]
@@ -102,7 +104,8 @@ def real_class_grad(theta, X, batch, cls):
         return [S.T @ G, rs @ G]
     W1, b1, W2, b2 = theta
     Hp = Xg @ W1 + b1
-    H1 = Hp.clamp_min(0)
+    Dm = (Hp > 0).to(X.dtype) if mult is None else (Hp > 0).to(X.dtype) * mult      # relu' (x the dropout multiplier)
+    H1 = Hp * Dm
     S = A1 @ (A0 @ H1)
     Z = S @ W2 + rs[:, None] * b2
     G = torch.softmax(Z, 1)
@@ -110,7 +113,7 @@ def real_class_grad(theta, X, batch, cls):
     G /= B
     Tm = G @ W2.T                 # [B, h]
     Y1 = A1.T @ Tm                # [n1, h]
-    dHp = (A0.T @ Y1) * (Hp > 0)  # [n2, h]   (the engine forms this edge-wise, without A0^T)
+    dHp = (A0.T @ Y1) * Dm        # [n2, h]   (the engine forms this edge-wise, without A0^T)
     return [Xg.T @ dHp, dHp.sum(0), S.T @ G, rs @ G]
 
 
@@ -119,10 +122,13 @@ def real_class_grad(theta, X, batch, cls):
 # ------------------------------------------------------------------------------------------------
 
 
-def syn_match(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="ours", K=2):
+def syn_match(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="ours", K=2, mults=None):
     """class_ranges[c] = (lo, hi) rows of class c (empty classes allowed: lo == hi -> skipped, the
     reference would produce NaN there; GraphSlim never creates one because of max(...,1)).
-    Returns (loss, dX, dA) with dX the gradient through the GNN input only (PGE path added later)."""
+    Returns (loss, dX, dA) with dX the gradient through the GNN input only (PGE path added later).
+    mults (two transforms): per class the dropout multiplier [n', h] of ITS synthetic forward (models/sgc.py:42: the model is called
+    once per class in training mode) — the hidden activations then exist once per class, H1_c = relu(.) * mults[c]; only class c's
+    rows of S_c = Q H1_c enter its loss, so every product below keeps its size (what csrc/gs_engine.hip's dropout path computes)."""
     n = Xs.shape[0]
     C = len(class_ranges)
     Q = adj_power(A, K)
@@ -161,9 +167,11 @@ def syn_match(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="o
     else:
         W1, b1, W2, b2 = theta
         Hp = Xs @ W1 + b1
-        M = (Hp > 0).to(Xs.dtype)
-        H1 = Hp * M
-        S = Q @ H1
+        M0 = (Hp > 0).to(Xs.dtype)
+        Ms = [M0 if mults is None else M0 * mults[c] for c in range(len(class_ranges))]      # relu' x class c's dropout multiplier
+        S = torch.zeros(n, Hp.shape[1], dtype=Xs.dtype)
+        for c, (lo, hi) in enumerate(class_ranges):      # S[lo:hi] = Q[lo:hi] H1_c  (one shared product when there is no dropout)
+            S[lo:hi] = Q[lo:hi] @ (Hp * Ms[c])
         Z = S @ W2 + rs[:, None] * b2
         P = torch.softmax(Z, 1)
         V = torch.zeros_like(P)
@@ -173,6 +181,7 @@ def syn_match(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="o
             nc = hi - lo
             if nc == 0:
                 continue
+            M = Ms[c]
             G = P[lo:hi].clone()
             G[:, c] -= 1
             G /= nc
@@ -193,9 +202,12 @@ def syn_match(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="o
             drs[lo:hi] = G @ Db2
         dS = dS + V @ W2.T
         drs = drs + V @ b2
-        dH1 = Q.T @ dS
-        dQ = dQ + dS @ H1.T + drs[:, None]
-        dX = dX + (dH1 * M) @ W1.T
+        dHm = torch.zeros_like(Hp)
+        for c, (lo, hi) in enumerate(class_ranges):      # class by class: the rows of dS belong to the class whose mask scaled H1
+            dHm = dHm + (Q[lo:hi].T @ dS[lo:hi]) * Ms[c]
+            dQ[lo:hi] += dS[lo:hi] @ (Hp * Ms[c]).T
+        dQ = dQ + drs[:, None]
+        dX = dX + dHm @ W1.T
     dA = adj_power_bwd(A, dQ, K)      # K = 2: dQ A^T + A^T dQ
     return loss, dX, dA
 

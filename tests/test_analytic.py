@@ -85,6 +85,41 @@ def test_syn_match_second_order(T, metric, K):
     np.testing.assert_allclose(dA.numpy(), ga.numpy(), rtol=1e-7, atol=1e-11)
 
 
+@pytest.mark.parametrize("metric,K", [("ours", 2), ("mse", 2), ("cos", 3)])
+def test_dropout_closed_forms(metric, K):
+    """Dropout in the condensation model (models/sgc.py:42): the closed forms with one multiplier per class forward — real batch and
+    synthetic graph — against autograd through the oracle with the same multipliers (oracle.gcond_oracle.DROPOUT)."""
+    p = tiny_problem(2, seed=5, sizes=(3, 2) if K == 2 else (3, 2, 2))
+    ns, h, pd = len(p["labels_syn"]), p["theta"][0].shape[1], 0.4
+    g = torch.Generator().manual_seed(11)
+    real = [(torch.rand(len(p["batches"][c][1]), h, generator=g, dtype=DT) > pd).to(DT) / (1 - pd) for c in range(p["nclass"])]
+    syn = [(torch.rand(ns, h, generator=g, dtype=DT) > pd).to(DT) / (1 - pd) for c in range(p["nclass"])]
+    O.DROPOUT = lambda where, x: {"real": real, "syn": syn}[where[0]][where[1]]
+    try:
+        theta = [t.clone().requires_grad_(True) for t in p["theta"]]
+        xs = p["xs"].clone().requires_grad_(True)
+        an = O.dense_gcn_norm(O.pge_forward(xs.detach(), p["pge"])).clone().requires_grad_(True)
+        loss = O.train_class("SGC", theta, p["batches"], p["x"], p["y"], xs, an, p["labels_syn"], p["ncd"], p["nclass"], K, metric)
+        gx, ga = torch.autograd.grad(loss, [xs, an])
+        ref_real = [O.class_real_grads("SGC", [t.clone().requires_grad_(True) for t in p["theta"]], p["x"], p["y"], p["batches"][c], K, c)[0]
+                    for c in range(p["nclass"])]
+    finally:
+        O.DROPOUT = None
+    gw_real = [A.real_class_grad(p["theta"], p["x"], dense_batch(p["batches"][c]), c, mult=real[c]) for c in range(p["nclass"])]
+    for ref, got in zip(ref_real, gw_real):
+        for r, q in zip(ref, got):
+            np.testing.assert_allclose(q.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
+    ranges = [tuple(p["ranges"][c]) for c in range(p["nclass"])]
+    coeffs = [p["ncd"][c] / ns for c in range(p["nclass"])]
+    l, dX, dA = A.syn_match(p["theta"], p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric, K=K, mults=syn)
+    np.testing.assert_allclose(float(l), float(loss), rtol=1e-10)
+    np.testing.assert_allclose(dX.numpy(), gx.numpy(), rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(dA.numpy(), ga.numpy(), rtol=1e-7, atol=1e-11)
+    # without the multipliers the closed form is the dropout-free one (a different loss)
+    l0, _, _ = A.syn_match(p["theta"], p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric, K=K)
+    assert abs(float(l0) - float(l)) > 1e-6 * abs(float(l))
+
+
 def test_gcn_norm_backward():
     torch.manual_seed(0)
     adj = torch.rand(9, 9, dtype=DT)
