@@ -53,7 +53,7 @@ class GCondIO(C.Structure):
 
 
 # measurement knobs / debug hooks declared in include/gslim_internal.h (not product ABI)
-INTERNAL_SYMBOLS = ["gs_panel_set_fwd_lds_pad", "gs_gemm_set_panel_tall", "gs_panel_set_hoist_share", "gs_panel_tall_debug", "gs_panel_tall_trace", "gs_gcond_set_edge_bits", "gs_gcond_set_edge_plan", "gs_gcond_set_ell_xcd", "gs_gcond_set_pad_zero", "gs_gcond_set_hoist_forward", "gs_gcond_set_knob",
+INTERNAL_SYMBOLS = ["gs_panel_set_fwd_lds_pad", "gs_gemm_set_panel_tall", "gs_panel_set_hoist_share", "gs_panel_tall_debug", "gs_panel_tall_trace", "gs_gcond_set_edge_bits", "gs_gcond_set_edge_plan", "gs_gcond_set_ell_xcd", "gs_gcond_set_pad_zero", "gs_gcond_set_hoist_forward_all", "gs_gcond_set_knob",
                     "gs_gcond_get_knob", "gs_gemm_set_tuning", "gs_gemm_set_small", "gs_gemm_set_panel", "gs_gemm_set_edge_kernel", "gs_gemm_set_panel_narrow_tail", "gs_gemm_set_panel_marg", "gs_gemm_set_panel_a1gen", "gs_panel_debug", "gs_gcond_set_folded_reductions", "gs_gcond_set_h1_bits", "gs_gcond_set_fused_chains", "gs_gcond_set_h1_rows", "gs_gcond_set_dw1_generated", "gs_gcond_set_aux_priority", "gs_sample_set_cand_cap"]
 
 # engine-level knob ids of include/gslim_internal.h (gs_gcond_set_knob / gs_gcond_get_knob); tests/test_abi.py pins them to the enum
@@ -72,14 +72,14 @@ SYMBOLS = [
     "gs_gcond_stage_pge_backward", "gs_gcond_stage_update", "gs_gcond_stage_inner", "gs_gcond_buffer", "gs_gcond_get_blocks", "gs_gcond_set_shard",
     "gs_gcond_set_overlap", "gs_gcond_set_operand_mode", "gs_gcond_set_full_neighbour", "gs_gcond_set_forward_reuse", "gs_gcond_set_dropout_iter",
     "gs_gcond_get_dropout_iter", "gs_gcond_probe",
-    "gs_gcond_probe_read", "gs_gcond_probe_read_spans", "gs_gcond_probe_read_pass", "gs_gcond_probe_read_spmm", "gs_gcond_invalidate_forward", "gs_gcond_forward_cached", "gs_gcond_forward_hoisted",
+    "gs_gcond_probe_read", "gs_gcond_probe_read_spans", "gs_gcond_probe_read_pass", "gs_gcond_probe_read_spmm", "gs_gcond_invalidate_forward", "gs_gcond_forward_cached", "gs_gcond_forward_hoisted", "gs_gcond_set_hoist_forward",
     "gs_gcond_adopt_cached_forward", "gs_gcond_stage_pge_forward_part", "gs_gcond_stage_pge_backward_part", "gs_gcond_stage_syn_finish",
     "gs_gcond_stage_inner_steps", "gs_bias_act_f32", "gs_log_softmax_f32", "gs_softmax_nll_grad_f32", "gs_colsum_f32", "gs_count_correct",
     "gs_edge_pair_sum_f32", "gs_bn_scratch_bytes", "gs_bn_relu_fwd_f32", "gs_bn_relu_bwd_f32", "gs_edge_score_f32", "gs_edge_scatter_sym_f32",
     "gs_edge_score_bwd_f32", "gs_segment_sum_rows_f32", "gs_colsum_tall_f32", "gs_mul_f32", "gs_mul_bwd_f32", "gs_mix_heads_f32",
     "gs_mix_heads_bwd_f32", "gs_sym_sigmoid_f32", "gs_sym_sigmoid_bwd_f32", "gs_bn_running_update_f32", "gs_bn_relu_eval_f32", "gs_ot_spectrum_f32",
     "gs_ot_value_f32", "gs_scale_cols_f32", "gs_ot_divdiff_f32", "gs_clamp_finite_f32", "gs_gcond_set_structure", "gs_gcond_set_block_structure",
-    "gs_comm_unique_id", "gs_comm_probe", "gs_comm_create_rccl", "gs_comm_create_callback", "gs_comm_create_null", "gs_comm_ipc_arena", "gs_comm_create_ipc", "gs_comm_ipc_error", "gs_comm_destroy", "gs_comm_rank", "gs_comm_world",
+    "gs_comm_unique_id", "gs_comm_probe", "gs_comm_create_rccl", "gs_comm_create_callback", "gs_comm_create_null", "gs_comm_ipc_arena", "gs_comm_create_ipc", "gs_comm_ipc_error", "gs_comm_check", "gs_comm_destroy", "gs_comm_rank", "gs_comm_world",
     "gs_comm_allreduce", "gs_comm_set_timing", "gs_comm_read_timing", "gs_comm_read_timing2", "gs_gcond_outer_step_sharded", "gs_gcond_outer_step_sharded_ex",
 ]
 
@@ -122,7 +122,7 @@ def lib():
     L.gs_gcond_set_edge_plan.argtypes = [i]
     L.gs_gcond_set_ell_xcd.argtypes = [i]
     L.gs_gcond_set_pad_zero.argtypes = [i]
-    L.gs_gcond_set_hoist_forward.argtypes = [i]
+    L.gs_gcond_set_hoist_forward_all.argtypes = [i]
     L.gs_gcond_set_knob.argtypes = [vp, i, i]
     L.gs_gcond_get_knob.argtypes = [vp, i]
     L.gs_reduce_slabs_f32.argtypes = [vp, vp, l, i, l, f, vp]
@@ -154,6 +154,7 @@ def lib():
     L.gs_gcond_set_full_neighbour.argtypes = [vp, vp, l, vp]
     L.gs_gcond_set_forward_reuse.argtypes = [vp, i]
     L.gs_gcond_forward_hoisted.argtypes = [vp]
+    L.gs_gcond_set_hoist_forward.argtypes = [vp, i]
     L.gs_gcond_set_dropout_iter.argtypes = [vp, C.c_uint64]
     L.gs_gcond_get_dropout_iter.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.gs_gcond_probe.argtypes = [vp, i]
@@ -203,6 +204,7 @@ def lib():
     L.gs_comm_ipc_arena.argtypes = [C.c_size_t, C.POINTER(vp), vp]
     L.gs_comm_create_ipc.argtypes = [vp, vp, C.c_size_t, i, i, vp, C.POINTER(vp)]
     L.gs_comm_ipc_error.argtypes = [vp, C.POINTER(i)]
+    L.gs_comm_check.argtypes = [vp]
     L.gs_comm_create_rccl.argtypes = [vp, i, i, C.POINTER(vp)]
     L.gs_comm_create_callback.argtypes = [ALLREDUCE_FN, vp, i, i, C.POINTER(vp)]
     L.gs_comm_create_null.argtypes = [i, i, C.POINTER(vp)]

@@ -102,6 +102,8 @@ struct gs_comm {
   unsigned long long seq;             // exchanges issued so far
   gs_comm* fallback;                  // exchanges beyond slot_bytes (not owned)
   bool own_arena;
+  unsigned* err_host;                 // host-pinned, device-mapped error word: a timed-out flag wait writes rank + 1 here (sticky) and the
+  unsigned* err_dev;                  // NEXT gs_comm_allreduce / gs_comm_ipc_error on the host sees it without a device synchronisation
 };
 
 // Is the RCCL binding usable in this process?  dlopen + the entry points + ncclGetVersion: allocates nothing and starts no bootstrap
@@ -176,6 +178,7 @@ struct gs_ipc_args {
   size_t slot_bytes;
   void* buf; long count;       // in place; count elements of 4 (fp32) or 8 (fp64) bytes
   int f64;
+  unsigned* err;               // host-visible sticky error word (gs_comm.err_dev)
 };
 
 template <typename T>
@@ -185,10 +188,16 @@ __device__ __forceinline__ void ipc_reduce(const gs_ipc_args& a, int par) {
   const long nv = a.count / VE;
   T* buf = (T*)a.buf;
   const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool aligned = (((uintptr_t)a.buf) & 15) == 0;      // (the slots are 16-byte aligned by construction; the caller's buffer need not be)
   for (long i = t0; i < nv; i += stride) {
     vec4 acc = *reinterpret_cast<const vec4*>(a.arena[0] + GS_IPC_HEADER + par * a.slot_bytes + i * 16);
     for (int r = 1; r < a.world; ++r) acc += *reinterpret_cast<const vec4*>(a.arena[r] + GS_IPC_HEADER + par * a.slot_bytes + i * 16);
-    *reinterpret_cast<vec4*>(buf + i * VE) = acc;
+    if (aligned) {
+      *reinterpret_cast<vec4*>(buf + i * VE) = acc;
+    } else {
+#pragma unroll
+      for (int q = 0; q < VE; ++q) buf[i * VE + q] = acc[q];
+    }
   }
   for (long i = nv * VE + t0; i < a.count; i += stride) {
     T acc = *reinterpret_cast<const T*>(a.arena[0] + GS_IPC_HEADER + par * a.slot_bytes + i * sizeof(T));
@@ -202,7 +211,9 @@ __global__ __launch_bounds__(256) void gs_ipc_allreduce_kernel(gs_ipc_args a) {
   char* mine = a.arena[a.rank];
   // 1. my contribution -> my slot (the slot of this parity was last read in exchange seq - 2: every peer has since published seq - 1)
   {
-    const long nb16 = (a.count * (a.f64 ? 8 : 4)) / 16, tail0 = nb16 * 16, nbytes = a.count * (a.f64 ? 8 : 4);
+    // (a buffer that is not 16-byte aligned goes through the 4-byte path as a whole: the transport is chosen from the COUNT alone, so that
+    // every rank provably takes the same branch whatever its pointer — ADVICE r05)
+    const long nbytes = a.count * (a.f64 ? 8 : 4), nb16 = (((uintptr_t)a.buf) & 15) ? 0 : nbytes / 16, tail0 = nb16 * 16;
     const long stride = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     for (long i = t0; i < nb16; i += stride)
@@ -218,7 +229,12 @@ __global__ __launch_bounds__(256) void gs_ipc_allreduce_kernel(gs_ipc_args a) {
     if (old + 1u == (unsigned)(a.seq * gridDim.x))
       __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  // 3. wait for every rank's flag (bounded: ~2 s; a rank that never arrives must not hang the device — the error word says so)
+  // 3. wait for every rank's flag (bounded: ~2 s; a rank that never arrives must not hang the device).  A timeout is FATAL for the
+  //    communicator: the error word — in the arena and in host-pinned memory — is sticky, this exchange leaves `buf`
+  //    untouched (no silently wrong sums), and the host refuses every later exchange (gs_comm_allreduce returns GS_ERR_STATE).
+  __shared__ int timed_out;
+  if (threadIdx.x == 0) timed_out = 0;
+  __syncthreads();
   if ((int)threadIdx.x < a.world) {
     const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(a.arena[threadIdx.x]);
     long spins = 0;
@@ -226,11 +242,14 @@ __global__ __launch_bounds__(256) void gs_ipc_allreduce_kernel(gs_ipc_args a) {
       __builtin_amdgcn_s_sleep(32);
       if (++spins > 4000000L) {
         __hip_atomic_store(reinterpret_cast<unsigned*>(mine + 128), 1u + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.err) __hip_atomic_store(a.err, 1u + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        timed_out = 1;
         break;
       }
     }
   }
   __syncthreads();
+  if (timed_out) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // system scope: nothing read below may come from a line cached before the flags
   // 4. the sum, ranks in ascending order on every rank: the replicas end with bitwise the same values
   if (a.f64) ipc_reduce<double>(a, par);
@@ -291,16 +310,49 @@ extern "C" int gs_comm_create_ipc(void* arena, const void* handles, size_t slot_
     }
     c->arena[r] = (char*)p;
   }
+  // the sticky error word the host polls without synchronising (absent => gs_comm_ipc_error falls back to a device read)
+  void* eh = nullptr;
+  if (hipHostMalloc(&eh, 64, hipHostMallocMapped) == hipSuccess) {
+    memset(eh, 0, 64);
+    void* ed = nullptr;
+    if (hipHostGetDevicePointer(&ed, eh, 0) == hipSuccess) { c->err_host = (unsigned*)eh; c->err_dev = (unsigned*)ed; }
+    else { (void)hipGetLastError(); (void)hipHostFree(eh); }
+  } else {
+    (void)hipGetLastError();
+  }
   *out = c;
   return GS_OK;
 }
 
-// 0 = every exchange so far found all its peers; r + 1 = a wait for rank r's flag timed out (the sums of that exchange are wrong)
+// 0 = every exchange so far found all its peers; r + 1 = a wait for rank r's flag timed out: that exchange left its buffer untouched and
+// the communicator is dead (every later gs_comm_allreduce returns GS_ERR_STATE).  sync != 0 waits for the device first (exact for
+// everything issued so far); 0 reads the host-visible word as it stands (what the product path polls once per epoch / read_loss).
+static int ipc_error_word(gs_comm* c, bool sync, unsigned* v) {
+  *v = 0;
+  if (sync || !c->err_host) {
+    GS_HIP(hipMemcpy(v, c->arena[c->rank] + 128, 4, hipMemcpyDeviceToHost));
+  } else {
+    *v = __atomic_load_n(c->err_host, __ATOMIC_ACQUIRE);
+  }
+  return GS_OK;
+}
 extern "C" int gs_comm_ipc_error(gs_comm* c, int* code) {
   if (!c || !code || c->kind != GS_COMM_IPC) GS_FAIL(GS_ERR_ARG, "gs_comm_ipc_error: not an ipc communicator");
   unsigned v = 0;
-  GS_HIP(hipMemcpy(&v, c->arena[c->rank] + 128, 4, hipMemcpyDeviceToHost));
+  GS_TRY(ipc_error_word(c, true, &v));
   *code = (int)v;
+  return GS_OK;
+}
+// the product path's check (graphslim_amd.parallel.ShardedGCond.read_loss, once per epoch): GS_OK, or GS_ERR_STATE with the peer named.
+// Communicators of other kinds have nothing to report.
+extern "C" int gs_comm_check(gs_comm* c) {
+  if (!c) GS_FAIL(GS_ERR_ARG, "gs_comm_check: null communicator");
+  if (c->kind != GS_COMM_IPC) return c->fallback ? gs_comm_check(c->fallback) : GS_OK;
+  unsigned v = 0;
+  GS_TRY(ipc_error_word(c, false, &v));
+  if (v) GS_FAIL(GS_ERR_STATE, "gs_comm (ipc): rank %d waited ~2 s for rank %u's flag and gave up: the exchange left its buffer untouched, "
+                               "the replicas have diverged — the communicator is dead (use the rccl transport if ranks can be seconds apart)",
+                 c->rank, v - 1u);
   return GS_OK;
 }
 
@@ -318,6 +370,7 @@ extern "C" void gs_comm_destroy(gs_comm* c) {
     for (int r = 0; r < c->world; ++r)
       if (r != c->rank && c->arena[r]) (void)hipIpcCloseMemHandle(c->arena[r]);
     if (c->own_arena && c->arena[c->rank]) (void)hipFree(c->arena[c->rank]);
+    if (c->err_host) (void)hipHostFree(c->err_host);
   }
   delete c;
 }
@@ -388,8 +441,10 @@ extern "C" int gs_comm_allreduce(gs_comm* c, void* buf, long count, int dtype, i
     if (rc != 0) GS_FAIL(GS_ERR_STATE, "gs_comm: the caller's all-reduce callback failed (%d)", rc);
   } else if (c->kind == GS_COMM_IPC) {
     const size_t nbytes = (size_t)count * (dtype ? 8 : 4);
-    if (nbytes > c->slot_bytes || (((uintptr_t)buf) & 15)) {
-      // (the count is the same on every rank, so every rank takes this branch together)
+    GS_TRY(gs_comm_check(c));      // a flag wait of an earlier exchange timed out: refuse (sticky)
+    if (nbytes > c->slot_bytes) {
+      // (decided from the count ALONE — the same on every rank — so every rank takes this branch together and `seq` stays in step; an
+      // unaligned buffer goes through the kernel's 4-byte path)
       if (!c->fallback) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_comm (ipc): an exchange of %zu bytes does not fit the %zu-byte slots and no fallback "
                                                     "communicator was given", nbytes, c->slot_bytes);
       c->calls[tag] -= 1; c->bytes[tag] -= (long)nbytes;      // (counted by this handle above; the fallback does not double-count for us)
@@ -399,7 +454,7 @@ extern "C" int gs_comm_allreduce(gs_comm* c, void* buf, long count, int dtype, i
     } else {
       gs_ipc_args a;
       for (int r = 0; r < GS_IPC_MAX_WORLD; ++r) a.arena[r] = r < c->world ? c->arena[r] : nullptr;
-      a.rank = c->rank; a.world = c->world; a.seq = ++c->seq; a.slot_bytes = c->slot_bytes; a.buf = buf; a.count = count; a.f64 = dtype;
+      a.rank = c->rank; a.world = c->world; a.seq = ++c->seq; a.slot_bytes = c->slot_bytes; a.buf = buf; a.count = count; a.f64 = dtype; a.err = c->err_dev;
       hipLaunchKernelGGL(gs_ipc_allreduce_kernel, dim3(GS_IPC_GRID), dim3(256), 0, s, a);
       GS_LAUNCH_CHECK();
     }

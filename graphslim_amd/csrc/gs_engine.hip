@@ -145,6 +145,7 @@ struct gs_gcond {
   // SGC steps (latency-bound launches on a few CUs) instead of at the top of the next call; the next call waits for ev_hoist
   hipStream_t low;
   hipEvent_t ev_inf, ev_hoist;
+  int hoist_fwd;                     // gs_gcond_set_hoist_forward: 0 (the library's default) = never, 1 = hoist, 2 = hoist + the 7/8 slab plan
   bool hoist_pending;                // a hoisted forward is (possibly) still in flight on `low`
   bool fwd_hoisted;                  // ... and is the training forward of the current (X~, theta_PGE)
   bool in_step;                      // inside gs_gcond_outer_step*: the stage entry points are being called by the step itself
@@ -589,7 +590,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   e->have_blocks = false;
   e->c_lo = 0; e->c_hi = e->C; e->r_lo = 0; e->r_hi = e->n;
   e->aux = nullptr; e->ev_fork = e->ev_join = e->ev_prefetch = nullptr; e->join_pending = false;
-  e->low = nullptr; e->ev_inf = e->ev_hoist = nullptr; e->hoist_pending = e->fwd_hoisted = e->in_step = e->hoisting = false;
+  e->low = nullptr; e->ev_inf = e->ev_hoist = nullptr; e->hoist_pending = e->fwd_hoisted = e->in_step = e->hoisting = false; e->hoist_fwd = 0;
   e->reuse_fwd = false; e->fwd_cached = false; e->real_beside = false;
   e->blk_cur = 0; e->prefetched = false; e->identity = false;
   e->probing = false; e->probe_n = 0; e->probe2_n = 0;
@@ -641,11 +642,24 @@ static int quiesce_hoist(gs_gcond* e) {
   e->fwd_hoisted = false;
   return GS_OK;
 }
-static int g_hoist_fwd = 1;         // measurement knob: 0 = the training forward at the top of the next call (the form of rounds 1-4)
-extern "C" int gs_gcond_set_hoist_forward(int on) {
-  g_hoist_fwd = on < 0 ? 0 : on;
+// Opt-in PER ENGINE (VERDICT r05 "next" 5): while a hoisted pass is in flight a kernel on the engine's third stream READS the caller-owned
+// io.feat_syn / io.pge_params after gs_gcond_outer_step has returned — a contract a C caller must ask for (the library's default is
+// off: between two default-configured steps nothing of the engine touches the caller's buffers); graphslim_amd.engine turns it on
+// for every engine it creates and brackets its own writes with gs_gcond_invalidate_forward.
+extern "C" int gs_gcond_set_hoist_forward(gs_gcond* e, int on) {
+  if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
+  if (on < 0 || on > 2) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_hoist_forward: on must be 0, 1 or 2 (2: with the edge product's 7/8 slab plan)");
+  GS_TRY(quiesce_hoist(e));
+  e->hoist_fwd = on;
   return GS_OK;
 }
+// process-wide measurement override (gslim_internal.h): -1 (default) = every engine follows its own setting, 0 / 1 / 2 = all engines
+static int g_hoist_fwd = -1;
+extern "C" int gs_gcond_set_hoist_forward_all(int on) {
+  g_hoist_fwd = on < -1 ? -1 : (on > 2 ? 2 : on);
+  return GS_OK;
+}
+static inline int hoist_mode(const gs_gcond* e) { return g_hoist_fwd >= 0 ? g_hoist_fwd : e->hoist_fwd; }
 
 extern "C" int gs_gcond_set_forward_reuse(gs_gcond* e, int on) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
@@ -2730,7 +2744,7 @@ static int outer_step_body(gs_gcond* e, int step_pge, int step_feat, int run_inf
     // the real-side branch forks behind the previous call's inner steps (it reads theta); the main stream takes up the forward's
     // results where the third stream left them.  (The edge product plans for the whole chip: by the time it runs the hoisted
     // forward has finished — it started an inner loop earlier.)
-    e->real_beside = g_hoist_fwd == 2;     // (2: the 7/8 slab plan of the un-hoisted step — measurement: 1 467 against 1 449-1 458 us)
+    e->real_beside = hoist_mode(e) == 2;     // (2: the 7/8 slab plan of the un-hoisted step — measurement: 1 467 against 1 449-1 458 us)
     const int rc_real = gs_gcond_stage_real_async(e, stream);
     e->real_beside = false;
     GS_TRY(rc_real);
@@ -2792,11 +2806,12 @@ static int outer_step_body(gs_gcond* e, int step_pge, int step_feat, int run_inf
   if (run_inner) {
     if (!e->identity && !run_inference) GS_FAIL(GS_ERR_ARG, "gs_gcond_outer_step_ex: inner steps need the inference pass");
     // Hoist: gcond.py:48 of the NEXT iteration, `adj_syn = pge(feat_syn)`, reads (X~, theta_PGE) only — both final now — while the
-    // inner steps (gcond.py:67-72) are ~20 dependent launches on a few compute units.  The same launches, the same inputs, the same
-    // buffers as at the top of the next call (bitwise the same values), issued on the lowest-priority stream so that the inner
+    // inner steps (gcond.py:67-72) are ~20 dependent launches on a few compute units.  The same function of the same inputs into the same
+    // buffers as at the top of the next call, on the persistent kernel with a capped grid (another fixed partition of the BatchNorm-2
+    // column sums: rounding-level differences from the un-hoisted pass, repeat runs bitwise equal), issued on the lowest-priority stream so that the inner
     // steps' small launches take compute units as they free up.  Not with forward reuse (nothing to recompute), not sharded (the
     // forward's exchanges stay in the next call), not without the second stream.
-    const bool hoist = g_hoist_fwd && !comm && !sharded_c(e) && !sharded_r(e) && !e->identity && run_inference && !e->reuse_fwd &&
+    const bool hoist = hoist_mode(e) && !comm && !sharded_c(e) && !sharded_r(e) && !e->identity && run_inference && !e->reuse_fwd &&
                        e->overlap && !e->overlap_sampling_only && e->low && e->cfg.inner_loop > 0;
     if (hoist) {
       hipStream_t s = (hipStream_t)stream;
@@ -2806,7 +2821,10 @@ static int outer_step_body(gs_gcond* e, int step_pge, int step_feat, int run_inf
       e->hoisting = true;
       const int rc_fwd = gs_gcond_stage_pge_forward(e, 0, (gs_stream_t)e->low);
       e->hoisting = false;
-      GS_TRY(rc_fwd);
+      if (rc_fwd != GS_OK) {      // launches already issued on `low` may still be writing U / V / E2 / adj_raw: drain them before the caller retries
+        (void)hipStreamSynchronize(e->low);
+        return rc_fwd;
+      }
       e->fwd_cached = cached;
       GS_HIP(hipEventRecord(e->ev_hoist, e->low));
       e->hoist_pending = true;

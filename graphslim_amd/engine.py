@@ -22,6 +22,8 @@ METRICS = {"ours": 0, "mse": 1, "cos": 2}
 # "f32" selects the fp32 matrix pipe (1/16 of the bf16 rate).  The C library's own default stays 0 = fp32.
 _OPERAND_MODE_NAMES = ("f32", "bf16x3", "bf16", "bf16x6")
 DEFAULT_OPERAND_MODE = os.environ.get("GS_OPERAND_MODE", "bf16x6")
+# the next iteration's training forward beside the inner steps (gs_gcond_set_hoist_forward; library default off, this mirror: on)
+DEFAULT_HOIST_FORWARD = int(os.environ.get("GS_HOIST_FWD", "1"))
 if DEFAULT_OPERAND_MODE not in _OPERAND_MODE_NAMES:      # (an unknown value used to reach ctypes as a str and fail there, opaquely)
     raise ValueError(f"GS_OPERAND_MODE={DEFAULT_OPERAND_MODE!r}: expected one of {', '.join(_OPERAND_MODE_NAMES)}")
 
@@ -394,6 +396,7 @@ class GCondEngine:
         self.h = h
         self.L = L
         self.set_operand_mode(DEFAULT_OPERAND_MODE)
+        self.set_hoist_forward(DEFAULT_HOIST_FORWARD)
 
     def _s(self):
         """torch's current stream — which must belong to this engine's device (an engine built for cuda:1 must
@@ -460,6 +463,11 @@ class GCondEngine:
 
     def forward_cached(self):
         return bool(self.L.gs_gcond_forward_cached(self.h))
+
+    def set_hoist_forward(self, on):
+        """gs_gcond_set_hoist_forward: the library's default is OFF (a C caller may write X~ / theta_PGE between steps); this host
+        mirror opts in for every engine (DEFAULT_HOIST_FORWARD) because set_feat / set_pge bracket their writes."""
+        check(self.L.gs_gcond_set_hoist_forward(self.h, int(on)))
 
     def forward_hoisted(self):
         """The last outer step issued the next iteration's training forward ahead and the next call will take it up."""

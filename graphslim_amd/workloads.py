@@ -22,6 +22,9 @@ WORKLOADS = {
     # job-level accuracy gate (tests/golden/make_job_accuracy.py): the ogbn-arxiv hyper-parameters at graph scale 0.05 with a rate
     # that keeps n' >= 128 (n' = 136): a whole job the CPU oracle finishes in minutes, through the headline shape's kernels
     "arxiv-gate": ("ogbn-arxiv", 0.03, 2, 256, 256, 10, 3, 0.01, 0.01, (10, 5)),
+    # the same hyper-parameters on the balanced 8-class variant of the shape (dataset/synthetic.py "arxiv-c8"): the seed-quiet whole job
+    # through the headline shape's kernels (n' = 136 >= 128, d = 128, h = P_h = 256, two transforms) — VERDICT r05 "next" 4a
+    "arxiv-gate-c8": ("arxiv-c8", 0.03, 2, 256, 256, 10, 3, 0.01, 0.01, (10, 5)),
     # `--nlayers 3` (dataset/loader.py:205-206: sizes [15, 10, 5]; models/sgc.py:45-51: three propagations on both sides) with the
     # ogbn-arxiv hyper-parameters: a parity-test case (tests/test_gpu_fullsize.py), not a bench line
     "arxiv-k3": ("ogbn-arxiv", 0.005, 2, 256, 256, 20, 3, 0.01, 0.01, (15, 10, 5)),
@@ -30,13 +33,13 @@ WORKLOADS = {
 }
 
 
-def build_problem(name, seed=1, scale=1.0):
+def build_problem(name, seed=1, scale=1.0, sep=1.0):
     from graphslim_amd.dataset.loader import TransAndInd, splits
     from graphslim_amd.dataset.synthetic import make_raw
     from graphslim_amd.host import generate_labels_syn, normalize_adj_sparse
     shape, rate, T, hidden, ph, outer, inner, lrf, lra, fan = WORKLOADS[name]
-    raw = splits(make_raw(shape, seed=seed, scale=scale))
-    data = TransAndInd(raw, shape)
+    raw = splits(make_raw(shape, seed=seed, scale=scale, sep=sep))
+    data = TransAndInd(raw, "ogbn-arxiv" if shape == "arxiv-c8" else shape)      # (the preprocessing of loader.py:110-121 goes by the dataset name)
     labels_train = data.labels_train.numpy()
     labels_syn, ncd, ranges = generate_labels_syn(labels_train, rate)
     setting = "ind" if shape in ("reddit", "flickr") else "trans"

@@ -369,14 +369,23 @@ int gs_gcond_new_epoch(gs_gcond* e, gs_stream_t stream);
 int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* blocks, gs_stream_t stream);
 /* PGE.inference at the end of iteration i (gcond.py:63-65) and `adj_syn = pge(self.feat_syn)` at the start of iteration i+1
  * (gcond.py:48) evaluate the same function on the same (X~, theta_PGE).  With forward reuse on, gs_gcond_outer_step adopts the
- * cached pass instead of recomputing it (bitwise the same values).  Off by default; call gs_gcond_invalidate_forward BEFORE and
- * after writing X~ or theta_PGE from the host (before: without forward reuse an outer step issues the next iteration's training
- * forward ahead, beside its inner steps, and that forward reads both — the call waits for it).  gs_gcond_forward_cached returns 1
- * when the next step would adopt. */
+ * cached pass instead of recomputing it (bitwise the same values).  Off by default; call gs_gcond_invalidate_forward after writing
+ * X~ or theta_PGE from the host (and BEFORE the write too when gs_gcond_set_hoist_forward is on, see there).  gs_gcond_forward_cached
+ * returns 1 when the next step would adopt. */
 int gs_gcond_set_forward_reuse(gs_gcond* e, int on);
-/* 1 when the last gs_gcond_outer_step* call issued the NEXT iteration's training forward ahead (beside its inner steps, on the engine's
- * third stream) and the next call will wait for it instead of computing it: unsharded engines without forward reuse, inner steps on.
- * Any other entry point that touches what that pass reads or writes waits for it and drops it. */
+/* Opt-in (library default 0 = off): with on = 1 a gs_gcond_outer_step* call that runs inner steps also issues the NEXT iteration's
+ * training forward `adj_syn = pge(feat_syn)` (gcond.py:48: a function of X~ and theta_PGE only, both final once this iteration's
+ * optimiser has stepped) on the engine's third, lowest-priority stream beside its inner SGC steps; the next call waits for it instead
+ * of computing it (unsharded engines without forward reuse).  THE CONTRACT THIS CHANGES: after such a call has returned a kernel of the
+ * engine may still be READING the caller-owned io.feat_syn / io.pge_params — a caller that opted in must call
+ * gs_gcond_invalidate_forward BEFORE it writes either buffer (the call waits for the pass and drops it).  With the default (off)
+ * nothing of the engine reads those buffers between two steps: a C caller may write them freely, as through round 4.  The Python host
+ * mirror (graphslim_amd.engine.GCondEngine) opts in for every engine it creates and brackets its own writes (set_feat / set_pge).
+ * Values: those of the un-hoisted step up to the BatchNorm-2 column sums' partition (rounding level; repeat runs bitwise equal).
+ * on = 2: additionally the edge product plans for 7/8 of the workgroup slots (measurement). */
+int gs_gcond_set_hoist_forward(gs_gcond* e, int on);
+/* 1 when the last gs_gcond_outer_step* call issued the NEXT iteration's training forward ahead and the next call will wait for it
+ * instead of computing it.  Any other entry point that touches what that pass reads or writes waits for it and drops it. */
 int gs_gcond_forward_hoisted(gs_gcond* e);
 /* cfg.dropout != 0: the iteration counter inside every dropout mask's key — 0 at creation, advanced by every gs_gcond_outer_step* call
  * (the staged calls read it and leave it alone).  Set it to resume a run at iteration i with the masks that run would have drawn, or
@@ -499,10 +508,16 @@ int gs_comm_create_null(int rank, int world, gs_comm** out);
    returns the 64-byte handle the other ranks open it with; the host side gathers the handles of all ranks in rank order
    ([world][64], e.g. torch.distributed.all_gather_object) and calls gs_comm_create_ipc (world <= 16), which takes ownership of the
    arena.  Exchanges larger than slot_bytes go to `fallback` (an RCCL / callback communicator, may be NULL: GS_ERR_UNSUPPORTED then).
-   gs_comm_ipc_error: 0, or r + 1 when a wait for rank r's flag timed out (~2 s: that exchange's sums are wrong, nothing hangs). */
+   The transport is chosen from the element COUNT alone (the same on every rank); a buffer that is not 16-byte aligned takes the
+   kernel's 4-byte path.  A wait for a peer's flag is bounded (~2 s) and a timeout is FATAL for the communicator: that exchange leaves
+   its buffer untouched, the error word is sticky, and every later gs_comm_allreduce on it returns GS_ERR_STATE (RCCL would simply
+   wait: use it when ranks can be seconds apart).  gs_comm_ipc_error: 0, or r + 1 for the peer r that did not arrive (waits for the
+   device); gs_comm_check: the same verdict as a return code, from a host-visible word without synchronising (any communicator kind;
+   what a driver polls once per epoch). */
 int gs_comm_ipc_arena(size_t slot_bytes, void** arena, void* handle64);
 int gs_comm_create_ipc(void* arena, const void* handles, size_t slot_bytes, int rank, int world, gs_comm* fallback, gs_comm** out);
 int gs_comm_ipc_error(gs_comm* c, int* code);
+int gs_comm_check(gs_comm* c);
 void gs_comm_destroy(gs_comm* c);
 int gs_comm_rank(const gs_comm* c);
 int gs_comm_world(const gs_comm* c);

@@ -106,11 +106,9 @@ int gs_gcond_set_ell_xcd(int on);
  * values: nothing reads those rows.  (The transposed gathers of the backward skip their padding rows unconditionally.) */
 int gs_gcond_set_pad_zero(int on);
 
-/* Measurement knob: 1 (default) = gs_gcond_outer_step* issues the NEXT iteration's training forward of the PGE (gcond.py:48: a function
- * of X~ and theta_PGE only, both final once the optimiser has stepped) on a third, lowest-priority stream beside its inner SGC steps;
- * the next call waits for it instead of computing it.  Same launches on the same inputs: bitwise the same values.  0 = the forward
- * at the top of the next call (the form of rounds 1-4).  Unsharded engines without forward reuse only. */
-int gs_gcond_set_hoist_forward(int on);
+/* Process-wide measurement override of gs_gcond_set_hoist_forward (gslim.h; per engine, library default off): -1 (default) = every
+ * engine follows its own setting, 0 / 1 / 2 = all engines of the process (2: hoisted with the edge product's 7/8 slab plan). */
+int gs_gcond_set_hoist_forward_all(int on);
 
 /* Priority of the second (real-side) stream of engines created AFTER the call: -1 = highest (default), 0 = normal, 1 = lowest. */
 int gs_gcond_set_aux_priority(int level);

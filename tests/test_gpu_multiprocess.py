@@ -117,7 +117,7 @@ def test_bench_full_neighbour_mode_one_and_two_ranks():
     two = _bench(2, {"GS_DIST_BACKEND": "gloo", "GS_SHARE_DEVICE": "1"}, extra_args=["--workload", "reddit", "--scale", "0.2",
                                                                                      "--full-neighbour"])
     assert two["n_gpus"] == 2 and two["full_neighbour"]["operators_ms"] > 0
-    a, b = one["config"]["mean_match_loss"], two["config"]["mean_match_loss"]
+    a, b = one["config"]["mean_class_loss_timed_steps"], two["config"]["mean_class_loss_timed_steps"]
     # (8 Adam steps at this config's lr = 0.1 between the first and the last loss: the re-associated exchanged sums of the two-rank
     # run — and the one-rank run's training forward on the persistent kernel, issued ahead — move the mean by a few 1e-4)
     assert abs(a - b) <= 1e-3 * abs(a), (a, b)

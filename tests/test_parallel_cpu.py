@@ -276,6 +276,68 @@ def test_verify_transport_falls_back_on_every_rank_when_one_rank_fails(scenario)
         assert t == 3.0
 
 
+def _ipc_fallback_worker(rank, world, port, q, scenario):
+    import torch.distributed as dist
+    from graphslim_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GS_COMM_TRANSPORT="ipc")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class FakeIpc:      # what Comm.ipc returns when every mapping worked (no GPU here): the REAL ipc_self_test runs on it
+        kind = "ipc"
+        ipc_self_test = parallel.Comm.ipc_self_test
+
+        def _first_exchange_ok(self, r, w):
+            if scenario == "first_exchange_times_out_on_rank1" and r == 1:
+                return False
+            if scenario == "first_exchange_raises_on_rank0" and r == 0:
+                raise RuntimeError("injected: flag wait failed")
+            return True
+
+    real_ipc = parallel.Comm.ipc.__func__
+
+    def ipc(cls, dist_, group=None, slot_bytes=0, fallback=None):
+        if scenario == "arena_fails_everywhere":      # the REAL Comm.ipc on a box without a GPU: gs_comm_ipc_arena fails on every rank
+            return real_ipc(cls, dist_, group, slot_bytes, fallback)
+        if scenario == "mapping_fails_on_rank1":      # the gather inside Comm.ipc makes the failure every rank's: all raise together
+            box = [None] * world
+            dist_.all_gather_object(box, "hipIpcOpenMemHandle failed" if rank == 1 else None, group=group)
+            if any(box):
+                raise RuntimeError(f"graphslim_amd: the ipc transport could not map every rank's arena: {box}")
+        return FakeIpc()
+
+    parallel.Comm.ipc = classmethod(ipc)
+    c = parallel.Comm.from_dist(dist, None, slot_bytes=1 << 16)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)      # the ranks are still in step
+    q.put((rank, c.kind, float(t)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["healthy", "arena_fails_everywhere", "mapping_fails_on_rank1", "first_exchange_times_out_on_rank1",
+                                      "first_exchange_raises_on_rank0"])
+def test_ipc_transport_falls_back_on_every_rank_when_one_rank_fails(scenario):
+    """VERDICT r05 "next" 7c: GS_COMM_TRANSPORT=ipc must end with the SAME transport on every rank — the ipc one only when every rank
+    mapped every arena and passed the first exchange, else the base transport (RCCL under nccl, the callback under gloo) everywhere."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ipc_fallback_worker, args=(r, 2, port, q, scenario)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = "ipc" if scenario == "healthy" else "callback"
+    for rank, kind, t in res:
+        assert kind == want, (scenario, rank, kind)
+        assert t == 3.0
+
+
 def test_null_transport_and_argument_checks():
     import ctypes as C
     from graphslim_amd import _lib

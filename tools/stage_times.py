@@ -22,7 +22,7 @@ for env, fn in (("GS_H1_BITS", "gs_gcond_set_h1_bits"), ("GS_EDGE_KERNEL", "gs_g
                 ("GS_FUSED_CHAINS", "gs_gcond_set_fused_chains"), ("GS_H1_ROWS", "gs_gcond_set_h1_rows"), ("GS_AUX_PRIORITY", "gs_gcond_set_aux_priority"),
                 ("GS_DW1_GEN", "gs_gcond_set_dw1_generated"), ("GS_EDGE_BITS", "gs_gcond_set_edge_bits"),
                 ("GS_EDGE_PLAN", "gs_gcond_set_edge_plan"), ("GS_ELL_XCD", "gs_gcond_set_ell_xcd"),
-                ("GS_HOIST_FWD", "gs_gcond_set_hoist_forward"), ("GS_PAD_ZERO", "gs_gcond_set_pad_zero"),
+                ("GS_HOIST_FWD", "gs_gcond_set_hoist_forward_all"), ("GS_PAD_ZERO", "gs_gcond_set_pad_zero"),
                 ("GS_HOIST_SHARE", "gs_panel_set_hoist_share")):   # A/B knobs of the library
     if os.environ.get(env):
         from graphslim_amd import _lib

@@ -12,7 +12,7 @@ import bench  # noqa: E402
 groups = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 if os.environ.get("GS_HOIST_FWD") is not None:
     from graphslim_amd import _lib
-    _lib.lib().gs_gcond_set_hoist_forward(int(os.environ["GS_HOIST_FWD"]))
+    _lib.lib().gs_gcond_set_hoist_forward_all(int(os.environ["GS_HOIST_FWD"]))
 if os.environ.get("GS_HOIST_SHARE") is not None:
     from graphslim_amd import _lib
     _lib.lib().gs_panel_set_hoist_share(int(os.environ["GS_HOIST_SHARE"]))

@@ -15,7 +15,7 @@ from graphslim_amd.parallel import Comm, ShardedGCond  # noqa: E402
 rank, world = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3, 8)
 layout = sys.argv[3] if len(sys.argv) > 3 else "rows"
 if os.environ.get("GS_HOIST_FWD") is not None:
-    _lib.lib().gs_gcond_set_hoist_forward(int(os.environ["GS_HOIST_FWD"]))
+    _lib.lib().gs_gcond_set_hoist_forward_all(int(os.environ["GS_HOIST_FWD"]))
 p = bench.build_problem("ogbn-arxiv", seed=1)
 eng = bench.make_engine(p, "cuda:0")
 bench.init_state(p, eng)
