@@ -39,6 +39,18 @@ int gs_chain_zg(const gs_zg_args*, hipStream_t);
 int gs_chain_group(const gs_gemm_desc*, int, const gs_adam_ep*, hipStream_t);
 int gs_panel_rows(const float*, long, const float*, long, const float*, int, float*, long, int, int, const int*, const int*, int, long, int,
                   void*, unsigned*, long, hipStream_t);
+// gs_inner.hip: the inner SGC steps as one persistent launch
+struct gs_inner_ws {
+  float *XT, *W1T, *WlT, *pb, *TT, *GT, *RT, *H1T, *dH1T, *rs, *Q, *QT;
+  unsigned* sync;
+  int npad, dpad, Cp;
+};
+extern "C" long gs_inner_persist_ws_floats(int n, int d, int h, int C);
+extern "C" int gs_inner_persist_eligible(int n, int d, int h, int C, int steps);
+extern "C" void gs_inner_persist_carve(float* ws, int n, int d, int h, int C, gs_inner_ws* o);
+int gs_inner_persist_launch(const gs_inner_ws& w, int n, int d, int h, int C, int steps, const float* X, long ldx, const int* labels,
+                            float* theta, float* m, float* v, float* g, long oW1, long ob1, long oWl, long obl, const float* step_size,
+                            const float* inv_sqrt_bc2, float b1, float b2, float eps, unsigned* counter_host, hipStream_t s);
 extern "C" int gs_comm_allreduce(gs_comm*, void*, long, int, int, gs_stream_t);
 extern "C" int gs_comm_world(const gs_comm*);
 
@@ -114,6 +126,8 @@ struct gs_gcond {
   double* parts;
   // inner loop
   float *adj_norm_in, *rnorm_in, *Qin, *rsq_in, *S_in, *g_model;
+  // the inner steps as one persistent launch (gs_inner.hip): workspace block, its carve, the host's copy of the arrival counter
+  float* ip_ws; gs_inner_ws ipw; unsigned ip_counter; long ip_ws_floats;
   // optimiser state
   float *m_feat, *v_feat, *m_pge, *v_pge, *m_model, *v_model;
   int step_feat, step_pge, step_model;
@@ -409,6 +423,12 @@ static size_t carve(gs_gcond* e, void* base) {
   e->statp = w.take<float>((long)gs_cdiv(n2, 32) * 2 * Ph);
   e->adj_norm_in = w.take<float>(n2); e->rnorm_in = w.take<float>(2 * n); e->Qin = w.take<float>(n2);
   e->rsq_in = w.take<float>(n); e->S_in = w.take<float>(n * F); e->g_model = w.take<float>(P);
+  e->ip_ws = nullptr; e->ip_ws_floats = 0; e->ip_counter = 0;
+  if (e->T == 2 && !e->gcn && !e->with_bn && gs_inner_persist_eligible((int)n, (int)d, (int)h, (int)C, 1)) {
+    e->ip_ws_floats = gs_inner_persist_ws_floats((int)n, (int)d, (int)h, (int)C);
+    e->ip_ws = w.take<float>(e->ip_ws_floats);
+    if (e->ip_ws) gs_inner_persist_carve(e->ip_ws, (int)n, (int)d, (int)h, (int)C, &e->ipw);
+  }
   e->m_feat = w.take<float>(n * d); e->v_feat = w.take<float>(n * d);
   e->m_pge = w.take<float>(e->Ppge); e->v_pge = w.take<float>(e->Ppge);
   e->m_model = w.take<float>(P); e->v_model = w.take<float>(P);
@@ -482,6 +502,7 @@ static int g_edge_bits = 0;         // the hop-2 gather also writes per-edge sig
 static int g_h1_bits = 0;
 static int g_h1_rows = 1;
 static int g_edge_plan = 1;         // real-side edge product on balanced slabs (gs_edge_plan); 0 = fixed-length slabs per class (the form of rounds 2-4)
+static int g_inner_persist = 1;     // the inner SGC steps (two transforms) as ONE persistent launch (gs_inner.hip); 0 = the launch chain of round 5
 static int g_chained_products = 1;  // the per-class products of the synthetic match chained through the MFMA accumulator registers, two
                                     // launches (gs_match.hip); 0 = the six batched products
 // measurement / test knob: 1 (default) = PGE epochs run the backward of layer 2 on generated operands (marginals as in feature epochs,
@@ -576,6 +597,8 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
     (void)hipMemsetAsync(e->loss_sum, 0, sizeof(double), s);
     (void)hipMemsetAsync(e->loss_last, 0, sizeof(float), s);
     (void)hipMemsetAsync(e->steps, 0, sizeof(long), s);
+    // (the arrival counter / error word, and the pad columns of Q | Q^T the products never write)
+    if (e->ip_ws) (void)hipMemsetAsync(e->ip_ws, 0, sizeof(float) * e->ip_ws_floats, s);
     if (e->marker)
       hipLaunchKernelGGL(gs_fill_int_kernel, dim3(gs_cdiv((long)C * e->N, 256)), dim3(256), 0, s, e->marker, (long)C * e->N,
                          0x7fffffff);
@@ -839,7 +862,7 @@ extern "C" int gs_gcond_set_knob(gs_gcond* e, int knob, int value) {
 }
 extern "C" int gs_gcond_get_knob(const gs_gcond* e, int knob) {
   if (!e || knob < 0 || knob >= GS_KNOB_COUNT) return -1;
-  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows != 0, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_chained_products, 0, g_edge_plan != 0};
+  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows != 0, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_chained_products, 0, g_edge_plan != 0, g_inner_persist};
   return knob_of(e, knob, def[knob]);
 }
 
@@ -2352,6 +2375,10 @@ extern "C" int gs_gcond_stage_update(gs_gcond* e, int epoch, gs_stream_t stream)
 // measurement / test knob: 1 (default) = the fused launch chains of gs_chain.hip (inner SGC steps: logits + softmax + NLL gradient in
 // one launch, products re-associated through the C-wide operand, Adam in the gradient products' epilogue; synthetic match: logits +
 // softmax in one launch); 0 = one launch per product / element-wise pass (the first form)
+extern "C" int gs_gcond_set_inner_persist(int on) {
+  g_inner_persist = on < 0 ? 0 : (on > 2 ? 2 : on);
+  return GS_OK;
+}
 extern "C" int gs_gcond_set_fused_chains(int on) {
   g_fused_chains = on != 0;
   return GS_OK;
@@ -2375,6 +2402,25 @@ static int inner_steps_fused(gs_gcond* e, gs_stream_t stream) {
   const float* th = e->io.model_params;
   const float* A = e->adj_norm_in;
   float* g = e->g_model;
+  // knob: 0 = the launch chain, 2 = always the persistent launch, 1 (default) = the persistent launch unless a hoisted training forward
+  // is in flight beside this stage (measured, profiles/r06: alone on the chip the one launch wins — 1 329 against 1 344 us per iteration
+  // with forward reuse — beside the forward's persistent grid its 48 resident workgroups lose to the chain's short launches: 1 458 / 1 416)
+  const int ipk = knob_of(e, GS_KNOB_INNER_PERSIST, g_inner_persist);
+  if (e->T == 2 && e->K == 2 && e->ip_ws && !e->drop_thr && (ipk == 2 || (ipk == 1 && !e->hoist_pending)) &&
+      gs_inner_persist_eligible(n, d, h, C, e->cfg.inner_loop)) {
+    // ONE persistent launch for all inner steps (gs_inner.hip): Q = A^ A^ and its transpose land in the launch's padded operands
+    gs_gemm_desc q2[2];
+    q2[0] = mk(A, n, 1, A, n, 1, e->ipw.Q, e->ipw.npad, n, n, n);
+    q2[1] = mk(A, 1, n, A, 1, n, e->ipw.QT, e->ipw.npad, n, n, n);       // Q^T = A^^T A^^T
+    GS_TRY(gs_gemm_group_f32(q2, 2, stream));
+    float ss[16], isb[16];
+    for (int it = 0; it < e->cfg.inner_loop; ++it) {
+      const gs_adam_ep ep = model_adam(e);
+      ss[it] = ep.step_size; isb[it] = ep.inv_sqrt_bc2;
+    }
+    return gs_inner_persist_launch(e->ipw, n, d, h, C, e->cfg.inner_loop, X, d, e->io.labels_syn, e->io.model_params, e->m_model, e->v_model, g,
+                                   e->oW1, e->ob1, e->oWl, e->obl, ss, isb, 0.9f, 0.999f, 1e-8f, &e->ip_counter, s);
+  }
   {
     if (e->K != 2) {
       GS_TRY(adj_powers(e, A, e->Qin, stream));      // (the training powers are not needed any more: the backward has run)
@@ -2961,7 +3007,17 @@ extern "C" int gs_gcond_read_loss(gs_gcond* e, double* loss_sum, long* steps, gs
   GS_HIP(hipMemcpyAsync(steps, e->steps, sizeof(long), hipMemcpyDeviceToHost, s));
   GS_HIP(hipMemsetAsync(e->loss_sum, 0, sizeof(double), s));
   GS_HIP(hipMemsetAsync(e->steps, 0, sizeof(long), s));
+  unsigned ip_err = 0;
+  if (e->ip_ws) GS_HIP(hipMemcpyAsync(&ip_err, e->ipw.sync + 16, sizeof(unsigned), hipMemcpyDeviceToHost, s));
   GS_HIP(hipStreamSynchronize(s));
+  if (ip_err) {      // a grid barrier of the persistent inner-step launch gave up (gs_inner.hip): theta of that iteration is garbage
+    (void)hipMemsetAsync(e->ipw.sync, 0, 256, s);
+    (void)hipStreamSynchronize(s);
+    e->ip_counter = 0;
+    GS_FAIL(GS_ERR_STATE, "gs_gcond: grid barrier %u of the persistent inner-step launch timed out (its workgroups were not co-resident "
+                          "for seconds): the model parameters of that iteration are invalid — run with the launch chain "
+                          "(gs_gcond_set_knob(e, GS_KNOB_INNER_PERSIST, 0)) when the device is shared", ip_err);
+  }
   return GS_OK;
 }
 
@@ -2974,7 +3030,7 @@ extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* 
       {"loss_c", e->loss_c, C},            {"d_feat", e->d_feat, n * e->d},     {"d_adj_norm", e->dAn, n * n},
       {"d_adj", e->d_adj, n * n},          {"d_pge", e->d_pge, e->Ppge},        {"adj_norm", e->adj_norm, n * n},
       {"adj_raw", e->adj_raw, n * n},      {"adj_norm_inner", e->adj_norm_in, n * n}, {"D", e->D, C * e->P},
-      {"g_model", e->g_model, e->P},       {"Sr", e->Sr, C * e->bcap * e->Fp},   {"rsr", e->rsr, C * e->bcap},
+      {"g_model", e->g_model, e->P},       {"m_model", e->m_model, e->P},       {"v_model", e->v_model, e->P},       {"Sr", e->Sr, C * e->bcap * e->Fp},   {"rsr", e->rsr, C * e->bcap},
       {"Q", e->Q, n * n},                  {"Ss", e->Ss, n * e->F},             {"Ps", e->Ps, n * C},
       {"dQ", e->dQ, n * n},                {"e3", e->e3, n * n},                {"H1full", e->H1full, e->H1full ? (long)e->N * e->h : 0},
       // all-reduce(sum) buffers of the sharded engine.  ar_bn2 / ar_l3 are fp64 (count in doubles), the rest fp32.

@@ -80,6 +80,14 @@ int gs_gcond_set_h1_bits(int on);
  * ones, Adam in the epilogue of the gradient products; the synthetic match's logits + softmax in one launch); 0 = one launch per
  * product (first form).  Same values up to fp32 re-association. */
 int gs_gcond_set_fused_chains(int on);
+/* Measurement knob: the inner SGC steps of a two-transform SGC model (gcond.py:63-72) as ONE persistent launch of ~48 workgroups with
+ * grid barriers between the four phases of a step (csrc/gs_inner.hip): 1 (default) = whenever no hoisted training forward runs beside
+ * the stage (forward reuse — what GCond.reduce runs —, staged drivers, sharded ranks), 2 = always, 0 = never (the launch chain of
+ * round 5: seven dependent launches per step).  Same values up to fp32 summation order.  Per engine: GS_KNOB_INNER_PERSIST.
+ * gs_inner_persist_set_grid: workgroups of that launch (default 48 = what the hoisted forward's 13/16 grid leaves free). */
+int gs_gcond_set_inner_persist(int on);
+int gs_inner_persist_set_grid(int workgroups);
+int gs_inner_persist_trace(void* device_u64_G_by_128);      /* measurement: s_memrealtime stamps around every grid barrier (NULL = off) */
 
 /* Measurement knob: 1 (default) = a sharded rank computes only the rows of H1 = relu(X W1 + b1) (models/sgc.py:38-43) that the
  * sampled blocks of ITS classes gather (marked and compacted on the device); 0 = every rank computes all N rows.  Same values. */
@@ -120,7 +128,7 @@ int gs_sample_set_cand_cap(int cap);
 /* Engine-level knobs per ENGINE (the int-only setters above change the process-wide default an engine follows while its own value is
    -1): knob ids below, value 0 / 1, -1 = follow the default again.  gs_gcond_get_knob returns the value in effect (-1: bad arguments). */
 enum { GS_KNOB_FUSED_CHAINS = 0, GS_KNOB_H1_ROWS = 1, GS_KNOB_H1_BITS = 2, GS_KNOB_EDGE_BITS = 3, GS_KNOB_DW1_GENERATED = 4,
-       GS_KNOB_FOLDED_REDUCTIONS = 5, GS_KNOB_CHAINED_PRODUCTS = 6, GS_KNOB_FORK_LATE = 7, GS_KNOB_EDGE_PLAN = 8, GS_KNOB_COUNT = 9 };
+       GS_KNOB_FOLDED_REDUCTIONS = 5, GS_KNOB_CHAINED_PRODUCTS = 6, GS_KNOB_FORK_LATE = 7, GS_KNOB_EDGE_PLAN = 8, GS_KNOB_INNER_PERSIST = 9, GS_KNOB_COUNT = 10 };
 int gs_gcond_set_knob(gs_gcond* e, int knob, int value);
 int gs_gcond_get_knob(const gs_gcond* e, int knob);
 
