@@ -46,6 +46,7 @@ struct gs_edge_args {
   const float* Y; long sYc; int f2;              // Y1 rows: Y[class * sYc + (k / f2) * 256 + n]
   const int* kcount; int kchunk;
   float* out; long sOc, sOs;                     // slabs: out[class * sOc + slab * sOs + m * 256 + n]
+  const int2* erow; const float2* ew;            // ENT: per K entry two (row of Y, weight) pairs; `col` holds the entry's source (f2 / w unused)
   const int* plan; int nclass;                   // balanced slabs (gs_edge_plan_kernel): [nclass + 1] first slab of a class, then [nclass] its
                                                  // slab length; slab b of the launch writes out[b * sOs + ...] (null: nsplit slabs of kchunk per class)
 };
@@ -216,7 +217,10 @@ __device__ __forceinline__ void eg_mfma_step(const float* __restrict__ stage, f3
   }
 }
 
-template <int MODE, bool BITS = false>
+// ENT (round 6): the K dimension runs over ENTRIES = (distinct source, up to two of its in-edges) instead of edge slots: the x row and the
+// mask row of a source are read once per entry, the B row is [H1[src] > 0] * (w0 Y[row0] + w1 Y[row1]) — the source's in-edges summed
+// in ascending slot order (fmaf(w1, y1, w0 y0)); a source with more than two in-edges takes several entries (the product is linear).
+template <int MODE, bool BITS = false, bool ENT = false>
 __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
   constexpr int STAGE_F = MODE == 4 ? EG4_STAGE / 4 : EG_STAGE;      // floats per stage
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_F];
@@ -246,11 +250,12 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
 
   if (k_lo < k_hi) {      // (block-uniform; an empty slab still writes zeros below: the reduction reads every slab)
     const int* __restrict__ col = p.col + (long)c * p.sK;
-    const float* __restrict__ wv = p.w + (long)c * p.sK;
+    const float* __restrict__ wv = ENT ? nullptr : p.w + (long)c * p.sK;
     const float* __restrict__ Y = p.Y + (long)c * p.sYc;
     const int row = tid >> 4, quad = tid & 15;
     const bool m_ok0 = m0 + 4 * quad < p.d, m_ok1 = m0 + 64 + 4 * quad < p.d;      // d % 4 == 0 (checked by the launcher)
-    f32x4 ra[2], rm[BITS ? 1 : 4], ry[4];
+    f32x4 ra[2], rm[BITS ? 1 : 4], ry[4], ry2[ENT ? 4 : 1];
+    float rw2 = 0.f;
     unsigned mw[BITS ? 4 : 1];                       // BITS: word 2 i + (quad >> 3) of the source row holds columns 4 quad + 64 i .. + 3
     const int bo = (4 * quad) & 31;
     float rw;
@@ -258,11 +263,21 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
       const int k = k0 + row;
       const int kk = min(k, k_hi - 1);
       const int src = col[kk];
-      rw = k < k_hi ? wv[kk] : 0.f;
+      int yrow = 0, yrow2 = 0;
+      if constexpr (ENT) {
+        const int2 rr = p.erow[(long)c * p.sK + kk];
+        const float2 ww = p.ew[(long)c * p.sK + kk];
+        yrow = rr.x; yrow2 = rr.y;
+        rw = k < k_hi ? ww.x : 0.f;
+        rw2 = k < k_hi ? ww.y : 0.f;
+      } else {
+        rw = k < k_hi ? wv[kk] : 0.f;
+        yrow = kk / p.f2;
+      }
       const float* xr = p.X + (long)src * p.ldx + m0 + 4 * quad;
       ra[0] = m_ok0 ? *reinterpret_cast<const f32x4*>(xr) : f32x4{0.f, 0.f, 0.f, 0.f};
       ra[1] = m_ok1 ? *reinterpret_cast<const f32x4*>(xr + 64) : f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* yr = Y + (long)(kk / p.f2) * 256 + 4 * quad;
+      const float* yr = Y + (long)yrow * 256 + 4 * quad;
       if constexpr (BITS) {
         const unsigned* br = p.bits + (p.bits_edge ? (long)c * p.sK + kk : (long)src) * p.ldbits + (quad >> 3);
 #pragma unroll
@@ -274,6 +289,15 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) ry[i] = *reinterpret_cast<const f32x4*>(yr + 64 * i);
+      if constexpr (ENT) {
+        const float* yr2 = Y + (long)yrow2 * 256 + 4 * quad;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ry2[i] = *reinterpret_cast<const f32x4*>(yr2 + 64 * i);
+      }
+    };
+    auto bval = [&](int i, int e) -> float {
+      if constexpr (ENT) return fmaf(rw2, ry2[i][e], rw * ry[i][e]);
+      else return rw * ry[i][e];
     };
     auto on = [&](int i, int e) -> bool {
       if constexpr (BITS) return (mw[i] >> (bo + e)) & 1u;
@@ -290,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
           bf16x4 bh, bm, bl;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float x = on(i, e) ? rw * ry[i][e] : 0.f;
+            const float x = on(i, e) ? bval(i, e) : 0.f;
             const __bf16 hb = (__bf16)x;
             const float r1 = x - (float)hb;
             const __bf16 mb = (__bf16)r1;
@@ -306,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void gs_edge_gemm_kernel(gs_edge_args p) {
         for (int i = 0; i < 4; ++i) {
           f32x4 b;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) b[e] = on(i, e) ? rw * ry[i][e] : 0.f;
+          for (int e = 0; e < 4; ++e) b[e] = on(i, e) ? bval(i, e) : 0.f;
           *reinterpret_cast<f32x4*>(bs + 64 * i) = b;
         }
       }
@@ -374,12 +398,17 @@ int gs_reduce_slabs_plan(float* out, long out_stride, const float* slabs, long n
   return GS_OK;
 }
 
-static int edge_launch(const gs_gemm_desc& d, const int* plan, int max_slabs, hipStream_t s);
+static int edge_launch(const gs_gemm_desc& d, const int* plan, int max_slabs, hipStream_t s, const void* erow = nullptr, const void* ew = nullptr);
+// ENT form: d.bgen_idx = the entries' sources [class][sGb1], erow / ew = their (row, weight) pairs; planned slabs only
+int gs_edge_launch_entries(const gs_gemm_desc& d, const void* erow, const void* ew, const int* plan, int max_slabs, hipStream_t s) {
+  return edge_launch(d, plan, max_slabs, s, erow, ew);
+}
 int gs_edge_launch(const gs_gemm_desc& d, hipStream_t s) { return edge_launch(d, nullptr, 0, s); }
 int gs_edge_launch_plan(const gs_gemm_desc& d, const int* plan, int max_slabs, hipStream_t s) { return edge_launch(d, plan, max_slabs, s); }
 
-static int edge_launch(const gs_gemm_desc& d, const int* plan, int max_slabs, hipStream_t s) {
+static int edge_launch(const gs_gemm_desc& d, const int* plan, int max_slabs, hipStream_t s, const void* erow, const void* ew) {
   gs_edge_args a;
+  a.erow = (const int2*)erow; a.ew = (const float2*)ew;
   a.X = d.A; a.ldx = d.sAk; a.d = d.M;
   a.col = d.bgen_idx; a.w = d.bgen_w; a.sK = d.sGb1;
   a.H1 = d.bgen_mask; a.ldm = d.bgen_ldm;
@@ -390,10 +419,12 @@ static int edge_launch(const gs_gemm_desc& d, const int* plan, int max_slabs, hi
   a.plan = plan; a.nclass = d.nb1;
   const dim3 grid(plan ? max_slabs : d.nb2, plan ? 1 : d.nb1, gs_cdiv(d.M, 128)), block(256);
   const bool bits = d.bgen_bits != nullptr && d.bgen_ldbits >= 8;
-#define GS_EDGE_LAUNCH(MODE_)                                                                    \
-  do {                                                                                           \
-    if (bits) hipLaunchKernelGGL((gs_edge_gemm_kernel<MODE_, true>), grid, block, 0, s, a);      \
-    else hipLaunchKernelGGL((gs_edge_gemm_kernel<MODE_, false>), grid, block, 0, s, a);          \
+#define GS_EDGE_LAUNCH(MODE_)                                                                               \
+  do {                                                                                                      \
+    if (erow && bits) hipLaunchKernelGGL((gs_edge_gemm_kernel<MODE_, true, true>), grid, block, 0, s, a);   \
+    else if (erow) hipLaunchKernelGGL((gs_edge_gemm_kernel<MODE_, false, true>), grid, block, 0, s, a);     \
+    else if (bits) hipLaunchKernelGGL((gs_edge_gemm_kernel<MODE_, true>), grid, block, 0, s, a);            \
+    else hipLaunchKernelGGL((gs_edge_gemm_kernel<MODE_, false>), grid, block, 0, s, a);                     \
   } while (0)
   if (d.prec == 0) GS_EDGE_LAUNCH(0);
   else if (d.prec == 1) GS_EDGE_LAUNCH(1);

@@ -39,6 +39,9 @@ int gs_chain_zg(const gs_zg_args*, hipStream_t);
 int gs_chain_group(const gs_gemm_desc*, int, const gs_adam_ep*, hipStream_t);
 int gs_panel_rows(const float*, long, const float*, long, const float*, int, float*, long, int, int, const int*, const int*, int, long, int,
                   void*, unsigned*, long, hipStream_t);
+int gs_dedup_last(const int*, const float*, const int*, int, int, int, int*, int, int*, int*, int*, int*, int*, int, int*, int*, void*, void*,
+                  hipStream_t);   // gs_sampler.hip
+int gs_edge_launch_entries(const gs_gemm_desc& d, const void* erow, const void* ew, const int* plan, int max_slabs, hipStream_t s);   // gs_edge.hip
 // gs_inner.hip: the inner SGC steps as one persistent launch
 struct gs_inner_ws {
   float *XT, *W1T, *WlT, *pb, *TT, *GT, *RT, *H1T, *dH1T, *rs, *Q, *QT;
@@ -126,6 +129,12 @@ struct gs_gcond {
   double* parts;
   // inner loop
   float *adj_norm_in, *rnorm_in, *Qin, *rsq_in, *S_in, *g_model;
+  // distinct sources of the outermost block (gs_dedup_last_kernel), one set per block buffer: the edge product's K dimension (round 6)
+  // (n0 / src0 / sptr0 / sedge0: distinct sources + CSC; nent / ent_src / ent_row / ent_w: the edge product's K entries — a source and up
+  // to two of its in-edges as (row of Y, weight))
+  struct { int *n0, *src0, *sptr0, *sedge0, *cur0, *nent, *ent_src; int2* ent_row; float2* ent_w; } dd[2];
+  int cap0;                            // capacity per class = capL * f2 (0: the form is not available for this configuration)
+  bool dd_valid[2];                    // dd[q] describes the blocks of buffer q (built behind a sampling / upload while the knob is on, else on demand)
   // the inner steps as one persistent launch (gs_inner.hip): workspace block, its carve, the host's copy of the arrival counter
   float* ip_ws; gs_inner_ws ipw; unsigned ip_counter; long ip_ws_floats;
   // optimiser state
@@ -326,7 +335,9 @@ static size_t carve(gs_gcond* e, void* base) {
     b.col0 = w.take<int>(C * capL * f2); b.val0 = w.take<float>(C * capL * f2);
   }
   e->blk = e->blkbuf[0];
-  e->marker = e->cfg.external_blocks ? nullptr : w.take<int>(C * N);
+  // distinct-source form of the edge product: SGC, two transforms, two hops, 256 hidden units (the dedicated edge kernel's shape)
+  e->cap0 = (e->T == 2 && !e->gcn && e->nmid == 0 && h == 256 && !e->drop_thr && e->cfg.dis_metric == 0) ? (int)(capL * f2) : 0;
+  e->marker = (e->cfg.external_blocks && !e->cap0) ? nullptr : w.take<int>(C * N);
   e->kcount = w.take<int>(C);
   {
     // chunk counts of colsum_batched: <= 64 chunks of >= 8 rows, or rows/256 chunks
@@ -423,6 +434,15 @@ static size_t carve(gs_gcond* e, void* base) {
   e->statp = w.take<float>((long)gs_cdiv(n2, 32) * 2 * Ph);
   e->adj_norm_in = w.take<float>(n2); e->rnorm_in = w.take<float>(2 * n); e->Qin = w.take<float>(n2);
   e->rsq_in = w.take<float>(n); e->S_in = w.take<float>(n * F); e->g_model = w.take<float>(P);
+  for (int q = 0; q < 2; ++q) {
+    const long c0p = e->cap0;
+    e->dd[q].n0 = c0p ? w.take<int>(C) : nullptr; e->dd[q].src0 = c0p ? w.take<int>(C * c0p) : nullptr;
+    e->dd[q].sptr0 = c0p ? w.take<int>(C * (c0p + 1)) : nullptr; e->dd[q].sedge0 = c0p ? w.take<int>(C * c0p) : nullptr;
+    e->dd[q].cur0 = c0p ? w.take<int>(C * (c0p + 1)) : nullptr;
+    e->dd[q].nent = c0p ? w.take<int>(C) : nullptr; e->dd[q].ent_src = c0p ? w.take<int>(C * c0p) : nullptr;
+    e->dd[q].ent_row = c0p ? w.take<int2>(C * c0p) : nullptr; e->dd[q].ent_w = c0p ? w.take<float2>(C * c0p) : nullptr;
+  }
+  e->dd_valid[0] = e->dd_valid[1] = false;
   e->ip_ws = nullptr; e->ip_ws_floats = 0; e->ip_counter = 0;
   if (e->T == 2 && !e->gcn && !e->with_bn && gs_inner_persist_eligible((int)n, (int)d, (int)h, (int)C, 1)) {
     e->ip_ws_floats = gs_inner_persist_ws_floats((int)n, (int)d, (int)h, (int)C);
@@ -502,6 +522,7 @@ static int g_edge_bits = 0;         // the hop-2 gather also writes per-edge sig
 static int g_h1_bits = 0;
 static int g_h1_rows = 1;
 static int g_edge_plan = 1;         // real-side edge product on balanced slabs (gs_edge_plan); 0 = fixed-length slabs per class (the form of rounds 2-4)
+static int g_edge_src = 0;          // real-side edge product over the DISTINCT sources of the outermost block (round 6: measured, not the default); 0 = over the edge slots
 static int g_inner_persist = 1;     // the inner SGC steps (two transforms) as ONE persistent launch (gs_inner.hip); 0 = the launch chain of round 5
 static int g_chained_products = 1;  // the per-class products of the synthetic match chained through the MFMA accumulator registers, two
                                     // launches (gs_match.hip); 0 = the six batched products
@@ -774,6 +795,7 @@ extern "C" int gs_gcond_get_blocks(gs_gcond* e, gs_blocks* out) {
   return GS_OK;
 }
 
+static int dedup_into(gs_gcond* e, int which, gs_stream_t stream);
 extern "C" int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* b, gs_stream_t stream) {
   if (!e || !b) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_blocks: null argument");
   e->prefetched = false;
@@ -797,7 +819,7 @@ extern "C" int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* b, gs_stream_t 
   CP(col0, C * capp * f2, int); CP(val0, C * capp * f2, float);
 #undef CP
   e->have_blocks = true;
-  return GS_OK;
+  return dedup_into(e, e->blk_cur, stream);
 }
 
 // sums[q][k] = sum over nblk partial blocks (fp64, fixed order): two stages so that the first one fills the chip
@@ -862,7 +884,7 @@ extern "C" int gs_gcond_set_knob(gs_gcond* e, int knob, int value) {
 }
 extern "C" int gs_gcond_get_knob(const gs_gcond* e, int knob) {
   if (!e || knob < 0 || knob >= GS_KNOB_COUNT) return -1;
-  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows != 0, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_chained_products, 0, g_edge_plan != 0, g_inner_persist};
+  const int def[GS_KNOB_COUNT] = {g_fused_chains, g_h1_rows != 0, g_h1_bits, g_edge_bits, g_dw1_generated, g_defer_last_stage, g_chained_products, 0, g_edge_plan != 0, g_inner_persist, g_edge_src};
   return knob_of(e, knob, def[knob]);
 }
 
@@ -895,6 +917,22 @@ int gs_sample_blocks_ex(const int*, const int*, const float*, int, const int*, c
 // ================================================================================================
 // stage: sampling
 // ================================================================================================
+// the distinct sources of the outermost block of block buffer `which` (this rank's classes): behind every sampling / upload of a set
+static int dedup_into(gs_gcond* e, int which, gs_stream_t stream) {
+  e->dd_valid[which] = false;
+  if (!e->cap0 || e->c_hi <= e->c_lo || e->S_full || !knob_of(e, GS_KNOB_EDGE_SRC, g_edge_src)) return GS_OK;
+  e->dd_valid[which] = true;
+  const gs_blocks keep = e->blk;
+  e->blk = e->blkbuf[which];
+  const gs_blocks b = blocks_view(e);
+  e->blk = keep;
+  const long c0 = e->c_lo, cap0 = e->cap0;
+  return gs_dedup_last(b.col0, b.val0, b.n1, e->capL, e->f2, e->N, e->marker + c0 * e->N, e->c_hi - e->c_lo, e->dd[which].n0 + c0,
+                       e->dd[which].src0 + c0 * cap0, e->dd[which].sptr0 + c0 * (cap0 + 1), e->dd[which].sedge0 + c0 * cap0,
+                       e->dd[which].cur0 + c0 * (cap0 + 1), e->cap0, e->dd[which].nent + c0, e->dd[which].ent_src + c0 * cap0,
+                       e->dd[which].ent_row + c0 * cap0, e->dd[which].ent_w + c0 * cap0, (hipStream_t)stream);
+}
+
 static int sample_into(gs_gcond* e, int which, gs_stream_t stream) {
   if (e->c_hi > e->c_lo) {
     const gs_blocks keep = e->blk;
@@ -904,6 +942,7 @@ static int sample_into(gs_gcond* e, int which, gs_stream_t stream) {
     GS_TRY(gs_sample_blocks_ex(e->io.rowptr, e->io.col, e->io.val, e->N, e->io.cls_ptr + e->c_lo, e->io.cls_nodes,
                                e->marker + (long)e->c_lo * e->N, &b, e->cfg.seed, e->sample_step, e->c_lo, stream,
                                e->S_full != nullptr));
+    GS_TRY(dedup_into(e, which, stream));
   }
   e->sample_step++;
   return GS_OK;
@@ -1269,6 +1308,30 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       if (use_bits) { gwd.bgen_bits = e->H1bits; gwd.bgen_ldbits = h / 32; }
       else if (have_ebits) { gwd.bgen_bits = e->edge_bits + c0 * cap1 * f2 * 8; gwd.bgen_ldbits = h / 32; gwd.bgen_bits_edge = 1; }
       gwd.prec = e->operand_mode;      // honoured by the dedicated edge kernel (gs_edge.hip); the tiled fallback is fp32
+    }
+    // Distinct-source form (knob EDGE_SRC, default on): the K dimension runs over ENTRIES = (distinct source, up to two of its in-edges)
+    // built behind every sampling (gs_dedup_last_kernel): x and the mask row of a source are fetched once per entry and its in-edges
+    // are summed in the operand path — the same sum in another association, K ~ 0.7 of the edge slots at ogbn-arxiv (8 700 live slots,
+    // 5 400 distinct sources, ~6 100 entries per class).  (The first form materialised the per-source sums: the edge kernel 168 -> 126 us
+    // but +140 us for that gather: profiles/r06/edge_src_materialised_not_kept.txt.)
+    if (plan && e->cap0 && knob_of(e, GS_KNOB_EDGE_SRC, g_edge_src) && !have_ebits && nmid == 0 && gs_edge_eligible(gwd)) {
+      const long cap0 = e->cap0;
+      if (!e->dd_valid[e->blk_cur]) {      // (the knob was switched on after these blocks were sampled: build the entries now — the
+        // marker rows are shared with a sampling possibly in flight on the second stream: behind it)
+        if (e->prefetched && e->ev_prefetch && s != e->aux) GS_HIP(hipStreamWaitEvent(s, e->ev_prefetch, 0));
+        GS_TRY(dedup_into(e, e->blk_cur, stream));
+      }
+      const auto& dd = e->dd[e->blk_cur];
+      int target = g_edge_plan > 1 ? g_edge_plan / gs_cdiv(d, 128) : (e->real_beside ? e->edge_target - e->edge_target / 8 : e->edge_target);
+      if (target > e->edge_cap - Cl) target = e->edge_cap - Cl;
+      GS_TRY(gs_edge_plan(dd.nent + c0, 1, Cl, target < 1 ? 1 : target, kcount, e->edge_plan, s));      // (re-plans over the entries: kcount[c] = nent[c])
+      gs_gemm_desc gs2 = gwd;
+      gs2.K = (int)cap0;
+      gs2.gatherA_k = dd.ent_src + c0 * cap0; gs2.sGb1 = cap0;
+      gs2.bgen_idx = gs2.gatherA_k; gs2.bgen_div = 1;
+      GS_TRY(gs_edge_launch_entries(gs2, dd.ent_row + c0 * cap0, dd.ent_w + c0 * cap0, e->edge_plan, e->edge_cap, s));
+      GS_TRY(gs_reduce_slabs_plan(gw + e->oW1, P, e->slabs_r, (long)d * h, (long)d * h, Cl, e->edge_plan, s));
+      return GS_OK;
     }
     if (plan && gs_edge_eligible(gwd)) {
       GS_TRY(gs_edge_launch_plan(gwd, e->edge_plan, e->edge_cap, s));
@@ -2375,6 +2438,10 @@ extern "C" int gs_gcond_stage_update(gs_gcond* e, int epoch, gs_stream_t stream)
 // measurement / test knob: 1 (default) = the fused launch chains of gs_chain.hip (inner SGC steps: logits + softmax + NLL gradient in
 // one launch, products re-associated through the C-wide operand, Adam in the gradient products' epilogue; synthetic match: logits +
 // softmax in one launch); 0 = one launch per product / element-wise pass (the first form)
+extern "C" int gs_gcond_set_edge_src(int on) {
+  g_edge_src = on != 0;
+  return GS_OK;
+}
 extern "C" int gs_gcond_set_inner_persist(int on) {
   g_inner_persist = on < 0 ? 0 : (on > 2 ? 2 : on);
   return GS_OK;
@@ -3041,6 +3108,12 @@ extern "C" int gs_gcond_buffer(gs_gcond* e, const char* name, void** ptr, long* 
       {"E2", e->E2, (long)(e->r_hi - e->r_lo) * n * Ph}, {"mu2", e->mu2, Ph}, {"is2", e->is2, Ph},
       {"edge_bits", e->edge_bits, e->edge_bits ? (long)C * e->cap1 * e->f2 * (e->h / 32) : 0},
       {"edge_plan", e->edge_plan, e->edge_plan ? 2L * C + 1 : 0},      // balanced slabs of the last real-side stage (ints)
+      // distinct sources of the current blocks' outermost hop (ints): counts, sources, CSC
+      {"dd_n0", e->dd[e->blk_cur].n0, e->cap0 ? C : 0}, {"dd_src0", e->dd[e->blk_cur].src0, e->cap0 ? C * (long)e->cap0 : 0},
+      {"dd_sptr0", e->dd[e->blk_cur].sptr0, e->cap0 ? C * ((long)e->cap0 + 1) : 0},
+      {"dd_sedge0", e->dd[e->blk_cur].sedge0, e->cap0 ? C * (long)e->cap0 : 0},
+      {"dd_nent", e->dd[e->blk_cur].nent, e->cap0 ? C : 0}, {"dd_ent_src", e->dd[e->blk_cur].ent_src, e->cap0 ? C * (long)e->cap0 : 0},
+      {"dd_ent_row", e->dd[e->blk_cur].ent_row, e->cap0 ? 2 * C * (long)e->cap0 : 0}, {"dd_ent_w", e->dd[e->blk_cur].ent_w, e->cap0 ? 2 * C * (long)e->cap0 : 0},
       // hidden activations of the synthetic rows and their gradient as the last inner step left them (two-transform models)
       {"H1s", e->H1s, e->H1s ? n * e->h : 0}, {"dH1m", e->dH1m, e->dH1m ? n * e->h : 0},
       // PGE backward intermediates where they are materialised (diagnosis: tools/diag_panel_stages.py)

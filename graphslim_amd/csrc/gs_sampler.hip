@@ -488,6 +488,167 @@ __global__ __launch_bounds__(256) void gs_sample_mid_kernel(const int* __restric
   if (tid == 0) blk.nm[m][c] = nc;
 }
 
+// ---- distinct sources of the OUTERMOST block (round 6) ----------------------------------------------------------------------------
+// The outermost hop keeps global source ids and is not de-duplicated (PyG's n_id is: dataset/loader.py:216-223) — the forward only
+// gathers rows.  The backward's edge product gW1_c = sum_e x_src(e) (x) (w_e [H1[src(e)] > 0] Y[row e]) however depends on the SOURCE
+// only through x and the mask: summing a source's in-edges first makes its K dimension the DISTINCT sources (ogbn-arxiv: 8 700 live
+// slots, ~3 200 distinct per class).  This kernel derives, for the blocks of one class per workgroup: src0 = the distinct sources in
+// the order of their first edge slot (deterministic), and the CSC of the block over them (sptr0 / sedge0: slots ascending per source —
+// a fixed summation order).  Same marker protocol as the middle hops (row all FREE on entry and on exit); everything in global memory.
+#define GS_DD_THREADS 1024
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* s_w, int* total) {      // s_w: 16 ints of LDS
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  __syncthreads();      // (s_w may still be read from the previous call)
+  if (lane == 63) s_w[w] = x;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < GS_DD_THREADS / 64; ++i) {
+    const int t = s_w[i];
+    if (i < w) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + x - v;
+}
+
+// One workgroup of 1 024 threads per class; the slot / source loops are independent iterations (the loads of several are in flight),
+// the two scans run over one contiguous chunk per thread.  (The first form — 256 threads, one scan step per 256 slots — took 423 us per
+// sampling at ogbn-arxiv: profiles/r06/edge_src_materialised_not_kept.txt.)
+__global__ __launch_bounds__(GS_DD_THREADS) void gs_dedup_last_kernel(const int* __restrict__ col0, const float* __restrict__ val0,
+                                                                       const int* __restrict__ n_last, int cap_last, int f2, int n_nodes,
+                                                                       int* marker, int* __restrict__ n0, int* __restrict__ src0,
+                                                                       int* __restrict__ sptr0, int* __restrict__ sedge0,
+                                                                       int* __restrict__ cur0, int cap0, int* __restrict__ nent,
+                                                                       int* __restrict__ ent_src, int2* __restrict__ ent_row,
+                                                                       float2* __restrict__ ent_w) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const int* colc = col0 + (long)c * cap_last * f2;
+  const float* valc = val0 + (long)c * cap_last * f2;
+  int* mk = marker + (long)c * n_nodes;
+  int* src = src0 + (long)c * cap0;
+  int* sptr = sptr0 + (long)c * (cap0 + 1);
+  int* sedge = sedge0 + (long)c * cap0;
+  int* cur = cur0 + (long)c * (cap0 + 1);
+  __shared__ int s_w[GS_DD_THREADS / 64];
+  const int nslots = n_last[c] * f2;
+  // 1. first occurrence (lowest slot) of every source (a live slot is recognised by its weight: padding carries exactly 0.f)
+  for (int sl = tid; sl < nslots; sl += GS_DD_THREADS)
+    if (valc[sl] != 0.f) atomicMin(&mk[colc[sl]], sl);
+  __threadfence();
+  __syncthreads();
+  // 2. local ids in slot order: thread t owns the contiguous slots [t per, (t + 1) per)
+  const int per = (nslots + GS_DD_THREADS - 1) / GS_DD_THREADS;
+  const int lo = min(tid * per, nslots), hi = min(lo + per, nslots);
+  unsigned winmask = 0;      // (per <= 32: cap_last f2 <= 32 768 slots; checked by the launcher)
+  for (int sl = lo; sl < hi; ++sl) {
+    const bool win = valc[sl] != 0.f && mk_load(&mk[colc[sl]]) == sl;
+    winmask |= (win ? 1u : 0u) << (sl - lo);
+  }
+  int nc = 0;
+  int lid = block_excl_scan_1024(__popc(winmask), s_w, &nc);
+  for (int sl = lo; sl < hi; ++sl) {
+    if ((winmask >> (sl - lo)) & 1u) {
+      const int g = colc[sl];
+      src[lid] = g;
+      mk_store(&mk[g], lid - GS_MARK_BIAS);
+      ++lid;
+    }
+  }
+  for (int i = tid; i <= nc; i += GS_DD_THREADS) cur[i] = 0;
+  __threadfence();
+  __syncthreads();
+  // 3. in-degree counts
+  for (int sl = tid; sl < nslots; sl += GS_DD_THREADS)
+    if (valc[sl] != 0.f) atomicAdd(&cur[mk_load(&mk[colc[sl]]) + GS_MARK_BIAS], 1);
+  __threadfence();
+  __syncthreads();
+  // 4. exclusive scan of the counts (one contiguous chunk of sources per thread); cur becomes the fill cursor.  The same chunks carry
+  //    the ENTRY scan: a source with k in-edges becomes ceil(k / 2) entries of the edge product (two edges each, below)
+  int ebase = 0, el0 = 0, el1 = 0;
+  {
+    const int perl = (nc + 1 + GS_DD_THREADS - 1) / GS_DD_THREADS;
+    const int l0 = min(tid * perl, nc + 1), l1 = min(l0 + perl, nc + 1);
+    int sum = 0, esum = 0;
+    for (int i = l0; i < l1; ++i) {
+      const int cnt = i < nc ? cur[i] : 0;
+      sum += cnt;
+      esum += (cnt + 1) >> 1;
+    }
+    int tot = 0, etot = 0;
+    int off = block_excl_scan_1024(sum, s_w, &tot);
+    ebase = block_excl_scan_1024(esum, s_w, &etot);
+    el0 = l0; el1 = min(l1, nc);
+    for (int i = l0; i < l1; ++i) {
+      const int cnt = i < nc ? cur[i] : 0;
+      sptr[i] = off;
+      cur[i] = off;
+      off += cnt;
+    }
+    if (tid == 0 && nent) nent[c] = etot;
+  }
+  __threadfence();
+  __syncthreads();
+  // 5. fill, then the marker row goes back to FREE, then every list ascending
+  for (int sl = tid; sl < nslots; sl += GS_DD_THREADS) {
+    if (valc[sl] != 0.f) {
+      const int pos = atomicAdd(&cur[mk_load(&mk[colc[sl]]) + GS_MARK_BIAS], 1);
+      sedge[pos] = sl;
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  for (int i = tid; i < nc; i += GS_DD_THREADS) mk_store(&mk[src[i]], GS_MARK_FREE);
+  for (int l = tid; l < nc; l += GS_DD_THREADS) {
+    const int a = sptr[l], b = sptr[l + 1];
+    for (int i = a + 1; i < b; ++i) {
+      const int x = sedge[i];
+      int q = i - 1;
+      while (q >= a && sedge[q] > x) { sedge[q + 1] = sedge[q]; --q; }
+      sedge[q + 1] = x;
+    }
+  }
+  if (tid == 0) n0[c] = nc;
+  // 6. the edge product's K entries (gs_edge.hip, ENT form): entry = (source, two of its in-edges as (row of Y, weight); the second
+  //    weight is 0.f for an odd tail) in source order, a source's edges in ascending slot order — each thread emits its own chunk of
+  //    sources (the lists it reads were sorted by OTHER threads: barrier first)
+  if (nent) {
+    __threadfence();
+    __syncthreads();
+    int* es = ent_src + (long)c * cap0;
+    int2* er = ent_row + (long)c * cap0;
+    float2* ew = ent_w + (long)c * cap0;
+    int e = ebase;
+    for (int l = el0; l < el1; ++l) {
+      const int a = sptr[l], b = sptr[l + 1], g = src[l];
+      for (int i = a; i < b; i += 2, ++e) {
+        const int s0 = sedge[i], s1 = i + 1 < b ? sedge[i + 1] : s0;
+        es[e] = g;
+        er[e] = make_int2(s0 / f2, s1 / f2);
+        ew[e] = make_float2(valc[s0], i + 1 < b ? valc[s1] : 0.f);
+      }
+    }
+  }
+}
+
+// engine-internal (gs_engine.hip): the distinct-source structure of `nclass` classes' outermost blocks
+int gs_dedup_last(const int* col0, const float* val0, const int* n_last, int cap_last, int f2, int n_nodes, int* marker, int nclass,
+                  int* n0, int* src0, int* sptr0, int* sedge0, int* cur0, int cap0, int* nent, int* ent_src, void* ent_row, void* ent_w,
+                  hipStream_t s) {
+  if (nclass < 1) return GS_OK;
+  if ((long)cap_last * f2 > 32L * GS_DD_THREADS) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_dedup_last: more than %d edge slots per class", 32 * GS_DD_THREADS);
+  hipLaunchKernelGGL(gs_dedup_last_kernel, dim3(nclass), dim3(GS_DD_THREADS), 0, s, col0, val0, n_last, cap_last, f2, n_nodes, marker, n0, src0,
+                     sptr0, sedge0, cur0, cap0, nent, ent_src, (int2*)ent_row, (float2*)ent_w);
+  GS_LAUNCH_CHECK();
+  return GS_OK;
+}
+
 // members of the crossing key bin that are ranked directly (<= 2048: the LDS candidate list); larger bins get a second 12-bit
 // level.  Test hook: a small value forces the two-level path on ordinary pools (same seeds either way: the selection is exact).
 static int g_cand_cap = 2048;

@@ -86,6 +86,14 @@ int gs_gcond_set_fused_chains(int on);
  * round 5: seven dependent launches per step).  Same values up to fp32 summation order.  Per engine: GS_KNOB_INNER_PERSIST.
  * gs_inner_persist_set_grid: workgroups of that launch (default 48 = what the hoisted forward's 13/16 grid leaves free). */
 int gs_gcond_set_inner_persist(int on);
+/* Measurement knob (default 0): 1 = the real-side edge product gW1_c = sum_e x_src(e) (x) (w_e [H1[src(e)] > 0] Y[row e]) runs over
+ * ENTRIES = (distinct source of the outermost block, up to two of its in-edges) instead of edge slots: x and the mask row of a source are
+ * fetched once per entry, its in-edges are summed in the operand path (gs_dedup_last_kernel builds the distinct sources, the block's CSC
+ * over them and the entries behind every sampling / gs_gcond_set_blocks).  The same sum in another association.  SGC, two transforms,
+ * two hops, 256 hidden units, 'ours'.  Measured at ogbn-arxiv (profiles/r06/edge_src_ab.txt): K 8 700 -> ~6 100 per class, the real
+ * side 452 -> 429 us alone, but the de-duplication kernel costs more than that beside the rest of the iteration: not the default.
+ * Per engine: GS_KNOB_EDGE_SRC. */
+int gs_gcond_set_edge_src(int on);
 int gs_inner_persist_set_grid(int workgroups);
 int gs_inner_persist_trace(void* device_u64_G_by_128);      /* measurement: s_memrealtime stamps around every grid barrier (NULL = off) */
 
@@ -128,7 +136,7 @@ int gs_sample_set_cand_cap(int cap);
 /* Engine-level knobs per ENGINE (the int-only setters above change the process-wide default an engine follows while its own value is
    -1): knob ids below, value 0 / 1, -1 = follow the default again.  gs_gcond_get_knob returns the value in effect (-1: bad arguments). */
 enum { GS_KNOB_FUSED_CHAINS = 0, GS_KNOB_H1_ROWS = 1, GS_KNOB_H1_BITS = 2, GS_KNOB_EDGE_BITS = 3, GS_KNOB_DW1_GENERATED = 4,
-       GS_KNOB_FOLDED_REDUCTIONS = 5, GS_KNOB_CHAINED_PRODUCTS = 6, GS_KNOB_FORK_LATE = 7, GS_KNOB_EDGE_PLAN = 8, GS_KNOB_INNER_PERSIST = 9, GS_KNOB_COUNT = 10 };
+       GS_KNOB_FOLDED_REDUCTIONS = 5, GS_KNOB_CHAINED_PRODUCTS = 6, GS_KNOB_FORK_LATE = 7, GS_KNOB_EDGE_PLAN = 8, GS_KNOB_INNER_PERSIST = 9, GS_KNOB_EDGE_SRC = 10, GS_KNOB_COUNT = 11 };
 int gs_gcond_set_knob(gs_gcond* e, int knob, int value);
 int gs_gcond_get_knob(const gs_gcond* e, int knob);
 
