@@ -39,15 +39,17 @@ class _ReluTies:
     sum lands on the other side of zero computes)."""
 
     def __init__(self, tol=1e-6, flip=()):
-        self.tol, self.flip, self.found, self.calls = tol, set(flip), [], {}
+        self.tol, self.flip, self.found, self.calls, self.sign = tol, set(flip), [], {}, {}
 
     def __call__(self, layer, e):
         k = self.calls.get(layer, 0)
         self.calls[layer] = k + 1
         gate = (e > 0)
         if k == 0:      # the training forward of the iteration (the later calls are the inference pass after the update)
-            near = torch.nonzero(e.detach().abs().reshape(-1) < self.tol).reshape(-1).tolist()
+            flat = e.detach().reshape(-1)
+            near = torch.nonzero(flat.abs() < self.tol).reshape(-1).tolist()
             self.found += [(layer, i) for i in near]
+            self.sign.update({(layer, i): bool(flat[i] > 0) for i in near})
             idx = [i for (ly, i) in self.flip if ly == layer]
             if idx:
                 gate = gate.clone().reshape(-1)
@@ -90,6 +92,11 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", re
         # ---- engine: one outer iteration, stage by stage (what gs_gcond_outer_step runs) ---------------------------------
         eng.stage_real_grads()
         eng.stage_pge_forward(False)
+        engine_z = None
+        if relu_flip is not None:      # the ENGINE's inputs of the PGE's two ReLUs in this training forward (to resolve ties, see test_cora_r05_full_size)
+            ph = eng.shapes.pge_hidden      # (the second ReLU: BatchNorm-2 of the layer-2 pre-activations E2 with the engine's batch statistics)
+            e2, mu2, is2 = eng.buffer("E2", (n * n, ph)), eng.buffer("mu2"), eng.buffer("is2")
+            engine_z = {1: ((e2 - mu2) * is2 * pge0[8] + pge0[9]).reshape(-1).clone()}
         eng.stage_syn_match()
         eng.syn_finish()
         loss = float(eng.buffer("loss")[0])
@@ -125,7 +132,8 @@ def run_config(name, epoch, lr_scale=1.0, operand_mode=None, driver="staged", re
         ref_loss, ref_gfeat, ref_gpge, _ = st.outer_iteration(epoch, batches, p["data"].bench_feat, p["data"].bench_labels, 0)
     finally:
         O.RELU_HOOK = None
-    out = dict(relu_ties=hook.found if hook else None, loss=loss, ref_loss=float(ref_loss), rel_loss=abs(loss - float(ref_loss)) / abs(float(ref_loss)),
+    out = dict(relu_ties=hook.found if hook else None, relu_sign=hook.sign if hook else None,
+               engine_z=engine_z if driver == "staged" and relu_flip is not None else None, loss=loss, ref_loss=float(ref_loss), rel_loss=abs(loss - float(ref_loss)) / abs(float(ref_loss)),
                g_feat=rel_max(g_feat, ref_gfeat), g_pge=[], n=n, name=name, epoch=epoch)
     o = 0
     for i, (shp, ref) in enumerate(zip(eng.pge_shapes(), ref_gpge)):
@@ -241,9 +249,9 @@ def test_cora_r05_full_size():
     627 200 inputs of the PGE's second ReLU lies 3.3e-7 from zero here — a tie at rounding distance that two fp32 forwards with
     different summation orders resolve differently (profiles/r04/cora_r05_panel_vs_general_single_relu_flip.txt: dE2 differs by 2e-6
     on that element and by 4e-10 elsewhere; with only n'^2 = 4 900 pair rows one flipped gate is 1.4e-3 of max |dW1|).  Round 4 gated
-    that run at a blanket 1e-2; now (VERDICT r04 "next" 8) the oracle reports its ReLU inputs within 1e-6 of zero and the engine must
-    meet the STRICT gates against the oracle with those ties resolved one way or the other — nothing else is loosened."""
-    import itertools
+    that run at a blanket 1e-2; round 5 searched over subsets of the reported ties until the strict gates held.  Now the oracle
+    reports its ReLU inputs within 1e-6 of zero AND their signs, the engine's own value of each of those inputs is read back, and the
+    oracle is replayed ONCE with exactly the gates the engine resolved the other way — nothing is searched, nothing else is loosened."""
     check(run_config("cora", 10, operand_mode="f32"))
     check(run_config("cora", 0, operand_mode="f32"))
     for epoch in (10, 0):
@@ -251,14 +259,20 @@ def test_cora_r05_full_size():
         ties = r["relu_ties"]
         print(f"cora r = 0.5, epoch {epoch}: ReLU inputs of the PGE within 1e-6 of zero in the oracle's forward: {ties}")
         assert len(ties) <= 4, ties
-        ok = all(e <= 1e-3 for _, e in r["g_pge"])
-        for k in range(1, len(ties) + 1):
-            for flip in itertools.combinations(ties, k):
-                if ok:
-                    break
-                r = run_config("cora", epoch, relu_flip=flip)
-                ok = all(e <= 1e-3 for _, e in r["g_pge"])
-                print(f"   with the tie(s) {flip} resolved the other way: d theta_PGE errors {[round(e, 6) for _, e in r['g_pge']]}")
+        # No search: a tie is resolved by the ENGINE's own value of that very ReLU input, read from its buffers —
+        # it must be a tie there too (|z| <= 1e-5: else the engine computed something else at that element and the strict gate below
+        # decides), and the oracle is replayed with exactly the gates whose sign the engine resolved the other way.
+        flip = []
+        for (layer, i) in ties:
+            assert layer in r["engine_z"], f"a tie in ReLU {layer} of the PGE: only the second ReLU's inputs are read back from the engine"
+            z = float(r["engine_z"][layer][i])
+            assert abs(z) <= 1e-5, (layer, i, z)
+            if (z > 0) != r["relu_sign"][(layer, i)]:
+                flip.append((layer, i))
+        print(f"   engine resolves {len(flip)} of {len(ties)} the other way: {flip}")
+        if flip:
+            r = run_config("cora", epoch, relu_flip=tuple(flip))
+            print(f"   oracle replayed with those gates flipped: d theta_PGE errors {[round(e, 6) for _, e in r['g_pge']]}")
         check(r)
 
 
@@ -281,6 +295,13 @@ def test_three_hops_against_the_oracle(name, scale):
     check(run_config(name, 10, scale=scale))
     check(run_config(name, 0, scale=scale))
     check(run_config(name, 10, scale=scale, driver="fused"))
+
+
+def test_three_hops_full_scale_fused_iteration():
+    """VERDICT r05 weak 2 / "next" 4b: bench.py quotes `--nlayers 3` at the FULL ogbn-arxiv shape (profiles/r05/bench_arxiv_three_hops.json:
+    frontier capacities of 45 056 rows per class, 7 GB of workspace) — one whole fused iteration at that size against the oracle on the
+    blocks the call sampled (feature epoch; the gates of every other full-size configuration)."""
+    check(run_config("arxiv-k3", 10, scale=1.0, driver="fused"))
 
 
 def test_three_hops_with_dropout_against_the_oracle():
