@@ -35,6 +35,13 @@ class _GradMatch(GCondBase):
         if args.condense_model not in ("SGC", "GCN"):
             raise NotImplementedError(f"graphslim_amd: condense_model must be SGC or GCN (got {args.condense_model})")
         depth = 2 if args.condense_model == "GCN" else args.ntrans      # models/gcn.py:8-23 vs models/sgc.py:16-35
+        if args.condense_model == "SGC" and args.ntrans > 2:
+            # models/sgc.py:32-35: ntrans - 2 hidden-to-hidden transforms.  The engine walks the layers on the two-transform kernels'
+            # shapes (csrc/gs_deep.inc; golden G27): 3 or 4 transforms, hidden 256, 'ours', two hops, no BatchNorm / dropout
+            if not (args.ntrans <= 4 and args.hidden == 256 and args.dis_metric == "ours" and args.nlayers == 2
+                    and not getattr(args, "with_bn", False) and not float(getattr(args, "dropout", 0.0) or 0.0)):
+                raise NotImplementedError("graphslim_amd: ntrans > 2 is built for ntrans 3 / 4, hidden = 256, dis_metric 'ours', nlayers = 2, "
+                                          "without with_bn / dropout")
         # `--nlayers` K (models/sgc.py:45-51 propagates K times; dataset/loader.py:197-210 samples K hops): 2 everywhere in the shipped
         # configs; 3 .. 5 for SGC (goldens G24).  K = 1 has no reference behaviour to match: PyG's NeighborSampler.sample returns the
         # single hop's Adj tuple itself instead of a list, and gcond_base.py:213 `[adj[0] for adj in adjs]` then indexes its

@@ -92,6 +92,16 @@ struct gs_gcond {
   int N, d, ldx, C, n, T, h, Ph, bcap, f1, f2, cap1, F, Fp;     // Fp = F rounded up to 4: row stride of the real side's P0 / Sr
   long P, Ppge;
   long oW1, ob1, oWl, obl;                                   // model parameter offsets
+  // ntrans >= 3 (models/sgc.py:32-35): `deep` = ntrans - 2 hidden-to-hidden transforms between the first and the last; T stays 2
+  // (every two-transform buffer exists), the stages dispatch on `deep` (gs_deep.inc).  theta = [W1 b1 | Wm_0 bm_0 | .. | Wl bl]
+  int deep; long oWm[2], obm[2];
+  float *Hmid_full[2];                 // [N][h] hidden activations of layers 2 .. 1 + deep for every node
+  float *WmT;                          // [h][h] scratch: a hidden-to-hidden weight transposed (k-contiguous operand)
+  float *Hmid_s[2];                    // [n'][h] the same on the synthetic rows
+  float *dp_cls[6], *dp_n[6];          // [C][n'][h] / [n'][h] scratch of the deep synthetic match
+  float *dr_out;                       // [C][max(d, h)][h] a weight's per-class gradients, contiguous (copied into gw_real's rows of stride P)
+  float *dr_a, *dr_b, *dr_c;           // [C][cap0][h] per-source backward rows of the deep real side (sum of in-edges, masked, through W^T)
+  float *ones0;                        // [C][cap0] unit weights of the per-source edge products
   long pW0, pb0, pW1, pb1, pw2, pb2, pg1, pbe1, pg2, pbe2;   // PGE parameter offsets
   gs_pdesc pd;
   int max_nc;
@@ -239,6 +249,8 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   e->gcn = (c.condense_model == 1);
   e->pge_chunks = c.pge_chunks > 1 ? c.pge_chunks : 1;
   if (e->gcn) e->T = 2;                       // GCN: two GraphConvolution layers, same parameter layout as SGC T = 2
+  e->deep = 0;
+  if (!e->gcn && c.ntrans > 2) { e->deep = c.ntrans - 2; e->T = 2; }
   e->F = (e->T == 1) ? c.d : c.hidden;
   e->Fp = (e->F + 3) & ~3;
   gs_pdesc& pd = e->pd;
@@ -252,13 +264,21 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
     pd.rows[1] = e->C; pd.cols[1] = 1; pd.off[1] = e->obl; pd.is_bias[1] = 1;
   } else {
     e->oW1 = 0; e->ob1 = (long)e->d * e->h;
-    e->oWl = e->ob1 + e->h; e->obl = e->oWl + (long)e->h * e->C;
-    e->P = e->obl + e->C;
-    pd.nparams = 4;
+    long o = e->ob1 + e->h;
+    int q = 2;
     pd.rows[0] = e->d; pd.cols[0] = e->h; pd.off[0] = 0; pd.is_bias[0] = 0;
     pd.rows[1] = e->h; pd.cols[1] = 1; pd.off[1] = e->ob1; pd.is_bias[1] = 1;
-    pd.rows[2] = e->h; pd.cols[2] = e->C; pd.off[2] = e->oWl; pd.is_bias[2] = 0;
-    pd.rows[3] = e->C; pd.cols[3] = 1; pd.off[3] = e->obl; pd.is_bias[3] = 1;
+    for (int k = 0; k < e->deep; ++k) {      // hidden-to-hidden transforms (nn.Module.parameters() order: layer by layer, weight then bias)
+      e->oWm[k] = o; e->obm[k] = o + (long)e->h * e->h;
+      pd.rows[q] = e->h; pd.cols[q] = e->h; pd.off[q] = e->oWm[k]; pd.is_bias[q] = 0; ++q;
+      pd.rows[q] = e->h; pd.cols[q] = 1; pd.off[q] = e->obm[k]; pd.is_bias[q] = 1; ++q;
+      o = e->obm[k] + e->h;
+    }
+    e->oWl = o; e->obl = e->oWl + (long)e->h * e->C;
+    e->P = e->obl + e->C;
+    pd.nparams = q + 2;
+    pd.rows[q] = e->h; pd.cols[q] = e->C; pd.off[q] = e->oWl; pd.is_bias[q] = 0;
+    pd.rows[q + 1] = e->C; pd.cols[q + 1] = 1; pd.off[q + 1] = e->obl; pd.is_bias[q + 1] = 1;
   }
   e->P_base = e->P;
   e->with_bn = c.with_bn != 0;
@@ -296,6 +316,7 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   // balanced slabs (round 5, gs_edge.hip): the 512 resident workgroup slots (2 per compute unit) per 128-feature tile, cut over the
   // classes in proportion to their live edge counts on the device; the buffer holds `edge_cap` slabs (the plan uses <= target + C)
   e->edge_target = 512 / gs_cdiv(e->d, 128) > 0 ? 512 / gs_cdiv(e->d, 128) : 1;
+  if (e->deep && 512 / gs_cdiv(e->h, 128) < e->edge_target) e->edge_target = 512 / gs_cdiv(e->h, 128);      // (the hidden-to-hidden weights' products have h feature rows)
   e->edge_cap = e->C * e->nsplit_r > e->edge_target + e->C ? e->C * e->nsplit_r : e->edge_target + e->C;
   // dW1 = dE2^T A1 over K = n'^2 pair rows: Ph/128 x Ph/128 output tiles per slab; aim at one full round of the 768
   // resident 128x128 workgroups (2 048 gave 404 workgroups at n' = 454: half the chip idle)
@@ -337,6 +358,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->blk = e->blkbuf[0];
   // distinct-source form of the edge product: SGC, two transforms, two hops, 256 hidden units (the dedicated edge kernel's shape)
   e->cap0 = (e->T == 2 && !e->gcn && e->nmid == 0 && h == 256 && !e->drop_thr && e->cfg.dis_metric == 0) ? (int)(capL * f2) : 0;
+  const long dh = d > h ? d : h;      // rows of the widest weight whose per-class gradient is an edge product
   e->marker = (e->cfg.external_blocks && !e->cap0) ? nullptr : w.take<int>(C * N);
   e->kcount = w.take<int>(C);
   {
@@ -373,7 +395,7 @@ static size_t carve(gs_gcond* e, void* base) {
     // (the materialised per-edge operand: only the metrics that need the bias gradient use it — with more than two hops it would be
     // tens of GB, so it exists there only when it is needed)
     e->Bmat = (e->nmid == 0 || e->cfg.dis_metric != 0 || e->drop_thr) ? w.take<float>(C * capL * f2 * h) : nullptr;
-    e->slabs_r = w.take<float>((long)e->edge_cap * d * h);
+    e->slabs_r = w.take<float>((long)e->edge_cap * (e->deep ? dh : d) * h);
     e->edge_plan = w.take<int>(2 * C + 1);
   } else {
     e->Tm = e->Y1 = e->Bmat = e->slabs_r = nullptr;
@@ -407,7 +429,7 @@ static size_t carve(gs_gcond* e, void* base) {
   e->ar_marg = w.take<float>(2 * n * Ph + Ph * Ph + Ph);     // [rowsum_c | colsum_r | dW1 | db1] contiguous (one all-reduce; the tail in PGE epochs)
   e->rowsum_c = e->ar_marg; e->colsum_r = e->ar_marg ? e->ar_marg + n * Ph : nullptr; e->dU = w.take<float>(n * Ph); e->W1T = w.take<float>(Ph * Ph); e->W1mT = w.take<float>(d * h);
   e->bsplit_main = w.take<float>(Ph * Ph * 3 / 2 + 16);             // pre-split B images: 4 B (modes 1, 2) or 6 B (mode 3) per element
-  e->bsplit_aux = w.take<float>((h > 0 ? h : 1) * d * 3 / 2 + 16);
+  e->bsplit_aux = w.take<float>((h > 0 ? h : 1) * (e->deep ? dh : d) * 3 / 2 + 16);
   e->probe_span = w.take<unsigned long long>(2 * 256);
   e->theta_eff = e->with_bn ? w.take<float>(P) : nullptr;
   e->bn_s2 = e->with_bn ? w.take<float>(h) : nullptr;
@@ -442,9 +464,23 @@ static size_t carve(gs_gcond* e, void* base) {
     e->dd[q].nent = c0p ? w.take<int>(C) : nullptr; e->dd[q].ent_src = c0p ? w.take<int>(C * c0p) : nullptr;
     e->dd[q].ent_row = c0p ? w.take<int2>(C * c0p) : nullptr; e->dd[q].ent_w = c0p ? w.take<float2>(C * c0p) : nullptr;
   }
+  for (int k = 0; k < 2; ++k) {
+    e->Hmid_full[k] = k < e->deep ? w.take<float>(N * h) : nullptr;
+    e->Hmid_s[k] = k < e->deep ? w.take<float>(n * h) : nullptr;
+  }
+  e->WmT = e->deep ? w.take<float>(h * h) : nullptr;
+  for (int k = 0; k < 6; ++k) {
+    e->dp_cls[k] = e->deep ? w.take<float>(C * n * h) : nullptr;
+    e->dp_n[k] = e->deep ? w.take<float>(n * h) : nullptr;
+  }
+  e->dr_out = e->deep ? w.take<float>(C * dh * h) : nullptr;
+  e->dr_a = e->deep ? w.take<float>(C * (long)e->cap0 * h) : nullptr;
+  e->dr_b = e->deep ? w.take<float>(C * (long)e->cap0 * h) : nullptr;
+  e->dr_c = e->deep ? w.take<float>(C * (long)e->cap0 * h) : nullptr;
+  e->ones0 = e->deep ? w.take<float>(C * (long)e->cap0) : nullptr;
   e->dd_valid[0] = e->dd_valid[1] = false;
   e->ip_ws = nullptr; e->ip_ws_floats = 0; e->ip_counter = 0;
-  if (e->T == 2 && !e->gcn && !e->with_bn && gs_inner_persist_eligible((int)n, (int)d, (int)h, (int)C, 1)) {
+  if (e->T == 2 && !e->gcn && !e->with_bn && !e->deep && gs_inner_persist_eligible((int)n, (int)d, (int)h, (int)C, 1)) {
     e->ip_ws_floats = gs_inner_persist_ws_floats((int)n, (int)d, (int)h, (int)C);
     e->ip_ws = w.take<float>(e->ip_ws_floats);
     if (e->ip_ws) gs_inner_persist_carve(e->ip_ws, (int)n, (int)d, (int)h, (int)C, &e->ipw);
@@ -470,14 +506,21 @@ static size_t carve(gs_gcond* e, void* base) {
 static int check_cfg(const gs_gcond_config* c) {
   if (!c) GS_FAIL(GS_ERR_ARG, "gs_gcond: null config");
   if (c->condense_model != 0 && c->condense_model != 1) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: condense_model must be 0 (SGC) or 1 (GCN)");
-  if (c->condense_model == 0 && c->ntrans != 1 && c->ntrans != 2) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: SGC ntrans must be 1 or 2 (got %d)", c->ntrans);
+  if (c->condense_model == 0 && (c->ntrans < 1 || c->ntrans > 4))
+    GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: SGC ntrans must be 1 .. 4 (got %d)", c->ntrans);
+  if (c->condense_model == 0 && c->ntrans > 2) {
+    // models/sgc.py:32-35: ntrans - 2 hidden-to-hidden transforms.  Built on the two-transform kernels' shapes, for the shipped metric
+    if (c->hidden != 256 || c->with_bn || c->dropout > 0.f || c->dis_metric != 0 || (c->nlayers != 0 && c->nlayers != 2) || c->d % 4 != 0)
+      GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: ntrans > 2 is built for hidden = 256, dis_metric 'ours', nlayers = 2, d %% 4 == 0, without "
+                                  "BatchNorm / dropout");
+  }
   if (c->condense_model == 1 && c->hidden < 1) GS_FAIL(GS_ERR_ARG, "gs_gcond: hidden must be > 0 for GCN");
   if (c->n_nodes < 1 || c->d < 1 || c->ldx < c->d || c->nclass < 1 || c->n_syn < 1 || c->pge_hidden < 1)
     GS_FAIL(GS_ERR_ARG, "gs_gcond: bad dimensions");
   if (c->nclass > 512) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nclass > 512");
   if (c->pge_hidden % 4 != 0 || c->pge_hidden > 1024 || c->pge_hidden < 4)
     GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: pge_hidden must be a multiple of 4 in [4, 1024] (the reference uses 128 / 256)");
-  if (c->condense_model == 0 && c->ntrans == 2 && c->hidden < 1) GS_FAIL(GS_ERR_ARG, "gs_gcond: hidden must be > 0 for ntrans = 2");
+  if (c->condense_model == 0 && c->ntrans >= 2 && c->hidden < 1) GS_FAIL(GS_ERR_ARG, "gs_gcond: hidden must be > 0 for ntrans = 2");
   if (c->bcap < 1 || c->bcap > 256 || c->f1 < 1 || c->f1 > 16 || c->f2 < 1 || c->f2 > 16)
     GS_FAIL(GS_ERR_ARG, "gs_gcond: bcap in [1,256], fan-outs in [1,16]");
   if (c->dis_metric < 0 || c->dis_metric > 2) GS_FAIL(GS_ERR_ARG, "DC error: unknown distance function");
@@ -620,6 +663,7 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
     (void)hipMemsetAsync(e->steps, 0, sizeof(long), s);
     // (the arrival counter / error word, and the pad columns of Q | Q^T the products never write)
     if (e->ip_ws) (void)hipMemsetAsync(e->ip_ws, 0, sizeof(float) * e->ip_ws_floats, s);
+    if (e->ones0) hipLaunchKernelGGL(gs_fill_kernel, dim3(gs_cdiv((long)C * e->cap0, 256)), dim3(256), 0, s, e->ones0, (long)C * e->cap0, 1.f);
     if (e->marker)
       hipLaunchKernelGGL(gs_fill_int_kernel, dim3(gs_cdiv((long)C * e->N, 256)), dim3(256), 0, s, e->marker, (long)C * e->N,
                          0x7fffffff);
@@ -795,7 +839,7 @@ extern "C" int gs_gcond_get_blocks(gs_gcond* e, gs_blocks* out) {
   return GS_OK;
 }
 
-static int dedup_into(gs_gcond* e, int which, gs_stream_t stream);
+static int dedup_into(gs_gcond* e, int which, gs_stream_t stream, bool force = false);
 extern "C" int gs_gcond_set_blocks(gs_gcond* e, const gs_blocks* b, gs_stream_t stream) {
   if (!e || !b) GS_FAIL(GS_ERR_ARG, "gs_gcond_set_blocks: null argument");
   e->prefetched = false;
@@ -861,6 +905,7 @@ static int colsum_batched(gs_gcond* e, const float* M, long batch_stride, int ro
 // collective is all-reduce(sum).  With the default full ranges the stages are the single-GPU path.
 // ================================================================================================
 extern "C" int gs_gcond_set_shard(gs_gcond* e, int c_lo, int c_hi, int r_lo, int r_hi) {
+  if (e && e->deep && (c_lo != 0 || c_hi != e->C)) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond_set_shard: ntrans > 2 is built unsharded");
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   GS_TRY(quiesce_hoist(e));
   if (c_lo < 0 || c_hi < c_lo || c_hi > e->C || r_lo < 0 || r_hi < r_lo || r_hi > e->n)
@@ -918,9 +963,10 @@ int gs_sample_blocks_ex(const int*, const int*, const float*, int, const int*, c
 // stage: sampling
 // ================================================================================================
 // the distinct sources of the outermost block of block buffer `which` (this rank's classes): behind every sampling / upload of a set
-static int dedup_into(gs_gcond* e, int which, gs_stream_t stream) {
+static int dedup_into(gs_gcond* e, int which, gs_stream_t stream, bool force) {
   e->dd_valid[which] = false;
-  if (!e->cap0 || e->c_hi <= e->c_lo || e->S_full || !knob_of(e, GS_KNOB_EDGE_SRC, g_edge_src)) return GS_OK;
+  // (the deep real side needs the per-source structure whatever the knob says)
+  if (!e->cap0 || e->c_hi <= e->c_lo || e->S_full || !(force || e->deep || knob_of(e, GS_KNOB_EDGE_SRC, g_edge_src))) return GS_OK;
   e->dd_valid[which] = true;
   const gs_blocks keep = e->blk;
   e->blk = e->blkbuf[which];
@@ -1094,6 +1140,78 @@ extern "C" int gs_gcond_set_h1_rows(int on) {
   return GS_OK;
 }
 
+// out[c][s][:] = in[c][s][:] * [Hfull[src0[c][s]][:] > 0] for the live sources s < n0[c] (h = 256: one wave per row, 16 bytes per lane)
+__global__ __launch_bounds__(256) void gs_gather_mask_rows_kernel(const float* __restrict__ in, const float* __restrict__ Hfull,
+                                                                  const int* __restrict__ src0, const int* __restrict__ n0, int cap0,
+                                                                  float* __restrict__ out, int nclass) {
+  const int lane = threadIdx.x & 63;
+  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= (long)nclass * cap0) return;
+  const int c = (int)(row / cap0), sidx = (int)(row - (long)c * cap0);
+  if (sidx >= n0[c]) return;
+  const float4 v = *reinterpret_cast<const float4*>(in + row * 256 + 4 * lane);
+  const float4 m = *reinterpret_cast<const float4*>(Hfull + (long)src0[row] * 256 + 4 * lane);
+  float4 o;
+  o.x = m.x > 0.f ? v.x : 0.f; o.y = m.y > 0.f ? v.y : 0.f; o.z = m.z > 0.f ? v.z : 0.f; o.w = m.w > 0.f ? v.w : 0.f;
+  *reinterpret_cast<float4*>(out + row * 256 + 4 * lane) = o;
+}
+
+// ntrans >= 3, real side backward (oracle/analytic.py real_class_grad_deep).  YL = the backward rows of the outermost block's TARGETS
+// ((A1^T (G Wl^T))[row], h wide).  The gradient wrt the last hidden layer's output on a SOURCE is the sum over its in-edges (the
+// outermost block's own transposed product over its CSC, gs_dedup_last_kernel); from there the layers are walked down per distinct
+// source: gW_k[c] = sum_s a_{k-1}[src s] (x) ([a_k[src s] > 0] * cur[c][s]) is the edge product in its per-source form (unit weights, one
+// Y row per K entry), and cur <- ([a_k[src] > 0] * cur) W_k^T is a batched product over the classes' live sources.
+static int deep_real_backward(gs_gcond* e, const gs_blocks& b, const float* YL, int Cl, int c0, float* gw, int* kcount, gs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int d = e->d, h = e->h, L = 2 + e->deep;
+  const long P = e->P, cap0 = e->cap0;
+  const float* th = e->io.model_params;
+  if (!cap0 || !e->edge_plan) GS_FAIL(GS_ERR_STATE, "gs_gcond: ntrans > 2 needs the per-source structure (hidden = 256, 'ours')");
+  if (!e->dd_valid[e->blk_cur]) {
+    if (e->prefetched && e->ev_prefetch && s != e->aux) GS_HIP(hipStreamWaitEvent(s, e->ev_prefetch, 0));
+    GS_TRY(dedup_into(e, e->blk_cur, stream, true));
+  }
+  const auto& dd = e->dd[e->blk_cur];
+  const int* n0 = dd.n0 + c0;
+  const int* src0 = dd.src0 + (long)c0 * cap0;
+  float* cur = e->dr_a + (long)c0 * cap0 * h; float* dlt = e->dr_b + (long)c0 * cap0 * h; float* nxt = e->dr_c + (long)c0 * cap0 * h;
+  // the gradient wrt a_{L-1} per distinct source: sum of its in-edges
+  hipLaunchKernelGGL(gs_csc_spmm_t_v4_kernel, dim3(gs_cdiv((long)Cl * cap0, 4)), dim3(256), 0, s, dd.sptr0 + (long)c0 * (cap0 + 1),
+                     dd.sedge0 + (long)c0 * cap0, b.val0, n0, (int)cap0, e->capL, e->f2, YL, cur, Cl);
+  GS_LAUNCH_CHECK();
+  for (int k = L - 1; k >= 1; --k) {      // hidden layer k: p_k = a_{k-1} W_k + b_k, a_k = relu(p_k)
+    const float* Aprev = k == 1 ? e->io.X : (k == 2 ? e->H1full : e->Hmid_full[k - 3]);
+    const long ldA = k == 1 ? e->ldx : h;
+    const int M = k == 1 ? d : h;
+    const float* Hk = k == 1 ? e->H1full : e->Hmid_full[k - 2];
+    const long oW = k == 1 ? e->oW1 : e->oWm[k - 2];
+    int target = 512 / gs_cdiv(M, 128);
+    if (target > e->edge_cap - Cl) target = e->edge_cap - Cl;
+    GS_TRY(gs_edge_plan(n0, 1, Cl, target < 1 ? 1 : target, kcount, e->edge_plan, s));      // kcount[c] = n0[c]
+    gs_gemm_desc g = mk(Aprev, 1, ldA, cur, h, 1, e->slabs_r, h, M, h, (int)cap0);
+    g.gatherA_k = src0; g.sGb1 = cap0;
+    g.nb1 = Cl; g.nb2 = 1; g.kchunk = 16; g.Kb = kcount;
+    g.sBb1 = cap0 * h; g.sCb1 = (long)M * h; g.sCb2 = (long)M * h;
+    g.bgen_mask = Hk; g.bgen_ldm = h; g.bgen_idx = src0; g.bgen_w = e->ones0 + (long)c0 * cap0; g.bgen_div = 1;
+    g.prec = e->operand_mode;
+    if (!gs_edge_eligible(g)) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: ntrans > 2: the per-source edge product does not fit the edge kernel");
+    GS_TRY(gs_edge_launch_plan(g, e->edge_plan, e->edge_cap, s));
+    // (reduced into a contiguous, 16-byte aligned buffer, then copied into the rows of gw_real: P need not be a multiple of 4)
+    GS_TRY(gs_reduce_slabs_plan(e->dr_out, (long)M * h, e->slabs_r, (long)M * h, (long)M * h, Cl, e->edge_plan, s));
+    GS_HIP(hipMemcpy2DAsync(gw + oW, sizeof(float) * P, e->dr_out, sizeof(float) * (size_t)M * h, sizeof(float) * (size_t)M * h, Cl,
+                            hipMemcpyDeviceToDevice, s));
+    if (k > 1) {
+      hipLaunchKernelGGL(gs_gather_mask_rows_kernel, dim3(gs_cdiv((long)Cl * cap0, 4)), dim3(256), 0, s, cur, Hk, src0, n0, (int)cap0, dlt, Cl);
+      GS_LAUNCH_CHECK();
+      gs_gemm_desc t = mk(dlt, h, 1, th + oW, 1, h, nxt, h, (int)cap0, h, h);      // (delta_k W_k^T)[s][i] = sum_j delta[s][j] W_k[i][j]
+      t.nb1 = Cl; t.sAb1 = cap0 * h; t.sCb1 = cap0 * h; t.Mb = n0;
+      GS_TRY(gs_gemm_f32(&t, stream));
+      float* sw = cur; cur = nxt; nxt = sw;
+    }
+  }
+  return GS_OK;
+}
+
 extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   if (!e->have_blocks) GS_FAIL(GS_ERR_STATE, "gs_gcond: no sampled blocks yet");
@@ -1180,6 +1298,16 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
     }
     src = e->H1full;
     ld_src = h;
+    // ntrans >= 3: the hidden-to-hidden transforms act row by row — every node's rows once per iteration, like H1full
+    for (int k = 0; k < e->deep; ++k) {
+      hipLaunchKernelGGL(gs_transpose_small_kernel, dim3(gs_cdiv(h, 32), gs_cdiv(h, 32)), dim3(32, 8), 0, s, th + e->oWm[k], h, h, e->WmT);
+      GS_LAUNCH_CHECK();
+      gs_gemm_desc g = mk(src, h, 1, e->WmT, 1, h, e->Hmid_full[k], h, e->N, h, h);
+      g.bias = th + e->obm[k]; g.relu = 1;
+      g.prec = e->operand_mode; g.scratch = e->bsplit_aux;
+      GS_TRY(gs_gemm_f32(&g, stream));
+      src = e->Hmid_full[k];
+    }
   }
   if (e->S_full) {      // full-neighbour mode: S_c = S_full[seeds of class c], rs_c = rs_full[seeds]
     hipLaunchKernelGGL(gs_gather_seed_rows_kernel, dim3(gs_cdiv((long)Cl * bcap, 4)), dim3(256), 0, s, e->S_full, e->ldS, e->rs_full,
@@ -1262,6 +1390,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
                            b.nm[m], b.capm[m], capp, b.fm[m], YL, h, Ym, Cl);
       YL = Ym;
     }
+    if (e->deep) return deep_real_backward(e, b, YL, Cl, (int)c0, gw, kcount, stream);
     // 'ours' needs no bias gradient -> Bmat is generated inside the GEMM (dropout: the materialised form carries the mask)
     const bool fused = (e->cfg.dis_metric == 0) && !e->drop_thr;
     // balanced slabs (knob EDGE_PLAN, default on): the chip's workgroup slots are cut over the classes by their live edge counts
@@ -1825,9 +1954,12 @@ static int match_distance_folded(gs_gcond* e, const float* gwr, const float* gws
 // and d loss / d A^ -> d adj     (gcond_base.py:226-239 + autograd through them).
 // Writes this rank's PARTIAL [d_feat | d_adj | loss_c] ("ar_syn"); gs_gcond_stage_syn_finish books the loss.
 // ================================================================================================
+#include "gs_deep.inc"
+
 extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   GS_TRY(quiesce_hoist(e));
+  if (e->deep) return deep_syn_match(e, stream);
   hipStream_t s = (hipStream_t)stream;
   const int C = e->C, Cl = e->c_hi - e->c_lo, n = e->n, d = e->d, h = e->h, F = e->F, mx = e->max_nc;
   const long P = e->P, c0 = e->c_lo;
@@ -2559,6 +2691,7 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int C = e->C, n = e->n, d = e->d, h = e->h, F = e->F;
   if (e->cfg.inner_loop == 0) return GS_OK;
+  if (e->deep) return deep_inner_steps(e, stream);
   if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && !e->gcn && !e->with_bn && !e->blk_pos && C <= 64) return inner_steps_fused(e, stream);
   const float* X = e->io.feat_syn;
   float* th_true = e->io.model_params;                 // Adam steps these ...

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(GS_IP_THREADS) void gs_inner_persist_kernel(gs_inne
   f32x4* const red = reinterpret_cast<f32x4*>(smem + 256 * 20);                   // [waves][3][64]
   float* const zt = smem + 256 * 20 + GS_IP_WAVES * 3 * 64 * 4;                   // [48][20]
   float* const rsl = zt + 48 * 20;                                                // [16]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, kq = lane >> 4;
+  const int tid = threadIdx.x;
   const int wg = blockIdx.x, G = a.G;
   const int n = a.n, npad = a.npad, d = a.d, dpad = a.dpad, h = a.h, C = a.C, Cp = a.Cp;
   const int nrb = npad / 16, nht = h / 16, nct = Cp / 16, ndt = dpad / 16, nkb = npad / 16;

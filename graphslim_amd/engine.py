@@ -331,7 +331,10 @@ def dropout_keep(seed, iteration, kind, index, rows, hidden, p):
 
 
 def model_param_count(d, hidden, nclass, ntrans):
-    return d * nclass + nclass if ntrans == 1 else d * hidden + hidden + hidden * nclass + nclass
+    """models/sgc.py:16-35: one transform [d, C]; else [d, h], ntrans - 2 x [h, h], [h, C] (each with its bias)."""
+    if ntrans == 1:
+        return d * nclass + nclass
+    return d * hidden + hidden + (ntrans - 2) * (hidden * hidden + hidden) + hidden * nclass + nclass
 
 
 def pge_param_count(d, ph):
@@ -427,7 +430,11 @@ class GCondEngine:
 
     def get_model(self):
         s, d = self.shapes, self.shapes.d
-        shp = [(d, s.nclass), (s.nclass,)] if (s.ntrans == 1 and s.model == "SGC") else [(d, s.hidden), (s.hidden,), (s.hidden, s.nclass), (s.nclass,)]
+        if s.ntrans == 1 and s.model == "SGC":
+            shp = [(d, s.nclass), (s.nclass,)]
+        else:
+            mid = [(s.hidden, s.hidden), (s.hidden,)] * (s.ntrans - 2 if s.model == "SGC" else 0)
+            shp = [(d, s.hidden), (s.hidden,)] + mid + [(s.hidden, s.nclass), (s.nclass,)]
         if s.with_bn:
             shp += [(s.hidden,), (s.hidden,)]          # bns.0.weight, bns.0.bias
         return _split(self.model_params, shp)

@@ -29,6 +29,10 @@ WORKLOADS = {
     # ogbn-arxiv hyper-parameters: a parity-test case (tests/test_gpu_fullsize.py), not a bench line
     "arxiv-k3": ("ogbn-arxiv", 0.005, 2, 256, 256, 20, 3, 0.01, 0.01, (15, 10, 5)),
     "cora-k3": ("cora", 0.5, 1, 256, 128, 20, 15, 1e-4, 1e-4, (15, 10, 5)),
+    # `--ntrans 3` / 4 (models/sgc.py:32-35: hidden-to-hidden transforms between the first and the last) with the ogbn-arxiv
+    # hyper-parameters: parity-test cases (tests/test_gpu_fullsize.py), not bench lines
+    "arxiv-t3": ("ogbn-arxiv", 0.005, 3, 256, 256, 20, 3, 0.01, 0.01, (10, 5)),
+    "arxiv-t4": ("ogbn-arxiv", 0.005, 4, 256, 256, 20, 3, 0.01, 0.01, (10, 5)),
     "cora-r0.25-k3": ("cora", 0.25, 1, 256, 128, 20, 15, 1e-4, 1e-4, (15, 10, 5)),      # the quiet job of the job-level gate with three hops
 }
 

@@ -309,7 +309,9 @@ int gs_ot_divdiff_f32(float* K, const float* lam, const float* g, const float* g
 typedef struct gs_gcond_config {
   int n_nodes, d, ldx;     /* real graph: X is [n_nodes][ldx], ldx >= d                      */
   int nclass, n_syn;
-  int ntrans;              /* SGC transforms T: 1 or 2 (models/sgc.py:22-35)                   */
+  int ntrans;              /* SGC transforms T: 1 .. 4 (models/sgc.py:22-35; 3 / 4 = one / two hidden-to-hidden transforms between
+                              the first and the last: hidden = 256, dis_metric 'ours', nlayers = 2, d % 4 == 0, no with_bn / dropout,
+                              unsharded; io.model_params = [W1 b1 | Wm_0 bm_0 | .. | Wl bl]) */
   int hidden;              /* SGC hidden width for T = 2                                       */
   int pge_hidden;          /* parametrized_adj.py:9-17                                         */
   int bcap, f1, f2;        /* loader.py:187,197-210: 256 seeds, fan-outs (f1 from seeds)       */

@@ -213,6 +213,144 @@ def syn_match(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="o
 
 
 # ------------------------------------------------------------------------------------------------
+# ntrans >= 3 (models/sgc.py:32-35: `ntrans - 2` hidden-to-hidden transforms between the first and the last): the same closed forms as
+# loops over the layers.  theta = [W_1, b_1, ..., W_L, b_L] (L = ntrans; W_1 [d, h], W_k [h, h], W_L [h, C]).
+#   forward   a_0 = X, p_k = a_{k-1} W_k + b_k, a_k = relu(p_k) = m_k * p_k (k < L), Z = Q (a_{L-1} W_L) + rs (x) b_L
+#   backward  dT = Q^T G, gW_L = a_{L-1}^T dT = S^T G (S = Q a_{L-1}), da_{L-1} = dT W_L^T, delta_k = da_k * m_k, gW_k = a_{k-1}^T delta_k,
+#             da_{k-1} = delta_k W_k^T
+# What csrc/gs_engine.hip's deep path computes (gs_deep.inc); checked against autograd in tests/test_analytic.py.
+# ------------------------------------------------------------------------------------------------
+
+
+def real_class_grad_deep(theta, X, batch, cls):
+    """The real-side class gradient for L >= 2 transforms (batch as in real_class_grad).  The hidden layers act row by row, so the engine
+    computes them once for every node; here on the batch's rows."""
+    B, n_id, blocks = batch
+    A1 = blocks[-1]
+    A0 = blocks[-2]
+    for blk in reversed(blocks[:-2]):
+        A0 = A0 @ blk
+    L = len(theta) // 2
+    a = [X[n_id]]
+    m = [None]
+    for k in range(1, L):
+        pk = a[-1] @ theta[2 * (k - 1)] + theta[2 * (k - 1) + 1]
+        m.append((pk > 0).to(X.dtype))
+        a.append(pk * m[-1])
+    one = torch.ones(a[0].shape[0], dtype=X.dtype)
+    rs = A1 @ (A0 @ one)
+    S = A1 @ (A0 @ a[-1])
+    WL, bL = theta[-2], theta[-1]
+    Z = S @ WL + rs[:, None] * bL
+    G = torch.softmax(Z, 1)
+    G[:, cls] -= 1
+    G /= B
+    gw = [None] * (2 * L)
+    gw[-2], gw[-1] = S.T @ G, rs @ G
+    da = A0.T @ (A1.T @ (G @ WL.T))            # gradient wrt a_{L-1} on the outermost frontier's rows (per SOURCE: the engine sums a source's in-edges)
+    for k in range(L - 1, 0, -1):
+        delta = da * m[k]
+        gw[2 * (k - 1)], gw[2 * (k - 1) + 1] = a[k - 1].T @ delta, delta.sum(0)
+        da = delta @ theta[2 * (k - 1)].T
+    return gw
+
+
+def syn_match_deep(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="ours", K=2):
+    """syn_match for L >= 2 transforms (no dropout): returns (loss, dX, dA) like syn_match."""
+    n = Xs.shape[0]
+    L = len(theta) // 2
+    W = [None] + [theta[2 * k] for k in range(L)]          # W[k], b[k] for k = 1 .. L
+    b = [None] + [theta[2 * k + 1] for k in range(L)]
+    Q = adj_power(A, K)
+    rs = Q.sum(1)
+    a, m = [Xs], [None]
+    for k in range(1, L):
+        pk = a[-1] @ W[k] + b[k]
+        m.append((pk > 0).to(Xs.dtype))
+        a.append(pk * m[-1])
+    S = Q @ a[L - 1]
+    Z = S @ W[L] + rs[:, None] * b[L]
+    P = torch.softmax(Z, 1)
+    loss = torch.zeros((), dtype=Xs.dtype)
+    dQ = torch.zeros_like(Q)
+    V = torch.zeros_like(P)
+    dS = torch.zeros_like(S)
+    drs = torch.zeros_like(rs)
+    Abar = [torch.zeros_like(t) for t in a]                # adjoints of a_0 .. a_{L-1} from the gW_k = a_{k-1}^T delta_k terms
+    for c, (lo, hi) in enumerate(class_ranges):
+        nc = hi - lo
+        if nc == 0:
+            continue
+        G = P[lo:hi].clone()
+        G[:, c] -= 1
+        G /= nc
+        dH2 = Q[lo:hi].T @ G                               # [n, C]  = dT restricted to class c's loss
+        gw = [None] * (2 * L)
+        gw[-2], gw[-1] = S[lo:hi].T @ G, rs[lo:hi] @ G
+        delta = [None] * L
+        da = dH2 @ W[L].T
+        for k in range(L - 1, 0, -1):
+            delta[k] = da * m[k]
+            gw[2 * (k - 1)], gw[2 * (k - 1) + 1] = a[k - 1].T @ delta[k], delta[k].sum(0)
+            da = delta[k] @ W[k].T
+        l, D = match_and_D(metric, gw_real[c], gw)
+        loss = loss + coeffs[c] * l
+        D = [coeffs[c] * t for t in D]
+        Dw = [None] + [D[2 * k] for k in range(L)]
+        Db = [None] + [D[2 * k + 1] for k in range(L)]
+        # adjoint of the backward pass, k = 1 .. L - 1 (the reverse of its order L - 1 .. 1)
+        dabar = None                                       # adjoint of da_k
+        for k in range(1, L):
+            dbar = a[k - 1] @ Dw[k] + Db[k]                # adjoint of delta_k from gW_k, gb_k
+            if dabar is not None:
+                dbar = dbar + dabar @ W[k]                 # ... and from da_{k-1} = delta_k W_k^T
+            Abar[k - 1] = Abar[k - 1] + delta[k] @ Dw[k].T
+            dabar = dbar * m[k]
+        Bc = dabar @ W[L]                                  # adjoint of dH2  [n, C]
+        dQ[lo:hi] += G @ Bc.T
+        U = Q[lo:hi] @ Bc + S[lo:hi] @ Dw[L] + rs[lo:hi, None] * Db[L]
+        Pc = P[lo:hi]
+        V[lo:hi] = (Pc * U - Pc * (Pc * U).sum(1, keepdim=True)) / nc
+        dS[lo:hi] = G @ Dw[L].T
+        drs[lo:hi] = G @ Db[L]
+    dS = dS + V @ W[L].T
+    drs = drs + V @ b[L]
+    abar = Q.T @ dS + Abar[L - 1]
+    dQ = dQ + dS @ a[L - 1].T + drs[:, None]
+    for k in range(L - 1, 0, -1):                          # the forward's adjoint
+        pbar = abar * m[k]
+        abar = pbar @ W[k].T + Abar[k - 1]
+    dA = adj_power_bwd(A, dQ, K)
+    return loss, abar, dA
+
+
+def sgc_dense_grad_deep(theta, Xs, A, labels, K=2):
+    """The inner steps' gradient (gcond.py:67-72: NLL over ALL n' rows) for L >= 2 transforms."""
+    n = Xs.shape[0]
+    L = len(theta) // 2
+    Q = adj_power(A, K)
+    rs = Q.sum(1)
+    a, m = [Xs], [None]
+    for k in range(1, L):
+        pk = a[-1] @ theta[2 * (k - 1)] + theta[2 * (k - 1) + 1]
+        m.append((pk > 0).to(Xs.dtype))
+        a.append(pk * m[-1])
+    S = Q @ a[-1]
+    Z = S @ theta[-2] + rs[:, None] * theta[-1]
+    G = torch.softmax(Z, 1)
+    G[torch.arange(n), labels] -= 1
+    G /= n
+    gw = [None] * (2 * L)
+    gw[-2], gw[-1] = S.T @ G, rs @ G
+    da = Q.T @ (G @ theta[-2].T)
+    for k in range(L - 1, 0, -1):
+        delta = da * m[k]
+        gw[2 * (k - 1)], gw[2 * (k - 1) + 1] = a[k - 1].T @ delta, delta.sum(0)
+        da = delta @ theta[2 * (k - 1)].T
+    return gw
+
+
+# ------------------------------------------------------------------------------------------------
 # dense GCN normalisation, forward and backward  (utils.py:429-439)
 # ------------------------------------------------------------------------------------------------
 

@@ -463,6 +463,16 @@ def g24():
     save("g24_train_class_three_hops", **out)
 
 
+def g27():
+    """ntrans > 2 (VERDICT r05 "missing" 2; models/sgc.py:32-35: `for i in range(self.ntrans - 2): self.layers.append(MyLinear(nhid,
+    nhid))`): train_class + backward of the reference for three and four transforms (hidden 256: the width the engine's deep path is
+    built for), two hops, 'ours'."""
+    out = {}
+    run_train_class("t3", 80, 4, 8, 256, 3, 0.4, "ogbn-arxiv", out)
+    run_train_class("t4", 80, 4, 8, 256, 4, 0.4, "ogbn-arxiv", out)
+    save("g27_train_class_deep", **out)
+
+
 # ---------------------------------------------------------------- G8-G10 full reduce + eval ----
 
 
@@ -1191,6 +1201,6 @@ def g22():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16",
-                             "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26"]
+                             "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26", "g27"]
     for w in which:
         globals()[w]()

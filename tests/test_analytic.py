@@ -85,6 +85,45 @@ def test_syn_match_second_order(T, metric, K):
     np.testing.assert_allclose(dA.numpy(), ga.numpy(), rtol=1e-7, atol=1e-11)
 
 
+@pytest.mark.parametrize("T", [2, 3, 4])
+@pytest.mark.parametrize("metric,K,sizes", [("ours", 2, (3, 2)), ("mse", 2, (3, 2)), ("cos", 2, (3, 2)), ("ours", 3, (3, 2, 2))])
+def test_deep_closed_forms(T, metric, K, sizes):
+    """`--ntrans` >= 3 (models/sgc.py:32-35): the closed forms as loops over the layers (oracle/analytic.py *_deep; at T = 2 they must
+    reproduce the two-transform forms) — real-side class gradients, the matching loss with its second-order gradients wrt X~ and A^,
+    and the inner steps' gradient — against autograd through the oracle, fp64."""
+    p = tiny_problem(T, seed=7, sizes=sizes)
+    gw_real = []
+    for c in range(p["nclass"]):
+        theta = [t.clone().requires_grad_(True) for t in p["theta"]]
+        ref, _ = O.class_real_grads("SGC", theta, p["x"], p["y"], p["batches"][c], K)
+        got = A.real_class_grad_deep(p["theta"], p["x"], dense_batch(p["batches"][c]), c)
+        for r, g in zip(ref, got):
+            np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
+        gw_real.append(got)
+    theta = [t.clone().requires_grad_(True) for t in p["theta"]]
+    xs = p["xs"].clone().requires_grad_(True)
+    an = O.dense_gcn_norm(O.pge_forward(xs.detach(), p["pge"])).clone().requires_grad_(True)
+    loss = O.train_class("SGC", theta, p["batches"], p["x"], p["y"], xs, an, p["labels_syn"], p["ncd"], p["nclass"], K, metric)
+    gx, ga = torch.autograd.grad(loss, [xs, an])
+    ns = len(p["labels_syn"])
+    ranges = [tuple(p["ranges"][c]) for c in range(p["nclass"])]
+    coeffs = [p["ncd"][c] / ns for c in range(p["nclass"])]
+    l, dX, dA = A.syn_match_deep(p["theta"], p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric, K=K)
+    np.testing.assert_allclose(float(l), float(loss), rtol=1e-10)
+    np.testing.assert_allclose(dX.numpy(), gx.numpy(), rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(dA.numpy(), ga.numpy(), rtol=1e-7, atol=1e-11)
+    if T == 2:
+        l2, dX2, dA2 = A.syn_match(p["theta"], p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric, K=K)
+        np.testing.assert_allclose(dX.numpy(), dX2.numpy(), rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(dA.numpy(), dA2.numpy(), rtol=1e-10, atol=1e-13)
+    # the inner steps' gradient
+    theta = [t.clone().requires_grad_(True) for t in p["theta"]]
+    out = O.sgc_forward(p["xs"], an.detach(), theta, K)
+    ref = torch.autograd.grad(F.nll_loss(out, p["labels_syn"]), theta)
+    for r, g in zip(ref, A.sgc_dense_grad_deep(p["theta"], p["xs"], an.detach(), p["labels_syn"], K)):
+        np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("metric,K", [("ours", 2), ("mse", 2), ("cos", 3)])
 def test_dropout_closed_forms(metric, K):
     """Dropout in the condensation model (models/sgc.py:42): the closed forms with one multiplier per class forward — real batch and

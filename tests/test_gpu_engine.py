@@ -43,13 +43,15 @@ def make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, x, f1, f2, bcap
                        lr_model=lrs[2], inner_loop=inner, dis_metric=metric, seed=seed, external_blocks=external, device=DEV)
 
 
-@pytest.mark.parametrize("tag,metric", [("t1", "ours"), ("t2", "ours"), ("t1mse", "mse"), ("gcn", "ours"), ("k3t1", "ours"), ("k3t2", "ours")])
+@pytest.mark.parametrize("tag,metric", [("t1", "ours"), ("t2", "ours"), ("t1mse", "mse"), ("gcn", "ours"), ("k3t1", "ours"), ("k3t2", "ours"),
+                                        ("t3", "ours"), ("t4", "ours")])
 def test_train_class_against_reference_golden(golden_dir, tag, metric):
     """G7: loss, d loss/d A^, d loss/d X~, d loss/d theta_PGE of the reference's train_class + backward.  G24 (tags k3*, round 5): the
     same with `--nlayers 3` — three sampled hops (a MIDDLE block with its CSC between hop 1 and the outermost block) on the real side,
-    Q = A^^3 with the product rule for d A^ on the synthetic side (dataset/loader.py:205-206, models/sgc.py:45-51)."""
+    Q = A^^3 with the product rule for d A^ on the synthetic side (dataset/loader.py:205-206, models/sgc.py:45-51).  G27 (tags t3, t4,
+    round 6): `--ntrans` 3 / 4 — the layers walked by csrc/gs_deep.inc (models/sgc.py:32-35)."""
     from graphslim_amd.engine import BlockSet
-    g = load_golden(golden_dir, "g24_train_class_three_hops" if tag.startswith("k3") else "g7_train_class")
+    g = load_golden(golden_dir, "g24_train_class_three_hops" if tag.startswith("k3") else ("g27_train_class_deep" if tag in ("t3", "t4") else "g7_train_class"))
     batches, (n, nclass, d, hidden, t), _ = rebuild_batches(g, tag)
     labels_syn = g[f"{tag}_labels_syn"]
     _, ncd, ranges = O.generate_labels_syn(g[f"{tag}_y"][g[f"{tag}_idx_train"]], float(g[f"{tag}_rate"]))
@@ -72,8 +74,9 @@ def test_train_class_against_reference_golden(golden_dir, tag, metric):
     for c in range(nclass):
         th = [p.clone().requires_grad_(True) for p in theta]
         ref, _ = O.class_real_grads(kind, th, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), batches[c], len(sizes))
-        if metric == "ours" and t == 2 and kind == "SGC":   # biases get distance 0 and D = 0 under 'ours' (utils.py:98-101): the costly
-            ref[1] = torch.zeros_like(ref[1])   # first-layer bias gradient (a pass over all sampled edges) is not formed
+        if metric == "ours" and t >= 2 and kind == "SGC":   # biases get distance 0 and D = 0 under 'ours' (utils.py:98-101): the costly
+            for q in range(1, 2 * t - 2, 2):    # hidden layers' bias gradients (a pass over all sampled edges each) are not formed
+                ref[q] = torch.zeros_like(ref[q])
         close(gw[c], torch.cat([r.reshape(-1) for r in ref]), 2e-4, f"gw_real class {c}")
     # PGE forward + norm
     eng.stage_pge_forward(False)
