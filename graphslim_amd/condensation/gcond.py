@@ -51,9 +51,9 @@ class _GradMatch(GCondBase):
                                       "single Adj tuple PyG's NeighborSampler returns for one hop (gcond_base.py:213)")
         if args.nlayers not in (2, 3, 4, 5):
             raise NotImplementedError(f"graphslim_amd: nlayers must be 2 .. 5 (dataset/loader.py:197-210 knows no other), got {args.nlayers}")
-        if args.nlayers != 2 and args.condense_model != "SGC":
-            raise NotImplementedError("graphslim_amd: nlayers != 2 is built for condense_model SGC (a K-layer GCN is another model: "
-                                      "models/gcn.py:8-23)")
+        if args.nlayers != 2 and args.condense_model != "SGC" and args.nlayers > 4:
+            # models/gcn.py:8-23: a K-layer GCN has one GraphConvolution per sampled hop (csrc/gs_gcnk.inc; golden G28): 2 .. 4 layers
+            raise NotImplementedError("graphslim_amd: the GCN condensation model takes nlayers 2 .. 4")
         with_bn = bool(getattr(args, "with_bn", False))
         if with_bn and args.condense_model == "GCN":
             # no reference behaviour to match: in train_class the synthetic forward hands the DENSE adj_syn to GraphConvolution.forward,
@@ -119,12 +119,14 @@ class _GradMatch(GCondBase):
         self.feat_syn = eng.feat_syn
         outer_loop, inner_loop = self.get_loops(args)
         loss_avg, best_val = 0, 0
-        init_sgc_params(self.d, args.hidden, nclass, depth)                 # model constructor draw (gcond.py:38)
+        # (GCN: one GraphConvolution per layer, `nlayers` of them — models/gcn.py:8-23; SGC: `ntrans` transforms)
+        mdepth = max(2, int(args.nlayers)) if args.condense_model == "GCN" else depth
+        init_sgc_params(self.d, args.hidden, nclass, mdepth)                # model constructor draw (gcond.py:38)
 
         def fresh_model():
             """model.initialize() (models/base.py:44-49): Linear layers re-drawn; with_bn: BatchNorm reset to weight 1, bias 0 and
             running statistics (0, 1) — no RNG draw — which check_bn then freezes in eval mode (gcond_base.py:261-285)."""
-            th = init_sgc_params(self.d, args.hidden, nclass, depth)
+            th = init_sgc_params(self.d, args.hidden, nclass, mdepth)
             if with_bn:
                 th = th + [torch.ones(args.hidden), torch.zeros(args.hidden)]
             return th

@@ -95,10 +95,16 @@ struct gs_gcond {
   // ntrans >= 3 (models/sgc.py:32-35): `deep` = ntrans - 2 hidden-to-hidden transforms between the first and the last; T stays 2
   // (every two-transform buffer exists), the stages dispatch on `deep` (gs_deep.inc).  theta = [W1 b1 | Wm_0 bm_0 | .. | Wl bl]
   int deep; long oWm[2], obm[2];
+  // GCN condensation model with nlayers = L > 2 (models/gcn.py:8-23): gdeep = L - 2 hidden-to-hidden GraphConvolution layers, same
+  // parameter layout; the stages dispatch to gs_gcnk.inc
+  int gdeep;
+  float *gk_sbuf[3];                   // [n'][h] s_k = A a_{k-1}, k = 2 .. L
+  float *gk_slabA;                     // [C][n'][n'] per-class contributions to d A^
+  float *gr_P1, *gr_H[4], *gr_T, *gr_dT, *gr_dHa, *gr_dHb;      // real side: [C][capL][d], [C][rows_k][h] per layer, scratch of capL rows
   float *Hmid_full[2];                 // [N][h] hidden activations of layers 2 .. 1 + deep for every node
   float *WmT;                          // [h][h] scratch: a hidden-to-hidden weight transposed (k-contiguous operand)
   float *Hmid_s[2];                    // [n'][h] the same on the synthetic rows
-  float *dp_cls[6], *dp_n[6];          // [C][n'][h] / [n'][h] scratch of the deep synthetic match
+  float *dp_cls[8], *dp_n[6];          // [C][n'][h] / [n'][h] scratch of the deep synthetic match
   float *dr_out;                       // [C][max(d, h)][h] a weight's per-class gradients, contiguous (copied into gw_real's rows of stride P)
   float *dr_a, *dr_b, *dr_c;           // [C][cap0][h] per-source backward rows of the deep real side (sum of in-edges, masked, through W^T)
   float *ones0;                        // [C][cap0] unit weights of the per-source edge products
@@ -249,8 +255,9 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
   e->gcn = (c.condense_model == 1);
   e->pge_chunks = c.pge_chunks > 1 ? c.pge_chunks : 1;
   if (e->gcn) e->T = 2;                       // GCN: two GraphConvolution layers, same parameter layout as SGC T = 2
-  e->deep = 0;
+  e->deep = 0; e->gdeep = 0;
   if (!e->gcn && c.ntrans > 2) { e->deep = c.ntrans - 2; e->T = 2; }
+  if (e->gcn && e->K > 2) e->gdeep = e->K - 2;
   e->F = (e->T == 1) ? c.d : c.hidden;
   e->Fp = (e->F + 3) & ~3;
   gs_pdesc& pd = e->pd;
@@ -268,7 +275,7 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
     int q = 2;
     pd.rows[0] = e->d; pd.cols[0] = e->h; pd.off[0] = 0; pd.is_bias[0] = 0;
     pd.rows[1] = e->h; pd.cols[1] = 1; pd.off[1] = e->ob1; pd.is_bias[1] = 1;
-    for (int k = 0; k < e->deep; ++k) {      // hidden-to-hidden transforms (nn.Module.parameters() order: layer by layer, weight then bias)
+    for (int k = 0; k < e->deep + e->gdeep; ++k) {      // hidden-to-hidden transforms / GraphConvolution layers (nn.Module.parameters() order: layer by layer, weight then bias)
       e->oWm[k] = o; e->obm[k] = o + (long)e->h * e->h;
       pd.rows[q] = e->h; pd.cols[q] = e->h; pd.off[q] = e->oWm[k]; pd.is_bias[q] = 0; ++q;
       pd.rows[q] = e->h; pd.cols[q] = 1; pd.off[q] = e->obm[k]; pd.is_bias[q] = 1; ++q;
@@ -469,9 +476,27 @@ static size_t carve(gs_gcond* e, void* base) {
     e->Hmid_s[k] = k < e->deep ? w.take<float>(n * h) : nullptr;
   }
   e->WmT = e->deep ? w.take<float>(h * h) : nullptr;
-  for (int k = 0; k < 6; ++k) {
-    e->dp_cls[k] = e->deep ? w.take<float>(C * n * h) : nullptr;
-    e->dp_n[k] = e->deep ? w.take<float>(n * h) : nullptr;
+  const bool anyd = e->deep || e->gdeep;
+  for (int k = 0; k < 2; ++k)
+    if (k < e->gdeep) e->Hmid_s[k] = w.take<float>(n * h);
+  for (int k = 0; k < 8; ++k) e->dp_cls[k] = (e->deep && k < 6) || e->gdeep ? w.take<float>(C * n * h) : nullptr;
+  for (int k = 0; k < 6; ++k) e->dp_n[k] = anyd ? w.take<float>(n * h) : nullptr;
+  for (int k = 0; k < 3; ++k) e->gk_sbuf[k] = k < e->gdeep + 1 && e->gdeep ? w.take<float>(n * h) : nullptr;
+  e->gk_slabA = e->gdeep ? w.take<float>(C * n2) : nullptr;
+  e->gr_P1 = e->gdeep ? w.take<float>(C * capL * d) : nullptr;
+  for (int k = 0; k < 4; ++k) e->gr_H[k] = nullptr;
+  if (e->gdeep) {
+    // layer k's output rows: the frontier it lands on (k = 1: the last middle frontier, capL rows; .. ; k = L - 1: hop 1's, cap1 rows)
+    const int L = 2 + e->gdeep;
+    for (int k = 1; k < L; ++k) {
+      const int f = L - k;
+      const long rows = f == 1 ? cap1 : e->capm[f - 2];
+      e->gr_H[k] = w.take<float>(C * rows * h);
+    }
+    e->gr_T = w.take<float>(C * capL * h); e->gr_dT = w.take<float>(C * capL * h);
+    e->gr_dHa = w.take<float>(C * capL * h); e->gr_dHb = w.take<float>(C * capL * h);
+  } else {
+    e->gr_T = e->gr_dT = e->gr_dHa = e->gr_dHb = nullptr;
   }
   e->dr_out = e->deep ? w.take<float>(C * dh * h) : nullptr;
   e->dr_a = e->deep ? w.take<float>(C * (long)e->cap0 * h) : nullptr;
@@ -539,7 +564,8 @@ static int check_cfg(const gs_gcond_config* c) {
     // models/sgc.py:45-51 propagates nlayers times, dataset/loader.py:205-210 samples as many hops; nlayers = 1 has no reference run
     // (PyG's sampler hands train_class the single hop's Adj tuple instead of a list: gcond_base.py:213 fails on it)
     if (c->nlayers < 3 || c->nlayers > 2 + GS_MAX_MID) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nlayers must be 2 .. %d", 2 + GS_MAX_MID);
-    if (c->condense_model != 0) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nlayers != 2 is built for condense_model SGC");
+    if (c->condense_model != 0 && (c->nlayers > 4 || c->with_bn || c->dropout > 0.f))
+      GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: a GCN condensation model takes nlayers 2 .. 4, without BatchNorm / dropout");
     for (int m = 0; m < c->nlayers - 2; ++m)
       if (c->fmid[m] < 1 || c->fmid[m] > 16) GS_FAIL(GS_ERR_ARG, "gs_gcond: middle fan-outs in [1, 16]");
   }
@@ -1212,6 +1238,8 @@ static int deep_real_backward(gs_gcond* e, const gs_blocks& b, const float* YL, 
   return GS_OK;
 }
 
+static int gcnk_real_grads(gs_gcond* e, const gs_blocks& b, int Cl, long c0, gs_stream_t stream);      // gs_gcnk.inc
+
 extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   if (!e->have_blocks) GS_FAIL(GS_ERR_STATE, "gs_gcond: no sampled blocks yet");
@@ -1223,7 +1251,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   // nlayers >= 3: the outermost block has one row per node of the LAST middle frontier (capL rows per class, nL[c] live)
   const int nmid = b.nmid, capL = e->capL;
   const int* nL = nmid ? b.nm[nmid - 1] : b.n1;
-  if (nmid && (e->S_full || e->gcn)) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nlayers != 2 with the full-neighbour mode or the GCN condense model");
+  if (nmid && (e->S_full || (e->gcn && !e->gdeep))) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nlayers != 2 with the full-neighbour mode");
+  if (e->gcn && e->gdeep) return gcnk_real_grads(e, b, Cl, c0, stream);
   // class-major scratch of this rank's classes
   const long Fp = e->Fp;
   float* P0 = e->P0 + c0 * capL * Fp; float* rs0 = e->rs0 + c0 * capL;
@@ -1955,11 +1984,13 @@ static int match_distance_folded(gs_gcond* e, const float* gwr, const float* gws
 // Writes this rank's PARTIAL [d_feat | d_adj | loss_c] ("ar_syn"); gs_gcond_stage_syn_finish books the loss.
 // ================================================================================================
 #include "gs_deep.inc"
+#include "gs_gcnk.inc"
 
 extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   GS_TRY(quiesce_hoist(e));
   if (e->deep) return deep_syn_match(e, stream);
+  if (e->gcn && e->gdeep) return gcnk_syn_match(e, stream);
   hipStream_t s = (hipStream_t)stream;
   const int C = e->C, Cl = e->c_hi - e->c_lo, n = e->n, d = e->d, h = e->h, F = e->F, mx = e->max_nc;
   const long P = e->P, c0 = e->c_lo;
@@ -2692,6 +2723,7 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
   const int C = e->C, n = e->n, d = e->d, h = e->h, F = e->F;
   if (e->cfg.inner_loop == 0) return GS_OK;
   if (e->deep) return deep_inner_steps(e, stream);
+  if (e->gcn && e->gdeep) return gcnk_inner_steps(e, stream);
   if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && !e->gcn && !e->with_bn && !e->blk_pos && C <= 64) return inner_steps_fused(e, stream);
   const float* X = e->io.feat_syn;
   float* th_true = e->io.model_params;                 // Adam steps these ...

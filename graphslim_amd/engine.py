@@ -376,7 +376,8 @@ class GCondEngine:
         self.labels_syn = i32(labels_syn)
         self.syn_lo = i32([r[0] for r in syn_ranges])
         self.syn_hi = i32([r[1] for r in syn_ranges])
-        self.P = model_param_count(d, s.hidden, s.nclass, 2 if s.model == "GCN" else s.ntrans) + (2 * s.hidden if s.with_bn else 0)
+        # (GCN: one GraphConvolution per sampled hop, models/gcn.py:8-23 — `nlayers` layers in the SGC layout)
+        self.P = model_param_count(d, s.hidden, s.nclass, max(2, s.nlayers) if s.model == "GCN" else s.ntrans) + (2 * s.hidden if s.with_bn else 0)
         self.Ppge = pge_param_count(d, s.pge_hidden)
         self.feat_syn = torch.zeros(s.n_syn, d, dtype=torch.float32, device=dev)
         self.pge_params = torch.zeros(self.Ppge, dtype=torch.float32, device=dev)
@@ -433,7 +434,7 @@ class GCondEngine:
         if s.ntrans == 1 and s.model == "SGC":
             shp = [(d, s.nclass), (s.nclass,)]
         else:
-            mid = [(s.hidden, s.hidden), (s.hidden,)] * (s.ntrans - 2 if s.model == "SGC" else 0)
+            mid = [(s.hidden, s.hidden), (s.hidden,)] * (s.ntrans - 2 if s.model == "SGC" else max(2, s.nlayers) - 2)
             shp = [(d, s.hidden), (s.hidden,)] + mid + [(s.hidden, s.nclass), (s.nclass,)]
         if s.with_bn:
             shp += [(s.hidden,), (s.hidden,)]          # bns.0.weight, bns.0.bias

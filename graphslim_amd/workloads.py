@@ -8,6 +8,8 @@ WORKLOADS = {
     # name: (dataset shape, rate, ntrans, hidden, pge_hidden, outer_loop, inner_loop, lr_feat, lr_adj, fan-outs)
     "ogbn-arxiv": ("ogbn-arxiv", 0.005, 2, 256, 256, 20, 3, 0.01, 0.01, (10, 5)),
     "cora": ("cora", 0.5, 1, 256, 128, 20, 15, 1e-4, 1e-4, (10, 5)),
+    # the ogbn-arxiv configuration at r = 1 % (n' = 909: 4x the PGE's pair rows): where, if anywhere, sharding pays
+    "ogbn-arxiv-r0.01": ("ogbn-arxiv", 0.01, 2, 256, 256, 20, 3, 0.01, 0.01, (10, 5)),
     # BASELINE.json configs[4]: inductive, train sub-graph, wide rows (d = 602) and fan-outs [15, 8]: the gather stress case
     "reddit": ("reddit", 0.001, 1, 256, 256, 10, 1, 0.1, 0.1, (15, 8)),
     # the other BASELINE.json configs (parity-test cases at FULL size, tests/test_gpu_fullsize.py; not bench lines)
@@ -33,6 +35,9 @@ WORKLOADS = {
     # hyper-parameters: parity-test cases (tests/test_gpu_fullsize.py), not bench lines
     "arxiv-t3": ("ogbn-arxiv", 0.005, 3, 256, 256, 20, 3, 0.01, 0.01, (10, 5)),
     "arxiv-t4": ("ogbn-arxiv", 0.005, 4, 256, 256, 20, 3, 0.01, 0.01, (10, 5)),
+    # `--condense_model GCN --nlayers 3` (models/gcn.py:8-23: one GraphConvolution per sampled hop) with the ogbn-arxiv hyper-parameters:
+    # a parity-test case (the third field is the model's depth)
+    "arxiv-gcn3": ("ogbn-arxiv", 0.005, 3, 256, 256, 20, 3, 0.01, 0.01, (15, 10, 5)),
     "cora-r0.25-k3": ("cora", 0.25, 1, 256, 128, 20, 15, 1e-4, 1e-4, (15, 10, 5)),      # the quiet job of the job-level gate with three hops
 }
 
@@ -55,14 +60,17 @@ def build_problem(name, seed=1, scale=1.0, sep=1.0):
         data.bench_feat, data.bench_labels, data.bench_n = data.feat_full, data.labels_full, data.num_nodes
     pools = data.class_pools(setting)
     return dict(data=data, labels_syn=labels_syn, ncd=ncd, ranges=[tuple(ranges[c]) for c in range(data.nclass)], csr=csr,
-                pools=pools, T=T, hidden=hidden, ph=ph, outer=outer, inner=inner, lrf=lrf, lra=lra, fan=fan, rate=rate, name=name)
+                pools=pools, T=T, hidden=hidden, ph=ph, outer=outer, inner=inner, lrf=lrf, lra=lra, fan=fan, rate=rate, name=name,
+                model="GCN" if "-gcn" in name else "SGC")
 
 
 def make_engine(p, device, bcap=256):
     from graphslim_amd.engine import EngineShapes, GCondEngine
     d = p["data"].feat_full.shape[1]
-    sh = EngineShapes(p["data"].bench_n, d, p["data"].nclass, len(p["labels_syn"]), p["T"], p["hidden"], p["ph"], bcap,
-                      p["fan"][0], p["fan"][-1], fmid=tuple(p["fan"][1:-1]), dropout=float(p.get("dropout", 0.0)))
+    gcn = p.get("model", "SGC") == "GCN"
+    sh = EngineShapes(p["data"].bench_n, d, p["data"].nclass, len(p["labels_syn"]), 2 if gcn else p["T"], p["hidden"], p["ph"], bcap,
+                      p["fan"][0], p["fan"][-1], fmid=tuple(p["fan"][1:-1]), dropout=float(p.get("dropout", 0.0)),
+                      model=p.get("model", "SGC"))
     cls_ptr = np.concatenate([[0], np.cumsum([len(q) for q in p["pools"]])])
     eng = GCondEngine(sh, p["data"].bench_feat, p["csr"], cls_ptr, np.concatenate(p["pools"]), p["labels_syn"], p["ranges"],
                       lr_feat=p["lrf"], lr_adj=p["lra"], lr_model=0.01, inner_loop=p["inner"], seed=1, device=device)

@@ -320,7 +320,8 @@ typedef struct gs_gcond_config {
   float lr_feat, lr_adj, lr_model;
   uint64_t seed;
   int external_blocks;     /* 1: blocks are supplied with gs_gcond_set_blocks (parity mode)    */
-  int condense_model;      /* 0 = SGC (models/sgc.py), 1 = 2-layer GCN (models/gcn.py): parameters laid out like SGC T = 2 */
+  int condense_model;      /* 0 = SGC (models/sgc.py), 1 = GCN (models/gcn.py:8-23) with `nlayers` = 2 .. 4 GraphConvolution layers, one per
+                              sampled hop: parameters laid out like SGC with as many transforms ([W1 b1 | W2 b2 | .. | W_L b_L]) */
   int pge_chunks;          /* <= 1: one BatchNorm batch over all n'^2 pairs; 5: the chunked PGE of reddit r >= 0.01
                               (parametrized_adj.py:41-55: np.array_split chunks, per-chunk batch statistics); not with row sharding */
   int with_bn;             /* 1: SGC (ntrans = 2) with a BatchNorm1d between its transforms (models/sgc.py:27-33), which GCond

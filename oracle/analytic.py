@@ -351,6 +351,123 @@ def sgc_dense_grad_deep(theta, Xs, A, labels, K=2):
 
 
 # ------------------------------------------------------------------------------------------------
+# K-layer GCN as condensation model (models/gcn.py:8-23, models/base.py:51-78): layer k computes x <- adj_k (x W_k) + b_k, ReLU between
+# the layers; on a sampled batch layer k uses block k (outermost first), on the synthetic graph every layer uses the dense A^.
+# theta = [W_1, b_1, ..., W_L, b_L] (L = nlayers).  What csrc/gs_engine.hip's GCN path computes for L >= 2 (gs_gcnk.inc).
+#   forward   a_0 = X, s_k = A a_{k-1}, p_k = s_k W_k + b_k, a_k = relu(p_k) = m_k * p_k (k < L), Z = p_L
+#   backward  delta_L = G, gW_k = s_k^T delta_k, u_k = delta_k W_k^T, abar_{k-1} = A^T u_k, delta_{k-1} = abar_{k-1} * m_{k-1}
+# ------------------------------------------------------------------------------------------------
+
+
+def real_class_grad_gcn_deep(theta, X, batch, cls):
+    """batch = (B, n_id, [block_1 (outermost) .. block_L (seeds <- frontier)]) dense blocks; layer k uses block k."""
+    B, n_id, blocks = batch
+    L = len(theta) // 2
+    assert len(blocks) == L
+    a, s, m = [X[n_id]], [None], [None]
+    for k in range(1, L + 1):
+        s.append(blocks[k - 1] @ a[-1])                  # (A_k a_{k-1}) W_k = A_k (a_{k-1} W_k)
+        pk = s[-1] @ theta[2 * (k - 1)] + theta[2 * (k - 1) + 1]
+        if k < L:
+            m.append((pk > 0).to(X.dtype))
+            a.append(pk * m[-1])
+    G = torch.softmax(pk, 1)
+    G[:, cls] -= 1
+    G /= B
+    gw = [None] * (2 * L)
+    delta = G
+    for k in range(L, 0, -1):
+        gw[2 * (k - 1)], gw[2 * (k - 1) + 1] = s[k].T @ delta, delta.sum(0)
+        if k > 1:
+            delta = (blocks[k - 1].T @ (delta @ theta[2 * (k - 1)].T)) * m[k - 1]
+    return gw
+
+
+def syn_match_gcn_deep(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="ours"):
+    """Returns (loss, dX, dA) for the L-layer GCN condense model on the dense normalised A (L = 2: syn_match_gcn)."""
+    n = Xs.shape[0]
+    L = len(theta) // 2
+    W = [None] + [theta[2 * k] for k in range(L)]
+    b = [None] + [theta[2 * k + 1] for k in range(L)]
+    a, s, m = [Xs], [None], [None]
+    for k in range(1, L + 1):
+        s.append(A @ a[-1])
+        pk = s[-1] @ W[k] + b[k]
+        if k < L:
+            m.append((pk > 0).to(Xs.dtype))
+            a.append(pk * m[-1])
+    P = torch.softmax(pk, 1)
+    loss = torch.zeros((), dtype=Xs.dtype)
+    dA = torch.zeros_like(A)
+    V = torch.zeros_like(P)
+    shat = [None] + [torch.zeros_like(s[k]) for k in range(1, L + 1)]        # adjoints of s_k from the gW_k = s_k^T delta_k terms
+    for c, (lo, hi) in enumerate(class_ranges):
+        nc = hi - lo
+        if nc == 0:
+            continue
+        G = torch.zeros_like(P)
+        G[lo:hi] = P[lo:hi]
+        G[lo:hi, c] -= 1
+        G[lo:hi] /= nc
+        delta, u = [None] * (L + 1), [None] * (L + 1)
+        delta[L] = G
+        gw = [None] * (2 * L)
+        for k in range(L, 0, -1):
+            gw[2 * (k - 1)], gw[2 * (k - 1) + 1] = s[k].T @ delta[k], delta[k].sum(0)
+            if k > 1:
+                u[k] = delta[k] @ W[k].T
+                delta[k - 1] = (A.T @ u[k]) * m[k - 1]
+        l, D = match_and_D(metric, gw_real[c], gw)
+        loss = loss + coeffs[c] * l
+        D = [coeffs[c] * t for t in D]
+        Dw = [None] + [D[2 * k] for k in range(L)]
+        Db = [None] + [D[2 * k + 1] for k in range(L)]
+        uhat = None
+        for k in range(1, L + 1):                          # the adjoint of the backward pass, in the reverse of its order
+            dhat = s[k] @ Dw[k] + Db[k]
+            if uhat is not None:
+                dhat = dhat + uhat @ W[k]
+            shat[k] = shat[k] + delta[k] @ Dw[k].T
+            if k < L:
+                q = dhat * m[k]                            # adjoint of abar_k
+                uhat = A @ q                               # adjoint of u_{k+1}
+                dA = dA + u[k + 1] @ q.T
+        Pc, U = P[lo:hi], dhat[lo:hi]                      # G depends on Z through class c's rows only
+        V[lo:hi] = (Pc * U - Pc * (Pc * U).sum(1, keepdim=True)) / nc
+    # the forward's adjoint
+    sbar = shat[L] + V @ W[L].T
+    for k in range(L, 0, -1):
+        dA = dA + sbar @ a[k - 1].T
+        abar = A.T @ sbar
+        if k > 1:
+            sbar = shat[k - 1] + (abar * m[k - 1]) @ W[k - 1].T
+    return loss, abar, dA
+
+
+def gcn_dense_grad_deep(theta, Xs, A, labels):
+    """The inner steps' gradient (NLL over all n' rows) of the L-layer GCN on the dense A."""
+    n = Xs.shape[0]
+    L = len(theta) // 2
+    a, s, m = [Xs], [None], [None]
+    for k in range(1, L + 1):
+        s.append(A @ a[-1])
+        pk = s[-1] @ theta[2 * (k - 1)] + theta[2 * (k - 1) + 1]
+        if k < L:
+            m.append((pk > 0).to(Xs.dtype))
+            a.append(pk * m[-1])
+    G = torch.softmax(pk, 1)
+    G[torch.arange(n), labels] -= 1
+    G /= n
+    gw = [None] * (2 * L)
+    delta = G
+    for k in range(L, 0, -1):
+        gw[2 * (k - 1)], gw[2 * (k - 1) + 1] = s[k].T @ delta, delta.sum(0)
+        if k > 1:
+            delta = (A.T @ (delta @ theta[2 * (k - 1)].T)) * m[k - 1]
+    return gw
+
+
+# ------------------------------------------------------------------------------------------------
 # dense GCN normalisation, forward and backward  (utils.py:429-439)
 # ------------------------------------------------------------------------------------------------
 

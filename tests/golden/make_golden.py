@@ -473,6 +473,16 @@ def g27():
     save("g27_train_class_deep", **out)
 
 
+def g28():
+    """K-layer GCN as condensation model (VERDICT r05 "missing" 3; models/gcn.py:8-23: one GraphConvolution per layer, `nlayers` of
+    them; models/base.py:51-78: layer i takes block i of the sampled list): train_class + backward of the reference for three and four
+    layers / sampled hops."""
+    out = {}
+    run_train_class("gcn3", 80, 4, 6, 12, 1, 0.4, "ogbn-arxiv", out, kind="GCN", sizes=(4, 3, 2), nlayers=3)
+    run_train_class("gcn4", 80, 4, 6, 12, 1, 0.4, "ogbn-arxiv", out, kind="GCN", sizes=(3, 2, 2, 2), nlayers=4)
+    save("g28_train_class_gcn_layers", **out)
+
+
 # ---------------------------------------------------------------- G8-G10 full reduce + eval ----
 
 
@@ -1201,6 +1211,6 @@ def g22():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16",
-                             "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26", "g27"]
+                             "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26", "g27", "g28"]
     for w in which:
         globals()[w]()

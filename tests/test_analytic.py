@@ -124,6 +124,46 @@ def test_deep_closed_forms(T, metric, K, sizes):
         np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("L,sizes", [(2, (3, 2)), (3, (3, 2, 2)), (4, (2, 2, 2, 2))])
+@pytest.mark.parametrize("metric", ["ours", "mse", "cos"])
+def test_gcn_deep_closed_forms(L, sizes, metric):
+    """K-layer GCN as condensation model (models/gcn.py:8-23, models/base.py:51-78): the closed forms as loops over the layers
+    (oracle/analytic.py *_gcn_deep; at L = 2 they must reproduce the two-layer forms) against autograd through the oracle, fp64."""
+    p = tiny_problem(1, seed=9, sizes=sizes)
+    d, hidden = p["x"].shape[1], 9
+    torch.manual_seed(4)
+    th0 = [t.to(DT) for t in O.init_gcn(d, hidden, p["nclass"], L)]
+    gw_real = []
+    for c in range(p["nclass"]):
+        theta = [t.clone().requires_grad_(True) for t in th0]
+        ref, _ = O.class_real_grads("GCN", theta, p["x"], p["y"], p["batches"][c], L)
+        got = A.real_class_grad_gcn_deep(th0, p["x"], dense_batch(p["batches"][c]), c)
+        for r, g in zip(ref, got):
+            np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
+        gw_real.append(got)
+    theta = [t.clone().requires_grad_(True) for t in th0]
+    xs = p["xs"].clone().requires_grad_(True)
+    an = O.dense_gcn_norm(O.pge_forward(xs.detach(), p["pge"])).clone().requires_grad_(True)
+    loss = O.train_class("GCN", theta, p["batches"], p["x"], p["y"], xs, an, p["labels_syn"], p["ncd"], p["nclass"], L, metric)
+    gx, ga = torch.autograd.grad(loss, [xs, an])
+    ns = len(p["labels_syn"])
+    ranges = [tuple(p["ranges"][c]) for c in range(p["nclass"])]
+    coeffs = [p["ncd"][c] / ns for c in range(p["nclass"])]
+    l, dX, dA = A.syn_match_gcn_deep(th0, p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric)
+    np.testing.assert_allclose(float(l), float(loss.detach()), rtol=1e-10)
+    np.testing.assert_allclose(dX.numpy(), gx.numpy(), rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(dA.numpy(), ga.numpy(), rtol=1e-7, atol=1e-11)
+    if L == 2:
+        l2, dX2, dA2 = A.syn_match_gcn(th0, p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric)
+        np.testing.assert_allclose(dX.numpy(), dX2.numpy(), rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(dA.numpy(), dA2.numpy(), rtol=1e-10, atol=1e-13)
+    theta = [t.clone().requires_grad_(True) for t in th0]
+    out = O.gcn_forward(p["xs"], an.detach(), theta)
+    ref = torch.autograd.grad(F.nll_loss(out, p["labels_syn"]), theta)
+    for r, g in zip(ref, A.gcn_dense_grad_deep(th0, p["xs"], an.detach(), p["labels_syn"])):
+        np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("metric,K", [("ours", 2), ("mse", 2), ("cos", 3)])
 def test_dropout_closed_forms(metric, K):
     """Dropout in the condensation model (models/sgc.py:42): the closed forms with one multiplier per class forward — real batch and

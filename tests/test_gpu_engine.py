@@ -44,14 +44,16 @@ def make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, x, f1, f2, bcap
 
 
 @pytest.mark.parametrize("tag,metric", [("t1", "ours"), ("t2", "ours"), ("t1mse", "mse"), ("gcn", "ours"), ("k3t1", "ours"), ("k3t2", "ours"),
-                                        ("t3", "ours"), ("t4", "ours")])
+                                        ("t3", "ours"), ("t4", "ours"), ("gcn3", "ours"), ("gcn4", "ours")])
 def test_train_class_against_reference_golden(golden_dir, tag, metric):
     """G7: loss, d loss/d A^, d loss/d X~, d loss/d theta_PGE of the reference's train_class + backward.  G24 (tags k3*, round 5): the
     same with `--nlayers 3` — three sampled hops (a MIDDLE block with its CSC between hop 1 and the outermost block) on the real side,
     Q = A^^3 with the product rule for d A^ on the synthetic side (dataset/loader.py:205-206, models/sgc.py:45-51).  G27 (tags t3, t4,
     round 6): `--ntrans` 3 / 4 — the layers walked by csrc/gs_deep.inc (models/sgc.py:32-35)."""
     from graphslim_amd.engine import BlockSet
-    g = load_golden(golden_dir, "g24_train_class_three_hops" if tag.startswith("k3") else ("g27_train_class_deep" if tag in ("t3", "t4") else "g7_train_class"))
+    fname = {"k3t1": "g24_train_class_three_hops", "k3t2": "g24_train_class_three_hops", "t3": "g27_train_class_deep", "t4": "g27_train_class_deep",
+             "gcn3": "g28_train_class_gcn_layers", "gcn4": "g28_train_class_gcn_layers"}.get(tag, "g7_train_class")      # (G28, round 6: K-layer GCN)
+    g = load_golden(golden_dir, fname)
     batches, (n, nclass, d, hidden, t), _ = rebuild_batches(g, tag)
     labels_syn = g[f"{tag}_labels_syn"]
     _, ncd, ranges = O.generate_labels_syn(g[f"{tag}_y"][g[f"{tag}_idx_train"]], float(g[f"{tag}_rate"]))
@@ -59,13 +61,13 @@ def test_train_class_against_reference_golden(golden_dir, tag, metric):
     ph = g[f"{tag}_pge2"].shape[0]
     sizes = [int(s) for s in g[f"{tag}_sizes"]]
     f1, f2, fmid = sizes[0], sizes[-1], tuple(sizes[1:-1])
-    kind = "GCN" if tag == "gcn" else "SGC"
+    kind = "GCN" if tag.startswith("gcn") else "SGC"
     if kind == "GCN":
         t = 2
     eng = make_engine(n, nclass, d, hidden, t, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, metric=metric, model=kind, fmid=fmid)
     eng.set_feat(T(g[f"{tag}_feat_syn"]))
     eng.set_pge([T(g[f"{tag}_pge{i}"]) for i in range(10)])
-    theta = [T(g[f"{tag}_theta{i}"]) for i in range(2 * t)]
+    theta = [T(g[f"{tag}_theta{i}"]) for i in range(2 * (len(sizes) if kind == "GCN" else t))]
     eng.set_model(theta)
     eng.set_blocks(BlockSet.from_batches(batches, 32, f1, f2, DEV, fmid=fmid))
     # real side
@@ -1579,28 +1581,44 @@ def test_retrieve_class_sampler_contract():
         assert int((d1 != 0).sum(1).max()) <= 10 and int((d0 != 0).sum(1).max()) <= 5
 
 
-@pytest.mark.parametrize("metric", ["ours", "mse"])
-def test_gcn_condense_model_follows_the_oracle(metric):
-    """condense_model = GCN (models/gcn.py, layers.py:36-51): three outer iterations per optimiser against the oracle."""
+@pytest.mark.parametrize("metric,L", [("ours", 2), ("mse", 2), ("ours", 3), ("mse", 3), ("cos", 3), ("ours", 4)])
+def test_gcn_condense_model_follows_the_oracle(metric, L):
+    """condense_model = GCN (models/gcn.py:8-23, layers.py:36-51, models/base.py:51-78): three outer iterations per optimiser against
+    the oracle.  L = `nlayers` GraphConvolution layers, one per sampled hop (round 6, csrc/gs_gcnk.inc: L = 3 / 4 — a middle block per
+    extra hop on the real side, the dense A^ inside every layer on the synthetic side; golden G28 pins the oracle for them)."""
     from graphslim_amd.engine import BlockSet
     p = _problem(2, seed=51)
     torch.manual_seed(5)
-    theta = O.init_gcn(p["d"], p["hidden"], p["nclass"], 2)
+    theta = O.init_gcn(p["d"], p["hidden"], p["nclass"], L)
+    sizes = {2: [p["f1"], p["f2"]], 3: [p["f1"], 3, p["f2"]], 4: [p["f1"], 3, 2, p["f2"]]}[L]
+    fmid = tuple(sizes[1:-1])
     eng = make_engine(p["n"], p["nclass"], p["d"], p["hidden"], 2, p["ph"], p["labels_syn"], p["ranges"], p["x"], p["f1"],
-                      p["f2"], bcap=p["bcap"], metric=metric, inner=2, lrs=(0.01, 0.005, 0.02), model="GCN")
-    st = O.GCondState(p["xs"], p["pge"], T(p["labels_syn"]), p["ncd"], p["nclass"], 0.01, 0.005, 0.02, "GCN", 2)
+                      p["f2"], bcap=p["bcap"], metric=metric, inner=2, lrs=(0.01, 0.005, 0.02), model="GCN", fmid=fmid)
+    st = O.GCondState(p["xs"], p["pge"], T(p["labels_syn"]), p["ncd"], p["nclass"], 0.01, 0.005, 0.02, "GCN", L)
     eng.set_feat(p["xs"])
     eng.set_pge(p["pge"]["lin"] + p["pge"]["bn"])
     X, Y = T(p["x"]), T(p["y"])
+    assert len(eng.get_model()) == 2 * L
     step = 0
     for epoch in (0, 10):
         st.new_epoch(theta)
         eng.set_model(theta)
         for _ in range(3):
-            batches = _batches(p, step)
+            batches = []
+            for c in range(p["nclass"]):
+                rng = np.random.default_rng(7000 + 100 * step + c)
+                seeds = rng.permutation(p["pools"][c])[: p["bcap"]]
+                batches.append(O.sample_blocks(*p["csr"], seeds, sizes, rng))
             step += 1
             l_ref, gfeat, gpge, adj_inner = st.outer_iteration(epoch, batches, X, Y, 2, metric)
-            eng.set_blocks(BlockSet.from_batches(batches, p["bcap"], p["f1"], p["f2"], DEV))
+            eng.set_blocks(BlockSet.from_batches(batches, p["bcap"], p["f1"], p["f2"], DEV, fmid=fmid))
+            if step == 1:      # the real-side class gradients of the first iteration, parameter by parameter
+                eng.stage_real_grads()
+                gw = eng.buffer("gw_real", (p["nclass"], -1))
+                for c in range(p["nclass"]):
+                    th = [q.clone().requires_grad_(True) for q in theta]
+                    ref, _ = O.class_real_grads("GCN", th, X, Y, batches[c], L)
+                    close(gw[c], torch.cat([r.reshape(-1) for r in ref]), 2e-4, f"gw_real class {c}")
             eng.outer_step(epoch)
             loss = float(eng.buffer("loss")[0])
             assert abs(loss - float(l_ref)) <= 1e-4 * abs(float(l_ref)), (epoch, loss, float(l_ref))
@@ -1724,6 +1742,35 @@ def test_three_hops_reduce_api(tmp_path, ntrans):
     graph1 = get_dataset(args1.dataset, args1)
     with pytest.raises(NotImplementedError):
         GCond(setting=args1.setting, data=graph1, args=args1).reduce(graph1, verbose=False)
+
+
+@pytest.mark.parametrize("nlayers", [3, 4])
+def test_gcn_condense_model_with_more_layers_reduce_api(tmp_path, nlayers):
+    """`--condense_model GCN --nlayers 3 / 4` through the reference's own entry points (round 6; models/gcn.py:8-23: one
+    GraphConvolution per layer, models/base.py:51-78: layer i takes block i of the `nlayers` sampled hops): sanity of the whole path —
+    parity is G28 and test_gcn_condense_model_follows_the_oracle; five layers are refused."""
+    import graphslim  # noqa: F401
+    from graphslim.config import cli
+    from graphslim.condensation import GCond
+    from graphslim.dataset import get_dataset
+    from graphslim.evaluation.eval_agent import Evaluator
+    argv = ["-D", "cora", "-M", "gcond", "-R", "0.5", "-G", "0", "--epochs", "12", "--eval_epochs", "30", "--run_eval", "2",
+            "--condense_model", "GCN", "--hidden", "64", "--save_path", str(tmp_path)]
+    args = cli(argv + ["--nlayers", str(nlayers)], standalone_mode=False)
+    args.run_inter_eval, args.checkpoints, args.outer_loop, args.inner_loop = 1, [5, 11], 2, 2
+    graph = get_dataset(args.dataset, args)
+    __import__('graphslim_amd.host', fromlist=['seed_everything']).seed_everything(args.seed)
+    agent = GCond(setting=args.setting, data=graph, args=args)
+    reduced = agent.reduce(graph, verbose=False)
+    assert agent.engine.shapes.nlayers == nlayers and len(agent.engine.get_model()) == 2 * nlayers
+    assert agent.engine.get_model()[2].shape == (64, 64)
+    assert torch.isfinite(reduced.feat_syn).all() and torch.isfinite(reduced.adj_syn).all()
+    mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
+    assert 0.0 <= mean <= 1.0
+    if nlayers == 3:
+        bad = cli(argv + ["--nlayers", "5"], standalone_mode=False)
+        with pytest.raises(NotImplementedError):
+            GCond(setting=bad.setting, data=graph, args=bad).reduce(graph, verbose=False)
 
 
 def test_full_neighbour_mode_against_the_oracle_on_full_blocks():

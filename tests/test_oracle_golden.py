@@ -115,15 +115,18 @@ def rebuild_batches(g, tag):
 
 @pytest.mark.parametrize("tag,kind,metric", [("t1", "SGC", "ours"), ("t2", "SGC", "ours"), ("t1mse", "SGC", "mse"),
                                              ("gcn", "GCN", "ours"), ("k3t1", "SGC", "ours"), ("k3t2", "SGC", "ours"),
-                                             ("t3", "SGC", "ours"), ("t4", "SGC", "ours")])
+                                             ("t3", "SGC", "ours"), ("t4", "SGC", "ours"), ("gcn3", "GCN", "ours"), ("gcn4", "GCN", "ours")])
 def test_g7_g24_train_class(golden_dir, tag, kind, metric):
     """G7: the reference's train_class + backward (two hops); G24 (tags k3*): the same with `--nlayers 3` — three sampled hops on the
     real side, adj_syn applied three times on the synthetic side (dataset/loader.py:205-206, models/sgc.py:45-51); G27 (tags t3, t4):
-    `--ntrans` 3 / 4 — hidden-to-hidden transforms between the first and the last (models/sgc.py:32-35)."""
-    g = load(golden_dir, "g24_train_class_three_hops" if tag.startswith("k3") else ("g27_train_class_deep" if tag in ("t3", "t4") else "g7_train_class"))
+    `--ntrans` 3 / 4 — hidden-to-hidden transforms between the first and the last (models/sgc.py:32-35); G28 (tags gcn3, gcn4): the GCN
+    condensation model with three / four GraphConvolution layers, one per sampled hop (models/gcn.py:8-23, models/base.py:51-78)."""
+    fname = {"k3t1": "g24_train_class_three_hops", "k3t2": "g24_train_class_three_hops", "t3": "g27_train_class_deep", "t4": "g27_train_class_deep",
+             "gcn3": "g28_train_class_gcn_layers", "gcn4": "g28_train_class_gcn_layers"}.get(tag, "g7_train_class")
+    g = load(golden_dir, fname)
     nlayers = len(g[f"{tag}_sizes"])
     batches, (n, nclass, d, hidden, t) = rebuild_batches(g, tag)
-    nth = 4 if kind == "GCN" else 2 * t
+    nth = 2 * max(2, nlayers) if kind == "GCN" else 2 * t
     theta = [T(g[f"{tag}_theta{i}"]).requires_grad_(True) for i in range(nth)]
     ps = [T(g[f"{tag}_pge{i}"]).requires_grad_(True) for i in range(10)]
     pge = {"lin": ps[:6], "bn": ps[6:]}
