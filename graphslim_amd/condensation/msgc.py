@@ -101,8 +101,8 @@ class MSGC(GCondBase):
         args = self.args
         if args.condense_model != "SGC":
             raise NotImplementedError("graphslim_amd: MSGC is built for condense_model SGC (every configs/msgc/*.json)")
-        if args.nlayers != 2:
-            raise NotImplementedError("graphslim_amd: nlayers (propagations) must be 2")
+        if args.nlayers not in (2, 3, 4, 5):
+            raise NotImplementedError(f"graphslim_amd: nlayers must be 2 .. 5 (dataset/loader.py:197-210 knows no other), got {args.nlayers}")
         if getattr(args, "with_bn", False) or float(getattr(args, "dropout", 0.0) or 0.0) != 0.0:
             raise NotImplementedError("graphslim_amd: MSGC with with_bn / dropout in the condensation model is not built")
         if args.setting == "trans":
@@ -116,9 +116,11 @@ class MSGC(GCondBase):
         feat_init = self.init()                                                           # :82
         lay = BatchLayout(self.y_syn.numpy(), nclass, B)
         pools = data.class_pools(args.setting)
-        sizes = (15, 8) if args.dataset in ("reddit", "flickr") else (10, 5)              # loader.py:197-210
+        sizes = {2: (15, 8) if args.dataset in ("reddit", "flickr") else (10, 5), 3: (15, 10, 5), 4: (15, 10, 5, 5),
+                 5: (15, 10, 5, 5, 5)}[args.nlayers]                                           # loader.py:197-210
         # the engine's dense PGE is not used (pge_hidden = 4 keeps its buffers small); the structure comes from the generator
-        shapes = EngineShapes(features.shape[0], d, nclass, lay.n_big, args.ntrans, args.hidden, 4, 256, sizes[0], sizes[1])
+        shapes = EngineShapes(features.shape[0], d, nclass, lay.n_big, args.ntrans, args.hidden, 4, 256, sizes[0], sizes[-1],
+                              fmid=tuple(sizes[1:-1]))
         cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
         eng = self.engine = GCondEngine(shapes, features, csr, cls_ptr, np.concatenate(pools), lay.labels_big, lay.ranges,
                                         lr_feat=args.lr_feat, lr_adj=args.lr_adj, lr_model=args.lr, inner_loop=args.inner_loop,

@@ -99,8 +99,10 @@ class SGDD(GCondBase):
         args = self.args
         if args.condense_model != "SGC":
             raise NotImplementedError("graphslim_amd: SGDD is built for condense_model SGC (every configs/sgdd/*.json)")
-        if args.nlayers != 2:
-            raise NotImplementedError("graphslim_amd: nlayers (propagations) must be 2")
+        if args.nlayers not in (2, 3, 4, 5):
+            # (`--nlayers` K: K sampled hops, K propagations on both sides — models/sgc.py:45-51, dataset/loader.py:205-210; the engine's
+            # stages take the structure from the IGNR whatever K is: Q = A^^K with the product rule for d A^)
+            raise NotImplementedError(f"graphslim_amd: nlayers must be 2 .. 5 (dataset/loader.py:197-210 knows no other), got {args.nlayers}")
         if getattr(args, "with_bn", False) or float(getattr(args, "dropout", 0.0) or 0.0) != 0.0:
             raise NotImplementedError("graphslim_amd: SGDD with with_bn / dropout in the condensation model is not built")
         args.mx_size = self.mx                                                            # sgdd.py:33-36
@@ -113,10 +115,11 @@ class SGDD(GCondBase):
         csr = normalize_adj_sparse(adj)                                                   # :48
         nclass, d, n = data.nclass, self.d, self.nnodes_syn
         pools = data.class_pools(args.setting)
-        sizes = (15, 8) if args.dataset in ("reddit", "flickr") else (10, 5)              # loader.py:197-210
+        sizes = {2: (15, 8) if args.dataset in ("reddit", "flickr") else (10, 5), 3: (15, 10, 5), 4: (15, 10, 5, 5),
+                 5: (15, 10, 5, 5, 5)}[args.nlayers]                                           # loader.py:197-210
         ranges = [tuple(self.syn_class_indices.get(c, (0, 0))) for c in range(nclass)]
         # the engine's dense PGE is not used (pge_hidden = 4 keeps its buffers small); the structure comes from the IGNR
-        shapes = EngineShapes(features.shape[0], d, nclass, n, args.ntrans, args.hidden, 4, 256, sizes[0], sizes[1])
+        shapes = EngineShapes(features.shape[0], d, nclass, n, args.ntrans, args.hidden, 4, 256, sizes[0], sizes[-1], fmid=tuple(sizes[1:-1]))
         cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
         eng = self.engine = GCondEngine(shapes, features, csr, cls_ptr, np.concatenate(pools), np.asarray(data.labels_syn), ranges,
                                         lr_feat=args.lr_feat, lr_adj=args.lr_adj, lr_model=args.lr, inner_loop=args.inner_loop,

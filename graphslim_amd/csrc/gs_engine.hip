@@ -1986,11 +1986,21 @@ static int match_distance_folded(gs_gcond* e, const float* gwr, const float* gws
 #include "gs_deep.inc"
 #include "gs_gcnk.inc"
 
+// A block structure (MSGC's batch of disconnected graphs) with nlayers != 2: the per-block products are written for A^ A^ only; the
+// dense products are the same values on a block-diagonal A^ (B^2 times the work of the per-block form, on matrices of a few hundred
+// rows) — the stage runs as if no block structure were set.  Entries of d A^ outside the blocks meet structural zeros downstream.
+struct gs_blk_dense_guard {
+  gs_gcond* e; const int* keep;
+  explicit gs_blk_dense_guard(gs_gcond* e_) : e(e_), keep(e_->blk_pos) { if (e->K != 2) e->blk_pos = nullptr; }
+  ~gs_blk_dense_guard() { e->blk_pos = keep; }
+};
+
 extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   GS_TRY(quiesce_hoist(e));
   if (e->deep) return deep_syn_match(e, stream);
   if (e->gcn && e->gdeep) return gcnk_syn_match(e, stream);
+  gs_blk_dense_guard blk_guard(e);
   hipStream_t s = (hipStream_t)stream;
   const int C = e->C, Cl = e->c_hi - e->c_lo, n = e->n, d = e->d, h = e->h, F = e->F, mx = e->max_nc;
   const long P = e->P, c0 = e->c_lo;
@@ -2724,6 +2734,7 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
   if (e->cfg.inner_loop == 0) return GS_OK;
   if (e->deep) return deep_inner_steps(e, stream);
   if (e->gcn && e->gdeep) return gcnk_inner_steps(e, stream);
+  gs_blk_dense_guard blk_guard(e);
   if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && !e->gcn && !e->with_bn && !e->blk_pos && C <= 64) return inner_steps_fused(e, stream);
   const float* X = e->io.feat_syn;
   float* th_true = e->io.model_params;                 // Adam steps these ...

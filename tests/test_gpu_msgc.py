@@ -90,7 +90,7 @@ def test_tile_and_fold_are_adjoint_index_maps():
     assert torch.equal(b3[1, 2, 5], a[pos[1, 2], pos[1, 5]])
 
 
-def _golden_setup(g, tag, external_blocks=True):
+def _golden_setup(g, tag, external_blocks=True, sizes=(4, 3)):
     from graphslim_amd import host as H
     from graphslim_amd.condensation.msgc import MSGCLoop
     from graphslim_amd.engine import EngineShapes, GCondEngine
@@ -106,7 +106,7 @@ def _golden_setup(g, tag, external_blocks=True):
     rows, cols, batch = H.msgc_edges(y_syn, nclass, B)
     sel = H.random_init_indices(idx_train, labels_train, {c: int(k) for c, k in enumerate(n_each)})
     lay = BatchLayout(y_syn, nclass, B)
-    sh = EngineShapes(n, d, nclass, lay.n_big, t, hidden, 4, 32, 4, 3)
+    sh = EngineShapes(n, d, nclass, lay.n_big, t, hidden, 4, 32, sizes[0], sizes[-1], fmid=tuple(sizes[1:-1]))
     eng = GCondEngine(sh, torch.from_numpy(x), None, None, None, lay.labels_big, lay.ranges, lr_feat=0.01, lr_adj=0.01,
                       lr_model=0.01, inner_loop=inner, external_blocks=external_blocks, device=DEV)
     loop = MSGCLoop(eng, params, rows, cols, batch, lay, torch.from_numpy(x[sel]), 0.01, 0.01)
@@ -115,30 +115,33 @@ def _golden_setup(g, tag, external_blocks=True):
                 meta=(n, nclass, d, hidden, t, inner, epochs, outer, B))
 
 
-def _blocks(s, calls):
+def _blocks(s, calls, sizes=(4, 3)):
     from graphslim_amd.engine import BlockSet
     nclass = s["meta"][1]
     batches = []
     for c in range(nclass):
         rng = np.random.default_rng(100000 + calls + c)
-        batches.append(O.sample_blocks(*s["csr"], rng.permutation(s["idx_train"][s["labels_train"] == c])[:256], [4, 3], rng))
-    return batches, BlockSet.from_batches(batches, 32, 4, 3, DEV)
+        batches.append(O.sample_blocks(*s["csr"], rng.permutation(s["idx_train"][s["labels_train"] == c])[:256], list(sizes), rng))
+    return batches, BlockSet.from_batches(batches, 32, sizes[0], sizes[-1], DEV, fmid=tuple(sizes[1:-1]))
 
 
-@pytest.mark.parametrize("tag,epoch", [("t1", 0), ("t1", 10), ("t2", 0), ("t2", 10)])
-def test_one_outer_iteration_against_the_oracle(golden_dir, tag, epoch):
+@pytest.mark.parametrize("tag,epoch,sizes", [("t1", 0, (4, 3)), ("t1", 10, (4, 3)), ("t2", 0, (4, 3)), ("t2", 10, (4, 3)),
+                                             ("t1", 10, (4, 3, 2)), ("t2", 0, (4, 3, 2)), ("t2", 10, (3, 2, 2, 2))])
+def test_one_outer_iteration_against_the_oracle(golden_dir, tag, epoch, sizes):
     """msgc.py:95-118 once (a structure epoch and a feature epoch): matching loss, d loss / d X~, d loss / d theta of the edge MLP,
-    the updated tensors, the normalised [B, n', n'] batch of the inner steps and the model after them."""
+    the updated tensors, the normalised [B, n', n'] batch of the inner steps and the model after them.  Round 6: also with `--nlayers`
+    3 / 4 (K sampled hops, K propagations through the batch of structures — the dense products on the block-diagonal A^; the oracle's
+    K-hop train_class is pinned by golden G24, its MSGC loop by G18)."""
     from graphslim_amd import host as H
     g = load_golden(golden_dir, "g18_msgc")
-    s = _golden_setup(g, tag)
+    s = _golden_setup(g, tag, sizes=sizes)
     n, nclass, d, hidden, t, inner, epochs, outer, B = s["meta"]
     eng, loop = s["eng"], s["loop"]
     model = H.init_sgc_params(d, hidden, nclass, t)
     eng.set_model(model)
     st = M.MSGCState(torch.from_numpy(s["x"][s["sel"]]), s["params"], torch.from_numpy(s["y_syn"]), torch.from_numpy(s["n_each"]),
-                     nclass, *(torch.from_numpy(a) for a in (s["rows"], s["cols"], s["batch"])), B, 0.01, 0.01, 0.01, model)
-    batches, blocks = _blocks(s, 0)
+                     nclass, *(torch.from_numpy(a) for a in (s["rows"], s["cols"], s["batch"])), B, 0.01, 0.01, 0.01, model, nlayers=len(sizes))
+    batches, blocks = _blocks(s, 0, sizes)
     eng.set_blocks(blocks)
     loop.step(epoch)
     loss, g_x, g_p, adj_in = st.outer_iteration(epoch, batches, torch.from_numpy(s["x"]), torch.from_numpy(s["y"]).long(), inner)
@@ -218,7 +221,8 @@ def test_model_optimiser_state_survives_the_epoch_boundary(golden_dir):
     assert not torch.equal(outs[True], outs[False])
 
 
-def test_msgc_reduce_api(tmp_path):
+@pytest.mark.parametrize("nlayers", [2, 3])
+def test_msgc_reduce_api(tmp_path, nlayers):
     """`-M msgc` end to end through the reference's entry points (examples/train_all.py pattern): cli -> get_dataset ->
     MSGC(...).reduce -> Evaluator.evaluate on the [B, n', n'] batch, with the shipped configs/msgc/cora.json, batch_adj = 16
     from method_config (config.py:252-253) and the `averaging` initialiser that JSON names (given on the command line: the
@@ -230,7 +234,8 @@ def test_msgc_reduce_api(tmp_path):
     from graphslim.evaluation.eval_agent import Evaluator
     from graphslim_amd.host import seed_everything
     args = cli(["-D", "cora", "-M", "msgc", "-R", "0.25", "-G", "0", "--epochs", "20", "--outer_loop", "2", "--inner_loop", "2",
-                "--eval_epochs", "40", "--run_eval", "2", "--init", "averaging", "--save_path", str(tmp_path)], standalone_mode=False)
+                "--eval_epochs", "40", "--run_eval", "2", "--init", "averaging", "--nlayers", str(nlayers), "--save_path", str(tmp_path)],
+               standalone_mode=False)      # (round 6: `--nlayers 3` — three sampled hops, three propagations — is honoured like upstream)
     assert args.batch_adj == 16 and args.init == "averaging" and args.lr_feat == 1e-4
     args.run_inter_eval = 1
     graph = get_dataset(args.dataset, args)

@@ -98,7 +98,7 @@ def test_transport_regulariser_against_fp64_autograd(n, mx, seed):
     assert float(reg.acc) == pytest.approx(float(reg.value), rel=1e-6)
 
 
-def _golden_setup(g, tag):
+def _golden_setup(g, tag, sizes=(4, 3)):
     from graphslim_amd import host as H
     from graphslim_amd.condensation.sgdd import SGDDLoop
     from graphslim_amd.engine import EngineShapes, GCondEngine
@@ -112,7 +112,7 @@ def _golden_setup(g, tag):
     assert np.array_equal(labels_syn, g[f"{tag}_labels_syn"])
     params = H.init_ignr_params(d, len(labels_syn), mx)
     sel = H.random_init_indices(idx_train, labels_train, ncd)
-    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, 4, 32, 4, 3)
+    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, 4, 32, sizes[0], sizes[-1], fmid=tuple(sizes[1:-1]))
     eng = GCondEngine(sh, torch.from_numpy(x), None, None, None, labels_syn, [tuple(ranges[c]) for c in range(nclass)], lr_feat=0.01,
                       lr_adj=0.01, lr_model=0.01, inner_loop=inner, external_blocks=True, device=DEV)
     eng.set_feat(torch.from_numpy(x[sel]))
@@ -122,31 +122,34 @@ def _golden_setup(g, tag):
                 ncd=ncd, params=params, sel=sel, eng=eng, loop=loop, scale=scale, meta=(n, nclass, d, hidden, t, inner, epochs, outer, mx))
 
 
-def _blocks(s, calls):
+def _blocks(s, calls, sizes=(4, 3)):
     from graphslim_amd.engine import BlockSet
     nclass = s["meta"][1]
     batches = []
     for c in range(nclass):
         rng = np.random.default_rng(100000 + calls + c)
-        batches.append(O.sample_blocks(*s["csr"], rng.permutation(s["idx_train"][s["labels_train"] == c])[:256], [4, 3], rng))
-    return batches, BlockSet.from_batches(batches, 32, 4, 3, DEV)
+        batches.append(O.sample_blocks(*s["csr"], rng.permutation(s["idx_train"][s["labels_train"] == c])[:256], list(sizes), rng))
+    return batches, BlockSet.from_batches(batches, 32, sizes[0], sizes[-1], DEV, fmid=tuple(sizes[1:-1]))
 
 
-@pytest.mark.parametrize("tag,epoch", [("t1", 0), ("t1", 10), ("t2", 0), ("t2", 10)])
-def test_one_outer_iteration_against_the_oracle(golden_dir, tag, epoch):
+@pytest.mark.parametrize("tag,epoch,sizes", [("t1", 0, (4, 3)), ("t1", 10, (4, 3)), ("t2", 0, (4, 3)), ("t2", 10, (4, 3)),
+                                             ("t1", 0, (4, 3, 2)), ("t2", 10, (4, 3, 2)), ("t2", 0, (3, 2, 2, 2))])
+def test_one_outer_iteration_against_the_oracle(golden_dir, tag, epoch, sizes):
     """sgdd.py:64-95 once (a structure epoch and a feature epoch): matching loss, regulariser value, d total / d X~ and d total / d theta
-    of the IGNR incl. the transport plan, the inference structure, the model after the inner steps."""
+    of the IGNR incl. the transport plan, the inference structure, the model after the inner steps.  Round 6: also with `--nlayers` 3 / 4
+    (three / four sampled hops on the real side, Q = A^^K of the IGNR's structure on the synthetic side and in the inner steps: the
+    oracle's K-hop train_class is pinned by golden G24, its SGDD loop by G20)."""
     from graphslim_amd import host as H
     g = load_golden(golden_dir, "g20_sgdd")
-    s = _golden_setup(g, tag)
+    s = _golden_setup(g, tag, sizes)
     n, nclass, d, hidden, t, inner, epochs, outer, mx = s["meta"]
     eng, loop = s["eng"], s["loop"]
     model = H.init_sgc_params(d, hidden, nclass, t)
     eng.set_model(model)
     st = S.SGDDState(torch.from_numpy(s["x"][s["sel"]]), s["params"], torch.from_numpy(s["labels_syn"]), s["ncd"], nclass,
-                     torch.from_numpy(g[f"{tag}_Lx_inv"]), 0.01, 0.01, 0.01, 0.5, s["scale"])
+                     torch.from_numpy(g[f"{tag}_Lx_inv"]), 0.01, 0.01, 0.01, 0.5, s["scale"], nlayers=len(sizes))
     st.new_epoch(model)
-    batches, blocks = _blocks(s, 0)
+    batches, blocks = _blocks(s, 0, sizes)
     eng.set_blocks(blocks)
     loop.step(epoch)
     ml, reg, g_x, g_p, adj_in = st.outer_iteration(epoch, batches, torch.from_numpy(s["x"]), torch.from_numpy(s["y"]).long(), inner)
@@ -291,7 +294,8 @@ def test_full_size_iterations_against_the_oracle(tmp_path, dataset, rate):
         assert abs(r["mean_e"] - r["mean_o"]) <= 2e-2 and abs(r["max_e"] - r["max_o"]) <= 5e-2, r
 
 
-def test_sgdd_reduce_api(tmp_path):
+@pytest.mark.parametrize("nlayers", [2, 3])
+def test_sgdd_reduce_api(tmp_path, nlayers):
     """`-M sgdd` end to end through the reference's entry points with the shipped configs/sgdd/cora.json (opt_scale 1e-11, ep_ratio
     0.5, mx_size 200): cli -> get_dataset -> SGDD(...).reduce (checkpoints incl. intermediate evaluation) -> Evaluator.evaluate."""
     import graphslim  # noqa: F401
@@ -301,7 +305,7 @@ def test_sgdd_reduce_api(tmp_path):
     from graphslim.evaluation.eval_agent import Evaluator
     from graphslim_amd.host import seed_everything
     args = cli(["-D", "cora", "-M", "sgdd", "-R", "0.25", "-G", "0", "--epochs", "20", "--outer_loop", "2", "--inner_loop", "2",
-                "--eval_epochs", "40", "--run_eval", "2", "--save_path", str(tmp_path)], standalone_mode=False)
+                "--eval_epochs", "40", "--run_eval", "2", "--nlayers", str(nlayers), "--save_path", str(tmp_path)], standalone_mode=False)
     assert args.opt_scale == 1e-11 and args.ep_ratio == 0.5 and args.mx_size == 200
     # the JSON's epochs = 600 fixed the checkpoint schedule before the explicit --epochs 20 was applied (config.py:231-234,385-389,
     # upstream too): name the checkpoints of the short run
