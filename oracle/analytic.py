@@ -359,8 +359,9 @@ def sgc_dense_grad_deep(theta, Xs, A, labels, K=2):
 # ------------------------------------------------------------------------------------------------
 
 
-def real_class_grad_gcn_deep(theta, X, batch, cls):
-    """batch = (B, n_id, [block_1 (outermost) .. block_L (seeds <- frontier)]) dense blocks; layer k uses block k."""
+def real_class_grad_gcn_deep(theta, X, batch, cls, mults=None):
+    """batch = (B, n_id, [block_1 (outermost) .. block_L (seeds <- frontier)]) dense blocks; layer k uses block k.
+    mults: the dropout multipliers of this forward (models/base.py:59), one [rows of layer k's output, h] per hidden layer k = 1 .. L-1."""
     B, n_id, blocks = batch
     L = len(theta) // 2
     assert len(blocks) == L
@@ -369,7 +370,7 @@ def real_class_grad_gcn_deep(theta, X, batch, cls):
         s.append(blocks[k - 1] @ a[-1])                  # (A_k a_{k-1}) W_k = A_k (a_{k-1} W_k)
         pk = s[-1] @ theta[2 * (k - 1)] + theta[2 * (k - 1) + 1]
         if k < L:
-            m.append((pk > 0).to(X.dtype))
+            m.append((pk > 0).to(X.dtype) if mults is None else (pk > 0).to(X.dtype) * mults[k - 1])     # relu' (x the multiplier)
             a.append(pk * m[-1])
     G = torch.softmax(pk, 1)
     G[:, cls] -= 1
@@ -383,28 +384,51 @@ def real_class_grad_gcn_deep(theta, X, batch, cls):
     return gw
 
 
-def syn_match_gcn_deep(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="ours"):
-    """Returns (loss, dX, dA) for the L-layer GCN condense model on the dense normalised A (L = 2: syn_match_gcn)."""
+def syn_match_gcn_deep(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, metric="ours", mults=None):
+    """Returns (loss, dX, dA) for the L-layer GCN condense model on the dense normalised A (L = 2: syn_match_gcn).
+    mults: per class c the dropout multipliers of ITS synthetic forward, mults[c][k - 1] = [n', h] for hidden layer k (models/base.py:59:
+    train_class calls the model once per class, gcond_base.py:228, so every class has its own forward — what gcnk_syn_match_drop of
+    csrc/gs_gcnk.inc computes).  Without dropout the classes share one forward and the adjoints are summed before they pass through it."""
     n = Xs.shape[0]
     L = len(theta) // 2
     W = [None] + [theta[2 * k] for k in range(L)]
     b = [None] + [theta[2 * k + 1] for k in range(L)]
-    a, s, m = [Xs], [None], [None]
-    for k in range(1, L + 1):
-        s.append(A @ a[-1])
-        pk = s[-1] @ W[k] + b[k]
-        if k < L:
-            m.append((pk > 0).to(Xs.dtype))
-            a.append(pk * m[-1])
-    P = torch.softmax(pk, 1)
+
+    def forward(mc):
+        a, s, m = [Xs], [None], [None]
+        for k in range(1, L + 1):
+            s.append(A @ a[-1])
+            pk = s[-1] @ W[k] + b[k]
+            if k < L:
+                m.append((pk > 0).to(Xs.dtype) if mc is None else (pk > 0).to(Xs.dtype) * mc[k - 1])
+                a.append(pk * m[-1])
+        return a, s, m, torch.softmax(pk, 1)
+
+    def forward_adjoint(a, m, sbar, shat):
+        """dA and d X~ of one forward from the adjoints of its s_k: sbar = that of s_L, shat[k] = those the gW_k terms hand to s_k."""
+        dA = torch.zeros_like(A)
+        for k in range(L, 0, -1):
+            dA = dA + sbar @ a[k - 1].T
+            abar = A.T @ sbar
+            if k > 1:
+                sbar = shat[k - 1] + (abar * m[k - 1]) @ W[k - 1].T
+        return abar, dA
+
+    if mults is None:
+        a, s, m, P = forward(None)
+        V = torch.zeros_like(P)
+        shat = [None] + [torch.zeros_like(s[k]) for k in range(1, L + 1)]    # adjoints of s_k from the gW_k = s_k^T delta_k terms
     loss = torch.zeros((), dtype=Xs.dtype)
     dA = torch.zeros_like(A)
-    V = torch.zeros_like(P)
-    shat = [None] + [torch.zeros_like(s[k]) for k in range(1, L + 1)]        # adjoints of s_k from the gW_k = s_k^T delta_k terms
+    dX = torch.zeros_like(Xs)
     for c, (lo, hi) in enumerate(class_ranges):
         nc = hi - lo
         if nc == 0:
             continue
+        if mults is not None:
+            a, s, m, P = forward(mults[c])
+            V = torch.zeros_like(P)
+            shat = [None] + [torch.zeros_like(s[k]) for k in range(1, L + 1)]
         G = torch.zeros_like(P)
         G[lo:hi] = P[lo:hi]
         G[lo:hi, c] -= 1
@@ -434,18 +458,18 @@ def syn_match_gcn_deep(theta, Xs, A, labels_syn, class_ranges, coeffs, gw_real, 
                 dA = dA + u[k + 1] @ q.T
         Pc, U = P[lo:hi], dhat[lo:hi]                      # G depends on Z through class c's rows only
         V[lo:hi] = (Pc * U - Pc * (Pc * U).sum(1, keepdim=True)) / nc
-    # the forward's adjoint
-    sbar = shat[L] + V @ W[L].T
-    for k in range(L, 0, -1):
-        dA = dA + sbar @ a[k - 1].T
-        abar = A.T @ sbar
-        if k > 1:
-            sbar = shat[k - 1] + (abar * m[k - 1]) @ W[k - 1].T
-    return loss, abar, dA
+        if mults is not None:                              # this class's own forward
+            dXc, dAc = forward_adjoint(a, m, shat[L] + V @ W[L].T, shat)
+            dX, dA = dX + dXc, dA + dAc
+    if mults is None:                                      # the shared forward, once
+        dX, dAf = forward_adjoint(a, m, shat[L] + V @ W[L].T, shat)
+        dA = dA + dAf
+    return loss, dX, dA
 
 
-def gcn_dense_grad_deep(theta, Xs, A, labels):
-    """The inner steps' gradient (NLL over all n' rows) of the L-layer GCN on the dense A."""
+def gcn_dense_grad_deep(theta, Xs, A, labels, mults=None):
+    """The inner steps' gradient (NLL over all n' rows) of the L-layer GCN on the dense A; mults[k - 1]: this step's dropout multiplier
+    of hidden layer k (the model is in training mode, gcond.py:45)."""
     n = Xs.shape[0]
     L = len(theta) // 2
     a, s, m = [Xs], [None], [None]
@@ -453,7 +477,7 @@ def gcn_dense_grad_deep(theta, Xs, A, labels):
         s.append(A @ a[-1])
         pk = s[-1] @ theta[2 * (k - 1)] + theta[2 * (k - 1) + 1]
         if k < L:
-            m.append((pk > 0).to(Xs.dtype))
+            m.append((pk > 0).to(Xs.dtype) if mults is None else (pk > 0).to(Xs.dtype) * mults[k - 1])
             a.append(pk * m[-1])
     G = torch.softmax(pk, 1)
     G[torch.arange(n), labels] -= 1

@@ -191,14 +191,19 @@ def sgc_bn_forward(x, adj, params, nlayers=2):
     return F.log_softmax(x, dim=1)
 
 
-def gcn_forward(x, adj, params):
-    """models/base.py:51-78 + layers.py:36-51: per layer adj @ (x@W) + b, relu between."""
+def gcn_forward(x, adj, params, where=None):
+    """models/base.py:51-78 + layers.py:36-51: per layer adj @ (x@W) + b, then relu and dropout behind every layer but the last.
+    Dropout: the hook gets `where` = (kind, index, rows, layer) with rows = the node ids of THIS layer's output rows (a sampled block's
+    targets are the first rows of its sources, loader.py:205-210) and layer = 0, 1, .. (the hidden layer the mask multiplies)."""
     nl = len(params) // 2
     for i in range(nl):
         a = adj[i] if isinstance(adj, (list, tuple)) else adj
         x = _prop(a, x @ params[2 * i]) + params[2 * i + 1]
         if i != nl - 1:
             x = F.relu(x)
+            if DROPOUT is not None:
+                kind, index, rows = where
+                x = x * DROPOUT((kind, index, None if rows is None else rows[:x.shape[0]], i), x)
     return F.log_softmax(x, dim=1)
 
 
@@ -363,11 +368,11 @@ def block_to_torch(block, dtype=torch.float32):
 def model_forward(kind, x, adj, params, nlayers, where=None):
     if kind == "SGC":
         return sgc_forward(x, adj, params, nlayers, where)
-    if DROPOUT is not None:
-        raise NotImplementedError("oracle: dropout is restated for SGC without BatchNorm only")
     if kind == "SGC_BN":
+        if DROPOUT is not None:
+            raise NotImplementedError("oracle: dropout is restated for SGC and GCN without BatchNorm only")
         return sgc_bn_forward(x, adj, params, nlayers)
-    return gcn_forward(x, adj, params)
+    return gcn_forward(x, adj, params, where)
 
 
 def class_real_grads(kind, params, features, labels, batch, nlayers=2, cls=None):

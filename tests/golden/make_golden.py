@@ -1012,6 +1012,95 @@ def g26():
     print("g26:", float(loss), losses, [float(m.mean()) for m in masks[:3]])
 
 
+def _gcn_dropout_case(tag, sizes, nlayers, out, seed):
+    n, nclass, d, hidden, rate, p_drop = 80, 4, 6, 12, 0.4, 0.4
+    a, x, y = make_graph(n, nclass, d, 5, seed=47)
+    per = [max(6, n // (4 * nclass)) + 2 * c for c in range(nclass)]
+    data = FakeData(a, x, y, nclass, per, 10, 10, seed=2, sizes=sizes)
+    args = args_obj(ntrans=1, hidden=hidden, reduction_rate=rate, dataset="ogbn-arxiv", condense_model="GCN", dropout=p_drop,
+                    inner_loop=2, lr=0.01, nlayers=nlayers)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    agent = GCondBase("trans", data, args)
+    n_syn = agent.nnodes_syn
+    with torch.no_grad():
+        agent.feat_syn.copy_(torch.randn(n_syn, d))
+    features, adj, labels = RU.to_tensor(data.feat_full, data.adj_full, label=data.labels_full, device="cpu")
+    adj = RU.normalize_adj_tensor(adj, sparse=True)
+    labels_syn = RU.to_tensor(label=data.labels_syn, device="cpu")
+    model = ref_model("GCN", d, hidden, nclass, args)
+    assert model.dropout == p_drop and model.nlayers == nlayers
+    model.initialize()
+    model.train()
+    adj_syn = agent.pge(agent.feat_syn)
+    agent.adj_syn = RU.normalize_adj_tensor(adj_syn, sparse=False)
+    calls0 = data.calls
+    masks = []
+    real_dropout = torch.nn.functional.dropout
+
+    def recording_dropout(t, p=0.5, training=True, inplace=False):
+        m = real_dropout(torch.ones_like(t), p, training)
+        masks.append(np_(m).reshape(-1, t.shape[-1]).copy())      # (dense adjacency: GraphConvolution hands on [1, n', hidden], layers.py:41-47)
+        return t * m
+
+    torch.nn.functional.dropout = recording_dropout
+    try:
+        loss = agent.train_class(model, adj, features, labels, labels_syn, args)
+        agent.optimizer_feat.zero_grad()
+        agent.optimizer_pge.zero_grad()
+        g_adjn = torch.autograd.grad(loss, agent.adj_syn, retain_graph=True)[0]
+        loss.backward()
+        assert len(masks) == 2 * nclass * (nlayers - 1)
+        coo = a.tocoo()
+        out.update({
+            f"{tag}_a_row": coo.row, f"{tag}_a_col": coo.col, f"{tag}_x": x, f"{tag}_y": y,
+            f"{tag}_idx_train": np_(data.idx_train), f"{tag}_meta": np.array([n, nclass, d, hidden, 1, calls0]),
+            f"{tag}_rate": np.array(rate), f"{tag}_sizes": np.array(sizes), f"{tag}_labels_syn": np_(labels_syn),
+            f"{tag}_feat_syn": np_(agent.feat_syn), f"{tag}_loss": np_(loss), f"{tag}_dfeat": np_(agent.feat_syn.grad),
+            f"{tag}_adj_syn": np_(adj_syn), f"{tag}_adj_norm": np_(agent.adj_syn), f"{tag}_dadj_norm": np_(g_adjn),
+            f"{tag}_dropout": np.array(p_drop),
+        })
+        for i, p in enumerate(model.parameters()):
+            out[f"{tag}_theta{i}"] = np_(p).copy()
+        for i, p in enumerate(agent.pge.parameters()):
+            out[f"{tag}_pge{i}"], out[f"{tag}_dpge{i}"] = np_(p), np_(p.grad)
+        optimizer_model = torch.optim.Adam(list(model.parameters()), lr=args.lr)      # gcond.py:63-72
+        feat_inner = agent.feat_syn.detach()
+        adj_inner = agent.pge.inference(feat_inner)
+        adj_inner_norm = RU.normalize_adj_tensor(adj_inner, sparse=False)
+        losses = []
+        for _ in range(args.inner_loop):
+            optimizer_model.zero_grad()
+            o = model.forward(feat_inner, adj_inner_norm)
+            li = torch.nn.functional.nll_loss(o, labels_syn)
+            li.backward()
+            optimizer_model.step()
+            losses.append(float(li))
+    finally:
+        torch.nn.functional.dropout = real_dropout
+    assert len(masks) == (2 * nclass + args.inner_loop) * (nlayers - 1)
+    for i, m in enumerate(masks):
+        assert set(np.unique(m)) <= {0.0, np.float32(1.0 / (1.0 - p_drop))}
+        out[f"{tag}_mask{i}"] = (m > 0).astype(np.uint8)
+    out[f"{tag}_adj_inner"] = np_(adj_inner)
+    out[f"{tag}_inner_losses"] = np.array(losses)
+    for i, p in enumerate(model.parameters()):
+        out[f"{tag}_theta_after{i}"] = np_(p)
+    print(f"g29 {tag}:", float(loss), losses, len(masks), [m.shape for m in masks[:2 * (nlayers - 1)]])
+
+
+def g29():
+    """Dropout in the GCN condensation model (VERDICT r05 "missing" 3; models/base.py:51-78: F.dropout behind relu in every layer but the
+    last, on the sampled block list and on the dense synthetic adjacency alike; the model is in training mode inside train_class and the
+    inner steps): train_class + backward and two inner steps of the reference for two and three layers, dropout 0.4, with torch's masks
+    recorded in call order as in G26 — per class the real batch's `nlayers - 1` masks (rows: the targets of that layer's block), then the
+    synthetic graph's; then `nlayers - 1` per inner step."""
+    out = {}
+    _gcn_dropout_case("gd2", (4, 3), 2, out, 71)
+    _gcn_dropout_case("gd3", (4, 3, 2), 3, out, 73)
+    save("g29_gcn_dropout", **out)
+
+
 def g17():
     """What the reference's evaluation model does with with_bn on a CONDENSED graph (models/base.py:156-161 inside
     fit_with_val(reduced=True), which every checkpoint of GCond.reduce and Evaluator.evaluate run): GraphConvolution.forward
@@ -1211,6 +1300,6 @@ def g22():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16",
-                             "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26", "g27", "g28"]
+                             "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26", "g27", "g28", "g29"]
     for w in which:
         globals()[w]()

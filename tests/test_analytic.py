@@ -164,6 +164,52 @@ def test_gcn_deep_closed_forms(L, sizes, metric):
         np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("L,sizes,metric", [(2, (3, 2), "ours"), (2, (3, 2), "mse"), (3, (3, 2, 2), "ours"), (4, (2, 2, 2, 2), "cos")])
+def test_gcn_dropout_closed_forms(L, sizes, metric):
+    """GCN condensation model with dropout (models/base.py:59: F.dropout behind relu in every layer but the last; one forward per class in
+    train_class, so one multiplier per class, forward and hidden layer): the closed forms of oracle/analytic.py *_gcn_deep with `mults`
+    — per-class forwards, per-class adjoints through them — against autograd through the oracle with the same multipliers, fp64."""
+    p = tiny_problem(1, seed=9, sizes=sizes)
+    d, hidden, pd = p["x"].shape[1], 9, 0.35
+    ns = len(p["labels_syn"])
+    torch.manual_seed(4)
+    th0 = [t.to(DT) for t in O.init_gcn(d, hidden, p["nclass"], L)]
+    g = torch.Generator().manual_seed(13)
+    draw = lambda rows: (torch.rand(rows, hidden, generator=g, dtype=DT) > pd).to(DT) / (1 - pd)
+    # rows of layer k's output on the real batch: the targets of block k (dense_batch: [targets, sources])
+    real = [[draw(blk.shape[0]) for blk in dense_batch(p["batches"][c])[2][:-1]] for c in range(p["nclass"])]
+    syn = [[draw(ns) for _ in range(L - 1)] for c in range(p["nclass"])]
+    inner = [draw(ns) for _ in range(L - 1)]
+    O.DROPOUT = lambda where, x: {"real": real, "syn": syn}[where[0]][where[1]][where[3]] if where[0] != "inner" else inner[where[3]]
+    try:
+        theta = [t.clone().requires_grad_(True) for t in th0]
+        xs = p["xs"].clone().requires_grad_(True)
+        an = O.dense_gcn_norm(O.pge_forward(xs.detach(), p["pge"])).clone().requires_grad_(True)
+        loss = O.train_class("GCN", theta, p["batches"], p["x"], p["y"], xs, an, p["labels_syn"], p["ncd"], p["nclass"], L, metric)
+        gx, ga = torch.autograd.grad(loss, [xs, an])
+        ref_real = [O.class_real_grads("GCN", [t.clone().requires_grad_(True) for t in th0], p["x"], p["y"], p["batches"][c], L, c)[0]
+                    for c in range(p["nclass"])]
+        theta = [t.clone().requires_grad_(True) for t in th0]
+        out = O.gcn_forward(p["xs"], an.detach(), theta, ("inner", 0, None))
+        ref_inner = torch.autograd.grad(F.nll_loss(out, p["labels_syn"]), theta)
+    finally:
+        O.DROPOUT = None
+    gw_real = [A.real_class_grad_gcn_deep(th0, p["x"], dense_batch(p["batches"][c]), c, mults=real[c]) for c in range(p["nclass"])]
+    for ref, got in zip(ref_real, gw_real):
+        for r, q in zip(ref, got):
+            np.testing.assert_allclose(q.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
+    ranges = [tuple(p["ranges"][c]) for c in range(p["nclass"])]
+    coeffs = [p["ncd"][c] / ns for c in range(p["nclass"])]
+    l, dX, dA = A.syn_match_gcn_deep(th0, p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric, mults=syn)
+    np.testing.assert_allclose(float(l), float(loss), rtol=1e-10)
+    np.testing.assert_allclose(dX.numpy(), gx.numpy(), rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(dA.numpy(), ga.numpy(), rtol=1e-7, atol=1e-11)
+    l0, _, _ = A.syn_match_gcn_deep(th0, p["xs"], an.detach(), p["labels_syn"], ranges, coeffs, gw_real, metric)
+    assert abs(float(l0) - float(l)) > 1e-6 * abs(float(l))
+    for r, q in zip(ref_inner, A.gcn_dense_grad_deep(th0, p["xs"], an.detach(), p["labels_syn"], mults=inner)):
+        np.testing.assert_allclose(q.numpy(), r.numpy(), rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("metric,K", [("ours", 2), ("mse", 2), ("cos", 3)])
 def test_dropout_closed_forms(metric, K):
     """Dropout in the condensation model (models/sgc.py:42): the closed forms with one multiplier per class forward — real batch and

@@ -266,6 +266,69 @@ def test_g26_dropout_train_class_and_inner_steps(golden_dir):
     assert abs(float(loss0) - float(g[f"{tag}_loss"])) > 1e-2 * abs(float(g[f"{tag}_loss"]))
 
 
+def replay_masks_gcn(g, tag, nclass, hid_layers, p_drop, dtype=torch.float32):
+    """oracle DROPOUT hook that replays golden G29's recorded multipliers: per class the real batch's `hid_layers` masks then the
+    synthetic graph's (train_class's call order), then `hid_layers` per inner step."""
+    def hook(where, x):
+        kind, index, _rows, layer = where
+        i = {"real": 2 * index * hid_layers, "syn": (2 * index + 1) * hid_layers, "inner": (2 * nclass + index) * hid_layers}[kind] + layer
+        m = torch.from_numpy(g[f"{tag}_mask{i}"].astype(np.float32)).to(dtype) / (1.0 - p_drop)
+        assert m.shape == x.shape, (where[:2], layer, m.shape, x.shape)
+        return m
+    return hook
+
+
+@pytest.mark.parametrize("tag", ["gd2", "gd3"])
+def test_g29_gcn_dropout_train_class_and_inner_steps(golden_dir, tag):
+    """Dropout in the GCN condensation model (models/base.py:51-78): the reference's train_class + backward and two inner steps for two
+    and three GraphConvolution layers with dropout 0.4, torch's masks recorded and replayed — pins where the restatement applies
+    dropout (behind relu in every layer but the last, on the rows of that layer's output), the order of the draws and the scaling."""
+    g = load(golden_dir, "g29_gcn_dropout")
+    p_drop = float(g[f"{tag}_dropout"])
+    nlayers = len(g[f"{tag}_sizes"])
+    batches, (n, nclass, d, hidden, t) = rebuild_batches(g, tag)
+    theta = [T(g[f"{tag}_theta{i}"]).requires_grad_(True) for i in range(2 * nlayers)]
+    ps = [T(g[f"{tag}_pge{i}"]).requires_grad_(True) for i in range(10)]
+    pge = {"lin": ps[:6], "bn": ps[6:]}
+    feat_syn = T(g[f"{tag}_feat_syn"]).requires_grad_(True)
+    labels_syn = T(g[f"{tag}_labels_syn"])
+    _, ncd, _ = O.generate_labels_syn(g[f"{tag}_y"][g[f"{tag}_idx_train"]], float(g[f"{tag}_rate"]))
+    adj_norm = O.dense_gcn_norm(O.pge_forward(feat_syn, pge))
+    adj_norm.retain_grad()
+    O.DROPOUT = replay_masks_gcn(g, tag, nclass, nlayers - 1, p_drop)
+    try:
+        loss = O.train_class("GCN", theta, batches, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]), feat_syn, adj_norm, labels_syn, ncd, nclass,
+                             nlayers, "ours")
+        loss.backward()
+        np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}_loss"]), rtol=1e-4)
+
+        def close(a, ref, rtol=2e-3):
+            np.testing.assert_allclose(a, ref, rtol=rtol, atol=1e-4 * np.abs(ref).max())
+
+        close(adj_norm.grad.numpy(), g[f"{tag}_dadj_norm"])
+        close(feat_syn.grad.numpy(), g[f"{tag}_dfeat"])
+        for i, p in enumerate(ps):
+            ref = g[f"{tag}_dpge{i}"]
+            if np.abs(ref).max() > 1e-6:
+                close(p.grad.numpy(), ref)
+        th = [T(g[f"{tag}_theta{i}"]).requires_grad_(True) for i in range(2 * nlayers)]
+        opt = O.Adam(th, 0.01)
+        with torch.no_grad():
+            adj_in = O.dense_gcn_norm(O.pge_forward(feat_syn.detach(), pge))
+        for it in range(2):
+            out = O.model_forward("GCN", feat_syn.detach(), adj_in, th, nlayers, ("inner", it, None))
+            li = torch.nn.functional.nll_loss(out, labels_syn)
+            np.testing.assert_allclose(float(li), float(g[f"{tag}_inner_losses"][it]), rtol=1e-5)
+            opt.step(torch.autograd.grad(li, th))
+        for i, q in enumerate(th):
+            np.testing.assert_allclose(q.detach().numpy(), g[f"{tag}_theta_after{i}"], rtol=1e-4, atol=2e-5)
+    finally:
+        O.DROPOUT = None
+    loss0 = O.train_class("GCN", [q.detach().requires_grad_(True) for q in theta], batches, T(g[f"{tag}_x"]), T(g[f"{tag}_y"]),
+                          feat_syn, O.dense_gcn_norm(O.pge_forward(feat_syn, pge)), labels_syn, ncd, nclass, nlayers, "ours")
+    assert abs(float(loss0) - float(g[f"{tag}_loss"])) > 1e-3 * abs(float(g[f"{tag}_loss"]))      # (ten times the gate above)
+
+
 @pytest.mark.parametrize("tag", ["cora_like", "arxiv_like"])
 def test_g8_full_reduce_and_evaluate(golden_dir, tag):
     """Replays a whole reference run (GCond.__init__ + reduce + intermediate evals + Evaluator.evaluate)."""
