@@ -69,14 +69,15 @@ class _GradMatch(GCondBase):
         dropout = float(getattr(args, "dropout", 0.0) or 0.0)
         if not 0.0 <= dropout < 1.0:
             raise ValueError(f"graphslim_amd: dropout must be in [0, 1), got {dropout}")
-        if dropout != 0.0 and not (args.condense_model == "SGC" and not with_bn):
-            # models/sgc.py:38-43 and models/base.py:51-78 apply F.dropout(training=True) after every transform BUT THE LAST, inside
-            # train_class and the inner loop.  SGC: one transform has no such layer (the value is accepted and — exactly as upstream —
-            # has no effect); two transforms run the engine's dropout stage (golden G26; masks: graphslim_amd.engine.dropout_keep).
-            # The GCN condensation model and with_bn have no dropout stage: a non-zero value must not be silently ignored
-            # (ADVICE r01); every configs/{gcond,doscond,gcondx,doscondx,msgc,sgdd}/*.json uses dropout = 0.
-            raise NotImplementedError("graphslim_amd: dropout != 0 is built for condense_model SGC without with_bn (the reference's "
-                                      "gradient-matching configs all use dropout = 0)")
+        if dropout != 0.0 and with_bn:
+            # models/sgc.py:38-43 and models/base.py:51-78 apply F.dropout(training=True) after every transform / layer BUT THE LAST,
+            # inside train_class and the inner loop.  SGC: one transform has no such layer (the value is accepted and — exactly as
+            # upstream — has no effect); two transforms run the engine's dropout stage (golden G26).  GCN: nlayers - 1 masks per forward,
+            # one forward per class (csrc/gs_gcnk.inc; golden G29).  Masks: graphslim_amd.engine.dropout_keep.  with_bn has no dropout
+            # stage: a non-zero value must not be silently ignored; every configs/{gcond,doscond,gcondx,doscondx,msgc,
+            # sgdd}/*.json uses dropout = 0.
+            raise NotImplementedError("graphslim_amd: dropout != 0 is built without with_bn (the reference's gradient-matching configs "
+                                      "all use dropout = 0)")
         labels_syn = np.asarray(data.labels_syn)
         if args.setting == "trans":
             features, adj = data.feat_full, data.adj_full

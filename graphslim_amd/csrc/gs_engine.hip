@@ -98,6 +98,8 @@ struct gs_gcond {
   // GCN condensation model with nlayers = L > 2 (models/gcn.py:8-23): gdeep = L - 2 hidden-to-hidden GraphConvolution layers, same
   // parameter layout; the stages dispatch to gs_gcnk.inc
   int gdeep;
+  bool gk;                           // the GCN model runs the layer loops of gs_gcnk.inc: nlayers > 2, or dropout (any nlayers)
+  float* gkd[7];                     // [C][n'][h] each: per-class activations / adjoints of the synthetic forwards under dropout
   float *gk_sbuf[3];                   // [n'][h] s_k = A a_{k-1}, k = 2 .. L
   float *gk_slabA;                     // [C][n'][n'] per-class contributions to d A^
   float *gr_P1, *gr_H[4], *gr_T, *gr_dT, *gr_dHa, *gr_dHb;      // real side: [C][capL][d], [C][rows_k][h] per layer, scratch of capL rows
@@ -297,6 +299,7 @@ static void derive(gs_gcond* e, const gs_gcond_config& c) {
     e->drop_thr = (unsigned)(thr < 1 ? 1 : thr > 65535 ? 65535 : thr);
     e->drop_q = (float)(1.0 / keep);
   }
+  e->gk = e->gcn && (e->gdeep > 0 || e->drop_thr != 0);
   e->og = e->obeta = 0;
   if (e->with_bn) {      // nn.Module.parameters() order: layers.*, then bns.0.weight, bns.0.bias (models/sgc.py:27-35)
     e->og = e->P; e->obeta = e->P + e->h;
@@ -476,16 +479,24 @@ static size_t carve(gs_gcond* e, void* base) {
     e->Hmid_s[k] = k < e->deep ? w.take<float>(n * h) : nullptr;
   }
   e->WmT = e->deep ? w.take<float>(h * h) : nullptr;
-  const bool anyd = e->deep || e->gdeep;
+  const bool anyd = e->deep || e->gk;
   for (int k = 0; k < 2; ++k)
     if (k < e->gdeep) e->Hmid_s[k] = w.take<float>(n * h);
-  for (int k = 0; k < 8; ++k) e->dp_cls[k] = (e->deep && k < 6) || e->gdeep ? w.take<float>(C * n * h) : nullptr;
+  for (int k = 0; k < 8; ++k) e->dp_cls[k] = (e->deep && k < 6) || e->gk ? w.take<float>(C * n * h) : nullptr;
   for (int k = 0; k < 6; ++k) e->dp_n[k] = anyd ? w.take<float>(n * h) : nullptr;
-  for (int k = 0; k < 3; ++k) e->gk_sbuf[k] = k < e->gdeep + 1 && e->gdeep ? w.take<float>(n * h) : nullptr;
-  e->gk_slabA = e->gdeep ? w.take<float>(C * n2) : nullptr;
-  e->gr_P1 = e->gdeep ? w.take<float>(C * capL * d) : nullptr;
+  for (int k = 0; k < 3; ++k) e->gk_sbuf[k] = k < e->gdeep + 1 && e->gk ? w.take<float>(n * h) : nullptr;
+  e->gk_slabA = e->gk ? w.take<float>(C * n2) : nullptr;
+  e->gr_P1 = e->gk ? w.take<float>(C * capL * d) : nullptr;
+  {      // dropout: a_k per class (k = 2 .. L - 1), s_k per class (k = 2 .. L), shat_k per class (k = 2 .. L - 1) — gcnk_syn_match_drop
+    const bool gd = e->gk && e->drop_thr;
+    const int L = 2 + e->gdeep;
+    for (int k = 0; k < 7; ++k) e->gkd[k] = nullptr;
+    for (int k = 2; gd && k <= L - 1; ++k) e->gkd[k - 2] = w.take<float>(C * n * h);
+    for (int k = 2; gd && k <= L; ++k) e->gkd[2 + k - 2] = w.take<float>(C * n * h);
+    for (int k = 2; gd && k <= L - 1; ++k) e->gkd[5 + k - 2] = w.take<float>(C * n * h);
+  }
   for (int k = 0; k < 4; ++k) e->gr_H[k] = nullptr;
-  if (e->gdeep) {
+  if (e->gk) {
     // layer k's output rows: the frontier it lands on (k = 1: the last middle frontier, capL rows; .. ; k = L - 1: hop 1's, cap1 rows)
     const int L = 2 + e->gdeep;
     for (int k = 1; k < L; ++k) {
@@ -556,16 +567,16 @@ static int check_cfg(const gs_gcond_config* c) {
   if (!(c->dropout >= 0.f && c->dropout < 1.f)) GS_FAIL(GS_ERR_ARG, "gs_gcond: dropout must be in [0, 1)");
   if (c->dropout > 0.f && !(c->condense_model == 0 && c->ntrans == 1)) {
     // models/sgc.py:38-43: F.dropout behind every transform but the last, in training mode inside train_class and the inner steps
-    if (c->condense_model != 0 || c->with_bn)
-      GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: dropout != 0 is built for condense_model SGC without BatchNorm");
+    // (GCN: models/base.py:59, behind relu in every layer but the last — the layer loops of gs_gcnk.inc, golden G29)
+    if (c->with_bn) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: dropout != 0 is built without BatchNorm");
     if (c->hidden % 4 != 0 || c->hidden > 1024) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: dropout != 0 needs hidden % 4 == 0, hidden <= 1024");
   }
   if (c->nlayers != 0 && c->nlayers != 2) {
     // models/sgc.py:45-51 propagates nlayers times, dataset/loader.py:205-210 samples as many hops; nlayers = 1 has no reference run
     // (PyG's sampler hands train_class the single hop's Adj tuple instead of a list: gcond_base.py:213 fails on it)
     if (c->nlayers < 3 || c->nlayers > 2 + GS_MAX_MID) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nlayers must be 2 .. %d", 2 + GS_MAX_MID);
-    if (c->condense_model != 0 && (c->nlayers > 4 || c->with_bn || c->dropout > 0.f))
-      GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: a GCN condensation model takes nlayers 2 .. 4, without BatchNorm / dropout");
+    if (c->condense_model != 0 && (c->nlayers > 4 || c->with_bn))
+      GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: a GCN condensation model takes nlayers 2 .. 4, without BatchNorm");
     for (int m = 0; m < c->nlayers - 2; ++m)
       if (c->fmid[m] < 1 || c->fmid[m] > 16) GS_FAIL(GS_ERR_ARG, "gs_gcond: middle fan-outs in [1, 16]");
   }
@@ -1252,7 +1263,7 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
   const int nmid = b.nmid, capL = e->capL;
   const int* nL = nmid ? b.nm[nmid - 1] : b.n1;
   if (nmid && (e->S_full || (e->gcn && !e->gdeep))) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_gcond: nlayers != 2 with the full-neighbour mode");
-  if (e->gcn && e->gdeep) return gcnk_real_grads(e, b, Cl, c0, stream);
+  if (e->gk) return gcnk_real_grads(e, b, Cl, c0, stream);
   // class-major scratch of this rank's classes
   const long Fp = e->Fp;
   float* P0 = e->P0 + c0 * capL * Fp; float* rs0 = e->rs0 + c0 * capL;
@@ -1999,7 +2010,7 @@ extern "C" int gs_gcond_stage_syn_match(gs_gcond* e, gs_stream_t stream) {
   if (!e) GS_FAIL(GS_ERR_ARG, "null engine");
   GS_TRY(quiesce_hoist(e));
   if (e->deep) return deep_syn_match(e, stream);
-  if (e->gcn && e->gdeep) return gcnk_syn_match(e, stream);
+  if (e->gk) return gcnk_syn_match(e, stream);
   gs_blk_dense_guard blk_guard(e);
   hipStream_t s = (hipStream_t)stream;
   const int C = e->C, Cl = e->c_hi - e->c_lo, n = e->n, d = e->d, h = e->h, F = e->F, mx = e->max_nc;
@@ -2733,7 +2744,7 @@ extern "C" int gs_gcond_stage_inner_steps(gs_gcond* e, gs_stream_t stream) {
   const int C = e->C, n = e->n, d = e->d, h = e->h, F = e->F;
   if (e->cfg.inner_loop == 0) return GS_OK;
   if (e->deep) return deep_inner_steps(e, stream);
-  if (e->gcn && e->gdeep) return gcnk_inner_steps(e, stream);
+  if (e->gk) return gcnk_inner_steps(e, stream);
   gs_blk_dense_guard blk_guard(e);
   if (knob_of(e, GS_KNOB_FUSED_CHAINS, g_fused_chains) && !e->gcn && !e->with_bn && !e->blk_pos && C <= 64) return inner_steps_fused(e, stream);
   const float* X = e->io.feat_syn;

@@ -52,6 +52,38 @@ __global__ __launch_bounds__(256) void gs_drop_rows_kernel(const float* __restri
   const float4 v = *reinterpret_cast<const float4*>(H + (long)row * h + col4);
   *reinterpret_cast<float4*>(out + ((long)c * n + row) * h + col4) = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
 }
+// buf[c][i][:] *= multiplier(kind, class0 + c, row i)     (per-class activations masked in place: the hidden layers of the GCN
+// condensation model under dropout, models/base.py:59; `kind` carries the layer, gs_gcnk.inc)
+__global__ __launch_bounds__(256) void gs_drop_rows_self_kernel(float* __restrict__ buf, int n, int h, int Cl, unsigned long long key0,
+                                                                int index0, unsigned thr, float q) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (c, row, col4)
+  const int h4 = h >> 2;
+  if (i >= (long)Cl * n * h4) return;
+  const int c = (int)(i / ((long)n * h4));
+  const long r = i - (long)c * n * h4;
+  const int row = (int)(r / h4), col4 = 4 * (int)(r - (long)row * h4);
+  const float4 m = gs_drop_mult4(gs_mix64(key0 + (unsigned)(index0 + c)), row, col4, thr, q);
+  float4* p = reinterpret_cast<float4*>(buf + ((long)c * n + row) * h + col4);
+  const float4 v = *p;
+  *p = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+}
+// buf[c][l][:] *= multiplier(kind, class0 + c, node ids[c][l]) for the live rows l < live[c] of class c's frontier (capacity `cap` rows):
+// the real batch's hidden activations, keyed by the GLOBAL node id of the row like the SGC path's gathered rows
+__global__ __launch_bounds__(256) void gs_drop_rows_ids_kernel(float* __restrict__ buf, const int* __restrict__ ids,
+                                                               const int* __restrict__ live, int cap, int h, int Cl,
+                                                               unsigned long long key0, int index0, unsigned thr, float q) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (c, row, col4)
+  const int h4 = h >> 2;
+  if (i >= (long)Cl * cap * h4) return;
+  const int c = (int)(i / ((long)cap * h4));
+  const long r = i - (long)c * cap * h4;
+  const int row = (int)(r / h4), col4 = 4 * (int)(r - (long)row * h4);
+  if (row >= live[c]) return;
+  const float4 m = gs_drop_mult4(gs_mix64(key0 + (unsigned)(index0 + c)), ids[(long)c * cap + row], col4, thr, q);
+  float4* p = reinterpret_cast<float4*>(buf + ((long)c * cap + row) * h + col4);
+  const float4 v = *p;
+  *p = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+}
 // buf = [Hc > 0] * q * buf   (the backward of relu + dropout: Hc = relu(.) * multiplier, so Hc > 0 <=> passed by both)
 __global__ __launch_bounds__(256) void gs_drop_mask_scale_kernel(float* __restrict__ buf, const float* __restrict__ Hc, long total, float q) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -314,11 +314,13 @@ def _mix64(z):
         return z ^ (z >> np.uint64(31))
 
 
-def dropout_keep(seed, iteration, kind, index, rows, hidden, p):
+def dropout_keep(seed, iteration, kind, index, rows, hidden, p, layer=0):
     """The engine's dropout mask (csrc/gs_kernels.h gs_drop_mult4), restated: bool [len(rows), hidden], True = kept.  kind "real" (index
-    = class, rows = the batch's node ids), "syn" (index = class, rows = 0 .. n'-1) or "inner" (index = inner step, rows = 0 .. n'-1).
-    The multiplier is keep / (1 - p) in fp32.  Parity tests hand these masks to the oracle (oracle.gcond_oracle.DROPOUT)."""
-    kind_id = {"real": 0, "syn": 1, "inner": 2}[kind]
+    = class, rows = the batch's node ids), "syn" (index = class, rows = 0 .. n'-1) or "inner" (index = inner step, rows = 0 .. n'-1);
+    layer = 0, 1, .. : the hidden layer the mask multiplies (the GCN condensation model has nlayers - 1 of them, csrc/gs_gcnk.inc gk_kind;
+    SGC with two transforms has one).  The multiplier is keep / (1 - p) in fp32.  Parity tests hand these masks to the oracle
+    (oracle.gcond_oracle.DROPOUT)."""
+    kind_id = {"real": 0, "syn": 1, "inner": 2}[kind] + 3 * int(layer)
     thr = min(max(int((1.0 - float(p)) * 65536.0 + 0.5), 1), 65535)
     with np.errstate(over="ignore"):
         key0 = _mix64(np.array([int(seed) & _M64], dtype=np.uint64))[0] + np.uint64((int(iteration) << 24) & _M64) + np.uint64(kind_id << 20)
