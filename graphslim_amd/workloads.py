@@ -38,6 +38,7 @@ WORKLOADS = {
     # `--condense_model GCN --nlayers 3` (models/gcn.py:8-23: one GraphConvolution per sampled hop) with the ogbn-arxiv hyper-parameters:
     # a parity-test case (the third field is the model's depth)
     "arxiv-gcn3": ("ogbn-arxiv", 0.005, 3, 256, 256, 20, 3, 0.01, 0.01, (15, 10, 5)),
+    "arxiv-gcn2": ("ogbn-arxiv", 0.005, 2, 256, 256, 20, 3, 0.01, 0.01, (10, 5)),      # (two layers: the dropout parity case)
     "cora-r0.25-k3": ("cora", 0.25, 1, 256, 128, 20, 15, 1e-4, 1e-4, (15, 10, 5)),      # the quiet job of the job-level gate with three hops
 }
 

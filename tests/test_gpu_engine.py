@@ -345,9 +345,7 @@ def test_dropout_train_class_and_inner_steps(golden_dir, metric):
         e.stage_syn_match()
         e.syn_finish()
     assert torch.equal(e0.buffer("d_adj_norm"), e1.buffer("d_adj_norm")) and torch.equal(e0.buffer("gw_real"), e1.buffer("gw_real"))
-    # refused, not ignored: the GCN condensation model, BatchNorm, p outside [0, 1)
-    with pytest.raises(RuntimeError):
-        make_engine(n, nclass, d, hidden, 2, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, model="GCN", dropout=p_drop)
+    # refused, not ignored: BatchNorm, p outside [0, 1)  (the GCN condensation model: test_gcn_dropout_train_class_and_inner_steps)
     with pytest.raises(RuntimeError):
         make_engine(n, nclass, d, hidden, 2, ph, labels_syn, ranges, g[f"{tag}_x"], f1, f2, with_bn=True, dropout=p_drop)
     with pytest.raises(RuntimeError):
@@ -1764,7 +1762,8 @@ def test_dropout_reduce_api(tmp_path):
     """`--dropout 0.3` through the reference's own entry points: GCond.reduce with the SGC (ntrans = 2) condensation model under dropout
     (models/sgc.py:42) — every outer iteration advances the masks' counter —, checkpoints and the final Evaluator run (evaluation models
     run without dropout: models/base.py:27-29).  Sanity of the whole path; parity is test_dropout_train_class_and_inner_steps and
-    test_outer_iterations_with_dropout_follow_the_oracle.  The GCN condensation model and with_bn refuse a non-zero value."""
+    test_outer_iterations_with_dropout_follow_the_oracle.  The same with `--condense_model GCN` (two and three layers, round 6:
+    models/base.py:59; parity is test_gcn_dropout_train_class_and_inner_steps).  with_bn refuses a non-zero value."""
     import graphslim  # noqa: F401
     from graphslim.config import cli
     from graphslim.condensation import GCond
@@ -1787,11 +1786,21 @@ def test_dropout_reduce_api(tmp_path):
         mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
         assert 0.0 <= mean <= 1.0
     assert not torch.equal(feats[0], feats[1])      # the masks entered the condensation
-    for extra in (["--condense_model", "GCN"], ["--with_bn"]):
-        bad = cli(argv + ["--dropout", "0.3"] + extra, standalone_mode=False)
-        graph = get_dataset(bad.dataset, bad)
-        with pytest.raises(NotImplementedError):
-            GCond(setting=bad.setting, data=graph, args=bad).reduce(graph, verbose=False)
+    for nl in (2, 3):
+        args = cli(argv + ["--dropout", "0.3", "--condense_model", "GCN", "--hidden", "64", "--nlayers", str(nl)], standalone_mode=False)
+        args.run_inter_eval, args.checkpoints, args.outer_loop, args.inner_loop = 1, [5, 11], 2, 2
+        graph = get_dataset(args.dataset, args)
+        __import__('graphslim_amd.host', fromlist=['seed_everything']).seed_everything(args.seed)
+        agent = GCond(setting=args.setting, data=graph, args=args)
+        reduced = agent.reduce(graph, verbose=False)
+        assert torch.isfinite(reduced.feat_syn).all() and torch.isfinite(reduced.adj_syn).all()
+        assert agent.engine.shapes.dropout == args.dropout and agent.engine.dropout_iter() == 12 * 2 and len(agent.engine.get_model()) == 2 * nl
+        mean, _ = Evaluator(args).evaluate(reduced, model_type="GCN", verbose=False)
+        assert 0.0 <= mean <= 1.0
+    bad = cli(argv + ["--dropout", "0.3", "--with_bn"], standalone_mode=False)
+    graph = get_dataset(bad.dataset, bad)
+    with pytest.raises(NotImplementedError):
+        GCond(setting=bad.setting, data=graph, args=bad).reduce(graph, verbose=False)
 
 
 @pytest.mark.parametrize("ntrans", [1, 2])
