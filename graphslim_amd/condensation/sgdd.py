@@ -28,9 +28,13 @@ class SGDDLoop:
         self.x = eng.feat_syn
         self.m_x, self.v_x, self.step_x = torch.zeros_like(self.x), torch.zeros_like(self.x), 0
         self.d_adj, self.d_feat = eng.view("d_adj").view(n, n), eng.view("d_feat").view(n, d)
+        self.iterations = 0
 
     def step(self, it):
         eng, gen, x = self.eng, self.gen, self.x
+        if eng.shapes.dropout:        # the masks of this iteration's train_class and inner steps (the staged calls do not advance the counter)
+            eng.set_dropout_iter(self.iterations)
+        self.iterations += 1
         eng.stage_real_async()
         adj = gen.forward(x, train=True)                                          # :65 self.pge(self.feat_syn, Lx=...)
         eng.set_structure(adj, inference=False)                                   # :66 normalize_adj_tensor
@@ -103,8 +107,15 @@ class SGDD(GCondBase):
             # (`--nlayers` K: K sampled hops, K propagations on both sides — models/sgc.py:45-51, dataset/loader.py:205-210; the engine's
             # stages take the structure from the IGNR whatever K is: Q = A^^K with the product rule for d A^)
             raise NotImplementedError(f"graphslim_amd: nlayers must be 2 .. 5 (dataset/loader.py:197-210 knows no other), got {args.nlayers}")
-        if getattr(args, "with_bn", False) or float(getattr(args, "dropout", 0.0) or 0.0) != 0.0:
-            raise NotImplementedError("graphslim_amd: SGDD with with_bn / dropout in the condensation model is not built")
+        if getattr(args, "with_bn", False):
+            raise NotImplementedError("graphslim_amd: SGDD with with_bn in the condensation model is not built")
+        # `--dropout`: sgdd.py:62 puts the model into training mode like gcond.py:45 — masks in train_class and the inner steps (golden
+        # G30 counts them); the engine's dropout stage for SGC with two transforms (one transform has no dropout layer, as upstream)
+        dropout = float(getattr(args, "dropout", 0.0) or 0.0)
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError(f"graphslim_amd: dropout must be in [0, 1), got {dropout}")
+        if dropout != 0.0 and args.ntrans > 2:
+            raise NotImplementedError("graphslim_amd: dropout != 0 with ntrans > 2 is not built")
         args.mx_size = self.mx                                                            # sgdd.py:33-36
         data.adj_mx = data.adj_full[:self.mx, :self.mx]
         if args.setting == "trans":
@@ -119,7 +130,8 @@ class SGDD(GCondBase):
                  5: (15, 10, 5, 5, 5)}[args.nlayers]                                           # loader.py:197-210
         ranges = [tuple(self.syn_class_indices.get(c, (0, 0))) for c in range(nclass)]
         # the engine's dense PGE is not used (pge_hidden = 4 keeps its buffers small); the structure comes from the IGNR
-        shapes = EngineShapes(features.shape[0], d, nclass, n, args.ntrans, args.hidden, 4, 256, sizes[0], sizes[-1], fmid=tuple(sizes[1:-1]))
+        shapes = EngineShapes(features.shape[0], d, nclass, n, args.ntrans, args.hidden, 4, 256, sizes[0], sizes[-1], fmid=tuple(sizes[1:-1]),
+                              dropout=dropout if args.ntrans == 2 else 0.0)
         cls_ptr = np.concatenate([[0], np.cumsum([len(p) for p in pools])])
         eng = self.engine = GCondEngine(shapes, features, csr, cls_ptr, np.concatenate(pools), np.asarray(data.labels_syn), ranges,
                                         lr_feat=args.lr_feat, lr_adj=args.lr_adj, lr_model=args.lr, inner_loop=args.inner_loop,

@@ -335,9 +335,10 @@ typedef struct gs_gcond_config {
   float dropout;           /* models/base.py:20 / models/sgc.py:42: F.dropout behind every transform but the last, active inside train_class
                               (one fresh mask per class on the real batch and one per class on the synthetic graph) and in every inner
                               step (gcond.py:45: training mode).  0 (every shipped configuration): none.  In (0, 1): SGC with two
-                              transforms, no BatchNorm; with one transform there is no such layer and the value has no effect, as
+                              transforms, or the GCN condensation model with nlayers 2 .. 4 (models/base.py:59: nlayers - 1 masks per
+                              forward), no BatchNorm; SGC with one transform has no such layer and the value has no effect, as
                               upstream.  torch's generator cannot be replayed, so the masks are the counter-based function of (seed,
-                              iteration, kind, class | step, row, column) stated in csrc/gs_kernels.h (gs_drop_mult4): Bernoulli(1 - p)
+                              iteration, kind + 3 x hidden layer, class | step, row, column) stated in csrc/gs_kernels.h (gs_drop_mult4): Bernoulli(1 - p)
                               entries scaled by 1 / (1 - p), p resolved to 1 / 65536 */
 } gs_gcond_config;
 

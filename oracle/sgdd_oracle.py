@@ -164,8 +164,8 @@ class SGDDState:
             x_in = self.feat_syn.detach()
             adj_in = ignr_structure(x_in, {k: v.detach() for k, v in self.p.items()}, self.run, self.ep, train=False)
             adj_in_norm = O.dense_gcn_norm(adj_in)
-        for _ in range(inner_loop):
-            out = O.sgc_forward(x_in, adj_in_norm, self.model, self.nlayers)
+        for i in range(inner_loop):      # (sgdd.py:62 model.train(): dropout draws a fresh mask per step, like GCond — golden G30)
+            out = O.sgc_forward(x_in, adj_in_norm, self.model, self.nlayers, ("inner", i, None))
             gm = torch.autograd.grad(F.nll_loss(out, self.labels_syn), self.model)
             self.opt_model.step(list(gm))
         return ml.detach(), reg.detach(), grads[0].detach(), dict(zip(PARAM_ORDER, [g.detach() for g in gp])), adj_in

@@ -1261,6 +1261,58 @@ def g20():
     save("g20_sgdd", **out)
 
 
+def g30():
+    """`--dropout` in the sibling methods: WHEN upstream's condensation model draws masks.  MSGC puts the model into eval mode before
+    every train_class (msgc.py:99 `basic_model.eval()  # fix basic_model while optimizing graphsyner`) and never back into training
+    mode, so F.dropout(training=False) is the identity in train_class AND in the inner steps: a run with dropout 0.4 reproduces the run
+    with dropout 0 bit for bit and draws no mask.  SGDD calls model.train() per epoch (sgdd.py:62) like GCond: per outer iteration
+    2 x nclass masks in train_class + one per inner step, and another loss sequence.  The fixture records both facts (two transforms)."""
+    from graphslim.condensation.msgc import MSGC
+    from graphslim.condensation.sgdd import SGDD
+    out = {}
+    real_dropout = torch.nn.functional.dropout
+    for method in ("msgc", "sgdd"):
+        for tag, p_drop in (("p0", 0.0), ("p4", 0.4)):
+            tmp = tempfile.mkdtemp(prefix="golden_")
+            try:
+                n, nclass, d = 90, 3, 8
+                a, x, y = make_graph(n, nclass, d, 5, seed=71)
+                data = FakeData(a, x, y, nclass, [8, 10, 14], 20, 30, seed=6, sizes=(4, 3))
+                epochs, outer, inner = 2, 2, 2
+                extra = dict(batch_adj=2) if method == "msgc" else dict(mx_size=40, opt_scale=1e-7, ep_ratio=0.5, sinkhorn_iter=10)
+                args = args_obj(ntrans=2, hidden=12, reduction_rate=0.5, dataset="ogbn-arxiv", epochs=epochs, outer_loop=outer,
+                                inner_loop=inner, checkpoints=[], save_path=tmp, logger=CapLogger(), lr_feat=0.01, lr_adj=0.01,
+                                seed=1, method=method, dropout=p_drop, **extra)
+                RU.seed_everything(args.seed)
+                agent = (MSGC if method == "msgc" else SGDD)("trans", data, args)
+                losses, calls = [], [0]
+                orig = agent.train_class
+
+                def spy(*a_, **k_):
+                    l = orig(*a_, **k_)
+                    losses.append(float(l))
+                    return l
+
+                def counting_dropout(t, p=0.5, training=True, inplace=False):
+                    calls[0] += int(bool(training) and p > 0)
+                    return real_dropout(t, p, training, inplace)
+
+                agent.train_class = spy
+                torch.nn.functional.dropout = counting_dropout
+                try:
+                    agent.reduce(data, verbose=False)
+                finally:
+                    torch.nn.functional.dropout = real_dropout
+                out[f"{method}_{tag}_losses"] = np.array(losses)
+                out[f"{method}_{tag}_masks_drawn"] = np.array(calls[0])
+                out[f"{method}_{tag}_feat_syn"] = np_(agent.feat_syn).copy()
+                out[f"{method}_meta"] = np.array([nclass, epochs, outer, inner])
+                print(f"g30 {method} dropout {p_drop}: masks drawn {calls[0]}, losses {losses}")
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+    save("g30_siblings_dropout", **out)
+
+
 def g21():
     """What the reference's gradient-matching family does with a MULTI-LABEL dataset (configs/gcond/{yelp,amazon}.json, config.py
     setting_config: metric f1, multi_label): GCondBase.__init__ calls generate_labels_syn (gcond_base.py:93-115), which counts
@@ -1300,6 +1352,6 @@ def g22():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16",
-                             "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26", "g27", "g28", "g29"]
+                             "g17", "g18", "g19", "g20", "g21", "g22", "g23", "g24", "g25", "g26", "g27", "g28", "g29", "g30"]
     for w in which:
         globals()[w]()

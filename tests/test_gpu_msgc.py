@@ -254,6 +254,32 @@ def test_msgc_reduce_api(tmp_path, nlayers):
     assert mean > 0.3, mean
 
 
+def test_msgc_dropout_has_no_effect_as_upstream(tmp_path, golden_dir):
+    """`--dropout` with `-M msgc`: upstream puts the condensation model into eval mode before every train_class and never back
+    (msgc.py:99), so no mask is ever drawn — golden G30 records the reference's run with dropout 0.4 reproducing dropout 0 bit for bit.
+    Here: accepted, and the condensed graph is bitwise the one of the run without it (two transforms, where GCond / SGDD do draw masks)."""
+    import graphslim  # noqa: F401
+    from graphslim.config import cli
+    from graphslim.condensation import MSGC
+    from graphslim.dataset import get_dataset
+    from graphslim_amd.host import seed_everything
+    g = load_golden(golden_dir, "g30_siblings_dropout")
+    assert int(g["msgc_p4_masks_drawn"]) == 0 and np.array_equal(g["msgc_p0_losses"], g["msgc_p4_losses"])
+    assert np.array_equal(g["msgc_p0_feat_syn"], g["msgc_p4_feat_syn"])
+    out = []
+    for extra in ([], ["--dropout", "0.4"]):
+        args = cli(["-D", "cora", "-M", "msgc", "-R", "0.25", "-G", "0", "--epochs", "10", "--outer_loop", "2", "--inner_loop", "2", "--ntrans", "2",
+                    "--hidden", "64", "--init", "averaging", "--save_path", str(tmp_path)] + extra, standalone_mode=False)
+        args.run_inter_eval, args.checkpoints = 1, []
+        graph = get_dataset(args.dataset, args)
+        seed_everything(args.seed)
+        agent = MSGC(setting=args.setting, data=graph, args=args)
+        agent.reduce(graph, verbose=False)
+        assert agent.engine.shapes.dropout == 0.0
+        out.append((agent.feat_syn.clone(), agent.adj_syn.clone()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("tag", ["t1", "t2"])
 def test_block_products_equal_the_dense_products(golden_dir, tag):
     """gs_gcond_set_block_structure: the per-block A^ A^ and dQ A^^T + A^^T dQ products give the iteration the dense products give

@@ -98,7 +98,7 @@ def test_transport_regulariser_against_fp64_autograd(n, mx, seed):
     assert float(reg.acc) == pytest.approx(float(reg.value), rel=1e-6)
 
 
-def _golden_setup(g, tag, sizes=(4, 3)):
+def _golden_setup(g, tag, sizes=(4, 3), dropout=0.0, seed=1):
     from graphslim_amd import host as H
     from graphslim_amd.condensation.sgdd import SGDDLoop
     from graphslim_amd.engine import EngineShapes, GCondEngine
@@ -112,9 +112,9 @@ def _golden_setup(g, tag, sizes=(4, 3)):
     assert np.array_equal(labels_syn, g[f"{tag}_labels_syn"])
     params = H.init_ignr_params(d, len(labels_syn), mx)
     sel = H.random_init_indices(idx_train, labels_train, ncd)
-    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, 4, 32, sizes[0], sizes[-1], fmid=tuple(sizes[1:-1]))
+    sh = EngineShapes(n, d, nclass, len(labels_syn), t, hidden, 4, 32, sizes[0], sizes[-1], fmid=tuple(sizes[1:-1]), dropout=dropout)
     eng = GCondEngine(sh, torch.from_numpy(x), None, None, None, labels_syn, [tuple(ranges[c]) for c in range(nclass)], lr_feat=0.01,
-                      lr_adj=0.01, lr_model=0.01, inner_loop=inner, external_blocks=True, device=DEV)
+                      lr_adj=0.01, lr_model=0.01, inner_loop=inner, seed=seed, external_blocks=True, device=DEV)
     eng.set_feat(torch.from_numpy(x[sel]))
     loop = SGDDLoop(eng, params, g[f"{tag}_Lx_inv"], 0.5, scale, 0.01, 0.01)
     H.init_sgc_params(d, hidden, nclass, t)                       # model constructor draw
@@ -173,6 +173,73 @@ def test_one_outer_iteration_against_the_oracle(golden_dir, tag, epoch, sizes):
         assert float((loop.gen.dX.cpu() - g_x).abs().max()) <= 2e-3 * float(g_x.abs().max())
         np.testing.assert_allclose(eng.feat_syn.cpu().numpy(), st.feat_syn.detach().numpy(), atol=2e-5)
         np.testing.assert_allclose(loop.adj_inner.cpu().numpy(), adj_in.numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize("epoch", [0, 10])
+def test_one_outer_iteration_with_dropout_against_the_oracle(golden_dir, epoch):
+    """`--dropout` with `-M sgdd` (round 6): sgdd.py:62 puts the condensation model into training mode like GCond — golden G30 counts
+    upstream's masks (2 x nclass per train_class + one per inner step) — so the engine's dropout stage runs under the IGNR's structure:
+    two iterations of sgdd.py:64-95 (the loop advances the masks' counter) with the engine's masks handed to the oracle — matching loss,
+    d total / d X~, the IGNR's gradients, the updated tensors, the model after the inner steps under their own masks."""
+    from graphslim_amd import host as H
+    from graphslim_amd.engine import dropout_keep
+    g, tag, p_drop, seed = load_golden(golden_dir, "g20_sgdd"), "t2", 0.4, 5
+    s = _golden_setup(g, tag, dropout=p_drop, seed=seed)
+    n, nclass, d, hidden, t, inner, epochs, outer, mx = s["meta"]
+    eng, loop = s["eng"], s["loop"]
+    model = H.init_sgc_params(d, hidden, nclass, t)
+    eng.set_model(model)
+    st = S.SGDDState(torch.from_numpy(s["x"][s["sel"]]), s["params"], torch.from_numpy(s["labels_syn"]), s["ncd"], nclass,
+                     torch.from_numpy(g[f"{tag}_Lx_inv"]), 0.01, 0.01, 0.01, 0.5, s["scale"])
+    st.new_epoch(model)
+
+    def masks(iteration):
+        def hook(where, x):
+            kind, index, rows = where[:3]
+            rows = np.arange(x.shape[0]) if rows is None else np.asarray(rows)
+            keep = dropout_keep(seed, iteration, kind, index, rows, x.shape[1], p_drop)
+            return torch.from_numpy(keep).to(x.dtype) * torch.tensor(np.float32(1.0 / (1.0 - p_drop))).to(x.dtype)
+        return hook
+
+    losses = []
+    try:
+        for it in range(2):
+            batches, blocks = _blocks(s, it * nclass)
+            eng.set_blocks(blocks)
+            loop.step(epoch)
+            assert eng.dropout_iter() == it
+            O.DROPOUT = masks(it)
+            ml, reg, g_x, g_p, adj_in = st.outer_iteration(epoch, batches, torch.from_numpy(s["x"]), torch.from_numpy(s["y"]).long(), inner)
+            O.DROPOUT = None
+            losses.append(float(ml))
+            assert abs(float(eng.buffer("loss")[0]) - float(ml)) <= 1e-4 * abs(float(ml)), (it, float(eng.buffer("loss")[0]), float(ml))
+            got = {k: v.cpu() for k, v in loop.gen.views(loop.gen.grad).items()}
+            for k, b in g_p.items():
+                if k in ("out_w", "out_b", "P") or (k.endswith("_b") and k[1] in "01") or epoch % 50 >= 10:
+                    continue
+                err = float((got[k] - b.reshape(got[k].shape)).abs().max())
+                assert err <= 2e-3 * float(b.abs().max()) + 1e-12, (it, k, err, float(b.abs().max()))
+            if epoch % 50 >= 10:
+                assert float((loop.gen.dX.cpu() - g_x).abs().max()) <= 2e-3 * float(g_x.abs().max())
+                np.testing.assert_allclose(eng.feat_syn.cpu().numpy(), st.feat_syn.detach().numpy(), atol=3e-5)
+            # the oracle continues from the engine's state, so that the second iteration is compared on identical inputs
+            with torch.no_grad():
+                st.feat_syn.copy_(eng.feat_syn.cpu())
+                for k, v in loop.gen.views().items():
+                    st.p[k].copy_(v.cpu().reshape(st.p[k].shape))
+            for a, b in zip(eng.get_model(), st.model):
+                np.testing.assert_allclose(a.cpu().numpy(), b.detach().numpy(), atol=3e-4 if epoch % 50 >= 10 else 5e-3)
+                with torch.no_grad():
+                    b.copy_(a.cpu())
+    finally:
+        O.DROPOUT = None
+    # without the masks the oracle lands elsewhere: the comparison gates the dropout path
+    s0 = _golden_setup(g, tag)
+    s0["eng"].set_model(model)
+    batches, blocks = _blocks(s0, 0)
+    s0["eng"].set_blocks(blocks)
+    s0["loop"].step(epoch)
+    assert abs(float(s0["eng"].buffer("loss")[0]) - losses[0]) > 1e-3 * abs(losses[0])
 
 
 @pytest.mark.parametrize("tag", ["t1", "t2"])

@@ -329,6 +329,25 @@ def test_g29_gcn_dropout_train_class_and_inner_steps(golden_dir, tag):
     assert abs(float(loss0) - float(g[f"{tag}_loss"])) > 1e-3 * abs(float(g[f"{tag}_loss"]))      # (ten times the gate above)
 
 
+def test_g30_dropout_in_the_sibling_methods(golden_dir):
+    """Golden G30 — WHEN the reference's sibling methods draw dropout masks (two transforms, dropout 0.4 against 0): MSGC never does
+    (msgc.py:99 `basic_model.eval()` before every train_class, never back to training mode): no mask drawn, losses and X~ bit for bit
+    those of the run without dropout — so graphslim_amd's MSGC accepts the value without effect; SGDD (sgdd.py:62 model.train()) draws
+    2 x nclass masks per train_class and one per inner step, as the restatement does (sgdd_oracle.SGDDState: train_class + the inner
+    loop's ("inner", i) hook) and the engine's dropout stage under the IGNR structure."""
+    g = load(golden_dir, "g30_siblings_dropout")
+    nclass, epochs, outer, inner = [int(v) for v in g["sgdd_meta"]]
+    assert int(g["msgc_p0_masks_drawn"]) == 0 and int(g["msgc_p4_masks_drawn"]) == 0
+    assert np.array_equal(g["msgc_p0_losses"], g["msgc_p4_losses"]) and np.array_equal(g["msgc_p0_feat_syn"], g["msgc_p4_feat_syn"])
+    assert int(g["sgdd_p0_masks_drawn"]) == 0 and int(g["sgdd_p4_masks_drawn"]) == epochs * outer * (2 * nclass + inner)
+    assert np.abs(g["sgdd_p0_losses"] - g["sgdd_p4_losses"]).min() > 1e-2
+    import inspect
+    import oracle.msgc_oracle as M
+    import oracle.sgdd_oracle as S
+    assert "DROPOUT" not in inspect.getsource(M.sgc_forward_batched)           # MSGC's restatement has no dropout stage
+    assert '("inner", i, None)' in inspect.getsource(S.SGDDState.outer_iteration)
+
+
 @pytest.mark.parametrize("tag", ["cora_like", "arxiv_like"])
 def test_g8_full_reduce_and_evaluate(golden_dir, tag):
     """Replays a whole reference run (GCond.__init__ + reduce + intermediate evals + Evaluator.evaluate)."""
