@@ -40,7 +40,8 @@ int gs_chain_group(const gs_gemm_desc*, int, const gs_adam_ep*, hipStream_t);
 int gs_panel_rows(const float*, long, const float*, long, const float*, int, float*, long, int, int, const int*, const int*, int, long, int,
                   void*, unsigned*, long, hipStream_t);
 int gs_dedup_last(const int*, const float*, const int*, int, int, int, int*, int, int*, int*, int*, int*, int*, int, int*, int*, void*, void*,
-                  hipStream_t);   // gs_sampler.hip
+                  int*, hipStream_t);   // gs_sampler.hip
+extern "C" long gs_dedup_scratch_ints(int nclass, int cap0);
 int gs_edge_launch_entries(const gs_gemm_desc& d, const void* erow, const void* ew, const int* plan, int max_slabs, hipStream_t s);   // gs_edge.hip
 // gs_inner.hip: the inner SGC steps as one persistent launch
 struct gs_inner_ws {
@@ -151,6 +152,7 @@ struct gs_gcond {
   // (n0 / src0 / sptr0 / sedge0: distinct sources + CSC; nent / ent_src / ent_row / ent_w: the edge product's K entries — a source and up
   // to two of its in-edges as (row of Y, weight))
   struct { int *n0, *src0, *sptr0, *sedge0, *cur0, *nent, *ent_src; int2* ent_row; float2* ent_w; } dd[2];
+  int* dd_scr;                       // scratch of the de-duplication's chain of launches (gs_dedup_scratch_ints)
   int cap0;                            // capacity per class = capL * f2 (0: the form is not available for this configuration)
   bool dd_valid[2];                    // dd[q] describes the blocks of buffer q (built behind a sampling / upload while the knob is on, else on demand)
   // the inner steps as one persistent launch (gs_inner.hip): workspace block, its carve, the host's copy of the arrival counter
@@ -474,6 +476,7 @@ static size_t carve(gs_gcond* e, void* base) {
     e->dd[q].nent = c0p ? w.take<int>(C) : nullptr; e->dd[q].ent_src = c0p ? w.take<int>(C * c0p) : nullptr;
     e->dd[q].ent_row = c0p ? w.take<int2>(C * c0p) : nullptr; e->dd[q].ent_w = c0p ? w.take<float2>(C * c0p) : nullptr;
   }
+  e->dd_scr = e->cap0 ? w.take<int>(gs_dedup_scratch_ints((int)C, e->cap0)) : nullptr;
   for (int k = 0; k < 2; ++k) {
     e->Hmid_full[k] = k < e->deep ? w.take<float>(N * h) : nullptr;
     e->Hmid_s[k] = k < e->deep ? w.take<float>(n * h) : nullptr;
@@ -638,6 +641,10 @@ extern "C" int gs_gcond_create(const gs_gcond_config* cfg, const gs_gcond_io* io
   }
   carve(e, io->workspace);
   hipStream_t s = (hipStream_t)stream;
+  // Once, off the hot path: the fixed-capacity gather outputs keep their padding rows UNWRITTEN (gs_gcond_set_pad_zero) and
+  // nothing reads them through a live index — but a buffer read (gs_gcond_buffer) or a caller's blocks whose padding slots point at
+  // them must find finite values, whatever the caller's allocation held.
+  (void)hipMemsetAsync(io->workspace, 0, need, s);
   const int C = e->C;
   int* lo = new int[C];
   int* hi = new int[C];
@@ -1013,7 +1020,7 @@ static int dedup_into(gs_gcond* e, int which, gs_stream_t stream, bool force) {
   return gs_dedup_last(b.col0, b.val0, b.n1, e->capL, e->f2, e->N, e->marker + c0 * e->N, e->c_hi - e->c_lo, e->dd[which].n0 + c0,
                        e->dd[which].src0 + c0 * cap0, e->dd[which].sptr0 + c0 * (cap0 + 1), e->dd[which].sedge0 + c0 * cap0,
                        e->dd[which].cur0 + c0 * (cap0 + 1), e->cap0, e->dd[which].nent + c0, e->dd[which].ent_src + c0 * cap0,
-                       e->dd[which].ent_row + c0 * cap0, e->dd[which].ent_w + c0 * cap0, (hipStream_t)stream);
+                       e->dd[which].ent_row + c0 * cap0, e->dd[which].ent_w + c0 * cap0, e->dd_scr, (hipStream_t)stream);
 }
 
 static int sample_into(gs_gcond* e, int which, gs_stream_t stream) {

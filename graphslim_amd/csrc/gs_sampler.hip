@@ -637,12 +637,266 @@ __global__ __launch_bounds__(GS_DD_THREADS) void gs_dedup_last_kernel(const int*
   }
 }
 
+// ---- the same structure by a chain of chip-wide launches (round 6) --------------------------------------------------------------------
+// The one-workgroup-per-class kernel above takes 373 us per sampling at ogbn-arxiv (40 workgroups, serial scans over 14 080 slots) and its
+// 1 024-thread workgroups hold compute units the persistent products of the main chain count on.  Here every phase is a launch over
+// (chunks of 1 024 slots or sources) x classes, 256 threads each; the two scans are two-level (chunk sums, then chunk base + in-chunk
+// scan).  Bitwise the structure of the kernel above: local ids in the order of the first edge slot, slots ascending per source, entries
+// in source order.  scratch (ints): [C][GS_DDM_CH] first-slot counts per slot chunk | [C][GS_DDM_CH] in-edge sums per source chunk |
+// [C][GS_DDM_CH] entry sums per source chunk | [C][cap0 + 1] entry offset per source | [C] number of LONG lists | [C][cap0 / GS_DDM_SMALL
+// + 1] their sources.  A source sampled by many frontier rows (a hub) has a long slot list: lists of more than GS_DDM_SMALL slots are
+// sorted by a workgroup in LDS (bitonic) instead of by one thread (the one-thread insertion sort of a 1 000-slot list was most of the
+// first form's 373 us).
+#define GS_DDM_CHUNK 1024
+#define GS_DDM_CH 64      // chunks per class at most (65 536 slots)
+#define GS_DDM_SMALL 16
+#define GS_DDM_LDS 16384  // ints: the longest list the workgroup sort holds
+__device__ __forceinline__ long ddm_off_eoff(int C) { return 3L * C * GS_DDM_CH; }
+__device__ __forceinline__ long ddm_off_nbig(int C, int cap0) { return 3L * C * GS_DDM_CH + (long)C * (cap0 + 1); }
+__device__ __forceinline__ long ddm_off_big(int C, int cap0) { return ddm_off_nbig(C, cap0) + C; }
+__device__ __forceinline__ int ddm_big_cap(int cap0) { return cap0 / GS_DDM_SMALL + 1; }
+// 1. first occurrence (lowest slot) of every source; cur <- 0
+__global__ __launch_bounds__(256) void gs_ddm_first_kernel(const int* __restrict__ col0, const float* __restrict__ val0,
+                                                           const int* __restrict__ n_last, int cap_last, int f2, int n_nodes, int* marker,
+                                                           int* __restrict__ cur0, int cap0, int* __restrict__ scratch) {
+  const int c = blockIdx.y, sl = blockIdx.x * 256 + threadIdx.x;
+  if (sl <= cap0) cur0[(long)c * (cap0 + 1) + sl] = 0;
+  if (sl == 0) scratch[ddm_off_nbig(gridDim.y, cap0) + c] = 0;
+  if (sl >= n_last[c] * f2) return;
+  const long o = (long)c * cap_last * f2 + sl;
+  if (val0[o] != 0.f) atomicMin(&marker[(long)c * n_nodes + col0[o]], sl);
+}
+// 2. / 3. slots that are their source's first: count per chunk (assign = 0), then local ids in slot order (assign = 1)
+template <int ASSIGN>
+__global__ __launch_bounds__(256) void gs_ddm_ids_kernel(const int* __restrict__ col0, const float* __restrict__ val0,
+                                                         const int* __restrict__ n_last, int cap_last, int f2, int n_nodes, int* marker,
+                                                         int* __restrict__ n0, int* __restrict__ src0, int cap0, int* __restrict__ scratch) {
+  __shared__ int s_w[4];
+  const int c = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const int nslots = n_last[c] * f2;
+  const int nch = (nslots + GS_DDM_CHUNK - 1) / GS_DDM_CHUNK;
+  if (ch >= nch && !(ASSIGN && ch == 0)) return;
+  const int* colc = col0 + (long)c * cap_last * f2;
+  const float* valc = val0 + (long)c * cap_last * f2;
+  int* mk = marker + (long)c * n_nodes;
+  int* cnt = scratch + (long)c * GS_DDM_CH;
+  const int lo = ch * GS_DDM_CHUNK + tid * 4;
+  unsigned win = 0;
+  int g[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int sl = lo + j;
+    g[j] = 0;
+    if (sl < nslots && valc[sl] != 0.f) {
+      g[j] = colc[sl];
+      win |= (mk_load(&mk[g[j]]) == sl ? 1u : 0u) << j;
+    }
+  }
+  int tot = 0;
+  int lid = block_excl_scan_256(__popc(win), s_w, &tot);
+  if (!ASSIGN) {
+    if (tid == 0) cnt[ch] = tot;
+    return;
+  }
+  int base = 0, all = 0;
+  for (int i = 0; i < nch; ++i) {
+    const int t = cnt[i];
+    if (i < ch) base += t;
+    all += t;
+  }
+  if (ch == 0 && tid == 0) n0[c] = all;
+  lid += base;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if ((win >> j) & 1u) {
+      src0[(long)c * cap0 + lid] = g[j];
+      mk_store(&mk[g[j]], lid - GS_MARK_BIAS);      // (every other slot of this source compares its own index with the marker: no longer equal)
+      ++lid;
+    }
+}
+// 4. / 6. in-degree counts (FILL = 0) and the slot lists (FILL = 1: cur is the fill cursor)
+template <int FILL>
+__global__ __launch_bounds__(256) void gs_ddm_edges_kernel(const int* __restrict__ col0, const float* __restrict__ val0,
+                                                           const int* __restrict__ n_last, int cap_last, int f2, int n_nodes,
+                                                           const int* marker, int* __restrict__ cur0, int* __restrict__ sedge0, int cap0) {
+  const int c = blockIdx.y, sl = blockIdx.x * 256 + threadIdx.x;
+  if (sl >= n_last[c] * f2) return;
+  const long o = (long)c * cap_last * f2 + sl;
+  if (val0[o] == 0.f) return;
+  const int l = mk_load(&marker[(long)c * n_nodes + col0[o]]) + GS_MARK_BIAS;
+  const int pos = atomicAdd(&cur0[(long)c * (cap0 + 1) + l], 1);
+  if (FILL) sedge0[(long)c * cap0 + pos] = sl;
+}
+// 5. exclusive scans over the sources: in-edge counts -> sptr / fill cursor, ceil(count / 2) -> entry offsets.  WRITE = 0: chunk sums
+template <int WRITE>
+__global__ __launch_bounds__(256) void gs_ddm_scan_kernel(const int* __restrict__ n0, int* __restrict__ sptr0, int* __restrict__ cur0,
+                                                          int cap0, int* __restrict__ nent, int* __restrict__ scratch, int C) {
+  __shared__ int s_w[4];
+  const int c = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  const int nc = n0[c];
+  const int nch = (nc + 1 + GS_DDM_CHUNK - 1) / GS_DDM_CHUNK;      // nc + 1 entries: sptr[nc] closes the last list
+  if (ch >= nch) return;
+  int* cur = cur0 + (long)c * (cap0 + 1);
+  int* sums = scratch + (long)C * GS_DDM_CH + (long)c * GS_DDM_CH;
+  int* esums = scratch + 2L * C * GS_DDM_CH + (long)c * GS_DDM_CH;
+  int* eoff = scratch + 3L * C * GS_DDM_CH + (long)c * (cap0 + 1);
+  const int lo = ch * GS_DDM_CHUNK + tid * 4;
+  int cnt[4], sum = 0, esum = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    cnt[j] = lo + j < nc ? cur[lo + j] : 0;
+    sum += cnt[j];
+    esum += (cnt[j] + 1) >> 1;
+  }
+  int tot = 0, etot = 0;
+  int off = block_excl_scan_256(sum, s_w, &tot);
+  int eo = block_excl_scan_256(esum, s_w, &etot);
+  if (!WRITE) {
+    if (tid == 0) { sums[ch] = tot; esums[ch] = etot; }
+    return;
+  }
+  int base = 0, ebase = 0, eall = 0;
+  for (int i = 0; i < nch; ++i) {
+    if (i < ch) { base += sums[i]; ebase += esums[i]; }
+    eall += esums[i];
+  }
+  if (ch == 0 && tid == 0 && nent) nent[c] = eall;
+  off += base; eo += ebase;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (lo + j <= nc) {
+      sptr0[(long)c * (cap0 + 1) + lo + j] = off;
+      cur[lo + j] = off;
+      eoff[lo + j] = eo;
+      off += cnt[j];
+      eo += (cnt[j] + 1) >> 1;
+      if (cnt[j] > GS_DDM_SMALL) {      // (the order of this list does not matter: each of its sources is finished on its own)
+        const int pos = atomicAdd(&scratch[ddm_off_nbig(C, cap0) + c], 1);
+        scratch[ddm_off_big(C, cap0) + (long)c * ddm_big_cap(cap0) + pos] = lo + j;
+      }
+    }
+}
+// 7. per source: the marker goes back to FREE, its slot list ascending, its entries
+__global__ __launch_bounds__(256) void gs_ddm_finish_kernel(const float* __restrict__ val0, int cap_last, int f2, int n_nodes, int* marker,
+                                                            const int* __restrict__ n0, const int* __restrict__ src0,
+                                                            const int* __restrict__ sptr0, int* __restrict__ sedge0, int cap0,
+                                                            const int* __restrict__ scratch, int C, int* __restrict__ ent_src,
+                                                            int2* __restrict__ ent_row, float2* __restrict__ ent_w) {
+  const int c = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= n0[c]) return;
+  const int g = src0[(long)c * cap0 + l];
+  mk_store(&marker[(long)c * n_nodes + g], GS_MARK_FREE);
+  int* sedge = sedge0 + (long)c * cap0;
+  const int a = sptr0[(long)c * (cap0 + 1) + l], b = sptr0[(long)c * (cap0 + 1) + l + 1];
+  if (b - a > GS_DDM_SMALL) return;      // a long list: gs_ddm_long_kernel
+  for (int i = a + 1; i < b; ++i) {
+    const int x = sedge[i];
+    int q = i - 1;
+    while (q >= a && sedge[q] > x) { sedge[q + 1] = sedge[q]; --q; }
+    sedge[q + 1] = x;
+  }
+  if (!ent_src) return;
+  const float* valc = val0 + (long)c * cap_last * f2;
+  int e = scratch[ddm_off_eoff(C) + (long)c * (cap0 + 1) + l];
+  for (int i = a; i < b; i += 2, ++e) {
+    const int s0 = sedge[i], s1 = i + 1 < b ? sedge[i + 1] : s0;
+    ent_src[(long)c * cap0 + e] = g;
+    ent_row[(long)c * cap0 + e] = make_int2(s0 / f2, s1 / f2);
+    ent_w[(long)c * cap0 + e] = make_float2(valc[s0], i + 1 < b ? valc[s1] : 0.f);
+  }
+}
+
+// 8. the long lists: one workgroup per list at a time — bitonic sort in LDS, then its entries by all threads
+__global__ __launch_bounds__(256) void gs_ddm_long_kernel(const float* __restrict__ val0, int cap_last, int f2, const int* __restrict__ src0,
+                                                          const int* __restrict__ sptr0, int* __restrict__ sedge0, int cap0,
+                                                          const int* __restrict__ scratch, int C, int* __restrict__ ent_src,
+                                                          int2* __restrict__ ent_row, float2* __restrict__ ent_w) {
+  __shared__ int s_v[GS_DDM_LDS];
+  const int c = blockIdx.y, tid = threadIdx.x;
+  const int nbig = scratch[ddm_off_nbig(C, cap0) + c];
+  const int* big = scratch + ddm_off_big(C, cap0) + (long)c * ddm_big_cap(cap0);
+  const float* valc = val0 + (long)c * cap_last * f2;
+  int* sedge = sedge0 + (long)c * cap0;
+  for (int bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    const int l = big[bi];
+    const int a = sptr0[(long)c * (cap0 + 1) + l], k = sptr0[(long)c * (cap0 + 1) + l + 1] - a;
+    const int* sorted = sedge + a;
+    __syncthreads();      // (s_v of the previous list)
+    if (k <= GS_DDM_LDS) {
+      int n2 = 1;
+      while (n2 < k) n2 <<= 1;
+      for (int i = tid; i < n2; i += 256) s_v[i] = i < k ? sedge[a + i] : 0x7fffffff;
+      __syncthreads();
+      for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+          for (int t = tid; t < (n2 >> 1); t += 256) {
+            const int i = 2 * t - (t & (stride - 1)), j = i + stride;      // i has bit `stride` clear
+            const bool up = (i & size) == 0;
+            const int x = s_v[i], y = s_v[j];
+            if ((x > y) == up) { s_v[i] = y; s_v[j] = x; }
+          }
+          __syncthreads();
+        }
+      for (int i = tid; i < k; i += 256) sedge[a + i] = s_v[i];
+      sorted = s_v;
+    } else {      // (more than 16 384 of a class's slots on ONE source: one thread, heap sort in place — correct, slow, not expected)
+      if (tid == 0) {
+        int* v = sedge + a;
+        for (int st = k / 2 - 1; st >= 0; --st)
+          for (int r = st;;) { int ch = 2 * r + 1; if (ch >= k) break; if (ch + 1 < k && v[ch + 1] > v[ch]) ++ch; if (v[r] >= v[ch]) break; const int t = v[r]; v[r] = v[ch]; v[ch] = t; r = ch; }
+        for (int e = k - 1; e > 0; --e) {
+          const int t0 = v[0]; v[0] = v[e]; v[e] = t0;
+          for (int r = 0;;) { int ch = 2 * r + 1; if (ch >= e) break; if (ch + 1 < e && v[ch + 1] > v[ch]) ++ch; if (v[r] >= v[ch]) break; const int t = v[r]; v[r] = v[ch]; v[ch] = t; r = ch; }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    if (ent_src) {
+      const int g = src0[(long)c * cap0 + l];
+      const int e0 = scratch[ddm_off_eoff(C) + (long)c * (cap0 + 1) + l];
+      for (int j = tid; 2 * j < k; j += 256) {
+        const int s0 = sorted[2 * j], s1 = 2 * j + 1 < k ? sorted[2 * j + 1] : s0;
+        ent_src[(long)c * cap0 + e0 + j] = g;
+        ent_row[(long)c * cap0 + e0 + j] = make_int2(s0 / f2, s1 / f2);
+        ent_w[(long)c * cap0 + e0 + j] = make_float2(valc[s0], 2 * j + 1 < k ? valc[s1] : 0.f);
+      }
+    }
+  }
+}
+
+static int g_dedup_form = 1;      // 1: the chain of chip-wide launches (needs scratch); 0: one workgroup per class (measurement / test hook)
+extern "C" int gs_dedup_set_form(int form) {
+  if (form < 0 || form > 1) GS_FAIL(GS_ERR_ARG, "gs_dedup_set_form: 0 or 1");
+  g_dedup_form = form;
+  return GS_OK;
+}
+extern "C" long gs_dedup_scratch_ints(int nclass, int cap0) {
+  return 3L * nclass * GS_DDM_CH + (long)nclass * (cap0 + 1) + nclass + (long)nclass * (cap0 / GS_DDM_SMALL + 1);
+}
+
 // engine-internal (gs_engine.hip): the distinct-source structure of `nclass` classes' outermost blocks
 int gs_dedup_last(const int* col0, const float* val0, const int* n_last, int cap_last, int f2, int n_nodes, int* marker, int nclass,
                   int* n0, int* src0, int* sptr0, int* sedge0, int* cur0, int cap0, int* nent, int* ent_src, void* ent_row, void* ent_w,
-                  hipStream_t s) {
+                  int* scratch, hipStream_t s) {
   if (nclass < 1) return GS_OK;
   if ((long)cap_last * f2 > 32L * GS_DD_THREADS) GS_FAIL(GS_ERR_UNSUPPORTED, "gs_dedup_last: more than %d edge slots per class", 32 * GS_DD_THREADS);
+  if (g_dedup_form == 1 && scratch && cap0 == cap_last * f2 && cap0 <= GS_DDM_CH * GS_DDM_CHUNK) {
+    const dim3 gslot(gs_cdiv(cap0 + 1, 256), nclass), gch(gs_cdiv(cap0 + 1, GS_DDM_CHUNK), nclass), gsrc(gs_cdiv(cap0, 256), nclass);
+    hipLaunchKernelGGL(gs_ddm_first_kernel, gslot, dim3(256), 0, s, col0, val0, n_last, cap_last, f2, n_nodes, marker, cur0, cap0, scratch);
+    hipLaunchKernelGGL((gs_ddm_ids_kernel<0>), gch, dim3(256), 0, s, col0, val0, n_last, cap_last, f2, n_nodes, marker, n0, src0, cap0, scratch);
+    hipLaunchKernelGGL((gs_ddm_ids_kernel<1>), gch, dim3(256), 0, s, col0, val0, n_last, cap_last, f2, n_nodes, marker, n0, src0, cap0, scratch);
+    hipLaunchKernelGGL((gs_ddm_edges_kernel<0>), gslot, dim3(256), 0, s, col0, val0, n_last, cap_last, f2, n_nodes, marker, cur0, sedge0, cap0);
+    hipLaunchKernelGGL((gs_ddm_scan_kernel<0>), gch, dim3(256), 0, s, n0, sptr0, cur0, cap0, nent, scratch, nclass);
+    hipLaunchKernelGGL((gs_ddm_scan_kernel<1>), gch, dim3(256), 0, s, n0, sptr0, cur0, cap0, nent, scratch, nclass);
+    hipLaunchKernelGGL((gs_ddm_edges_kernel<1>), gslot, dim3(256), 0, s, col0, val0, n_last, cap_last, f2, n_nodes, marker, cur0, sedge0, cap0);
+    hipLaunchKernelGGL(gs_ddm_finish_kernel, gsrc, dim3(256), 0, s, val0, cap_last, f2, n_nodes, marker, n0, src0, sptr0, sedge0, cap0, scratch,
+                       nclass, nent ? ent_src : (int*)nullptr, (int2*)ent_row, (float2*)ent_w);
+    hipLaunchKernelGGL(gs_ddm_long_kernel, dim3(16, nclass), dim3(256), 0, s, val0, cap_last, f2, src0, sptr0, sedge0, cap0, scratch, nclass,
+                       nent ? ent_src : (int*)nullptr, (int2*)ent_row, (float2*)ent_w);
+    GS_LAUNCH_CHECK();
+    return GS_OK;
+  }
   hipLaunchKernelGGL(gs_dedup_last_kernel, dim3(nclass), dim3(GS_DD_THREADS), 0, s, col0, val0, n_last, cap_last, f2, n_nodes, marker, n0, src0,
                      sptr0, sedge0, cur0, cap0, nent, ent_src, (int2*)ent_row, (float2*)ent_w);
   GS_LAUNCH_CHECK();

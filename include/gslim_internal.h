@@ -94,6 +94,9 @@ int gs_gcond_set_inner_persist(int on);
  * side 452 -> 429 us alone, but the de-duplication kernel costs more than that beside the rest of the iteration: not the default.
  * Per engine: GS_KNOB_EDGE_SRC. */
 int gs_gcond_set_edge_src(int on);
+/* the de-duplication behind every sampling: 1 (default) = a chain of chip-wide launches, 0 = one workgroup per class (round 6's first form:
+ * measurement / test hook); bitwise the same structure */
+int gs_dedup_set_form(int form);
 int gs_inner_persist_set_grid(int workgroups);
 int gs_inner_persist_trace(void* device_u64_G_by_128);      /* measurement: s_memrealtime stamps around every grid barrier (NULL = off) */
 
