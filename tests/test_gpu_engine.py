@@ -1304,6 +1304,50 @@ def test_balanced_edge_slabs_give_the_fixed_slab_gradients(mode):
         _lib.check(L.gs_gcond_set_knob(eng.h, KNOB, -1))
 
 
+def _check_dedup_against_numpy(eng, c_lo, c_hi):
+    """The distinct-source structure of the engine's current blocks (dd_* buffers) against numpy: distinct sources by first live slot,
+    every live slot once in its source's list, lists ascending, entries = the lists cut in pairs.  Returns slots - entries."""
+    blk = eng.get_blocks()
+    col0, val0, n1 = (getattr(blk, k).cpu().numpy() for k in ("col0", "val0", "n1"))
+    dd = {k: eng.view(k, torch.int32).cpu().numpy() for k in ("dd_n0", "dd_src0", "dd_sptr0", "dd_sedge0")}
+    cap0 = col0.shape[1] * col0.shape[2]
+    fewer = 0
+    for c in range(c_lo, c_hi):
+        live = np.flatnonzero(val0[c, :n1[c]].reshape(-1) != 0)
+        srcs = col0[c, :n1[c]].reshape(-1)[live]
+        uniq, first = np.unique(srcs, return_index=True)
+        order = uniq[np.argsort(first)]                                   # distinct sources by first live slot
+        n0 = int(dd["dd_n0"][c])
+        assert n0 == len(order) and np.array_equal(dd["dd_src0"][c * cap0:c * cap0 + n0], order), c
+        sptr = dd["dd_sptr0"][c * (cap0 + 1):c * (cap0 + 1) + n0 + 1]
+        sedge = dd["dd_sedge0"][c * cap0:c * cap0 + sptr[-1]]
+        assert sptr[0] == 0 and sptr[-1] == len(live) and (np.diff(sptr) >= 1).all()
+        assert np.array_equal(np.sort(sedge), live)                       # every live slot exactly once
+        owner = np.repeat(np.arange(n0), np.diff(sptr))
+        assert np.array_equal(col0[c].reshape(-1)[sedge], order[owner])   # ... in its own source's list
+        asc = np.ones(len(sedge), bool)
+        asc[1:] = (np.diff(sedge) > 0) | (np.diff(owner) > 0)
+        assert asc.all()                                                  # ... lists ascending by slot
+        # the K entries: every source's list cut in pairs, (row of Y, weight) per edge, 0.f weight behind an odd tail
+        nent = int(eng.view("dd_nent", torch.int32)[c])
+        deg = np.diff(sptr)
+        assert nent == int(((deg + 1) // 2).sum())
+        esrc = eng.view("dd_ent_src", torch.int32)[c * cap0:c * cap0 + nent].cpu().numpy()
+        erow = eng.view("dd_ent_row", torch.int32)[2 * c * cap0:2 * (c * cap0 + nent)].cpu().numpy().reshape(-1, 2)
+        ew = eng.view("dd_ent_w")[2 * c * cap0:2 * (c * cap0 + nent)].cpu().numpy().reshape(-1, 2)
+        f2_ = col0.shape[2]
+        vflat = val0[c].reshape(-1)
+        starts = np.concatenate([np.arange(a, b, 2) for a, b in zip(sptr[:-1], sptr[1:])]) if n0 else np.zeros(0, int)
+        has2 = (starts + 1) < np.repeat(sptr[1:], (deg + 1) // 2)
+        s0 = sedge[starts]
+        s1 = np.where(has2, sedge[np.minimum(starts + 1, len(sedge) - 1)], s0)
+        assert np.array_equal(esrc, np.repeat(order, (deg + 1) // 2))
+        assert np.array_equal(erow, np.stack([s0 // f2_, s1 // f2_], 1))
+        assert np.array_equal(ew, np.stack([vflat[s0], np.where(has2, vflat[s1], 0.0)], 1).astype(np.float32))
+        fewer += len(live) - nent
+    return fewer
+
+
 @pytest.mark.parametrize("workload,scale,mode", [("ogbn-arxiv", 0.25, "f32"), ("ogbn-arxiv", 0.25, "bf16x6"), ("ogbn-arxiv", 1.0, "bf16x6"),
                                                  ("arxiv-gate-c8", 0.05, "bf16x6")])
 def test_edge_product_over_distinct_sources(workload, scale, mode):
@@ -1334,6 +1378,9 @@ def test_edge_product_over_distinct_sources(workload, scale, mode):
     shards = ((0, C), (1, 4), (C - 1, C)) if C > 8 else ((0, C), (2, 3))
     for c_lo, c_hi in shards:
         eng.set_shard(c_lo, c_hi, 0, len(p["labels_syn"]))
+        # (the last shard with the one-workgroup-per-class form of the de-duplication: the numpy check below pins the structure
+        # bit for bit, so both forms passing it are equal)
+        _lib.check(L.gs_dedup_set_form(0 if (c_lo, c_hi) == shards[-1] else 1))
         eng.stage_sample()
         _lib.check(L.gs_gcond_set_knob(eng.h, KNOB, 0))
         eng.stage_real_grads()
@@ -1348,49 +1395,9 @@ def test_edge_product_over_distinct_sources(workload, scale, mode):
         err = float(((got - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max())
         assert err <= 5e-6, (mode, c_lo, c_hi, err)
         assert torch.equal(got, again), (mode, c_lo, c_hi)
-        # the plan ran over the SOURCES: kcount = distinct sources
-        blk = eng.get_blocks()
-        col0, val0, n1 = (getattr(blk, k).cpu().numpy() for k in ("col0", "val0", "n1"))
-        dd = {k: eng.view(k, torch.int32).cpu().numpy() for k in ("dd_n0", "dd_src0", "dd_sptr0", "dd_sedge0")}
-        cap0 = col0.shape[1] * col0.shape[2]
-        fewer = 0
-        for c in range(c_lo, c_hi):
-            live = np.flatnonzero(val0[c, :n1[c]].reshape(-1) != 0)
-            srcs = col0[c, :n1[c]].reshape(-1)[live]
-            uniq, first = np.unique(srcs, return_index=True)
-            order = uniq[np.argsort(first)]                                   # distinct sources by first live slot
-            n0 = int(dd["dd_n0"][c])
-            assert n0 == len(order) and np.array_equal(dd["dd_src0"][c * cap0:c * cap0 + n0], order), c
-            sptr = dd["dd_sptr0"][c * (cap0 + 1):c * (cap0 + 1) + n0 + 1]
-            sedge = dd["dd_sedge0"][c * cap0:c * cap0 + sptr[-1]]
-            assert sptr[0] == 0 and sptr[-1] == len(live) and (np.diff(sptr) >= 1).all()
-            assert np.array_equal(np.sort(sedge), live)                       # every live slot exactly once
-            owner = np.repeat(np.arange(n0), np.diff(sptr))
-            assert np.array_equal(col0[c].reshape(-1)[sedge], order[owner])   # ... in its own source's list
-            asc = np.ones(len(sedge), bool)
-            asc[1:] = (np.diff(sedge) > 0) | (np.diff(owner) > 0)
-            assert asc.all()                                                  # ... lists ascending by slot
-            # the K entries: every source's list cut in pairs, (row of Y, weight) per edge, 0.f weight behind an odd tail
-            nent = int(eng.view("dd_nent", torch.int32)[c])
-            deg = np.diff(sptr)
-            assert nent == int(((deg + 1) // 2).sum())
-            esrc = eng.view("dd_ent_src", torch.int32)[c * cap0:c * cap0 + nent].cpu().numpy()
-            erow = eng.view("dd_ent_row", torch.int32)[2 * c * cap0:2 * (c * cap0 + nent)].cpu().numpy().reshape(-1, 2)
-            ew = eng.view("dd_ent_w")[2 * c * cap0:2 * (c * cap0 + nent)].cpu().numpy().reshape(-1, 2)
-            f2_ = col0.shape[2]
-            want_src, want_row, want_w = [], [], []
-            vflat = val0[c].reshape(-1)
-            for l in range(n0):
-                lst = sedge[sptr[l]:sptr[l + 1]]
-                for i in range(0, len(lst), 2):
-                    pair = lst[i:i + 2]
-                    want_src.append(order[l])
-                    want_row.append([pair[0] // f2_, pair[-1] // f2_])
-                    want_w.append([vflat[pair[0]], vflat[pair[1]] if len(pair) == 2 else 0.0])
-            assert np.array_equal(esrc, np.array(want_src)) and np.array_equal(erow, np.array(want_row))
-            assert np.array_equal(ew, np.array(want_w, dtype=np.float32))
-            fewer += len(live) - nent
+        fewer = _check_dedup_against_numpy(eng, c_lo, c_hi)
         assert fewer > 0      # (the form has something to save)
+    _lib.check(L.gs_dedup_set_form(1))
     # blocks supplied by the caller are de-duplicated on upload
     eng.set_shard(0, C, 0, len(p["labels_syn"]))
     eng.stage_sample()
@@ -1408,6 +1415,49 @@ def test_edge_product_over_distinct_sources(workload, scale, mode):
     ext.stage_real_grads()
     torch.cuda.synchronize()
     assert torch.equal(ext.view("gw_real"), want)
+
+
+def test_dedup_long_slot_lists():
+    """The de-duplication's long lists (csrc/gs_sampler.hip gs_ddm_long_kernel): a source sampled by many frontier rows.  Blocks of the
+    flickr shape (fan-out [15, 8]: 32 768 edge slots per class) are rewritten so that class 0 hangs EVERY live slot on one node (a list
+    beyond the 16 384 slots the workgroup sort holds in LDS: the one-thread heap sort), class 1 on two nodes alternately (two bitonic
+    sorts of thousands of slots), class 2 on 40 nodes (lists of hundreds) — uploaded through gs_gcond_set_blocks and checked against
+    numpy like the sampled blocks of test_edge_product_over_distinct_sources (which also compares the two forms of the de-duplication
+    bitwise; the one-workgroup form's one-thread insertion sort would take seconds on these lists)."""
+    import bench
+    from graphslim_amd import _lib
+    from graphslim_amd.engine import GCondEngine
+    L = _lib.lib()
+    p = bench.build_problem("flickr", seed=1, scale=0.3)
+    C = p["data"].nclass
+    eng = bench.make_engine(p, DEV)
+    bench.init_state(p, eng)
+    eng.stage_sample()
+    blocks = eng.get_blocks()
+    torch.cuda.synchronize()
+    n1 = blocks.n1.cpu().numpy()
+    f2 = blocks.col0.shape[2]
+    assert int(n1[0]) * f2 > 16384, (n1, f2)      # class 0's single list exceeds the LDS sort
+    for c, nodes in ((0, [7]), (1, [3, 11]), (2, list(range(100, 140)))):
+        k = int(n1[c]) * f2
+        pick = torch.tensor(nodes, dtype=torch.int32, device=DEV)[torch.arange(k, device=DEV) % len(nodes)]
+        blocks.col0[c].view(-1)[:k] = pick
+        blocks.val0[c].view(-1)[:k] = torch.where(blocks.val0[c].view(-1)[:k] != 0, blocks.val0[c].view(-1)[:k], torch.full((k,), 0.25, device=DEV))
+    KNOB = _lib.KNOBS["EDGE_SRC"]
+    ext = GCondEngine(eng.shapes, p["data"].bench_feat, None, None, None, p["labels_syn"], p["ranges"], lr_feat=p["lrf"], lr_adj=p["lra"],
+                      lr_model=0.01, inner_loop=p["inner"], external_blocks=True, device=DEV)
+    _lib.check(L.gs_gcond_set_knob(ext.h, KNOB, 1))
+    ext.set_blocks(blocks)
+    torch.cuda.synchronize()
+    assert _check_dedup_against_numpy(ext, 0, C) > 0
+    n0 = ext.view("dd_n0", torch.int32).cpu().numpy()
+    assert int(n0[0]) == 1 and int(n0[1]) == 2 and int(n0[2]) == 40
+    # the marker rows are FREE again: the same upload a second time gives the same structure
+    before = {k: ext.view(k, torch.int32).clone() for k in ("dd_n0", "dd_nent", "dd_ent_src")}
+    ext.set_blocks(blocks)
+    torch.cuda.synchronize()
+    assert _check_dedup_against_numpy(ext, 0, C) > 0
+    assert torch.equal(before["dd_n0"], ext.view("dd_n0", torch.int32)) and torch.equal(before["dd_nent"], ext.view("dd_nent", torch.int32))
 
 
 def test_every_knob_reports_its_process_default():
