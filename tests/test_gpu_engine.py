@@ -1435,9 +1435,11 @@ def test_dedup_long_slot_lists():
     eng.stage_sample()
     blocks = eng.get_blocks()
     torch.cuda.synchronize()
+    f2, cap1 = blocks.col0.shape[2], blocks.col0.shape[1]
+    # (the de-duplication reads col0 / val0 / n1 only — nothing else of these blocks is used here: every row of classes 0 and 1 is made live)
+    blocks.n1[0], blocks.n1[1] = cap1, (3 * cap1) // 4
     n1 = blocks.n1.cpu().numpy()
-    f2 = blocks.col0.shape[2]
-    assert int(n1[0]) * f2 > 16384, (n1, f2)      # class 0's single list exceeds the LDS sort
+    assert int(n1[0]) * f2 > 16384 and int(n1[1]) * f2 // 2 > 4096, (n1, f2)      # class 0's single list exceeds the LDS sort
     for c, nodes in ((0, [7]), (1, [3, 11]), (2, list(range(100, 140)))):
         k = int(n1[c]) * f2
         pick = torch.tensor(nodes, dtype=torch.int32, device=DEV)[torch.arange(k, device=DEV) % len(nodes)]
