@@ -54,7 +54,7 @@ class GCondIO(C.Structure):
 
 # measurement knobs / debug hooks declared in include/gslim_internal.h (not product ABI)
 INTERNAL_SYMBOLS = ["gs_panel_set_fwd_lds_pad", "gs_gemm_set_panel_tall", "gs_panel_set_hoist_share", "gs_panel_tall_debug", "gs_panel_tall_trace", "gs_gcond_set_edge_bits", "gs_gcond_set_edge_plan", "gs_gcond_set_ell_xcd", "gs_gcond_set_pad_zero", "gs_gcond_set_hoist_forward_all", "gs_gcond_set_knob",
-                    "gs_gcond_get_knob", "gs_gemm_set_tuning", "gs_gemm_set_small", "gs_gemm_set_panel", "gs_gemm_set_edge_kernel", "gs_gemm_set_panel_narrow_tail", "gs_gemm_set_panel_marg", "gs_gemm_set_panel_a1gen", "gs_panel_debug", "gs_gcond_set_folded_reductions", "gs_gcond_set_h1_bits", "gs_gcond_set_fused_chains", "gs_gcond_set_inner_persist", "gs_gcond_set_edge_src", "gs_dedup_set_form", "gs_inner_persist_set_grid", "gs_inner_persist_trace", "gs_gcond_set_h1_rows", "gs_gcond_set_dw1_generated", "gs_gcond_set_aux_priority", "gs_sample_set_cand_cap"]
+                    "gs_gcond_get_knob", "gs_gemm_set_tuning", "gs_gemm_set_small", "gs_gemm_set_panel", "gs_gemm_set_edge_kernel", "gs_gemm_set_panel_narrow_tail", "gs_gemm_set_panel_marg", "gs_gemm_set_panel_a1gen", "gs_panel_debug", "gs_gcond_set_folded_reductions", "gs_gcond_set_h1_bits", "gs_gcond_set_fused_chains", "gs_gcond_set_inner_persist", "gs_gcond_set_edge_src", "gs_dedup_set_form", "gs_panel_set_plain_share", "gs_inner_persist_set_grid", "gs_inner_persist_trace", "gs_gcond_set_h1_rows", "gs_gcond_set_dw1_generated", "gs_gcond_set_aux_priority", "gs_sample_set_cand_cap"]
 
 # engine-level knob ids of include/gslim_internal.h (gs_gcond_set_knob / gs_gcond_get_knob); tests/test_abi.py pins them to the enum
 KNOBS = {"FUSED_CHAINS": 0, "H1_ROWS": 1, "H1_BITS": 2, "EDGE_BITS": 3, "DW1_GENERATED": 4, "FOLDED_REDUCTIONS": 5,
@@ -223,6 +223,7 @@ def lib():
     L.gs_gcond_set_inner_persist.argtypes = [i]
     L.gs_gcond_set_edge_src.argtypes = [i]
     L.gs_dedup_set_form.argtypes = [i]
+    L.gs_panel_set_plain_share.argtypes = [i]
     L.gs_inner_persist_set_grid.argtypes = [i]
     L.gs_inner_persist_trace.argtypes = [vp]
     L.gs_gcond_set_h1_bits.argtypes = [i]

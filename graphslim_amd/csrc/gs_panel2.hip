@@ -710,6 +710,11 @@ static unsigned* g_tall_trace = nullptr;
 static int g_tall_split = 1;      // 1: waves 0-3 [prepare, MFMA], waves 4-7 [MFMA, prepare]; 0: every wave [MFMA, prepare]
 
 static int g_tall_hoist_share = 13;     // compute units (in sixteenths) the hoisted pass's persistent grid takes (gs_tall_forward_a1, alone = 2)
+static int g_tall_plain_share = 14;     // compute units (in sixteenths) of the persistent grid of H1 = relu(X W1 + b1) (gs_tall_plain): it is HBM-bound (the same 75 us on 12/16 of the chip) and a full grid holds every register file, so the main stream's first launches of the iteration waited for it (profiles/r06/stage_times_plain_share.txt: fused iteration 1 471 -> 1 448 us at 14/16)
+extern "C" int gs_panel_set_plain_share(int sixteenths) {
+  g_tall_plain_share = sixteenths < 1 ? 1 : (sixteenths > 16 ? 16 : sixteenths);
+  return GS_OK;
+}
 extern "C" int gs_panel_set_hoist_share(int sixteenths) {
   g_tall_hoist_share = sixteenths < 1 ? 1 : (sixteenths > 16 ? 16 : sixteenths);
   return GS_OK;
@@ -766,7 +771,9 @@ int gs_tall_plain(const float* A, long lda, const void* Bimg, long ldb_bytes, co
   memset(&a, 0, sizeof(a));
   a.A = A; a.lda = lda; a.B = Bimg; a.ldb_bytes = ldb_bytes; a.C = C; a.ldc = ldc; a.c_rows = c_rows; a.M = M; a.K = K;
   a.bias = bias; a.relu = relu; a.rowidx = rowidx; a.m_dev = m_dev; a.krep = g_tall_krep; a.triage = g_tall_triage; a.phases = g_tall_phases;
-  const dim3 grid(tall_grid(gs_cdiv(M, 64), 4)), block(512);
+  dim3 grid(tall_grid(gs_cdiv(M, 64), 4));
+  const dim3 block(512);
+  if (g_tall_plain_share < 16 && g_tall_grid == 0) { const int cap = tall_cus() * g_tall_plain_share / 16; if ((int)grid.x > cap) grid.x = cap > 0 ? cap : 1; }
 #define TP_LAUNCH(FORM_, RIDX_, TRI_)                                                                               \
   do {                                                                                                             \
     if (g_tall_split) hipLaunchKernelGGL((gs_tall_kernel<FORM_, RIDX_, TRI_, 1>), grid, block, 0, s, a);           \

@@ -97,6 +97,9 @@ int gs_gcond_set_edge_src(int on);
 /* the de-duplication behind every sampling: 1 (default) = a chain of chip-wide launches, 0 = one workgroup per class (round 6's first form:
  * measurement / test hook); bitwise the same structure */
 int gs_dedup_set_form(int form);
+/* compute units (in sixteenths) the persistent grid of H1 = relu(X W1 + b1) takes (16 = all: default; measurement knob — the rows are tiled
+ * the same way whatever the grid: bitwise the same H1) */
+int gs_panel_set_plain_share(int sixteenths);
 int gs_inner_persist_set_grid(int workgroups);
 int gs_inner_persist_trace(void* device_u64_G_by_128);      /* measurement: s_memrealtime stamps around every grid barrier (NULL = off) */
 

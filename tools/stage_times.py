@@ -24,7 +24,7 @@ for env, fn in (("GS_H1_BITS", "gs_gcond_set_h1_bits"), ("GS_EDGE_KERNEL", "gs_g
                 ("GS_EDGE_PLAN", "gs_gcond_set_edge_plan"), ("GS_ELL_XCD", "gs_gcond_set_ell_xcd"),
                 ("GS_HOIST_FWD", "gs_gcond_set_hoist_forward_all"), ("GS_PAD_ZERO", "gs_gcond_set_pad_zero"),
                 ("GS_HOIST_SHARE", "gs_panel_set_hoist_share"), ("GS_INNER_PERSIST", "gs_gcond_set_inner_persist"),
-                ("GS_INNER_GRID", "gs_inner_persist_set_grid"), ("GS_EDGE_SRC", "gs_gcond_set_edge_src"), ("GS_DEDUP_FORM", "gs_dedup_set_form")):   # A/B knobs of the library
+                ("GS_INNER_GRID", "gs_inner_persist_set_grid"), ("GS_EDGE_SRC", "gs_gcond_set_edge_src"), ("GS_DEDUP_FORM", "gs_dedup_set_form"), ("GS_PLAIN_SHARE", "gs_panel_set_plain_share")):   # A/B knobs of the library
     if os.environ.get(env):
         from graphslim_amd import _lib
         getattr(_lib.lib(), fn)(int(os.environ[env]))
