@@ -177,40 +177,32 @@ __global__ __launch_bounds__(256) void gs_ell_spmm_kernel(const int* __restrict_
   for (int c0 = lane * VEC; c0 < F; c0 += 64 * VEC) {
     if (VEC == 4) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      int j = 0;
-      for (; j + 4 <= f; j += 4) {
-        float w[4];
-        float4 x[4];
+      // up to eight gathers in flight before their FMAs (round 6: fan-outs of 5 … 8 took a second, dependent round of loads behind the
+      // first four); the predicates are wave-uniform, the FMA order is j = 0, 1, .. as before: identical sums
+      for (int j = 0; j < f; j += 8) {
+        float w[8];
+        float4 x[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          w[u] = __int_as_float(__builtin_amdgcn_readlane(evalb, j + u));
-          x[u] = *reinterpret_cast<const float4*>(src + (cb + __builtin_amdgcn_readlane(ecol, j + u)) * ld_src + c0);
-          if (DROP) {
-            const float4 m = gs_drop_mult4(dkey, cb + __builtin_amdgcn_readlane(ecol, j + u), c0, dthr, dq);
-            x[u].x *= m.x; x[u].y *= m.y; x[u].z *= m.z; x[u].w *= m.w;
+        for (int u = 0; u < 8; ++u) {
+          if (j + u < f) {
+            w[u] = __int_as_float(__builtin_amdgcn_readlane(evalb, j + u));
+            x[u] = *reinterpret_cast<const float4*>(src + (cb + __builtin_amdgcn_readlane(ecol, j + u)) * ld_src + c0);
+            if (DROP) {
+              const float4 m = gs_drop_mult4(dkey, cb + __builtin_amdgcn_readlane(ecol, j + u), c0, dthr, dq);
+              x[u].x *= m.x; x[u].y *= m.y; x[u].z *= m.z; x[u].w *= m.w;
+            }
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          acc.x = fmaf(w[u], x[u].x, acc.x);
-          acc.y = fmaf(w[u], x[u].y, acc.y);
-          acc.z = fmaf(w[u], x[u].z, acc.z);
-          acc.w = fmaf(w[u], x[u].w, acc.w);
-          if (ebits) gs_ell_put_bits(ebits + (ebase + j + u) * 8, x[u], lane);
+        for (int u = 0; u < 8; ++u) {
+          if (j + u < f) {
+            acc.x = fmaf(w[u], x[u].x, acc.x);
+            acc.y = fmaf(w[u], x[u].y, acc.y);
+            acc.z = fmaf(w[u], x[u].z, acc.z);
+            acc.w = fmaf(w[u], x[u].w, acc.w);
+            if (ebits) gs_ell_put_bits(ebits + (ebase + j + u) * 8, x[u], lane);
+          }
         }
-      }
-      for (; j < f; ++j) {
-        const float w = __int_as_float(__builtin_amdgcn_readlane(evalb, j));
-        float4 x = *reinterpret_cast<const float4*>(src + (cb + __builtin_amdgcn_readlane(ecol, j)) * ld_src + c0);
-        if (DROP) {
-          const float4 m = gs_drop_mult4(dkey, cb + __builtin_amdgcn_readlane(ecol, j), c0, dthr, dq);
-          x.x *= m.x; x.y *= m.y; x.z *= m.z; x.w *= m.w;
-        }
-        acc.x = fmaf(w, x.x, acc.x);
-        acc.y = fmaf(w, x.y, acc.y);
-        acc.z = fmaf(w, x.z, acc.z);
-        acc.w = fmaf(w, x.w, acc.w);
-        if (ebits) gs_ell_put_bits(ebits + (ebase + j) * 8, x, lane);
       }
       *reinterpret_cast<float4*>(o + c0) = acc;
     } else {
