@@ -1485,8 +1485,8 @@ extern "C" int gs_gcond_stage_real_grads(gs_gcond* e, gs_stream_t stream) {
       else if (have_ebits) { gwd.bgen_bits = e->edge_bits + c0 * cap1 * f2 * 8; gwd.bgen_ldbits = h / 32; gwd.bgen_bits_edge = 1; }
       gwd.prec = e->operand_mode;      // honoured by the dedicated edge kernel (gs_edge.hip); the tiled fallback is fp32
     }
-    // Distinct-source form (knob EDGE_SRC, default on): the K dimension runs over ENTRIES = (distinct source, up to two of its in-edges)
-    // built behind every sampling (gs_dedup_last_kernel): x and the mask row of a source are fetched once per entry and its in-edges
+    // Distinct-source form (knob EDGE_SRC, default OFF: measured net-neutral): the K dimension runs over ENTRIES = (distinct source, up to two of its in-edges)
+    // built behind every sampling (gs_dedup_last: a chain of chip-wide launches): x and the mask row of a source are fetched once per entry and its in-edges
     // are summed in the operand path — the same sum in another association, K ~ 0.7 of the edge slots at ogbn-arxiv (8 700 live slots,
     // 5 400 distinct sources, ~6 100 entries per class).  (The first form materialised the per-source sums: the edge kernel 168 -> 126 us
     // but +140 us for that gather: profiles/r06/edge_src_materialised_not_kept.txt.)
